@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (TEST INFRASTRUCTURE).
+
+Run in the build container only (the reference is at /root/reference and cannot travel to the GPU box):
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+The reference imports gymnasium/pygame, which are not installed; oracle/gym_shim provides the small slice of
+their public API the hot path touches.  Everything recorded here comes out of reference code:
+`gym.make(id)`, `env.reset(seed=...)`, `env.step(a)`, `FullyObsWrapper.observation`, `Grid.encode`.
+
+Vector semantics recorded: Gymnasium >= 1.0 NEXT_STEP autoreset — the step after a done ignores its action,
+calls `env.reset()` (no new seed: the env's own PCG64 stream continues), and reports reward 0 / False / False.
+
+Files:
+  rollout_<id>.npz   S seeds x T steps: actions, obs (partial 7x7x3), full (FullyObsWrapper), dir, mission id,
+                     reward f64, terminated, truncated, agent records, for uniform-random and solver-driven
+                     action streams.
+  gen_<id>.npz       initial states of 3 consecutive episodes (reset(seed), reset(), reset()) for seeds 0..NGEN-1.
+  rng_kat.npz        numpy SeedSequence / PCG64 / bounded-integer / shuffle / choice streams.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from collections import deque
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "gym_shim"))
+sys.path.insert(0, "/root/reference")
+
+import gymnasium as gym  # noqa: E402  (the shim)
+import numpy as np  # noqa: E402
+
+import minigrid  # noqa: E402,F401  (registers the env ids)
+from minigrid.core.constants import COLOR_TO_IDX, OBJECT_TO_IDX  # noqa: E402
+from minigrid.wrappers import FullyObsWrapper  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+MISSIONS = {
+    "MiniGrid-Empty": ["get to the green goal square"],
+    "MiniGrid-DoorKey": ["use the key to open the door and then get to the goal"],
+    "MiniGrid-LavaCrossing": ["avoid the lava and get to the green goal square"],
+    "MiniGrid-SimpleCrossing": ["find the opening and get to the green goal square"],
+    "BabyAI-GoToRedBall": ["go to the red ball", "go to a red ball"],
+}
+
+
+def mission_id(env_id, s):
+    for k, v in MISSIONS.items():
+        if env_id.startswith(k):
+            return v.index(s)
+    raise KeyError(env_id)
+
+
+def agent_record(env, pending):
+    u = env.unwrapped
+    c = u.carrying
+    return [int(u.agent_pos[0]), int(u.agent_pos[1]), int(u.agent_dir),
+            0 if c is None else OBJECT_TO_IDX[c.type], 0 if c is None else COLOR_TO_IDX[c.color],
+            int(u.step_count), int(pending), 0]
+
+
+# ---- a tiny planner so that goldens contain solved episodes (key pickup, door unlock, goal/ball success) ----
+def _passable(u, x, y, avoid_lava=True):
+    c = u.grid.get(x, y)
+    if c is None:
+        return True
+    if c.type == "lava":
+        return not avoid_lava
+    return c.can_overlap()
+
+
+def plan_to_face(u, target, stand_on=False):
+    """BFS over (x, y, dir) to a state facing `target` (or standing on it).  Returns a list of actions."""
+    DIRS = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+    start = (int(u.agent_pos[0]), int(u.agent_pos[1]), int(u.agent_dir))
+    prev = {start: None}
+    q = deque([start])
+    while q:
+        s = q.popleft()
+        x, y, d = s
+        if stand_on:
+            if (x, y) == tuple(target):
+                break
+        elif (x + DIRS[d][0], y + DIRS[d][1]) == tuple(target):
+            break
+        for a, ns in ((0, (x, y, (d + 3) % 4)), (1, (x, y, (d + 1) % 4)), (2, (x + DIRS[d][0], y + DIRS[d][1], d))):
+            if a == 2 and not (0 <= ns[0] < u.width and 0 <= ns[1] < u.height and _passable(u, ns[0], ns[1])):
+                continue
+            if ns not in prev:
+                prev[ns] = (s, a)
+                q.append(ns)
+    else:
+        return None
+    acts = []
+    while prev[s] is not None:
+        s, a = prev[s]
+        acts.append(a)
+    return acts[::-1]
+
+
+def find(u, type_, color=None):
+    for i in range(u.width):
+        for j in range(u.height):
+            c = u.grid.get(i, j)
+            if c is not None and c.type == type_ and (color is None or c.color == color):
+                return (i, j)
+    return None
+
+
+def solver_action(env_id, u):
+    """Next scripted action for the current state, or None."""
+    if env_id.startswith("MiniGrid-DoorKey"):
+        door = find(u, "door")
+        d = u.grid.get(*door)
+        if d.is_locked and u.carrying is None:
+            p = plan_to_face(u, find(u, "key"))
+            return 3 if p == [] else (p[0] if p else None)
+        if not d.is_open:
+            p = plan_to_face(u, door)
+            return 5 if p == [] else (p[0] if p else None)
+    if env_id.startswith("BabyAI-GoToRedBall"):
+        p = plan_to_face(u, find(u, "ball", "red"))
+        return p[0] if p else None
+    goal = find(u, "goal")
+    if goal is None:
+        return None
+    p = plan_to_face(u, goal, stand_on=True)
+    return p[0] if p else None
+
+
+def rollout(env_id, seed, T, mode, noise=0.25):
+    env = gym.make(env_id)
+    fo = FullyObsWrapper(env)
+    arng = np.random.default_rng(10_000 + seed)
+    obs, _ = env.reset(seed=seed)
+    rec = dict(actions=[], obs=[obs["image"]], full=[fo.observation(obs)["image"]], dir=[obs["direction"]],
+               mission=[mission_id(env_id, obs["mission"])], reward=[], term=[], trunc=[], agent=[agent_record(env, 0)])
+    pending = False
+    for _ in range(T):
+        a = int(arng.integers(0, 7))
+        if mode == "solver" and arng.random() >= noise and not pending:
+            sa = solver_action(env_id, env.unwrapped)
+            if sa is not None:
+                a = sa
+        if pending:
+            obs, _ = env.reset()
+            r, term, trunc = 0.0, False, False
+            pending = False
+        else:
+            obs, r, term, trunc, _ = env.step(a)
+            pending = bool(term or trunc)
+        assert obs["direction"] == env.unwrapped.agent_dir
+        rec["actions"].append(a)
+        rec["obs"].append(obs["image"])
+        rec["full"].append(fo.observation(obs)["image"])
+        rec["dir"].append(obs["direction"])
+        rec["mission"].append(mission_id(env_id, obs["mission"]))
+        rec["reward"].append(float(r))
+        rec["term"].append(term)
+        rec["trunc"].append(trunc)
+        rec["agent"].append(agent_record(env, pending))
+    return rec
+
+
+def make_rollouts(env_id, seeds, T):
+    out = {}
+    for mode in ("random", "solver"):
+        recs = [rollout(env_id, s, T, mode) for s in seeds]
+        out[f"{mode}_actions"] = np.array([r["actions"] for r in recs], np.uint8)
+        out[f"{mode}_obs"] = np.array([r["obs"] for r in recs], np.uint8)
+        out[f"{mode}_full"] = np.array([r["full"] for r in recs], np.uint8)
+        out[f"{mode}_dir"] = np.array([r["dir"] for r in recs], np.uint8)
+        out[f"{mode}_mission"] = np.array([r["mission"] for r in recs], np.uint8)
+        out[f"{mode}_reward"] = np.array([r["reward"] for r in recs], np.float64)
+        out[f"{mode}_term"] = np.array([r["term"] for r in recs], bool)
+        out[f"{mode}_trunc"] = np.array([r["trunc"] for r in recs], bool)
+        out[f"{mode}_agent"] = np.array([r["agent"] for r in recs], np.int32)
+    out["seeds"] = np.array(seeds, np.uint64)
+    env = gym.make(env_id)
+    env.reset(seed=0)
+    out["max_steps"] = np.int64(env.unwrapped.max_steps)
+    return out
+
+
+def make_gen(env_id, nseeds, episodes=3):
+    env = gym.make(env_id)
+    grids, agents, missions = [], [], []
+    for s in range(nseeds):
+        g, a, m = [], [], []
+        for ep in range(episodes):
+            obs, _ = env.reset(seed=s) if ep == 0 else env.reset()
+            g.append(env.unwrapped.grid.encode())
+            a.append(agent_record(env, 0))
+            m.append(mission_id(env_id, obs["mission"]))
+        grids.append(g)
+        agents.append(a)
+        missions.append(m)
+    return dict(grid=np.array(grids, np.uint8), agent=np.array(agents, np.int32), mission=np.array(missions, np.uint8))
+
+
+def make_rng_kat():
+    seeds = [0, 1, 2, 3, 7, 123, 1337, 65535, 2**31, 2**32 - 1, 2**32, 2**32 + 5, 2**40 + 3, 2**63 + 11, 2**64 - 1]
+    ss, n32, bounded, shuf, choice = [], [], {}, [], []
+    bounds = [2, 3, 4, 5, 6, 7, 8, 9, 14, 1000, 2**31 + 7]
+    for s in seeds:
+        ss.append(np.random.SeedSequence(s).generate_state(4, np.uint64))
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+        n32.append(g.integers(0, 2**32, size=33, dtype=np.uint32))   # 33: leaves a cached half behind
+        for b in bounds:
+            g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+            bounded.setdefault(b, []).append([int(g.integers(0, b)) for _ in range(24)])
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+        rows = []
+        for n in (2, 3, 6, 9):
+            lst = list(range(n))
+            g.shuffle(lst)
+            rows += lst
+        shuf.append(rows)
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
+        choice.append([int(g.choice(range(3, 3 + n))) for n in (7, 7, 3, 5, 1, 9)])
+    out = dict(seeds=np.array(seeds, np.uint64), seedseq=np.array(ss, np.uint64), next32=np.array(n32, np.uint32),
+               shuffle=np.array(shuf, np.int32), choice=np.array(choice, np.int64), bounds=np.array(bounds, np.int64))
+    for b in bounds:
+        out[f"bounded_{b}"] = np.array(bounded[b], np.int64)
+    return out
+
+
+MAIN_IDS = ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "BabyAI-GoToRedBall-v0"]
+EXTRA_IDS = ["MiniGrid-Empty-5x5-v0", "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-Empty-16x16-v0",
+             "MiniGrid-DoorKey-5x5-v0", "MiniGrid-DoorKey-6x6-v0", "MiniGrid-DoorKey-16x16-v0",
+             "MiniGrid-LavaCrossingS9N2-v0", "MiniGrid-LavaCrossingS9N3-v0", "MiniGrid-LavaCrossingS11N5-v0",
+             "MiniGrid-SimpleCrossingS9N1-v0", "MiniGrid-SimpleCrossingS11N5-v0", "BabyAI-GoToRedBallNoDists-v0"]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
+    main_seeds = list(range(12)) + [100, 243, 500, 1337]
+    for env_id in MAIN_IDS:
+        T = 700 if "DoorKey" in env_id else 400     # DoorKey-8x8 max_steps = 640: cover a truncation
+        np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, main_seeds, T))
+        np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 256))
+        print("done", env_id, flush=True)
+    for env_id in EXTRA_IDS:
+        np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 1337], 160))
+        np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
+        print("done", env_id, flush=True)
+
+
+if __name__ == "__main__":
+    main()

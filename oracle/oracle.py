@@ -1,0 +1,190 @@
+"""ctypes front-end of the CPU oracle (oracle/minigrid_oracle.c) — TEST INFRASTRUCTURE ONLY.
+
+Never imported by the product package `minigrid_amd`.  Used by tests/ as the parity checker, by
+`__graft_entry__.smoke()` as the checker, and by `bench.py`'s `cpu_baseline` leg as the timed CPU port.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# env kinds / object codes (mirror of the enums in minigrid_oracle.c)
+K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL = 0, 1, 2, 3
+T_WALL, T_LAVA = 2, 9
+
+
+class OracleCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
+        "num_crossings", "obstacle_type", "num_dists", "full_obs")]
+
+
+# Static config rows restated from the reference registry (minigrid/__init__.py:24-28,105-109,182-185,577-580
+# and sibling rows) + constructor defaults (empty.py:68-91, doorkey.py:62-68, crossing.py:89-117,
+# goto.py:129-131, roomgrid_level.py:77-83).
+def spec(env_id: str) -> dict:
+    def empty(size, random_start=False):
+        return dict(kind=K_EMPTY, width=size, height=size, max_steps=4 * size * size, see_through=1,
+                    start_x=-1 if random_start else 1, start_y=-1 if random_start else 1, start_dir=0,
+                    missions=["get to the green goal square"])
+
+    def doorkey(size):
+        return dict(kind=K_DOORKEY, width=size, height=size, max_steps=10 * size * size, see_through=0,
+                    missions=["use the key to open the door and then get to the goal"])
+
+    def crossing(size, n, lava=True):
+        return dict(kind=K_CROSSING, width=size, height=size, max_steps=4 * size * size, see_through=0,
+                    num_crossings=n, obstacle_type=T_LAVA if lava else T_WALL,
+                    missions=["avoid the lava and get to the green goal square" if lava
+                              else "find the opening and get to the green goal square"])
+
+    table = {
+        "MiniGrid-Empty-5x5-v0": empty(5), "MiniGrid-Empty-Random-5x5-v0": empty(5, True),
+        "MiniGrid-Empty-6x6-v0": empty(6), "MiniGrid-Empty-Random-6x6-v0": empty(6, True),
+        "MiniGrid-Empty-8x8-v0": empty(8), "MiniGrid-Empty-16x16-v0": empty(16),
+        "MiniGrid-DoorKey-5x5-v0": doorkey(5), "MiniGrid-DoorKey-6x6-v0": doorkey(6),
+        "MiniGrid-DoorKey-8x8-v0": doorkey(8), "MiniGrid-DoorKey-16x16-v0": doorkey(16),
+        "MiniGrid-LavaCrossingS9N1-v0": crossing(9, 1), "MiniGrid-LavaCrossingS9N2-v0": crossing(9, 2),
+        "MiniGrid-LavaCrossingS9N3-v0": crossing(9, 3), "MiniGrid-LavaCrossingS11N5-v0": crossing(11, 5),
+        "MiniGrid-SimpleCrossingS9N1-v0": crossing(9, 1, False), "MiniGrid-SimpleCrossingS9N2-v0": crossing(9, 2, False),
+        "MiniGrid-SimpleCrossingS9N3-v0": crossing(9, 3, False), "MiniGrid-SimpleCrossingS11N5-v0": crossing(11, 5, False),
+        "BabyAI-GoToRedBall-v0": dict(kind=K_GOTO_REDBALL, width=8, height=8, max_steps=64, see_through=0, num_dists=7,
+                                      missions=["go to the red ball", "go to a red ball"]),
+        "BabyAI-GoToRedBallNoDists-v0": dict(kind=K_GOTO_REDBALL, width=8, height=8, max_steps=64, see_through=0,
+                                             num_dists=0, missions=["go to the red ball", "go to a red ball"]),
+    }
+    return table[env_id]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/minigrid_oracle.c -> oracle/liboracle.so (gcc; seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "minigrid_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(OracleCfg), C.c_int]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_obs_bytes.argtypes = [C.c_void_p]
+        vp = C.c_void_p
+        L.oracle_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.oracle_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        for f in (L.oracle_get_state, L.oracle_set_state):
+            f.argtypes = [vp, vp, vp]
+        for f in (L.oracle_get_rng, L.oracle_set_rng):
+            f.argtypes = [vp, vp]
+        L.oracle_rng_kat.argtypes = [C.c_uint64, vp, vp, C.c_int, vp, C.c_int, C.c_int64]
+        L.oracle_shuffle_kat.argtypes = [C.c_uint64, vp, C.c_int]
+        L.oracle_reward_lut.argtypes = [C.c_int, vp]
+        L.oracle_rollout.restype = C.c_uint64
+        L.oracle_rollout.argtypes = [vp, C.c_int, C.c_uint64, vp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleVec:
+    """N independent reference-semantics envs stepped in lockstep on the CPU (scalar C)."""
+
+    def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, **overrides):
+        s = dict(spec(env_id))
+        s.update(overrides)
+        self.missions = s.pop("missions")
+        self.cfg = OracleCfg(full_obs=int(full_obs), **{k: int(v) for k, v in s.items()})
+        self.n = num_envs
+        self.W, self.H = self.cfg.width, self.cfg.height
+        self.full_obs = full_obs
+        self.h = lib().oracle_create(C.byref(self.cfg), num_envs)
+        if not self.h:
+            raise RuntimeError("oracle_create failed")
+        self.obs_shape = (self.W, self.H, 3) if full_obs else (7, 7, 3)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oracle_destroy(self.h)
+            self.h = None
+
+    def _outs(self):
+        n = self.n
+        return (np.zeros((n,) + self.obs_shape, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+
+    def reset(self, seeds=None, mask=None):
+        obs, d, m = self._outs()
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().oracle_reset(self.h, _p(sd), _p(mk), _p(obs), _p(d), _p(m))
+        return obs, d, m
+
+    def step(self, actions, autoreset: int = 1):
+        obs, d, m = self._outs()
+        a = np.ascontiguousarray(actions, dtype=np.uint8)
+        rew = np.zeros(self.n, np.float64)
+        term = np.zeros(self.n, np.uint8)
+        trunc = np.zeros(self.n, np.uint8)
+        rc = lib().oracle_step(self.h, _p(a), autoreset, _p(obs), _p(rew), _p(term), _p(trunc), _p(d), _p(m))
+        if rc == -1:
+            raise ValueError("Unknown action")
+        if rc:
+            raise AssertionError("front cell out of bounds")
+        return obs, rew, term.astype(bool), trunc.astype(bool), d, m
+
+    def get_state(self):
+        grid = np.zeros((self.n, self.W, self.H, 3), np.uint8)
+        agent = np.zeros((self.n, 8), np.int32)
+        lib().oracle_get_state(self.h, _p(grid), _p(agent))
+        return grid, agent
+
+    def set_state(self, grid, agent):
+        grid = np.ascontiguousarray(grid, np.uint8)
+        agent = np.ascontiguousarray(agent, np.int32)
+        assert grid.shape == (self.n, self.W, self.H, 3) and agent.shape == (self.n, 8)
+        lib().oracle_set_state(self.h, _p(grid), _p(agent))
+
+    def get_rng(self):
+        r = np.zeros((self.n, 5), np.uint64)
+        lib().oracle_get_rng(self.h, _p(r))
+        return r
+
+    def set_rng(self, r):
+        r = np.ascontiguousarray(r, np.uint64)
+        lib().oracle_set_rng(self.h, _p(r))
+
+    def rollout(self, T: int, action_seed: int = 0) -> int:
+        scratch = np.zeros(int(np.prod(self.obs_shape)), np.uint8)
+        return int(lib().oracle_rollout(self.h, T, action_seed, _p(scratch)))
+
+
+def rng_kat(seed: int, n32: int = 16, nb: int = 16, bound_hi: int = 7):
+    ss = np.zeros(4, np.uint64)
+    n32o = np.zeros(n32, np.uint32)
+    bo = np.zeros(nb, np.int64)
+    lib().oracle_rng_kat(seed, _p(ss), _p(n32o), n32, _p(bo), nb, bound_hi)
+    return ss, n32o, bo
+
+
+def shuffle_kat(seed: int, n: int):
+    a = np.arange(n, dtype=np.int32)
+    lib().oracle_shuffle_kat(seed, _p(a), n)
+    return a
+
+
+def reward_lut(max_steps: int):
+    out = np.zeros(max_steps + 1, np.float64)
+    lib().oracle_reward_lut(max_steps, _p(out))
+    return out
