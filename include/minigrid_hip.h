@@ -1,0 +1,167 @@
+/*
+ * minigrid_hip.h — C ABI of libminigrid_hip.so, the MI355X-native lockstep-batched MiniGrid hot path.
+ *
+ * The reference (Farama-Foundation/Minigrid, pure Python) has no FFI of its own: its extension boundary is the
+ * Gymnasium Env protocol.  This header is the boundary a binding for that protocol calls into; each entry point
+ * cites the reference interface it replaces (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add; minigrid_amd/_binding.py is that stub in this repo.
+ *
+ * Conventions
+ *   - plain C types only; every function returns MG_OK (0) or a negative mg_status; mg_last_error() has the text.
+ *   - one mg_env = one device + one HIP stream + N lockstep environments.  Calls on one handle are not
+ *     re-entrant; different handles may be driven from different host threads.
+ *   - the library owns all device buffers.  Output device pointers (mg_get_outputs) are borrowed, stay valid for
+ *     the life of the handle, and their CONTENT is overwritten by the next mg_step / mg_reset / mg_rollout.
+ *   - mg_step / mg_reset / mg_rollout are asynchronous with respect to the host; mg_copy_outputs and mg_sync
+ *     synchronise with the handle's stream.
+ *   - all "image" tensors use the reference's index order image[x][y][channel] (core/grid.py:252-266).
+ */
+#ifndef MINIGRID_HIP_H
+#define MINIGRID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MG_API __attribute__((visibility("default")))
+#else
+#define MG_API
+#endif
+
+typedef enum mg_status {
+  MG_OK = 0,
+  MG_ERR_INVALID = -1,     /* bad argument / unsupported configuration (reference: assert / TypeError)      */
+  MG_ERR_HIP = -2,         /* a HIP runtime call failed                                                       */
+  MG_ERR_BAD_ACTION = -3,  /* an action outside 0..6 was seen (reference: ValueError, minigrid_env.py:584-585) */
+  MG_ERR_GENERATOR = -4,   /* map generation exhausted its retry bound (reference: RecursionError,
+                              minigrid_env.py:342-343; roomgrid_level.py:131-134 retries instead)            */
+  MG_ERR_NO_DEVICE = -5,   /* no usable HIP device                                                            */
+  MG_ERR_OOB = -6          /* front cell outside the grid (reference: AssertionError, core/grid.py:74-78)     */
+} mg_status;
+
+/* Map generators = the reference's `_gen_grid` implementations on the path. */
+typedef enum mg_env_kind {
+  MG_ENV_EMPTY = 0,         /* envs/empty.py:97-114                                           */
+  MG_ENV_DOORKEY = 1,       /* envs/doorkey.py:74-99                                          */
+  MG_ENV_CROSSING = 2,      /* envs/crossing.py:131-188 (LavaCrossing / SimpleCrossing)       */
+  MG_ENV_GOTO_REDBALL = 3   /* envs/babyai/goto.py:133-141 + core/roomgrid.py + roomgrid_level.py:119-144 */
+} mg_env_kind;
+
+typedef enum mg_obs_mode {
+  MG_OBS_PARTIAL = 0,  /* MiniGridEnv.gen_obs (minigrid_env.py:634-650): (N,7,7,3) u8; also ImgObsWrapper (wrappers.py:187-214) */
+  MG_OBS_FULL = 1      /* FullyObsWrapper.observation (wrappers.py:419-426): (N,W,H,3) u8                                       */
+} mg_obs_mode;
+
+typedef enum mg_autoreset_mode {
+  MG_AUTORESET_NEXT_STEP = 0, /* Gymnasium >= 1.0 default: the step after a done resets, ignores its action, reward 0 */
+  MG_AUTORESET_DISABLED = 1   /* never reset implicitly; the caller uses mg_reset with a mask                         */
+} mg_autoreset_mode;
+
+typedef enum mg_rng_mode {
+  MG_RNG_PCG64 = 0,   /* bit-exact numpy Generator(PCG64(SeedSequence(seed))) stream: reset(seed=s) reproduces the
+                         reference's layouts for the same seed, across autoresets (minigrid_env.py:125,247-311)  */
+  MG_RNG_PHILOX = 1   /* Philox4x32-10 keyed by (seed, episode): same generator algorithm and distribution,
+                         different layouts; no carried 128-bit state                                            */
+} mg_rng_mode;
+
+typedef enum mg_action_dtype { MG_ACT_U8 = 0, MG_ACT_I32 = 1, MG_ACT_I64 = 2 } mg_action_dtype;
+
+/* Static per-env-id configuration = one row of the reference registry (minigrid/__init__.py) plus the
+ * constructor defaults of that env class.  minigrid_amd/registry.py holds the rows. */
+typedef struct mg_config {
+  int32_t abi_version;        /* MG_ABI_VERSION */
+  int32_t env_kind;           /* mg_env_kind */
+  int32_t width, height;      /* grid size in cells (minigrid_env.py:99-100) */
+  int32_t max_steps;          /* minigrid_env.py:105; BabyAI: roomgrid_level.py:77-83 */
+  int32_t see_through_walls;  /* minigrid_env.py:107 */
+  int32_t agent_view_size;    /* must be 7 (minigrid_env.py:66-68 default) */
+  int32_t obs_mode;           /* mg_obs_mode */
+  int32_t autoreset_mode;     /* mg_autoreset_mode */
+  int32_t rng_mode;           /* mg_rng_mode */
+  int32_t num_envs;           /* N lockstep envs on this device */
+  int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty: fixed start (empty.py:71-72); x < 0 => place_agent() */
+  int32_t num_crossings;      /* Crossing (crossing.py:92) */
+  int32_t obstacle_type;      /* Crossing: 9 = lava, 2 = wall (crossing.py:93) */
+  int32_t num_dists;          /* GoToRedBall (goto.py:129) */
+  int32_t reserved[7];
+  int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
+} mg_config;
+
+/* Borrowed device pointers to the outputs of the last step/reset. */
+typedef struct mg_outputs {
+  uint8_t* obs;         /* (N, 7,7,3) or (N, W,H,3) u8, C-contiguous                                  */
+  double* reward;       /* (N) f64: 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245) */
+  uint8_t* terminated;  /* (N) u8 0/1                                                                 */
+  uint8_t* truncated;   /* (N) u8 0/1 (minigrid_env.py:587-588)                                       */
+  uint8_t* direction;   /* (N) u8 agent_dir 0..3 (obs["direction"], minigrid_env.py:648)              */
+  uint8_t* mission_id;  /* (N) u8 index into the config's mission-string table (obs["mission"])       */
+  int64_t obs_bytes_per_env;
+  int64_t num_envs;
+} mg_outputs;
+
+typedef struct mg_env mg_env;
+
+/* gym.make(id) -> Env.__init__ (minigrid_env.py:34-117).  device < 0 => current device.
+ * stream: a hipStream_t to run on (borrowed), or NULL to let the library create its own non-blocking stream. */
+MG_API int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out);
+MG_API int mg_destroy(mg_env* env);                                   /* Env.close() */
+
+/* Env.reset(seed=...) for the selected envs (minigrid_env.py:119-157).
+ *   seeds: host array [N] of per-env seeds (env i is seeded exactly like `reset(seed=seeds[i])`), or NULL to
+ *          continue each env's own stream like `reset()`;  mask: host array [N] u8 (non-zero = reset), or NULL = all.
+ * Produces the reset observation for every env in the output buffers (reward 0, flags 0). */
+MG_API int mg_reset(mg_env* env, const uint64_t* seeds, const uint8_t* mask);
+
+/* Env.step(action) for all N envs in lockstep (minigrid_env.py:525-595; BabyAI roomgrid_level.py:87-104).
+ * actions: N values of `dtype`, on the host (on_device = 0; copied asynchronously) or already on this device. */
+MG_API int mg_step(mg_env* env, const void* actions, int dtype, int on_device);
+
+/* T steps under a uniform-random policy generated on the device (Philox4x32-10 keyed by action_seed, global env
+ * index and step number) — the benchmark loop of minigrid/benchmark.py:39-40 with random actions.
+ * Every step writes its full outputs exactly as mg_step does.  fused != 0 uses the single-launch variant. */
+MG_API int mg_rollout(mg_env* env, int T, uint64_t action_seed, int fused);
+
+MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
+/* Synchronises the stream, then copies whichever destinations are non-NULL to host memory.
+ * Also surfaces device-side error flags (MG_ERR_BAD_ACTION / MG_ERR_GENERATOR / MG_ERR_OOB). */
+MG_API int mg_copy_outputs(mg_env* env, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
+                    uint8_t* direction, uint8_t* mission_id);
+MG_API int mg_sync(mg_env* env);        /* hipStreamSynchronize + error-flag check */
+
+/* State exchange (checkpoint/resume and parity-harness state injection).
+ *   grid : (N, W, H, 3) u8 in Grid.encode() layout (core/grid.py:244-268), decoded like Grid.decode (270-289)
+ *   agent: (N, 8) i32 = {x, y, dir, carry_type, carry_color, step_count, reset_pending, mission_id}      */
+MG_API int mg_get_state(mg_env* env, uint8_t* grid, int32_t* agent);
+MG_API int mg_set_state(mg_env* env, const uint8_t* grid, const int32_t* agent);
+/* Per-env generator state (N, 5) u64 = {state_hi, state_lo, inc_hi, inc_lo, (has_uint32 << 32) | uinteger}:
+ * numpy's PCG64 state as the reference env would hold it at this point of the episode sequence. */
+MG_API int mg_get_rng(mg_env* env, uint64_t* out);
+MG_API int mg_set_rng(mg_env* env, const uint64_t* in);
+
+/* HIP-event timing on the handle's stream (bench.py uses these for the roofline line). */
+MG_API int mg_timer_start(mg_env* env);
+MG_API int mg_timer_stop(mg_env* env, float* elapsed_ms);   /* synchronises on the stop event */
+
+/* counters since create: [0] env-steps executed, [1] episodes finished, [2] maps generated, [3] generator retries */
+MG_API int mg_get_counters(mg_env* env, uint64_t out[4]);
+
+MG_API const char* mg_last_error(mg_env* env);   /* env may be NULL for creation errors */
+MG_API int mg_abi_version(void);
+MG_API int mg_device_count(void);
+
+/* Host-side self-test hooks (no GPU needed): run the library's own inline helpers on the CPU so that the
+ * bit-parallel formulations can be checked exhaustively in the CPU test-suite. */
+MG_API int mg_selftest_vis_row(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
+MG_API int mg_selftest_reward_lut(int32_t max_steps, double* out /* [max_steps+1] */);
+MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINIGRID_HIP_H */

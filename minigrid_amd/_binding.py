@@ -1,0 +1,103 @@
+"""ctypes binding of libminigrid_hip.so (include/minigrid_hip.h) — the thin layer the reference's Gymnasium
+surface sits on.  There is NO CPU fallback: if the library cannot be built/loaded this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+MG_ABI_VERSION = 1
+MG_OK, MG_ERR_INVALID, MG_ERR_HIP, MG_ERR_BAD_ACTION, MG_ERR_GENERATOR, MG_ERR_NO_DEVICE, MG_ERR_OOB = 0, -1, -2, -3, -4, -5, -6
+OBS_PARTIAL, OBS_FULL = 0, 1
+AUTORESET_NEXT_STEP, AUTORESET_DISABLED = 0, 1
+RNG_PCG64, RNG_PHILOX = 0, 1
+ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
+
+
+class MgConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "env_kind", "width", "height", "max_steps", "see_through_walls", "agent_view_size",
+        "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
+        "num_crossings", "obstacle_type", "num_dists")] + [("reserved", C.c_int32 * 7), ("env_index_base", C.c_int64)]
+
+
+class MgOutputs(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
+                ("direction", C.c_void_p), ("mission_id", C.c_void_p), ("obs_bytes_per_env", C.c_int64),
+                ("num_envs", C.c_int64)]
+
+
+class MiniGridHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/minigrid_hip.h declares (tests/test_abi.py checks the built library exports all of them)
+SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_get_outputs", "mg_copy_outputs",
+           "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
+           "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
+           "mg_selftest_reward_lut", "mg_selftest_pack_cell"]
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building first if stale/missing) libminigrid_hip.so.  Imports torch first when it is available so
+    that both use the same HIP runtime (see build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if os.environ.get("MINIGRID_AMD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401  (side effect: its libamdhip64.so becomes the process's HIP runtime)
+        except Exception:
+            pass
+    path = _build.LIB
+    if not os.path.exists(path) or os.environ.get("MINIGRID_AMD_REBUILD", "0") == "1":
+        path = _build.build()
+    L = C.CDLL(path)
+    vp, i, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.mg_create.argtypes = [C.POINTER(MgConfig), i, vp, C.POINTER(vp)]
+    L.mg_destroy.argtypes = [vp]
+    L.mg_reset.argtypes = [vp, vp, vp]
+    L.mg_step.argtypes = [vp, vp, i, i]
+    L.mg_rollout.argtypes = [vp, i, u64, i]
+    L.mg_get_outputs.argtypes = [vp, C.POINTER(MgOutputs)]
+    L.mg_copy_outputs.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.mg_sync.argtypes = [vp]
+    L.mg_get_state.argtypes = [vp, vp, vp]
+    L.mg_set_state.argtypes = [vp, vp, vp]
+    L.mg_get_rng.argtypes = [vp, vp]
+    L.mg_set_rng.argtypes = [vp, vp]
+    L.mg_timer_start.argtypes = [vp]
+    L.mg_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mg_get_counters.argtypes = [vp, vp]
+    L.mg_last_error.argtypes = [vp]
+    L.mg_last_error.restype = C.c_char_p
+    L.mg_selftest_vis_row.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mg_selftest_reward_lut.argtypes = [C.c_int32, vp]
+    L.mg_selftest_pack_cell.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if L.mg_abi_version() != MG_ABI_VERSION:
+        raise MiniGridHipError(f"libminigrid_hip ABI {L.mg_abi_version()} != binding {MG_ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(rc: int, handle=None):
+    """Map mg_status to the exception the reference would raise at the same point."""
+    if rc == MG_OK:
+        return
+    msg = (load().mg_last_error(handle) or b"").decode(errors="replace")
+    if rc == MG_ERR_BAD_ACTION:
+        raise ValueError(msg or "Unknown action")                 # minigrid_env.py:584-585
+    if rc == MG_ERR_GENERATOR:
+        raise RecursionError(msg or "rejection sampling failed")  # minigrid_env.py:342-343
+    if rc == MG_ERR_OOB:
+        raise AssertionError(msg)                                 # core/grid.py:74-78
+    if rc == MG_ERR_INVALID:
+        raise ValueError(msg or "invalid argument")
+    raise MiniGridHipError(f"libminigrid_hip error {rc}: {msg}")

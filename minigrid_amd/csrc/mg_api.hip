@@ -1,0 +1,482 @@
+// mg_api.hip — C ABI of libminigrid_hip.so (see include/minigrid_hip.h).  Host side: buffers, launches, state
+// exchange.  No CPU fallback exists: every entry point that computes needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/minigrid_hip.h"
+#include "mg_kernels.h"
+
+using namespace mg;
+
+static thread_local std::string g_create_error;
+
+struct mg_env {
+  mg_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // geometry
+  int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
+  int lds_per_wave = 0, t_offset = 0, TS = 0, wpb = 4;
+  bool tpad = false, static_gen = false;
+  int rule = RULE_NONE, rule_cell = 0;
+  // device buffers
+  uint8_t *grid = nullptr, *spare_grid = nullptr;
+  uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *seeds = nullptr;
+  uint8_t *mask = nullptr, *actions = nullptr;
+  uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
+  double *reward = nullptr, *reward_lut = nullptr;
+  uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
+  unsigned long long* counters = nullptr;
+  // bookkeeping
+  uint32_t launches = 0;      // parity of the refill-queue counter
+  uint32_t t = 0;             // rollout step counter (Philox action counter)
+  std::string last_error;
+};
+
+static int fail(mg_env* env, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (env) env->last_error = buf; else g_create_error = buf;
+  return code;
+}
+#define HIP_TRY(env, call)                                                                         \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess) return fail(env, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+// _reward LUT on the host: three separately rounded IEEE f64 operations (no contraction: built with
+// -ffp-contract=off and volatile temporaries), identical to CPython's `1 - 0.9 * (step_count / max_steps)`.
+static void build_reward_lut(int max_steps, double* out) {
+  for (int t = 0; t <= max_steps; t++) {
+    volatile double q = (double)t / (double)max_steps;
+    volatile double p = 0.9 * q;
+    out[t] = 1.0 - p;
+  }
+}
+
+static GenParams gen_params(const mg_env* e) {
+  GenParams g;
+  g.kind = e->cfg.env_kind; g.W = e->W; g.H = e->H;
+  g.start_x = e->cfg.agent_start_x; g.start_y = e->cfg.agent_start_y; g.start_dir = e->cfg.agent_start_dir;
+  g.num_crossings = e->cfg.num_crossings;
+  g.obstacle_cell = e->cfg.obstacle_type == (int)T_WALL ? (int)CELL_WALL_GREY : (int)CELL_LAVA;
+  g.num_dists = e->cfg.num_dists;
+  return g;
+}
+
+// ---- launches -------------------------------------------------------------------------------------------
+static int launch_generate(mg_env* e, bool to_spare, bool queue_mode, const uint8_t* d_mask) {
+  GenArgs A;
+  A.gp = gen_params(e);
+  A.dst_grid = to_spare ? e->spare_grid : e->grid;
+  A.dst_agent = to_spare ? e->spare_agent : e->agent;
+  A.rng = e->rng;
+  A.rng_snap = to_spare ? e->rng_snap : nullptr;
+  A.queue = queue_mode ? e->queue : nullptr;
+  // the step launched just before this used counter (launches-1)&1; clear the other one for the next step
+  A.count = queue_mode ? e->qcount + ((e->launches - 1) & 1) : nullptr;
+  A.zero_count = queue_mode ? e->qcount + (e->launches & 1) : nullptr;
+  A.mask = d_mask; A.err = e->err; A.counters = e->counters;
+  A.N = e->N; A.CS = e->CS; A.GS = e->GS;
+  int blocks = (e->N + 63) / 64;
+  if (queue_mode) blocks = std::min(blocks, 2048);
+  size_t lds = (size_t)64 * e->GS;
+  if (e->cfg.rng_mode == MG_RNG_PHILOX)
+    hipLaunchKernelGGL(k_generate<PhiloxStream>, dim3(blocks), dim3(64), lds, e->stream, A);
+  else
+    hipLaunchKernelGGL(k_generate<Pcg64Stream>, dim3(blocks), dim3(64), lds, e->stream, A);
+  HIP_TRY(e, hipGetLastError());
+  return MG_OK;
+}
+
+static void fill_step_params(mg_env* e, StepParams& P, int phase) {
+  P.grid = e->grid; P.spare_grid = e->spare_grid; P.agent = e->agent; P.spare_agent = e->spare_agent;
+  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
+  P.obs = e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
+  P.reward_lut = e->reward_lut; P.refill_queue = e->queue; P.refill_count = e->qcount + (e->launches & 1);
+  P.err = e->err; P.counters = e->counters;
+  P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
+  P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
+  P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
+  P.phase = phase; P.static_gen = e->static_gen;
+  P.lds_per_wave = e->lds_per_wave; P.t_offset = e->t_offset; P.TS = e->TS;
+  const uint32_t cpe = (uint32_t)(e->CS >> 4);
+  P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
+  P.cells_magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)e->cells - 1) / (uint64_t)e->cells);
+  P.env_base = e->cfg.env_index_base;
+}
+
+static int launch_step(mg_env* e, const StepParams& P) {
+  const int waves = (e->N + 63) / 64;
+  const int blocks = (waves + e->wpb - 1) / e->wpb;
+  const size_t lds = (size_t)e->wpb * e->lds_per_wave;
+  dim3 grid(blocks), block(64 * e->wpb);
+  if (e->cfg.obs_mode == MG_OBS_PARTIAL)
+    hipLaunchKernelGGL((k_step<0, false>), grid, block, lds, e->stream, P);
+  else if (e->tpad)
+    hipLaunchKernelGGL((k_step<1, true>), grid, block, lds, e->stream, P);
+  else
+    hipLaunchKernelGGL((k_step<1, false>), grid, block, lds, e->stream, P);
+  HIP_TRY(e, hipGetLastError());
+  e->launches++;
+  if (!e->static_gen) return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/true, nullptr);
+  return MG_OK;
+}
+
+static int check_device_errors(mg_env* e) {
+  uint32_t bits = 0;
+  HIP_TRY(e, hipMemcpyAsync(&bits, e->err, sizeof bits, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (!bits) return MG_OK;
+  HIP_TRY(e, hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
+  if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
+  if (bits & ERR_OOB) return fail(e, MG_ERR_OOB, "front cell outside the grid (core/grid.py:74-78 assert)");
+  return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound");
+}
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+// ---- C ABI ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+int mg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* mg_last_error(mg_env* env) { return env ? env->last_error.c_str() : g_create_error.c_str(); }
+
+int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
+  if (!cfg || !out) return fail(nullptr, MG_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != MG_ABI_VERSION) return fail(nullptr, MG_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, MG_ABI_VERSION);
+  if (cfg->num_envs < 1) return fail(nullptr, MG_ERR_INVALID, "num_envs must be >= 1");
+  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25)
+    return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
+  if (cfg->agent_view_size != 7) return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be 7 on this path");
+  if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTO_REDBALL) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_GOTO_REDBALL && (cfg->width != 8 || cfg->height != 8))
+    return fail(nullptr, MG_ERR_INVALID, "GoToRedBall is a single 8x8 room (goto.py:129-131)");
+  if (cfg->env_kind == MG_ENV_CROSSING && ((cfg->width & 1) == 0 || (cfg->height & 1) == 0 || cfg->width > 11 || cfg->height > 11))
+    return fail(nullptr, MG_ERR_INVALID, "Crossing needs an odd size <= 11 (crossing.py:132 assert)");
+  if (cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0 &&
+      (cfg->agent_start_x >= cfg->width || cfg->agent_start_y < 0 || cfg->agent_start_y >= cfg->height || (unsigned)cfg->agent_start_dir > 3u))
+    return fail(nullptr, MG_ERR_INVALID, "agent start outside the grid");
+  int ndev = mg_device_count();
+  if (ndev < 1) return fail(nullptr, MG_ERR_NO_DEVICE, "no HIP device visible: libminigrid_hip has no CPU fallback");
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= ndev) return fail(nullptr, MG_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+
+  mg_env* e = new mg_env();
+  e->cfg = *cfg; e->device = device;
+  e->N = cfg->num_envs; e->W = cfg->width; e->H = cfg->height; e->cells = e->W * e->H;
+  e->CS = (e->cells + 15) & ~15;
+  e->GS = e->CS + 4;                                     // odd dword stride: conflict-free same-cell LDS reads
+  const bool full = cfg->obs_mode == MG_OBS_FULL;
+  e->obs_bytes = full ? e->cells * 3 : PARTIAL_OBS_BYTES;
+  const int grid_region = (64 * e->GS + 15) & ~15;
+  if (!full) {
+    e->TS = VIEW_CELLS; e->tpad = false; e->t_offset = 0;          // T aliases the staged grids (read before written)
+    e->lds_per_wave = std::max(grid_region, 64 * VIEW_CELLS * 4);
+  } else {
+    e->TS = e->cells | 1; e->tpad = (e->cells & 1) == 0; e->t_offset = grid_region;
+    e->lds_per_wave = grid_region + ((64 * e->TS * 4 + 15) & ~15);
+  }
+  e->wpb = 4;
+  while (e->wpb > 1 && e->wpb * e->lds_per_wave > 64 * 1024) e->wpb >>= 1;
+  if (e->lds_per_wave > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
+  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
+  if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
+
+  mg_env* env = e;   // for HIP_TRY
+#define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)
+  TRY_OR_FREE(hipSetDevice(device));
+  if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
+  else { TRY_OR_FREE(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+  TRY_OR_FREE(hipEventCreate(&e->ev0));
+  TRY_OR_FREE(hipEventCreate(&e->ev1));
+  const size_t N = (size_t)e->N;
+  TRY_OR_FREE(dalloc(&e->grid, N * e->CS));
+  TRY_OR_FREE(dalloc(&e->spare_grid, N * e->CS));
+  TRY_OR_FREE(dalloc(&e->agent, N));
+  TRY_OR_FREE(dalloc(&e->spare_agent, N));
+  TRY_OR_FREE(dalloc(&e->rng, 5 * N));
+  TRY_OR_FREE(dalloc(&e->rng_snap, 5 * N));
+  TRY_OR_FREE(dalloc(&e->seeds, N));
+  TRY_OR_FREE(dalloc(&e->mask, N));
+  TRY_OR_FREE(dalloc(&e->actions, 8 * N));
+  TRY_OR_FREE(dalloc(&e->obs, N * e->obs_bytes + 16));
+  TRY_OR_FREE(dalloc(&e->reward, N));
+  TRY_OR_FREE(dalloc(&e->term, N));
+  TRY_OR_FREE(dalloc(&e->trunc, N));
+  TRY_OR_FREE(dalloc(&e->dir, N));
+  TRY_OR_FREE(dalloc(&e->mission, N));
+  TRY_OR_FREE(dalloc(&e->reward_lut, (size_t)cfg->max_steps + 1));
+  TRY_OR_FREE(dalloc(&e->queue, N));
+  TRY_OR_FREE(dalloc(&e->qcount, 2));
+  TRY_OR_FREE(dalloc(&e->err, 1));
+  TRY_OR_FREE(dalloc(&e->counters, 4));
+  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 2 * sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, N * e->CS, e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->obs, 0, N * e->obs_bytes + 16, e->stream));
+  {
+    std::vector<double> lut((size_t)cfg->max_steps + 1);
+    build_reward_lut(cfg->max_steps, lut.data());
+    TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (e->lds_per_wave * e->wpb > 64 * 1024) {
+    const int bytes = e->lds_per_wave * e->wpb;
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
+#undef TRY_OR_FREE
+  (void)env;
+  // a usable state from the start: env i seeded with its global index (like reset(seed=env_index_base + i))
+  std::vector<uint64_t> seeds(N);
+  for (size_t i = 0; i < N; i++) seeds[i] = (uint64_t)(cfg->env_index_base + (long long)i);
+  int rc = mg_reset(e, seeds.data(), nullptr);
+  if (rc != MG_OK) { g_create_error = e->last_error; mg_destroy(e); return rc; }
+  rc = mg_sync(e);
+  if (rc != MG_OK) { g_create_error = e->last_error; mg_destroy(e); return rc; }
+  *out = e;
+  return MG_OK;
+}
+
+int mg_destroy(mg_env* e) {
+  if (!e) return MG_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions,
+                   e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters };
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return MG_OK;
+}
+
+int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
+  if (!e) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int N = e->N;
+  const uint8_t* d_mask = nullptr;
+  if (mask) {
+    HIP_TRY(e, hipMemcpyAsync(e->mask, mask, (size_t)N, hipMemcpyHostToDevice, e->stream));
+    d_mask = e->mask;
+  }
+  const int tb = 256, nb = (N + tb - 1) / tb;
+  if (seeds) {
+    // reset(seed=s): reseed, draw this episode, then draw the spare (episode 2 of the same stream)
+    HIP_TRY(e, hipMemcpyAsync(e->seeds, seeds, (size_t)N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    if (e->cfg.rng_mode == MG_RNG_PHILOX)
+      hipLaunchKernelGGL(k_seed<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
+    else
+      hipLaunchKernelGGL(k_seed<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
+    HIP_TRY(e, hipGetLastError());
+    int rc = launch_generate(e, /*to_spare=*/false, /*queue_mode=*/false, d_mask);
+    if (rc) return rc;
+    rc = launch_generate(e, /*to_spare=*/true, /*queue_mode=*/false, d_mask);
+    if (rc) return rc;
+  } else {
+    // reset(): continue each env's own stream == consume the pre-drawn spare
+    hipLaunchKernelGGL(k_mark_pending, dim3(nb), dim3(tb), 0, e->stream, e->agent, d_mask, N);
+    HIP_TRY(e, hipGetLastError());
+  }
+  StepParams P;
+  fill_step_params(e, P, PHASE_OBSERVE);
+  return launch_step(e, P);
+}
+
+int mg_step(mg_env* e, const void* actions, int dtype, int on_device) {
+  if (!e || !actions) return MG_ERR_INVALID;
+  if (dtype < MG_ACT_U8 || dtype > MG_ACT_I64) return fail(e, MG_ERR_INVALID, "bad action dtype");
+  HIP_TRY(e, hipSetDevice(e->device));
+  StepParams P;
+  fill_step_params(e, P, PHASE_STEP);
+  P.act_dtype = dtype;
+  if (on_device) P.actions = actions;
+  else {
+    const size_t sz = (size_t)e->N * (dtype == MG_ACT_U8 ? 1 : dtype == MG_ACT_I32 ? 4 : 8);
+    HIP_TRY(e, hipMemcpyAsync(e->actions, actions, sz, hipMemcpyHostToDevice, e->stream));
+    P.actions = e->actions;
+  }
+  return launch_step(e, P);
+}
+
+int mg_rollout(mg_env* e, int T, uint64_t action_seed, int fused) {
+  if (!e || T < 0) return MG_ERR_INVALID;
+  (void)fused;
+  HIP_TRY(e, hipSetDevice(e->device));
+  for (int i = 0; i < T; i++) {
+    StepParams P;
+    fill_step_params(e, P, PHASE_STEP);
+    P.act_src = ACT_SRC_PHILOX; P.action_seed = action_seed; P.t = e->t++;
+    int rc = launch_step(e, P);
+    if (rc) return rc;
+  }
+  return MG_OK;
+}
+
+int mg_get_outputs(mg_env* e, mg_outputs* o) {
+  if (!e || !o) return MG_ERR_INVALID;
+  o->obs = e->obs; o->reward = e->reward; o->terminated = e->term; o->truncated = e->trunc;
+  o->direction = e->dir; o->mission_id = e->mission; o->obs_bytes_per_env = e->obs_bytes; o->num_envs = e->N;
+  return MG_OK;
+}
+
+int mg_copy_outputs(mg_env* e, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint8_t* mission) {
+  if (!e) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  if (obs) HIP_TRY(e, hipMemcpyAsync(obs, e->obs, N * e->obs_bytes, hipMemcpyDeviceToHost, e->stream));
+  if (reward) HIP_TRY(e, hipMemcpyAsync(reward, e->reward, N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (term) HIP_TRY(e, hipMemcpyAsync(term, e->term, N, hipMemcpyDeviceToHost, e->stream));
+  if (trunc) HIP_TRY(e, hipMemcpyAsync(trunc, e->trunc, N, hipMemcpyDeviceToHost, e->stream));
+  if (dir) HIP_TRY(e, hipMemcpyAsync(dir, e->dir, N, hipMemcpyDeviceToHost, e->stream));
+  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, e->mission, N, hipMemcpyDeviceToHost, e->stream));
+  return check_device_errors(e);
+}
+
+int mg_sync(mg_env* e) {
+  if (!e) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  return check_device_errors(e);
+}
+
+int mg_get_state(mg_env* e, uint8_t* grid, int32_t* agent) {
+  if (!e || !grid || !agent) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  std::vector<uint8_t> g(N * e->CS);
+  std::vector<uint64_t> a(N);
+  HIP_TRY(e, hipMemcpyAsync(g.data(), e->grid, g.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(a.data(), e->agent, N * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  for (size_t n = 0; n < N; n++) {
+    for (int x = 0; x < e->W; x++) for (int y = 0; y < e->H; y++) {
+      uint32_t tri = cell_triple(g[n * e->CS + (size_t)y * e->W + x]);
+      uint8_t* p = grid + ((n * e->W + x) * e->H + y) * 3;
+      p[0] = (uint8_t)tri; p[1] = (uint8_t)(tri >> 8); p[2] = (uint8_t)(tri >> 16);
+    }
+    Agent ag = agent_unpack(a[n]);
+    int32_t* o = agent + n * 8;
+    o[0] = (int32_t)ag.x; o[1] = (int32_t)ag.y; o[2] = (int32_t)ag.dir;
+    o[3] = ag.carry ? (int32_t)(cell_triple(ag.carry) & 0xFF) : 0;
+    o[4] = ag.carry ? (int32_t)cell_color(ag.carry) : 0;
+    o[5] = (int32_t)ag.step; o[6] = (int32_t)(ag.flags & FLAG_RESET_PENDING); o[7] = (int32_t)ag.mission;
+  }
+  return MG_OK;
+}
+
+int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
+  if (!e || !grid || !agent) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  std::vector<uint8_t> g(N * e->CS, 0);
+  std::vector<uint64_t> a(N);
+  for (size_t n = 0; n < N; n++) {
+    for (int x = 0; x < e->W; x++) for (int y = 0; y < e->H; y++) {
+      const uint8_t* p = grid + ((n * e->W + x) * e->H + y) * 3;
+      g[n * e->CS + (size_t)y * e->W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
+    }
+    const int32_t* o = agent + n * 8;
+    if (o[0] < 0 || o[0] >= e->W || o[1] < 0 || o[1] >= e->H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535)
+      return fail(e, MG_ERR_INVALID, "agent record %zu out of range", n);
+    Agent ag;
+    ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];
+    ag.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
+    if (ag.carry == CELL_EMPTY) ag.carry = 0;
+    ag.step = (uint32_t)o[5]; ag.flags = o[6] ? FLAG_RESET_PENDING : 0u; ag.mission = (uint32_t)o[7];
+    a[n] = agent_pack(ag);
+  }
+  HIP_TRY(e, hipMemcpyAsync(e->grid, g.data(), g.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->agent, a.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return MG_OK;
+}
+
+int mg_get_rng(mg_env* e, uint64_t* out) {
+  if (!e || !out) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  // the reference env's stream position "now" is the state BEFORE the spare episode was drawn
+  const uint64_t* src = e->static_gen ? e->rng : e->rng_snap;
+  std::vector<uint64_t> soa(5 * N);
+  HIP_TRY(e, hipMemcpyAsync(soa.data(), src, soa.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  for (size_t n = 0; n < N; n++) for (int k = 0; k < 5; k++) out[n * 5 + k] = soa[k * N + n];
+  return MG_OK;
+}
+
+int mg_set_rng(mg_env* e, const uint64_t* in) {
+  if (!e || !in) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  std::vector<uint64_t> soa(5 * N);
+  for (size_t n = 0; n < N; n++) for (int k = 0; k < 5; k++) soa[k * N + n] = in[n * 5 + k];
+  HIP_TRY(e, hipMemcpyAsync(e->rng, soa.data(), soa.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  // re-draw every spare from the injected position
+  return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/false, nullptr);
+}
+
+int mg_timer_start(mg_env* e) {
+  if (!e) return MG_ERR_INVALID;
+  HIP_TRY(e, hipEventRecord(e->ev0, e->stream));
+  return MG_OK;
+}
+
+int mg_timer_stop(mg_env* e, float* ms) {
+  if (!e || !ms) return MG_ERR_INVALID;
+  HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
+  HIP_TRY(e, hipEventSynchronize(e->ev1));
+  HIP_TRY(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  return MG_OK;
+}
+
+int mg_get_counters(mg_env* e, uint64_t out[4]) {
+  if (!e || !out) return MG_ERR_INVALID;
+  HIP_TRY(e, hipMemcpyAsync(out, e->counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return MG_OK;
+}
+
+// ---- host self-test hooks (run the library's inline helpers on the CPU) ----
+int mg_selftest_vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
+  if (!m_out || !up_out) return MG_ERR_INVALID;
+  vis_row(m & 0x7F, t & 0x7F, m_out, up_out);
+  return MG_OK;
+}
+int mg_selftest_reward_lut(int32_t max_steps, double* out) {
+  if (!out || max_steps < 1) return MG_ERR_INVALID;
+  build_reward_lut(max_steps, out);
+  return MG_OK;
+}
+int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple) {
+  if (!code || !triple) return MG_ERR_INVALID;
+  *code = cell_from_triple((uint32_t)type, (uint32_t)color, (uint32_t)state);
+  *triple = cell_triple(*code);
+  return MG_OK;
+}
+
+}  // extern "C"

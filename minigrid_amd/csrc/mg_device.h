@@ -1,0 +1,133 @@
+// mg_device.h — cell encoding, object predicates and the bit-parallel visibility row shared by the kernels.
+// Product code (gfx950).  Reference semantics cited per function (paths relative to the reference root).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MG_HD __host__ __device__ __forceinline__
+#define MG_D __device__ __forceinline__
+
+namespace mg {
+
+// ---- object / colour / state codes: core/constants.py:20,25-37,42-46 ----
+enum : uint32_t { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5, T_BALL = 6,
+                  T_BOX = 7, T_GOAL = 8, T_LAVA = 9, T_AGENT = 10,
+                  // internal-only type codes so a cell fits one byte: a door's state rides in the type nibble
+                  T_DOOR_CLOSED = 11, T_DOOR_LOCKED = 12 };
+enum : uint32_t { C_RED = 0, C_GREEN = 1, C_BLUE = 2, C_PURPLE = 3, C_YELLOW = 4, C_GREY = 5 };
+// core/actions.py:7-20
+enum : uint32_t { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
+
+// A grid cell in HBM/LDS is ONE byte: code = type | colour << 4.
+//   empty (Python None)  -> T_EMPTY, colour 0  == 0x01, which decodes to the reference's (1,0,0) for free
+//   door open/closed/locked -> type 4 / 11 / 12 (state 0 / 1 / 2)
+//   0x00 is "no object" for the carrying slot.
+constexpr uint32_t CELL_EMPTY = T_EMPTY;
+constexpr uint32_t CELL_WALL_GREY = T_WALL | (C_GREY << 4);
+constexpr uint32_t CELL_GOAL = T_GOAL | (C_GREEN << 4);
+constexpr uint32_t CELL_LAVA = T_LAVA | (C_RED << 4);
+constexpr uint32_t CELL_BALL_RED = T_BALL | (C_RED << 4);
+
+MG_HD uint32_t cell_type(uint32_t code) { return code & 15u; }
+MG_HD uint32_t cell_color(uint32_t code) { return (code >> 4) & 7u; }
+MG_HD uint32_t make_cell(uint32_t type, uint32_t color) { return type | (color << 4); }
+
+// (type, colour, state) of the reference encoding -> cell code.  Mirrors WorldObj.decode (core/world_object.py:69-102):
+// empty/unseen/agent -> None; Goal()/Lava() take their default colours; non-door state is ignored.
+MG_HD uint32_t cell_from_triple(uint32_t type, uint32_t color, uint32_t state) {
+  if (type == T_EMPTY || type == T_UNSEEN || type >= T_AGENT) return CELL_EMPTY;
+  if (type == T_GOAL) return CELL_GOAL;
+  if (type == T_LAVA) return CELL_LAVA;
+  if (type == T_DOOR) type = state == 0 ? (uint32_t)T_DOOR : (state == 2 ? (uint32_t)T_DOOR_LOCKED : (uint32_t)T_DOOR_CLOSED);
+  return make_cell(type, color & 7u);
+}
+// cell code -> type | colour << 8 | state << 16, i.e. the three bytes WorldObj.encode / Door.encode produce
+// (core/world_object.py:65-67,196-212) and Grid.encode writes for None (core/grid.py:260-263).
+MG_HD uint32_t cell_triple(uint32_t code) {
+  uint32_t t = code & 15u, c = (code >> 4) & 7u;
+  uint32_t st = t >= T_DOOR_CLOSED ? t - 10u : 0u;
+  t = t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t;
+  return t | (c << 8) | (st << 16);
+}
+
+// predicate bitmaps over the 4-bit type code
+// can_overlap (world_object.py:113,128,141,177-179): goal, floor, lava, OPEN door; None (empty) is walkable too
+constexpr uint32_t WALKABLE_MASK = (1u << T_EMPTY) | (1u << T_FLOOR) | (1u << T_DOOR) | (1u << T_GOAL) | (1u << T_LAVA);
+// can_pickup (world_object.py:243,265,277)
+constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX);
+// NOT see_behind (world_object.py:164,181-182): wall, closed door, locked door
+constexpr uint32_t OPAQUE_MASK = (1u << T_WALL) | (1u << T_DOOR_CLOSED) | (1u << T_DOOR_LOCKED);
+
+MG_HD bool cell_walkable(uint32_t code) { return (WALKABLE_MASK >> (code & 15u)) & 1u; }
+MG_HD bool cell_pickable(uint32_t code) { return (PICKUP_MASK >> (code & 15u)) & 1u; }
+MG_HD bool cell_transparent(uint32_t code) { return !((OPAQUE_MASK >> (code & 15u)) & 1u); }
+
+// Door.toggle (world_object.py:184-194) / Box.toggle (290-293, contains is None on this path) on a cell code.
+// Returns the new code (unchanged when toggling does nothing).
+MG_HD uint32_t cell_toggle(uint32_t code, uint32_t carry) {
+  uint32_t t = code & 15u;
+  if (t == T_DOOR_LOCKED) {
+    bool has_key = (carry & 15u) == T_KEY && ((carry >> 4) & 7u) == ((code >> 4) & 7u);
+    return has_key ? ((code & ~15u) | T_DOOR) : code;
+  }
+  if (t == T_DOOR) return (code & ~15u) | T_DOOR_CLOSED;
+  if (t == T_DOOR_CLOSED) return (code & ~15u) | T_DOOR;
+  if (t == T_BOX) return CELL_EMPTY;
+  return code;
+}
+
+// ---- one row of Grid.process_vis (core/grid.py:291-328), bit-parallel ----
+// Row j of the 7-wide view: `m` = mask bits already set in this row (bit i = mask[i][j]), `t` = transparency bits
+// (cell is None or see_behind()).  The reference sweeps i = 0..5 left-to-right (lit & transparent cell lights
+// i+1 in this row and i, i+1 in row j-1), then i = 6..1 right-to-left (lights i-1 / i-1, i above), each sweep
+// seeing its own writes.  A sweep is a one-directional occluded fill, done here with Kogge-Stone steps.
+// Returns the final row mask in *m_out and the bits contributed to row j-1 in *up_out.
+// tests/test_vis_row.py checks all 2^14 inputs against the literal loops.
+MG_HD void vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
+  // sweep 1: lit&transparent set A closed under "i in A, t[i+1], -> i+1 in A" plus seeds m&t
+  uint32_t g = m & t, p = t;
+  g |= p & (g << 1); p &= p << 1;
+  g |= p & (g << 2); p &= p << 2;
+  g |= p & (g << 4);
+  // fixpoint subtlety: a lit-but-opaque cell does not propagate, an unlit cell becomes lit by its left neighbour
+  // in A; so A must also absorb cells that become lit then are transparent -> already covered by the fill above.
+  uint32_t s1 = g & 0x3Fu;                 // sources i = 0..5
+  uint32_t m1 = (m | (s1 << 1)) & 0x7Fu;
+  uint32_t up = s1 | (s1 << 1);
+  // sweep 2 on the running mask
+  g = m1 & t; p = t;
+  g |= p & (g >> 1); p &= p >> 1;
+  g |= p & (g >> 2); p &= p >> 2;
+  g |= p & (g >> 4);
+  uint32_t s2 = g & 0x7Eu;                 // sources i = 6..1
+  *m_out = (m1 | (s2 >> 1)) & 0x7Fu;
+  *up_out = (up | s2 | (s2 >> 1)) & 0x7Fu;
+}
+
+// agent record: one u64 per env
+//   byte 0 x, 1 y, 2 dir, 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16), 6 flags, 7 mission id
+constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode; NEXT_STEP autoreset is due
+struct Agent {
+  uint32_t x, y, dir, carry, step, flags, mission;
+};
+MG_HD Agent agent_unpack(uint64_t r) {
+  Agent a;
+  a.x = (uint32_t)(r & 0xFF); a.y = (uint32_t)((r >> 8) & 0xFF); a.dir = (uint32_t)((r >> 16) & 0xFF);
+  a.carry = (uint32_t)((r >> 24) & 0xFF); a.step = (uint32_t)((r >> 32) & 0xFFFF);
+  a.flags = (uint32_t)((r >> 48) & 0xFF); a.mission = (uint32_t)((r >> 56) & 0xFF);
+  return a;
+}
+MG_HD uint64_t agent_pack(const Agent& a) {
+  return (uint64_t)(a.x & 0xFF) | ((uint64_t)(a.y & 0xFF) << 8) | ((uint64_t)(a.dir & 0xFF) << 16) |
+         ((uint64_t)(a.carry & 0xFF) << 24) | ((uint64_t)(a.step & 0xFFFF) << 32) |
+         ((uint64_t)(a.flags & 0xFF) << 48) | ((uint64_t)(a.mission & 0xFF) << 56);
+}
+
+// DIR_TO_VEC (core/constants.py:49-58) without a table: dir 0:(1,0) 1:(0,1) 2:(-1,0) 3:(0,-1)
+MG_HD int dir_dx(uint32_t d) { return (d & 1u) ? 0 : 1 - (int)(d & 2u); }
+MG_HD int dir_dy(uint32_t d) { return (d & 1u) ? 1 - (int)(d & 2u) : 0; }
+
+// device error bits (accumulated with atomicOr, surfaced by mg_sync / mg_copy_outputs)
+enum : uint32_t { ERR_BAD_ACTION = 1u, ERR_GENERATOR = 2u, ERR_OOB = 4u };
+
+}  // namespace mg

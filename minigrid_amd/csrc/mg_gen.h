@@ -1,0 +1,219 @@
+// mg_gen.h — device-side map generators (the reference's `_gen_grid` implementations on the hot path).
+// One lane generates one episode into its private byte grid (in LDS), drawing from its own stream in exactly the
+// order the reference draws, so that with Pcg64Stream the layout for a given seed is the reference's layout.
+#pragma once
+#include "mg_device.h"
+#include "mg_rng.h"
+
+namespace mg {
+
+struct GenParams {
+  int kind, W, H;
+  int start_x, start_y, start_dir;   // Empty
+  int num_crossings, obstacle_cell;  // Crossing (obstacle_cell = cell code of Lava()/Wall())
+  int num_dists;                     // GoToRedBall
+};
+
+struct GenResult {
+  uint32_t ax, ay, dir, mission;
+  uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
+  bool failed;        // retry bound exhausted
+};
+
+// Byte grid, row-major index y*W+x (core/grid.py:28-35,65-78)
+struct GridRef {
+  uint8_t* p; int W, H;
+  MG_D uint32_t get(int x, int y) const { return p[y * W + x]; }
+  MG_D void set(int x, int y, uint32_t c) { p[y * W + x] = (uint8_t)c; }
+  // Grid(width,height) + wall_rect(0,0,W,H) (core/grid.py:28-35,104-108)
+  MG_D void clear_with_walls() {
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++)
+        p[y * W + x] = (uint8_t)((x == 0 || y == 0 || x == W - 1 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
+  }
+};
+
+// MiniGridEnv.place_obj (minigrid_env.py:313-372).  (ax, ay) is the agent position to avoid ((-1,-1) while the
+// agent itself is being placed).  near_reject = core/roomgrid.py:11-20 reject_next_to.  max_tries < 0 = math.inf.
+// Returns false on the reference's RecursionError.
+template <class R>
+MG_D bool place_obj(R& rng, GridRef& g, uint32_t cell, int topx, int topy, int sx, int sy, int ax, int ay,
+                    bool near_reject, int max_tries, int& px, int& py) {
+  topx = topx < 0 ? 0 : topx; topy = topy < 0 ? 0 : topy;
+  const int hx = min(topx + sx, g.W), hy = min(topy + sy, g.H);
+  int tries = 0;
+  for (;;) {
+    if (max_tries >= 0 && tries > max_tries) return false;
+    if (tries > (1 << 20)) return false;          // device safety bound for the unbounded reference loop
+    tries++;
+    int x = rand_int(rng, topx, hx);
+    int y = rand_int(rng, topy, hy);
+    if (g.get(x, y) != CELL_EMPTY) continue;
+    if (x == ax && y == ay) continue;
+    if (near_reject && (abs(ax - x) + abs(ay - y)) < 2) continue;
+    if (cell != CELL_EMPTY) g.set(x, y, cell);
+    px = x; py = y;
+    return true;
+  }
+}
+// MiniGridEnv.place_agent (minigrid_env.py:383-395)
+template <class R>
+MG_D bool place_agent(R& rng, GridRef& g, int topx, int topy, int sx, int sy, int max_tries, GenResult& out) {
+  int x, y;
+  if (!place_obj(rng, g, CELL_EMPTY, topx, topy, sx, sy, -1, -1, false, max_tries, x, y)) return false;
+  out.ax = (uint32_t)x; out.ay = (uint32_t)y;
+  out.dir = (uint32_t)rand_int(rng, 0, 4);
+  return true;
+}
+
+// envs/empty.py:97-114
+template <class R>
+MG_D void gen_empty(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  g.set(g.W - 2, g.H - 2, CELL_GOAL);
+  if (P.start_x >= 0) { out.ax = P.start_x; out.ay = P.start_y; out.dir = P.start_dir; }
+  else if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  out.mission = 0;
+}
+
+// envs/doorkey.py:74-99
+template <class R>
+MG_D void gen_doorkey(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  g.set(g.W - 2, g.H - 2, CELL_GOAL);
+  int split = rand_int(rng, 2, g.W - 2);
+  for (int y = 0; y < g.H; y++) g.set(split, y, CELL_WALL_GREY);
+  if (!place_agent(rng, g, 0, 0, split, g.H, -1, out)) out.failed = true;
+  int door = rand_int(rng, 1, g.W - 2);
+  g.set(split, door, make_cell(T_DOOR_LOCKED, C_YELLOW));
+  int kx, ky;
+  if (!place_obj(rng, g, make_cell(T_KEY, C_YELLOW), 0, 0, split, g.H, (int)out.ax, (int)out.ay, false, -1, kx, ky))
+    out.failed = true;
+  out.mission = 0;
+}
+
+// envs/crossing.py:131-188.  Rivers sit on even coordinates 2..size-3, at most 8 of them for the registered sizes
+// (S9: 3+3, S11: 4+4), so the shuffled river list is 8 bytes packed in a u64 (byte = orientation << 7 | position)
+// and the per-orientation sorted position lists are bitmasks.
+template <class R>
+MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H;
+  g.clear_with_walls();
+  out.ax = 1; out.ay = 1; out.dir = 0;
+  g.set(W - 2, H - 2, CELL_GOAL);
+  uint64_t rivers = 0; int n = 0;
+  for (int i = 2; i < H - 2; i += 2) { rivers |= (uint64_t)(i) << (8 * n); n++; }          // (v, i)
+  for (int j = 2; j < W - 2; j += 2) { rivers |= (uint64_t)(0x80 | j) << (8 * n); n++; }   // (h, j)
+  // np_random.shuffle(rivers): for i = n-1..1: j = random_interval(i); swap
+  for (int i = n - 1; i >= 1; i--) {
+    int j = (int)rand_interval(rng, (uint32_t)i);
+    uint64_t bi = (rivers >> (8 * i)) & 0xFF, bj = (rivers >> (8 * j)) & 0xFF;
+    rivers &= ~((0xFFull << (8 * i)) | (0xFFull << (8 * j)));
+    rivers |= (bj << (8 * i)) | (bi << (8 * j));
+  }
+  n = min(n, P.num_crossings);
+  uint32_t vmask = 0, hmask = 0; int nv = 0, nh = 0;    // sorted(rivers_v), sorted(rivers_h) as position bitmasks
+  for (int k = 0; k < n; k++) {
+    uint32_t b = (uint32_t)(rivers >> (8 * k)) & 0xFF;
+    if (b & 0x80) { hmask |= 1u << (b & 0x7F); nh++; } else { vmask |= 1u << b; nv++; }
+  }
+  for (int p = 2; p < 32; p += 2) {
+    if ((hmask >> p) & 1) for (int i = 1; i < W - 1; i++) g.set(i, p, P.obstacle_cell);
+    if ((vmask >> p) & 1) for (int j = 1; j < H - 1; j++) g.set(p, j, P.obstacle_cell);
+  }
+  // path = [h]*len(rivers_v) + [v]*len(rivers_h); shuffle.  bit k of `path` = 1 for h.
+  uint32_t path = (1u << nv) - 1u; const int np = nv + nh;
+  for (int i = np - 1; i >= 1; i--) {
+    int j = (int)rand_interval(rng, (uint32_t)i);
+    uint32_t bi = (path >> i) & 1u, bj = (path >> j) & 1u;
+    path = (path & ~((1u << i) | (1u << j))) | (bj << i) | (bi << j);
+  }
+  // limits_v = [0] + rivers_v + [H-1]; limits_h = [0] + rivers_h + [W-1]; walk the path opening one gap per river
+  int room_i = 0, room_j = 0;
+  int lv_lo = 0, lh_lo = 0;                 // limits_v[room_i], limits_h[room_j]
+  uint32_t vrem = vmask, hrem = hmask;      // not-yet-crossed rivers, lowest bit = next limit
+  for (int k = 0; k < np; k++) {
+    int lv_hi = vrem ? __builtin_ctz(vrem) : H - 1;   // limits_v[room_i + 1]
+    int lh_hi = hrem ? __builtin_ctz(hrem) : W - 1;   // limits_h[room_j + 1]
+    int i, j;
+    if ((path >> k) & 1u) {    // direction is h: cross the next vertical river
+      i = lv_hi;
+      j = rand_int(rng, lh_lo + 1, lh_hi);            // np_random.choice(range(a, b)) == a + integers(0, b-a)
+      room_i++; lv_lo = lv_hi; vrem &= vrem - 1;
+    } else {                   // direction is v: cross the next horizontal river
+      i = rand_int(rng, lv_lo + 1, lv_hi);
+      j = lh_hi;
+      room_j++; lh_lo = lh_hi; hrem &= hrem - 1;
+    }
+    g.set(i, j, CELL_EMPTY);
+  }
+  (void)room_i; (void)room_j;
+  out.mission = 0;
+}
+
+// BabyAI GoToRedBall: envs/babyai/goto.py:133-141 gen_mission over a 1x1 RoomGrid (core/roomgrid.py:123-179),
+// RoomGrid.place_agent (313-334), add_object/place_in_room (198-228,181-196: reject_next_to, max_tries=1000),
+// add_distractors (396-438, all_unique=False), check_objs_reachable (roomgrid_level.py:250-302) and the
+// regenerate-on-reject loop (roomgrid_level.py:119-144).  Mission surface: verifier.py:73-103.
+// The 8x8 grid is one 64-bit bitboard for the reachability flood.
+template <class R>
+MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H;
+  for (uint32_t attempt = 0; attempt < 4096; attempt++) {
+    out.retries = attempt;
+    g.clear_with_walls();
+    // RoomGrid.place_agent: integers(0,1) for the room draws nothing; loop until the front cell is None or a wall
+    bool ok = true;
+    for (;;) {
+      if (!place_agent(rng, g, 0, 0, W, H, 1000, out)) { ok = false; break; }
+      uint32_t f = g.get((int)out.ax + dir_dx(out.dir), (int)out.ay + dir_dy(out.dir));
+      if (f == CELL_EMPTY || cell_type(f) == T_WALL) break;
+    }
+    if (!ok) continue;
+    int x, y;
+    if (!place_obj(rng, g, CELL_BALL_RED, 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y)) continue;
+    for (int d = 0; d < P.num_dists && ok; d++) {
+      // COLOR_NAMES is sorted: blue, green, grey, purple, red, yellow (core/constants.py:17)
+      const uint32_t sorted_colors = (C_BLUE) | (C_GREEN << 4) | (C_GREY << 8) | (C_PURPLE << 12) | (C_RED << 16) | (C_YELLOW << 20);
+      uint32_t color = (sorted_colors >> (4 * rand_int(rng, 0, 6))) & 15u;
+      uint32_t type = T_KEY + (uint32_t)rand_int(rng, 0, 3);     // ["key", "ball", "box"] = 5, 6, 7
+      ok = place_obj(rng, g, make_cell(type, color), 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y);
+    }
+    if (!ok) continue;
+    // check_objs_reachable: flood from the agent through None/door cells; every non-wall object must be in the
+    // visited set (= passable flood plus its 4-neighbourhood).  Bit index = y*8+x (W == H == 8).
+    uint64_t passable = 0, objects = 0; uint32_t nred = 0;
+    for (int k = 0; k < 64; k++) {
+      uint32_t c = g.p[k], t = cell_type(c);
+      if (c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED) passable |= 1ull << k;
+      else if (t != T_WALL) objects |= 1ull << k;
+      nred += (c == CELL_BALL_RED);
+    }
+    const uint64_t notA = 0xFEFEFEFEFEFEFEFEull, notH = 0x7F7F7F7F7F7F7F7Full;
+    uint64_t reach = 1ull << (out.ay * 8 + out.ax);
+    for (;;) {
+      uint64_t grow = ((reach << 1) & notA) | ((reach >> 1) & notH) | (reach << 8) | (reach >> 8);
+      uint64_t next = reach | (grow & passable);
+      if (next == reach) break;
+      reach = next;
+    }
+    uint64_t visited = reach | ((reach << 1) & notA) | ((reach >> 1) & notH) | (reach << 8) | (reach >> 8);
+    if (objects & ~visited) continue;             // RejectSampling("unreachable object")
+    out.mission = nred > 1 ? 1u : 0u;             // "go to the red ball" / "go to a red ball"
+    return;
+  }
+  out.failed = true;
+}
+
+template <class R>
+MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
+  switch (P.kind) {
+    case 0: gen_empty(rng, g, P, out); break;
+    case 1: gen_doorkey(rng, g, P, out); break;
+    case 2: gen_crossing(rng, g, P, out); break;
+    default: gen_goto_redball(rng, g, P, out); break;
+  }
+}
+
+}  // namespace mg

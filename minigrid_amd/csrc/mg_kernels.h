@@ -1,0 +1,368 @@
+// mg_kernels.h — HIP kernels for gfx950 (MI355X): the lockstep MiniGridEnv.step()/gen_obs()/FullyObs hot path,
+// the queue-driven episode generator, and seeding.  One wavefront lane per environment.
+//
+// HBM layout (all per mg_env handle; N envs, env-major):
+//   grid        u8  [N][CS]   one byte per cell (mg_device.h), row-major y*W+x, CS = W*H rounded up to 16
+//   spare_grid  u8  [N][CS]   the NEXT episode's map, generated ahead of time (see below)
+//   agent       u64 [N]       packed agent record (x, y, dir, carrying, step_count, flags, mission)
+//   spare_agent u64 [N]
+//   rng / rng_snap u64 [5][N] SoA generator state (current, and as it was before the spare was drawn)
+//   obs u8 [N][147 | W*H*3], reward f64 [N], terminated/truncated/direction/mission u8 [N]
+//
+// Why a spare episode: in the reference an env's np_random stream is consumed ONLY by reset() on this path, so the
+// map of episode k+1 can be drawn any time after episode k's map without changing the stream.  The step kernel
+// therefore never runs a generator: on (auto)reset it copies the pre-generated spare (CS bytes) and enqueues the
+// env id; a separate, fully-occupied generator kernel refills the spares of the enqueued envs.  The sequential,
+// divergent PCG64 + rejection-sampling code stays off the step critical path.
+#pragma once
+#include "mg_device.h"
+#include "mg_gen.h"
+#include "mg_rng.h"
+
+namespace mg {
+
+// wave-local LDS hand-off: all lanes of ONE wave wrote LDS, other lanes of the same wave read it next.
+#define MG_WAVE_SYNC()                                        \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+constexpr int VIEW = 7;
+constexpr int VIEW_CELLS = VIEW * VIEW;        // 49
+constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
+
+enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
+enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
+enum : int { RULE_NONE = 0, RULE_GOTO = 1 };
+
+struct StepParams {
+  // state
+  uint8_t* grid; const uint8_t* spare_grid; uint64_t* agent; const uint64_t* spare_agent;
+  // inputs
+  const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t;
+  // outputs
+  uint8_t* obs; double* reward; uint8_t* term; uint8_t* trunc; uint8_t* dir_out; uint8_t* mission_out;
+  // tables / bookkeeping
+  const double* reward_lut; uint32_t* refill_queue; uint32_t* refill_count; uint32_t* err;
+  unsigned long long* counters;
+  // config
+  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen;
+  int lds_per_wave, t_offset, TS;
+  uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
+  uint32_t cells_magic;   // ceil(2^32 / cells)  (low 32 bits; exact for q < 2^16)
+  long long env_base;
+};
+
+// _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).
+// Normally read from the host-built LUT; this exact device form covers step_count > max_steps (autoreset disabled).
+MG_D double reward_exact(uint32_t step, int max_steps) {
+  double q = __ddiv_rn((double)step, (double)max_steps);
+  double p = __dmul_rn(0.9, q);
+  return __dsub_rn(1.0, p);
+}
+
+MG_D uint32_t load_action(const StepParams& P, int e) {
+  if (P.act_src == ACT_SRC_PHILOX) {
+    uint64_t gi = (uint64_t)(P.env_base + e);
+    uint32_t c[4] = { (uint32_t)gi, (uint32_t)(gi >> 32), P.t, 0x41435431u };
+    philox4x32_10(c, (uint32_t)P.action_seed, (uint32_t)(P.action_seed >> 32));
+    return (uint32_t)(((uint64_t)c[0] * 7u) >> 32);      // uniform over Discrete(7) (minigrid_env.py:63)
+  }
+  if (P.act_dtype == 0) return ((const uint8_t*)P.actions)[e];
+  if (P.act_dtype == 1) return (uint32_t)((const int32_t*)P.actions)[e];
+  long long v = ((const long long*)P.actions)[e];
+  return (v < 0 || v > 255) ? 255u : (uint32_t)v;
+}
+
+// 12-byte output chunk = 4 consecutive (type, colour, state) triples
+struct __attribute__((aligned(4))) Chunk12 { uint32_t a, b, c; };
+MG_D Chunk12 pack_triples(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+  Chunk12 o;
+  o.a = t0 | (t1 << 24);
+  o.b = (t1 >> 8) | (t2 << 16);
+  o.c = (t2 >> 16) | (t3 << 8);
+  return o;
+}
+
+// The wave's observations are one contiguous byte stream (envs are consecutive, records are dense), i.e. the flat
+// concatenation of 3-byte triples.  T holds one u32 per triple at index q (+ q/cells when rows are padded to an odd
+// stride); every lane packs 4 triples into 12 bytes and the wave stores 768 contiguous bytes per instruction.
+template <bool PAD>
+MG_D void emit_obs_stream(const uint32_t* T, uint8_t* obase, int ntriples, uint32_t cells_magic, int lane) {
+  const int nfull = ntriples >> 2;
+  for (int c = lane; c < nfull; c += 64) {
+    uint32_t t0, t1, t2, t3;
+    if (!PAD) {
+      uint4 v = ((const uint4*)T)[c];
+      t0 = v.x; t1 = v.y; t2 = v.z; t3 = v.w;
+    } else {
+      uint32_t q = 4u * (uint32_t)c;
+      t0 = T[q + __umulhi(q, cells_magic)];
+      t1 = T[q + 1 + __umulhi(q + 1, cells_magic)];
+      t2 = T[q + 2 + __umulhi(q + 2, cells_magic)];
+      t3 = T[q + 3 + __umulhi(q + 3, cells_magic)];
+    }
+    *(Chunk12*)(obase + 12 * (size_t)c) = pack_triples(t0, t1, t2, t3);
+  }
+  // ragged tail (only when the wave's env count is not a multiple of 4): byte stores
+  const int rem = ntriples & 3;
+  if (rem && lane < rem) {
+    uint32_t q = (uint32_t)(nfull * 4 + lane);
+    uint32_t v = T[PAD ? q + __umulhi(q, cells_magic) : q];
+    uint8_t* p = obase + 3 * (size_t)q;
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16);
+  }
+}
+
+// ======================================================================================================
+// k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
+// verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
+// FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
+// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.  TPAD: T rows padded to an odd dword stride.
+// ======================================================================================================
+template <int MODE, bool TPAD>
+__global__ void __launch_bounds__(256) k_step(const StepParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wave_env0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64;
+  if (wave_env0 >= P.N) return;                     // wave-uniform; only wave-level syncs below
+  uint8_t* wl = smem + wave * P.lds_per_wave;
+  const int e = wave_env0 + lane;
+  const bool active = e < P.N;
+  const int nvalid = min(64, P.N - wave_env0);
+  const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
+
+  // ---- issue every independent load up front: agent record, action, the wave's 64 grids (coalesced 16 B/lane) ----
+  uint64_t rec = active ? P.agent[e] : 0ull;
+  uint32_t act = (active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE;
+  {
+    const int cpe = CS >> 4;                        // 16-byte chunks per env
+    const int nchunks = nvalid * cpe;
+    const uint4* src = (const uint4*)(P.grid + (size_t)wave_env0 * CS);
+    for (int c = lane; c < nchunks; c += 64) {
+      uint4 v = src[c];
+      uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
+      uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
+      uint32_t* dst = (uint32_t*)(wl + el * GS + part * 16);
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  }
+  MG_WAVE_SYNC();
+
+  Agent a = agent_unpack(rec);
+  uint8_t* mygrid = wl + lane * GS;
+  double reward = 0.0;
+  uint32_t term = 0, trunc = 0;
+  uint32_t errbits = 0;
+
+  if (active) {
+    if ((a.flags & FLAG_RESET_PENDING) && (P.autoreset_next_step || P.phase == PHASE_OBSERVE)) {
+      // ---- (auto)reset: MiniGridEnv.reset (119-157) with the map drawn ahead of time ----
+      const uint4* sp = (const uint4*)(P.spare_grid + (size_t)e * CS);
+      uint4* live = (uint4*)(P.grid + (size_t)e * CS);
+      for (int k = 0; k < (CS >> 4); k++) {
+        uint4 v = sp[k];
+        live[k] = v;
+        uint32_t* dst = (uint32_t*)(mygrid + k * 16);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+      a = agent_unpack(P.spare_agent[e]);
+      a.carry = 0; a.step = 0; a.flags = 0;
+      if (!P.static_gen) {
+        uint32_t slot = atomicAdd(P.refill_count, 1u);
+        P.refill_queue[slot] = (uint32_t)e;
+      }
+    } else if (P.phase == PHASE_STEP) {
+      // ---- MiniGridEnv.step ----
+      a.step = min(a.step + 1u, 0xFFFFu);
+      const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+      const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
+      if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
+      const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
+      const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
+      uint32_t newF = F;
+      const uint32_t ftype = cell_type(F);
+      bool success = false;
+      if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
+      else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
+      else if (act == A_FORWARD) {
+        if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
+        if (ftype == T_GOAL) { term = 1; success = true; }
+        if (ftype == T_LAVA) term = 1;
+      } else if (act == A_PICKUP) {
+        if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
+      } else if (act == A_DROP) {
+        if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
+      } else if (act == A_TOGGLE) {
+        newF = cell_toggle(F, a.carry);
+      } else if (act != A_DONE) {
+        errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
+      }
+      if (newF != F && inb) {
+        mygrid[fidx] = (uint8_t)newF;
+        P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
+      }
+      trunc = a.step >= (uint32_t)P.max_steps;
+      if (P.rule == RULE_GOTO) {
+        // GoToInstr.verify_action on the post-action state: front cell holds a target object
+        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (int)mygrid[gy * W + gx] == P.rule_cell) {
+          term = 1; success = true;
+        }
+      }
+      if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
+      if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
+      if (term | trunc) atomicAdd(&P.counters[1], 1ull);
+    }
+  }
+
+  uint32_t* T = (uint32_t*)(wl + P.t_offset) + lane * P.TS;
+
+  if (MODE == 0) {
+    // ---- gen_obs_grid: closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
+    //      view cell (vx,vy) is world cell agent + f*(6-vy) + r*(vx-3), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
+    //      outside the grid -> grey wall (grid.py:136-139). ----
+    const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
+    const int rx = -fyv, ry = fxv;
+    const int bx = (int)a.x + fxv * 6 - rx * 3, by = (int)a.y + fyv * 6 - ry * 3;
+    uint32_t cells[VIEW_CELLS];
+    uint32_t trow[VIEW];
+#pragma unroll
+    for (int vy = 0; vy < VIEW; vy++) {
+      uint32_t tr = 0;
+#pragma unroll
+      for (int vx = 0; vx < VIEW; vx++) {
+        const int wx = bx + rx * vx - fxv * vy, wy = by + ry * vx - fyv * vy;
+        const bool in = (unsigned)wx < (unsigned)W && (unsigned)wy < (unsigned)H;
+        const uint32_t c = in ? (uint32_t)mygrid[in ? wy * W + wx : 0] : (uint32_t)CELL_WALL_GREY;
+        cells[vx * VIEW + vy] = c;
+        tr |= (uint32_t)cell_transparent(c) << vx;
+      }
+      trow[vy] = tr;
+    }
+    // ---- process_vis (grid.py:291-328), one bit-parallel row at a time, bottom row first ----
+    uint32_t vrow[VIEW];
+    if (P.see_through) {
+#pragma unroll
+      for (int j = 0; j < VIEW; j++) vrow[j] = 0x7Fu;
+    } else {
+      uint32_t m = 1u << (VIEW / 2);
+#pragma unroll
+      for (int j = VIEW - 1; j >= 0; j--) {
+        uint32_t up;
+        vis_row(m, trow[j], &vrow[j], &up);
+        m = up;
+      }
+    }
+    // the agent's own cell shows what it carries (623-630), after visibility
+    cells[(VIEW / 2) * VIEW + (VIEW - 1)] = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+    // ---- Grid.encode(vis_mask) (grid.py:244-268): invisible -> (0,0,0) ----
+#pragma unroll
+    for (int vx = 0; vx < VIEW; vx++) {
+#pragma unroll
+      for (int vy = 0; vy < VIEW; vy++) {
+        const uint32_t tri = cell_triple(cells[vx * VIEW + vy]);
+        T[vx * VIEW + vy] = ((vrow[vy] >> vx) & 1u) ? tri : 0u;
+      }
+    }
+  } else {
+    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir) ----
+    int k = 0;
+    for (int x = 0; x < W; x++) {
+      for (int y = 0; y < H; y++, k++) {
+        uint32_t tri = cell_triple((uint32_t)mygrid[y * W + x]);
+        if (x == (int)a.x && y == (int)a.y) tri = (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | (a.dir << 16);
+        T[k] = tri;
+      }
+    }
+  }
+  MG_WAVE_SYNC();
+
+  const int obs_cells = MODE == 0 ? VIEW_CELLS : P.cells;
+  uint8_t* obase = P.obs + (size_t)wave_env0 * (size_t)(obs_cells * 3);
+  emit_obs_stream<TPAD>((const uint32_t*)(wl + P.t_offset), obase, nvalid * obs_cells, P.cells_magic, lane);
+
+  if (active) {
+    if (P.phase == PHASE_STEP || (rec != agent_pack(a))) P.agent[e] = agent_pack(a);
+    P.reward[e] = reward;
+    P.term[e] = (uint8_t)term;
+    P.trunc[e] = (uint8_t)trunc;
+    P.dir_out[e] = (uint8_t)a.dir;
+    P.mission_out[e] = (uint8_t)a.mission;
+    if (errbits) atomicOr(P.err, errbits);
+  }
+  if (P.phase == PHASE_STEP && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
+}
+
+// ======================================================================================================
+// k_generate: draw one episode per listed env (the reference's _gen_grid, see mg_gen.h) into `dst`.
+// Work list: either the refill queue filled by k_step, or all envs selected by `mask`.
+// ======================================================================================================
+struct GenArgs {
+  GenParams gp;
+  uint8_t* dst_grid; uint64_t* dst_agent;
+  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state there first
+  const uint32_t* queue; const uint32_t* count;      // queue mode (count read on device)
+  uint32_t* zero_count;                              // the other queue counter, cleared for the next step
+  const uint8_t* mask;                               // direct mode: optional per-env mask
+  uint32_t* err; unsigned long long* counters;
+  int N, CS, GS;
+};
+
+template <class RNG>
+__global__ void __launch_bounds__(64) k_generate(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  if (A.zero_count && blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
+  const int total = A.queue ? (int)*A.count : A.N;
+  uint8_t* mygrid = smem + lane * A.GS;
+  for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+    const int i = base + lane;
+    if (i >= total) continue;
+    const int e = A.queue ? (int)A.queue[i] : i;
+    if (!A.queue && A.mask && !A.mask[e]) continue;
+    RNG rng;
+    rng.load(A.rng, (size_t)A.N, (size_t)e);
+    if (A.rng_snap) rng.store(A.rng_snap, (size_t)A.N, (size_t)e);
+    if constexpr (RNG::kEpisodic) rng.begin_episode();
+    GridRef g{ mygrid, A.gp.W, A.gp.H };
+    for (int k = A.gp.W * A.gp.H; k < A.CS; k++) mygrid[k] = 0;
+    GenResult out;
+    generate_episode(rng, g, A.gp, out);
+    rng.store(A.rng, (size_t)A.N, (size_t)e);
+    if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
+    uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
+    for (int k = 0; k < (A.CS >> 4); k++) {
+      const uint32_t* s = (const uint32_t*)(mygrid + k * 16);
+      dst[k] = make_uint4(s[0], s[1], s[2], s[3]);
+    }
+    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
+    A.dst_agent[e] = agent_pack(ag);
+    atomicAdd(&A.counters[2], 1ull);
+    if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
+  }
+}
+
+// gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)
+template <class RNG>
+__global__ void k_seed(uint64_t* rng, const uint64_t* seeds, const uint8_t* mask, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N || (mask && !mask[e])) return;
+  RNG r;
+  r.seed(seeds[e]);
+  r.store(rng, (size_t)N, (size_t)e);
+}
+
+// mark envs for an explicit reset() that continues their stream (consumes the spare)
+__global__ void k_mark_pending(uint64_t* agent, const uint8_t* mask, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N || (mask && !mask[e])) return;
+  Agent a = agent_unpack(agent[e]);
+  a.flags |= FLAG_RESET_PENDING;
+  agent[e] = agent_pack(a);
+}
+
+}  // namespace mg

@@ -1,0 +1,88 @@
+"""Static config table: env id -> mg_config fields.
+
+These rows restate the reference registry (`minigrid/__init__.py`: e.g. :24-28 LavaCrossingS9N1, :105-109 DoorKey-8x8,
+:182-185 Empty-8x8, :577-580 BabyAI-GoToRedBall) together with the constructor defaults of each env class
+(`envs/empty.py:68-91`, `envs/doorkey.py:62-68`, `envs/crossing.py:89-117`, `envs/babyai/goto.py:129-131`,
+`envs/babyai/core/roomgrid_level.py:77-83` for the per-episode max_steps).  It is the reference's "plugin API"
+(string id -> class + kwargs) reduced to data.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Dict, Tuple
+
+# mirror of include/minigrid_hip.h enums
+ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL = 0, 1, 2, 3
+OBJ_WALL, OBJ_LAVA = 2, 9
+
+
+@dataclass(frozen=True)
+class EnvSpec:
+    id: str
+    env_kind: int
+    width: int
+    height: int
+    max_steps: int
+    see_through_walls: bool
+    missions: Tuple[str, ...]
+    agent_start: Tuple[int, int, int] = (-1, -1, 0)   # (x, y, dir); x < 0 => place_agent()
+    num_crossings: int = 0
+    obstacle_type: int = OBJ_LAVA
+    num_dists: int = 0
+    entry_point: str = ""                              # the reference class this row configures
+    kwargs: dict = field(default_factory=dict)
+
+    def with_max_steps(self, max_steps: int) -> "EnvSpec":
+        return replace(self, max_steps=int(max_steps))
+
+
+def _empty(id_, size, random_start=False):
+    return EnvSpec(id_, ENV_EMPTY, size, size, 4 * size * size, True, ("get to the green goal square",),
+                   agent_start=(-1, -1, 0) if random_start else (1, 1, 0), entry_point="minigrid.envs:EmptyEnv",
+                   kwargs={"size": size, **({"agent_start_pos": None} if random_start else {})})
+
+
+def _doorkey(id_, size):
+    return EnvSpec(id_, ENV_DOORKEY, size, size, 10 * size * size, False,
+                   ("use the key to open the door and then get to the goal",),
+                   entry_point="minigrid.envs:DoorKeyEnv", kwargs={"size": size})
+
+
+def _crossing(id_, size, n, lava=True):
+    return EnvSpec(id_, ENV_CROSSING, size, size, 4 * size * size, False,
+                   ("avoid the lava and get to the green goal square" if lava
+                    else "find the opening and get to the green goal square",),
+                   num_crossings=n, obstacle_type=OBJ_LAVA if lava else OBJ_WALL,
+                   entry_point="minigrid.envs:CrossingEnv",
+                   kwargs={"size": size, "num_crossings": n, **({} if lava else {"obstacle_type": "wall"})})
+
+
+def _goto_red_ball(id_, num_dists):
+    # room_size 8, 1x1 rooms => 8x8 grid; max_steps = num_navs(1) * room_size**2 * rows * cols = 64
+    return EnvSpec(id_, ENV_GOTO_REDBALL, 8, 8, 64, False, ("go to the red ball", "go to a red ball"),
+                   num_dists=num_dists, entry_point="minigrid.envs.babyai:GoToRedBall",
+                   kwargs={} if num_dists == 7 else {"num_dists": num_dists})
+
+
+_ROWS = [
+    _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
+    _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
+    _empty("MiniGrid-Empty-8x8-v0", 8), _empty("MiniGrid-Empty-16x16-v0", 16),
+    _doorkey("MiniGrid-DoorKey-5x5-v0", 5), _doorkey("MiniGrid-DoorKey-6x6-v0", 6),
+    _doorkey("MiniGrid-DoorKey-8x8-v0", 8), _doorkey("MiniGrid-DoorKey-16x16-v0", 16),
+    _crossing("MiniGrid-LavaCrossingS9N1-v0", 9, 1), _crossing("MiniGrid-LavaCrossingS9N2-v0", 9, 2),
+    _crossing("MiniGrid-LavaCrossingS9N3-v0", 9, 3), _crossing("MiniGrid-LavaCrossingS11N5-v0", 11, 5),
+    _crossing("MiniGrid-SimpleCrossingS9N1-v0", 9, 1, False), _crossing("MiniGrid-SimpleCrossingS9N2-v0", 9, 2, False),
+    _crossing("MiniGrid-SimpleCrossingS9N3-v0", 9, 3, False), _crossing("MiniGrid-SimpleCrossingS11N5-v0", 11, 5, False),
+    _goto_red_ball("BabyAI-GoToRedBall-v0", 7), _goto_red_ball("BabyAI-GoToRedBallNoDists-v0", 0),
+]
+
+registry: Dict[str, EnvSpec] = {r.id: r for r in _ROWS}
+
+
+def spec(env_id: str) -> EnvSpec:
+    try:
+        return registry[env_id]
+    except KeyError:
+        raise KeyError(
+            f"{env_id!r} is not on the accelerated path. Supported ids: {sorted(registry)}") from None

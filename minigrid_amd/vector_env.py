@@ -1,0 +1,290 @@
+"""MiniGridVecEnv — N lockstep MiniGrid environments on one MI355X behind the Gymnasium VectorEnv surface.
+
+Mirrors, for a batch, what the reference exposes per env:
+  * `MiniGridEnv.reset(*, seed, options)` / `step(action)` (minigrid/minigrid_env.py:119-157, 525-595),
+  * observation dict {image (7,7,3) u8, direction, mission} (minigrid_env.py:72-84, 634-650),
+  * `ImgObsWrapper` (wrappers.py:187-214) and `FullyObsWrapper` (wrappers.py:383-426) semantics
+    (see minigrid_amd/wrappers.py),
+  * errors: unknown action -> ValueError (minigrid_env.py:584-585).
+Batch semantics follow gymnasium.vector.VectorEnv (>= 1.0): `reset(seed=int)` seeds env i with seed+i, NEXT_STEP
+autoreset by default, rewards float64, terminations/truncations bool, `infos == {}`.
+
+All compute happens in libminigrid_hip.so (HIP, gfx950).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Optional, Sequence
+
+import numpy as np
+
+from . import _binding as B
+from . import spaces
+from .registry import EnvSpec, spec as _spec
+
+try:  # subclass the real thing when it exists so isinstance checks pass
+    from gymnasium.vector import VectorEnv as _VectorEnvBase  # type: ignore
+except Exception:
+    class _VectorEnvBase:  # type: ignore
+        pass
+
+_AUTORESET = {"next_step": B.AUTORESET_NEXT_STEP, "disabled": B.AUTORESET_DISABLED}
+_RNG = {"pcg64": B.RNG_PCG64, "philox": B.RNG_PHILOX}
+
+
+class _DeviceArray:
+    """Zero-copy view of a library-owned device buffer (`__cuda_array_interface__` v3; torch.as_tensor accepts it)."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+        self._owner = owner  # keep the env alive
+
+
+class MiniGridVecEnv(_VectorEnvBase):
+    metadata = {"render_modes": [], "autoreset_mode": "next_step"}
+
+    def __init__(self, env_id: str, num_envs: int, *, obs_mode: str = "partial", device: Optional[int] = None,
+                 autoreset_mode: str = "next_step", rng: str = "pcg64", env_index_base: int = 0,
+                 max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
+                 image_only: bool = False):
+        if obs_mode not in ("partial", "full"):
+            raise ValueError("obs_mode must be 'partial' or 'full'")
+        if output not in ("numpy", "torch"):
+            raise ValueError("output must be 'numpy' or 'torch'")
+        s: EnvSpec = _spec(env_id)
+        if max_steps is not None:
+            if not isinstance(max_steps, int):
+                raise AssertionError(f"The argument max_steps must be an integer, got: {type(max_steps)}")  # minigrid_env.py:102-104
+            s = s.with_max_steps(max_steps)
+        self.spec_row = s
+        self.env_id = env_id
+        self.num_envs = int(num_envs)
+        self.obs_mode = obs_mode
+        self.output = output
+        self.image_only = bool(image_only)
+        self.env_index_base = int(env_index_base)
+        self.metadata = dict(type(self).metadata, autoreset_mode=autoreset_mode)
+        self._lib = B.load()
+        if self._lib.mg_device_count() < 1:
+            raise B.MiniGridHipError("no HIP device visible: minigrid_amd has no CPU fallback (MI355X/gfx950 required)")
+        cfg = B.MgConfig(
+            abi_version=B.MG_ABI_VERSION, env_kind=s.env_kind, width=s.width, height=s.height, max_steps=s.max_steps,
+            see_through_walls=int(s.see_through_walls), agent_view_size=7,
+            obs_mode=B.OBS_FULL if obs_mode == "full" else B.OBS_PARTIAL, autoreset_mode=_AUTORESET[autoreset_mode],
+            rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
+            agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
+            num_dists=s.num_dists, env_index_base=self.env_index_base)
+        self._cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.mg_create(C.byref(cfg), -1 if device is None else int(device), stream, C.byref(h))
+        B.check(rc, None)
+        self._h = h
+        outs = B.MgOutputs()
+        B.check(self._lib.mg_get_outputs(self._h, C.byref(outs)), self._h)
+        self._outs = outs
+        self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
+        self.image_shape = (s.width, s.height, 3) if obs_mode == "full" else (7, 7, 3)
+        self._missions = np.asarray(s.missions)
+        self._seeded = False
+        # spaces (minigrid_env.py:63, 72-84; FullyObsWrapper wrappers.py:404-417; ImgObsWrapper :211)
+        img = spaces.Box(0, 255, self.image_shape, np.uint8)
+        self.single_action_space = spaces.Discrete(7)
+        if image_only:
+            self.single_observation_space = img
+            self.observation_space = spaces.Box(0, 255, (self.num_envs,) + self.image_shape, np.uint8)
+        else:
+            self.single_observation_space = spaces.Dict({"image": img, "direction": spaces.Discrete(4),
+                                                         "mission": spaces.MissionSpace(s.missions)})
+            self.observation_space = spaces.Dict({
+                "image": spaces.Box(0, 255, (self.num_envs,) + self.image_shape, np.uint8),
+                "direction": spaces.MultiDiscrete([4] * self.num_envs),
+                "mission": spaces.MissionSpace(s.missions)})
+        self.action_space = spaces.MultiDiscrete([7] * self.num_envs)
+        # host staging (numpy output mode)
+        n = self.num_envs
+        self._h_obs = np.empty((n,) + self.image_shape, np.uint8)
+        self._h_rew = np.empty(n, np.float64)
+        self._h_term = np.empty(n, np.uint8)
+        self._h_trunc = np.empty(n, np.uint8)
+        self._h_dir = np.empty(n, np.uint8)
+        self._h_mis = np.empty(n, np.uint8)
+        self._torch_views = None
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def _p(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def device_outputs(self) -> dict:
+        """Zero-copy device views of the output buffers (valid until close(); rewritten by every step/reset)."""
+        n, o = self.num_envs, self._outs
+        return {"image": _DeviceArray(o.obs, (n,) + self.image_shape, "|u1", self),
+                "reward": _DeviceArray(o.reward, (n,), "<f8", self),
+                "terminated": _DeviceArray(o.terminated, (n,), "|u1", self),
+                "truncated": _DeviceArray(o.truncated, (n,), "|u1", self),
+                "direction": _DeviceArray(o.direction, (n,), "|u1", self),
+                "mission_id": _DeviceArray(o.mission_id, (n,), "|u1", self)}
+
+    def torch_outputs(self) -> dict:
+        """The same buffers as torch CUDA tensors (no copy)."""
+        if self._torch_views is None:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._torch_views = {k: torch.as_tensor(v, device=dev) for k, v in self.device_outputs().items()}
+        return self._torch_views
+
+    def sync(self):
+        B.check(self._lib.mg_sync(self._h), self._h)
+
+    def _collect(self):
+        if self.output == "torch":
+            t = self.torch_outputs()
+            image = t["image"]
+            if self.image_only:
+                obs = image
+            else:
+                obs = {"image": image, "direction": t["direction"], "mission_id": t["mission_id"]}
+            return obs, t["reward"], t["terminated"].bool(), t["truncated"].bool()
+        rc = self._lib.mg_copy_outputs(self._h, self._p(self._h_obs), self._p(self._h_rew), self._p(self._h_term),
+                                       self._p(self._h_trunc), self._p(self._h_dir), self._p(self._h_mis))
+        B.check(rc, self._h)
+        image = self._h_obs.copy()
+        if self.image_only:
+            obs = image
+        else:
+            obs = {"image": image, "direction": self._h_dir.astype(np.int64),
+                   "mission": self._missions[self._h_mis]}
+        return obs, self._h_rew.copy(), self._h_term.astype(bool), self._h_trunc.astype(bool)
+
+    # ------------------------------------------------------------------ Gymnasium VectorEnv surface
+    def reset(self, *, seed: Any = None, options: Optional[dict] = None):
+        n = self.num_envs
+        mask = None
+        if options and options.get("reset_mask") is not None:
+            mask = np.ascontiguousarray(options["reset_mask"], dtype=np.uint8)
+            if mask.shape != (n,):
+                raise ValueError("options['reset_mask'] must have shape (num_envs,)")
+        seeds = None
+        if seed is None:
+            if not self._seeded:      # like a never-seeded gymnasium env: fresh OS entropy per env
+                seeds = np.random.SeedSequence().generate_state(n, np.uint64)
+        elif isinstance(seed, (int, np.integer)):
+            if seed < 0:
+                raise ValueError(f"Seed must be a non-negative integer, got {seed}")
+            seeds = (np.uint64(seed) + np.uint64(self.env_index_base) + np.arange(n, dtype=np.uint64))
+        else:
+            seq = list(seed)
+            if len(seq) != n:
+                raise ValueError("seed list must have one entry per env")
+            if any(s is None for s in seq):
+                m2 = np.array([s is not None for s in seq], np.uint8)
+                if mask is not None:
+                    m2 &= mask
+                # envs with seed None continue their stream; reseed the others in a second call
+                none_mask = np.array([s is None for s in seq], np.uint8) if mask is None else (np.array([s is None for s in seq], np.uint8) & mask)
+                if none_mask.any():
+                    B.check(self._lib.mg_reset(self._h, None, self._p(none_mask)), self._h)
+                mask = m2
+                seq = [0 if s is None else s for s in seq]
+            seeds = np.asarray(seq, dtype=np.uint64)
+        self._seeded = True
+        rc = self._lib.mg_reset(self._h, None if seeds is None else self._p(np.ascontiguousarray(seeds)),
+                                None if mask is None else self._p(mask))
+        B.check(rc, self._h)
+        obs, _, _, _ = self._collect()
+        return obs, {}
+
+    def step(self, actions):
+        if self.output == "torch" and hasattr(actions, "data_ptr"):
+            a = actions
+            if a.dtype not in _TORCH_ACT or a.numel() != self.num_envs or not a.is_contiguous():
+                raise ValueError("actions tensor must be contiguous uint8/int32/int64 of length num_envs")
+            rc = self._lib.mg_step(self._h, C.c_void_p(a.data_ptr()), _TORCH_ACT[a.dtype], 1 if a.is_cuda else 0)
+        else:
+            a = np.asarray(actions)
+            if a.shape != (self.num_envs,):
+                raise ValueError(f"actions must have shape ({self.num_envs},), got {a.shape}")
+            if a.dtype == np.uint8:
+                dt = B.ACT_U8
+            elif a.dtype == np.int32:
+                dt = B.ACT_I32
+            else:
+                a = a.astype(np.int64, copy=False)
+                dt = B.ACT_I64
+            a = np.ascontiguousarray(a)
+            rc = self._lib.mg_step(self._h, self._p(a), dt, 0)
+        B.check(rc, self._h)
+        obs, rew, term, trunc = self._collect()
+        return obs, rew, term, trunc, {}
+
+    def rollout(self, steps: int, action_seed: int = 0, fused: bool = False):
+        """`steps` lockstep steps under a uniform-random policy generated on the device (benchmark loop)."""
+        B.check(self._lib.mg_rollout(self._h, int(steps), int(action_seed), int(fused)), self._h)
+
+    def close(self, **kwargs):
+        if getattr(self, "_h", None):
+            self._lib.mg_destroy(self._h)
+            self._h = None
+            self._torch_views = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state exchange (checkpoint / parity harness)
+    def get_state(self):
+        grid = np.empty((self.num_envs, self.width, self.height, 3), np.uint8)
+        agent = np.empty((self.num_envs, 8), np.int32)
+        B.check(self._lib.mg_get_state(self._h, self._p(grid), self._p(agent)), self._h)
+        return grid, agent
+
+    def set_state(self, grid, agent):
+        grid = np.ascontiguousarray(grid, np.uint8)
+        agent = np.ascontiguousarray(agent, np.int32)
+        if grid.shape != (self.num_envs, self.width, self.height, 3) or agent.shape != (self.num_envs, 8):
+            raise ValueError("bad state shapes")
+        B.check(self._lib.mg_set_state(self._h, self._p(grid), self._p(agent)), self._h)
+
+    def get_rng_state(self):
+        r = np.empty((self.num_envs, 5), np.uint64)
+        B.check(self._lib.mg_get_rng(self._h, self._p(r)), self._h)
+        return r
+
+    def set_rng_state(self, r):
+        r = np.ascontiguousarray(r, np.uint64)
+        B.check(self._lib.mg_set_rng(self._h, self._p(r)), self._h)
+
+    def counters(self) -> dict:
+        c = np.zeros(4, np.uint64)
+        B.check(self._lib.mg_get_counters(self._h, self._p(c)), self._h)
+        return {"env_steps": int(c[0]), "episodes": int(c[1]), "maps_generated": int(c[2]), "generator_retries": int(c[3])}
+
+    def timer_start(self):
+        B.check(self._lib.mg_timer_start(self._h), self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        B.check(self._lib.mg_timer_stop(self._h, C.byref(ms)), self._h)
+        return float(ms.value)
+
+
+try:
+    import torch as _torch
+    _TORCH_ACT = {_torch.uint8: B.ACT_U8, _torch.int32: B.ACT_I32, _torch.int64: B.ACT_I64}
+except Exception:  # pragma: no cover
+    _TORCH_ACT = {}
+
+
+def make_vec(env_id: str, num_envs: int, **kwargs) -> MiniGridVecEnv:
+    """`gymnasium.make_vec(id, num_envs)` for the accelerated ids (minigrid/__init__.py registry rows)."""
+    return MiniGridVecEnv(env_id, num_envs, **kwargs)

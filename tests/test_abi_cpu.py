@@ -1,0 +1,120 @@
+"""CPU-side checks of the product library: it builds, loads, exports the whole C ABI, its host-callable inline
+helpers are exact, and the product never falls back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from minigrid_amd import _binding as B
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    L = B.load()
+    header = open(os.path.join(ROOT, "include", "minigrid_hip.h")).read()
+    declared = set(re.findall(r"MG_API\s+(?:const char\*|int)\s+(mg_\w+)\s*\(", header))
+    assert declared == set(B.SYMBOLS), declared ^ set(B.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mg_abi_version() == B.MG_ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    # 17 int32 + 7 reserved int32 + one int64 = 104 bytes, int64 8-aligned at offset 96
+    assert C.sizeof(B.MgConfig) == 104
+    assert B.MgConfig.env_index_base.offset == 96
+    assert C.sizeof(B.MgOutputs) == 64
+
+
+def _vis_row_literal(m, t):
+    """core/grid.py:296-321 for one row j > 0: returns (row mask after both sweeps, bits set in row j-1)."""
+    mask = [(m >> i) & 1 for i in range(7)]
+    up = [0] * 7
+    for i in range(0, 6):
+        if not mask[i]:
+            continue
+        if not (t >> i) & 1:
+            continue
+        mask[i + 1] = 1
+        up[i + 1] = 1
+        up[i] = 1
+    for i in reversed(range(1, 7)):
+        if not mask[i]:
+            continue
+        if not (t >> i) & 1:
+            continue
+        mask[i - 1] = 1
+        up[i - 1] = 1
+        up[i] = 1
+    return sum(b << i for i, b in enumerate(mask)), sum(b << i for i, b in enumerate(up))
+
+
+def test_vis_row_bit_parallel_equals_reference_loops_exhaustively():
+    L = B.load()
+    mo, uo = C.c_uint32(), C.c_uint32()
+    for m in range(128):
+        for t in range(128):
+            assert L.mg_selftest_vis_row(m, t, C.byref(mo), C.byref(uo)) == 0
+            assert (mo.value, uo.value) == _vis_row_literal(m, t), (m, t)
+
+
+@pytest.mark.parametrize("T", [64, 100, 256, 324, 484, 640, 2560, 65535])
+def test_reward_lut_is_bit_exact_python_float_arithmetic(T):
+    L = B.load()
+    out = np.zeros(T + 1, np.float64)
+    assert L.mg_selftest_reward_lut(T, out.ctypes.data_as(C.c_void_p)) == 0
+    want = np.array([1 - 0.9 * (t / T) for t in range(T + 1)], np.float64)
+    assert out.tobytes() == want.tobytes()
+
+
+def test_cell_code_roundtrip_matches_worldobj_decode_encode():
+    """cell_from_triple/cell_triple == WorldObj.decode(...).encode() (core/world_object.py:65-102,196-212)."""
+    L = B.load()
+    code, tri = C.c_uint32(), C.c_uint32()
+    for t in range(11):
+        for c in range(6):
+            for s in range(3):
+                L.mg_selftest_pack_cell(t, c, s, C.byref(code), C.byref(tri))
+                got = (tri.value & 255, (tri.value >> 8) & 255, tri.value >> 16)
+                if t in (0, 1, 10):
+                    want = (1, 0, 0)              # decode -> None -> Grid.encode writes (1,0,0)
+                elif t == 8:
+                    want = (8, 1, 0)              # Goal() is green
+                elif t == 9:
+                    want = (9, 0, 0)              # Lava() is red
+                elif t == 4:
+                    want = (4, c, s)
+                else:
+                    want = (t, c, 0)
+                assert got == want, (t, c, s, got)
+                assert code.value < 256
+
+
+def test_no_cpu_fallback_without_gpu():
+    import minigrid_amd as mg
+    if B.load().mg_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(B.MiniGridHipError):
+        mg.make_vec("MiniGrid-Empty-8x8-v0", 8)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "minigrid_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_registry_rows_match_oracle_table():
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    for env_id, row in mg.registry.items():
+        o = O.spec(env_id)
+        assert (row.env_kind, row.width, row.height, row.max_steps, int(row.see_through_walls)) == \
+               (o["kind"], o["width"], o["height"], o["max_steps"], o["see_through"]), env_id
+        assert list(row.missions) == o["missions"]
+        assert row.num_crossings == o.get("num_crossings", 0) and row.num_dists == o.get("num_dists", 0)

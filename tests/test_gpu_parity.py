@@ -1,0 +1,262 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI, against
+ (a) the golden vectors produced by the unmodified reference (tests/golden/), and
+ (b) the CPU oracle on the same seeds/actions at sizes up to BASELINE.json's full configs.
+Everything is bit-exact (u8 obs, f64 reward compared by bytes, flags)."""
+import numpy as np
+import pytest
+
+from conftest import ALL_IDS, MAIN_IDS, golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(env_id, n, **kw):
+    import minigrid_amd as mg
+    return mg.make_vec(env_id, n, **kw)
+
+
+def _assert_native_loaded():
+    maps = open("/proc/self/maps").read()
+    assert "libminigrid_hip.so" in maps, "HIP extension not loaded"
+
+
+@pytest.mark.parametrize("env_id", ALL_IDS)
+def test_generators_match_reference_goldens(env_id):
+    g = golden(f"gen_{env_id}.npz")
+    n, episodes = g["grid"].shape[:2]
+    env = _mk(env_id, n)
+    _assert_native_loaded()
+    for ep in range(episodes):
+        obs, info = env.reset(seed=list(range(n))) if ep == 0 else env.reset()
+        assert info == {}
+        grid, agent = env.get_state()
+        assert (grid == g["grid"][:, ep]).all(), (env_id, ep)
+        assert (agent[:, :6] == g["agent"][:, ep, :6]).all(), (env_id, ep)
+        assert (env._missions[g["mission"][:, ep]] == obs["mission"]).all()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ALL_IDS)
+@pytest.mark.parametrize("mode", ["random", "solver"])
+@pytest.mark.parametrize("full", [False, True])
+def test_rollouts_match_reference_goldens(env_id, mode, full):
+    g = golden(f"rollout_{env_id}.npz")
+    acts = g[f"{mode}_actions"]
+    S, T = acts.shape
+    want_obs = g[f"{mode}_full"] if full else g[f"{mode}_obs"]
+    env = _mk(env_id, S, obs_mode="full" if full else "partial")
+    assert env.max_steps == int(g["max_steps"])
+    obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
+    assert obs["image"].dtype == np.uint8 and (obs["image"] == want_obs[:, 0]).all()
+    assert (obs["direction"] == g[f"{mode}_dir"][:, 0]).all()
+    for t in range(T):
+        obs, rew, term, trunc, info = env.step(acts[:, t])
+        assert (obs["image"] == want_obs[:, t + 1]).all(), (env_id, t)
+        assert rew.dtype == np.float64 and rew.tobytes() == g[f"{mode}_reward"][:, t].tobytes(), (env_id, t)
+        assert term.dtype == bool and (term == g[f"{mode}_term"][:, t]).all(), (env_id, t)
+        assert (trunc == g[f"{mode}_trunc"][:, t]).all(), (env_id, t)
+        assert obs["direction"].dtype == np.int64 and (obs["direction"] == g[f"{mode}_dir"][:, t + 1]).all()
+        assert (obs["mission"] == env._missions[g[f"{mode}_mission"][:, t + 1]]).all()
+        assert info == {}
+        if t % 16 == 0 or t == T - 1:
+            _, agent = env.get_state()
+            assert (agent[:, :7] == g[f"{mode}_agent"][:, t + 1, :7]).all(), (env_id, t)
+    env.close()
+
+
+def _compare_with_oracle(env_id, n, T, full, seed0=0, action_seed=0, probs=None, autoreset="next_step"):
+    from oracle import oracle as O
+    env = _mk(env_id, n, obs_mode="full" if full else "partial", autoreset_mode=autoreset)
+    orc = O.OracleVec(env_id, n, full_obs=full)
+    seeds = np.arange(seed0, seed0 + n, dtype=np.uint64)
+    obs, _ = env.reset(seed=int(seed0))
+    o_obs, o_dir, o_mis = orc.reset(seeds=seeds)
+    assert (obs["image"] == o_obs).all() and (obs["direction"] == o_dir).all()
+    rng = np.random.default_rng(action_seed)
+    nterm = ntrunc = 0
+    for t in range(T):
+        a = rng.choice(7, size=n, p=probs).astype(np.uint8) if probs is not None else rng.integers(0, 7, n, dtype=np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=1 if autoreset == "next_step" else 0)
+        assert (obs["image"] == oo).all(), (env_id, t, np.argwhere((obs["image"] != oo).reshape(n, -1).any(1))[:5])
+        assert rew.tobytes() == orew.tobytes(), (env_id, t)
+        assert (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (obs["direction"] == od).all() and (obs["mission"] == env._missions[om]).all(), (env_id, t)
+        nterm += int(term.sum()); ntrunc += int(trunc.sum())
+    g1, a1 = env.get_state()
+    g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+    return nterm, ntrunc
+
+
+@pytest.mark.parametrize("env_id", MAIN_IDS)
+@pytest.mark.parametrize("full", [False, True])
+def test_vs_oracle_4096_envs_multi_episode(env_id, full):
+    # forward-heavy policy so that goals / lava / red balls are actually reached many times
+    nterm, ntrunc = _compare_with_oracle(env_id, 4096, 300, full, seed0=1000,
+                                         probs=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05])
+    assert nterm > 50
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 257, 1000])
+def test_ragged_batch_sizes(n):
+    _compare_with_oracle("MiniGrid-DoorKey-8x8-v0", n, 60, False, seed0=7)
+    _compare_with_oracle("MiniGrid-LavaCrossingS9N1-v0", n, 60, True, seed0=7)
+
+
+def test_full_size_config2_empty8x8_65536_envs():
+    """BASELINE.json configs[1] at full size, every env, every step, bit-exact against the oracle."""
+    nterm, ntrunc = _compare_with_oracle("MiniGrid-Empty-8x8-v0", 65536, 300, False)
+    assert ntrunc > 30000 and nterm > 1000      # the synchronized truncation burst at step 256 is inside the window
+
+
+def test_full_size_config3_doorkey8x8_262144_envs():
+    _compare_with_oracle("MiniGrid-DoorKey-8x8-v0", 262144, 40, False)
+
+
+def test_full_size_config4_shard_lavacrossing_fullobs_131072_envs():
+    """configs[3] per-GPU shard: 1 048 576 / 8 = 131 072 envs, FullyObsWrapper encode."""
+    _compare_with_oracle("MiniGrid-LavaCrossingS9N1-v0", 131072, 60, True)
+
+
+def test_full_size_config5_shard_gotoredball_32768_envs():
+    nterm, _ = _compare_with_oracle("BabyAI-GoToRedBall-v0", 32768, 150, False)
+    assert nterm > 1000
+
+
+def test_autoreset_disabled_steps_past_max_steps_like_the_reference():
+    # reward formula beyond max_steps (exact device f64 ops) and no implicit resets
+    _compare_with_oracle("BabyAI-GoToRedBall-v0", 512, 200, False, autoreset="disabled")
+    _compare_with_oracle("MiniGrid-Empty-5x5-v0", 512, 250, False, autoreset="disabled")
+
+
+def test_max_steps_truncation_kat():
+    # reference tests/test_envs.py:160-177: max_steps=50, action 4 (drop) forever -> truncated exactly at step 50
+    env = _mk("MiniGrid-Empty-8x8-v0", 5, max_steps=50)
+    env.reset(seed=0)
+    for t in range(1, 51):
+        _, rew, term, trunc, _ = env.step(np.full(5, 4))
+        assert (trunc == (t >= 50)).all() and not term.any() and (rew == 0).all()
+    env.close()
+
+
+def test_unknown_action_raises_value_error():
+    env = _mk("MiniGrid-Empty-8x8-v0", 8)
+    env.reset(seed=0)
+    with pytest.raises(ValueError):
+        env.step(np.array([0, 1, 2, 3, 7, 5, 6, 0]))
+    env.close()
+
+
+def test_reference_doctest_lava_seed2():
+    # minigrid/wrappers.py:819-823
+    env = _mk("MiniGrid-LavaCrossingS9N1-v0", 1)
+    env.reset(seed=2)
+    env.step([1])
+    _, r, term, trunc, _ = env.step([2])
+    assert r[0] == 0.0 and term[0] and not trunc[0]
+    env.close()
+
+
+def test_seed_int_means_seed_plus_index_and_is_shard_invariant():
+    a = _mk("MiniGrid-DoorKey-8x8-v0", 64)
+    b = _mk("MiniGrid-DoorKey-8x8-v0", 32, env_index_base=32)
+    oa, _ = a.reset(seed=5)
+    ob, _ = b.reset(seed=5)
+    assert (oa["image"][32:] == ob["image"]).all()
+    ga, _ = a.get_state()
+    c = _mk("MiniGrid-DoorKey-8x8-v0", 64)
+    c.reset(seed=[5 + i for i in range(64)])
+    gc, _ = c.get_state()
+    assert (ga == gc).all()
+    for e in (a, b, c):
+        e.close()
+
+
+def test_reset_mask_and_stream_continuation():
+    from oracle import oracle as O
+    n = 100
+    env = _mk("BabyAI-GoToRedBall-v0", n)
+    orc = O.OracleVec("BabyAI-GoToRedBall-v0", n)
+    env.reset(seed=3)
+    orc.reset(seeds=np.arange(3, 3 + n, dtype=np.uint64))
+    mask = (np.arange(n) % 3 == 0)
+    for _ in range(3):
+        obs, _ = env.reset(options={"reset_mask": mask})
+        orc.reset(mask=mask)
+        g1, a1 = env.get_state()
+        g2, a2 = orc.get_state()
+        assert (g1 == g2).all() and (a1[:, :6] == a2[:, :6]).all()
+    env.close()
+
+
+def test_state_and_rng_checkpoint_roundtrip():
+    env = _mk("MiniGrid-LavaCrossingS9N1-v0", 300)
+    env.reset(seed=11)
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        env.step(rng.integers(0, 7, 300))
+    grid, agent = env.get_state()
+    rs = env.get_rng_state()
+    twin = _mk("MiniGrid-LavaCrossingS9N1-v0", 300)
+    twin.set_state(grid, agent)
+    twin.set_rng_state(rs)
+    for _ in range(200):
+        a = rng.integers(0, 7, 300)
+        o1 = env.step(a)
+        o2 = twin.step(a)
+        assert (o1[0]["image"] == o2[0]["image"]).all() and o1[1].tobytes() == o2[1].tobytes()
+        assert (o1[2] == o2[2]).all() and (o1[3] == o2[3]).all()
+    env.close(); twin.close()
+
+
+def test_img_and_fully_obs_wrappers():
+    import minigrid_amd as mg
+    env = mg.ImgObsWrapper(_mk("MiniGrid-Empty-8x8-v0", 16))
+    obs, _ = env.reset(seed=0)
+    assert isinstance(obs, np.ndarray) and obs.shape == (16, 7, 7, 3) and obs.dtype == np.uint8
+    assert env.single_observation_space.shape == (7, 7, 3)
+    env.close()
+    env = mg.FullyObsWrapper(_mk("MiniGrid-LavaCrossingS9N1-v0", 16))
+    obs, _ = env.reset(seed=0)
+    assert obs["image"].shape == (16, 9, 9, 3) and set(obs) == {"image", "direction", "mission"}
+    assert (obs["image"][:, 1, 1] == np.array([10, 0, 0])).all()      # agent cell (wrappers.py:422-424)
+    env.close()
+
+
+def test_philox_mode_generates_valid_deterministic_maps():
+    a = _mk("MiniGrid-DoorKey-8x8-v0", 2048, rng="philox")
+    b = _mk("MiniGrid-DoorKey-8x8-v0", 2048, rng="philox")
+    a.reset(seed=9); b.reset(seed=9)
+    g, ag = a.get_state()
+    g2, _ = b.get_state()
+    assert (g == g2).all()
+    t = g[..., 0]
+    assert ((t == 4).sum(axis=(1, 2)) == 1).all() and ((t == 5).sum(axis=(1, 2)) == 1).all()
+    assert (g[:, 6, 6, 0] == 8).all()
+    doors = np.argwhere(t == 4)
+    keys = np.argwhere(t == 5)
+    assert (keys[:, 1] < doors[:, 1]).all() and (ag[:, 0] < doors[:, 1]).all()   # key and agent left of the wall
+    assert len({tuple(x) for x in doors[:, 1:]}) > 10                            # actually random
+    # distribution of the split column is uniform over {2..5} (doorkey.py:84)
+    counts = np.bincount(doors[:, 1], minlength=6)[2:6]
+    assert counts.min() > 2048 / 4 * 0.8
+    a.close(); b.close()
+
+
+def test_device_rollout_counts_and_torch_views():
+    import torch
+    env = _mk("MiniGrid-Empty-8x8-v0", 4096, output="torch")
+    env.reset(seed=0)
+    env.rollout(300, action_seed=1)
+    env.sync()
+    c = env.counters()
+    assert c["env_steps"] == 4096 * 300 and c["episodes"] >= 4096
+    t = env.torch_outputs()
+    assert t["image"].is_cuda and tuple(t["image"].shape) == (4096, 7, 7, 3) and t["image"].dtype == torch.uint8
+    obs, rew, term, trunc, _ = env.step(torch.zeros(4096, dtype=torch.int64, device="cuda"))
+    env.sync()
+    assert obs["image"].data_ptr() == t["image"].data_ptr() and rew.dtype == torch.float64
+    env.close()
