@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the MI355X-native MiniGrid hot path under a uniform-random policy.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one lockstep pass of MiniGridEnv.step()+gen_obs() over the whole batch (BASELINE.json configs[1]:
+MiniGrid-Empty-8x8-v0, 65 536 envs per GPU, 7x7x3 partial obs), actions drawn on the device (Philox4x32-10), every
+step writing its full outputs (obs u8 (N,7,7,3), reward f64, terminated, truncated, direction, mission id) to HBM,
+NEXT_STEP autoreset inside the timed region.  Env state and all buffers are resident in HBM before timing starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel (k_step): ALGORITHMIC bytes per launch (324 B/env-step partial obs,
+                 W*H*3*2+30 for FullyObs) / average launch period measured with HIP events on the launch stream.
+  cpu_baseline — the oracle's C port (oracle/minigrid_oracle.c) timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (env id, envs per GPU, obs mode)
+    "empty8x8": ("MiniGrid-Empty-8x8-v0", 65536, "partial"),            # BASELINE.json configs[1]  (headline)
+    "doorkey8x8": ("MiniGrid-DoorKey-8x8-v0", 262144, "partial"),       # configs[2]
+    "lavacrossing_full": ("MiniGrid-LavaCrossingS9N1-v0", 131072, "full"),  # configs[3], per-GPU shard of 1 048 576
+    "gotoredball": ("BabyAI-GoToRedBall-v0", 32768, "partial"),         # configs[4], per-GPU shard of 262 144
+}
+
+
+def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int) -> int:
+    """action 1 + grid read (49 view cells or W*H cells) x 3 B + agent record r/w 8+8 +
+    cell write-back 3 + image out + reward 8 + terminated 1 + truncated 1 (+ direction 1 + mission id 1 for BabyAI)."""
+    cells = W * H if obs_mode == "full" else 49
+    b = 1 + cells * 3 + 8 + 8 + 3 + cells * 3 + 8 + 1 + 1
+    if env_id.startswith("BabyAI"):
+        b += 2
+    return b
+
+
+def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 12.0):
+    """Time the oracle's C port on all host cores (one independent batch per thread; ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    n_per = 1024
+    vecs = [O.OracleVec(env_id, n_per, full_obs=(obs_mode == "full")) for _ in range(cores)]
+    for i, v in enumerate(vecs):
+        v.reset(seeds=range(i * n_per, (i + 1) * n_per))
+    t0 = time.perf_counter()
+    vecs[0].rollout(50, 1)                       # calibration on one core
+    per_step = (time.perf_counter() - t0) / 50
+    T = max(50, int(budget_s / max(per_step, 1e-6)))
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda v: v.rollout(T, 7), vecs))
+        dt = time.perf_counter() - t0
+    return {"value": cores * n_per * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} obs), oracle C port, "
+                      f"xorshift random actions, NEXT_STEP autoreset, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--workload", default="empty8x8", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=0, help="use the fused multi-step rollout kernel")
+    ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import minigrid_amd as mg
+
+    env_id, n_per_gpu, obs_mode = WORKLOADS[args.workload]
+    if args.envs_per_gpu:
+        n_per_gpu = args.envs_per_gpu
+    env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, env_index_base=rank * n_per_gpu,
+                      output="torch")
+    env.reset(seed=0)
+    env.sync()
+
+    gathered = None
+    if args.gather_obs and world > 1:
+        img = env.torch_outputs()["image"]
+        gathered = torch.empty((world,) + tuple(img.shape), dtype=img.dtype, device=img.device)
+
+    def run(k, seed):
+        if gathered is None:
+            env.rollout(k, action_seed=seed, fused=bool(args.fused))
+        else:
+            img = env.torch_outputs()["image"]
+            for _ in range(k):
+                env.rollout(1, action_seed=seed)
+                env.sync()
+                dist.all_gather_into_tensor(gathered, img)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, 1)
+    env.sync()
+    barrier()
+    env.timer_start()
+    t0 = time.perf_counter()
+    run(args.steps, 2)
+    env.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = env.timer_stop()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    counters = env.counters()
+
+    if rank == 0:
+        total_envs = n_per_gpu * world
+        value = total_envs * args.steps / dt
+        bpe = algorithmic_bytes_per_env_step(env_id, obs_mode, env.width, env.height)
+        launch_s = (ev_ms / 1e3) / args.steps           # average k_step launch period on its stream (HIP events)
+        achieved = n_per_gpu * bpe / launch_s / 1e9
+        out = {
+            "metric": "env-steps/s (random policy)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
+                                   f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
+                       "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
+                       "launch": "fused-rollout" if args.fused else "one k_step launch per step",
+                       "gather_obs": bool(gathered is not None), "episodes_finished_rank0": counters["episodes"]},
+            "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(env_id, obs_mode)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

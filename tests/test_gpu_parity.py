@@ -85,7 +85,8 @@ def _compare_with_oracle(env_id, n, T, full, seed0=0, action_seed=0, probs=None,
         nterm += int(term.sum()); ntrunc += int(trunc.sum())
     g1, a1 = env.get_state()
     g2, a2 = orc.get_state()
-    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    ncmp = 7 if autoreset == "next_step" else 6     # the pending-reset flag only exists under NEXT_STEP autoreset
+    assert (g1 == g2).all() and (a1[:, :ncmp] == a2[:, :ncmp]).all()
     assert (env.get_rng_state() == orc.get_rng()).all()
     env.close()
     return nterm, ntrunc
