@@ -47,27 +47,34 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int) -
     return b
 
 
-def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 12.0):
-    """Time the oracle's C port on all host cores (one independent batch per thread; ctypes drops the GIL)."""
+def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
+    """Time the oracle's C port on the host cores this process may use (one independent batch per thread; ctypes
+    drops the GIL).  Bounded: a short all-thread calibration sizes the sample to ~budget_s seconds."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    n_per = 1024
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    n_per = 512
     vecs = [O.OracleVec(env_id, n_per, full_obs=(obs_mode == "full")) for _ in range(cores)]
     for i, v in enumerate(vecs):
         v.reset(seeds=range(i * n_per, (i + 1) * n_per))
-    t0 = time.perf_counter()
-    vecs[0].rollout(50, 1)                       # calibration on one core
-    per_step = (time.perf_counter() - t0) / 50
-    T = max(50, int(budget_s / max(per_step, 1e-6)))
-    with ThreadPoolExecutor(cores) as ex:
-        t0 = time.perf_counter()
-        list(ex.map(lambda v: v.rollout(T, 7), vecs))
-        dt = time.perf_counter() - t0
+
+    def timed(T):
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda v: v.rollout(T, 7), vecs))
+            return time.perf_counter() - t0
+
+    cal = timed(20)                               # all threads together: includes any cgroup CPU quota
+    T = int(min(max(20, budget_s / max(cal / 20, 1e-7)), 200000))
+    dt = timed(T)
     return {"value": cores * n_per * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} obs), oracle C port, "
-                      f"xorshift random actions, NEXT_STEP autoreset, {dt:.1f}s"}
+            "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} obs), oracle C port "
+                      f"(oracle/minigrid_oracle.c), xorshift random actions, NEXT_STEP autoreset, {dt:.1f}s"}
 
 
 def main():

@@ -24,8 +24,8 @@ struct mg_env {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
-  int lds_per_wave = 0, t_offset = 0, TS = 0, wpb = 4;
-  bool tpad = false, static_gen = false;
+  int off_trow = 0, off_T = 0, off_lut = 0, off_act = 0, TSB = 0, lds_bytes = 0;
+  bool static_gen = false;
   int rule = RULE_NONE, rule_cell = 0;
   // device buffers
   uint8_t *grid = nullptr, *spare_grid = nullptr;
@@ -108,7 +108,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen;
-  P.lds_per_wave = e->lds_per_wave; P.t_offset = e->t_offset; P.TS = e->TS;
+  P.off_trow = e->off_trow; P.off_T = e->off_T; P.off_lut = e->off_lut; P.off_act = e->off_act; P.TSB = e->TSB;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
   P.cells_magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)e->cells - 1) / (uint64_t)e->cells);
@@ -116,16 +116,12 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 }
 
 static int launch_step(mg_env* e, const StepParams& P) {
-  const int waves = (e->N + 63) / 64;
-  const int blocks = (waves + e->wpb - 1) / e->wpb;
-  const size_t lds = (size_t)e->wpb * e->lds_per_wave;
-  dim3 grid(blocks), block(64 * e->wpb);
+  const int blocks = (e->N + 63) / 64;                  // one 256-thread workgroup per 64 consecutive envs
+  dim3 grid(blocks), block(STEP_THREADS);
   if (e->cfg.obs_mode == MG_OBS_PARTIAL)
-    hipLaunchKernelGGL((k_step<0, false>), grid, block, lds, e->stream, P);
-  else if (e->tpad)
-    hipLaunchKernelGGL((k_step<1, true>), grid, block, lds, e->stream, P);
+    hipLaunchKernelGGL(k_step<0>, grid, block, (size_t)e->lds_bytes, e->stream, P);
   else
-    hipLaunchKernelGGL((k_step<1, false>), grid, block, lds, e->stream, P);
+    hipLaunchKernelGGL(k_step<1>, grid, block, (size_t)e->lds_bytes, e->stream, P);
   HIP_TRY(e, hipGetLastError());
   e->launches++;
   if (!e->static_gen) return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/true, nullptr);
@@ -188,17 +184,17 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->GS = e->CS + 4;                                     // odd dword stride: conflict-free same-cell LDS reads
   const bool full = cfg->obs_mode == MG_OBS_FULL;
   e->obs_bytes = full ? e->cells * 3 : PARTIAL_OBS_BYTES;
-  const int grid_region = (64 * e->GS + 15) & ~15;
-  if (!full) {
-    e->TS = VIEW_CELLS; e->tpad = false; e->t_offset = 0;          // T aliases the staged grids (read before written)
-    e->lds_per_wave = std::max(grid_region, 64 * VIEW_CELLS * 4);
-  } else {
-    e->TS = e->cells | 1; e->tpad = (e->cells & 1) == 0; e->t_offset = grid_region;
-    e->lds_per_wave = grid_region + ((64 * e->TS * 4 + 15) & ~15);
+  {
+    // LDS carve-up of k_step (bytes): 64 staged grids | transparency rows | cell codes in output order | decode table | actions
+    const int obs_cells = full ? e->cells : VIEW_CELLS;
+    e->TSB = obs_cells + ((obs_cells & 3) == 0 ? 4 : 0);   // +4 keeps byte-column writes off a single LDS bank pair
+    e->off_trow = (64 * e->GS + 15) & ~15;
+    e->off_T = e->off_trow + 64 * 8;
+    e->off_lut = e->off_T + ((64 * e->TSB + 15) & ~15);
+    e->off_act = e->off_lut + 256 * 4;
+    e->lds_bytes = e->off_act + 64;
   }
-  e->wpb = 4;
-  while (e->wpb > 1 && e->wpb * e->lds_per_wave > 64 * 1024) e->wpb >>= 1;
-  if (e->lds_per_wave > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
+  if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
 
@@ -242,11 +238,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     build_reward_lut(cfg->max_steps, lut.data());
     TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (e->lds_per_wave * e->wpb > 64 * 1024) {
-    const int bytes = e->lds_per_wave * e->wpb;
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (e->lds_bytes > 64 * 1024) {
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   }
 #undef TRY_OR_FREE
   (void)env;

@@ -84,24 +84,18 @@ MG_HD uint32_t cell_toggle(uint32_t code, uint32_t carry) {
 // Returns the final row mask in *m_out and the bits contributed to row j-1 in *up_out.
 // tests/test_vis_row.py checks all 2^14 inputs against the literal loops.
 MG_HD void vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
-  // sweep 1: lit&transparent set A closed under "i in A, t[i+1], -> i+1 in A" plus seeds m&t
-  uint32_t g = m & t, p = t;
-  g |= p & (g << 1); p &= p << 1;
-  g |= p & (g << 2); p &= p << 2;
-  g |= p & (g << 4);
-  // fixpoint subtlety: a lit-but-opaque cell does not propagate, an unlit cell becomes lit by its left neighbour
-  // in A; so A must also absorb cells that become lit then are transparent -> already covered by the fill above.
-  uint32_t s1 = g & 0x3Fu;                 // sources i = 0..5
-  uint32_t m1 = (m | (s1 << 1)) & 0x7Fu;
-  uint32_t up = s1 | (s1 << 1);
-  // sweep 2 on the running mask
-  g = m1 & t; p = t;
-  g |= p & (g >> 1); p &= p >> 1;
-  g |= p & (g >> 2); p &= p >> 2;
-  g |= p & (g >> 4);
-  uint32_t s2 = g & 0x7Eu;                 // sources i = 6..1
-  *m_out = (m1 | (s2 >> 1)) & 0x7Fu;
-  *up_out = (up | s2 | (s2 >> 1)) & 0x7Fu;
+  // Both sweeps start from the same seeds: a cell lit by sweep 1 is reached through transparent cells from a seed
+  // s, so sweeping left from it only re-walks the run back to s and then continues as s itself would.  Hence the
+  // lit-and-transparent set after both sweeps is fill_right(m&t) | fill_left(m&t), two independent occluded fills.
+  const uint32_t g0 = m & t;
+  uint32_t gr = g0, pr = t, gl = g0, pl = t;
+  gr |= pr & (gr << 1); pr &= pr << 1;      gl |= pl & (gl >> 1); pl &= pl >> 1;
+  gr |= pr & (gr << 2); pr &= pr << 2;      gl |= pl & (gl >> 2); pl &= pl >> 2;
+  gr |= pr & (gr << 4);                     gl |= pl & (gl >> 4);
+  const uint32_t s1 = gr & 0x3Fu;           // sweep-1 sources i = 0..5: light i+1 here, i and i+1 above
+  const uint32_t s2 = (gr | gl) & 0x7Eu;    // sweep-2 sources i = 6..1: light i-1 here, i and i-1 above
+  *m_out = (m | (s1 << 1) | (s2 >> 1)) & 0x7Fu;
+  *up_out = (s1 | (s1 << 1) | s2 | (s2 >> 1)) & 0x7Fu;
 }
 
 // agent record: one u64 per env

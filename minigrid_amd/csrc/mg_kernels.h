@@ -32,6 +32,7 @@ namespace mg {
 constexpr int VIEW = 7;
 constexpr int VIEW_CELLS = VIEW * VIEW;        // 49
 constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
+constexpr int STEP_THREADS = 256;              // 4 waves cooperate on one group of 64 envs
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
@@ -49,9 +50,9 @@ struct StepParams {
   unsigned long long* counters;
   // config
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen;
-  int lds_per_wave, t_offset, TS;
+  int off_trow, off_T, off_lut, off_act, TSB;   // LDS carve-up (bytes); TSB = T row stride in bytes
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
-  uint32_t cells_magic;   // ceil(2^32 / cells)  (low 32 bits; exact for q < 2^16)
+  uint32_t cells_magic;   // ceil(2^32 / cells)
   long long env_base;
 };
 
@@ -86,97 +87,88 @@ MG_D Chunk12 pack_triples(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
   return o;
 }
 
-// The wave's observations are one contiguous byte stream (envs are consecutive, records are dense), i.e. the flat
-// concatenation of 3-byte triples.  T holds one u32 per triple at index q (+ q/cells when rows are padded to an odd
-// stride); every lane packs 4 triples into 12 bytes and the wave stores 768 contiguous bytes per instruction.
-template <bool PAD>
-MG_D void emit_obs_stream(const uint32_t* T, uint8_t* obase, int ntriples, uint32_t cells_magic, int lane) {
-  const int nfull = ntriples >> 2;
-  for (int c = lane; c < nfull; c += 64) {
-    uint32_t t0, t1, t2, t3;
-    if (!PAD) {
-      uint4 v = ((const uint4*)T)[c];
-      t0 = v.x; t1 = v.y; t2 = v.z; t3 = v.w;
-    } else {
-      uint32_t q = 4u * (uint32_t)c;
-      t0 = T[q + __umulhi(q, cells_magic)];
-      t1 = T[q + 1 + __umulhi(q + 1, cells_magic)];
-      t2 = T[q + 2 + __umulhi(q + 2, cells_magic)];
-      t3 = T[q + 3 + __umulhi(q + 3, cells_magic)];
-    }
-    *(Chunk12*)(obase + 12 * (size_t)c) = pack_triples(t0, t1, t2, t3);
-  }
-  // ragged tail (only when the wave's env count is not a multiple of 4): byte stores
-  const int rem = ntriples & 3;
-  if (rem && lane < rem) {
-    uint32_t q = (uint32_t)(nfull * 4 + lane);
-    uint32_t v = T[PAD ? q + __umulhi(q, cells_magic) : q];
-    uint8_t* p = obase + 3 * (size_t)q;
-    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16);
-  }
+// bits k in [0,6] with 0 <= c0 + s*k < L (s = +1 or -1): the in-bounds run of a view row/column
+MG_D uint32_t inb_mask7(int c0, int s, int L) {
+  const int lo = s > 0 ? max(0, -c0) : max(0, c0 - (L - 1));
+  const int hi = s > 0 ? min(6, L - 1 - c0) : min(6, c0);
+  const uint32_t m = ((2u << (hi & 31)) - 1u) & ~((1u << (lo & 31)) - 1u);
+  return hi >= lo ? m : 0u;
 }
 
 // ======================================================================================================
 // k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
 // verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
-// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.  TPAD: T rows padded to an odd dword stride.
+// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.
+//
+// One 256-thread workgroup = 64 consecutive envs.  Lane l of EVERY wave is env l: the scalar part (dynamics, ~100
+// instructions) is computed redundantly by the 4 waves, the cell-parallel parts (view gather / encode / output) are
+// split across them, so the dependent chain per wave is ~4x shorter and a CU holds 4x more waves than with one
+// lane per env alone.  LDS: the 64 grids (staged with coalesced 16 B/lane loads), per-env transparency rows, the
+// observation as one byte code per cell in output order, and a 256-entry code -> (type,colour,state) table.
 // ======================================================================================================
-template <int MODE, bool TPAD>
-__global__ void __launch_bounds__(256) k_step(const StepParams P) {
+template <int MODE>
+__global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wave_env0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64;
-  if (wave_env0 >= P.N) return;                     // wave-uniform; only wave-level syncs below
-  uint8_t* wl = smem + wave * P.lds_per_wave;
-  const int e = wave_env0 + lane;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int env0 = blockIdx.x * 64;
+  const int e = env0 + lane;
   const bool active = e < P.N;
-  const int nvalid = min(64, P.N - wave_env0);
+  const int nvalid = min(64, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
+  uint8_t* sgrid = smem;
+  uint8_t* strow = smem + P.off_trow;
+  uint8_t* sT = smem + P.off_T;
+  uint32_t* slut = (uint32_t*)(smem + P.off_lut);
+  uint8_t* sact = smem + P.off_act;
+  const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
 
-  // ---- issue every independent load up front: agent record, action, the wave's 64 grids (coalesced 16 B/lane) ----
-  uint64_t rec = active ? P.agent[e] : 0ull;
-  uint32_t act = (active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE;
+  // ---- every independent load is issued up front ----
+  const uint64_t rec = active ? P.agent[e] : 0ull;
+  slut[tid] = cell_triple((uint32_t)tid);
+  if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
   {
-    const int cpe = CS >> 4;                        // 16-byte chunks per env
+    // stage the 64 grids: 16 B per lane, fully coalesced; an env whose previous step ended its episode takes the
+    // pre-generated spare episode instead (MiniGridEnv.reset, minigrid_env.py:119-157) and makes it the live grid
+    const int cpe = CS >> 4;
     const int nchunks = nvalid * cpe;
-    const uint4* src = (const uint4*)(P.grid + (size_t)wave_env0 * CS);
-    for (int c = lane; c < nchunks; c += 64) {
-      uint4 v = src[c];
-      uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
-      uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
-      uint32_t* dst = (uint32_t*)(wl + el * GS + part * 16);
+    const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
+    for (int c = tid; c < nchunks; c += STEP_THREADS) {
+      const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
+      const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
+      const uint64_t srec = P.agent[env0 + el];
+      uint4 v = live[c];
+      if (((uint32_t)(srec >> 48) & FLAG_RESET_PENDING) && reset_enabled) {
+        v = ((const uint4*)(P.spare_grid + (size_t)env0 * CS))[c];
+        ((uint4*)(P.grid + (size_t)env0 * CS))[c] = v;
+      }
+      uint32_t* dst = (uint32_t*)(sgrid + el * GS + part * 16);
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
   }
-  MG_WAVE_SYNC();
+  __syncthreads();
 
   Agent a = agent_unpack(rec);
-  uint8_t* mygrid = wl + lane * GS;
+  uint8_t* mygrid = sgrid + lane * GS;
+  const uint32_t act = sact[lane];
   double reward = 0.0;
-  uint32_t term = 0, trunc = 0;
-  uint32_t errbits = 0;
+  uint32_t term = 0, trunc = 0, errbits = 0;
+  bool rec_dirty = false;
 
   if (active) {
-    if ((a.flags & FLAG_RESET_PENDING) && (P.autoreset_next_step || P.phase == PHASE_OBSERVE)) {
-      // ---- (auto)reset: MiniGridEnv.reset (119-157) with the map drawn ahead of time ----
-      const uint4* sp = (const uint4*)(P.spare_grid + (size_t)e * CS);
-      uint4* live = (uint4*)(P.grid + (size_t)e * CS);
-      for (int k = 0; k < (CS >> 4); k++) {
-        uint4 v = sp[k];
-        live[k] = v;
-        uint32_t* dst = (uint32_t*)(mygrid + k * 16);
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-      }
+    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled) {
       a = agent_unpack(P.spare_agent[e]);
       a.carry = 0; a.step = 0; a.flags = 0;
-      if (!P.static_gen) {
-        uint32_t slot = atomicAdd(P.refill_count, 1u);
+      rec_dirty = true;
+      if (wave == 0 && !P.static_gen) {
+        const uint32_t slot = atomicAdd(P.refill_count, 1u);
         P.refill_queue[slot] = (uint32_t)e;
       }
     } else if (P.phase == PHASE_STEP) {
       // ---- MiniGridEnv.step ----
+      rec_dirty = true;
       a.step = min(a.step + 1u, 0xFFFFu);
       const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
       const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
@@ -202,8 +194,8 @@ __global__ void __launch_bounds__(256) k_step(const StepParams P) {
         errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
       }
       if (newF != F && inb) {
-        mygrid[fidx] = (uint8_t)newF;
-        P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
+        mygrid[fidx] = (uint8_t)newF;                                // every wave writes the same byte: benign
+        if (wave == 0) P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
       }
       trunc = a.step >= (uint32_t)P.max_steps;
       if (P.rule == RULE_GOTO) {
@@ -215,86 +207,133 @@ __global__ void __launch_bounds__(256) k_step(const StepParams P) {
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
       if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
-      if (term | trunc) atomicAdd(&P.counters[1], 1ull);
+      if ((term | trunc) && wave == 0) atomicAdd(&P.counters[1], 1ull);
     }
   }
 
-  uint32_t* T = (uint32_t*)(wl + P.t_offset) + lane * P.TS;
+  // per-env scalar outputs, spread over the waves (each wave holds identical values)
+  if (active) {
+    if (wave == 0) { if (rec_dirty) P.agent[e] = agent_pack(a); if (errbits) atomicOr(P.err, errbits); }
+    else if (wave == 1) P.reward[e] = reward;
+    else if (wave == 2) { P.term[e] = (uint8_t)term; P.trunc[e] = (uint8_t)trunc; }
+    else { P.dir_out[e] = (uint8_t)a.dir; P.mission_out[e] = (uint8_t)a.mission; }
+  }
 
+  int obs_cells;
   if (MODE == 0) {
+    obs_cells = VIEW_CELLS;
     // ---- gen_obs_grid: closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
     //      view cell (vx,vy) is world cell agent + f*(6-vy) + r*(vx-3), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
-    //      outside the grid -> grey wall (grid.py:136-139). ----
+    //      outside the grid -> grey wall (grid.py:136-139).  wx depends on only one of vx/vy and wy on the other,
+    //      so in-bounds-ness is (column mask)[vx] & (row mask)[vy]. ----
     const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
     const int rx = -fyv, ry = fxv;
-    const int bx = (int)a.x + fxv * 6 - rx * 3, by = (int)a.y + fyv * 6 - ry * 3;
-    uint32_t cells[VIEW_CELLS];
-    uint32_t trow[VIEW];
+    const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
+    const uint32_t colmask = horiz ? inb_mask7((int)a.y - 3 * ry, ry, H) : inb_mask7((int)a.x - 3 * rx, rx, W);
+    const uint32_t rowmask = horiz ? inb_mask7((int)a.x + 6 * fxv, -fxv, W) : inb_mask7((int)a.y + 6 * fyv, -fyv, H);
+    const int SR = ry * W + rx;                                 // linear index step per vx
+    const int SU = -(fyv * W + fxv);                            // linear index step per vy
+    const int lbase = lane * GS;
+    const int base = lbase + ((int)a.y + 6 * fyv - 3 * ry) * W + ((int)a.x + 6 * fxv - 3 * rx);
+    const int lo = lbase, hi = lbase + P.cells - 1;
+    // opaque-type bitmap replicated for 5-bit indexing by (code & 31): bit4 of a code is a colour bit
+    const uint32_t OPQ32 = OPAQUE_MASK | (OPAQUE_MASK << 16);
+    uint32_t mycell[2][VIEW];
 #pragma unroll
-    for (int vy = 0; vy < VIEW; vy++) {
-      uint32_t tr = 0;
+    for (int r = 0; r < 2; r++) {
+      const int vy = wave + 4 * r;                              // rows {w, w+4}; wave 3 has only row 3
+      if (vy < VIEW) {
+        const int rowbase = base + vy * SU;
+        const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
+        uint32_t opq = 0;
 #pragma unroll
-      for (int vx = 0; vx < VIEW; vx++) {
-        const int wx = bx + rx * vx - fxv * vy, wy = by + ry * vx - fyv * vy;
-        const bool in = (unsigned)wx < (unsigned)W && (unsigned)wy < (unsigned)H;
-        const uint32_t c = in ? (uint32_t)mygrid[in ? wy * W + wx : 0] : (uint32_t)CELL_WALL_GREY;
-        cells[vx * VIEW + vy] = c;
-        tr |= (uint32_t)cell_transparent(c) << vx;
+        for (int vx = 0; vx < VIEW; vx++) {
+          const int addr = min(max(rowbase + vx * SR, lo), hi);
+          const uint32_t raw = sgrid[addr];
+          const uint32_t valid = 0u - ((cm >> vx) & 1u);
+          const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+          mycell[r][vx] = c;
+          opq |= ((OPQ32 >> (c & 31u)) & 1u) << vx;
+        }
+        strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);          // transparency bits of this view row
       }
-      trow[vy] = tr;
     }
-    // ---- process_vis (grid.py:291-328), one bit-parallel row at a time, bottom row first ----
-    uint32_t vrow[VIEW];
+    __syncthreads();
+    // ---- process_vis (grid.py:291-328), bit-parallel rows bottom-up; every wave needs the whole mask ----
+    unsigned long long vis = 0;
     if (P.see_through) {
-#pragma unroll
-      for (int j = 0; j < VIEW; j++) vrow[j] = 0x7Fu;
+      vis = (1ull << VIEW_CELLS) - 1ull;
     } else {
+      const uint2 tw = *(const uint2*)(strow + lane * 8);
       uint32_t m = 1u << (VIEW / 2);
 #pragma unroll
       for (int j = VIEW - 1; j >= 0; j--) {
-        uint32_t up;
-        vis_row(m, trow[j], &vrow[j], &up);
+        const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
+        uint32_t vr, up;
+        vis_row(m, t, &vr, &up);
+        vis |= (unsigned long long)vr << (7 * j);
         m = up;
       }
     }
-    // the agent's own cell shows what it carries (623-630), after visibility
-    cells[(VIEW / 2) * VIEW + (VIEW - 1)] = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-    // ---- Grid.encode(vis_mask) (grid.py:244-268): invisible -> (0,0,0) ----
+    // ---- Grid.encode(vis_mask) (grid.py:244-268) as one byte code per cell in image[x][y] order; invisible -> 0,
+    //      the agent's own cell shows what it carries (minigrid_env.py:623-630) ----
 #pragma unroll
-    for (int vx = 0; vx < VIEW; vx++) {
+    for (int r = 0; r < 2; r++) {
+      const int vy = wave + 4 * r;
+      if (vy < VIEW) {
+        const uint32_t vrow = (uint32_t)(vis >> (7 * vy)) & 0x7Fu;
+        uint8_t* trow = sT + lane * VIEW_CELLS + vy;
 #pragma unroll
-      for (int vy = 0; vy < VIEW; vy++) {
-        const uint32_t tri = cell_triple(cells[vx * VIEW + vy]);
-        T[vx * VIEW + vy] = ((vrow[vy] >> vx) & 1u) ? tri : 0u;
+        for (int vx = 0; vx < VIEW; vx++) {
+          uint32_t c = mycell[r][vx];
+          if (vx == VIEW / 2) c = (vy == VIEW - 1) ? (a.carry ? a.carry : (uint32_t)CELL_EMPTY) : c;
+          trow[vx * VIEW] = (uint8_t)(c & (0u - ((vrow >> vx) & 1u)));
+        }
       }
     }
   } else {
-    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir) ----
-    int k = 0;
-    for (int x = 0; x < W; x++) {
-      for (int y = 0; y < H; y++, k++) {
-        uint32_t tri = cell_triple((uint32_t)mygrid[y * W + x]);
-        if (x == (int)a.x && y == (int)a.y) tri = (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | (a.dir << 16);
-        T[k] = tri;
+    obs_cells = P.cells;
+    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir).
+    //      The agent cell is emitted as internal code 0x80 | dir (decoded by the table below). ----
+    uint8_t* trow = sT + lane * P.TSB;
+    for (int x = wave; x < W; x += 4) {
+      for (int y = 0; y < H; y++) {
+        uint32_t c = mygrid[y * W + x];
+        if (x == (int)a.x && y == (int)a.y) c = 0x80u | a.dir;
+        trow[x * H + y] = (uint8_t)c;
       }
     }
+    if (tid < 4) slut[0x80 + tid] = (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | ((uint32_t)tid << 16);
   }
-  MG_WAVE_SYNC();
+  __syncthreads();
 
-  const int obs_cells = MODE == 0 ? VIEW_CELLS : P.cells;
-  uint8_t* obase = P.obs + (size_t)wave_env0 * (size_t)(obs_cells * 3);
-  emit_obs_stream<TPAD>((const uint32_t*)(wl + P.t_offset), obase, nvalid * obs_cells, P.cells_magic, lane);
-
-  if (active) {
-    if (P.phase == PHASE_STEP || (rec != agent_pack(a))) P.agent[e] = agent_pack(a);
-    P.reward[e] = reward;
-    P.term[e] = (uint8_t)term;
-    P.trunc[e] = (uint8_t)trunc;
-    P.dir_out[e] = (uint8_t)a.dir;
-    P.mission_out[e] = (uint8_t)a.mission;
-    if (errbits) atomicOr(P.err, errbits);
+  // ---- the block's observations are one contiguous byte stream = the flat concatenation of 3-byte triples.
+  //      Each lane decodes 4 consecutive cell codes through the LDS table and stores 12 bytes; a wave stores
+  //      768 contiguous bytes per instruction. ----
+  {
+    uint8_t* obase = P.obs + (size_t)env0 * (size_t)(obs_cells * 3);
+    const int ntriples = nvalid * obs_cells;
+    const int nfull = ntriples >> 2;
+    const int pad = P.TSB - obs_cells;                       // 0, or 4 when obs_cells % 4 == 0 (bank spreading)
+    for (int c = tid; c < nfull; c += STEP_THREADS) {
+      uint32_t off = 4u * (uint32_t)c;
+      if (MODE == 1 && pad) off += (uint32_t)pad * __umulhi(off, P.cells_magic);
+      const uint32_t codes = *(const uint32_t*)(sT + off);   // rows are dense (or padded by 4): always dword-aligned
+      const uint32_t t0 = slut[codes & 0xFF], t1 = slut[(codes >> 8) & 0xFF];
+      const uint32_t t2 = slut[(codes >> 16) & 0xFF], t3 = slut[codes >> 24];
+      *(Chunk12*)(obase + 12 * (size_t)c) = pack_triples(t0, t1, t2, t3);
+    }
+    const int rem = ntriples & 3;                            // ragged tail: only when nvalid*cells is not a multiple of 4
+    if (rem && tid < rem) {
+      uint32_t q = (uint32_t)(nfull * 4 + tid);
+      uint32_t off = q;
+      if (MODE == 1 && pad) off += (uint32_t)pad * __umulhi(q, P.cells_magic);
+      const uint32_t v = slut[sT[off]];
+      uint8_t* p = obase + 3 * (size_t)q;
+      p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16);
+    }
   }
-  if (P.phase == PHASE_STEP && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
+  if (P.phase == PHASE_STEP && tid == 0 && blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
 }
 
 // ======================================================================================================
