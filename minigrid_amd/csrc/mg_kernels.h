@@ -156,6 +156,12 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
   double reward = 0.0;
   uint32_t term = 0, trunc = 0, errbits = 0;
   bool rec_dirty = false;
+  // The staged LDS grid is READ-ONLY after the barrier: the 4 waves recompute the dynamics redundantly, so a wave
+  // that wrote the toggled/picked/dropped cell back into LDS would be seen by a slower wave as its *input*.
+  // Instead the one cell an action can change is patched on the fly.  It can only change under pickup/drop/toggle,
+  // which leave the pose alone, so it is always the cell straight ahead: view cell (3,5).
+  int dirty_idx = -1;              // linear index of the modified cell, -1 = none
+  uint32_t dirty_code = 0;
 
   if (active) {
     if ((a.flags & FLAG_RESET_PENDING) && reset_enabled) {
@@ -194,15 +200,17 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
         errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
       }
       if (newF != F && inb) {
-        mygrid[fidx] = (uint8_t)newF;                                // every wave writes the same byte: benign
+        dirty_idx = (int)fidx; dirty_code = newF;
         if (wave == 0) P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
       }
       trunc = a.step >= (uint32_t)P.max_steps;
       if (P.rule == RULE_GOTO) {
         // GoToInstr.verify_action on the post-action state: front cell holds a target object
         const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && (int)mygrid[gy * W + gx] == P.rule_cell) {
-          term = 1; success = true;
+        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
+          const int gidx = gy * W + gx;
+          const uint32_t G = gidx == dirty_idx ? dirty_code : (uint32_t)mygrid[gidx];
+          if ((int)G == P.rule_cell) { term = 1; success = true; }
         }
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
@@ -251,7 +259,8 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
           const int addr = min(max(rowbase + vx * SR, lo), hi);
           const uint32_t raw = sgrid[addr];
           const uint32_t valid = 0u - ((cm >> vx) & 1u);
-          const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+          uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+          if (r == 1 && vx == VIEW / 2) c = (wave == 1 && dirty_idx >= 0) ? dirty_code : c;   // view (3,5)
           mycell[r][vx] = c;
           opq |= ((OPQ32 >> (c & 31u)) & 1u) << vx;
         }
@@ -299,6 +308,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
     for (int x = wave; x < W; x += 4) {
       for (int y = 0; y < H; y++) {
         uint32_t c = mygrid[y * W + x];
+        if (y * W + x == dirty_idx) c = dirty_code;
         if (x == (int)a.x && y == (int)a.y) c = 0x80u | a.dir;
         trow[x * H + y] = (uint8_t)c;
       }
