@@ -87,13 +87,15 @@ static int launch_generate(mg_env* e, bool to_spare, bool queue_mode, const uint
   A.zero_count = queue_mode ? e->qcount + (e->launches & 1) : nullptr;
   A.mask = d_mask; A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.GS = e->GS;
-  int blocks = (e->N + 63) / 64;
-  if (queue_mode) blocks = std::min(blocks, 2048);
-  size_t lds = (size_t)64 * e->GS;
+  // one wavefront per episode, 4 per workgroup; the queue length is only known on the device, so queue mode
+  // launches a fixed grid (most steps enqueue a few hundred envs: <= 1 episode per wave) and strides over it
+  const int wpb = GEN_THREADS / 64;
+  int blocks = std::min((e->N + wpb - 1) / wpb, queue_mode ? 1024 : 8192);
+  size_t lds = (size_t)wpb * e->CS;
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
-    hipLaunchKernelGGL(k_generate<PhiloxStream>, dim3(blocks), dim3(64), lds, e->stream, A);
+    hipLaunchKernelGGL(k_generate<WavePhilox>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
   else
-    hipLaunchKernelGGL(k_generate<Pcg64Stream>, dim3(blocks), dim3(64), lds, e->stream, A);
+    hipLaunchKernelGGL(k_generate<WavePcg64>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
 }

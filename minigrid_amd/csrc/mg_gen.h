@@ -1,6 +1,8 @@
 // mg_gen.h — device-side map generators (the reference's `_gen_grid` implementations on the hot path).
-// One lane generates one episode into its private byte grid (in LDS), drawing from its own stream in exactly the
-// order the reference draws, so that with Pcg64Stream the layout for a given seed is the reference's layout.
+// One WAVEFRONT generates one episode into a byte grid in LDS, drawing from the env's stream in exactly the order
+// the reference draws, so that with the PCG64 stream the layout for a given seed is the reference's layout.
+// All control flow below is wave-uniform (draws come out of v_readlane, cells out of v_readfirstlane); the 64 lanes
+// are used for the bulk parts: the jumped-ahead draws (mg_rng.h), clearing the grid, the reachability bitboards.
 #pragma once
 #include "mg_device.h"
 #include "mg_rng.h"
@@ -20,16 +22,39 @@ struct GenResult {
   bool failed;        // retry bound exhausted
 };
 
-// Byte grid, row-major index y*W+x (core/grid.py:28-35,65-78)
+// LDS hand-off inside ONE wave: lanes wrote different addresses, the wave reads them next (DS ops of a wave execute
+// in order; the fences only stop the compiler from moving the accesses across).
+#define MG_WAVE_LDS_SYNC()                                    \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+// Byte grid owned by one wave, row-major index y*W+x (core/grid.py:28-35,65-78).  get/set take wave-uniform
+// coordinates: every lane reads (broadcast) or writes (same value) the same LDS byte.
 struct GridRef {
-  uint8_t* p; int W, H;
-  MG_D uint32_t get(int x, int y) const { return p[y * W + x]; }
+  uint8_t* p; int W, H; int lane;
+  MG_D uint32_t get(int x, int y) const { return uni32((uint32_t)p[y * W + x]); }
   MG_D void set(int x, int y, uint32_t c) { p[y * W + x] = (uint8_t)c; }
-  // Grid(width,height) + wall_rect(0,0,W,H) (core/grid.py:28-35,104-108)
+  // Grid(width,height) + wall_rect(0,0,W,H) (core/grid.py:28-35,104-108), 64 cells per instruction
   MG_D void clear_with_walls() {
-    for (int y = 0; y < H; y++)
-      for (int x = 0; x < W; x++)
-        p[y * W + x] = (uint8_t)((x == 0 || y == 0 || x == W - 1 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+    for (int k = lane; k < W * H; k += 64) {
+      const int y = k / W, x = k - y * W;
+      p[k] = (uint8_t)((x == 0 || y == 0 || x == W - 1 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
+    }
+    MG_WAVE_LDS_SYNC();
+  }
+  // 8x8 grids only (bit index = y*8+x = lane): cells the reachability flood may pass (None or any door), cells
+  // holding a non-wall object, and the number of red balls
+  MG_D void reach_masks_8x8(uint64_t& passable, uint64_t& objects, uint32_t& nred) const {
+    MG_WAVE_LDS_SYNC();
+    const uint32_t c = p[lane], t = cell_type(c);
+    const bool pass = c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED;
+    passable = __ballot(pass);
+    objects = __ballot(!pass && t != T_WALL);
+    nred = (uint32_t)__popcll(__ballot(c == CELL_BALL_RED));
   }
 };
 
@@ -182,13 +207,8 @@ MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     if (!ok) continue;
     // check_objs_reachable: flood from the agent through None/door cells; every non-wall object must be in the
     // visited set (= passable flood plus its 4-neighbourhood).  Bit index = y*8+x (W == H == 8).
-    uint64_t passable = 0, objects = 0; uint32_t nred = 0;
-    for (int k = 0; k < 64; k++) {
-      uint32_t c = g.p[k], t = cell_type(c);
-      if (c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED) passable |= 1ull << k;
-      else if (t != T_WALL) objects |= 1ull << k;
-      nred += (c == CELL_BALL_RED);
-    }
+    uint64_t passable, objects; uint32_t nred;
+    g.reach_masks_8x8(passable, objects, nred);
     const uint64_t notA = 0xFEFEFEFEFEFEFEFEull, notH = 0x7F7F7F7F7F7F7F7Full;
     uint64_t reach = 1ull << (out.ay * 8 + out.ax);
     for (;;) {

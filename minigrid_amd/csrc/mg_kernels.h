@@ -12,22 +12,14 @@
 // Why a spare episode: in the reference an env's np_random stream is consumed ONLY by reset() on this path, so the
 // map of episode k+1 can be drawn any time after episode k's map without changing the stream.  The step kernel
 // therefore never runs a generator: on (auto)reset it copies the pre-generated spare (CS bytes) and enqueues the
-// env id; a separate, fully-occupied generator kernel refills the spares of the enqueued envs.  The sequential,
-// divergent PCG64 + rejection-sampling code stays off the step critical path.
+// env id; a separate generator kernel (one wavefront per enqueued env, see mg_gen.h) refills those spares.  The
+// sequential PCG64 + rejection-sampling code stays off the step critical path.
 #pragma once
 #include "mg_device.h"
 #include "mg_gen.h"
 #include "mg_rng.h"
 
 namespace mg {
-
-// wave-local LDS hand-off: all lanes of ONE wave wrote LDS, other lanes of the same wave read it next.
-#define MG_WAVE_SYNC()                                        \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
-    __builtin_amdgcn_wave_barrier();                          \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
-  } while (0)
 
 constexpr int VIEW = 7;
 constexpr int VIEW_CELLS = VIEW * VIEW;        // 49
@@ -361,37 +353,45 @@ struct GenArgs {
   int N, CS, GS;
 };
 
+MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4]; }
+
+constexpr int GEN_THREADS = 256;               // 4 waves per workgroup, each wave generates one episode at a time
+
 template <class RNG>
-__global__ void __launch_bounds__(64) k_generate(const GenArgs A) {
+__global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x;
-  if (A.zero_count && blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
-  const int total = A.queue ? (int)*A.count : A.N;
-  uint8_t* mygrid = smem + lane * A.GS;
-  for (int base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
-    const int i = base + lane;
-    if (i >= total) continue;
-    const int e = A.queue ? (int)A.queue[i] : i;
-    if (!A.queue && A.mask && !A.mask[e]) continue;
+  const uint32_t lane = threadIdx.x & 63u;
+  const int wave = (int)(threadIdx.x >> 6);
+  if (A.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_count = 0u;
+  const int total = A.queue ? (int)uni32(*A.count) : A.N;
+  uint8_t* mygrid = smem + wave * A.CS;
+  const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
+  const size_t N = (size_t)A.N;
+  for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
+    const int e = A.queue ? (int)uni32(A.queue[i]) : i;
+    if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
     RNG rng;
-    rng.load(A.rng, (size_t)A.N, (size_t)e);
-    if (A.rng_snap) rng.store(A.rng_snap, (size_t)A.N, (size_t)e);
+    rng.load(A.rng, N, (size_t)e, lane);
+    if (A.rng_snap && lane < 5u) A.rng_snap[lane * N + (size_t)e] = pick5(rng.w_in, lane);
     if constexpr (RNG::kEpisodic) rng.begin_episode();
-    GridRef g{ mygrid, A.gp.W, A.gp.H };
-    for (int k = A.gp.W * A.gp.H; k < A.CS; k++) mygrid[k] = 0;
+    GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
+    for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
     GenResult out;
     generate_episode(rng, g, A.gp, out);
-    rng.store(A.rng, (size_t)A.N, (size_t)e);
-    if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
+    uint64_t w[5];
+    rng.final_words(w);
+    if (lane < 5u) A.rng[lane * N + (size_t)e] = pick5(w, lane);
+    MG_WAVE_LDS_SYNC();
     uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
-    for (int k = 0; k < (A.CS >> 4); k++) {
-      const uint32_t* s = (const uint32_t*)(mygrid + k * 16);
-      dst[k] = make_uint4(s[0], s[1], s[2], s[3]);
+    for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
+    if (lane == 0) {
+      Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
+      A.dst_agent[e] = agent_pack(ag);
+      if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
+      atomicAdd(&A.counters[2], 1ull);
+      if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
     }
-    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
-    A.dst_agent[e] = agent_pack(ag);
-    atomicAdd(&A.counters[2], 1ull);
-    if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
+    MG_WAVE_LDS_SYNC();
   }
 }
 

@@ -139,6 +139,133 @@ struct PhiloxStream {
   }
 };
 
+// ======================================================================================================
+// Wave-cooperative streams: ONE wavefront draws for ONE environment.
+// A stream is sequential by definition, but both generators can be jumped: the 64 lanes compute the next 64
+// raw outputs in parallel, and the (wave-uniform) consumer picks draw k with v_readlane.  The generator code
+// that consumes the draws (mg_gen.h) is then uniform control flow: no lane ever waits on another env's
+// rejection loop, which is what made one-lane-per-env generation latency-bound.
+// ======================================================================================================
+MG_D uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+MG_D uint64_t uni64(uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); }
+MG_D uint32_t lane32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+MG_D uint64_t lane64(uint64_t v, uint32_t l) { return (uint64_t)lane32((uint32_t)v, l) | ((uint64_t)lane32((uint32_t)(v >> 32), l) << 32); }
+
+// LCG jump table: state after k steps = A_k * state + S_k * inc (mod 2^128), A_k = mult^k, S_k = 1 + mult + ... + mult^(k-1)
+struct PcgJump { uint64_t a_hi[65], a_lo[65], s_hi[65], s_lo[65]; };
+constexpr PcgJump make_pcg_jump() {
+  PcgJump t{};
+  const u128 mult = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
+  u128 a = 1, s = 0;
+  for (int k = 0; k <= 64; k++) {
+    t.a_hi[k] = (uint64_t)(a >> 64); t.a_lo[k] = (uint64_t)a; t.s_hi[k] = (uint64_t)(s >> 64); t.s_lo[k] = (uint64_t)s;
+    s = s * mult + 1; a = a * mult;
+  }
+  return t;
+}
+#if defined(__HIPCC__)
+__device__ const PcgJump kPcgJump = make_pcg_jump();
+
+// numpy PCG64 stream position = (state, inc, has_uint32, uinteger); same SoA words as Pcg64Stream.
+// Buffer: lane l holds the state after l+1 steps from `base` and that step's 64-bit output, i.e. 128 32-bit draws
+// (numpy hands out the low half first and caches the high half).
+struct WavePcg64 {
+  static constexpr bool kEpisodic = false;
+  u128 base, inc;              // wave-uniform
+  u128 st;                     // per lane
+  uint32_t out_lo, out_hi;     // per lane
+  uint32_t wpos;               // uniform: 32-bit words consumed from the current buffer, 0..128
+  uint32_t pending, cache_in;  // a cached high half carried in from the previous episode comes first
+  uint32_t lane;
+  uint64_t w_in[5];            // the words as loaded (the caller snapshots them)
+
+  MG_D void refill() {
+    const uint32_t k = lane + 1u;
+    const u128 A = ((u128)kPcgJump.a_hi[k] << 64) | kPcgJump.a_lo[k];
+    const u128 S = ((u128)kPcgJump.s_hi[k] << 64) | kPcgJump.s_lo[k];
+    st = A * base + S * inc;
+    const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
+    const uint64_t x = hi ^ lo;
+    const uint32_t rot = (uint32_t)(hi >> 58);
+    const uint64_t o = (x >> rot) | (x << ((64u - rot) & 63u));
+    out_lo = (uint32_t)o; out_hi = (uint32_t)(o >> 32);
+    wpos = 0;
+  }
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_) {
+    lane = lane_;
+#pragma unroll
+    for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
+    base = ((u128)w_in[0] << 64) | w_in[1];
+    inc = ((u128)w_in[2] << 64) | w_in[3];
+    pending = (uint32_t)(w_in[4] >> 32) & 1u; cache_in = (uint32_t)w_in[4];
+    refill();
+  }
+  MG_D uint32_t next32() {
+    if (pending) { pending = 0; return cache_in; }
+    if (wpos == 128u) {
+      cache_in = lane32(out_hi, 63);
+      base = ((u128)lane64((uint64_t)(st >> 64), 63) << 64) | lane64((uint64_t)st, 63);
+      refill();
+    }
+    const uint32_t j = wpos >> 1;
+    const uint32_t v = (wpos & 1u) ? lane32(out_hi, j) : lane32(out_lo, j);
+    wpos++;
+    return v;
+  }
+  // every lane holds the same final words; the caller lets one lane write them
+  MG_D void final_words(uint64_t w[5]) const {
+    const uint32_t nout = (wpos + 1u) >> 1;
+    const uint32_t l = nout ? nout - 1u : 0u;
+    const uint64_t sh = lane64((uint64_t)(st >> 64), l), sl = lane64((uint64_t)st, l);
+    const uint32_t ch = lane32(out_hi, l);
+    w[0] = nout ? sh : (uint64_t)(base >> 64); w[1] = nout ? sl : (uint64_t)base;
+    w[2] = (uint64_t)(inc >> 64); w[3] = (uint64_t)inc;
+    const uint32_t has = pending ? 1u : (wpos & 1u);
+    const uint32_t cache = nout ? ch : cache_in;
+    w[4] = ((uint64_t)has << 32) | cache;
+  }
+};
+
+// Philox4x32-10: lane l computes counter block (bbase + l) of the episode = 256 draws per buffer.
+struct WavePhilox {
+  static constexpr bool kEpisodic = true;
+  uint64_t key, episode;       // uniform
+  uint32_t bbase, dpos;        // uniform: first block of the buffer, draws consumed from it (0..256)
+  uint32_t buf[4];             // per lane
+  uint32_t lane;
+  uint64_t w_in[5];
+
+  MG_D void refill() {
+    buf[0] = bbase + lane; buf[1] = (uint32_t)episode; buf[2] = (uint32_t)(episode >> 32); buf[3] = 0x4D47u;
+    philox4x32_10(buf, (uint32_t)key, (uint32_t)(key >> 32));
+    dpos = 0;
+  }
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_) {
+    lane = lane_;
+#pragma unroll
+    for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
+    key = w_in[0]; episode = w_in[1]; bbase = 0; dpos = 0;
+    buf[0] = buf[1] = buf[2] = buf[3] = 0;
+  }
+  MG_D void begin_episode() { episode++; bbase = 0; refill(); }
+  MG_D uint32_t next32() {
+    if (dpos == 256u) { bbase += 64u; refill(); }
+    const uint32_t l = dpos >> 2, k = dpos & 3u;
+    const uint32_t a = lane32(buf[0], l), b = lane32(buf[1], l), c = lane32(buf[2], l), d = lane32(buf[3], l);
+    dpos++;
+    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+  }
+  MG_D void final_words(uint64_t w[5]) const {
+    const uint32_t nblk = (dpos + 3u) >> 2;
+    const uint32_t l = nblk ? nblk - 1u : 0u;
+    w[0] = key; w[1] = episode;
+    w[2] = ((uint64_t)(bbase + nblk) << 8) | (nblk ? dpos - 4u * (nblk - 1u) : 4u);
+    w[3] = (uint64_t)lane32(buf[0], l) | ((uint64_t)lane32(buf[1], l) << 32);
+    w[4] = (uint64_t)lane32(buf[2], l) | ((uint64_t)lane32(buf[3], l) << 32);
+  }
+};
+#endif  // __HIPCC__
+
 // ---------------- numpy draw primitives on top of next32() ----------------
 // Generator.integers(low, high) for a range that fits 32 bits: range 1 draws nothing; otherwise Lemire's
 // nearly-divisionless method with rejection (buffered_bounded_lemire_uint32).  MiniGridEnv._rand_int (247-252).
