@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,7 +25,8 @@ struct mg_env {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
-  int off_trow = 0, off_T = 0, off_lut = 0, off_act = 0, TSB = 0, lds_bytes = 0;
+  int off_grid = 0, off_trow = 0, off_vis = 0, off_T = 0, off_lut = 0, off_act = 0, lds_bytes = 0;
+  int wpg = 4;                // wavefronts per group of 64 envs in k_step
   bool static_gen = false;
   int rule = RULE_NONE, rule_cell = 0;
   // device buffers
@@ -110,20 +112,25 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen;
-  P.off_trow = e->off_trow; P.off_T = e->off_T; P.off_lut = e->off_lut; P.off_act = e->off_act; P.TSB = e->TSB;
+  P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
+  P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->obs_bytes;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
-  P.cells_magic = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)e->cells - 1) / (uint64_t)e->cells);
   P.env_base = e->cfg.env_index_base;
 }
 
 static int launch_step(mg_env* e, const StepParams& P) {
-  const int blocks = (e->N + 63) / 64;                  // one 256-thread workgroup per 64 consecutive envs
-  dim3 grid(blocks), block(STEP_THREADS);
-  if (e->cfg.obs_mode == MG_OBS_PARTIAL)
-    hipLaunchKernelGGL(k_step<0>, grid, block, (size_t)e->lds_bytes, e->stream, P);
-  else
-    hipLaunchKernelGGL(k_step<1>, grid, block, (size_t)e->lds_bytes, e->stream, P);
+  const int blocks = (e->N + 63) / 64;                  // one workgroup of wpg wavefronts per 64 consecutive envs
+  dim3 grid(blocks), block(64 * e->wpg);
+  const size_t lds = (size_t)e->lds_bytes;
+  const bool partial = e->cfg.obs_mode == MG_OBS_PARTIAL;
+#define MG_LAUNCH_STEP(MODE, WPG) hipLaunchKernelGGL((k_step<MODE, WPG>), grid, block, lds, e->stream, P)
+  switch (e->wpg) {
+    case 1: if (partial) MG_LAUNCH_STEP(0, 1); else MG_LAUNCH_STEP(1, 1); break;
+    case 2: if (partial) MG_LAUNCH_STEP(0, 2); else MG_LAUNCH_STEP(1, 2); break;
+    default: if (partial) MG_LAUNCH_STEP(0, 4); else MG_LAUNCH_STEP(1, 4); break;
+  }
+#undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
   e->launches++;
   if (!e->static_gen) return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/true, nullptr);
@@ -187,14 +194,24 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   const bool full = cfg->obs_mode == MG_OBS_FULL;
   e->obs_bytes = full ? e->cells * 3 : PARTIAL_OBS_BYTES;
   {
-    // LDS carve-up of k_step (bytes): 64 staged grids | transparency rows | cell codes in output order | decode table | actions
-    const int obs_cells = full ? e->cells : VIEW_CELLS;
-    e->TSB = obs_cells + ((obs_cells & 3) == 0 ? 4 : 0);   // +4 keeps byte-column writes off a single LDS bank pair
-    e->off_trow = (64 * e->GS + 15) & ~15;
-    e->off_T = e->off_trow + 64 * 8;
-    e->off_lut = e->off_T + ((64 * e->TSB + 15) & ~15);
+    // LDS carve-up of k_step (bytes): guard | 64 staged grids | guard | opacity rows | visibility masks |
+    // observation bytes in output order | decode table | actions.  The guard bands cover the furthest a view cell
+    // can lie outside an env's own grid (6 rows + 6 cells): such reads are masked, they only have to stay in LDS.
+    const int guard = (6 * e->W + 6 + 15) & ~15;
+    e->off_grid = guard;
+    e->off_trow = (guard + 64 * e->GS + guard + 15) & ~15;
+    e->off_vis = e->off_trow + 64 * 8;
+    e->off_T = e->off_vis + 64 * 8;
+    e->off_lut = e->off_T + ((64 * e->obs_bytes + 15) & ~15);
     e->off_act = e->off_lut + 256 * 4;
     e->lds_bytes = e->off_act + 64;
+  }
+  {
+    // waves per 64-env group.  Measured on MI355X (profiles/r1/sweep_wpg.txt): 4 wins at every batch size from
+    // 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
+    // dependent LDS/HBM latency per wave, not by issue slots.  MG_WPG overrides (tuning / tests).
+    e->wpg = 4;
+    if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) e->wpg = v; }
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
@@ -241,8 +258,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (e->lds_bytes > 64 * 1024) {
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    const void* fns[] = { (const void*)k_step<0, 1>, (const void*)k_step<0, 2>, (const void*)k_step<0, 4>,
+                          (const void*)k_step<1, 1>, (const void*)k_step<1, 2>, (const void*)k_step<1, 4> };
+    for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   }
 #undef TRY_OR_FREE
   (void)env;

@@ -18,19 +18,27 @@ enum : uint32_t { C_RED = 0, C_GREEN = 1, C_BLUE = 2, C_PURPLE = 3, C_YELLOW = 4
 // core/actions.py:7-20
 enum : uint32_t { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
 
-// A grid cell in HBM/LDS is ONE byte: code = type | colour << 4.
+// A grid cell in HBM/LDS is ONE byte: code = type | colour << 4 | opaque << 7.
 //   empty (Python None)  -> T_EMPTY, colour 0  == 0x01, which decodes to the reference's (1,0,0) for free
 //   door open/closed/locked -> type 4 / 11 / 12 (state 0 / 1 / 2)
+//   bit 7 = "NOT see_behind()" (world_object.py:164,181-182: wall, closed door, locked door), kept in the code so
+//           that the visibility pass reads it with one bit-field extract; make_cell() is the only place that sets it
 //   0x00 is "no object" for the carrying slot.
-constexpr uint32_t CELL_EMPTY = T_EMPTY;
-constexpr uint32_t CELL_WALL_GREY = T_WALL | (C_GREY << 4);
-constexpr uint32_t CELL_GOAL = T_GOAL | (C_GREEN << 4);
-constexpr uint32_t CELL_LAVA = T_LAVA | (C_RED << 4);
-constexpr uint32_t CELL_BALL_RED = T_BALL | (C_RED << 4);
+//   type 13 (internal) marks the agent's own cell in the FullyObs encode: colour field = agent_dir.
+constexpr uint32_t T_AGENT_MARK = 13;
+constexpr uint32_t OPAQUE_TYPES = (1u << T_WALL) | (1u << 11) | (1u << 12);
+constexpr uint32_t OPAQUE_BIT = 0x80u;
 
 MG_HD uint32_t cell_type(uint32_t code) { return code & 15u; }
 MG_HD uint32_t cell_color(uint32_t code) { return (code >> 4) & 7u; }
-MG_HD uint32_t make_cell(uint32_t type, uint32_t color) { return type | (color << 4); }
+MG_HD constexpr uint32_t make_cell(uint32_t type, uint32_t color) {
+  return type | (color << 4) | (((OPAQUE_TYPES >> type) & 1u) << 7);
+}
+constexpr uint32_t CELL_EMPTY = T_EMPTY;
+constexpr uint32_t CELL_WALL_GREY = make_cell(T_WALL, C_GREY);
+constexpr uint32_t CELL_GOAL = make_cell(T_GOAL, C_GREEN);
+constexpr uint32_t CELL_LAVA = make_cell(T_LAVA, C_RED);
+constexpr uint32_t CELL_BALL_RED = make_cell(T_BALL, C_RED);
 
 // (type, colour, state) of the reference encoding -> cell code.  Mirrors WorldObj.decode (core/world_object.py:69-102):
 // empty/unseen/agent -> None; Goal()/Lava() take their default colours; non-door state is ignored.
@@ -45,6 +53,7 @@ MG_HD uint32_t cell_from_triple(uint32_t type, uint32_t color, uint32_t state) {
 // (core/world_object.py:65-67,196-212) and Grid.encode writes for None (core/grid.py:260-263).
 MG_HD uint32_t cell_triple(uint32_t code) {
   uint32_t t = code & 15u, c = (code >> 4) & 7u;
+  if (t == T_AGENT_MARK) return (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | (c << 16);   // wrappers.py:422-424
   uint32_t st = t >= T_DOOR_CLOSED ? t - 10u : 0u;
   t = t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t;
   return t | (c << 8) | (st << 16);
@@ -55,23 +64,21 @@ MG_HD uint32_t cell_triple(uint32_t code) {
 constexpr uint32_t WALKABLE_MASK = (1u << T_EMPTY) | (1u << T_FLOOR) | (1u << T_DOOR) | (1u << T_GOAL) | (1u << T_LAVA);
 // can_pickup (world_object.py:243,265,277)
 constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX);
-// NOT see_behind (world_object.py:164,181-182): wall, closed door, locked door
-constexpr uint32_t OPAQUE_MASK = (1u << T_WALL) | (1u << T_DOOR_CLOSED) | (1u << T_DOOR_LOCKED);
 
 MG_HD bool cell_walkable(uint32_t code) { return (WALKABLE_MASK >> (code & 15u)) & 1u; }
 MG_HD bool cell_pickable(uint32_t code) { return (PICKUP_MASK >> (code & 15u)) & 1u; }
-MG_HD bool cell_transparent(uint32_t code) { return !((OPAQUE_MASK >> (code & 15u)) & 1u); }
+MG_HD bool cell_transparent(uint32_t code) { return !(code & OPAQUE_BIT); }
 
 // Door.toggle (world_object.py:184-194) / Box.toggle (290-293, contains is None on this path) on a cell code.
 // Returns the new code (unchanged when toggling does nothing).
 MG_HD uint32_t cell_toggle(uint32_t code, uint32_t carry) {
-  uint32_t t = code & 15u;
+  const uint32_t t = code & 15u, col = (code >> 4) & 7u;
   if (t == T_DOOR_LOCKED) {
-    bool has_key = (carry & 15u) == T_KEY && ((carry >> 4) & 7u) == ((code >> 4) & 7u);
-    return has_key ? ((code & ~15u) | T_DOOR) : code;
+    bool has_key = (carry & 15u) == T_KEY && ((carry >> 4) & 7u) == col;
+    return has_key ? make_cell(T_DOOR, col) : code;
   }
-  if (t == T_DOOR) return (code & ~15u) | T_DOOR_CLOSED;
-  if (t == T_DOOR_CLOSED) return (code & ~15u) | T_DOOR;
+  if (t == T_DOOR) return make_cell(T_DOOR_CLOSED, col);
+  if (t == T_DOOR_CLOSED) return make_cell(T_DOOR, col);
   if (t == T_BOX) return CELL_EMPTY;
   return code;
 }

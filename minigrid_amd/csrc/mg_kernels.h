@@ -24,7 +24,6 @@ namespace mg {
 constexpr int VIEW = 7;
 constexpr int VIEW_CELLS = VIEW * VIEW;        // 49
 constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
-constexpr int STEP_THREADS = 256;              // 4 waves cooperate on one group of 64 envs
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
@@ -42,9 +41,8 @@ struct StepParams {
   unsigned long long* counters;
   // config
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen;
-  int off_trow, off_T, off_lut, off_act, TSB;   // LDS carve-up (bytes); TSB = T row stride in bytes
+  int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
-  uint32_t cells_magic;   // ceil(2^32 / cells)
   long long env_base;
 };
 
@@ -69,16 +67,6 @@ MG_D uint32_t load_action(const StepParams& P, int e) {
   return (v < 0 || v > 255) ? 255u : (uint32_t)v;
 }
 
-// 12-byte output chunk = 4 consecutive (type, colour, state) triples
-struct __attribute__((aligned(4))) Chunk12 { uint32_t a, b, c; };
-MG_D Chunk12 pack_triples(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
-  Chunk12 o;
-  o.a = t0 | (t1 << 24);
-  o.b = (t1 >> 8) | (t2 << 16);
-  o.c = (t2 >> 16) | (t3 << 8);
-  return o;
-}
-
 // bits k in [0,6] with 0 <= c0 + s*k < L (s = +1 or -1): the in-bounds run of a view row/column
 MG_D uint32_t inb_mask7(int c0, int s, int L) {
   const int lo = s > 0 ? max(0, -c0) : max(0, c0 - (L - 1));
@@ -91,17 +79,21 @@ MG_D uint32_t inb_mask7(int c0, int s, int L) {
 // k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
 // verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
-// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.
+// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.  WPG = wavefronts per group of 64 envs (1, 2 or 4).
 //
-// One 256-thread workgroup = 64 consecutive envs.  Lane l of EVERY wave is env l: the scalar part (dynamics, ~100
-// instructions) is computed redundantly by the 4 waves, the cell-parallel parts (view gather / encode / output) are
-// split across them, so the dependent chain per wave is ~4x shorter and a CU holds 4x more waves than with one
-// lane per env alone.  LDS: the 64 grids (staged with coalesced 16 B/lane loads), per-env transparency rows, the
-// observation as one byte code per cell in output order, and a 256-entry code -> (type,colour,state) table.
+// One workgroup = 64 consecutive envs; lane l of EVERY wave is env l.  The kernel is VALU-issue bound (profiles/),
+// so the split is chosen to minimise instructions while keeping the chip full: the per-env scalar dynamics (~150
+// instructions) are recomputed by each wave; view rows / grid columns are dealt round-robin to the waves; the
+// sequential process_vis pass runs in ONE wave and is shared through LDS; the host picks WPG so that a launch has
+// >= ~4 waves per SIMD (small batches: 4, large batches: 1 = no redundant work at all).
+// LDS: the 64 staged grids (coalesced 16 B/lane loads) between two guard bands so that out-of-grid view cells
+// need no address clamp, per-env opacity rows, the visibility mask, the observation as final output bytes (copied
+// out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
 // ======================================================================================================
-template <int MODE>
-__global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
+template <int MODE, int WPG>
+__global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NT = 64 * WPG;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -110,16 +102,21 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
   const bool active = e < P.N;
   const int nvalid = min(64, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
-  uint8_t* sgrid = smem;
+  uint8_t* sgrid = smem + P.off_grid;
   uint8_t* strow = smem + P.off_trow;
+  unsigned long long* svis = (unsigned long long*)(smem + P.off_vis);
   uint8_t* sT = smem + P.off_T;
   uint32_t* slut = (uint32_t*)(smem + P.off_lut);
   uint8_t* sact = smem + P.off_act;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
+  auto block_sync = [&]() {
+    if constexpr (WPG == 1) { MG_WAVE_LDS_SYNC(); } else { __syncthreads(); }
+  };
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
-  slut[tid] = cell_triple((uint32_t)tid);
+#pragma unroll
+  for (int k = tid; k < 256; k += NT) slut[k] = cell_triple((uint32_t)k);
   if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
   {
     // stage the 64 grids: 16 B per lane, fully coalesced; an env whose previous step ended its episode takes the
@@ -127,7 +124,7 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
     const int cpe = CS >> 4;
     const int nchunks = nvalid * cpe;
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
-    for (int c = tid; c < nchunks; c += STEP_THREADS) {
+    for (int c = tid; c < nchunks; c += NT) {
       const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
       const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
       const uint64_t srec = P.agent[env0 + el];
@@ -140,15 +137,15 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
   }
-  __syncthreads();
+  block_sync();
 
   Agent a = agent_unpack(rec);
-  uint8_t* mygrid = sgrid + lane * GS;
+  const uint8_t* mygrid = sgrid + lane * GS;
   const uint32_t act = sact[lane];
   double reward = 0.0;
   uint32_t term = 0, trunc = 0, errbits = 0;
   bool rec_dirty = false;
-  // The staged LDS grid is READ-ONLY after the barrier: the 4 waves recompute the dynamics redundantly, so a wave
+  // The staged LDS grid is READ-ONLY after the barrier: the waves recompute the dynamics redundantly, so a wave
   // that wrote the toggled/picked/dropped cell back into LDS would be seen by a slower wave as its *input*.
   // Instead the one cell an action can change is patched on the fly.  It can only change under pickup/drop/toggle,
   // which leave the pose alone, so it is always the cell straight ahead: view cell (3,5).
@@ -207,25 +204,28 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
       if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
-      if ((term | trunc) && wave == 0) atomicAdd(&P.counters[1], 1ull);
     }
+  }
+  if (wave == 0 && P.phase == PHASE_STEP) {
+    const unsigned long long fin = __ballot(active && (term | trunc));   // episodes finished in this group
+    if (fin && lane == 0) atomicAdd(&P.counters[1], (unsigned long long)__popcll(fin));
   }
 
   // per-env scalar outputs, spread over the waves (each wave holds identical values)
   if (active) {
     if (wave == 0) { if (rec_dirty) P.agent[e] = agent_pack(a); if (errbits) atomicOr(P.err, errbits); }
-    else if (wave == 1) P.reward[e] = reward;
-    else if (wave == 2) { P.term[e] = (uint8_t)term; P.trunc[e] = (uint8_t)trunc; }
-    else { P.dir_out[e] = (uint8_t)a.dir; P.mission_out[e] = (uint8_t)a.mission; }
+    if (wave == 1 % WPG) P.reward[e] = reward;
+    if (wave == 2 % WPG) { P.term[e] = (uint8_t)term; P.trunc[e] = (uint8_t)trunc; }
+    if (wave == 3 % WPG) { P.dir_out[e] = (uint8_t)a.dir; P.mission_out[e] = (uint8_t)a.mission; }
   }
 
-  int obs_cells;
+  const int obe = P.OBE;
   if (MODE == 0) {
-    obs_cells = VIEW_CELLS;
     // ---- gen_obs_grid: closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
     //      view cell (vx,vy) is world cell agent + f*(6-vy) + r*(vx-3), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
     //      outside the grid -> grey wall (grid.py:136-139).  wx depends on only one of vx/vy and wy on the other,
     //      so in-bounds-ness is (column mask)[vx] & (row mask)[vy]. ----
+    constexpr int RPW = (VIEW + WPG - 1) / WPG;                 // view rows per wave: rows wave, wave+WPG, ...
     const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
     const int rx = -fyv, ry = fxv;
     const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
@@ -233,107 +233,91 @@ __global__ void __launch_bounds__(STEP_THREADS) k_step(const StepParams P) {
     const uint32_t rowmask = horiz ? inb_mask7((int)a.x + 6 * fxv, -fxv, W) : inb_mask7((int)a.y + 6 * fyv, -fyv, H);
     const int SR = ry * W + rx;                                 // linear index step per vx
     const int SU = -(fyv * W + fxv);                            // linear index step per vy
-    const int lbase = lane * GS;
-    const int base = lbase + ((int)a.y + 6 * fyv - 3 * ry) * W + ((int)a.x + 6 * fxv - 3 * rx);
-    const int lo = lbase, hi = lbase + P.cells - 1;
-    // opaque-type bitmap replicated for 5-bit indexing by (code & 31): bit4 of a code is a colour bit
-    const uint32_t OPQ32 = OPAQUE_MASK | (OPAQUE_MASK << 16);
-    uint32_t mycell[2][VIEW];
+    // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
+    const uint8_t* vbase = mygrid + ((int)a.y + 6 * fyv - 3 * ry) * W + ((int)a.x + 6 * fxv - 3 * rx);
+    uint32_t mycell[RPW][VIEW];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int vy = wave + 4 * r;                              // rows {w, w+4}; wave 3 has only row 3
+    for (int r = 0; r < RPW; r++) {
+      const int vy = wave + WPG * r;
       if (vy < VIEW) {
-        const int rowbase = base + vy * SU;
+        const uint8_t* rowp = vbase + vy * SU;
         const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
         uint32_t opq = 0;
 #pragma unroll
         for (int vx = 0; vx < VIEW; vx++) {
-          const int addr = min(max(rowbase + vx * SR, lo), hi);
-          const uint32_t raw = sgrid[addr];
+          const uint32_t raw = rowp[vx * SR];
           const uint32_t valid = 0u - ((cm >> vx) & 1u);
           uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-          if (r == 1 && vx == VIEW / 2) c = (wave == 1 && dirty_idx >= 0) ? dirty_code : c;   // view (3,5)
+          if (vx == VIEW / 2 && vy == VIEW - 2) c = dirty_idx >= 0 ? dirty_code : c;   // view (3,5)
           mycell[r][vx] = c;
-          opq |= ((OPQ32 >> (c & 31u)) & 1u) << vx;
+          opq |= (c >> 7) << vx;
         }
-        strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);          // transparency bits of this view row
+        if (!P.see_through) strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);   // transparency bits of this view row
       }
     }
-    __syncthreads();
-    // ---- process_vis (grid.py:291-328), bit-parallel rows bottom-up; every wave needs the whole mask ----
-    unsigned long long vis = 0;
-    if (P.see_through) {
-      vis = (1ull << VIEW_CELLS) - 1ull;
-    } else {
-      const uint2 tw = *(const uint2*)(strow + lane * 8);
-      uint32_t m = 1u << (VIEW / 2);
+    // ---- process_vis (grid.py:291-328), bit-parallel rows bottom-up, in ONE wave; shared through LDS ----
+    unsigned long long vis = (1ull << VIEW_CELLS) - 1ull;
+    if (!P.see_through) {
+      block_sync();
+      if (wave == WPG - 1) {
+        const uint2 tw = *(const uint2*)(strow + lane * 8);
+        uint32_t m = 1u << (VIEW / 2);
+        vis = 0;
 #pragma unroll
-      for (int j = VIEW - 1; j >= 0; j--) {
-        const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
-        uint32_t vr, up;
-        vis_row(m, t, &vr, &up);
-        vis |= (unsigned long long)vr << (7 * j);
-        m = up;
+        for (int j = VIEW - 1; j >= 0; j--) {
+          const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
+          uint32_t vr, up;
+          vis_row(m, t, &vr, &up);
+          vis |= (unsigned long long)vr << (7 * j);
+          m = up;
+        }
+        if (WPG > 1) svis[lane] = vis;
       }
+      if (WPG > 1) { block_sync(); vis = svis[lane]; }
     }
-    // ---- Grid.encode(vis_mask) (grid.py:244-268) as one byte code per cell in image[x][y] order; invisible -> 0,
-    //      the agent's own cell shows what it carries (minigrid_env.py:623-630) ----
+    // ---- Grid.encode(vis_mask) (grid.py:244-268) straight into the output byte image [vx][vy][3]; invisible ->
+    //      (0,0,0); the agent's own cell shows what it carries (minigrid_env.py:623-630) ----
+    uint8_t* myT = sT + lane * obe;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int vy = wave + 4 * r;
+    for (int r = 0; r < RPW; r++) {
+      const int vy = wave + WPG * r;
       if (vy < VIEW) {
         const uint32_t vrow = (uint32_t)(vis >> (7 * vy)) & 0x7Fu;
-        uint8_t* trow = sT + lane * VIEW_CELLS + vy;
 #pragma unroll
         for (int vx = 0; vx < VIEW; vx++) {
           uint32_t c = mycell[r][vx];
-          if (vx == VIEW / 2) c = (vy == VIEW - 1) ? (a.carry ? a.carry : (uint32_t)CELL_EMPTY) : c;
-          trow[vx * VIEW] = (uint8_t)(c & (0u - ((vrow >> vx) & 1u)));
+          if (vx == VIEW / 2 && vy == VIEW - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+          const uint32_t tri = slut[c & (0u - ((vrow >> vx) & 1u))];
+          uint8_t* o = myT + (vx * VIEW + vy) * 3;
+          o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
         }
       }
     }
   } else {
-    obs_cells = P.cells;
-    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir).
-    //      The agent cell is emitted as internal code 0x80 | dir (decoded by the table below). ----
-    uint8_t* trow = sT + lane * P.TSB;
-    for (int x = wave; x < W; x += 4) {
+    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir) ----
+    uint8_t* myT = sT + lane * obe;
+    const int aidx = (int)a.y * W + (int)a.x;
+    for (int x = wave; x < W; x += WPG) {
       for (int y = 0; y < H; y++) {
-        uint32_t c = mygrid[y * W + x];
-        if (y * W + x == dirty_idx) c = dirty_code;
-        if (x == (int)a.x && y == (int)a.y) c = 0x80u | a.dir;
-        trow[x * H + y] = (uint8_t)c;
+        const int idx = y * W + x;
+        uint32_t c = mygrid[idx];
+        if (idx == dirty_idx) c = dirty_code;
+        if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
+        const uint32_t tri = slut[c];
+        uint8_t* o = myT + (x * H + y) * 3;
+        o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
       }
     }
-    if (tid < 4) slut[0x80 + tid] = (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | ((uint32_t)tid << 16);
   }
-  __syncthreads();
+  block_sync();
 
-  // ---- the block's observations are one contiguous byte stream = the flat concatenation of 3-byte triples.
-  //      Each lane decodes 4 consecutive cell codes through the LDS table and stores 12 bytes; a wave stores
-  //      768 contiguous bytes per instruction. ----
+  // ---- the group's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
   {
-    uint8_t* obase = P.obs + (size_t)env0 * (size_t)(obs_cells * 3);
-    const int ntriples = nvalid * obs_cells;
-    const int nfull = ntriples >> 2;
-    const int pad = P.TSB - obs_cells;                       // 0, or 4 when obs_cells % 4 == 0 (bank spreading)
-    for (int c = tid; c < nfull; c += STEP_THREADS) {
-      uint32_t off = 4u * (uint32_t)c;
-      if (MODE == 1 && pad) off += (uint32_t)pad * __umulhi(off, P.cells_magic);
-      const uint32_t codes = *(const uint32_t*)(sT + off);   // rows are dense (or padded by 4): always dword-aligned
-      const uint32_t t0 = slut[codes & 0xFF], t1 = slut[(codes >> 8) & 0xFF];
-      const uint32_t t2 = slut[(codes >> 16) & 0xFF], t3 = slut[codes >> 24];
-      *(Chunk12*)(obase + 12 * (size_t)c) = pack_triples(t0, t1, t2, t3);
-    }
-    const int rem = ntriples & 3;                            // ragged tail: only when nvalid*cells is not a multiple of 4
-    if (rem && tid < rem) {
-      uint32_t q = (uint32_t)(nfull * 4 + tid);
-      uint32_t off = q;
-      if (MODE == 1 && pad) off += (uint32_t)pad * __umulhi(q, P.cells_magic);
-      const uint32_t v = slut[sT[off]];
-      uint8_t* p = obase + 3 * (size_t)q;
-      p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16);
-    }
+    uint8_t* obase = P.obs + (size_t)env0 * (size_t)obe;          // 64*obe is a multiple of 16
+    const int nbytes = nvalid * obe;
+    const int nvec = nbytes >> 4;
+    for (int c = tid; c < nvec; c += NT) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
+    for (int b = (nvec << 4) + tid; b < nbytes; b += NT) obase[b] = sT[b];   // ragged last group only
   }
   if (P.phase == PHASE_STEP && tid == 0 && blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
 }
