@@ -47,6 +47,33 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int) -
     return b
 
 
+def pmc_traffic_bytes(workload: str, n_per_gpu: int):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload>.txt, separate --pmc runs, written by profiles/collect.sh).
+    Units and gfx950 correction as MI355X_MICROARCH.md prescribes: the counters are in KiB (x1024); FETCH_SIZE reads
+    exactly half of a wide (16 B/lane) coalesced read stream on gfx950, so it is doubled; WRITE_SIZE is taken as is.
+    Counters cannot be read from inside the timed process, so this is the committed measurement, or None."""
+    import glob
+    import re
+    if n_per_gpu != WORKLOADS[workload][1]:
+        return None
+    best = None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = os.path.join(d, f"pmc_{c}_{workload}.txt")
+            if not os.path.exists(f):
+                break
+            for line in open(f):
+                m = re.match(rf"{c},void mg::k_step<[^,]*(?:, \d+)?>,calls=\d+,mean=([0-9.]+)", line)
+                if m:
+                    vals[c] = float(m.group(1))
+                    break
+        if len(vals) == 2:
+            best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return best
+
+
 def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
     """Time the oracle's C port on the host cores this process may use (one independent batch per thread; ctypes
     drops the GIL).  Bounded: a short all-thread calibration sizes the sample to ~budget_s seconds."""
@@ -106,25 +133,29 @@ def main():
     env_id, n_per_gpu, obs_mode = WORKLOADS[args.workload]
     if args.envs_per_gpu:
         n_per_gpu = args.envs_per_gpu
-    env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, env_index_base=rank * n_per_gpu,
-                      output="torch")
+    gather = bool(args.gather_obs and world > 1)
+    if world > 1:
+        # weak scaling: the global batch is world x n_per_gpu envs; rank g owns the contiguous block g (seed = global
+        # env index), no data-path collective unless --gather-obs asks for the optional all-gather of the obs tensor
+        from minigrid_amd.sharded import ShardedVecEnv
+        senv = ShardedVecEnv(env_id, n_per_gpu * world, gather=gather, obs_mode=obs_mode, device=local_rank)
+        env = senv.local
+        assert env.env_index_base == rank * n_per_gpu and env.num_envs == n_per_gpu
+    else:
+        senv = None
+        env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch")
     env.reset(seed=0)
     env.sync()
 
-    gathered = None
-    if args.gather_obs and world > 1:
-        img = env.torch_outputs()["image"]
-        gathered = torch.empty((world,) + tuple(img.shape), dtype=img.dtype, device=img.device)
-
     def run(k, seed):
-        if gathered is None:
+        if not gather:
             env.rollout(k, action_seed=seed, fused=bool(args.fused))
         else:
             img = env.torch_outputs()["image"]
             for _ in range(k):
                 env.rollout(1, action_seed=seed)
-                env.sync()
-                dist.all_gather_into_tensor(gathered, img)
+                env.sync()                       # the env runs on its own HIP stream; RCCL on torch's
+                senv.all_gather(img)
 
     def barrier():
         if world > 1:
@@ -162,9 +193,11 @@ def main():
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
                        "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
                        "launch": "fused-rollout" if args.fused else "one k_step launch per step",
-                       "gather_obs": bool(gathered is not None), "episodes_finished_rank0": counters["episodes"]},
+                       "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu),
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": bpe * n_per_gpu,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:

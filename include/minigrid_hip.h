@@ -89,7 +89,9 @@ typedef struct mg_config {
   int32_t num_crossings;      /* Crossing (crossing.py:92) */
   int32_t obstacle_type;      /* Crossing: 9 = lava, 2 = wall (crossing.py:93) */
   int32_t num_dists;          /* GoToRedBall (goto.py:129) */
-  int32_t reserved[7];
+  int32_t null_stream_sync;   /* library-created stream only: 1 = blocking stream (hipStreamDefault), i.e. ordered
+                                 with the legacy NULL stream a framework such as PyTorch launches on; 0 = non-blocking */
+  int32_t reserved[6];
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
 } mg_config;
 

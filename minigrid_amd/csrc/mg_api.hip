@@ -221,7 +221,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)
   TRY_OR_FREE(hipSetDevice(device));
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
-  else { TRY_OR_FREE(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+  else {
+    TRY_OR_FREE(hipStreamCreateWithFlags(&e->stream, cfg->null_stream_sync ? hipStreamDefault : hipStreamNonBlocking));
+    e->own_stream = true;
+  }
   TRY_OR_FREE(hipEventCreate(&e->ev0));
   TRY_OR_FREE(hipEventCreate(&e->ev1));
   const size_t N = (size_t)e->N;

@@ -75,6 +75,16 @@ class MiniGridVecEnv(_VectorEnvBase):
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, env_index_base=self.env_index_base)
+        if output == "torch" and stream is None:
+            # outputs are handed out as torch tensors: run stream-ordered with torch.  A non-default current stream is
+            # borrowed; the legacy NULL stream (torch's default) cannot be passed as a handle, so the library's own
+            # stream is created blocking, which orders it with NULL-stream work in both directions.
+            import torch
+            ts = int(torch.cuda.current_stream().cuda_stream)
+            if ts:
+                stream = ts
+            else:
+                cfg.null_stream_sync = 1
         self._cfg = cfg
         h = C.c_void_p()
         rc = self._lib.mg_create(C.byref(cfg), -1 if device is None else int(device), stream, C.byref(h))
@@ -220,6 +230,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                 a = a.astype(np.int64, copy=False)
                 dt = B.ACT_I64
             a = np.ascontiguousarray(a)
+            self._last_actions = a          # the async H2D copy may still read it after this call returns
             rc = self._lib.mg_step(self._h, self._p(a), dt, 0)
         B.check(rc, self._h)
         obs, rew, term, trunc = self._collect()

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_config_struct_layout_matches_header():
-    # 17 int32 + 7 reserved int32 + one int64 = 104 bytes, int64 8-aligned at offset 96
+    # 18 int32 + 6 reserved int32 + one int64 = 104 bytes, int64 8-aligned at offset 96
     assert C.sizeof(B.MgConfig) == 104
     assert B.MgConfig.env_index_base.offset == 96
     assert C.sizeof(B.MgOutputs) == 64

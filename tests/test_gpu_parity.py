@@ -261,3 +261,34 @@ def test_device_rollout_counts_and_torch_views():
     env.sync()
     assert obs["image"].data_ptr() == t["image"].data_ptr() and rew.dtype == torch.float64
     env.close()
+
+
+def test_sharded_env_single_rank_group_on_gpu():
+    """ShardedVecEnv over the real HIP shard (a 1-rank process group: the only size a 1-GPU box offers; the 2-rank
+    logic is covered on CPU by tests/test_sharded_gloo.py)."""
+    import socket
+
+    import torch.distributed as dist
+    from minigrid_amd.sharded import ShardedVecEnv
+    from oracle import oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        n = 1000
+        env = ShardedVecEnv("MiniGrid-DoorKey-8x8-v0", n, gather=True)
+        orc = O.OracleVec("MiniGrid-DoorKey-8x8-v0", n)
+        obs, _ = env.reset(seed=3)
+        o_obs, _, _ = orc.reset(seeds=np.arange(3, 3 + n, dtype=np.uint64))
+        env.sync()
+        assert obs["image"].is_cuda and (obs["image"].cpu().numpy() == o_obs).all()
+        rng = np.random.default_rng(0)
+        for _ in range(30):
+            a = rng.integers(0, 7, n, dtype=np.uint8)
+            obs, rew, term, trunc, _ = env.step(a)
+            env.sync()
+            oo, orew, oterm, otrunc, _, _ = orc.step(a)
+            assert (obs["image"].cpu().numpy() == oo).all() and rew.cpu().numpy().tobytes() == orew.tobytes()
+            assert (term.cpu().numpy() == oterm).all() and (trunc.cpu().numpy() == otrunc).all()
+        env.close()
+    finally:
+        dist.destroy_process_group()

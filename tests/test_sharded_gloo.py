@@ -1,0 +1,115 @@
+"""The N>1 path on CPU: two processes, `gloo` backend, the product's ShardedVecEnv driving an ORACLE-backed shard
+(the HIP shard needs a GPU; the sharding / seeding / gather logic under test is the same code either way).
+Checks that a batch split over 2 ranks is bit-identical to the same batch in one process, that ragged shard sizes
+work, and that bench.py's max-over-ranks timing reduction runs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+from minigrid_amd.sharded import ShardedVecEnv, shard_range
+
+
+class OracleShard:
+    """Stand-in for MiniGridVecEnv with the same constructor/step/reset surface, computed by the CPU oracle."""
+
+    def __init__(self, env_id, num_envs, *, env_index_base=0, obs_mode="partial", **_):
+        from oracle import oracle as O
+        self.o = O.OracleVec(env_id, num_envs, full_obs=(obs_mode == "full"))
+        self.num_envs, self.env_index_base = num_envs, env_index_base
+        self._missions = np.asarray(self.o.missions)
+
+    def _obs(self, img, d, m):
+        return {"image": img, "direction": d.astype(np.int64), "mission": self._missions[m]}
+
+    def reset(self, *, seed=None, options=None):
+        if isinstance(seed, (int, np.integer)):
+            seeds = np.uint64(seed) + np.uint64(self.env_index_base) + np.arange(self.num_envs, dtype=np.uint64)
+        else:
+            seeds = None if seed is None else np.asarray(seed, np.uint64)
+        mask = None if not options else options.get("reset_mask")
+        return self._obs(*self.o.reset(seeds=seeds, mask=mask)), {}
+
+    def step(self, actions):
+        img, rew, term, trunc, d, m = self.o.step(np.asarray(actions, np.uint8))
+        return self._obs(img, d, m), rew, term, trunc, {}
+
+    def close(self):
+        pass
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, env_id, n, full, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = ShardedVecEnv(env_id, n, gather=True, make=OracleShard, obs_mode="full" if full else "partial")
+        assert (env.lo, env.hi) == shard_range(n, rank, world)
+        obs, _ = env.reset(seed=5)
+        log = [obs["image"].numpy().copy(), obs["direction"].numpy().copy()]
+        rng = np.random.default_rng(3)
+        for t in range(40):
+            a = rng.integers(0, 7, n, dtype=np.uint8)           # every rank draws the same global action vector
+            obs, rew, term, trunc, _ = env.step(a if t % 2 == 0 else a[env.lo:env.hi])   # global or local slice
+            log += [obs["image"].numpy().copy(), rew.numpy().copy(), term.numpy().copy(), trunc.numpy().copy(),
+                    np.asarray(obs["mission"] == env._missions[0])]
+        # bench.py's timing reduction: MAX over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), *log)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env_id,n,full", [("MiniGrid-DoorKey-8x8-v0", 64, False),
+                                            ("MiniGrid-LavaCrossingS9N1-v0", 37, True),     # ragged: 19 + 18
+                                            ("BabyAI-GoToRedBall-v0", 50, False)])
+def test_two_rank_batch_equals_single_process_batch(tmp_path, env_id, n, full):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), env_id, n, full, str(tmp_path)), nprocs=world, join=True)
+    # single-process truth
+    ref = OracleShard(env_id, n, obs_mode="full" if full else "partial")
+    obs, _ = ref.reset(seed=5)
+    want = [obs["image"], obs["direction"]]
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        a = rng.integers(0, 7, n, dtype=np.uint8)
+        obs, rew, term, trunc, _ = ref.step(a)
+        want += [obs["image"], rew, term, trunc, obs["mission"] == ref._missions[0]]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        arrs = [got[k] for k in got.files]
+        assert len(arrs) == len(want)
+        for i, (g, w) in enumerate(zip(arrs, want)):
+            assert g.shape == np.asarray(w).shape and (g == w).all(), (r, i)
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 2, 7, 8, 9, 1000, 1 << 20):
+        for w in (1, 2, 3, 4, 8):
+            if n < w:
+                with pytest.raises(ValueError):
+                    shard_range(n, 0, w)
+                continue
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
