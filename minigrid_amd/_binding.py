@@ -56,8 +56,8 @@ def load():
             import torch  # noqa: F401  (side effect: its libamdhip64.so becomes the process's HIP runtime)
         except Exception:
             pass
-    path = _build.LIB
-    if not os.path.exists(path) or os.environ.get("MINIGRID_AMD_REBUILD", "0") == "1":
+    path = os.environ.get("MINIGRID_AMD_LIB") or _build.LIB      # override: an alternative build of the same ABI
+    if path == _build.LIB and (not os.path.exists(path) or os.environ.get("MINIGRID_AMD_REBUILD", "0") == "1"):
         path = _build.build()
     L = C.CDLL(path)
     vp, i, u64 = C.c_void_p, C.c_int, C.c_uint64

@@ -38,7 +38,9 @@ struct mg_env {
   uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
   unsigned long long* counters = nullptr;
   // bookkeeping
-  uint32_t launches = 0;      // parity of the refill-queue counter
+  uint32_t launches = 0;      // k_step launches so far (refill queue slot = launches % 3)
+  int gen_blocks = 0;         // generator workgroups at the head of every k_step launch
+  int gen_cap_words = 0;      // their draw-buffer capacity (words), limited by the launch's LDS size
   uint32_t t = 0;             // rollout step counter (Philox action counter)
   std::string last_error;
 };
@@ -76,24 +78,30 @@ static GenParams gen_params(const mg_env* e) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------
-static int launch_generate(mg_env* e, bool to_spare, bool queue_mode, const uint8_t* d_mask) {
+// GenArgs common to the stand-alone generator launches and the generator role inside k_step
+static GenArgs gen_args(mg_env* e, bool to_spare) {
   GenArgs A;
   A.gp = gen_params(e);
   A.dst_grid = to_spare ? e->spare_grid : e->grid;
   A.dst_agent = to_spare ? e->spare_agent : e->agent;
   A.rng = e->rng;
   A.rng_snap = to_spare ? e->rng_snap : nullptr;
-  A.queue = queue_mode ? e->queue : nullptr;
-  // the step launched just before this used counter (launches-1)&1; clear the other one for the next step
-  A.count = queue_mode ? e->qcount + ((e->launches - 1) & 1) : nullptr;
-  A.zero_count = queue_mode ? e->qcount + (e->launches & 1) : nullptr;
-  A.mask = d_mask; A.err = e->err; A.counters = e->counters;
-  A.N = e->N; A.CS = e->CS; A.GS = e->GS;
-  // one wavefront per episode, 4 per workgroup; the queue length is only known on the device, so queue mode
-  // launches a fixed grid (most steps enqueue a few hundred envs: <= 1 episode per wave) and strides over it
+  A.queue = nullptr; A.count = nullptr; A.zero_count = nullptr; A.mask = nullptr;
+  A.err = e->err; A.counters = e->counters;
+  A.N = e->N; A.CS = e->CS; A.cap_words = 2048;
+  return A;
+}
+
+// Stand-alone generator launch.  queue_slot < 0: direct mode over all envs (optionally masked);
+// otherwise: process refill queue `queue_slot` (its length is only known on the device).
+static int launch_generate(mg_env* e, bool to_spare, int queue_slot, const uint8_t* d_mask) {
+  GenArgs A = gen_args(e, to_spare);
+  const bool queue_mode = queue_slot >= 0;
+  if (queue_mode) { A.queue = e->queue + (size_t)queue_slot * e->N; A.count = e->qcount + queue_slot; }
+  A.mask = d_mask;
   const int wpb = GEN_THREADS / 64;
   int blocks = std::min((e->N + wpb - 1) / wpb, queue_mode ? 1024 : 8192);
-  size_t lds = (size_t)wpb * e->CS;
+  size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
     hipLaunchKernelGGL(k_generate<WavePhilox>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
   else
@@ -102,16 +110,28 @@ static int launch_generate(mg_env* e, bool to_spare, bool queue_mode, const uint
   return MG_OK;
 }
 
+// The spares consumed by the most recent k_step launch are refilled by the generator role of the NEXT k_step
+// launch.  Entry points that read or overwrite spares / stream positions first bring them up to date.
+static int flush_refills(mg_env* e) {
+  if (e->static_gen || e->launches == 0) return MG_OK;
+  const int slot = (int)((e->launches - 1) % 3);
+  int rc = launch_generate(e, /*to_spare=*/true, slot, nullptr);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemsetAsync(e->qcount + slot, 0, sizeof(uint32_t), e->stream));
+  return MG_OK;
+}
+
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.grid = e->grid; P.spare_grid = e->spare_grid; P.agent = e->agent; P.spare_agent = e->spare_agent;
   P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
   P.obs = e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
-  P.reward_lut = e->reward_lut; P.refill_queue = e->queue; P.refill_count = e->qcount + (e->launches & 1);
+  P.reward_lut = e->reward_lut;
+  P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + (e->launches % 3);
   P.err = e->err; P.counters = e->counters;
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.phase = phase; P.static_gen = e->static_gen;
+  P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks;
   P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
   P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->obs_bytes;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
@@ -120,11 +140,24 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 }
 
 static int launch_step(mg_env* e, const StepParams& P) {
-  const int blocks = (e->N + 63) / 64;                  // one workgroup of wpg wavefronts per 64 consecutive envs
+  // grid = [gen_blocks generator workgroups | one workgroup of wpg wavefronts per 64 consecutive envs].
+  // Launch L appends the envs whose spare it consumed to refill queue L%3; its generator role drains queue (L-1)%3
+  // and clears the counter of queue (L+1)%3, which nobody touches during launch L.
+  const int blocks = (e->N + 63) / 64 + e->gen_blocks;
   dim3 grid(blocks), block(64 * e->wpg);
   const size_t lds = (size_t)e->lds_bytes;
   const bool partial = e->cfg.obs_mode == MG_OBS_PARTIAL;
-#define MG_LAUNCH_STEP(MODE, WPG) hipLaunchKernelGGL((k_step<MODE, WPG>), grid, block, lds, e->stream, P)
+  const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
+  GenArgs A = gen_args(e, /*to_spare=*/true);
+  const uint32_t L = e->launches;
+  A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + (L + 2) % 3;
+  A.zero_count = e->qcount + (L + 1) % 3;
+  A.cap_words = e->gen_cap_words;
+#define MG_LAUNCH_STEP(MODE, WPG)                                                                         \
+  do {                                                                                                    \
+    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox>), grid, block, lds, e->stream, P, A);   \
+    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64>), grid, block, lds, e->stream, P, A);           \
+  } while (0)
   switch (e->wpg) {
     case 1: if (partial) MG_LAUNCH_STEP(0, 1); else MG_LAUNCH_STEP(1, 1); break;
     case 2: if (partial) MG_LAUNCH_STEP(0, 2); else MG_LAUNCH_STEP(1, 2); break;
@@ -133,7 +166,6 @@ static int launch_step(mg_env* e, const StepParams& P) {
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
   e->launches++;
-  if (!e->static_gen) return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/true, nullptr);
   return MG_OK;
 }
 
@@ -206,6 +238,16 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_act = e->off_lut + 256 * 4;
     e->lds_bytes = e->off_act + 64;
   }
+  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
+  if (!e->static_gen) {
+    // generator role of k_step: ONE generating wave per generator workgroup, which may use the whole LDS
+    // allocation of the launch for its draw buffer (>= 1024 draws; the buffer only limits how many whole-map
+    // retries a GoToRedBall episode may take before ERR_GENERATOR: 1024 draws ~ 17 retries, p ~ 1e-14)
+    const int min_lds = gen_wave_lds_bytes(e->CS, 1024);
+    if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
+    e->gen_cap_words = std::min(4096, (e->lds_bytes - e->CS - GEN_SBASE_BYTES) / 4 - 4);
+    e->gen_blocks = std::min(1024, e->N);
+  }
   {
     // waves per 64-env group.  Measured on MI355X (profiles/r1/sweep_wpg.txt): 4 wins at every batch size from
     // 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
@@ -214,7 +256,6 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) e->wpg = v; }
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
-  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
 
   mg_env* env = e;   // for HIP_TRY
@@ -244,13 +285,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(dalloc(&e->dir, N));
   TRY_OR_FREE(dalloc(&e->mission, N));
   TRY_OR_FREE(dalloc(&e->reward_lut, (size_t)cfg->max_steps + 1));
-  TRY_OR_FREE(dalloc(&e->queue, N));
-  TRY_OR_FREE(dalloc(&e->qcount, 2));
+  TRY_OR_FREE(dalloc(&e->queue, 3 * N));
+  TRY_OR_FREE(dalloc(&e->qcount, 3));
   TRY_OR_FREE(dalloc(&e->err, 1));
-  TRY_OR_FREE(dalloc(&e->counters, 4));
-  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 2 * sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(dalloc(&e->counters, 16));
+  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 3 * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, 4 * sizeof(unsigned long long), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, 16 * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
@@ -261,8 +302,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (e->lds_bytes > 64 * 1024) {
-    const void* fns[] = { (const void*)k_step<0, 1>, (const void*)k_step<0, 2>, (const void*)k_step<0, 4>,
-                          (const void*)k_step<1, 1>, (const void*)k_step<1, 2>, (const void*)k_step<1, 4> };
+    const void* fns[] = { (const void*)k_step<0, 1, WavePcg64>, (const void*)k_step<0, 2, WavePcg64>, (const void*)k_step<0, 4, WavePcg64>,
+                          (const void*)k_step<1, 1, WavePcg64>, (const void*)k_step<1, 2, WavePcg64>, (const void*)k_step<1, 4, WavePcg64>,
+                          (const void*)k_step<0, 1, WavePhilox>, (const void*)k_step<0, 2, WavePhilox>, (const void*)k_step<0, 4, WavePhilox>,
+                          (const void*)k_step<1, 1, WavePhilox>, (const void*)k_step<1, 2, WavePhilox>, (const void*)k_step<1, 4, WavePhilox> };
     for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   }
 #undef TRY_OR_FREE
@@ -302,6 +345,7 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     d_mask = e->mask;
   }
   const int tb = 256, nb = (N + tb - 1) / tb;
+  { int rc = flush_refills(e); if (rc) return rc; }
   if (seeds) {
     // reset(seed=s): reseed, draw this episode, then draw the spare (episode 2 of the same stream)
     HIP_TRY(e, hipMemcpyAsync(e->seeds, seeds, (size_t)N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
@@ -310,9 +354,9 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     else
       hipLaunchKernelGGL(k_seed<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
     HIP_TRY(e, hipGetLastError());
-    int rc = launch_generate(e, /*to_spare=*/false, /*queue_mode=*/false, d_mask);
+    int rc = launch_generate(e, /*to_spare=*/false, -1, d_mask);
     if (rc) return rc;
-    rc = launch_generate(e, /*to_spare=*/true, /*queue_mode=*/false, d_mask);
+    rc = launch_generate(e, /*to_spare=*/true, -1, d_mask);
     if (rc) return rc;
   } else {
     // reset(): continue each env's own stream == consume the pre-drawn spare
@@ -436,6 +480,7 @@ int mg_get_rng(mg_env* e, uint64_t* out) {
   if (!e || !out) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
+  { int rc = flush_refills(e); if (rc) return rc; }
   // the reference env's stream position "now" is the state BEFORE the spare episode was drawn
   const uint64_t* src = e->static_gen ? e->rng : e->rng_snap;
   std::vector<uint64_t> soa(5 * N);
@@ -449,12 +494,13 @@ int mg_set_rng(mg_env* e, const uint64_t* in) {
   if (!e || !in) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
+  { int rc = flush_refills(e); if (rc) return rc; }
   std::vector<uint64_t> soa(5 * N);
   for (size_t n = 0; n < N; n++) for (int k = 0; k < 5; k++) soa[k * N + n] = in[n * 5 + k];
   HIP_TRY(e, hipMemcpyAsync(e->rng, soa.data(), soa.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   // re-draw every spare from the injected position
-  return launch_generate(e, /*to_spare=*/true, /*queue_mode=*/false, nullptr);
+  return launch_generate(e, /*to_spare=*/true, -1, nullptr);
 }
 
 int mg_timer_start(mg_env* e) {
@@ -477,6 +523,14 @@ int mg_get_counters(mg_env* e, uint64_t out[4]) {
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   return MG_OK;
 }
+
+#ifdef MG_DEBUG_TIMING
+MG_API int mg_debug_stamps(mg_env* e, uint64_t out[12]) {
+  HIP_TRY(e, hipMemcpyAsync(out, e->counters + 4, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  return MG_OK;
+}
+#endif
 
 // ---- host self-test hooks (run the library's inline helpers on the CPU) ----
 int mg_selftest_vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {

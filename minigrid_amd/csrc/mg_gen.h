@@ -22,15 +22,6 @@ struct GenResult {
   bool failed;        // retry bound exhausted
 };
 
-// LDS hand-off inside ONE wave: lanes wrote different addresses, the wave reads them next (DS ops of a wave execute
-// in order; the fences only stop the compiler from moving the accesses across).
-#define MG_WAVE_LDS_SYNC()                                    \
-  do {                                                        \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
-    __builtin_amdgcn_wave_barrier();                          \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
-  } while (0)
-
 // Byte grid owned by one wave, row-major index y*W+x (core/grid.py:28-35,65-78).  get/set take wave-uniform
 // coordinates: every lane reads (broadcast) or writes (same value) the same LDS byte.
 struct GridRef {
@@ -40,10 +31,9 @@ struct GridRef {
   // Grid(width,height) + wall_rect(0,0,W,H) (core/grid.py:28-35,104-108), 64 cells per instruction
   MG_D void clear_with_walls() {
     MG_WAVE_LDS_SYNC();
-    for (int k = lane; k < W * H; k += 64) {
-      const int y = k / W, x = k - y * W;
-      p[k] = (uint8_t)((x == 0 || y == 0 || x == W - 1 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
-    }
+    const bool edge_x = lane == 0 || lane == W - 1;
+    for (int y = 0; y < H; y++)                      // one row per instruction (W <= 25 lanes busy), no division
+      if (lane < W) p[y * W + lane] = (uint8_t)((edge_x || y == 0 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
     MG_WAVE_LDS_SYNC();
   }
   // 8x8 grids only (bit index = y*8+x = lane): cells the reachability flood may pass (None or any door), cells
@@ -69,7 +59,7 @@ MG_D bool place_obj(R& rng, GridRef& g, uint32_t cell, int topx, int topy, int s
   int tries = 0;
   for (;;) {
     if (max_tries >= 0 && tries > max_tries) return false;
-    if (tries > (1 << 20)) return false;          // device safety bound for the unbounded reference loop
+    if (rng.dead()) return false;                 // out of buffered draws: the caller replays with a larger budget
     tries++;
     int x = rand_int(rng, topx, hx);
     int y = rand_int(rng, topy, hy);
@@ -184,7 +174,7 @@ MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 template <class R>
 MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H;
-  for (uint32_t attempt = 0; attempt < 4096; attempt++) {
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     g.clear_with_walls();
     // RoomGrid.place_agent: integers(0,1) for the room draws nothing; loop until the front cell is None or a wall

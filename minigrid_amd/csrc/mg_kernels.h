@@ -40,7 +40,7 @@ struct StepParams {
   const double* reward_lut; uint32_t* refill_queue; uint32_t* refill_count; uint32_t* err;
   unsigned long long* counters;
   // config
-  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen;
+  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen, gen_blocks;
   int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
   long long env_base;
@@ -76,6 +76,100 @@ MG_D uint32_t inb_mask7(int c0, int s, int L) {
 }
 
 // ======================================================================================================
+// Episode generation (the reference's _gen_grid, see mg_gen.h): one wavefront draws one episode.
+// Work list: the refill queue written by k_step, or all envs selected by `mask` (explicit reset(seed=...)).
+// ======================================================================================================
+struct GenArgs {
+  GenParams gp;
+  uint8_t* dst_grid; uint64_t* dst_agent;
+  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state there first
+  const uint32_t* queue; const uint32_t* count;      // queue mode (count read on device)
+  uint32_t* zero_count;                              // a queue counter nobody uses during this launch: cleared
+  const uint8_t* mask;                               // direct mode: optional per-env mask
+  uint32_t* err; unsigned long long* counters;
+  int N, CS;
+  int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
+};
+
+#ifdef MG_DEBUG_TIMING
+// tuning aid (never built into the product library): cycle stamps of the first wave of block 0 -> counters[4..]
+#define MG_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) A.counters[4 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MG_STAMP(k) do { } while (0)
+#endif
+
+MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4]; }
+
+constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
+MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4; }
+
+// wave-cooperative: all 64 lanes of one wave call this with the same `e`; `lds` = gen_wave_lds_bytes() of LDS
+template <class RNG>
+MG_D void generate_one(const GenArgs& A, int e, uint32_t lane, uint8_t* lds) {
+  const size_t N = (size_t)A.N;
+  uint8_t* mygrid = lds;
+  MG_STAMP(1);
+  RNG rng;
+  rng.load(A.rng, N, (size_t)e, lane, lds + A.CS);
+  MG_STAMP(2);
+  if (A.rng_snap && lane < 5u) A.rng_snap[lane * N + (size_t)e] = pick5(rng.w_in, lane);
+  GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
+  for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
+  GenResult out;
+  // draw-budget loop: buffer `budget` draws, run the generator; a pass that ran out of draws is replayed (same
+  // draws, same path) with twice as many.  One refill covers every DoorKey/Crossing episode; GoToRedBall (about 60
+  // draws per whole-map attempt, 15.6 % of attempts rejected) starts with three.
+  const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
+  uint32_t budget = A.gp.kind == 3 ? ((384u + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords : RNG::kRefillWords;
+  for (;;) {
+    budget = min(budget, cap);
+    while (rng.limit < rng.off + budget) rng.refill();
+    MG_STAMP(3);
+    rng.begin_pass();
+    generate_episode(rng, g, A.gp, out);
+    MG_STAMP(4);
+    if (!rng.dead()) break;
+    if (budget >= cap) { out.failed = true; break; }
+    budget *= 2u;
+  }
+  uint64_t w[5];
+  rng.final_words(w);
+  MG_STAMP(5);
+  if (lane < 5u) A.rng[lane * N + (size_t)e] = pick5(w, lane);
+  MG_WAVE_LDS_SYNC();
+  uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
+  for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
+  if (lane == 0) {
+    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
+    A.dst_agent[e] = agent_pack(ag);
+    if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
+    atomicAdd(&A.counters[2], 1ull);
+    if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
+  }
+  MG_STAMP(6);
+  MG_WAVE_LDS_SYNC();
+}
+
+// stand-alone launch: 4 generating waves per workgroup (explicit resets, flushes of a pending refill queue)
+constexpr int GEN_THREADS = 256;
+template <class RNG>
+__global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const int wave = (int)(threadIdx.x >> 6);
+  MG_STAMP(0);
+  if (A.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_count = 0u;
+  const int total = A.queue ? (int)uni32(*A.count) : A.N;
+  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
+  const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
+  for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
+    const int e = A.queue ? (int)uni32(A.queue[i]) : i;
+    if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
+    generate_one<RNG>(A, e, lane, lds);
+  }
+}
+
+// ======================================================================================================
 // k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
 // verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
@@ -90,14 +184,27 @@ MG_D uint32_t inb_mask7(int c0, int s, int L) {
 // need no address clamp, per-env opacity rows, the visibility mask, the observation as final output bytes (copied
 // out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
 // ======================================================================================================
-template <int MODE, int WPG>
-__global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P) {
+template <int MODE, int WPG, class RNG>
+__global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P, const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = 64 * WPG;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int env0 = blockIdx.x * 64;
+  // ---- generator role: the FIRST gen_blocks workgroups refill the spare episodes that the PREVIOUS launch
+  //      consumed (its refill queue), one generating wave per workgroup, concurrently with this launch's step
+  //      groups.  Disjointness: an env consumed its spare in launch L-1 without stepping, so it cannot be due for
+  //      a reset in launch L; the step groups of launch L therefore never read the spares written here, and launch
+  //      L+1 starts after this one has completed. ----
+  if ((int)blockIdx.x < P.gen_blocks) {
+    if (wave != 0) return;
+    if (blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
+    const int total = (int)uni32(*A.count);
+    for (int i = (int)blockIdx.x; i < total; i += P.gen_blocks)
+      generate_one<RNG>(A, (int)uni32(A.queue[i]), (uint32_t)lane, smem);
+    return;
+  }
+  const int env0 = ((int)blockIdx.x - P.gen_blocks) * 64;
   const int e = env0 + lane;
   const bool active = e < P.N;
   const int nvalid = min(64, P.N - env0);
@@ -319,64 +426,7 @@ __global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P) {
     for (int c = tid; c < nvec; c += NT) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
     for (int b = (nvec << 4) + tid; b < nbytes; b += NT) obase[b] = sT[b];   // ragged last group only
   }
-  if (P.phase == PHASE_STEP && tid == 0 && blockIdx.x == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
-}
-
-// ======================================================================================================
-// k_generate: draw one episode per listed env (the reference's _gen_grid, see mg_gen.h) into `dst`.
-// Work list: either the refill queue filled by k_step, or all envs selected by `mask`.
-// ======================================================================================================
-struct GenArgs {
-  GenParams gp;
-  uint8_t* dst_grid; uint64_t* dst_agent;
-  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state there first
-  const uint32_t* queue; const uint32_t* count;      // queue mode (count read on device)
-  uint32_t* zero_count;                              // the other queue counter, cleared for the next step
-  const uint8_t* mask;                               // direct mode: optional per-env mask
-  uint32_t* err; unsigned long long* counters;
-  int N, CS, GS;
-};
-
-MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4]; }
-
-constexpr int GEN_THREADS = 256;               // 4 waves per workgroup, each wave generates one episode at a time
-
-template <class RNG>
-__global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const int wave = (int)(threadIdx.x >> 6);
-  if (A.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_count = 0u;
-  const int total = A.queue ? (int)uni32(*A.count) : A.N;
-  uint8_t* mygrid = smem + wave * A.CS;
-  const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
-  const size_t N = (size_t)A.N;
-  for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
-    const int e = A.queue ? (int)uni32(A.queue[i]) : i;
-    if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
-    RNG rng;
-    rng.load(A.rng, N, (size_t)e, lane);
-    if (A.rng_snap && lane < 5u) A.rng_snap[lane * N + (size_t)e] = pick5(rng.w_in, lane);
-    if constexpr (RNG::kEpisodic) rng.begin_episode();
-    GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
-    for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
-    GenResult out;
-    generate_episode(rng, g, A.gp, out);
-    uint64_t w[5];
-    rng.final_words(w);
-    if (lane < 5u) A.rng[lane * N + (size_t)e] = pick5(w, lane);
-    MG_WAVE_LDS_SYNC();
-    uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
-    for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
-    if (lane == 0) {
-      Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
-      A.dst_agent[e] = agent_pack(ag);
-      if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
-      atomicAdd(&A.counters[2], 1ull);
-      if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
-    }
-    MG_WAVE_LDS_SYNC();
-  }
+  if (P.phase == PHASE_STEP && tid == 0 && env0 == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
 }
 
 // gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)

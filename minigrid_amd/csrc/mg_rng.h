@@ -57,6 +57,7 @@ struct Pcg64Stream {
     const u128 mult = (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
     state = state * mult + inc;
   }
+  MG_HD bool dead() const { return false; }
   MG_HD void seed(uint64_t s) {
     uint64_t w[4];
     seedseq_words(s, w);
@@ -116,6 +117,7 @@ struct PhiloxStream {
   uint32_t block, pos;       // pos = next unread word of buf (4 = empty)
   uint32_t buf[4];
 
+  MG_HD bool dead() const { return false; }
   MG_HD void seed(uint64_t s) { key = s; episode = 0; block = 0; pos = 4; buf[0] = buf[1] = buf[2] = buf[3] = 0; }
   MG_HD void begin_episode() { episode++; block = 0; pos = 4; }
   MG_HD uint32_t next32() {
@@ -141,15 +143,28 @@ struct PhiloxStream {
 
 // ======================================================================================================
 // Wave-cooperative streams: ONE wavefront draws for ONE environment.
-// A stream is sequential by definition, but both generators can be jumped: the 64 lanes compute the next 64
-// raw outputs in parallel, and the (wave-uniform) consumer picks draw k with v_readlane.  The generator code
-// that consumes the draws (mg_gen.h) is then uniform control flow: no lane ever waits on another env's
-// rejection loop, which is what made one-lane-per-env generation latency-bound.
+// A stream is sequential by definition, but both generators can be jumped: the 64 lanes compute the next 64 raw
+// outputs in parallel and park them, in consumption order, in a per-wave LDS buffer; the (wave-uniform) consumer in
+// mg_gen.h then takes draw k with one broadcast LDS read.  next32() is ~5 instructions and never refills: a pass
+// that runs past the buffered draws goes "dead" (returns draw 0, every draw-dependent loop exits), and the caller
+// replays the episode from its start with twice the budget.  A replay sees the same draws, so it follows the same
+// path and continues.  This keeps the generator code small enough to stay in the instruction cache -- with the
+// refill inlined at every draw site the kernel was instruction-fetch bound (12 us for one DoorKey episode).
 // ======================================================================================================
 MG_D uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 MG_D uint64_t uni64(uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); }
 MG_D uint32_t lane32(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-MG_D uint64_t lane64(uint64_t v, uint32_t l) { return (uint64_t)lane32((uint32_t)v, l) | ((uint64_t)lane32((uint32_t)(v >> 32), l) << 32); }
+
+// LDS hand-off inside ONE wave: lanes wrote different addresses, the wave reads them next (DS ops of a wave execute
+// in order; the fences only stop the compiler from moving the accesses across).
+#define MG_WAVE_LDS_SYNC()                                    \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
+
+constexpr uint32_t GEN_SBASE_ENTRIES = 40;                    // PCG64 stream bases after r refills (16 B each)
 
 // LCG jump table: state after k steps = A_k * state + S_k * inc (mod 2^128), A_k = mult^k, S_k = 1 + mult + ... + mult^(k-1)
 struct PcgJump { uint64_t a_hi[65], a_lo[65], s_hi[65], s_lo[65]; };
@@ -166,102 +181,128 @@ constexpr PcgJump make_pcg_jump() {
 #if defined(__HIPCC__)
 __device__ const PcgJump kPcgJump = make_pcg_jump();
 
+MG_D u128 pcg_jump(u128 state, u128 inc, uint32_t k) {
+  const u128 A = ((u128)kPcgJump.a_hi[k] << 64) | kPcgJump.a_lo[k];
+  const u128 S = ((u128)kPcgJump.s_hi[k] << 64) | kPcgJump.s_lo[k];
+  return A * state + S * inc;
+}
+
 // numpy PCG64 stream position = (state, inc, has_uint32, uinteger); same SoA words as Pcg64Stream.
-// Buffer: lane l holds the state after l+1 steps from `base` and that step's 64-bit output, i.e. 128 32-bit draws
-// (numpy hands out the low half first and caches the high half).
+// One refill = the next 64 raw outputs = 128 32-bit draws (numpy hands out the low half first, then the cached
+// high half).  A cached half carried in from the previous episode is simply the first word of the buffer.
 struct WavePcg64 {
   static constexpr bool kEpisodic = false;
-  u128 base, inc;              // wave-uniform
-  u128 st;                     // per lane
-  uint32_t out_lo, out_hi;     // per lane
-  uint32_t wpos;               // uniform: 32-bit words consumed from the current buffer, 0..128
-  uint32_t pending, cache_in;  // a cached high half carried in from the previous episode comes first
-  uint32_t lane;
+  static constexpr uint32_t kRefillWords = 128;
+  uint32_t* buf;               // LDS: [carried-in half][stream words ...]
+  uint64_t* sbase;             // LDS: stream state after r refills (hi, lo), r < GEN_SBASE_ENTRIES
+  u128 inc;                    // wave-uniform
+  uint32_t off, limit, wpos, refills, cache_in, lane;
+  uint32_t reg_even, reg_odd;  // per lane: logical draws 2*lane and 2*lane+1 (the first 128 draws live in registers:
+                               // v_readlane is ~10x quicker than the LDS round trip, and most episodes need < 128)
   uint64_t w_in[5];            // the words as loaded (the caller snapshots them)
 
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_, uint8_t* lds) {
+    lane = lane_;
+    sbase = (uint64_t*)lds; buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
+#pragma unroll
+    for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
+    inc = ((u128)w_in[2] << 64) | w_in[3];
+    off = (uint32_t)(w_in[4] >> 32) & 1u; cache_in = (uint32_t)w_in[4];
+    sbase[0] = w_in[0]; sbase[1] = w_in[1];
+    buf[0] = cache_in;                       // overwritten by stream word 0 when nothing was carried in
+    refills = 0; limit = off; wpos = 0;
+    MG_WAVE_LDS_SYNC();
+  }
   MG_D void refill() {
-    const uint32_t k = lane + 1u;
-    const u128 A = ((u128)kPcgJump.a_hi[k] << 64) | kPcgJump.a_lo[k];
-    const u128 S = ((u128)kPcgJump.s_hi[k] << 64) | kPcgJump.s_lo[k];
-    st = A * base + S * inc;
+    const u128 base = ((u128)uni64(sbase[2 * refills]) << 64) | uni64(sbase[2 * refills + 1]);
+    const u128 st = pcg_jump(base, inc, lane + 1u);
     const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
     const uint64_t x = hi ^ lo;
     const uint32_t rot = (uint32_t)(hi >> 58);
     const uint64_t o = (x >> rot) | (x << ((64u - rot) & 63u));
-    out_lo = (uint32_t)o; out_hi = (uint32_t)(o >> 32);
-    wpos = 0;
-  }
-  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_) {
-    lane = lane_;
-#pragma unroll
-    for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
-    base = ((u128)w_in[0] << 64) | w_in[1];
-    inc = ((u128)w_in[2] << 64) | w_in[3];
-    pending = (uint32_t)(w_in[4] >> 32) & 1u; cache_in = (uint32_t)w_in[4];
-    refill();
-  }
-  MG_D uint32_t next32() {
-    if (pending) { pending = 0; return cache_in; }
-    if (wpos == 128u) {
-      cache_in = lane32(out_hi, 63);
-      base = ((u128)lane64((uint64_t)(st >> 64), 63) << 64) | lane64((uint64_t)st, 63);
-      refill();
+    uint32_t* dst = buf + off + kRefillWords * refills + 2u * lane;
+    dst[0] = (uint32_t)o; dst[1] = (uint32_t)(o >> 32);
+    if (refills == 0) {
+      // logical draw order = [carried-in half] lo0 hi0 lo1 hi1 ...; with a carried-in half everything shifts by one
+      const uint32_t prev_hi = (uint32_t)__shfl_up((int)(uint32_t)(o >> 32), 1);
+      reg_even = off ? (lane == 0 ? cache_in : prev_hi) : (uint32_t)o;
+      reg_odd = off ? (uint32_t)o : (uint32_t)(o >> 32);
     }
-    const uint32_t j = wpos >> 1;
-    const uint32_t v = (wpos & 1u) ? lane32(out_hi, j) : lane32(out_lo, j);
+    const u128 nb = pcg_jump(base, inc, 64u);
+    sbase[2 * refills + 2] = (uint64_t)(nb >> 64); sbase[2 * refills + 3] = (uint64_t)nb;
+    refills++; limit = off + kRefillWords * refills;
+    MG_WAVE_LDS_SYNC();
+  }
+  MG_D void begin_pass() { wpos = 0; }
+  MG_D bool dead() const { return wpos > limit; }
+  MG_D uint32_t next32() {
+    uint32_t v;
+    if (__builtin_expect(wpos < 128u, 1)) v = (wpos & 1u) ? lane32(reg_odd, wpos >> 1) : lane32(reg_even, wpos >> 1);
+    else v = uni32(buf[wpos < limit ? wpos : 0u]);
     wpos++;
     return v;
   }
-  // every lane holds the same final words; the caller lets one lane write them
+  // every lane computes the same final words; the caller lets lanes 0..4 write them
   MG_D void final_words(uint64_t w[5]) const {
-    const uint32_t nout = (wpos + 1u) >> 1;
-    const uint32_t l = nout ? nout - 1u : 0u;
-    const uint64_t sh = lane64((uint64_t)(st >> 64), l), sl = lane64((uint64_t)st, l);
-    const uint32_t ch = lane32(out_hi, l);
-    w[0] = nout ? sh : (uint64_t)(base >> 64); w[1] = nout ? sl : (uint64_t)base;
-    w[2] = (uint64_t)(inc >> 64); w[3] = (uint64_t)inc;
-    const uint32_t has = pending ? 1u : (wpos & 1u);
-    const uint32_t cache = nout ? ch : cache_in;
+    const uint32_t used = wpos > off ? wpos - off : 0u;      // stream words consumed (the carried-in half is not one)
+    const uint32_t nout = (used + 1u) >> 1;                  // raw 64-bit outputs consumed
+    const uint32_t r = nout >> 6, k = nout & 63u;
+    const u128 base = ((u128)uni64(sbase[2 * r]) << 64) | uni64(sbase[2 * r + 1]);
+    const u128 st = pcg_jump(base, inc, k);                  // k == 0: A = 1, S = 0
+    w[0] = (uint64_t)(st >> 64); w[1] = (uint64_t)st; w[2] = (uint64_t)(inc >> 64); w[3] = (uint64_t)inc;
+    const uint32_t has = wpos < off ? 1u : (used & 1u);      // carried-in half still unread, or a fresh half cached
+    const uint32_t cache = nout ? uni32(buf[off + 2u * nout - 1u]) : cache_in;
     w[4] = ((uint64_t)has << 32) | cache;
   }
 };
 
-// Philox4x32-10: lane l computes counter block (bbase + l) of the episode = 256 draws per buffer.
+// Philox4x32-10: lane l computes counter block (64 r + l) of the episode; one refill = 256 draws.
 struct WavePhilox {
   static constexpr bool kEpisodic = true;
+  static constexpr uint32_t kRefillWords = 256;
+  uint32_t* buf;
   uint64_t key, episode;       // uniform
-  uint32_t bbase, dpos;        // uniform: first block of the buffer, draws consumed from it (0..256)
-  uint32_t buf[4];             // per lane
-  uint32_t lane;
+  uint32_t off, limit, wpos, refills, lane;
+  uint32_t reg[4];             // per lane: draws 4*lane .. 4*lane+3 of the first refill
   uint64_t w_in[5];
 
-  MG_D void refill() {
-    buf[0] = bbase + lane; buf[1] = (uint32_t)episode; buf[2] = (uint32_t)(episode >> 32); buf[3] = 0x4D47u;
-    philox4x32_10(buf, (uint32_t)key, (uint32_t)(key >> 32));
-    dpos = 0;
-  }
-  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_) {
-    lane = lane_;
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_, uint8_t* lds) {
+    lane = lane_; buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
 #pragma unroll
     for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
-    key = w_in[0]; episode = w_in[1]; bbase = 0; dpos = 0;
-    buf[0] = buf[1] = buf[2] = buf[3] = 0;
+    key = w_in[0]; episode = w_in[1] + 1u;      // the counter restarts with every episode
+    off = 0; refills = 0; limit = 0; wpos = 0;
+    buf[0] = 0;
+    MG_WAVE_LDS_SYNC();
   }
-  MG_D void begin_episode() { episode++; bbase = 0; refill(); }
+  MG_D void refill() {
+    uint32_t c[4] = { 64u * refills + lane, (uint32_t)episode, (uint32_t)(episode >> 32), 0x4D47u };
+    philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+    uint32_t* dst = buf + kRefillWords * refills + 4u * lane;
+    dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3];
+    if (refills == 0) { reg[0] = c[0]; reg[1] = c[1]; reg[2] = c[2]; reg[3] = c[3]; }
+    refills++; limit = kRefillWords * refills;
+    MG_WAVE_LDS_SYNC();
+  }
+  MG_D void begin_pass() { wpos = 0; }
+  MG_D bool dead() const { return wpos > limit; }
   MG_D uint32_t next32() {
-    if (dpos == 256u) { bbase += 64u; refill(); }
-    const uint32_t l = dpos >> 2, k = dpos & 3u;
-    const uint32_t a = lane32(buf[0], l), b = lane32(buf[1], l), c = lane32(buf[2], l), d = lane32(buf[3], l);
-    dpos++;
-    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+    uint32_t v;
+    if (__builtin_expect(wpos < 256u, 1)) {
+      const uint32_t l = wpos >> 2, k = wpos & 3u;
+      const uint32_t a = lane32(reg[0], l), b = lane32(reg[1], l), c = lane32(reg[2], l), d = lane32(reg[3], l);
+      v = k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+    } else v = uni32(buf[wpos < limit ? wpos : 0u]);
+    wpos++;
+    return v;
   }
   MG_D void final_words(uint64_t w[5]) const {
-    const uint32_t nblk = (dpos + 3u) >> 2;
-    const uint32_t l = nblk ? nblk - 1u : 0u;
+    const uint32_t nblk = (wpos + 3u) >> 2;
+    const uint32_t last = nblk ? 4u * (nblk - 1u) : 0u;
     w[0] = key; w[1] = episode;
-    w[2] = ((uint64_t)(bbase + nblk) << 8) | (nblk ? dpos - 4u * (nblk - 1u) : 4u);
-    w[3] = (uint64_t)lane32(buf[0], l) | ((uint64_t)lane32(buf[1], l) << 32);
-    w[4] = (uint64_t)lane32(buf[2], l) | ((uint64_t)lane32(buf[3], l) << 32);
+    w[2] = ((uint64_t)nblk << 8) | (nblk ? wpos - last : 4u);
+    w[3] = (uint64_t)uni32(buf[last]) | ((uint64_t)uni32(buf[last + 1]) << 32);
+    w[4] = (uint64_t)uni32(buf[last + 2]) | ((uint64_t)uni32(buf[last + 3]) << 32);
   }
 };
 #endif  // __HIPCC__
@@ -269,6 +310,9 @@ struct WavePhilox {
 // ---------------- numpy draw primitives on top of next32() ----------------
 // Generator.integers(low, high) for a range that fits 32 bits: range 1 draws nothing; otherwise Lemire's
 // nearly-divisionless method with rejection (buffered_bounded_lemire_uint32).  MiniGridEnv._rand_int (247-252).
+__host__ __device__ __attribute__((noinline)) inline uint32_t lemire_threshold(uint32_t rng, uint32_t rng_excl) {
+  return (0xFFFFFFFFu - rng) % rng_excl;          // taken with probability ~range / 2^32: keep the division out of line
+}
 template <class R>
 MG_HD int rand_int(R& r, int low, int high) {
   uint32_t rng = (uint32_t)(high - 1 - low);
@@ -276,9 +320,12 @@ MG_HD int rand_int(R& r, int low, int high) {
   uint32_t rng_excl = rng + 1u;
   uint64_t m = (uint64_t)r.next32() * rng_excl;
   uint32_t leftover = (uint32_t)m;
-  if (leftover < rng_excl) {
-    uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
-    while (leftover < threshold) { m = (uint64_t)r.next32() * rng_excl; leftover = (uint32_t)m; }
+  if (__builtin_expect(leftover < rng_excl, 0)) {
+    uint32_t threshold = lemire_threshold(rng, rng_excl);
+#if defined(__HIP_DEVICE_COMPILE__)
+    threshold = uni32(threshold);     // a call result is not known to be wave-uniform; keep the draw position scalar
+#endif
+    while (leftover < threshold && !r.dead()) { m = (uint64_t)r.next32() * rng_excl; leftover = (uint32_t)m; }
   }
   return low + (int)(m >> 32);
 }
@@ -289,7 +336,7 @@ MG_HD uint32_t rand_interval(R& r, uint32_t max) {
   uint32_t mask = max;
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
   uint32_t v;
-  do { v = r.next32() & mask; } while (v > max);
+  do { v = r.next32() & mask; } while (v > max && !r.dead());
   return v;
 }
 
