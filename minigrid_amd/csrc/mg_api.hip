@@ -17,6 +17,9 @@ using namespace mg;
 
 static thread_local std::string g_create_error;
 
+// the three refill-queue counters live on separate 256-byte lines: one is hammered by atomics while another is read
+constexpr int QC_STRIDE = 64;
+
 struct mg_env {
   mg_config cfg;
   int device = 0;
@@ -37,6 +40,8 @@ struct mg_env {
   double *reward = nullptr, *reward_lut = nullptr;
   uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
   unsigned long long* counters = nullptr;
+  size_t ncounters = 0;
+  uint64_t env_steps = 0;     // env-steps executed (host-side count: N per PHASE_STEP launch)
   // bookkeeping
   uint32_t launches = 0;      // k_step launches so far (refill queue slot = launches % 3)
   int gen_blocks = 0;         // generator workgroups at the head of every k_step launch
@@ -88,7 +93,7 @@ static GenArgs gen_args(mg_env* e, bool to_spare) {
   A.rng_snap = to_spare ? e->rng_snap : nullptr;
   A.queue = nullptr; A.count = nullptr; A.zero_count = nullptr; A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
-  A.N = e->N; A.CS = e->CS; A.cap_words = 2048;
+  A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + (e->N + 63) / 64;
   return A;
 }
 
@@ -97,7 +102,7 @@ static GenArgs gen_args(mg_env* e, bool to_spare) {
 static int launch_generate(mg_env* e, bool to_spare, int queue_slot, const uint8_t* d_mask) {
   GenArgs A = gen_args(e, to_spare);
   const bool queue_mode = queue_slot >= 0;
-  if (queue_mode) { A.queue = e->queue + (size_t)queue_slot * e->N; A.count = e->qcount + queue_slot; }
+  if (queue_mode) { A.queue = e->queue + (size_t)queue_slot * e->N; A.count = e->qcount + QC_STRIDE * queue_slot; }
   A.mask = d_mask;
   const int wpb = GEN_THREADS / 64;
   int blocks = std::min((e->N + wpb - 1) / wpb, queue_mode ? 1024 : 8192);
@@ -117,7 +122,7 @@ static int flush_refills(mg_env* e) {
   const int slot = (int)((e->launches - 1) % 3);
   int rc = launch_generate(e, /*to_spare=*/true, slot, nullptr);
   if (rc) return rc;
-  HIP_TRY(e, hipMemsetAsync(e->qcount + slot, 0, sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->qcount + QC_STRIDE * slot, 0, sizeof(uint32_t), e->stream));
   return MG_OK;
 }
 
@@ -126,7 +131,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
   P.obs = e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
   P.reward_lut = e->reward_lut;
-  P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + (e->launches % 3);
+  P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + QC_STRIDE * (e->launches % 3);
   P.err = e->err; P.counters = e->counters;
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
@@ -150,8 +155,8 @@ static int launch_step(mg_env* e, const StepParams& P) {
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
   GenArgs A = gen_args(e, /*to_spare=*/true);
   const uint32_t L = e->launches;
-  A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + (L + 2) % 3;
-  A.zero_count = e->qcount + (L + 1) % 3;
+  A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + QC_STRIDE * ((L + 2) % 3);
+  A.zero_count = e->qcount + QC_STRIDE * ((L + 1) % 3);
   A.cap_words = e->gen_cap_words;
 #define MG_LAUNCH_STEP(MODE, WPG)                                                                         \
   do {                                                                                                    \
@@ -166,6 +171,7 @@ static int launch_step(mg_env* e, const StepParams& P) {
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
   e->launches++;
+  if (P.phase == PHASE_STEP) e->env_steps += (uint64_t)e->N;
   return MG_OK;
 }
 
@@ -238,22 +244,23 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_act = e->off_lut + 256 * 4;
     e->lds_bytes = e->off_act + 64;
   }
-  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
-  if (!e->static_gen) {
-    // generator role of k_step: ONE generating wave per generator workgroup, which may use the whole LDS
-    // allocation of the launch for its draw buffer (>= 1024 draws; the buffer only limits how many whole-map
-    // retries a GoToRedBall episode may take before ERR_GENERATOR: 1024 draws ~ 17 retries, p ~ 1e-14)
-    const int min_lds = gen_wave_lds_bytes(e->CS, 1024);
-    if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
-    e->gen_cap_words = std::min(4096, (e->lds_bytes - e->CS - GEN_SBASE_BYTES) / 4 - 4);
-    e->gen_blocks = std::min(1024, e->N);
-  }
   {
     // waves per 64-env group.  Measured on MI355X (profiles/r1/sweep_wpg.txt): 4 wins at every batch size from
     // 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
     // dependent LDS/HBM latency per wave, not by issue slots.  MG_WPG overrides (tuning / tests).
     e->wpg = 4;
     if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) e->wpg = v; }
+  }
+  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
+  if (!e->static_gen) {
+    // generator role of k_step: every wave of a generator workgroup draws episodes, each with 1/wpg of the launch's
+    // LDS allocation (>= 512 draws: one whole-map attempt of GoToRedBall needs ~60, and an attempt that runs out
+    // restarts from its checkpoint, so the buffer size is not a correctness limit)
+    const int min_lds = e->wpg * gen_wave_lds_bytes(e->CS, 512);
+    if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
+    e->gen_cap_words = std::min(2048, (e->lds_bytes / e->wpg - e->CS - GEN_SBASE_BYTES) / 4 - 4) & ~3;
+    e->gen_blocks = std::min(1024, e->N);
+    if (const char* s = getenv("MG_GEN_BLOCKS")) { int v = atoi(s); if (v >= 1 && v <= 65536) e->gen_blocks = std::min(v, e->N); }
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
@@ -286,12 +293,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(dalloc(&e->mission, N));
   TRY_OR_FREE(dalloc(&e->reward_lut, (size_t)cfg->max_steps + 1));
   TRY_OR_FREE(dalloc(&e->queue, 3 * N));
-  TRY_OR_FREE(dalloc(&e->qcount, 3));
+  TRY_OR_FREE(dalloc(&e->qcount, 3 * QC_STRIDE));
   TRY_OR_FREE(dalloc(&e->err, 1));
-  TRY_OR_FREE(dalloc(&e->counters, 16));
-  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 3 * sizeof(uint32_t), e->stream));
+  e->ncounters = (size_t)STAT_EPISODES + (size_t)(e->N + 63) / 64 + 2 * (size_t)STAT_GEN_SLOTS;
+  TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
+  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 3 * QC_STRIDE * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, 16 * sizeof(unsigned long long), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
@@ -519,8 +527,13 @@ int mg_timer_stop(mg_env* e, float* ms) {
 
 int mg_get_counters(mg_env* e, uint64_t out[4]) {
   if (!e || !out) return MG_ERR_INVALID;
-  HIP_TRY(e, hipMemcpyAsync(out, e->counters, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  std::vector<uint64_t> c(e->ncounters);
+  HIP_TRY(e, hipMemcpyAsync(c.data(), e->counters, c.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  const size_t groups = (size_t)(e->N + 63) / 64, g0 = (size_t)STAT_EPISODES + groups;
+  out[0] = e->env_steps; out[1] = out[2] = out[3] = 0;
+  for (size_t k = 0; k < groups; k++) out[1] += c[STAT_EPISODES + k];
+  for (size_t k = 0; k < STAT_GEN_SLOTS; k++) { out[2] += c[g0 + 2 * k]; out[3] += c[g0 + 2 * k + 1]; }
   return MG_OK;
 }
 

@@ -176,6 +176,7 @@ MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& ou
   const int W = g.W, H = g.H;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
+    rng.checkpoint();           // a rejected map needs nothing but the stream position: restart point
     g.clear_with_walls();
     // RoomGrid.place_agent: integers(0,1) for the room draws nothing; loop until the front cell is None or a wall
     bool ok = true;

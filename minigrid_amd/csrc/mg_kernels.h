@@ -89,7 +89,13 @@ struct GenArgs {
   uint32_t* err; unsigned long long* counters;
   int N, CS;
   int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
+  int stat_gen_off;                                  // first generator statistics slot in `counters`
 };
+
+// `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env group |
+// STAT_GEN_SLOTS x {maps generated, whole-map retries}; mg_get_counters sums them on the host
+constexpr int STAT_EPISODES = 16;
+constexpr uint32_t STAT_GEN_SLOTS = 4096;
 
 #ifdef MG_DEBUG_TIMING
 // tuning aid (never built into the product library): cycle stamps of the first wave of block 0 -> counters[4..]
@@ -105,22 +111,24 @@ MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTE
 
 // wave-cooperative: all 64 lanes of one wave call this with the same `e`; `lds` = gen_wave_lds_bytes() of LDS
 template <class RNG>
-MG_D void generate_one(const GenArgs& A, int e, uint32_t lane, uint8_t* lds) {
+MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t* lds) {
   const size_t N = (size_t)A.N;
   uint8_t* mygrid = lds;
   MG_STAMP(1);
-  RNG rng;
-  rng.load(A.rng, N, (size_t)e, lane, lds + A.CS);
+  rng.load(A.rng, N, (size_t)e, lds + A.CS);
   MG_STAMP(2);
   if (A.rng_snap && lane < 5u) A.rng_snap[lane * N + (size_t)e] = pick5(rng.w_in, lane);
   GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
   for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
   GenResult out;
-  // draw-budget loop: buffer `budget` draws, run the generator; a pass that ran out of draws is replayed (same
-  // draws, same path) with twice as many.  One refill covers every DoorKey/Crossing episode; GoToRedBall (about 60
-  // draws per whole-map attempt, 15.6 % of attempts rejected) starts with three.
+  // draw-budget loop: buffer `budget` draws, run the generator.  A pass that ran out of draws restarts from its
+  // last checkpoint (GoToRedBall: the start of the current whole-map attempt) with a fresh buffer, or -- no
+  // checkpoint passed -- is replayed from the start (same draws, same path) with twice the budget.  One refill
+  // covers every DoorKey/Crossing episode; GoToRedBall (about 60 draws per attempt, 15.6 % of attempts rejected)
+  // starts with three.
   const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
-  uint32_t budget = A.gp.kind == 3 ? ((384u + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords : RNG::kRefillWords;
+  const uint32_t budget0 = A.gp.kind == 3 ? ((384u + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords : RNG::kRefillWords;
+  uint32_t budget = budget0, retries_before = 0;
   for (;;) {
     budget = min(budget, cap);
     while (rng.limit < rng.off + budget) rng.refill();
@@ -128,7 +136,9 @@ MG_D void generate_one(const GenArgs& A, int e, uint32_t lane, uint8_t* lds) {
     rng.begin_pass();
     generate_episode(rng, g, A.gp, out);
     MG_STAMP(4);
+    out.retries += retries_before;
     if (!rng.dead()) break;
+    if (rng.ck != 0) { retries_before = out.retries; rng.rebase_to_checkpoint(); budget = budget0; continue; }
     if (budget >= cap) { out.failed = true; break; }
     budget *= 2u;
   }
@@ -143,8 +153,9 @@ MG_D void generate_one(const GenArgs& A, int e, uint32_t lane, uint8_t* lds) {
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
     A.dst_agent[e] = agent_pack(ag);
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
-    atomicAdd(&A.counters[2], 1ull);
-    if (out.retries) atomicAdd(&A.counters[3], (unsigned long long)out.retries);
+    unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
+    atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
+    if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
   }
   MG_STAMP(6);
   MG_WAVE_LDS_SYNC();
@@ -159,13 +170,15 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   const int wave = (int)(threadIdx.x >> 6);
   MG_STAMP(0);
   if (A.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_count = 0u;
+  RNG rng;
+  rng.prefetch(lane);
   const int total = A.queue ? (int)uni32(*A.count) : A.N;
   uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
   const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
   for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
     const int e = A.queue ? (int)uni32(A.queue[i]) : i;
     if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
-    generate_one<RNG>(A, e, lane, lds);
+    generate_one<RNG>(A, rng, e, lane, lds);
   }
 }
 
@@ -185,7 +198,8 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
 // ======================================================================================================
 template <int MODE, int WPG, class RNG>
-__global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P, const GenArgs A) {
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(64)))   // <= 64 VGPRs and (800 SGPRs per SIMD) <= 64+16 SGPRs: 8 waves/SIMD
+k_step(const StepParams P, const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = 64 * WPG;
   const int tid = threadIdx.x;
@@ -197,11 +211,23 @@ __global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P, const Gen
   //      a reset in launch L; the step groups of launch L therefore never read the spares written here, and launch
   //      L+1 starts after this one has completed. ----
   if ((int)blockIdx.x < P.gen_blocks) {
-    if (wave != 0) return;
+    MG_STAMP(0);
+    __builtin_amdgcn_s_setprio(3);      // few, latency-critical scalar waves: issue ahead of the step waves
     if (blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
+    // the queue slot, the queue length and the jump table are loaded together (one memory round trip, not three);
+    // a slot beyond the queue's length holds a stale env id that is simply not used
+    // Entry i of the queue goes to wave (i / gen_blocks) % WPG of workgroup i % gen_blocks: a short queue is served
+    // by the wave 0s of as many workgroups as possible, a synchronized truncation burst by all waves.
+    RNG rng;
+    rng.prefetch((uint32_t)lane);
+    const int first = (int)blockIdx.x + wave * P.gen_blocks;
+    int e = first < A.N ? (int)A.queue[first] : 0;
     const int total = (int)uni32(*A.count);
-    for (int i = (int)blockIdx.x; i < total; i += P.gen_blocks)
-      generate_one<RNG>(A, (int)uni32(A.queue[i]), (uint32_t)lane, smem);
+    uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
+    for (int i = first; i < total; i += P.gen_blocks * WPG) {
+      if (i != first) e = (int)A.queue[i];
+      generate_one<RNG>(A, rng, (int)uni32((uint32_t)e), (uint32_t)lane, lds);
+    }
     return;
   }
   const int env0 = ((int)blockIdx.x - P.gen_blocks) * 64;
@@ -315,7 +341,8 @@ __global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P, const Gen
   }
   if (wave == 0 && P.phase == PHASE_STEP) {
     const unsigned long long fin = __ballot(active && (term | trunc));   // episodes finished in this group
-    if (fin && lane == 0) atomicAdd(&P.counters[1], (unsigned long long)__popcll(fin));
+    // statistics go to a slot owned by this workgroup: atomics contended on ONE line cost 4-12 us per launch here
+    if (fin && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + (env0 >> 6)], (unsigned long long)__popcll(fin));
   }
 
   // per-env scalar outputs, spread over the waves (each wave holds identical values)
@@ -426,7 +453,6 @@ __global__ void __launch_bounds__(64 * WPG) k_step(const StepParams P, const Gen
     for (int c = tid; c < nvec; c += NT) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
     for (int b = (nvec << 4) + tid; b < nbytes; b += NT) obase[b] = sT[b];   // ragged last group only
   }
-  if (P.phase == PHASE_STEP && tid == 0 && env0 == 0) atomicAdd(&P.counters[0], (unsigned long long)P.N);
 }
 
 // gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)

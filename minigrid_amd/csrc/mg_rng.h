@@ -196,13 +196,22 @@ struct WavePcg64 {
   uint32_t* buf;               // LDS: [carried-in half][stream words ...]
   uint64_t* sbase;             // LDS: stream state after r refills (hi, lo), r < GEN_SBASE_ENTRIES
   u128 inc;                    // wave-uniform
-  uint32_t off, limit, wpos, refills, cache_in, lane;
+  uint32_t off, limit, wpos, refills, cache_in, lane, ck;
   uint32_t reg_even, reg_odd;  // per lane: logical draws 2*lane and 2*lane+1 (the first 128 draws live in registers:
                                // v_readlane is ~10x quicker than the LDS round trip, and most episodes need < 128)
+  u128 reg_st;                 // per lane: stream state after lane+1 outputs of the first refill
+  u128 jA, jS, jA64, jS64;     // jump multipliers for k = lane+1 (per lane) and k = 64 (uniform), loaded up front
   uint64_t w_in[5];            // the words as loaded (the caller snapshots them)
 
-  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_, uint8_t* lds) {
+  // independent of the env: issue these loads before anything else so that they overlap the queue / state loads
+  MG_D void prefetch(uint32_t lane_) {
     lane = lane_;
+    const uint32_t k = lane + 1u;
+    jA = ((u128)kPcgJump.a_hi[k] << 64) | kPcgJump.a_lo[k]; jS = ((u128)kPcgJump.s_hi[k] << 64) | kPcgJump.s_lo[k];
+    jA64 = ((u128)kPcgJump.a_hi[64] << 64) | kPcgJump.a_lo[64]; jS64 = ((u128)kPcgJump.s_hi[64] << 64) | kPcgJump.s_lo[64];
+  }
+
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint8_t* lds) {
     sbase = (uint64_t*)lds; buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
 #pragma unroll
     for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
@@ -215,7 +224,7 @@ struct WavePcg64 {
   }
   MG_D void refill() {
     const u128 base = ((u128)uni64(sbase[2 * refills]) << 64) | uni64(sbase[2 * refills + 1]);
-    const u128 st = pcg_jump(base, inc, lane + 1u);
+    const u128 st = jA * base + jS * inc;
     const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
     const uint64_t x = hi ^ lo;
     const uint32_t rot = (uint32_t)(hi >> 58);
@@ -227,14 +236,16 @@ struct WavePcg64 {
       const uint32_t prev_hi = (uint32_t)__shfl_up((int)(uint32_t)(o >> 32), 1);
       reg_even = off ? (lane == 0 ? cache_in : prev_hi) : (uint32_t)o;
       reg_odd = off ? (uint32_t)o : (uint32_t)(o >> 32);
+      reg_st = st;
     }
-    const u128 nb = pcg_jump(base, inc, 64u);
+    const u128 nb = jA64 * base + jS64 * inc;
     sbase[2 * refills + 2] = (uint64_t)(nb >> 64); sbase[2 * refills + 3] = (uint64_t)nb;
     refills++; limit = off + kRefillWords * refills;
     MG_WAVE_LDS_SYNC();
   }
-  MG_D void begin_pass() { wpos = 0; }
+  MG_D void begin_pass() { wpos = 0; ck = 0; }
   MG_D bool dead() const { return wpos > limit; }
+  MG_D void checkpoint() { ck = wpos; }     // a restart point of the generator: nothing before it is needed again
   MG_D uint32_t next32() {
     uint32_t v;
     if (__builtin_expect(wpos < 128u, 1)) v = (wpos & 1u) ? lane32(reg_odd, wpos >> 1) : lane32(reg_even, wpos >> 1);
@@ -242,14 +253,33 @@ struct WavePcg64 {
     wpos++;
     return v;
   }
-  // every lane computes the same final words; the caller lets lanes 0..4 write them
-  MG_D void final_words(uint64_t w[5]) const {
+  // stream position after `pos` draws, in numpy's terms.  Every lane computes the same words.
+  MG_D void final_words(uint64_t w[5]) const { words_at(wpos, w); }
+  // make the checkpoint the new origin of the draw buffer (the draws before it are never replayed)
+  MG_D void rebase_to_checkpoint() {
+    uint64_t w[5];
+    words_at(ck, w);
+    MG_WAVE_LDS_SYNC();
+    off = (uint32_t)(w[4] >> 32) & 1u; cache_in = (uint32_t)w[4];
+    sbase[0] = w[0]; sbase[1] = w[1];
+    buf[0] = cache_in;
+    refills = 0; limit = off; wpos = 0; ck = 0;
+    MG_WAVE_LDS_SYNC();
+  }
+  MG_D void words_at(uint32_t pos, uint64_t w[5]) const {
+    const uint32_t wpos = pos;
     const uint32_t used = wpos > off ? wpos - off : 0u;      // stream words consumed (the carried-in half is not one)
     const uint32_t nout = (used + 1u) >> 1;                  // raw 64-bit outputs consumed
     const uint32_t r = nout >> 6, k = nout & 63u;
-    const u128 base = ((u128)uni64(sbase[2 * r]) << 64) | uni64(sbase[2 * r + 1]);
-    const u128 st = pcg_jump(base, inc, k);                  // k == 0: A = 1, S = 0
-    w[0] = (uint64_t)(st >> 64); w[1] = (uint64_t)st; w[2] = (uint64_t)(inc >> 64); w[3] = (uint64_t)inc;
+    if (r == 0 && k != 0) {                                  // the usual case: a lane of the first refill holds it
+      w[0] = (uint64_t)lane32((uint32_t)(reg_st >> 64), k - 1u) | ((uint64_t)lane32((uint32_t)(reg_st >> 96), k - 1u) << 32);
+      w[1] = (uint64_t)lane32((uint32_t)reg_st, k - 1u) | ((uint64_t)lane32((uint32_t)(reg_st >> 32), k - 1u) << 32);
+    } else {
+      const u128 base = ((u128)uni64(sbase[2 * r]) << 64) | uni64(sbase[2 * r + 1]);
+      const u128 st = pcg_jump(base, inc, k);                // k == 0: A = 1, S = 0
+      w[0] = (uint64_t)(st >> 64); w[1] = (uint64_t)st;
+    }
+    w[2] = (uint64_t)(inc >> 64); w[3] = (uint64_t)inc;
     const uint32_t has = wpos < off ? 1u : (used & 1u);      // carried-in half still unread, or a fresh half cached
     const uint32_t cache = nout ? uni32(buf[off + 2u * nout - 1u]) : cache_in;
     w[4] = ((uint64_t)has << 32) | cache;
@@ -262,45 +292,57 @@ struct WavePhilox {
   static constexpr uint32_t kRefillWords = 256;
   uint32_t* buf;
   uint64_t key, episode;       // uniform
-  uint32_t off, limit, wpos, refills, lane;
-  uint32_t reg[4];             // per lane: draws 4*lane .. 4*lane+3 of the first refill
+  uint32_t cbase, skip;        // the buffer starts at counter block `cbase`; its first `skip` words are already used
+  uint32_t off, limit, wpos, refills, lane, ck;    // off/limit/wpos count draws from the buffer origin (off == 0)
+  uint32_t reg[4];             // per lane: buffer words 4*lane .. 4*lane+3 of the first refill
   uint64_t w_in[5];
 
-  MG_D void load(const uint64_t* b, size_t n, size_t i, uint32_t lane_, uint8_t* lds) {
-    lane = lane_; buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
+  MG_D void prefetch(uint32_t lane_) { lane = lane_; }
+  MG_D void load(const uint64_t* b, size_t n, size_t i, uint8_t* lds) {
+    buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
 #pragma unroll
     for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
     key = w_in[0]; episode = w_in[1] + 1u;      // the counter restarts with every episode
-    off = 0; refills = 0; limit = 0; wpos = 0;
+    cbase = 0; skip = 0; off = 0; refills = 0; limit = 0; wpos = 0; ck = 0;
     buf[0] = 0;
     MG_WAVE_LDS_SYNC();
   }
   MG_D void refill() {
-    uint32_t c[4] = { 64u * refills + lane, (uint32_t)episode, (uint32_t)(episode >> 32), 0x4D47u };
+    uint32_t c[4] = { cbase + 64u * refills + lane, (uint32_t)episode, (uint32_t)(episode >> 32), 0x4D47u };
     philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
     uint32_t* dst = buf + kRefillWords * refills + 4u * lane;
     dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2]; dst[3] = c[3];
     if (refills == 0) { reg[0] = c[0]; reg[1] = c[1]; reg[2] = c[2]; reg[3] = c[3]; }
-    refills++; limit = kRefillWords * refills;
+    refills++; limit = kRefillWords * refills - skip;
     MG_WAVE_LDS_SYNC();
   }
-  MG_D void begin_pass() { wpos = 0; }
+  MG_D void begin_pass() { wpos = 0; ck = 0; }
   MG_D bool dead() const { return wpos > limit; }
+  MG_D void checkpoint() { ck = wpos; }
+  // counter-based: the checkpoint becomes the origin of a fresh buffer (block-aligned, `skip` words into its block)
+  MG_D void rebase_to_checkpoint() {
+    MG_WAVE_LDS_SYNC();
+    const uint32_t q = ck + skip;
+    cbase += q >> 2; skip = q & 3u;
+    refills = 0; limit = 0; wpos = 0; ck = 0;
+  }
   MG_D uint32_t next32() {
     uint32_t v;
-    if (__builtin_expect(wpos < 256u, 1)) {
-      const uint32_t l = wpos >> 2, k = wpos & 3u;
+    const uint32_t q = wpos + skip;
+    if (__builtin_expect(q < 256u, 1)) {
+      const uint32_t l = q >> 2, k = q & 3u;
       const uint32_t a = lane32(reg[0], l), b = lane32(reg[1], l), c = lane32(reg[2], l), d = lane32(reg[3], l);
       v = k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
-    } else v = uni32(buf[wpos < limit ? wpos : 0u]);
+    } else v = uni32(buf[wpos < limit ? q : 0u]);
     wpos++;
     return v;
   }
   MG_D void final_words(uint64_t w[5]) const {
-    const uint32_t nblk = (wpos + 3u) >> 2;
+    const uint32_t q = wpos + skip;                  // words consumed from the buffer origin
+    const uint32_t nblk = (q + 3u) >> 2;
     const uint32_t last = nblk ? 4u * (nblk - 1u) : 0u;
     w[0] = key; w[1] = episode;
-    w[2] = ((uint64_t)nblk << 8) | (nblk ? wpos - last : 4u);
+    w[2] = ((uint64_t)(cbase + nblk) << 8) | (nblk ? q - last : 4u);
     w[3] = (uint64_t)uni32(buf[last]) | ((uint64_t)uni32(buf[last + 1]) << 32);
     w[4] = (uint64_t)uni32(buf[last + 2]) | ((uint64_t)uni32(buf[last + 3]) << 32);
   }
