@@ -65,7 +65,7 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int):
             if not os.path.exists(f):
                 break
             for line in open(f):
-                m = re.match(rf"{c},void mg::k_step<[^,]*(?:, \d+)?>,calls=\d+,mean=([0-9.]+)", line)
+                m = re.match(rf"{c},void mg::k_step<[^>]*>,calls=\d+,mean=([0-9.]+)", line)
                 if m:
                     vals[c] = float(m.group(1))
                     break

@@ -126,7 +126,8 @@ MG_API int mg_step(mg_env* env, const void* actions, int dtype, int on_device);
 
 /* T steps under a uniform-random policy generated on the device (Philox4x32-10 keyed by action_seed, global env
  * index and step number) — the benchmark loop of minigrid/benchmark.py:39-40 with random actions.
- * Every step writes its full outputs exactly as mg_step does.  fused != 0 uses the single-launch variant. */
+ * Every step writes its full outputs exactly as mg_step does (one k_step launch per step, so a policy could read
+ * them between steps).  `fused` is reserved for a multi-step single-launch variant and is currently ignored. */
 MG_API int mg_rollout(mg_env* env, int T, uint64_t action_seed, int fused);
 
 MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
@@ -150,7 +151,8 @@ MG_API int mg_set_rng(mg_env* env, const uint64_t* in);
 MG_API int mg_timer_start(mg_env* env);
 MG_API int mg_timer_stop(mg_env* env, float* elapsed_ms);   /* synchronises on the stop event */
 
-/* counters since create: [0] env-steps executed, [1] episodes finished, [2] maps generated, [3] generator retries */
+/* counters since create: [0] env-steps executed, [1] episodes finished, [2] maps generated, [3] generator retries
+ * (summed on the host from per-workgroup slots; synchronises the stream) */
 MG_API int mg_get_counters(mg_env* env, uint64_t out[4]);
 
 MG_API const char* mg_last_error(mg_env* env);   /* env may be NULL for creation errors */

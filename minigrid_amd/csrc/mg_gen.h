@@ -57,6 +57,30 @@ MG_D bool place_obj(R& rng, GridRef& g, uint32_t cell, int topx, int topy, int s
   topx = topx < 0 ? 0 : topx; topy = topy < 0 ? 0 : topy;
   const int hx = min(topx + sx, g.W), hy = min(topy + sy, g.H);
   int tries = 0;
+  // Speculative rejection sampling: when both ranges are powers of two (numpy's Lemire draw then never rejects:
+  // threshold (2^32 - r) % r == 0, value = top bits) every try consumes exactly two draws, so lane t can evaluate
+  // try t from draws wpos+2t, wpos+2t+1 and the first acceptable lane is the reference's accepted try.
+  const uint32_t rx = (uint32_t)(hx - topx), ry = (uint32_t)(hy - topy);
+  if (rx >= 2u && ry >= 2u && (rx & (rx - 1u)) == 0u && (ry & (ry - 1u)) == 0u && !rng.dead()) {
+    const uint32_t win = rng.window();
+    const uint32_t p0 = rng.wpos + 2u * (uint32_t)g.lane;
+    const bool valid = p0 + 1u < win;
+    const uint32_t w0 = rng.peek_lane(p0), w1 = rng.peek_lane(p0 + 1u);
+    const int x = topx + (int)(((uint64_t)w0 * rx) >> 32), y = topy + (int)(((uint64_t)w1 * ry) >> 32);
+    const uint32_t c = valid ? (uint32_t)g.p[y * g.W + x] : 0u;
+    const bool ok = valid && c == CELL_EMPTY && !(x == ax && y == ay) && !(near_reject && (abs(ax - x) + abs(ay - y)) < 2);
+    const unsigned long long m = __ballot(ok);
+    const int nvalid = win > rng.wpos ? (int)min((win - rng.wpos) >> 1, 64u) : 0;
+    if (m) {
+      const int t = __ffsll((long long)m) - 1;
+      if (max_tries >= 0 && t > max_tries) return false;
+      rng.wpos += 2u * (uint32_t)(t + 1);
+      px = (int)lane32((uint32_t)x, (uint32_t)t); py = (int)lane32((uint32_t)y, (uint32_t)t);
+      if (cell != CELL_EMPTY) g.set(px, py, cell);
+      return true;
+    }
+    tries = nvalid; rng.wpos += 2u * (uint32_t)nvalid;     // every buffered try was rejected: carry on one by one
+  }
   for (;;) {
     if (max_tries >= 0 && tries > max_tries) return false;
     if (rng.dead()) return false;                 // out of buffered draws: the caller replays with a larger budget

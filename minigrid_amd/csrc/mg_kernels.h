@@ -113,6 +113,7 @@ MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTE
 template <class RNG>
 MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t* lds) {
   const size_t N = (size_t)A.N;
+
   uint8_t* mygrid = lds;
   MG_STAMP(1);
   rng.load(A.rng, N, (size_t)e, lds + A.CS);

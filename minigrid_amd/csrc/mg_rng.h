@@ -253,6 +253,13 @@ struct WavePcg64 {
     wpos++;
     return v;
   }
+  // lane-parallel look-ahead for speculative rejection sampling: logical draw p (a different p per lane) out of the
+  // register window; only meaningful for p < window()
+  MG_D uint32_t window() const { return limit < 128u ? limit : 128u; }
+  MG_D uint32_t peek_lane(uint32_t p) const {
+    const uint32_t e = (uint32_t)__shfl((int)reg_even, (int)(p >> 1)), o = (uint32_t)__shfl((int)reg_odd, (int)(p >> 1));
+    return (p & 1u) ? o : e;
+  }
   // stream position after `pos` draws, in numpy's terms.  Every lane computes the same words.
   MG_D void final_words(uint64_t w[5]) const { words_at(wpos, w); }
   // make the checkpoint the new origin of the draw buffer (the draws before it are never replayed)
@@ -336,6 +343,13 @@ struct WavePhilox {
     } else v = uni32(buf[wpos < limit ? q : 0u]);
     wpos++;
     return v;
+  }
+  MG_D uint32_t window() const { const uint32_t w = limit + skip < 256u ? limit + skip : 256u; return w - skip; }
+  MG_D uint32_t peek_lane(uint32_t p) const {
+    const uint32_t q = p + skip, l = q >> 2, k = q & 3u;
+    const uint32_t a = (uint32_t)__shfl((int)reg[0], (int)l), b = (uint32_t)__shfl((int)reg[1], (int)l);
+    const uint32_t c = (uint32_t)__shfl((int)reg[2], (int)l), d = (uint32_t)__shfl((int)reg[3], (int)l);
+    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
   }
   MG_D void final_words(uint64_t w[5]) const {
     const uint32_t q = wpos + skip;                  // words consumed from the buffer origin
