@@ -50,7 +50,10 @@ typedef enum mg_env_kind {
   MG_ENV_EMPTY = 0,         /* envs/empty.py:97-114                                           */
   MG_ENV_DOORKEY = 1,       /* envs/doorkey.py:74-99                                          */
   MG_ENV_CROSSING = 2,      /* envs/crossing.py:131-188 (LavaCrossing / SimpleCrossing)       */
-  MG_ENV_GOTO_REDBALL = 3   /* envs/babyai/goto.py:133-141 + core/roomgrid.py + roomgrid_level.py:119-144 */
+  MG_ENV_GOTO_REDBALL = 3,  /* envs/babyai/goto.py:133-141 + core/roomgrid.py + roomgrid_level.py:119-144 */
+  MG_ENV_LAVAGAP = 4,       /* envs/lavagap.py:100-135                                        */
+  MG_ENV_DISTSHIFT = 5,     /* envs/distshift.py:103-124                                      */
+  MG_ENV_FOURROOMS = 6      /* envs/fourrooms.py:77-130 (agent_pos = goal_pos = None)         */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
@@ -85,13 +88,14 @@ typedef struct mg_config {
   int32_t autoreset_mode;     /* mg_autoreset_mode */
   int32_t rng_mode;           /* mg_rng_mode */
   int32_t num_envs;           /* N lockstep envs on this device */
-  int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty: fixed start (empty.py:71-72); x < 0 => place_agent() */
+  int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty / DistShift: fixed start (empty.py:71-72); x < 0 => place_agent() */
   int32_t num_crossings;      /* Crossing (crossing.py:92) */
-  int32_t obstacle_type;      /* Crossing: 9 = lava, 2 = wall (crossing.py:93) */
+  int32_t obstacle_type;      /* Crossing / LavaGap: 9 = lava, 2 = wall (crossing.py:93, lavagap.py:69) */
   int32_t num_dists;          /* GoToRedBall (goto.py:129) */
   int32_t null_stream_sync;   /* library-created stream only: 1 = blocking stream (hipStreamDefault), i.e. ordered
                                  with the legacy NULL stream a framework such as PyTorch launches on; 0 = non-blocking */
-  int32_t reserved[6];
+  int32_t strip2_row;         /* DistShift (distshift.py:72) */
+  int32_t reserved[5];
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
 } mg_config;
 

@@ -19,7 +19,7 @@ class MgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "env_kind", "width", "height", "max_steps", "see_through_walls", "agent_view_size",
         "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
-        "num_crossings", "obstacle_type", "num_dists", "null_stream_sync")] + [("reserved", C.c_int32 * 6), ("env_index_base", C.c_int64)]
+        "num_crossings", "obstacle_type", "num_dists", "null_stream_sync", "strip2_row")] + [("reserved", C.c_int32 * 5), ("env_index_base", C.c_int64)]
 
 
 class MgOutputs(C.Structure):

@@ -79,6 +79,7 @@ static GenParams gen_params(const mg_env* e) {
   g.num_crossings = e->cfg.num_crossings;
   g.obstacle_cell = e->cfg.obstacle_type == (int)T_WALL ? (int)CELL_WALL_GREY : (int)CELL_LAVA;
   g.num_dists = e->cfg.num_dists;
+  g.strip2_row = e->cfg.strip2_row;
   return g;
 }
 
@@ -211,12 +212,18 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
   if (cfg->agent_view_size != 7) return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be 7 on this path");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTO_REDBALL) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_FOURROOMS) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_LAVAGAP && (cfg->width < 5 || cfg->height < 5))
+    return fail(nullptr, MG_ERR_INVALID, "LavaGap needs width, height >= 5 (lavagap.py:101 assert)");
+  if (cfg->env_kind == MG_ENV_DISTSHIFT && (cfg->width < 7 || cfg->strip2_row < 1 || cfg->strip2_row > cfg->height - 2))
+    return fail(nullptr, MG_ERR_INVALID, "DistShift needs width >= 7 and the second lava strip inside the grid");
+  if (cfg->env_kind == MG_ENV_FOURROOMS && (cfg->width < 7 || cfg->height < 7))
+    return fail(nullptr, MG_ERR_INVALID, "FourRooms needs width, height >= 7");
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL && (cfg->width != 8 || cfg->height != 8))
     return fail(nullptr, MG_ERR_INVALID, "GoToRedBall is a single 8x8 room (goto.py:129-131)");
   if (cfg->env_kind == MG_ENV_CROSSING && ((cfg->width & 1) == 0 || (cfg->height & 1) == 0 || cfg->width > 11 || cfg->height > 11))
     return fail(nullptr, MG_ERR_INVALID, "Crossing needs an odd size <= 11 (crossing.py:132 assert)");
-  if (cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0 &&
+  if ((cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0 &&
       (cfg->agent_start_x >= cfg->width || cfg->agent_start_y < 0 || cfg->agent_start_y >= cfg->height || (unsigned)cfg->agent_start_dir > 3u))
     return fail(nullptr, MG_ERR_INVALID, "agent start outside the grid");
   int ndev = mg_device_count();
@@ -251,7 +258,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->wpg = 4;
     if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) e->wpg = v; }
   }
-  e->static_gen = cfg->env_kind == MG_ENV_EMPTY && cfg->agent_start_x >= 0;   // empty.py:108-110: no RNG draws
+  // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
+  e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   if (!e->static_gen) {
     // generator role of k_step: every wave of a generator workgroup draws episodes, each with 1/wpg of the launch's
     // LDS allocation (>= 512 draws: one whole-map attempt of GoToRedBall needs ~60, and an attempt that runs out

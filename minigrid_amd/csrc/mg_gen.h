@@ -14,6 +14,7 @@ struct GenParams {
   int start_x, start_y, start_dir;   // Empty
   int num_crossings, obstacle_cell;  // Crossing (obstacle_cell = cell code of Lava()/Wall())
   int num_dists;                     // GoToRedBall
+  int strip2_row;                    // DistShift
 };
 
 struct GenResult {
@@ -240,6 +241,55 @@ MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& ou
   out.failed = true;
 }
 
+// envs/lavagap.py:100-135
+template <class R>
+MG_D void gen_lavagap(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  out.ax = 1; out.ay = 1; out.dir = 0;
+  g.set(g.W - 2, g.H - 2, CELL_GOAL);
+  const int gx = rand_int(rng, 2, g.W - 2);
+  const int gy = rand_int(rng, 1, g.H - 1);
+  for (int j = 1; j < g.H - 1; j++) g.set(gx, j, (uint32_t)P.obstacle_cell);     // vert_wall(x, 1, height - 2, obstacle)
+  g.set(gx, gy, CELL_EMPTY);
+  out.mission = 0;
+}
+
+// envs/distshift.py:103-124
+template <class R>
+MG_D void gen_distshift(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  g.set(g.W - 2, 1, CELL_GOAL);
+  for (int i = 0; i < g.W - 6; i++) { g.set(3 + i, 1, CELL_LAVA); g.set(3 + i, P.strip2_row, CELL_LAVA); }
+  if (P.start_x >= 0) { out.ax = P.start_x; out.ay = P.start_y; out.dir = P.start_dir; }
+  else if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  out.mission = 0;
+}
+
+// envs/fourrooms.py:77-130 with agent_pos = goal_pos = None (the registered configuration)
+template <class R>
+MG_D void gen_fourrooms(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H;
+  g.clear_with_walls();                                  // horz_wall(0,0), horz_wall(0,H-1), vert_wall(0,0), vert_wall(W-1,0)
+  const int room_w = W / 2, room_h = H / 2;
+  for (int j = 0; j < 2; j++) {
+    for (int i = 0; i < 2; i++) {
+      const int xL = i * room_w, yT = j * room_h, xR = xL + room_w, yB = yT + room_h;
+      if (i + 1 < 2) {
+        for (int k = 0; k < room_h; k++) g.set(xR, yT + k, CELL_WALL_GREY);
+        g.set(xR, rand_int(rng, yT + 1, yB), CELL_EMPTY);
+      }
+      if (j + 1 < 2) {
+        for (int k = 0; k < room_w; k++) g.set(xL + k, yB, CELL_WALL_GREY);
+        g.set(rand_int(rng, xL + 1, xR), yB, CELL_EMPTY);
+      }
+    }
+  }
+  if (!place_agent(rng, g, 0, 0, W, H, -1, out)) out.failed = true;
+  int x, y;
+  if (!place_obj(rng, g, CELL_GOAL, 0, 0, W, H, (int)out.ax, (int)out.ay, false, -1, x, y)) out.failed = true;
+  out.mission = 0;
+}
+
 template <class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
@@ -247,6 +297,9 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     case 0: gen_empty(rng, g, P, out); break;
     case 1: gen_doorkey(rng, g, P, out); break;
     case 2: gen_crossing(rng, g, P, out); break;
+    case 4: gen_lavagap(rng, g, P, out); break;
+    case 5: gen_distshift(rng, g, P, out); break;
+    case 6: gen_fourrooms(rng, g, P, out); break;
     default: gen_goto_redball(rng, g, P, out); break;
   }
 }

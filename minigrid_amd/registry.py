@@ -12,7 +12,7 @@ from dataclasses import dataclass, field, replace
 from typing import Dict, Tuple
 
 # mirror of include/minigrid_hip.h enums
-ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL = 0, 1, 2, 3
+ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS = 0, 1, 2, 3, 4, 5, 6
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -29,6 +29,7 @@ class EnvSpec:
     num_crossings: int = 0
     obstacle_type: int = OBJ_LAVA
     num_dists: int = 0
+    strip2_row: int = 0
     entry_point: str = ""                              # the reference class this row configures
     kwargs: dict = field(default_factory=dict)
 
@@ -64,6 +65,19 @@ def _goto_red_ball(id_, num_dists):
                    kwargs={} if num_dists == 7 else {"num_dists": num_dists})
 
 
+def _lavagap(id_, size):
+    # envs/lavagap.py:68-91 (obstacle_type=Lava, max_steps = 4*size**2), registry rows minigrid/__init__.py:294-310
+    return EnvSpec(id_, ENV_LAVAGAP, size, size, 4 * size * size, False,
+                   ("avoid the lava and get to the green goal square",), agent_start=(1, 1, 0), obstacle_type=OBJ_LAVA,
+                   entry_point="minigrid.envs:LavaGapEnv", kwargs={"size": size})
+
+
+def _distshift(id_, strip2_row):
+    # envs/distshift.py:65-93 (9x7, see_through_walls=True, max_steps = 4*w*h), rows minigrid/__init__.py:78-88
+    return EnvSpec(id_, ENV_DISTSHIFT, 9, 7, 4 * 9 * 7, True, ("get to the green goal square",), agent_start=(1, 1, 0),
+                   strip2_row=strip2_row, entry_point="minigrid.envs:DistShiftEnv", kwargs={"strip2_row": strip2_row})
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -75,6 +89,11 @@ _ROWS = [
     _crossing("MiniGrid-SimpleCrossingS9N1-v0", 9, 1, False), _crossing("MiniGrid-SimpleCrossingS9N2-v0", 9, 2, False),
     _crossing("MiniGrid-SimpleCrossingS9N3-v0", 9, 3, False), _crossing("MiniGrid-SimpleCrossingS11N5-v0", 11, 5, False),
     _goto_red_ball("BabyAI-GoToRedBall-v0", 7), _goto_red_ball("BabyAI-GoToRedBallNoDists-v0", 0),
+    _lavagap("MiniGrid-LavaGapS5-v0", 5), _lavagap("MiniGrid-LavaGapS6-v0", 6), _lavagap("MiniGrid-LavaGapS7-v0", 7),
+    _distshift("MiniGrid-DistShift1-v0", 2), _distshift("MiniGrid-DistShift2-v0", 5),
+    # envs/fourrooms.py:59-73: 19x19, max_steps=100, default see_through_walls=False; row minigrid/__init__.py:213-216
+    EnvSpec("MiniGrid-FourRooms-v0", ENV_FOURROOMS, 19, 19, 100, False, ("reach the goal",),
+            entry_point="minigrid.envs:FourRoomsEnv"),
 ]
 
 registry: Dict[str, EnvSpec] = {r.id: r for r in _ROWS}

@@ -44,6 +44,9 @@ MISSIONS = {
     "MiniGrid-LavaCrossing": ["avoid the lava and get to the green goal square"],
     "MiniGrid-SimpleCrossing": ["find the opening and get to the green goal square"],
     "BabyAI-GoToRedBall": ["go to the red ball", "go to a red ball"],
+    "MiniGrid-LavaGap": ["avoid the lava and get to the green goal square"],
+    "MiniGrid-DistShift": ["get to the green goal square"],
+    "MiniGrid-FourRooms": ["reach the goal"],
 }
 
 
@@ -235,8 +238,22 @@ EXTRA_IDS = ["MiniGrid-Empty-5x5-v0", "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-
              "MiniGrid-SimpleCrossingS9N1-v0", "MiniGrid-SimpleCrossingS11N5-v0", "BabyAI-GoToRedBallNoDists-v0"]
 
 
+# ids added when the path was widened; `python oracle/make_golden.py wide` writes only these
+WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
+            "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0"]
+
+
+def main_wide():
+    for env_id in WIDE_IDS:
+        np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 3, 1337], 260))
+        np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
+        print("done", env_id, flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        return main_wide()
     np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
     main_seeds = list(range(12)) + [100, 243, 500, 1337]
     for env_id in MAIN_IDS:
@@ -248,6 +265,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 1337], 160))
         np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
         print("done", env_id, flush=True)
+    main_wide()
 
 
 if __name__ == "__main__":

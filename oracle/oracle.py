@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
-K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL = 0, 1, 2, 3
+K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS = 0, 1, 2, 3, 4, 5, 6
 T_WALL, T_LAVA = 2, 9
 
 
 class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
-        "num_crossings", "obstacle_type", "num_dists", "full_obs")]
+        "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row")]
 
 
 # Static config rows restated from the reference registry (minigrid/__init__.py:24-28,105-109,182-185,577-580
@@ -44,7 +44,20 @@ def spec(env_id: str) -> dict:
                     missions=["avoid the lava and get to the green goal square" if lava
                               else "find the opening and get to the green goal square"])
 
+    def lavagap(size):
+        return dict(kind=K_LAVAGAP, width=size, height=size, max_steps=4 * size * size, see_through=0,
+                    obstacle_type=T_LAVA, missions=["avoid the lava and get to the green goal square"])
+
+    def distshift(row):
+        return dict(kind=K_DISTSHIFT, width=9, height=7, max_steps=4 * 9 * 7, see_through=1, start_x=1, start_y=1,
+                    start_dir=0, strip2_row=row, missions=["get to the green goal square"])
+
     table = {
+        # lavagap.py:68-91, distshift.py:65-93, fourrooms.py:59-73 + their registry rows (minigrid/__init__.py:78-88,213-216,294-310)
+        "MiniGrid-LavaGapS5-v0": lavagap(5), "MiniGrid-LavaGapS6-v0": lavagap(6), "MiniGrid-LavaGapS7-v0": lavagap(7),
+        "MiniGrid-DistShift1-v0": distshift(2), "MiniGrid-DistShift2-v0": distshift(5),
+        "MiniGrid-FourRooms-v0": dict(kind=K_FOURROOMS, width=19, height=19, max_steps=100, see_through=0,
+                                      missions=["reach the goal"]),
         "MiniGrid-Empty-5x5-v0": empty(5), "MiniGrid-Empty-Random-5x5-v0": empty(5, True),
         "MiniGrid-Empty-6x6-v0": empty(6), "MiniGrid-Empty-Random-6x6-v0": empty(6, True),
         "MiniGrid-Empty-8x8-v0": empty(8), "MiniGrid-Empty-16x16-v0": empty(16),

@@ -5,7 +5,7 @@ Everything is bit-exact (u8 obs, f64 reward compared by bytes, flags)."""
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, golden
+from conftest import ALL_IDS, MAIN_IDS, WIDE_IDS, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -99,6 +99,13 @@ def test_vs_oracle_4096_envs_multi_episode(env_id, full):
     nterm, ntrunc = _compare_with_oracle(env_id, 4096, 300, full, seed0=1000,
                                          probs=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05])
     assert nterm > 50
+
+
+@pytest.mark.parametrize("env_id", WIDE_IDS)
+@pytest.mark.parametrize("full", [False, True])
+def test_vs_oracle_widened_ids_2048_envs_multi_episode(env_id, full):
+    nterm, ntrunc = _compare_with_oracle(env_id, 2048, 260, full, seed0=77, probs=[0.15, 0.15, 0.45, 0.05, 0.05, 0.1, 0.05])
+    assert nterm > 20 and nterm + ntrunc > 100          # many finished episodes => autoreset + generator covered
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 257, 1000])
