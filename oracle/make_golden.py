@@ -34,7 +34,8 @@ import numpy as np  # noqa: E402
 
 import minigrid  # noqa: E402,F401  (registers the env ids)
 from minigrid.core.constants import COLOR_TO_IDX, OBJECT_TO_IDX  # noqa: E402
-from minigrid.wrappers import FullyObsWrapper  # noqa: E402
+from minigrid.wrappers import (FullyObsWrapper, NoDeath, OneHotPartialObsWrapper, SymbolicObsWrapper,  # noqa: E402
+                               ViewSizeWrapper)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
@@ -238,6 +239,88 @@ EXTRA_IDS = ["MiniGrid-Empty-5x5-v0", "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-
              "MiniGrid-SimpleCrossingS9N1-v0", "MiniGrid-SimpleCrossingS11N5-v0", "BabyAI-GoToRedBallNoDists-v0"]
 
 
+# ---- observation / step wrappers: ViewSizeWrapper, OneHotPartialObsWrapper, SymbolicObsWrapper
+#      evaluated on the SAME states of one rollout; NoDeath changes the dynamics, so it gets its own rollouts ----
+WRAPPER_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-8x8-v0", "BabyAI-GoToRedBall-v0", "MiniGrid-Empty-5x5-v0",
+               "MiniGrid-FourRooms-v0"]
+VIEW_SIZES = [3, 5, 9, 11]
+NODEATH_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-DistShift1-v0"]
+
+
+def make_wrapper_goldens(env_id, seeds, T):
+    out = {f"view{v}": [] for v in VIEW_SIZES}
+    out.update(onehot=[], symbolic=[], actions=[])
+    for seed in seeds:
+        env = gym.make(env_id)
+        views = {v: ViewSizeWrapper(env, agent_view_size=v) for v in VIEW_SIZES}
+        onehot, symbolic = OneHotPartialObsWrapper(env), SymbolicObsWrapper(env)
+        arng = np.random.default_rng(20_000 + seed)
+        obs, _ = env.reset(seed=seed)
+        rec = {k: [] for k in out}
+        pending = False
+
+        def snap(obs):
+            for v in VIEW_SIZES:
+                rec[f"view{v}"].append(views[v].observation(dict(obs))["image"])
+            rec["onehot"].append(onehot.observation(dict(obs))["image"])
+            rec["symbolic"].append(np.asarray(symbolic.observation(dict(obs))["image"]).astype(np.int8))
+        snap(obs)
+        for _ in range(T):
+            a = int(arng.integers(0, 7))
+            if arng.random() < 0.6 and not pending:
+                sa = solver_action(env_id, env.unwrapped)
+                a = sa if sa is not None else a
+            if pending:
+                obs, _ = env.reset()
+                pending = False
+            else:
+                obs, r, term, trunc, _ = env.step(a)
+                pending = bool(term or trunc)
+            rec["actions"].append(a)
+            snap(obs)
+        for k in out:
+            out[k].append(rec[k])
+    res = {k: np.array(v, np.int8 if k == "symbolic" else np.uint8) for k, v in out.items()}
+    res["seeds"] = np.array(seeds, np.uint64)
+    return res
+
+
+def make_nodeath_goldens(env_id, seeds, T, death_cost=-1.0):
+    recs = dict(actions=[], obs=[], reward=[], term=[], trunc=[], agent=[])
+    for seed in seeds:
+        env = NoDeath(gym.make(env_id), no_death_types=("lava",), death_cost=death_cost)
+        arng = np.random.default_rng(30_000 + seed)
+        obs, _ = env.reset(seed=seed)
+        rec = dict(actions=[], obs=[obs["image"]], reward=[], term=[], trunc=[], agent=[agent_record(env, 0)])
+        pending = False
+        for _ in range(T):
+            a = int(arng.choice(7, p=[0.15, 0.15, 0.5, 0.05, 0.05, 0.05, 0.05]))      # forward-heavy: walks into lava
+            if pending:
+                obs, _ = env.reset()
+                r, term, trunc = 0.0, False, False
+                pending = False
+            else:
+                obs, r, term, trunc, _ = env.step(a)
+                pending = bool(term or trunc)
+            rec["actions"].append(a); rec["obs"].append(obs["image"]); rec["reward"].append(float(r))
+            rec["term"].append(term); rec["trunc"].append(trunc); rec["agent"].append(agent_record(env, pending))
+        for k in recs:
+            recs[k].append(rec[k])
+    return dict(actions=np.array(recs["actions"], np.uint8), obs=np.array(recs["obs"], np.uint8),
+                reward=np.array(recs["reward"], np.float64), term=np.array(recs["term"], bool),
+                trunc=np.array(recs["trunc"], bool), agent=np.array(recs["agent"], np.int32),
+                seeds=np.array(seeds, np.uint64), death_cost=np.float64(death_cost))
+
+
+def main_wrappers():
+    for env_id in WRAPPER_IDS:
+        np.savez_compressed(os.path.join(OUT, f"wrappers_{env_id}.npz"), **make_wrapper_goldens(env_id, [0, 1, 2, 1337], 120))
+        print("done wrappers", env_id, flush=True)
+    for env_id in NODEATH_IDS:
+        np.savez_compressed(os.path.join(OUT, f"nodeath_{env_id}.npz"), **make_nodeath_goldens(env_id, [0, 1, 2, 3, 1337], 300))
+        print("done nodeath", env_id, flush=True)
+
+
 # ids added when the path was widened; `python oracle/make_golden.py wide` writes only these
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
             "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0"]
@@ -254,6 +337,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         return main_wide()
+    if len(sys.argv) > 1 and sys.argv[1] == "wrappers":
+        return main_wrappers()
     np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
     main_seeds = list(range(12)) + [100, 243, 500, 1337]
     for env_id in MAIN_IDS:
@@ -266,6 +351,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
         print("done", env_id, flush=True)
     main_wide()
+    main_wrappers()
 
 
 if __name__ == "__main__":

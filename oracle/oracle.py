@@ -22,7 +22,13 @@ T_WALL, T_LAVA = 2, 9
 class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
-        "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row")]
+        "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row", "view_size", "no_death_mask")] + [
+        ("death_cost", C.c_double)]
+
+
+OBS_KINDS = {"partial": 0, "full": 1, "onehot": 2, "symbolic": 3}
+OBJECT_TO_IDX = {"unseen": 0, "empty": 1, "wall": 2, "floor": 3, "door": 4, "key": 5, "ball": 6, "box": 7, "goal": 8,
+                 "lava": 9, "agent": 10}          # minigrid/core/constants.py:25-37
 
 
 # Static config rows restated from the reference registry (minigrid/__init__.py:24-28,105-109,182-185,577-580
@@ -115,18 +121,28 @@ def _p(a):
 class OracleVec:
     """N independent reference-semantics envs stepped in lockstep on the CPU (scalar C)."""
 
-    def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, **overrides):
+    def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, obs: str | None = None, view_size: int = 7,
+                 no_death_types=(), death_cost: float = -1.0, **overrides):
+        """obs: "partial" | "full" (FullyObsWrapper) | "onehot" (OneHotPartialObsWrapper) | "symbolic"
+        (SymbolicObsWrapper, returned as int8); view_size: ViewSizeWrapper; no_death_types/death_cost: NoDeath."""
         s = dict(spec(env_id))
         s.update(overrides)
         self.missions = s.pop("missions")
-        self.cfg = OracleCfg(full_obs=int(full_obs), **{k: int(v) for k, v in s.items()})
+        kind = OBS_KINDS[obs] if obs is not None else int(bool(full_obs))
+        mask = 0
+        for t in no_death_types:
+            mask |= 1 << OBJECT_TO_IDX[t]
+        self.cfg = OracleCfg(full_obs=kind, view_size=int(view_size), no_death_mask=mask, death_cost=float(death_cost),
+                             **{k: int(v) for k, v in s.items()})
         self.n = num_envs
         self.W, self.H = self.cfg.width, self.cfg.height
-        self.full_obs = full_obs
+        self.full_obs = kind == 1
         self.h = lib().oracle_create(C.byref(self.cfg), num_envs)
         if not self.h:
             raise RuntimeError("oracle_create failed")
-        self.obs_shape = (self.W, self.H, 3) if full_obs else (7, 7, 3)
+        self.obs_shape = {0: (view_size, view_size, 3), 1: (self.W, self.H, 3), 2: (view_size, view_size, 20),
+                          3: (self.W, self.H, 3)}[kind]
+        self.obs_dtype = np.int8 if kind == 3 else np.uint8
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -135,7 +151,7 @@ class OracleVec:
 
     def _outs(self):
         n = self.n
-        return (np.zeros((n,) + self.obs_shape, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+        return (np.zeros((n,) + self.obs_shape, self.obs_dtype), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
 
     def reset(self, seeds=None, mask=None):
         obs, d, m = self._outs()

@@ -130,3 +130,43 @@ def test_state_roundtrip():
             o2 = w.step(a)
             for x, y in zip(o1, o2):
                 assert (x == y).all()
+
+
+# ---- wrappers: goldens produced by the reference's own wrapper classes ----
+WRAPPER_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-8x8-v0", "BabyAI-GoToRedBall-v0", "MiniGrid-Empty-5x5-v0",
+               "MiniGrid-FourRooms-v0"]
+NODEATH_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-DistShift1-v0"]
+
+
+@pytest.mark.parametrize("env_id", WRAPPER_IDS)
+@pytest.mark.parametrize("what", ["view3", "view5", "view9", "view11", "onehot", "symbolic"])
+def test_oracle_observation_wrappers_match_reference(env_id, what):
+    g = golden(f"wrappers_{env_id}.npz")
+    acts, want = g["actions"], g[what]
+    S, T = acts.shape
+    kw = dict(view_size=int(what[4:])) if what.startswith("view") else dict(obs=what)
+    v = O.OracleVec(env_id, S, **kw)
+    obs, _, _ = v.reset(seeds=g["seeds"])
+    assert obs.dtype == want.dtype and (obs == want[:, 0]).all()
+    for t in range(T):
+        obs = v.step(acts[:, t])[0]
+        assert (obs == want[:, t + 1]).all(), (env_id, what, t)
+
+
+@pytest.mark.parametrize("env_id", NODEATH_IDS)
+def test_oracle_nodeath_matches_reference(env_id):
+    g = golden(f"nodeath_{env_id}.npz")
+    acts = g["actions"]
+    S, T = acts.shape
+    v = O.OracleVec(env_id, S, no_death_types=("lava",), death_cost=float(g["death_cost"]))
+    obs, _, _ = v.reset(seeds=g["seeds"])
+    assert (obs == g["obs"][:, 0]).all()
+    cancelled = 0
+    for t in range(T):
+        obs, rew, term, trunc, _, _ = v.step(acts[:, t])
+        assert (obs == g["obs"][:, t + 1]).all(), (env_id, t)
+        assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all()
+        cancelled += int((rew == g["death_cost"]).sum())
+    assert cancelled > 10          # the wrapper's branch was actually taken
+    _, agent = v.get_state()
+    assert (agent[:, :7] == g["agent"][:, -1, :7]).all()
