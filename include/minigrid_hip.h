@@ -57,8 +57,11 @@ typedef enum mg_env_kind {
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
-  MG_OBS_PARTIAL = 0,  /* MiniGridEnv.gen_obs (minigrid_env.py:634-650): (N,7,7,3) u8; also ImgObsWrapper (wrappers.py:187-214) */
-  MG_OBS_FULL = 1      /* FullyObsWrapper.observation (wrappers.py:419-426): (N,W,H,3) u8                                       */
+  MG_OBS_PARTIAL = 0,  /* MiniGridEnv.gen_obs (minigrid_env.py:634-650): (N,V,V,3) u8; also ImgObsWrapper (wrappers.py:187-214);
+                          V = agent_view_size (7, or any odd 3..15 = ViewSizeWrapper, wrappers.py:629-673)                     */
+  MG_OBS_FULL = 1,     /* FullyObsWrapper.observation (wrappers.py:419-426): (N,W,H,3) u8                                       */
+  MG_OBS_ONEHOT = 2,   /* OneHotPartialObsWrapper.observation (wrappers.py:267-284): (N,V,V,20) u8                              */
+  MG_OBS_SYMBOLIC = 3  /* SymbolicObsWrapper.observation (wrappers.py:763-782): (N,W,H,3) i8 = (x, y, type or -1), agent = 10   */
 } mg_obs_mode;
 
 typedef enum mg_autoreset_mode {
@@ -83,7 +86,7 @@ typedef struct mg_config {
   int32_t width, height;      /* grid size in cells (minigrid_env.py:99-100) */
   int32_t max_steps;          /* minigrid_env.py:105; BabyAI: roomgrid_level.py:77-83 */
   int32_t see_through_walls;  /* minigrid_env.py:107 */
-  int32_t agent_view_size;    /* must be 7 (minigrid_env.py:66-68 default) */
+  int32_t agent_view_size;    /* odd, 3..15; 7 = the reference default (minigrid_env.py:44,66-68), else ViewSizeWrapper */
   int32_t obs_mode;           /* mg_obs_mode */
   int32_t autoreset_mode;     /* mg_autoreset_mode */
   int32_t rng_mode;           /* mg_rng_mode */
@@ -95,13 +98,15 @@ typedef struct mg_config {
   int32_t null_stream_sync;   /* library-created stream only: 1 = blocking stream (hipStreamDefault), i.e. ordered
                                  with the legacy NULL stream a framework such as PyTorch launches on; 0 = non-blocking */
   int32_t strip2_row;         /* DistShift (distshift.py:72) */
-  int32_t reserved[5];
+  int32_t no_death_mask;      /* NoDeath wrapper (wrappers.py:845-882): bit t = cells of OBJECT_TO_IDX type t do not kill */
+  double death_cost;          /* ... and add this to the reward instead (wrappers.py:879-880)                           */
+  int32_t reserved[2];
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
 } mg_config;
 
 /* Borrowed device pointers to the outputs of the last step/reset. */
 typedef struct mg_outputs {
-  uint8_t* obs;         /* (N, 7,7,3) or (N, W,H,3) u8, C-contiguous                                  */
+  uint8_t* obs;         /* (N, V,V,3) | (N, W,H,3) | (N, V,V,20) u8 or (N, W,H,3) i8, C-contiguous     */
   double* reward;       /* (N) f64: 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245) */
   uint8_t* terminated;  /* (N) u8 0/1                                                                 */
   uint8_t* truncated;   /* (N) u8 0/1 (minigrid_env.py:587-588)                                       */
@@ -166,6 +171,7 @@ MG_API int mg_device_count(void);
 /* Host-side self-test hooks (no GPU needed): run the library's own inline helpers on the CPU so that the
  * bit-parallel formulations can be checked exhaustively in the CPU test-suite. */
 MG_API int mg_selftest_vis_row(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
+MG_API int mg_selftest_vis_row_n(int32_t view, uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_reward_lut(int32_t max_steps, double* out /* [max_steps+1] */);
 MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple);
 

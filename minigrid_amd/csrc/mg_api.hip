@@ -140,6 +140,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks;
   P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
   P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->obs_bytes;
+  P.view = e->cfg.agent_view_size; P.no_death_mask = e->cfg.no_death_mask; P.death_cost = e->cfg.death_cost;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
   P.env_base = e->cfg.env_index_base;
@@ -152,22 +153,30 @@ static int launch_step(mg_env* e, const StepParams& P) {
   const int blocks = (e->N + 63) / 64 + e->gen_blocks;
   dim3 grid(blocks), block(64 * e->wpg);
   const size_t lds = (size_t)e->lds_bytes;
-  const bool partial = e->cfg.obs_mode == MG_OBS_PARTIAL;
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
   GenArgs A = gen_args(e, /*to_spare=*/true);
   const uint32_t L = e->launches;
   A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + QC_STRIDE * ((L + 2) % 3);
   A.zero_count = e->qcount + QC_STRIDE * ((L + 1) % 3);
   A.cap_words = e->gen_cap_words;
-#define MG_LAUNCH_STEP(MODE, WPG)                                                                         \
-  do {                                                                                                    \
-    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox>), grid, block, lds, e->stream, P, A);   \
-    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64>), grid, block, lds, e->stream, P, A);           \
+#define MG_LAUNCH_STEP(MODE, WPG, VT)                                                                         \
+  do {                                                                                                        \
+    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox, VT>), grid, block, lds, e->stream, P, A);   \
+    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64, VT>), grid, block, lds, e->stream, P, A);           \
   } while (0)
-  switch (e->wpg) {
-    case 1: if (partial) MG_LAUNCH_STEP(0, 1); else MG_LAUNCH_STEP(1, 1); break;
-    case 2: if (partial) MG_LAUNCH_STEP(0, 2); else MG_LAUNCH_STEP(1, 2); break;
-    default: if (partial) MG_LAUNCH_STEP(0, 4); else MG_LAUNCH_STEP(1, 4); break;
+  // instantiated variants: the default 7x7 view and the FullyObs encode with 1/2/4 waves per group (tuning knob);
+  // the wrappers' encodes (other view sizes, one-hot, symbolic) with 4
+  const bool v7 = e->cfg.agent_view_size == 7;
+  switch (e->cfg.obs_mode) {
+    case MG_OBS_FULL:
+      if (e->wpg == 1) MG_LAUNCH_STEP(1, 1, 7); else if (e->wpg == 2) MG_LAUNCH_STEP(1, 2, 7); else MG_LAUNCH_STEP(1, 4, 7);
+      break;
+    case MG_OBS_SYMBOLIC: MG_LAUNCH_STEP(3, 4, 7); break;
+    case MG_OBS_ONEHOT: if (v7) MG_LAUNCH_STEP(2, 4, 7); else MG_LAUNCH_STEP(2, 4, 15); break;
+    default:
+      if (!v7) MG_LAUNCH_STEP(0, 4, 15);
+      else if (e->wpg == 1) MG_LAUNCH_STEP(0, 1, 7); else if (e->wpg == 2) MG_LAUNCH_STEP(0, 2, 7); else MG_LAUNCH_STEP(0, 4, 7);
+      break;
   }
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
@@ -210,7 +219,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->num_envs < 1) return fail(nullptr, MG_ERR_INVALID, "num_envs must be >= 1");
   if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25)
     return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
-  if (cfg->agent_view_size != 7) return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be 7 on this path");
+  if (cfg->agent_view_size < 3 || cfg->agent_view_size > 15 || (cfg->agent_view_size & 1) == 0)
+    return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be odd and in 3..15 (wrappers.py:650-651 asserts odd, >= 3)");
+  if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
+  if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_FOURROOMS) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind == MG_ENV_LAVAGAP && (cfg->width < 5 || cfg->height < 5))
@@ -236,16 +248,20 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->N = cfg->num_envs; e->W = cfg->width; e->H = cfg->height; e->cells = e->W * e->H;
   e->CS = (e->cells + 15) & ~15;
   e->GS = e->CS + 4;                                     // odd dword stride: conflict-free same-cell LDS reads
-  const bool full = cfg->obs_mode == MG_OBS_FULL;
-  e->obs_bytes = full ? e->cells * 3 : PARTIAL_OBS_BYTES;
+  const int V = cfg->agent_view_size;
+  switch (cfg->obs_mode) {
+    case MG_OBS_FULL: case MG_OBS_SYMBOLIC: e->obs_bytes = e->cells * 3; break;
+    case MG_OBS_ONEHOT: e->obs_bytes = V * V * 20; break;
+    default: e->obs_bytes = V * V * 3; break;
+  }
   {
     // LDS carve-up of k_step (bytes): guard | 64 staged grids | guard | opacity rows | visibility masks |
     // observation bytes in output order | decode table | actions.  The guard bands cover the furthest a view cell
-    // can lie outside an env's own grid (6 rows + 6 cells): such reads are masked, they only have to stay in LDS.
-    const int guard = (6 * e->W + 6 + 15) & ~15;
+    // can lie outside an env's own grid (V-1 rows + V-1 cells): such reads are masked, they only have to stay in LDS.
+    const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
     e->off_grid = guard;
     e->off_trow = (guard + 64 * e->GS + guard + 15) & ~15;
-    e->off_vis = e->off_trow + 64 * 8;
+    e->off_vis = e->off_trow + 64 * 32;                     // one u16 per view row and env (one u8 for V == 7)
     e->off_T = e->off_vis + 64 * 8;
     e->off_lut = e->off_T + ((64 * e->obs_bytes + 15) & ~15);
     e->off_act = e->off_lut + 256 * 4;
@@ -256,7 +272,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
     // dependent LDS/HBM latency per wave, not by issue slots.  MG_WPG overrides (tuning / tests).
     e->wpg = 4;
-    if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) e->wpg = v; }
+    const bool tunable = cfg->agent_view_size == 7 && (cfg->obs_mode == MG_OBS_PARTIAL || cfg->obs_mode == MG_OBS_FULL);
+    if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (tunable && (v == 1 || v == 2 || v == 4)) e->wpg = v; }
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -318,10 +335,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (e->lds_bytes > 64 * 1024) {
-    const void* fns[] = { (const void*)k_step<0, 1, WavePcg64>, (const void*)k_step<0, 2, WavePcg64>, (const void*)k_step<0, 4, WavePcg64>,
-                          (const void*)k_step<1, 1, WavePcg64>, (const void*)k_step<1, 2, WavePcg64>, (const void*)k_step<1, 4, WavePcg64>,
-                          (const void*)k_step<0, 1, WavePhilox>, (const void*)k_step<0, 2, WavePhilox>, (const void*)k_step<0, 4, WavePhilox>,
-                          (const void*)k_step<1, 1, WavePhilox>, (const void*)k_step<1, 2, WavePhilox>, (const void*)k_step<1, 4, WavePhilox> };
+    const void* fns[] = {
+#define MG_K(MODE, WPG, VT) (const void*)k_step<MODE, WPG, WavePcg64, VT>, (const void*)k_step<MODE, WPG, WavePhilox, VT>
+      MG_K(0, 1, 7), MG_K(0, 2, 7), MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 1, 7), MG_K(1, 2, 7), MG_K(1, 4, 7),
+      MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7)
+#undef MG_K
+    };
     for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   }
 #undef TRY_OR_FREE
@@ -557,6 +576,12 @@ MG_API int mg_debug_stamps(mg_env* e, uint64_t out[12]) {
 int mg_selftest_vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
   if (!m_out || !up_out) return MG_ERR_INVALID;
   vis_row(m & 0x7F, t & 0x7F, m_out, up_out);
+  return MG_OK;
+}
+int mg_selftest_vis_row_n(int32_t view, uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
+  if (!m_out || !up_out || view < 3 || view > 16) return MG_ERR_INVALID;
+  const uint32_t full = (1u << view) - 1u;
+  vis_row_n(m & full, t & full, view, m_out, up_out);
   return MG_OK;
 }
 int mg_selftest_reward_lut(int32_t max_steps, double* out) {

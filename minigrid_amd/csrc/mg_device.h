@@ -105,6 +105,24 @@ MG_HD void vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
   *up_out = (s1 | (s1 << 1) | s2 | (s2 >> 1)) & 0x7Fu;
 }
 
+// The same for a view of width V <= 16 (ViewSizeWrapper, wrappers.py:629-673): one more Kogge-Stone step, masks from V.
+MG_HD void vis_row_n(uint32_t m, uint32_t t, int V, uint32_t* m_out, uint32_t* up_out) {
+  const uint32_t full = (1u << V) - 1u;
+  const uint32_t g0 = m & t;
+  uint32_t gr = g0, pr = t, gl = g0, pl = t;
+  gr |= pr & (gr << 1); pr &= pr << 1;      gl |= pl & (gl >> 1); pl &= pl >> 1;
+  gr |= pr & (gr << 2); pr &= pr << 2;      gl |= pl & (gl >> 2); pl &= pl >> 2;
+  gr |= pr & (gr << 4); pr &= pr << 4;      gl |= pl & (gl >> 4); pl &= pl >> 4;
+  gr |= pr & (gr << 8);                     gl |= pl & (gl >> 8);
+  const uint32_t s1 = gr & (full >> 1);     // sweep-1 sources i = 0..V-2
+  const uint32_t s2 = (gr | gl) & full & ~1u;   // sweep-2 sources i = V-1..1
+  *m_out = (m | (s1 << 1) | (s2 >> 1)) & full;
+  *up_out = (s1 | (s1 << 1) | s2 | (s2 >> 1)) & full;
+}
+
+// reference OBJECT_TO_IDX of a cell code (the internal closed/locked door types are doors)
+MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t; }
+
 // agent record: one u64 per env
 //   byte 0 x, 1 y, 2 dir, 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16), 6 flags, 7 mission id
 constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode; NEXT_STEP autoreset is due

@@ -42,6 +42,8 @@ struct StepParams {
   // config
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen, gen_blocks;
   int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
+  int view;               // agent view size V (odd, 3..15)
+  int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
   long long env_base;
 };
@@ -67,10 +69,10 @@ MG_D uint32_t load_action(const StepParams& P, int e) {
   return (v < 0 || v > 255) ? 255u : (uint32_t)v;
 }
 
-// bits k in [0,6] with 0 <= c0 + s*k < L (s = +1 or -1): the in-bounds run of a view row/column
-MG_D uint32_t inb_mask7(int c0, int s, int L) {
+// bits k in [0,V-1] with 0 <= c0 + s*k < L (s = +1 or -1): the in-bounds run of a view row/column
+MG_D uint32_t inb_mask_v(int c0, int s, int L, int V) {
   const int lo = s > 0 ? max(0, -c0) : max(0, c0 - (L - 1));
-  const int hi = s > 0 ? min(6, L - 1 - c0) : min(6, c0);
+  const int hi = s > 0 ? min(V - 1, L - 1 - c0) : min(V - 1, c0);
   const uint32_t m = ((2u << (hi & 31)) - 1u) & ~((1u << (lo & 31)) - 1u);
   return hi >= lo ? m : 0u;
 }
@@ -187,7 +189,8 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
 // verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
-// MODE 0 = partial 7x7x3 view, MODE 1 = full WxHx3 grid.  WPG = wavefronts per group of 64 envs (1, 2 or 4).
+// MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3.
+// WPG = wavefronts per group of 64 envs (1, 2 or 4).  VT = 7 (default view, unrolled) or 15 (run-time V <= 15).
 //
 // One workgroup = 64 consecutive envs; lane l of EVERY wave is env l.  The kernel is VALU-issue bound (profiles/),
 // so the split is chosen to minimise instructions while keeping the chip full: the per-env scalar dynamics (~150
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // need no address clamp, per-env opacity rows, the visibility mask, the observation as final output bytes (copied
 // out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
 // ======================================================================================================
-template <int MODE, int WPG, class RNG>
+template <int MODE, int WPG, class RNG, int VT>
 __global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(64)))   // <= 64 VGPRs and (800 SGPRs per SIMD) <= 64+16 SGPRs: 8 waves/SIMD
 k_step(const StepParams P, const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -337,6 +340,14 @@ k_step(const StepParams P, const GenArgs A) {
         }
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
+      if (P.no_death_mask && term) {
+        // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
+        // cell does not terminate; death_cost is added to the reward instead
+        const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
+        const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
+        const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
+        if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
+      }
       if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
     }
   }
@@ -355,81 +366,121 @@ k_step(const StepParams P, const GenArgs A) {
   }
 
   const int obe = P.OBE;
-  if (MODE == 0) {
-    // ---- gen_obs_grid: closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
-    //      view cell (vx,vy) is world cell agent + f*(6-vy) + r*(vx-3), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
+  if (MODE == 0 || MODE == 2) {
+    // ---- gen_obs_grid(V): closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
+    //      view cell (vx,vy) is world cell agent + f*(V-1-vy) + r*(vx-V/2), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
     //      outside the grid -> grey wall (grid.py:136-139).  wx depends on only one of vx/vy and wy on the other,
-    //      so in-bounds-ness is (column mask)[vx] & (row mask)[vy]. ----
-    constexpr int RPW = (VIEW + WPG - 1) / WPG;                 // view rows per wave: rows wave, wave+WPG, ...
+    //      so in-bounds-ness is (column mask)[vx] & (row mask)[vy].
+    //      VT == 7: the reference's default view, fully unrolled.  VT == 15: ViewSizeWrapper (any odd V <= 15),
+    //      same code with the loops guarded by the run-time V. ----
+    const int V = VT == 7 ? 7 : P.view;
+    const int HV = V >> 1;
+    constexpr int RPW = (VT + WPG - 1) / WPG;                   // view rows per wave: rows wave, wave+WPG, ...
     const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
     const int rx = -fyv, ry = fxv;
     const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
-    const uint32_t colmask = horiz ? inb_mask7((int)a.y - 3 * ry, ry, H) : inb_mask7((int)a.x - 3 * rx, rx, W);
-    const uint32_t rowmask = horiz ? inb_mask7((int)a.x + 6 * fxv, -fxv, W) : inb_mask7((int)a.y + 6 * fyv, -fyv, H);
+    const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
+    const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
     const int SR = ry * W + rx;                                 // linear index step per vx
     const int SU = -(fyv * W + fxv);                            // linear index step per vy
     // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
-    const uint8_t* vbase = mygrid + ((int)a.y + 6 * fyv - 3 * ry) * W + ((int)a.x + 6 * fxv - 3 * rx);
-    uint32_t mycell[RPW][VIEW];
+    const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
+    const uint32_t full = (1u << V) - 1u;
+    uint32_t mycell[RPW][VT];
 #pragma unroll
     for (int r = 0; r < RPW; r++) {
       const int vy = wave + WPG * r;
-      if (vy < VIEW) {
+      if (vy < V) {
         const uint8_t* rowp = vbase + vy * SU;
         const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
         uint32_t opq = 0;
 #pragma unroll
-        for (int vx = 0; vx < VIEW; vx++) {
-          const uint32_t raw = rowp[vx * SR];
-          const uint32_t valid = 0u - ((cm >> vx) & 1u);
-          uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-          if (vx == VIEW / 2 && vy == VIEW - 2) c = dirty_idx >= 0 ? dirty_code : c;   // view (3,5)
-          mycell[r][vx] = c;
-          opq |= (c >> 7) << vx;
+        for (int vx = 0; vx < VT; vx++) {
+          if (VT == 7 || vx < V) {
+            const uint32_t raw = rowp[vx * SR];
+            const uint32_t valid = 0u - ((cm >> vx) & 1u);
+            uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+            if (vx == HV && vy == V - 2) c = dirty_idx >= 0 ? dirty_code : c;   // the cell straight ahead
+            mycell[r][vx] = c;
+            opq |= (c >> 7) << vx;
+          }
         }
-        if (!P.see_through) strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);   // transparency bits of this view row
+        if (!P.see_through) {                                    // transparency bits of this view row
+          if (VT == 7) strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);
+          else ((uint16_t*)strow)[lane * 16 + vy] = (uint16_t)(~opq & full);
+        }
       }
     }
     // ---- process_vis (grid.py:291-328), bit-parallel rows bottom-up, in ONE wave; shared through LDS ----
-    unsigned long long vis = (1ull << VIEW_CELLS) - 1ull;
+    unsigned long long vis = ~0ull;                              // VT == 7: 49 bits, row j at bits 7j..7j+6
     if (!P.see_through) {
       block_sync();
-      if (wave == WPG - 1) {
-        const uint2 tw = *(const uint2*)(strow + lane * 8);
-        uint32_t m = 1u << (VIEW / 2);
-        vis = 0;
+      if (VT == 7) {
+        if (wave == WPG - 1) {
+          const uint2 tw = *(const uint2*)(strow + lane * 8);
+          uint32_t m = 1u << (VIEW / 2);
+          vis = 0;
 #pragma unroll
-        for (int j = VIEW - 1; j >= 0; j--) {
-          const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
-          uint32_t vr, up;
-          vis_row(m, t, &vr, &up);
-          vis |= (unsigned long long)vr << (7 * j);
-          m = up;
+          for (int j = VIEW - 1; j >= 0; j--) {
+            const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
+            uint32_t vr, up;
+            vis_row(m, t, &vr, &up);
+            vis |= (unsigned long long)vr << (7 * j);
+            m = up;
+          }
+          if (WPG > 1) svis[lane] = vis;
         }
-        if (WPG > 1) svis[lane] = vis;
+        if (WPG > 1) { block_sync(); vis = svis[lane]; }
+      } else {
+        // wider views: one 16-bit mask per row, written back over the transparency rows
+        if (wave == WPG - 1) {
+          uint16_t* rows = (uint16_t*)strow + lane * 16;
+          uint32_t m = 1u << HV;
+          for (int j = V - 1; j >= 0; j--) {
+            uint32_t vr, up;
+            vis_row_n(m, rows[j], V, &vr, &up);
+            rows[j] = (uint16_t)vr;
+            m = up;
+          }
+        }
+        block_sync();
       }
-      if (WPG > 1) { block_sync(); vis = svis[lane]; }
     }
-    // ---- Grid.encode(vis_mask) (grid.py:244-268) straight into the output byte image [vx][vy][3]; invisible ->
-    //      (0,0,0); the agent's own cell shows what it carries (minigrid_env.py:623-630) ----
+    // ---- Grid.encode(vis_mask) (grid.py:244-268) straight into the output byte image [vx][vy][...]; invisible ->
+    //      (0,0,0); the agent's own cell shows what it carries (minigrid_env.py:623-630).
+    //      MODE 2: OneHotPartialObsWrapper (wrappers.py:267-284): 20 bytes per cell, one 1 in each of the type /
+    //      colour / state groups. ----
     uint8_t* myT = sT + lane * obe;
 #pragma unroll
     for (int r = 0; r < RPW; r++) {
       const int vy = wave + WPG * r;
-      if (vy < VIEW) {
-        const uint32_t vrow = (uint32_t)(vis >> (7 * vy)) & 0x7Fu;
+      if (vy < V) {
+        uint32_t vrow;
+        if (VT == 7) vrow = (uint32_t)(vis >> (7 * vy)) & 0x7Fu;
+        else vrow = P.see_through ? full : (uint32_t)((const uint16_t*)strow)[lane * 16 + vy];
 #pragma unroll
-        for (int vx = 0; vx < VIEW; vx++) {
-          uint32_t c = mycell[r][vx];
-          if (vx == VIEW / 2 && vy == VIEW - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-          const uint32_t tri = slut[c & (0u - ((vrow >> vx) & 1u))];
-          uint8_t* o = myT + (vx * VIEW + vy) * 3;
-          o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
+        for (int vx = 0; vx < VT; vx++) {
+          if (VT == 7 || vx < V) {
+            uint32_t c = mycell[r][vx];
+            if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+            const uint32_t tri = slut[c & (0u - ((vrow >> vx) & 1u))];
+            if (MODE == 0) {
+              uint8_t* o = myT + (vx * V + vy) * 3;
+              o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
+            } else if (active) {
+              // lanes past the batch end hold stale LDS "cells": their codes could index past the 20 bytes
+              uint8_t* o = myT + (vx * V + vy) * 20;
+              uint32_t* o4 = (uint32_t*)o;
+              o4[0] = 0; o4[1] = 0; o4[2] = 0; o4[3] = 0; o4[4] = 0;
+              o[tri & 0xFF] = 1; o[11 + ((tri >> 8) & 0xFF)] = 1; o[17 + (tri >> 16)] = 1;
+            }
+          }
         }
       }
     }
   } else {
-    // ---- FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir) ----
+    // ---- MODE 1: FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir)
+    //      MODE 3: SymbolicObsWrapper.observation: (x, y, type or -1), agent cell type = 10 ----
     uint8_t* myT = sT + lane * obe;
     const int aidx = (int)a.y * W + (int)a.x;
     for (int x = wave; x < W; x += WPG) {
@@ -437,10 +488,15 @@ k_step(const StepParams P, const GenArgs A) {
         const int idx = y * W + x;
         uint32_t c = mygrid[idx];
         if (idx == dirty_idx) c = dirty_code;
-        if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
-        const uint32_t tri = slut[c];
         uint8_t* o = myT + (x * H + y) * 3;
-        o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
+        if (MODE == 1) {
+          if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
+          const uint32_t tri = slut[c];
+          o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
+        } else {
+          const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
+          o[0] = (uint8_t)x; o[1] = (uint8_t)y; o[2] = (uint8_t)t;
+        }
       }
     }
   }

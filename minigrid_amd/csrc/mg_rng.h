@@ -200,16 +200,9 @@ struct WavePcg64 {
   uint32_t reg_even, reg_odd;  // per lane: logical draws 2*lane and 2*lane+1 (the first 128 draws live in registers:
                                // v_readlane is ~10x quicker than the LDS round trip, and most episodes need < 128)
   u128 reg_st;                 // per lane: stream state after lane+1 outputs of the first refill
-  u128 jA, jS, jA64, jS64;     // jump multipliers for k = lane+1 (per lane) and k = 64 (uniform), loaded up front
   uint64_t w_in[5];            // the words as loaded (the caller snapshots them)
 
-  // independent of the env: issue these loads before anything else so that they overlap the queue / state loads
-  MG_D void prefetch(uint32_t lane_) {
-    lane = lane_;
-    const uint32_t k = lane + 1u;
-    jA = ((u128)kPcgJump.a_hi[k] << 64) | kPcgJump.a_lo[k]; jS = ((u128)kPcgJump.s_hi[k] << 64) | kPcgJump.s_lo[k];
-    jA64 = ((u128)kPcgJump.a_hi[64] << 64) | kPcgJump.a_lo[64]; jS64 = ((u128)kPcgJump.s_hi[64] << 64) | kPcgJump.s_lo[64];
-  }
+  MG_D void prefetch(uint32_t lane_) { lane = lane_; }
 
   MG_D void load(const uint64_t* b, size_t n, size_t i, uint8_t* lds) {
     sbase = (uint64_t*)lds; buf = (uint32_t*)(lds + GEN_SBASE_ENTRIES * 16);
@@ -224,7 +217,7 @@ struct WavePcg64 {
   }
   MG_D void refill() {
     const u128 base = ((u128)uni64(sbase[2 * refills]) << 64) | uni64(sbase[2 * refills + 1]);
-    const u128 st = jA * base + jS * inc;
+    const u128 st = pcg_jump(base, inc, lane + 1u);
     const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
     const uint64_t x = hi ^ lo;
     const uint32_t rot = (uint32_t)(hi >> 58);
@@ -238,7 +231,7 @@ struct WavePcg64 {
       reg_odd = off ? (uint32_t)o : (uint32_t)(o >> 32);
       reg_st = st;
     }
-    const u128 nb = jA64 * base + jS64 * inc;
+    const u128 nb = pcg_jump(base, inc, 64u);
     sbase[2 * refills + 2] = (uint64_t)(nb >> 64); sbase[2 * refills + 3] = (uint64_t)nb;
     refills++; limit = off + kRefillWords * refills;
     MG_WAVE_LDS_SYNC();

@@ -20,6 +20,7 @@ import numpy as np
 
 from . import _binding as B
 from . import spaces
+from .mission_vocab import string_to_indices
 from .registry import EnvSpec, spec as _spec
 
 try:  # subclass the real thing when it exists so isinstance checks pass
@@ -29,6 +30,10 @@ except Exception:
         pass
 
 _AUTORESET = {"next_step": B.AUTORESET_NEXT_STEP, "disabled": B.AUTORESET_DISABLED}
+_OBS_MODES = {"partial": B.OBS_PARTIAL, "full": B.OBS_FULL, "onehot": B.OBS_ONEHOT, "symbolic": B.OBS_SYMBOLIC}
+# minigrid/core/constants.py:25-37
+OBJECT_TO_IDX = {"unseen": 0, "empty": 1, "wall": 2, "floor": 3, "door": 4, "key": 5, "ball": 6, "box": 7, "goal": 8,
+                 "lava": 9, "agent": 10}
 _RNG = {"pcg64": B.RNG_PCG64, "philox": B.RNG_PHILOX}
 
 
@@ -47,9 +52,16 @@ class MiniGridVecEnv(_VectorEnvBase):
     def __init__(self, env_id: str, num_envs: int, *, obs_mode: str = "partial", device: Optional[int] = None,
                  autoreset_mode: str = "next_step", rng: str = "pcg64", env_index_base: int = 0,
                  max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
-                 image_only: bool = False):
-        if obs_mode not in ("partial", "full"):
-            raise ValueError("obs_mode must be 'partial' or 'full'")
+                 image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
+                 death_cost: float = -1.0, dict_mission: bool = False):
+        if obs_mode not in _OBS_MODES:
+            raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
+        # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
+        assert agent_view_size % 2 == 1
+        assert agent_view_size >= 3
+        if agent_view_size > 15:
+            raise ValueError("agent_view_size up to 15 is supported on the accelerated path")
+        assert "goal" not in no_death_types, "goal cannot be a death cell"      # NoDeath.__init__ (wrappers.py:854)
         if output not in ("numpy", "torch"):
             raise ValueError("output must be 'numpy' or 'torch'")
         s: EnvSpec = _spec(env_id)
@@ -68,10 +80,18 @@ class MiniGridVecEnv(_VectorEnvBase):
         self._lib = B.load()
         if self._lib.mg_device_count() < 1:
             raise B.MiniGridHipError("no HIP device visible: minigrid_amd has no CPU fallback (MI355X/gfx950 required)")
+        self.agent_view_size = int(agent_view_size)
+        self.no_death_types = tuple(no_death_types)
+        self.death_cost = float(death_cost)
+        self.dict_mission = bool(dict_mission)
+        no_death_mask = 0
+        for t in self.no_death_types:
+            no_death_mask |= 1 << OBJECT_TO_IDX[t]
         cfg = B.MgConfig(
             abi_version=B.MG_ABI_VERSION, env_kind=s.env_kind, width=s.width, height=s.height, max_steps=s.max_steps,
-            see_through_walls=int(s.see_through_walls), agent_view_size=7,
-            obs_mode=B.OBS_FULL if obs_mode == "full" else B.OBS_PARTIAL, autoreset_mode=_AUTORESET[autoreset_mode],
+            see_through_walls=int(s.see_through_walls), agent_view_size=self.agent_view_size,
+            no_death_mask=no_death_mask, death_cost=self.death_cost,
+            obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET[autoreset_mode],
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, env_index_base=self.env_index_base)
@@ -94,18 +114,27 @@ class MiniGridVecEnv(_VectorEnvBase):
         B.check(self._lib.mg_get_outputs(self._h, C.byref(outs)), self._h)
         self._outs = outs
         self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
-        self.image_shape = (s.width, s.height, 3) if obs_mode == "full" else (7, 7, 3)
+        v = self.agent_view_size
+        self.image_shape = {"partial": (v, v, 3), "full": (s.width, s.height, 3), "onehot": (v, v, 20),
+                            "symbolic": (s.width, s.height, 3)}[obs_mode]
         self._missions = np.asarray(s.missions)
+        # DictObservationSpaceWrapper (wrappers.py:429-554): mission string -> padded word-index vector, per mission id
+        self._mission_tokens = np.asarray([string_to_indices(m) for m in s.missions], np.int64)
         self._seeded = False
         # spaces (minigrid_env.py:63, 72-84; FullyObsWrapper wrappers.py:404-417; ImgObsWrapper :211)
-        img = spaces.Box(0, 255, self.image_shape, np.uint8)
+        # image spaces as the reference wrappers declare them (wrappers.py:263-267, 404-411, 655-662, 749-758)
+        img_high = 10 if obs_mode == "symbolic" else 255
+        img = spaces.Box(0, img_high, self.image_shape, np.uint8)
         self.single_action_space = spaces.Discrete(7)
         if image_only:
             self.single_observation_space = img
             self.observation_space = spaces.Box(0, 255, (self.num_envs,) + self.image_shape, np.uint8)
         else:
+            from .mission_vocab import MAX_WORDS_IN_MISSION, minigrid_words
+            mission_space = (spaces.MultiDiscrete([len(minigrid_words())] * MAX_WORDS_IN_MISSION) if self.dict_mission
+                             else spaces.MissionSpace(s.missions))       # wrappers.py:464-472 / minigrid_env.py:72-84
             self.single_observation_space = spaces.Dict({"image": img, "direction": spaces.Discrete(4),
-                                                         "mission": spaces.MissionSpace(s.missions)})
+                                                         "mission": mission_space})
             self.observation_space = spaces.Dict({
                 "image": spaces.Box(0, 255, (self.num_envs,) + self.image_shape, np.uint8),
                 "direction": spaces.MultiDiscrete([4] * self.num_envs),
@@ -113,7 +142,7 @@ class MiniGridVecEnv(_VectorEnvBase):
         self.action_space = spaces.MultiDiscrete([7] * self.num_envs)
         # host staging (numpy output mode)
         n = self.num_envs
-        self._h_obs = np.empty((n,) + self.image_shape, np.uint8)
+        self._h_obs = np.empty((n,) + self.image_shape, np.int8 if obs_mode == "symbolic" else np.uint8)
         self._h_rew = np.empty(n, np.float64)
         self._h_term = np.empty(n, np.uint8)
         self._h_trunc = np.empty(n, np.uint8)
@@ -136,7 +165,7 @@ class MiniGridVecEnv(_VectorEnvBase):
     def device_outputs(self) -> dict:
         """Zero-copy device views of the output buffers (valid until close(); rewritten by every step/reset)."""
         n, o = self.num_envs, self._outs
-        return {"image": _DeviceArray(o.obs, (n,) + self.image_shape, "|u1", self),
+        return {"image": _DeviceArray(o.obs, (n,) + self.image_shape, "|i1" if self.obs_mode == "symbolic" else "|u1", self),
                 "reward": _DeviceArray(o.reward, (n,), "<f8", self),
                 "terminated": _DeviceArray(o.terminated, (n,), "|u1", self),
                 "truncated": _DeviceArray(o.truncated, (n,), "|u1", self),
@@ -166,12 +195,13 @@ class MiniGridVecEnv(_VectorEnvBase):
         rc = self._lib.mg_copy_outputs(self._h, self._p(self._h_obs), self._p(self._h_rew), self._p(self._h_term),
                                        self._p(self._h_trunc), self._p(self._h_dir), self._p(self._h_mis))
         B.check(rc, self._h)
-        image = self._h_obs.copy()
+        # SymbolicObsWrapper returns numpy's default integer array (np.mgrid, wrappers.py:773-780); the device emits int8
+        image = self._h_obs.astype(np.int64) if self.obs_mode == "symbolic" else self._h_obs.copy()
         if self.image_only:
             obs = image
         else:
             obs = {"image": image, "direction": self._h_dir.astype(np.int64),
-                   "mission": self._missions[self._h_mis]}
+                   "mission": self._mission_tokens[self._h_mis] if self.dict_mission else self._missions[self._h_mis]}
         return obs, self._h_rew.copy(), self._h_term.astype(bool), self._h_trunc.astype(bool)
 
     # ------------------------------------------------------------------ Gymnasium VectorEnv surface

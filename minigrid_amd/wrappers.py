@@ -16,7 +16,9 @@ from .vector_env import MiniGridVecEnv
 def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
     kw = dict(obs_mode=env.obs_mode, autoreset_mode=env.metadata["autoreset_mode"],
               rng="philox" if env._cfg.rng_mode == 1 else "pcg64", env_index_base=env.env_index_base,
-              max_steps=env.max_steps, output=env.output, image_only=env.image_only)
+              max_steps=env.max_steps, output=env.output, image_only=env.image_only,
+              agent_view_size=env.agent_view_size, no_death_types=env.no_death_types, death_cost=env.death_cost,
+              dict_mission=env.dict_mission)
     kw.update(changes)
     new = MiniGridVecEnv(env.env_id, env.num_envs, **kw)
     env.close()
@@ -31,3 +33,33 @@ def ImgObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
 def FullyObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
     """Fully observable gridworld using a compact grid encoding instead of the agent view (wrappers.py:383-426)."""
     return _rebuild(env, obs_mode="full")
+
+
+def ViewSizeWrapper(env: MiniGridVecEnv, agent_view_size: int = 7) -> MiniGridVecEnv:
+    """Customize the agent field of view size (wrappers.py:629-673); like the reference it cannot be combined with
+    the fully observable wrappers."""
+    if env.obs_mode in ("full", "symbolic"):
+        raise ValueError("ViewSizeWrapper cannot be used with fully observable wrappers")
+    return _rebuild(env, agent_view_size=agent_view_size)
+
+
+def OneHotPartialObsWrapper(env: MiniGridVecEnv, tile_size: int = 8) -> MiniGridVecEnv:
+    """One-hot encoding of the partially observable agent view: (V, V, 11+6+3) (wrappers.py:217-284)."""
+    if env.obs_mode != "partial":
+        raise ValueError("OneHotPartialObsWrapper encodes the partial view")
+    return _rebuild(env, obs_mode="onehot")
+
+
+def SymbolicObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
+    """Fully observable grid with a symbolic (x, y, object index or -1) representation (wrappers.py:729-782)."""
+    return _rebuild(env, obs_mode="symbolic", agent_view_size=7)
+
+
+def NoDeath(env: MiniGridVecEnv, no_death_types, death_cost: float = -1.0) -> MiniGridVecEnv:
+    """Prevent death in specific cells, paying `death_cost` instead (wrappers.py:809-882)."""
+    return _rebuild(env, no_death_types=tuple(no_death_types), death_cost=death_cost)
+
+
+def DictObservationSpaceWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
+    """Replace the mission string by its word indices in the Minigrid vocabulary, padded to 50 (wrappers.py:429-554)."""
+    return _rebuild(env, dict_mission=True)

@@ -118,3 +118,41 @@ def test_registry_rows_match_oracle_table():
                (o["kind"], o["width"], o["height"], o["max_steps"], o["see_through"]), env_id
         assert list(row.missions) == o["missions"]
         assert row.num_crossings == o.get("num_crossings", 0) and row.num_dists == o.get("num_dists", 0)
+
+
+def _vis_row_literal_n(m, t, V):
+    mask = [(m >> i) & 1 for i in range(V)]
+    up = [0] * V
+    for i in range(0, V - 1):
+        if mask[i] and (t >> i) & 1:
+            mask[i + 1] = 1; up[i + 1] = 1; up[i] = 1
+    for i in reversed(range(1, V)):
+        if mask[i] and (t >> i) & 1:
+            mask[i - 1] = 1; up[i - 1] = 1; up[i] = 1
+    return sum(b << i for i, b in enumerate(mask)), sum(b << i for i, b in enumerate(up))
+
+
+@pytest.mark.parametrize("V", [3, 5, 7, 9, 11, 13, 15])
+def test_vis_row_n_equals_reference_loops(V):
+    """ViewSizeWrapper widths: exhaustive up to V = 7, 20 000 random (mask, transparency) pairs above."""
+    L = B.load()
+    mo, uo = C.c_uint32(), C.c_uint32()
+    if V <= 7:
+        pairs = [(m, t) for m in range(1 << V) for t in range(1 << V)]
+    else:
+        rng = np.random.default_rng(V)
+        pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, 1 << V, 20000), rng.integers(0, 1 << V, 20000))]
+        pairs += [(1 << (V // 2), (1 << V) - 1), ((1 << V) - 1, 0), (1, (1 << V) - 1), (1 << (V - 1), (1 << V) - 1)]
+    for m, t in pairs:
+        assert L.mg_selftest_vis_row_n(V, m, t, C.byref(mo), C.byref(uo)) == 0
+        assert (mo.value, uo.value) == _vis_row_literal_n(m, t, V), (V, m, t)
+
+
+def test_dict_observation_space_vocabulary_doctest():
+    # reference doctest minigrid/wrappers.py:442-447 (LavaCrossingS11N5 mission)
+    from minigrid_amd.mission_vocab import MAX_WORDS_IN_MISSION, minigrid_words, string_to_indices
+    idx = string_to_indices("avoid the lava and get to the green goal square")
+    assert idx[:10] == [19, 31, 17, 36, 20, 38, 31, 2, 15, 35] and len(idx) == MAX_WORDS_IN_MISSION and idx[10:] == [0] * 40
+    assert len(minigrid_words()) == 51
+    with pytest.raises(ValueError):
+        string_to_indices("avoid the dragon")

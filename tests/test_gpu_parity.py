@@ -299,3 +299,123 @@ def test_sharded_env_single_rank_group_on_gpu():
         env.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---- wrappers ----
+WRAPPER_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-8x8-v0", "BabyAI-GoToRedBall-v0", "MiniGrid-Empty-5x5-v0",
+               "MiniGrid-FourRooms-v0"]
+NODEATH_IDS = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-DistShift1-v0"]
+
+
+def _wrap(env_id, n, what, **kw):
+    import minigrid_amd as mg
+    env = _mk(env_id, n, **kw)
+    if what.startswith("view"):
+        return mg.ViewSizeWrapper(env, agent_view_size=int(what[4:]))
+    return {"onehot": mg.OneHotPartialObsWrapper, "symbolic": mg.SymbolicObsWrapper}[what](env)
+
+
+@pytest.mark.parametrize("env_id", WRAPPER_IDS)
+@pytest.mark.parametrize("what", ["view3", "view5", "view9", "view11", "onehot", "symbolic"])
+def test_observation_wrappers_match_reference_goldens(env_id, what):
+    g = golden(f"wrappers_{env_id}.npz")
+    acts, want = g["actions"], g[what]
+    S, T = acts.shape
+    env = _wrap(env_id, S, what)
+    obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
+    assert obs["image"].shape == want[:, 0].shape and (obs["image"] == want[:, 0]).all()
+    assert env.single_observation_space["image"].shape == want.shape[2:]
+    for t in range(T):
+        obs = env.step(acts[:, t])[0]
+        assert (obs["image"] == want[:, t + 1]).all(), (env_id, what, t)
+    if what == "symbolic":
+        assert obs["image"].dtype == np.int64          # np.mgrid's dtype in the reference (wrappers.py:773)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", NODEATH_IDS)
+def test_nodeath_matches_reference_goldens(env_id):
+    import minigrid_amd as mg
+    g = golden(f"nodeath_{env_id}.npz")
+    acts = g["actions"]
+    S, T = acts.shape
+    env = mg.NoDeath(_mk(env_id, S), no_death_types=("lava",), death_cost=float(g["death_cost"]))
+    obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
+    assert (obs["image"] == g["obs"][:, 0]).all()
+    for t in range(T):
+        obs, rew, term, trunc, _ = env.step(acts[:, t])
+        assert (obs["image"] == g["obs"][:, t + 1]).all(), (env_id, t)
+        assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all()
+    _, agent = env.get_state()
+    assert (agent[:, :7] == g["agent"][:, -1, :7]).all()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,what", [("MiniGrid-DoorKey-8x8-v0", "view3"), ("MiniGrid-DoorKey-16x16-v0", "view9"),
+                                         ("MiniGrid-LavaCrossingS11N5-v0", "view5"), ("MiniGrid-FourRooms-v0", "view13"),
+                                         ("BabyAI-GoToRedBall-v0", "view15"), ("MiniGrid-DoorKey-8x8-v0", "onehot"),
+                                         ("MiniGrid-FourRooms-v0", "symbolic"), ("BabyAI-GoToRedBall-v0", "symbolic"),
+                                         ("MiniGrid-Empty-Random-6x6-v0", "view11")])
+def test_wrappers_vs_oracle_2048_envs(env_id, what):
+    from oracle import oracle as O
+    n = 2048
+    env = _wrap(env_id, n, what)
+    kw = dict(view_size=int(what[4:])) if what.startswith("view") else dict(obs=what)
+    orc = O.OracleVec(env_id, n, **kw)
+    obs, _ = env.reset(seed=11)
+    o_obs, _, _ = orc.reset(seeds=np.arange(11, 11 + n, dtype=np.uint64))
+    assert (obs["image"] == o_obs).all()
+    rng = np.random.default_rng(5)
+    for t in range(150):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, _, _ = orc.step(a)
+        assert (obs["image"] == oo).all(), (env_id, what, t)
+        assert rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all()
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 65, 127])
+def test_ragged_batch_sizes_wrappers(n):
+    # lanes past the end of the batch see stale LDS "cells": they must not disturb the valid lanes' outputs
+    from oracle import oracle as O
+    for what, kw in (("onehot", dict(obs="onehot")), ("view9", dict(view_size=9)), ("symbolic", dict(obs="symbolic"))):
+        env = _wrap("MiniGrid-DoorKey-6x6-v0", n, what)
+        orc = O.OracleVec("MiniGrid-DoorKey-6x6-v0", n, **kw)
+        obs, _ = env.reset(seed=3)
+        assert (obs["image"] == orc.reset(seeds=np.arange(3, 3 + n, dtype=np.uint64))[0]).all()
+        rng = np.random.default_rng(n)
+        for t in range(40):
+            a = rng.integers(0, 7, n, dtype=np.uint8)
+            obs = env.step(a)[0]
+            assert (obs["image"] == orc.step(a)[0]).all(), (what, n, t)
+        env.close()
+
+
+def test_nodeath_and_onehot_view5_compose_vs_oracle():
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 1024
+    env = mg.OneHotPartialObsWrapper(mg.ViewSizeWrapper(mg.NoDeath(_mk("MiniGrid-LavaCrossingS9N3-v0", n), ("lava",), -0.5), 5))
+    orc = O.OracleVec("MiniGrid-LavaCrossingS9N3-v0", n, obs="onehot", view_size=5, no_death_types=("lava",), death_cost=-0.5)
+    obs, _ = env.reset(seed=0)
+    assert obs["image"].shape == (n, 5, 5, 20) and (obs["image"] == orc.reset(seeds=np.arange(n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(9)
+    hits = 0
+    for t in range(200):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.5, 0.05, 0.05, 0.05, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, _, _ = orc.step(a)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all()
+        hits += int((rew == -0.5).sum())
+    assert hits > 1000
+    env.close()
+
+
+def test_dict_observation_space_wrapper():
+    import minigrid_amd as mg
+    env = mg.DictObservationSpaceWrapper(_mk("MiniGrid-LavaCrossingS11N5-v0", 4))
+    obs, _ = env.reset(seed=0)
+    assert obs["mission"].shape == (4, 50) and list(obs["mission"][0, :10]) == [19, 31, 17, 36, 20, 38, 31, 2, 15, 35]
+    assert env.single_observation_space["mission"].shape == (50,)
+    env.close()
