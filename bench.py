@@ -37,11 +37,12 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int) -> int:
+def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, view: int = 7) -> int:
     """action 1 + grid read (49 view cells or W*H cells) x 3 B + agent record r/w 8+8 +
     cell write-back 3 + image out + reward 8 + terminated 1 + truncated 1 (+ direction 1 + mission id 1 for BabyAI)."""
-    cells = W * H if obs_mode == "full" else 49
-    b = 1 + cells * 3 + 8 + 8 + 3 + cells * 3 + 8 + 1 + 1
+    cells = W * H if obs_mode in ("full", "symbolic") else view * view
+    out_per_cell = 20 if obs_mode == "onehot" else 3
+    b = 1 + cells * 3 + 8 + 8 + 3 + cells * out_per_cell + 8 + 1 + 1
     if env_id.startswith("BabyAI"):
         b += 2
     return b
@@ -113,6 +114,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="use the fused multi-step rollout kernel")
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
+    ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic")
+    ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,17 +136,20 @@ def main():
     env_id, n_per_gpu, obs_mode = WORKLOADS[args.workload]
     if args.envs_per_gpu:
         n_per_gpu = args.envs_per_gpu
+    if args.obs_mode:
+        obs_mode = args.obs_mode
     gather = bool(args.gather_obs and world > 1)
     if world > 1:
         # weak scaling: the global batch is world x n_per_gpu envs; rank g owns the contiguous block g (seed = global
         # env index), no data-path collective unless --gather-obs asks for the optional all-gather of the obs tensor
         from minigrid_amd.sharded import ShardedVecEnv
-        senv = ShardedVecEnv(env_id, n_per_gpu * world, gather=gather, obs_mode=obs_mode, device=local_rank)
+        senv = ShardedVecEnv(env_id, n_per_gpu * world, gather=gather, obs_mode=obs_mode, device=local_rank,
+                             agent_view_size=args.view)
         env = senv.local
         assert env.env_index_base == rank * n_per_gpu and env.num_envs == n_per_gpu
     else:
         senv = None
-        env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch")
+        env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
     env.reset(seed=0)
     env.sync()
 
@@ -182,7 +188,7 @@ def main():
     if rank == 0:
         total_envs = n_per_gpu * world
         value = total_envs * args.steps / dt
-        bpe = algorithmic_bytes_per_env_step(env_id, obs_mode, env.width, env.height)
+        bpe = algorithmic_bytes_per_env_step(env_id, obs_mode, env.width, env.height, args.view)
         launch_s = (ev_ms / 1e3) / args.steps           # average k_step launch period on its stream (HIP events)
         achieved = n_per_gpu * bpe / launch_s / 1e9
         out = {
@@ -195,13 +201,13 @@ def main():
                        "launch": "fused-rollout" if args.fused else "one k_step launch per step",
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes_per_launch": bpe * n_per_gpu,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(env_id, obs_mode)
+            out["cpu_baseline"] = cpu_baseline(env_id, obs_mode if obs_mode in ("partial", "full") else "partial")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
