@@ -53,7 +53,9 @@ typedef enum mg_env_kind {
   MG_ENV_GOTO_REDBALL = 3,  /* envs/babyai/goto.py:133-141 + core/roomgrid.py + roomgrid_level.py:119-144 */
   MG_ENV_LAVAGAP = 4,       /* envs/lavagap.py:100-135                                        */
   MG_ENV_DISTSHIFT = 5,     /* envs/distshift.py:103-124                                      */
-  MG_ENV_FOURROOMS = 6      /* envs/fourrooms.py:77-130 (agent_pos = goal_pos = None)         */
+  MG_ENV_FOURROOMS = 6,     /* envs/fourrooms.py:77-130 (agent_pos = goal_pos = None)         */
+  MG_ENV_FETCH = 7,         /* envs/fetch.py:107-175 (num_dists = numObjs); mission id = syntax*12 + colour*2 + type  */
+  MG_ENV_GOTODOOR = 8       /* envs/gotodoor.py:92-149; mission id = COLOR_NAMES index of the target door          */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
@@ -94,7 +96,7 @@ typedef struct mg_config {
   int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty / DistShift: fixed start (empty.py:71-72); x < 0 => place_agent() */
   int32_t num_crossings;      /* Crossing (crossing.py:92) */
   int32_t obstacle_type;      /* Crossing / LavaGap: 9 = lava, 2 = wall (crossing.py:93, lavagap.py:69) */
-  int32_t num_dists;          /* GoToRedBall (goto.py:129) */
+  int32_t num_dists;          /* GoToRedBall num_dists (goto.py:129); Fetch numObjs (fetch.py:67) */
   int32_t null_stream_sync;   /* library-created stream only: 1 = blocking stream (hipStreamDefault), i.e. ordered
                                  with the legacy NULL stream a framework such as PyTorch launches on; 0 = non-blocking */
   int32_t strip2_row;         /* DistShift (distshift.py:72) */

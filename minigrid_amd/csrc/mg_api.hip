@@ -224,7 +224,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_FOURROOMS) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTODOOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_FETCH && (cfg->num_dists < 1 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "Fetch supports numObjs in 1..8");
+  if (cfg->env_kind == MG_ENV_GOTODOOR && (cfg->width < 5 || cfg->height < 5))
+    return fail(nullptr, MG_ERR_INVALID, "GoToDoor needs size >= 5 (gotodoor.py:67 assert)");
   if (cfg->env_kind == MG_ENV_LAVAGAP && (cfg->width < 5 || cfg->height < 5))
     return fail(nullptr, MG_ERR_INVALID, "LavaGap needs width, height >= 5 (lavagap.py:101 assert)");
   if (cfg->env_kind == MG_ENV_DISTSHIFT && (cfg->width < 7 || cfg->strip2_row < 1 || cfg->strip2_row > cfg->height - 2))
@@ -289,6 +293,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
+  if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
+  if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
 
   mg_env* env = e;   // for HIP_TRY
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)

@@ -120,6 +120,12 @@ MG_HD void vis_row_n(uint32_t m, uint32_t t, int V, uint32_t* m_out, uint32_t* u
   *up_out = (s1 | (s1 << 1) | s2 | (s2 >> 1)) & full;
 }
 
+// COLOR_NAMES is sorted alphabetically (core/constants.py:17): blue, green, grey, purple, red, yellow -> COLOR_TO_IDX
+MG_HD uint32_t color_from_sorted(uint32_t i) {
+  const uint32_t packed = (C_BLUE) | (C_GREEN << 4) | (C_GREY << 8) | (C_PURPLE << 12) | (C_RED << 16) | (C_YELLOW << 20);
+  return (packed >> (4u * i)) & 15u;
+}
+
 // reference OBJECT_TO_IDX of a cell code (the internal closed/locked door types are doors)
 MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t; }
 

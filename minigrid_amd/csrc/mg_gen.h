@@ -214,9 +214,7 @@ MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     int x, y;
     if (!place_obj(rng, g, CELL_BALL_RED, 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y)) continue;
     for (int d = 0; d < P.num_dists && ok; d++) {
-      // COLOR_NAMES is sorted: blue, green, grey, purple, red, yellow (core/constants.py:17)
-      const uint32_t sorted_colors = (C_BLUE) | (C_GREEN << 4) | (C_GREY << 8) | (C_PURPLE << 12) | (C_RED << 16) | (C_YELLOW << 20);
-      uint32_t color = (sorted_colors >> (4 * rand_int(rng, 0, 6))) & 15u;
+      uint32_t color = color_from_sorted((uint32_t)rand_int(rng, 0, 6));
       uint32_t type = T_KEY + (uint32_t)rand_int(rng, 0, 3);     // ["key", "ball", "box"] = 5, 6, 7
       ok = place_obj(rng, g, make_cell(type, color), 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y);
     }
@@ -290,6 +288,58 @@ MG_D void gen_fourrooms(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
   out.mission = 0;
 }
 
+// envs/fetch.py:107-160 (P.num_dists = numObjs <= 8).  Mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1):
+// the step rule recovers the target (type, colour) from it, so no extra per-env state is needed.
+template <class R>
+MG_D void gen_fetch(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  uint64_t objs = 0;                           // byte k = colour index * 2 + type index of object k
+  int x, y;
+  const int n = min(P.num_dists, 8);
+  for (int k = 0; k < n; k++) {
+    const uint32_t ty = (uint32_t)rand_int(rng, 0, 2);          // _rand_elem(["key", "ball"])
+    const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);          // _rand_elem(COLOR_NAMES)
+    if (!place_obj(rng, g, make_cell(ty == 0 ? (uint32_t)T_KEY : (uint32_t)T_BALL, color_from_sorted(ci)), 0, 0, g.W, g.H,
+                   -1, -1, false, -1, x, y)) out.failed = true;
+    objs |= (uint64_t)(ci * 2u + ty) << (8 * k);
+  }
+  if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  const int t = rand_int(rng, 0, n);
+  const uint32_t syntax = (uint32_t)rand_int(rng, 0, 5);
+  out.mission = syntax * 12u + (uint32_t)((objs >> (8 * t)) & 0xFF);
+}
+
+// envs/gotodoor.py:92-131.  The room is w x h <= W x H in the top-left corner; the rest of the grid stays None.
+// Mission id = COLOR_NAMES index of the target door (door colours are distinct, so it identifies the door).
+template <class R>
+MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int w = rand_int(rng, 5, g.W + 1);
+  const int h = rand_int(rng, 5, g.H + 1);
+  MG_WAVE_LDS_SYNC();
+  for (int y = 0; y < g.H; y++)
+    if (g.lane < g.W) {
+      const bool in_room = g.lane < w && y < h;
+      const bool edge = g.lane == 0 || g.lane == w - 1 || y == 0 || y == h - 1;
+      g.p[y * g.W + g.lane] = (uint8_t)((in_room && edge) ? CELL_WALL_GREY : CELL_EMPTY);      // wall_rect(0, 0, w, h)
+    }
+  MG_WAVE_LDS_SYNC();
+  int px[4], py[4];
+  px[0] = rand_int(rng, 2, w - 2); py[0] = 0;
+  px[1] = rand_int(rng, 2, w - 2); py[1] = h - 1;
+  px[2] = 0; py[2] = rand_int(rng, 2, h - 2);
+  px[3] = w - 1; py[3] = rand_int(rng, 2, h - 2);
+  uint32_t colors = 0, used = 0;               // nibble k = COLOR_NAMES index of door k
+  for (int n = 0; n < 4 && !rng.dead();) {
+    const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);
+    if ((used >> ci) & 1u) continue;
+    used |= 1u << ci; colors |= ci << (4 * n); n++;
+  }
+  for (int k = 0; k < 4; k++) g.set(px[k], py[k], make_cell(T_DOOR_CLOSED, color_from_sorted((colors >> (4 * k)) & 15u)));
+  if (!place_agent(rng, g, 0, 0, w, h, -1, out)) out.failed = true;
+  const int d = rand_int(rng, 0, 4);
+  out.mission = (colors >> (4 * d)) & 15u;
+}
+
 template <class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
@@ -300,6 +350,8 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     case 4: gen_lavagap(rng, g, P, out); break;
     case 5: gen_distshift(rng, g, P, out); break;
     case 6: gen_fourrooms(rng, g, P, out); break;
+    case 7: gen_fetch(rng, g, P, out); break;
+    case 8: gen_gotodoor(rng, g, P, out); break;
     default: gen_goto_redball(rng, g, P, out); break;
   }
 }

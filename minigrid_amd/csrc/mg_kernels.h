@@ -27,7 +27,7 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
-enum : int { RULE_NONE = 0, RULE_GOTO = 1 };
+enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3 };
 
 struct StepParams {
   // state
@@ -337,6 +337,31 @@ k_step(const StepParams P, const GenArgs A) {
           const int gidx = gy * W + gx;
           const uint32_t G = gidx == dirty_idx ? dirty_code : (uint32_t)mygrid[gidx];
           if ((int)G == P.rule_cell) { term = 1; success = true; }
+        }
+      }
+      if (P.rule == RULE_FETCH && a.carry != 0) {
+        // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
+        // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
+        const uint32_t m12 = a.mission % 12u;
+        const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
+        term = 1; success = a.carry == target;
+      }
+      if (P.rule == RULE_GOTODOOR) {
+        // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
+        // door = the door whose colour the mission names (door colours are distinct and doors never move)
+        if (act == A_TOGGLE) term = 1;
+        if (act == A_DONE) {
+          const uint32_t tc = color_from_sorted(a.mission);
+          bool next_to = false;
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
+            if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
+              const uint32_t c = mygrid[ny * W + nx];
+              next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
+            }
+          }
+          term = 1; success = next_to;
         }
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);

@@ -12,7 +12,7 @@ from dataclasses import dataclass, field, replace
 from typing import Dict, Tuple
 
 # mirror of include/minigrid_hip.h enums
-ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS = 0, 1, 2, 3, 4, 5, 6
+ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -78,6 +78,25 @@ def _distshift(id_, strip2_row):
                    strip2_row=strip2_row, entry_point="minigrid.envs:DistShiftEnv", kwargs={"strip2_row": strip2_row})
 
 
+_COLOR_NAMES = ("blue", "green", "grey", "purple", "red", "yellow")       # sorted, core/constants.py:17
+
+
+def _fetch(id_, size, num_objs):
+    # envs/fetch.py:66-103: see_through_walls=True, max_steps = 5*size**2; mission id = syntax*12 + colour*2 + type,
+    # the order of the MissionSpace's ordered placeholders.  Rows minigrid/__init__.py:196-208
+    syntax = ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
+    missions = tuple(f"{s} {c} {t}" for s in syntax for c in _COLOR_NAMES for t in ("key", "ball"))
+    return EnvSpec(id_, ENV_FETCH, size, size, 5 * size * size, True, missions, num_dists=num_objs,
+                   entry_point="minigrid.envs:FetchEnv", kwargs={"size": size, "numObjs": num_objs})
+
+
+def _gotodoor(id_, size):
+    # envs/gotodoor.py:66-86: see_through_walls=True, max_steps = 4*size**2.  Rows minigrid/__init__.py:221-236
+    return EnvSpec(id_, ENV_GOTODOOR, size, size, 4 * size * size, True,
+                   tuple(f"go to the {c} door" for c in _COLOR_NAMES),
+                   entry_point="minigrid.envs:GoToDoorEnv", kwargs={"size": size})
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -94,6 +113,8 @@ _ROWS = [
     # envs/fourrooms.py:59-73: 19x19, max_steps=100, default see_through_walls=False; row minigrid/__init__.py:213-216
     EnvSpec("MiniGrid-FourRooms-v0", ENV_FOURROOMS, 19, 19, 100, False, ("reach the goal",),
             entry_point="minigrid.envs:FourRoomsEnv"),
+    _fetch("MiniGrid-Fetch-5x5-N2-v0", 5, 2), _fetch("MiniGrid-Fetch-6x6-N2-v0", 6, 2), _fetch("MiniGrid-Fetch-8x8-N3-v0", 8, 3),
+    _gotodoor("MiniGrid-GoToDoor-5x5-v0", 5), _gotodoor("MiniGrid-GoToDoor-6x6-v0", 6), _gotodoor("MiniGrid-GoToDoor-8x8-v0", 8),
 ]
 
 registry: Dict[str, EnvSpec] = {r.id: r for r in _ROWS}

@@ -48,6 +48,10 @@ MISSIONS = {
     "MiniGrid-LavaGap": ["avoid the lava and get to the green goal square"],
     "MiniGrid-DistShift": ["get to the green goal square"],
     "MiniGrid-FourRooms": ["reach the goal"],
+    # ordered placeholders of the MissionSpace (fetch.py:77-89, gotodoor.py:66-70) with COLOR_NAMES sorted
+    "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
+                       for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
+    "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
 }
 
 
@@ -128,6 +132,12 @@ def solver_action(env_id, u):
     if env_id.startswith("BabyAI-GoToRedBall"):
         p = plan_to_face(u, find(u, "ball", "red"))
         return p[0] if p else None
+    if env_id.startswith("MiniGrid-Fetch"):
+        p = plan_to_face(u, find(u, u.targetType, u.targetColor))
+        return 3 if p == [] else (p[0] if p else None)
+    if env_id.startswith("MiniGrid-GoToDoor"):
+        p = plan_to_face(u, u.target_pos)
+        return 6 if p == [] else (p[0] if p else None)
     goal = find(u, "goal")
     if goal is None:
         return None
@@ -323,7 +333,8 @@ def main_wrappers():
 
 # ids added when the path was widened; `python oracle/make_golden.py wide` writes only these
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
-            "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0"]
+            "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-5x5-N2-v0", "MiniGrid-Fetch-6x6-N2-v0",
+            "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0"]
 
 
 def main_wide():

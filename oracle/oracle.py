@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
-K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS = 0, 1, 2, 3, 4, 5, 6
+K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 T_WALL, T_LAVA = 2, 9
 
 
@@ -58,7 +58,21 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_DISTSHIFT, width=9, height=7, max_steps=4 * 9 * 7, see_through=1, start_x=1, start_y=1,
                     start_dir=0, strip2_row=row, missions=["get to the green goal square"])
 
+    color_names = ["blue", "green", "grey", "purple", "red", "yellow"]         # sorted COLOR_NAMES (constants.py:17)
+
+    def fetch(size, n):
+        # fetch.py:66-103: missions f"{syntax} {color} {type}", id = syntax*12 + color*2 + type
+        syntax = ["get a", "go get a", "fetch a", "go fetch a", "you must fetch a"]
+        return dict(kind=K_FETCH, width=size, height=size, max_steps=5 * size * size, see_through=1, num_dists=n,
+                    missions=[f"{s} {c} {t}" for s in syntax for c in color_names for t in ("key", "ball")])
+
+    def gotodoor(size):
+        return dict(kind=K_GOTODOOR, width=size, height=size, max_steps=4 * size * size, see_through=1,
+                    missions=[f"go to the {c} door" for c in color_names])
+
     table = {
+        "MiniGrid-Fetch-5x5-N2-v0": fetch(5, 2), "MiniGrid-Fetch-6x6-N2-v0": fetch(6, 2), "MiniGrid-Fetch-8x8-N3-v0": fetch(8, 3),
+        "MiniGrid-GoToDoor-5x5-v0": gotodoor(5), "MiniGrid-GoToDoor-6x6-v0": gotodoor(6), "MiniGrid-GoToDoor-8x8-v0": gotodoor(8),
         # lavagap.py:68-91, distshift.py:65-93, fourrooms.py:59-73 + their registry rows (minigrid/__init__.py:78-88,213-216,294-310)
         "MiniGrid-LavaGapS5-v0": lavagap(5), "MiniGrid-LavaGapS6-v0": lavagap(6), "MiniGrid-LavaGapS7-v0": lavagap(7),
         "MiniGrid-DistShift1-v0": distshift(2), "MiniGrid-DistShift2-v0": distshift(5),
