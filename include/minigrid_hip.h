@@ -55,7 +55,11 @@ typedef enum mg_env_kind {
   MG_ENV_DISTSHIFT = 5,     /* envs/distshift.py:103-124                                      */
   MG_ENV_FOURROOMS = 6,     /* envs/fourrooms.py:77-130 (agent_pos = goal_pos = None)         */
   MG_ENV_FETCH = 7,         /* envs/fetch.py:107-175 (num_dists = numObjs); mission id = syntax*12 + colour*2 + type  */
-  MG_ENV_GOTODOOR = 8       /* envs/gotodoor.py:92-149; mission id = COLOR_NAMES index of the target door          */
+  MG_ENV_GOTODOOR = 8,      /* envs/gotodoor.py:92-149; mission id = COLOR_NAMES index of the target door          */
+  /* RoomGrid levels (core/roomgrid.py:72-334), width = (room_size-1)*num_cols+1, height likewise: */
+  MG_ENV_UNLOCK = 9,                /* envs/unlock.py:75-98                                                        */
+  MG_ENV_UNLOCKPICKUP = 10,         /* envs/unlockpickup.py:82-107; mission id = COLOR_NAMES index of the box      */
+  MG_ENV_BLOCKEDUNLOCKPICKUP = 11   /* envs/blockedunlockpickup.py:90-119; mission id = colour index * 2 (box)     */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
@@ -102,7 +106,8 @@ typedef struct mg_config {
   int32_t strip2_row;         /* DistShift (distshift.py:72) */
   int32_t no_death_mask;      /* NoDeath wrapper (wrappers.py:845-882): bit t = cells of OBJECT_TO_IDX type t do not kill */
   double death_cost;          /* ... and add this to the reward instead (wrappers.py:879-880)                           */
-  int32_t reserved[2];
+  int32_t room_size;          /* RoomGrid levels (core/roomgrid.py:75)                                                  */
+  int32_t reserved[1];
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
 } mg_config;
 

@@ -31,7 +31,7 @@ struct mg_env {
   int off_grid = 0, off_trow = 0, off_vis = 0, off_T = 0, off_lut = 0, off_act = 0, lds_bytes = 0;
   int wpg = 4;                // wavefronts per group of 64 envs in k_step
   bool static_gen = false;
-  int rule = RULE_NONE, rule_cell = 0;
+  int rule = RULE_NONE, rule_cell = 0, rule_div = 1;
   // device buffers
   uint8_t *grid = nullptr, *spare_grid = nullptr;
   uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *seeds = nullptr;
@@ -80,6 +80,7 @@ static GenParams gen_params(const mg_env* e) {
   g.obstacle_cell = e->cfg.obstacle_type == (int)T_WALL ? (int)CELL_WALL_GREY : (int)CELL_LAVA;
   g.num_dists = e->cfg.num_dists;
   g.strip2_row = e->cfg.strip2_row;
+  g.room_size = e->cfg.room_size;
   return g;
 }
 
@@ -135,7 +136,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + QC_STRIDE * (e->launches % 3);
   P.err = e->err; P.counters = e->counters;
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
-  P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell;
+  P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks;
   P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
@@ -224,7 +225,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTODOOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BLOCKEDUNLOCKPICKUP) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_UNLOCK && cfg->env_kind <= MG_ENV_BLOCKEDUNLOCKPICKUP &&
+      (cfg->room_size < 4 || cfg->width != 2 * (cfg->room_size - 1) + 1 || cfg->height != cfg->room_size))
+    return fail(nullptr, MG_ERR_INVALID, "Unlock levels are 1 x 2 RoomGrids: width = 2*(room_size-1)+1, height = room_size >= 4");
   if (cfg->env_kind == MG_ENV_FETCH && (cfg->num_dists < 1 || cfg->num_dists > 8))
     return fail(nullptr, MG_ERR_INVALID, "Fetch supports numObjs in 1..8");
   if (cfg->env_kind == MG_ENV_GOTODOOR && (cfg->width < 5 || cfg->height < 5))
@@ -295,6 +299,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
+  if (cfg->env_kind == MG_ENV_UNLOCK) { e->rule = RULE_UNLOCK; e->rule_cell = cfg->room_size - 1; }
+  if (cfg->env_kind == MG_ENV_UNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
 
   mg_env* env = e;   // for HIP_TRY
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)

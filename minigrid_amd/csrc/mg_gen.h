@@ -15,6 +15,7 @@ struct GenParams {
   int num_crossings, obstacle_cell;  // Crossing (obstacle_cell = cell code of Lava()/Wall())
   int num_dists;                     // GoToRedBall
   int strip2_row;                    // DistShift
+  int room_size;                     // RoomGrid levels
 };
 
 struct GenResult {
@@ -340,6 +341,49 @@ MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = (colors >> (4 * d)) & 15u;
 }
 
+// ---- core/roomgrid.py pieces for the 1 x 2 RoomGrid levels (Unlock, UnlockPickup, BlockedUnlockPickup) ----
+// RoomGrid.place_agent (roomgrid.py:313-334): place_agent in the room until the front cell is None or a wall
+template <class R>
+MG_D bool rg_place_agent(R& rng, GridRef& g, int topx, int topy, int rs, GenResult& out) {
+  for (;;) {
+    if (!place_agent(rng, g, topx, topy, rs, rs, 1000, out)) return false;
+    const uint32_t f = g.get((int)out.ax + dir_dx(out.dir), (int)out.ay + dir_dy(out.dir));
+    if (f == CELL_EMPTY || cell_type(f) == T_WALL) return true;
+  }
+}
+// envs/unlock.py:75-88, envs/unlockpickup.py:82-97, envs/blockedunlockpickup.py:90-110 (variant 0 / 1 / 2)
+template <class R>
+MG_D void gen_unlock_family(R& rng, GridRef& g, const GenParams& P, GenResult& out, int variant) {
+  const int rs = P.room_size, W = g.W, H = g.H;
+  // RoomGrid._gen_grid (roomgrid.py:123-179): wall_rect per room; one door position drawn per room pair; the agent
+  // "starts in the middle": that provisional position is what reject_next_to / place_obj see until place_agent
+  MG_WAVE_LDS_SYNC();
+  for (int y = 0; y < H; y++)
+    if (g.lane < W) {
+      const bool wall = y == 0 || y == H - 1 || (g.lane % (rs - 1)) == 0;
+      g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
+    }
+  MG_WAVE_LDS_SYNC();
+  const int door_x = rs - 1, door_y = rand_int(rng, 1, rs - 1);          // room (0,0).door_pos[0] = (x_m, rand(y_l, y_m))
+  const int mid_x = (2 / 2) * (rs - 1) + rs / 2, mid_y = rs / 2;         // provisional agent_pos (num_cols = 2, num_rows = 1)
+  int x, y;
+  uint32_t box_ci = 0;
+  if (variant >= 1) {                                                    // add_object(1, 0, kind="box"): colour draw, then place
+    box_ci = (uint32_t)rand_int(rng, 0, 6);
+    if (!place_obj(rng, g, make_cell(T_BOX, color_from_sorted(box_ci)), rs - 1, 0, rs, rs, mid_x, mid_y, true, 1000, x, y)) out.failed = true;
+  }
+  const uint32_t door_ci = (uint32_t)rand_int(rng, 0, 6);                // add_door(0, 0, 0, locked=True): colour draw
+  g.set(door_x, door_y, make_cell(T_DOOR_LOCKED, color_from_sorted(door_ci)));
+  if (variant == 2) {                                                    // block the door with a ball of a random colour
+    const uint32_t bc = (uint32_t)rand_int(rng, 0, 6);
+    g.set(door_x - 1, door_y, make_cell(T_BALL, color_from_sorted(bc)));
+  }
+  // add_object(0, 0, "key", door.color)
+  if (!place_obj(rng, g, make_cell(T_KEY, color_from_sorted(door_ci)), 0, 0, rs, rs, mid_x, mid_y, true, 1000, x, y)) out.failed = true;
+  if (!rg_place_agent(rng, g, 0, 0, rs, out)) out.failed = true;
+  out.mission = variant == 0 ? 0u : (variant == 1 ? box_ci : box_ci * 2u);
+}
+
 template <class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
@@ -352,6 +396,9 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     case 6: gen_fourrooms(rng, g, P, out); break;
     case 7: gen_fetch(rng, g, P, out); break;
     case 8: gen_gotodoor(rng, g, P, out); break;
+    case 9: gen_unlock_family(rng, g, P, out, 0); break;
+    case 10: gen_unlock_family(rng, g, P, out, 1); break;
+    case 11: gen_unlock_family(rng, g, P, out, 2); break;
     default: gen_goto_redball(rng, g, P, out); break;
   }
 }

@@ -27,7 +27,7 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
-enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3 };
+enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5 };
 
 struct StepParams {
   // state
@@ -40,7 +40,7 @@ struct StepParams {
   const double* reward_lut; uint32_t* refill_queue; uint32_t* refill_count; uint32_t* err;
   unsigned long long* counters;
   // config
-  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, autoreset_next_step, phase, static_gen, gen_blocks;
+  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen, gen_blocks;
   int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
@@ -345,6 +345,23 @@ k_step(const StepParams P, const GenArgs A) {
         const uint32_t m12 = a.mission % 12u;
         const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
         term = 1; success = a.carry == target;
+      }
+      if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
+        // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
+        // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
+        bool open = false;
+        for (int y = 1; y < H - 1; y++) {
+          const int idx = y * W + P.rule_cell;
+          const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
+          open |= cell_type(c) == T_DOOR;
+        }
+        if (open) { term = 1; success = true; }
+      }
+      if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
+        // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
+        // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
+        const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
+        if (a.carry == target) { term = 1; success = true; }
       }
       if (P.rule == RULE_GOTODOOR) {
         // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target

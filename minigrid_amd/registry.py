@@ -13,6 +13,7 @@ from typing import Dict, Tuple
 
 # mirror of include/minigrid_hip.h enums
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
+ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP = 9, 10, 11
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -30,6 +31,7 @@ class EnvSpec:
     obstacle_type: int = OBJ_LAVA
     num_dists: int = 0
     strip2_row: int = 0
+    room_size: int = 0
     entry_point: str = ""                              # the reference class this row configures
     kwargs: dict = field(default_factory=dict)
 
@@ -97,6 +99,12 @@ def _gotodoor(id_, size):
                    entry_point="minigrid.envs:GoToDoorEnv", kwargs={"size": size})
 
 
+def _roomgrid_1x2(id_, kind, room_size, max_steps, missions, entry_point):
+    # core/roomgrid.py:72-100: width = (room_size-1)*num_cols + 1, height = (room_size-1)*num_rows + 1, see_through_walls=False
+    return EnvSpec(id_, kind, (room_size - 1) * 2 + 1, room_size, max_steps, False, missions, room_size=room_size,
+                   entry_point=entry_point)
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -115,6 +123,14 @@ _ROWS = [
             entry_point="minigrid.envs:FourRoomsEnv"),
     _fetch("MiniGrid-Fetch-5x5-N2-v0", 5, 2), _fetch("MiniGrid-Fetch-6x6-N2-v0", 6, 2), _fetch("MiniGrid-Fetch-8x8-N3-v0", 8, 3),
     _gotodoor("MiniGrid-GoToDoor-5x5-v0", 5), _gotodoor("MiniGrid-GoToDoor-6x6-v0", 6), _gotodoor("MiniGrid-GoToDoor-8x8-v0", 8),
+    # unlock.py:52-70 (room_size 6, max_steps 8*36), unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (16*36);
+    # rows minigrid/__init__.py:17-21,555,560-563
+    _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
+    _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
+                  tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),
+    _roomgrid_1x2("MiniGrid-BlockedUnlockPickup-v0", ENV_BLOCKEDUNLOCKPICKUP, 6, 16 * 36,
+                  tuple(f"pick up the {c} {t}" for c in _COLOR_NAMES for t in ("box", "key")),
+                  "minigrid.envs:BlockedUnlockPickupEnv"),
 ]
 
 registry: Dict[str, EnvSpec] = {r.id: r for r in _ROWS}

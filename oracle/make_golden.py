@@ -52,6 +52,10 @@ MISSIONS = {
     "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
                        for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
     "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-UnlockPickup": [f"pick up the {c} box" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-Unlock-": ["open the door"],
+    "MiniGrid-BlockedUnlockPickup": [f"pick up the {c} {t}" for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                                     for t in ("box", "key")],
 }
 
 
@@ -132,6 +136,28 @@ def solver_action(env_id, u):
     if env_id.startswith("BabyAI-GoToRedBall"):
         p = plan_to_face(u, find(u, "ball", "red"))
         return p[0] if p else None
+    if env_id.startswith(("MiniGrid-Unlock", "MiniGrid-BlockedUnlockPickup")):
+        door = find(u, "door")
+        d = u.grid.get(*door)
+        if d.is_locked and (u.carrying is None or u.carrying.type != "key"):
+            if u.carrying is not None:          # holding the blocking ball: put it down somewhere free
+                return 4 if u.grid.get(*u.front_pos) is None else 0
+            blocker = u.grid.get(door[0] - 1, door[1])
+            if blocker is not None and blocker.type == "ball":
+                p = plan_to_face(u, (door[0] - 1, door[1]))
+                return 3 if p == [] else (p[0] if p else None)
+            p = plan_to_face(u, find(u, "key"))
+            return 3 if p == [] else (p[0] if p else None)
+        if not d.is_open:
+            p = plan_to_face(u, door)
+            return 5 if p == [] else (p[0] if p else None)
+        box = find(u, "box")
+        if box is not None:
+            if u.carrying is not None:
+                return 4 if u.grid.get(*u.front_pos) is None else 0
+            p = plan_to_face(u, box)
+            return 3 if p == [] else (p[0] if p else None)
+        return None
     if env_id.startswith("MiniGrid-Fetch"):
         p = plan_to_face(u, find(u, u.targetType, u.targetColor))
         return 3 if p == [] else (p[0] if p else None)
@@ -334,7 +360,8 @@ def main_wrappers():
 # ids added when the path was widened; `python oracle/make_golden.py wide` writes only these
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
             "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-5x5-N2-v0", "MiniGrid-Fetch-6x6-N2-v0",
-            "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0"]
+            "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0",
+            "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0"]
 
 
 def main_wide():

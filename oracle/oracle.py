@@ -16,6 +16,7 @@ _LIB = None
 
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
+K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP = 9, 10, 11
 T_WALL, T_LAVA = 2, 9
 
 
@@ -23,7 +24,7 @@ class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
         "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row", "view_size", "no_death_mask")] + [
-        ("death_cost", C.c_double)]
+        ("death_cost", C.c_double), ("room_size", C.c_int32), ("pad_", C.c_int32)]
 
 
 OBS_KINDS = {"partial": 0, "full": 1, "onehot": 2, "symbolic": 3}
@@ -70,7 +71,17 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_GOTODOOR, width=size, height=size, max_steps=4 * size * size, see_through=1,
                     missions=[f"go to the {c} door" for c in color_names])
 
+    def roomgrid(kind, room_size, rows, cols, max_steps, missions):
+        # core/roomgrid.py:72-100: width = (room_size-1)*num_cols + 1, see_through_walls=False
+        return dict(kind=kind, width=(room_size - 1) * cols + 1, height=(room_size - 1) * rows + 1, max_steps=max_steps,
+                    see_through=0, room_size=room_size, missions=missions)
+
     table = {
+        # unlock.py:52-70, unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (room_size 6, 1x2 rooms)
+        "MiniGrid-Unlock-v0": roomgrid(K_UNLOCK, 6, 1, 2, 8 * 36, ["open the door"]),
+        "MiniGrid-UnlockPickup-v0": roomgrid(K_UNLOCKPICKUP, 6, 1, 2, 8 * 36, [f"pick up the {c} box" for c in color_names]),
+        "MiniGrid-BlockedUnlockPickup-v0": roomgrid(K_BLOCKEDUNLOCKPICKUP, 6, 1, 2, 16 * 36,
+                                                   [f"pick up the {c} {t}" for c in color_names for t in ("box", "key")]),
         "MiniGrid-Fetch-5x5-N2-v0": fetch(5, 2), "MiniGrid-Fetch-6x6-N2-v0": fetch(6, 2), "MiniGrid-Fetch-8x8-N3-v0": fetch(8, 3),
         "MiniGrid-GoToDoor-5x5-v0": gotodoor(5), "MiniGrid-GoToDoor-6x6-v0": gotodoor(6), "MiniGrid-GoToDoor-8x8-v0": gotodoor(8),
         # lavagap.py:68-91, distshift.py:65-93, fourrooms.py:59-73 + their registry rows (minigrid/__init__.py:78-88,213-216,294-310)

@@ -104,8 +104,10 @@ def test_vs_oracle_4096_envs_multi_episode(env_id, full):
 @pytest.mark.parametrize("env_id", WIDE_IDS)
 @pytest.mark.parametrize("full", [False, True])
 def test_vs_oracle_widened_ids_2048_envs_multi_episode(env_id, full):
-    nterm, ntrunc = _compare_with_oracle(env_id, 2048, 260, full, seed0=77, probs=[0.15, 0.15, 0.45, 0.05, 0.05, 0.1, 0.05])
-    assert nterm > 20 and nterm + ntrunc > 100          # many finished episodes => autoreset + generator covered
+    T = 600 if "Unlock" in env_id else 260               # cover max_steps (288 / 576) of the RoomGrid levels
+    n = 1024 if "Unlock" in env_id else 2048
+    nterm, ntrunc = _compare_with_oracle(env_id, n, T, full, seed0=77, probs=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05])
+    assert nterm + ntrunc > 100                          # many finished episodes => autoreset + generator covered
 
 
 @pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 257, 1000])
