@@ -59,7 +59,9 @@ typedef enum mg_env_kind {
   /* RoomGrid levels (core/roomgrid.py:72-334), width = (room_size-1)*num_cols+1, height likewise: */
   MG_ENV_UNLOCK = 9,                /* envs/unlock.py:75-98                                                        */
   MG_ENV_UNLOCKPICKUP = 10,         /* envs/unlockpickup.py:82-107; mission id = COLOR_NAMES index of the box      */
-  MG_ENV_BLOCKEDUNLOCKPICKUP = 11   /* envs/blockedunlockpickup.py:90-119; mission id = colour index * 2 (box)     */
+  MG_ENV_BLOCKEDUNLOCKPICKUP = 11,  /* envs/blockedunlockpickup.py:90-119; mission id = colour index * 2 (box)     */
+  MG_ENV_REDBLUEDOORS = 12, /* envs/redbluedoors.py:78-126 (width = 2 * height)                                    */
+  MG_ENV_MEMORY = 13        /* envs/memory.py:92-164 (odd size; random_length)                                     */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
@@ -107,7 +109,7 @@ typedef struct mg_config {
   int32_t no_death_mask;      /* NoDeath wrapper (wrappers.py:845-882): bit t = cells of OBJECT_TO_IDX type t do not kill */
   double death_cost;          /* ... and add this to the reward instead (wrappers.py:879-880)                           */
   int32_t room_size;          /* RoomGrid levels (core/roomgrid.py:75)                                                  */
-  int32_t reserved[1];
+  int32_t random_length;      /* Memory (memory.py:70)                                                                  */
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
 } mg_config;
 

@@ -20,7 +20,7 @@ class MgConfig(C.Structure):
         "abi_version", "env_kind", "width", "height", "max_steps", "see_through_walls", "agent_view_size",
         "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
         "num_crossings", "obstacle_type", "num_dists", "null_stream_sync", "strip2_row", "no_death_mask")] + [
-        ("death_cost", C.c_double), ("room_size", C.c_int32), ("reserved", C.c_int32 * 1), ("env_index_base", C.c_int64)]
+        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("env_index_base", C.c_int64)]
 
 
 class MgOutputs(C.Structure):

@@ -81,6 +81,7 @@ static GenParams gen_params(const mg_env* e) {
   g.num_dists = e->cfg.num_dists;
   g.strip2_row = e->cfg.strip2_row;
   g.room_size = e->cfg.room_size;
+  g.random_length = e->cfg.random_length;
   return g;
 }
 
@@ -225,7 +226,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BLOCKEDUNLOCKPICKUP) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_MEMORY) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_REDBLUEDOORS && (cfg->width != 2 * cfg->height || cfg->height < 4))
+    return fail(nullptr, MG_ERR_INVALID, "RedBlueDoors is 2*size wide and size high (redbluedoors.py:70-71)");
+  if (cfg->env_kind == MG_ENV_MEMORY && ((cfg->height & 1) == 0 || cfg->height < 7 || cfg->width < 7))
+    return fail(nullptr, MG_ERR_INVALID, "Memory needs an odd size >= 7 (memory.py:101 assert)");
   if (cfg->env_kind >= MG_ENV_UNLOCK && cfg->env_kind <= MG_ENV_BLOCKEDUNLOCKPICKUP &&
       (cfg->room_size < 4 || cfg->width != 2 * (cfg->room_size - 1) + 1 || cfg->height != cfg->room_size))
     return fail(nullptr, MG_ERR_INVALID, "Unlock levels are 1 x 2 RoomGrids: width = 2*(room_size-1)+1, height = room_size >= 4");
@@ -299,6 +304,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
+  if (cfg->env_kind == MG_ENV_REDBLUEDOORS) e->rule = RULE_REDBLUE;
+  if (cfg->env_kind == MG_ENV_MEMORY) e->rule = RULE_MEMORY;
   if (cfg->env_kind == MG_ENV_UNLOCK) { e->rule = RULE_UNLOCK; e->rule_cell = cfg->room_size - 1; }
   if (cfg->env_kind == MG_ENV_UNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }

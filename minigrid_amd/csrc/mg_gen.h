@@ -16,6 +16,7 @@ struct GenParams {
   int num_dists;                     // GoToRedBall
   int strip2_row;                    // DistShift
   int room_size;                     // RoomGrid levels
+  int random_length;                 // Memory
 };
 
 struct GenResult {
@@ -384,6 +385,46 @@ MG_D void gen_unlock_family(R& rng, GridRef& g, const GenParams& P, GenResult& o
   out.mission = variant == 0 ? 0u : (variant == 1 ? box_ci : box_ci * 2u);
 }
 
+// envs/redbluedoors.py:78-102 (size = H, width = 2 * size)
+template <class R>
+MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int S = g.H, W = g.W;
+  MG_WAVE_LDS_SYNC();
+  for (int y = 0; y < S; y++)
+    if (g.lane < W) {           // wall_rect(0, 0, 2S, S) and wall_rect(S/2, 0, S, S)
+      const bool wall = y == 0 || y == S - 1 || g.lane == 0 || g.lane == W - 1 || g.lane == S / 2 || g.lane == S / 2 + S - 1;
+      g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
+    }
+  MG_WAVE_LDS_SYNC();
+  if (!place_agent(rng, g, S / 2, 0, S, S, -1, out)) out.failed = true;
+  g.set(S / 2, rand_int(rng, 1, S - 1), make_cell(T_DOOR_CLOSED, C_RED));
+  g.set(S / 2 + S - 1, rand_int(rng, 1, S - 1), make_cell(T_DOOR_CLOSED, C_BLUE));
+  out.mission = 0;
+}
+
+// envs/memory.py:92-149
+template <class R>
+MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H, mid = H / 2;
+  g.clear_with_walls();
+  const int upper = mid - 2, lower = mid + 2;
+  const int he = P.random_length ? rand_int(rng, 4, W - 2) : W - 3;
+  for (int i = 1; i < 5; i++) { g.set(i, upper, CELL_WALL_GREY); g.set(i, lower, CELL_WALL_GREY); }
+  g.set(4, upper + 1, CELL_WALL_GREY); g.set(4, lower - 1, CELL_WALL_GREY);
+  for (int i = 5; i < he; i++) { g.set(i, upper + 1, CELL_WALL_GREY); g.set(i, lower - 1, CELL_WALL_GREY); }
+  for (int j = 0; j < H; j++) {
+    if (j != mid) g.set(he, j, CELL_WALL_GREY);
+    g.set(he + 2, j, CELL_WALL_GREY);
+  }
+  out.ax = (uint32_t)rand_int(rng, 1, he + 1); out.ay = (uint32_t)mid; out.dir = 0;
+  const uint32_t start_ball = (uint32_t)rand_int(rng, 0, 2);                   // _rand_elem([Key, Ball])
+  g.set(1, mid - 1, make_cell(start_ball ? (uint32_t)T_BALL : (uint32_t)T_KEY, C_GREEN));
+  const uint32_t top_ball = rand_int(rng, 0, 2) == 0;                          // _rand_elem([[Ball, Key], [Key, Ball]])
+  g.set(he + 1, mid - 2, make_cell(top_ball ? (uint32_t)T_BALL : (uint32_t)T_KEY, C_GREEN));
+  g.set(he + 1, mid + 2, make_cell(top_ball ? (uint32_t)T_KEY : (uint32_t)T_BALL, C_GREEN));
+  out.mission = 0;
+}
+
 template <class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
@@ -399,6 +440,8 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     case 9: gen_unlock_family(rng, g, P, out, 0); break;
     case 10: gen_unlock_family(rng, g, P, out, 1); break;
     case 11: gen_unlock_family(rng, g, P, out, 2); break;
+    case 12: gen_redbluedoors(rng, g, P, out); break;
+    case 13: gen_memory(rng, g, P, out); break;
     default: gen_goto_redball(rng, g, P, out); break;
   }
 }

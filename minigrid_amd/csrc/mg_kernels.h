@@ -27,7 +27,8 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
-enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5 };
+enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
+              RULE_REDBLUE = 6, RULE_MEMORY = 7 };
 
 struct StepParams {
   // state
@@ -278,7 +279,8 @@ k_step(const StepParams P, const GenArgs A) {
 
   Agent a = agent_unpack(rec);
   const uint8_t* mygrid = sgrid + lane * GS;
-  const uint32_t act = sact[lane];
+  uint32_t act = sact[lane];
+  if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;     // MemoryEnv.step (memory.py:151-153)
   double reward = 0.0;
   uint32_t term = 0, trunc = 0, errbits = 0;
   bool rec_dirty = false;
@@ -362,6 +364,33 @@ k_step(const StepParams P, const GenArgs A) {
         // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
         const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
         if (a.carry == target) { term = 1; success = true; }
+      }
+      if (P.rule == RULE_REDBLUE) {
+        // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
+        // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
+        bool red_before = false, red_after = false, blue_before = false, blue_after = false;
+        const int xr = H / 2, xb = H / 2 + H - 1;
+        for (int y = 1; y < H - 1; y++) {
+          const int ir = y * W + xr, ib = y * W + xb;
+          const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
+          const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
+          red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
+          blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
+        }
+        if (blue_after) { term = 1; success = red_before; }
+        else if (red_after && blue_before) { term = 1; success = false; }
+      }
+      if (P.rule == RULE_MEMORY) {
+        // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
+        // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
+        // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
+        // the start-room object at (1, H/2 - 1)
+        const int mid = H / 2;
+        const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
+        if (oy >= 0) {
+          const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
+          if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
+        }
       }
       if (P.rule == RULE_GOTODOOR) {
         // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target

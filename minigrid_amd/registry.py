@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 
 # mirror of include/minigrid_hip.h enums
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
-ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP = 9, 10, 11
+ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY = 9, 10, 11, 12, 13
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -32,6 +32,7 @@ class EnvSpec:
     num_dists: int = 0
     strip2_row: int = 0
     room_size: int = 0
+    random_length: bool = False
     entry_point: str = ""                              # the reference class this row configures
     kwargs: dict = field(default_factory=dict)
 
@@ -125,6 +126,16 @@ _ROWS = [
     _gotodoor("MiniGrid-GoToDoor-5x5-v0", 5), _gotodoor("MiniGrid-GoToDoor-6x6-v0", 6), _gotodoor("MiniGrid-GoToDoor-8x8-v0", 8),
     # unlock.py:52-70 (room_size 6, max_steps 8*36), unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (16*36);
     # rows minigrid/__init__.py:17-21,555,560-563
+    # redbluedoors.py:60-76 (width 2*size, max_steps 20*size**2); rows minigrid/__init__.py:541-549
+    EnvSpec("MiniGrid-RedBlueDoors-6x6-v0", ENV_REDBLUEDOORS, 12, 6, 20 * 36, False, ("open the red door then the blue door",),
+            entry_point="minigrid.envs:RedBlueDoorEnv", kwargs={"size": 6}),
+    EnvSpec("MiniGrid-RedBlueDoors-8x8-v0", ENV_REDBLUEDOORS, 16, 8, 20 * 64, False, ("open the red door then the blue door",),
+            entry_point="minigrid.envs:RedBlueDoorEnv"),
+    # memory.py:69-90 (max_steps 5*size**2, see_through_walls=False); rows minigrid/__init__.py:323-357
+    *[EnvSpec(f"MiniGrid-MemoryS{sz}{'Random' if rnd else ''}-v0", ENV_MEMORY, sz, sz, 5 * sz * sz, False,
+              ("go to the matching object at the end of the hallway",), random_length=rnd,
+              entry_point="minigrid.envs:MemoryEnv", kwargs={"size": sz, **({"random_length": True} if rnd else {})})
+      for sz, rnd in ((17, True), (13, True), (13, False), (11, False), (9, False), (7, False))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),

@@ -94,7 +94,8 @@ class MiniGridVecEnv(_VectorEnvBase):
             obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET[autoreset_mode],
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
-            num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, env_index_base=self.env_index_base)
+            num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
+            env_index_base=self.env_index_base)
         if output == "torch" and stream is None:
             # outputs are handed out as torch tensors: run stream-ordered with torch.  A non-default current stream is
             # borrowed; the legacy NULL stream (torch's default) cannot be passed as a handle, so the library's own

@@ -52,6 +52,8 @@ MISSIONS = {
     "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
                        for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
     "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-RedBlueDoors": ["open the red door then the blue door"],
+    "MiniGrid-Memory": ["go to the matching object at the end of the hallway"],
     "MiniGrid-UnlockPickup": [f"pick up the {c} box" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Unlock-": ["open the door"],
     "MiniGrid-BlockedUnlockPickup": [f"pick up the {c} {t}" for c in ("blue", "green", "grey", "purple", "red", "yellow")
@@ -158,6 +160,17 @@ def solver_action(env_id, u):
             p = plan_to_face(u, box)
             return 3 if p == [] else (p[0] if p else None)
         return None
+    if env_id.startswith("MiniGrid-RedBlueDoors"):
+        door = u.red_door if not u.red_door.is_open else u.blue_door
+        pos = find(u, "door", door.color)
+        if u.np_random is not None and u.step_count % 7 == 3:          # sometimes go for the wrong door first
+            pos = find(u, "door", "blue")
+        p = plan_to_face(u, pos)
+        return 5 if p == [] else (p[0] if p else None)
+    if env_id.startswith("MiniGrid-Memory"):
+        target = u.success_pos if (u.step_count // 40) % 2 == 0 else u.failure_pos
+        p = plan_to_face(u, target, stand_on=True)
+        return p[0] if p else None
     if env_id.startswith("MiniGrid-Fetch"):
         p = plan_to_face(u, find(u, u.targetType, u.targetColor))
         return 3 if p == [] else (p[0] if p else None)
@@ -361,7 +374,10 @@ def main_wrappers():
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
             "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-5x5-N2-v0", "MiniGrid-Fetch-6x6-N2-v0",
             "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0",
-            "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0"]
+            "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0",
+            "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-MemoryS17Random-v0",
+            "MiniGrid-MemoryS13Random-v0", "MiniGrid-MemoryS13-v0", "MiniGrid-MemoryS11-v0", "MiniGrid-MemoryS9-v0",
+            "MiniGrid-MemoryS7-v0"]
 
 
 def main_wide():

@@ -16,7 +16,7 @@ _LIB = None
 
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
-K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP = 9, 10, 11
+K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY = 9, 10, 11, 12, 13
 T_WALL, T_LAVA = 2, 9
 
 
@@ -24,7 +24,7 @@ class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
         "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row", "view_size", "no_death_mask")] + [
-        ("death_cost", C.c_double), ("room_size", C.c_int32), ("pad_", C.c_int32)]
+        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32)]
 
 
 OBS_KINDS = {"partial": 0, "full": 1, "onehot": 2, "symbolic": 3}
@@ -76,7 +76,21 @@ def spec(env_id: str) -> dict:
         return dict(kind=kind, width=(room_size - 1) * cols + 1, height=(room_size - 1) * rows + 1, max_steps=max_steps,
                     see_through=0, room_size=room_size, missions=missions)
 
+    def redblue(size):
+        # redbluedoors.py:60-76: width = 2*size, max_steps = 20*size**2, default see_through_walls=False
+        return dict(kind=K_REDBLUEDOORS, width=2 * size, height=size, max_steps=20 * size * size, see_through=0,
+                    missions=["open the red door then the blue door"])
+
+    def memory(size, random_length=False):
+        # memory.py:69-90: max_steps = 5*size**2, see_through_walls=False
+        return dict(kind=K_MEMORY, width=size, height=size, max_steps=5 * size * size, see_through=0,
+                    random_length=int(random_length), missions=["go to the matching object at the end of the hallway"])
+
     table = {
+        "MiniGrid-RedBlueDoors-6x6-v0": redblue(6), "MiniGrid-RedBlueDoors-8x8-v0": redblue(8),
+        "MiniGrid-MemoryS17Random-v0": memory(17, True), "MiniGrid-MemoryS13Random-v0": memory(13, True),
+        "MiniGrid-MemoryS13-v0": memory(13), "MiniGrid-MemoryS11-v0": memory(11), "MiniGrid-MemoryS9-v0": memory(9),
+        "MiniGrid-MemoryS7-v0": memory(7),
         # unlock.py:52-70, unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (room_size 6, 1x2 rooms)
         "MiniGrid-Unlock-v0": roomgrid(K_UNLOCK, 6, 1, 2, 8 * 36, ["open the door"]),
         "MiniGrid-UnlockPickup-v0": roomgrid(K_UNLOCKPICKUP, 6, 1, 2, 8 * 36, [f"pick up the {c} box" for c in color_names]),

@@ -17,7 +17,10 @@ EXTRA_IDS = ["MiniGrid-Empty-5x5-v0", "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
             "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-5x5-N2-v0", "MiniGrid-Fetch-6x6-N2-v0",
             "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0",
-            "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0"]
+            "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0",
+            "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-MemoryS17Random-v0",
+            "MiniGrid-MemoryS13Random-v0", "MiniGrid-MemoryS13-v0", "MiniGrid-MemoryS11-v0", "MiniGrid-MemoryS9-v0",
+            "MiniGrid-MemoryS7-v0"]
 ALL_IDS = MAIN_IDS + EXTRA_IDS + WIDE_IDS
 
 
