@@ -61,7 +61,8 @@ typedef enum mg_env_kind {
   MG_ENV_UNLOCKPICKUP = 10,         /* envs/unlockpickup.py:82-107; mission id = COLOR_NAMES index of the box      */
   MG_ENV_BLOCKEDUNLOCKPICKUP = 11,  /* envs/blockedunlockpickup.py:90-119; mission id = colour index * 2 (box)     */
   MG_ENV_REDBLUEDOORS = 12, /* envs/redbluedoors.py:78-126 (width = 2 * height)                                    */
-  MG_ENV_MEMORY = 13        /* envs/memory.py:92-164 (odd size; random_length)                                     */
+  MG_ENV_MEMORY = 13,       /* envs/memory.py:92-164 (odd size; random_length)                                     */
+  MG_ENV_KEYCORRIDOR = 14   /* envs/keycorridor.py:106-145 (3 x num_rows RoomGrid, connect_all); mission id = ball colour */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {

@@ -226,7 +226,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_MEMORY) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_KEYCORRIDOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_KEYCORRIDOR && (cfg->room_size < 3 || cfg->width != 3 * (cfg->room_size - 1) + 1 ||
+      (cfg->height - 1) % (cfg->room_size - 1) != 0 || (cfg->height - 1) / (cfg->room_size - 1) < 1 || (cfg->height - 1) / (cfg->room_size - 1) > 3 || cfg->width > 16 || cfg->height > 16))
+    return fail(nullptr, MG_ERR_INVALID, "KeyCorridor is a 3 x (1..3) RoomGrid with room_size >= 3 and a grid of at most 16 x 16");
   if (cfg->env_kind == MG_ENV_REDBLUEDOORS && (cfg->width != 2 * cfg->height || cfg->height < 4))
     return fail(nullptr, MG_ERR_INVALID, "RedBlueDoors is 2*size wide and size high (redbluedoors.py:70-71)");
   if (cfg->env_kind == MG_ENV_MEMORY && ((cfg->height & 1) == 0 || cfg->height < 7 || cfg->width < 7))
@@ -308,6 +311,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_MEMORY) e->rule = RULE_MEMORY;
   if (cfg->env_kind == MG_ENV_UNLOCK) { e->rule = RULE_UNLOCK; e->rule_cell = cfg->room_size - 1; }
   if (cfg->env_kind == MG_ENV_UNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_KEYCORRIDOR) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BALL; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
 
   mg_env* env = e;   // for HIP_TRY

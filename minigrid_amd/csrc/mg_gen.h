@@ -385,6 +385,97 @@ MG_D void gen_unlock_family(R& rng, GridRef& g, const GenParams& P, GenResult& o
   out.mission = variant == 0 ? 0u : (variant == 1 ? box_ci : box_ci * 2u);
 }
 
+// ---- general RoomGrid (core/roomgrid.py) for KeyCorridor: 3 columns x up to 3 rows of rooms.  Room bookkeeping is
+//      packed: 4 bits per room for the right-door y and the down-door x, one bit per (room, wall) for "has a door or
+//      no wall" (Room.doors truthiness), one bit per room for Room.locked. ----
+struct RoomGridState {
+  int rs, ncols, nrows;
+  uint64_t right_y, down_x;     // nibble per room
+  uint64_t doors;               // bit room*4 + k, k = right, down, left, up
+  uint32_t locked;              // bit per room
+  MG_D int room(int i, int j) const { return j * ncols + i; }
+  MG_D bool has_nb(int i, int j, int k) const { return k == 0 ? i < ncols - 1 : k == 1 ? j < nrows - 1 : k == 2 ? i > 0 : j > 0; }
+  MG_D void door_pos(int i, int j, int k, int& x, int& y) const {     // Room.door_pos[k] (roomgrid.py:158-171)
+    if (k == 2) { i -= 1; k = 0; }
+    if (k == 3) { j -= 1; k = 1; }
+    const int r = room(i, j);
+    if (k == 0) { x = i * (rs - 1) + rs - 1; y = (int)((right_y >> (4 * r)) & 15u); }
+    else { x = (int)((down_x >> (4 * r)) & 15u); y = j * (rs - 1) + rs - 1; }
+  }
+  MG_D void mark(int i, int j, int k) {                               // room.doors[k] and the neighbour's opposite side
+    doors |= 1ull << (room(i, j) * 4 + k);
+    const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+    doors |= 1ull << (room(ni, nj) * 4 + ((k + 2) & 3));
+  }
+};
+
+// envs/keycorridor.py:106-133 on RoomGrid._gen_grid / remove_wall / add_door / add_object / place_agent / connect_all
+// (roomgrid.py:123-394).  Mission id = COLOR_NAMES index of the ball.
+template <class R>
+MG_D void gen_keycorridor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  RoomGridState S;
+  S.rs = P.room_size; S.ncols = (g.W - 1) / (S.rs - 1); S.nrows = (g.H - 1) / (S.rs - 1);
+  S.right_y = 0; S.down_x = 0; S.doors = 0; S.locked = 0;
+  const int rs = S.rs, W = g.W, H = g.H;
+  MG_WAVE_LDS_SYNC();
+  for (int y = 0; y < H; y++)
+    if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % (rs - 1)) == 0 || (y % (rs - 1)) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+  MG_WAVE_LDS_SYNC();
+  for (int j = 0; j < S.nrows; j++)
+    for (int i = 0; i < S.ncols; i++) {
+      const int tx = i * (rs - 1), ty = j * (rs - 1), r = S.room(i, j);
+      if (i < S.ncols - 1) S.right_y |= (uint64_t)rand_int(rng, ty + 1, ty + rs - 1) << (4 * r);
+      if (j < S.nrows - 1) S.down_x |= (uint64_t)rand_int(rng, tx + 1, tx + rs - 1) << (4 * r);
+    }
+  const int mid_x = (S.ncols / 2) * (rs - 1) + rs / 2, mid_y = (S.nrows / 2) * (rs - 1) + rs / 2;   // provisional agent_pos
+  for (int j = 1; j < S.nrows; j++) {                       // remove_wall(1, j, 3): the middle column becomes a hallway
+    for (int k = 1; k < rs - 1; k++) g.set((rs - 1) + k, j * (rs - 1), CELL_EMPTY);
+    S.mark(1, j, 3);
+  }
+  const int room_idx = rand_int(rng, 0, S.nrows);
+  int x, y;
+  const uint32_t door_ci = (uint32_t)rand_int(rng, 0, 6);   // add_door(2, room_idx, 2, locked=True)
+  S.door_pos(2, room_idx, 2, x, y);
+  g.set(x, y, make_cell(T_DOOR_LOCKED, color_from_sorted(door_ci)));
+  S.mark(2, room_idx, 2);
+  S.locked |= 1u << S.room(2, room_idx);
+  const uint32_t ball_ci = (uint32_t)rand_int(rng, 0, 6);   // add_object(2, room_idx, kind="ball")
+  if (!place_obj(rng, g, make_cell(T_BALL, color_from_sorted(ball_ci)), 2 * (rs - 1), room_idx * (rs - 1), rs, rs,
+                 mid_x, mid_y, true, 1000, x, y)) out.failed = true;
+  const int kj = rand_int(rng, 0, S.nrows);                 // add_object(0, rand, "key", door.color)
+  if (!place_obj(rng, g, make_cell(T_KEY, color_from_sorted(door_ci)), 0, kj * (rs - 1), rs, rs, mid_x, mid_y, true, 1000, x, y))
+    out.failed = true;
+  if (!rg_place_agent(rng, g, rs - 1, (S.nrows / 2) * (rs - 1), rs, out)) out.failed = true;
+  // connect_all (roomgrid.py:336-394)
+  const int start = S.room((int)out.ax / (rs - 1), (int)out.ay / (rs - 1));
+  const int nrooms = S.ncols * S.nrows;
+  for (int itr = 0; !rng.dead(); itr++) {
+    if (itr > 5000) { out.failed = true; break; }
+    uint32_t reach = 1u << start;
+    for (;;) {
+      uint32_t next = reach;
+      for (int r = 0; r < nrooms; r++)
+        if ((reach >> r) & 1u) {
+          const int i = r % S.ncols, j = r / S.ncols;
+          for (int k = 0; k < 4; k++)
+            if ((S.doors >> (r * 4 + k)) & 1ull) next |= 1u << S.room(i + (k == 0) - (k == 2), j + (k == 1) - (k == 3));
+        }
+      if (next == reach) break;
+      reach = next;
+    }
+    if (reach == (1u << nrooms) - 1u) break;
+    const int i = rand_int(rng, 0, S.ncols), j = rand_int(rng, 0, S.nrows), k = rand_int(rng, 0, 4);
+    if (!S.has_nb(i, j, k) || ((S.doors >> (S.room(i, j) * 4 + k)) & 1ull)) continue;
+    const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+    if (((S.locked >> S.room(i, j)) | (S.locked >> S.room(ni, nj))) & 1u) continue;
+    const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);
+    S.door_pos(i, j, k, x, y);
+    g.set(x, y, make_cell(T_DOOR_CLOSED, color_from_sorted(ci)));
+    S.mark(i, j, k);
+  }
+  out.mission = ball_ci;
+}
+
 // envs/redbluedoors.py:78-102 (size = H, width = 2 * size)
 template <class R>
 MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -442,6 +533,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     case 11: gen_unlock_family(rng, g, P, out, 2); break;
     case 12: gen_redbluedoors(rng, g, P, out); break;
     case 13: gen_memory(rng, g, P, out); break;
+    case 14: gen_keycorridor(rng, g, P, out); break;
     default: gen_goto_redball(rng, g, P, out); break;
   }
 }

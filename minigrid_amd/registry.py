@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 
 # mirror of include/minigrid_hip.h enums
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
-ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY = 9, 10, 11, 12, 13
+ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY, ENV_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -136,6 +136,11 @@ _ROWS = [
               ("go to the matching object at the end of the hallway",), random_length=rnd,
               entry_point="minigrid.envs:MemoryEnv", kwargs={"size": sz, **({"random_length": True} if rnd else {})})
       for sz, rnd in ((17, True), (13, True), (13, False), (11, False), (9, False), (7, False))],
+    # keycorridor.py:75-104 (num_cols 3, max_steps 30*room_size**2, obj_type "ball"); rows minigrid/__init__.py:255-289
+    *[EnvSpec(f"MiniGrid-KeyCorridorS{rs}R{rows}-v0", ENV_KEYCORRIDOR, 3 * (rs - 1) + 1, rows * (rs - 1) + 1, 30 * rs * rs, False,
+              tuple(f"pick up the {c} ball" for c in _COLOR_NAMES), room_size=rs, entry_point="minigrid.envs:KeyCorridorEnv",
+              kwargs={"room_size": rs, "num_rows": rows})
+      for rs, rows in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),

@@ -52,6 +52,7 @@ MISSIONS = {
     "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
                        for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
     "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-KeyCorridor": [f"pick up the {c} ball" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-RedBlueDoors": ["open the red door then the blue door"],
     "MiniGrid-Memory": ["go to the matching object at the end of the hallway"],
     "MiniGrid-UnlockPickup": [f"pick up the {c} box" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
@@ -159,6 +160,29 @@ def solver_action(env_id, u):
                 return 4 if u.grid.get(*u.front_pos) is None else 0
             p = plan_to_face(u, box)
             return 3 if p == [] else (p[0] if p else None)
+        return None
+    if env_id.startswith("MiniGrid-KeyCorridor"):
+        # key -> doors -> ball; the BFS treats closed doors as walls, so open the reachable ones on the way
+        def reachable_closed_door(locked_ok):
+            for i in range(u.width):
+                for j in range(u.height):
+                    c = u.grid.get(i, j)
+                    if c is not None and c.type == "door" and not c.is_open and (locked_ok or not c.is_locked):
+                        q = plan_to_face(u, (i, j))
+                        if q is not None:
+                            return 5 if q == [] else q[0]
+            return None
+        tgt = find(u, "ball")
+        if u.carrying is None:
+            key = find(u, "key")
+            p = plan_to_face(u, key if key is not None else tgt)
+            if p is None:
+                return reachable_closed_door(False)
+            return 3 if p == [] else p[0]
+        if u.carrying.type == "key":
+            if plan_to_face(u, tgt) is None:
+                return reachable_closed_door(True)
+            return 4 if u.grid.get(*u.front_pos) is None else 0      # way to the ball is open: put the key down
         return None
     if env_id.startswith("MiniGrid-RedBlueDoors"):
         door = u.red_door if not u.red_door.is_open else u.blue_door
@@ -377,7 +401,8 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-Unlock-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0",
             "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-MemoryS17Random-v0",
             "MiniGrid-MemoryS13Random-v0", "MiniGrid-MemoryS13-v0", "MiniGrid-MemoryS11-v0", "MiniGrid-MemoryS9-v0",
-            "MiniGrid-MemoryS7-v0"]
+            "MiniGrid-MemoryS7-v0", "MiniGrid-KeyCorridorS3R1-v0", "MiniGrid-KeyCorridorS3R2-v0", "MiniGrid-KeyCorridorS3R3-v0",
+            "MiniGrid-KeyCorridorS4R3-v0", "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-KeyCorridorS6R3-v0"]
 
 
 def main_wide():

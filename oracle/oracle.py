@@ -16,7 +16,7 @@ _LIB = None
 
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
-K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY = 9, 10, 11, 12, 13
+K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 T_WALL, T_LAVA = 2, 9
 
 
@@ -86,7 +86,13 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_MEMORY, width=size, height=size, max_steps=5 * size * size, see_through=0,
                     random_length=int(random_length), missions=["go to the matching object at the end of the hallway"])
 
+    def keycorridor(room_size, rows):
+        # keycorridor.py:75-104: num_cols = 3 (RoomGrid default), max_steps = 30*room_size**2, obj_type "ball"
+        return roomgrid(K_KEYCORRIDOR, room_size, rows, 3, 30 * room_size * room_size,
+                        [f"pick up the {c} ball" for c in color_names])
+
     table = {
+        **{f"MiniGrid-KeyCorridorS{s_}R{r_}-v0": keycorridor(s_, r_) for s_, r_ in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))},
         "MiniGrid-RedBlueDoors-6x6-v0": redblue(6), "MiniGrid-RedBlueDoors-8x8-v0": redblue(8),
         "MiniGrid-MemoryS17Random-v0": memory(17, True), "MiniGrid-MemoryS13Random-v0": memory(13, True),
         "MiniGrid-MemoryS13-v0": memory(13), "MiniGrid-MemoryS11-v0": memory(11), "MiniGrid-MemoryS9-v0": memory(9),
