@@ -166,19 +166,14 @@ static int launch_step(mg_env* e, const StepParams& P) {
     if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox, VT>), grid, block, lds, e->stream, P, A);   \
     else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64, VT>), grid, block, lds, e->stream, P, A);           \
   } while (0)
-  // instantiated variants: the default 7x7 view and the FullyObs encode with 1/2/4 waves per group (tuning knob);
-  // the wrappers' encodes (other view sizes, one-hot, symbolic) with 4
+  // instantiated variants (each carries the ~17 k-instruction generator role, so the list is kept short): 4 waves per
+  // group only -- 1 and 2 were measured slower at every batch size (profiles/r1_baseline/sweep_wpg.txt)
   const bool v7 = e->cfg.agent_view_size == 7;
   switch (e->cfg.obs_mode) {
-    case MG_OBS_FULL:
-      if (e->wpg == 1) MG_LAUNCH_STEP(1, 1, 7); else if (e->wpg == 2) MG_LAUNCH_STEP(1, 2, 7); else MG_LAUNCH_STEP(1, 4, 7);
-      break;
+    case MG_OBS_FULL: MG_LAUNCH_STEP(1, 4, 7); break;
     case MG_OBS_SYMBOLIC: MG_LAUNCH_STEP(3, 4, 7); break;
     case MG_OBS_ONEHOT: if (v7) MG_LAUNCH_STEP(2, 4, 7); else MG_LAUNCH_STEP(2, 4, 15); break;
-    default:
-      if (!v7) MG_LAUNCH_STEP(0, 4, 15);
-      else if (e->wpg == 1) MG_LAUNCH_STEP(0, 1, 7); else if (e->wpg == 2) MG_LAUNCH_STEP(0, 2, 7); else MG_LAUNCH_STEP(0, 4, 7);
-      break;
+    default: if (v7) MG_LAUNCH_STEP(0, 4, 7); else MG_LAUNCH_STEP(0, 4, 15); break;
   }
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
@@ -284,12 +279,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->lds_bytes = e->off_act + 64;
   }
   {
-    // waves per 64-env group.  Measured on MI355X (profiles/r1/sweep_wpg.txt): 4 wins at every batch size from
-    // 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
-    // dependent LDS/HBM latency per wave, not by issue slots.  MG_WPG overrides (tuning / tests).
+    // waves per 64-env group.  Measured on MI355X (profiles/r1_baseline/sweep_wpg.txt): 4 wins at every batch size
+    // from 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
+    // dependent LDS/HBM latency per wave, not by issue slots.  k_step keeps WPG as a template parameter; only 4 is built.
     e->wpg = 4;
-    const bool tunable = cfg->agent_view_size == 7 && (cfg->obs_mode == MG_OBS_PARTIAL || cfg->obs_mode == MG_OBS_FULL);
-    if (const char* s = getenv("MG_WPG")) { int v = atoi(s); if (tunable && (v == 1 || v == 2 || v == 4)) e->wpg = v; }
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -361,8 +354,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->lds_bytes > 64 * 1024) {
     const void* fns[] = {
 #define MG_K(MODE, WPG, VT) (const void*)k_step<MODE, WPG, WavePcg64, VT>, (const void*)k_step<MODE, WPG, WavePhilox, VT>
-      MG_K(0, 1, 7), MG_K(0, 2, 7), MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 1, 7), MG_K(1, 2, 7), MG_K(1, 4, 7),
-      MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7)
+      MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7)
 #undef MG_K
     };
     for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
