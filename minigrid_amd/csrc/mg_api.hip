@@ -45,6 +45,7 @@ struct mg_env {
   // bookkeeping
   uint32_t launches = 0;      // k_step launches so far (refill queue slot = launches % 3)
   int gen_blocks = 0;         // generator workgroups at the head of every k_step launch
+  int gen_group = GG_NONE;    // which generators the k_step variant carries (mg_gen.h)
   int gen_cap_words = 0;      // their draw-buffer capacity (words), limited by the launch's LDS size
   uint32_t t = 0;             // rollout step counter (Philox action counter)
   std::string last_error;
@@ -161,12 +162,18 @@ static int launch_step(mg_env* e, const StepParams& P) {
   A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + QC_STRIDE * ((L + 2) % 3);
   A.zero_count = e->qcount + QC_STRIDE * ((L + 1) % 3);
   A.cap_words = e->gen_cap_words;
-#define MG_LAUNCH_STEP(MODE, WPG, VT)                                                                         \
-  do {                                                                                                        \
-    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox, VT>), grid, block, lds, e->stream, P, A);   \
-    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64, VT>), grid, block, lds, e->stream, P, A);           \
+#define MG_LAUNCH_STEP_G(MODE, WPG, VT, GG)                                                                       \
+  do {                                                                                                            \
+    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox, VT, GG>), grid, block, lds, e->stream, P, A);   \
+    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64, VT, GG>), grid, block, lds, e->stream, P, A);           \
   } while (0)
-  // instantiated variants (each carries the ~17 k-instruction generator role, so the list is kept short): 4 waves per
+#define MG_LAUNCH_STEP(MODE, WPG, VT)                                                    \
+  do {                                                                                   \
+    if (e->gen_group == GG_NONE) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_NONE);               \
+    else if (e->gen_group == GG_LIGHT) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_LIGHT);        \
+    else MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_ROOMGRID);                                   \
+  } while (0)
+  // instantiated variants (each carries its generator group's code, so the list is kept short): 4 waves per
   // group only -- 1 and 2 were measured slower at every batch size (profiles/r1_baseline/sweep_wpg.txt)
   const bool v7 = e->cfg.agent_view_size == 7;
   switch (e->cfg.obs_mode) {
@@ -175,6 +182,7 @@ static int launch_step(mg_env* e, const StepParams& P) {
     case MG_OBS_ONEHOT: if (v7) MG_LAUNCH_STEP(2, 4, 7); else MG_LAUNCH_STEP(2, 4, 15); break;
     default: if (v7) MG_LAUNCH_STEP(0, 4, 7); else MG_LAUNCH_STEP(0, 4, 15); break;
   }
+#undef MG_LAUNCH_STEP_G
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
   e->launches++;
@@ -294,6 +302,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
     e->gen_cap_words = std::min(2048, (e->lds_bytes / e->wpg - e->CS - GEN_SBASE_BYTES) / 4 - 4) & ~3;
     e->gen_blocks = std::min(1024, e->N);
+    e->gen_group = gen_group_of_kind(cfg->env_kind);
     if (const char* s = getenv("MG_GEN_BLOCKS")) { int v = atoi(s); if (v >= 1 && v <= 65536) e->gen_blocks = std::min(v, e->N); }
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
@@ -353,9 +362,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   if (e->lds_bytes > 64 * 1024) {
     const void* fns[] = {
-#define MG_K(MODE, WPG, VT) (const void*)k_step<MODE, WPG, WavePcg64, VT>, (const void*)k_step<MODE, WPG, WavePhilox, VT>
+#define MG_KG(MODE, WPG, VT, GG) (const void*)k_step<MODE, WPG, WavePcg64, VT, GG>, (const void*)k_step<MODE, WPG, WavePhilox, VT, GG>
+#define MG_K(MODE, WPG, VT) MG_KG(MODE, WPG, VT, GG_NONE), MG_KG(MODE, WPG, VT, GG_LIGHT), MG_KG(MODE, WPG, VT, GG_ROOMGRID)
       MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7)
 #undef MG_K
+#undef MG_KG
     };
     for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
   }

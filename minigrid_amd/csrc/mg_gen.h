@@ -144,9 +144,12 @@ MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = 1; out.ay = 1; out.dir = 0;
   g.set(W - 2, H - 2, CELL_GOAL);
   uint64_t rivers = 0; int n = 0;
+#pragma unroll 1
   for (int i = 2; i < H - 2; i += 2) { rivers |= (uint64_t)(i) << (8 * n); n++; }          // (v, i)
+#pragma unroll 1
   for (int j = 2; j < W - 2; j += 2) { rivers |= (uint64_t)(0x80 | j) << (8 * n); n++; }   // (h, j)
   // np_random.shuffle(rivers): for i = n-1..1: j = random_interval(i); swap
+#pragma unroll 1
   for (int i = n - 1; i >= 1; i--) {
     int j = (int)rand_interval(rng, (uint32_t)i);
     uint64_t bi = (rivers >> (8 * i)) & 0xFF, bj = (rivers >> (8 * j)) & 0xFF;
@@ -155,16 +158,23 @@ MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   }
   n = min(n, P.num_crossings);
   uint32_t vmask = 0, hmask = 0; int nv = 0, nh = 0;    // sorted(rivers_v), sorted(rivers_h) as position bitmasks
+#pragma unroll 1
   for (int k = 0; k < n; k++) {
     uint32_t b = (uint32_t)(rivers >> (8 * k)) & 0xFF;
     if (b & 0x80) { hmask |= 1u << (b & 0x7F); nh++; } else { vmask |= 1u << b; nv++; }
   }
+#pragma unroll 1
   for (int p = 2; p < 32; p += 2) {
-    if ((hmask >> p) & 1) for (int i = 1; i < W - 1; i++) g.set(i, p, P.obstacle_cell);
-    if ((vmask >> p) & 1) for (int j = 1; j < H - 1; j++) g.set(p, j, P.obstacle_cell);
+    if ((hmask >> p) & 1) {
+#pragma unroll 1
+      for (int i = 1; i < W - 1; i++) g.set(i, p, P.obstacle_cell); }
+    if ((vmask >> p) & 1) {
+#pragma unroll 1
+      for (int j = 1; j < H - 1; j++) g.set(p, j, P.obstacle_cell); }
   }
   // path = [h]*len(rivers_v) + [v]*len(rivers_h); shuffle.  bit k of `path` = 1 for h.
   uint32_t path = (1u << nv) - 1u; const int np = nv + nh;
+#pragma unroll 1
   for (int i = np - 1; i >= 1; i--) {
     int j = (int)rand_interval(rng, (uint32_t)i);
     uint32_t bi = (path >> i) & 1u, bj = (path >> j) & 1u;
@@ -174,6 +184,7 @@ MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   int room_i = 0, room_j = 0;
   int lv_lo = 0, lh_lo = 0;                 // limits_v[room_i], limits_h[room_j]
   uint32_t vrem = vmask, hrem = hmask;      // not-yet-crossed rivers, lowest bit = next limit
+#pragma unroll 1
   for (int k = 0; k < np; k++) {
     int lv_hi = vrem ? __builtin_ctz(vrem) : H - 1;   // limits_v[room_i + 1]
     int lh_hi = hrem ? __builtin_ctz(hrem) : W - 1;   // limits_h[room_j + 1]
@@ -516,26 +527,43 @@ MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = 0;
 }
 
-template <class R>
+// Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
+// pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
+// under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
+//   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
+//   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall)
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ALL = 3 };
+MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14) ? GG_ROOMGRID : GG_LIGHT; }
+
+template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
-  switch (P.kind) {
-    case 0: gen_empty(rng, g, P, out); break;
-    case 1: gen_doorkey(rng, g, P, out); break;
-    case 2: gen_crossing(rng, g, P, out); break;
-    case 4: gen_lavagap(rng, g, P, out); break;
-    case 5: gen_distshift(rng, g, P, out); break;
-    case 6: gen_fourrooms(rng, g, P, out); break;
-    case 7: gen_fetch(rng, g, P, out); break;
-    case 8: gen_gotodoor(rng, g, P, out); break;
-    case 9: gen_unlock_family(rng, g, P, out, 0); break;
-    case 10: gen_unlock_family(rng, g, P, out, 1); break;
-    case 11: gen_unlock_family(rng, g, P, out, 2); break;
-    case 12: gen_redbluedoors(rng, g, P, out); break;
-    case 13: gen_memory(rng, g, P, out); break;
-    case 14: gen_keycorridor(rng, g, P, out); break;
-    default: gen_goto_redball(rng, g, P, out); break;
+  if constexpr (GG == GG_LIGHT || GG == GG_ALL) {
+    switch (P.kind) {
+      case 0: gen_empty(rng, g, P, out); return;
+      case 1: gen_doorkey(rng, g, P, out); return;
+      case 2: gen_crossing(rng, g, P, out); return;
+      case 4: gen_lavagap(rng, g, P, out); return;
+      case 5: gen_distshift(rng, g, P, out); return;
+      case 6: gen_fourrooms(rng, g, P, out); return;
+      case 7: gen_fetch(rng, g, P, out); return;
+      case 8: gen_gotodoor(rng, g, P, out); return;
+      case 12: gen_redbluedoors(rng, g, P, out); return;
+      case 13: gen_memory(rng, g, P, out); return;
+      default: break;
+    }
   }
+  if constexpr (GG == GG_ROOMGRID || GG == GG_ALL) {
+    switch (P.kind) {
+      case 3: gen_goto_redball(rng, g, P, out); return;
+      case 9: gen_unlock_family(rng, g, P, out, 0); return;
+      case 10: gen_unlock_family(rng, g, P, out, 1); return;
+      case 11: gen_unlock_family(rng, g, P, out, 2); return;
+      case 14: gen_keycorridor(rng, g, P, out); return;
+      default: break;
+    }
+  }
+  out.failed = true;      // a kind this instantiation was not built for (the host never launches that)
 }
 
 }  // namespace mg

@@ -113,7 +113,7 @@ constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
 MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4; }
 
 // wave-cooperative: all 64 lanes of one wave call this with the same `e`; `lds` = gen_wave_lds_bytes() of LDS
-template <class RNG>
+template <int GG, class RNG>
 MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t* lds) {
   const size_t N = (size_t)A.N;
 
@@ -138,7 +138,15 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     while (rng.limit < rng.off + budget) rng.refill();
     MG_STAMP(3);
     rng.begin_pass();
-    generate_episode(rng, g, A.gp, out);
+    // The generator parameters are made opaque per pass: otherwise every switch case's loop-invariant set-up is
+    // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70, i.e.
+    // 256 B/lane of scratch on every wave of a k_step launch under its register budget.
+    GenParams gp = A.gp;
+    asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
+    asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length));
+    g.W = gp.W; g.H = gp.H;
+    asm volatile("" : "+v"(g.p), "+v"(g.lane));
+    generate_episode<GG>(rng, g, gp, out);
     MG_STAMP(4);
     out.retries += retries_before;
     if (!rng.dead()) break;
@@ -182,7 +190,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
     const int e = A.queue ? (int)uni32(A.queue[i]) : i;
     if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
-    generate_one<RNG>(A, rng, e, lane, lds);
+    generate_one<GG_ALL, RNG>(A, rng, e, lane, lds);
   }
 }
 
@@ -192,6 +200,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
 // MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3.
 // WPG = wavefronts per group of 64 envs (1, 2 or 4).  VT = 7 (default view, unrolled) or 15 (run-time V <= 15).
+// GG = generator group compiled into the generator role (mg_gen.h; GG_NONE for levels whose reset draws nothing).
 //
 // One workgroup = 64 consecutive envs; lane l of EVERY wave is env l.  The kernel is VALU-issue bound (profiles/),
 // so the split is chosen to minimise instructions while keeping the chip full: the per-env scalar dynamics (~150
@@ -202,8 +211,8 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // need no address clamp, per-env opacity rows, the visibility mask, the observation as final output bytes (copied
 // out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
 // ======================================================================================================
-template <int MODE, int WPG, class RNG, int VT>
-__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(64)))   // <= 64 VGPRs and (800 SGPRs per SIMD) <= 64+16 SGPRs: 8 waves/SIMD
+template <int MODE, int WPG, class RNG, int VT, int GG>
+__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs: no scratch in any 7x7 variant; measured best
 k_step(const StepParams P, const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = 64 * WPG;
@@ -215,7 +224,7 @@ k_step(const StepParams P, const GenArgs A) {
   //      groups.  Disjointness: an env consumed its spare in launch L-1 without stepping, so it cannot be due for
   //      a reset in launch L; the step groups of launch L therefore never read the spares written here, and launch
   //      L+1 starts after this one has completed. ----
-  if ((int)blockIdx.x < P.gen_blocks) {
+  if (GG != GG_NONE && (int)blockIdx.x < P.gen_blocks) {
     MG_STAMP(0);
     __builtin_amdgcn_s_setprio(3);      // few, latency-critical scalar waves: issue ahead of the step waves
     if (blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
@@ -231,7 +240,7 @@ k_step(const StepParams P, const GenArgs A) {
     uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
     for (int i = first; i < total; i += P.gen_blocks * WPG) {
       if (i != first) e = (int)A.queue[i];
-      generate_one<RNG>(A, rng, (int)uni32((uint32_t)e), (uint32_t)lane, lds);
+      generate_one<GG, RNG>(A, rng, (int)uni32((uint32_t)e), (uint32_t)lane, lds);
     }
     return;
   }
