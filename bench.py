@@ -97,8 +97,9 @@ def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
             list(ex.map(lambda v: v.rollout(T, 7), vecs))
             return time.perf_counter() - t0
 
-    cal = timed(20)                               # all threads together: includes any cgroup CPU quota
-    T = int(min(max(20, budget_s / max(cal / 20, 1e-7)), 200000))
+    timed(50)                                     # warm the thread pool / page in the library
+    cal = timed(400)                              # all threads together: includes any cgroup CPU quota
+    T = int(min(max(400, budget_s / max(cal / 400, 1e-7)), 2_000_000))
     dt = timed(T)
     return {"value": cores * n_per * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} obs), oracle C port "
