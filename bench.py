@@ -98,9 +98,10 @@ def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
             return time.perf_counter() - t0
 
     timed(50)                                     # warm the thread pool / page in the library
-    cal = timed(400)                              # all threads together: includes any cgroup CPU quota
-    T = int(min(max(400, budget_s / max(cal / 400, 1e-7)), 2_000_000))
-    dt = timed(T)
+    T, dt, chunk = 0, 0.0, 1000                   # fixed-size chunks until the sample is ~budget_s long (bounded)
+    while dt < budget_s and T < 5_000_000:
+        dt += timed(chunk)
+        T += chunk
     return {"value": cores * n_per * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} obs), oracle C port "
                       f"(oracle/minigrid_oracle.c), xorshift random actions, NEXT_STEP autoreset, {dt:.1f}s"}
