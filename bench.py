@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic")
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets the multi-process path be exercised "
+                         "on a box with fewer GPUs than ranks: ranks then share devices round-robin)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,9 +132,14 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import minigrid_amd as mg
 
@@ -182,7 +190,7 @@ def main():
     ev_ms = env.timer_stop()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     counters = env.counters()
