@@ -52,6 +52,7 @@ MISSIONS = {
     "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
                        for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
     "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-Dynamic-Obstacles": ["get to the green goal square"],
     "MiniGrid-KeyCorridor": [f"pick up the {c} ball" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-RedBlueDoors": ["open the red door then the blue door"],
     "MiniGrid-Memory": ["go to the matching object at the end of the hallway"],
@@ -402,7 +403,9 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-MemoryS17Random-v0",
             "MiniGrid-MemoryS13Random-v0", "MiniGrid-MemoryS13-v0", "MiniGrid-MemoryS11-v0", "MiniGrid-MemoryS9-v0",
             "MiniGrid-MemoryS7-v0", "MiniGrid-KeyCorridorS3R1-v0", "MiniGrid-KeyCorridorS3R2-v0", "MiniGrid-KeyCorridorS3R3-v0",
-            "MiniGrid-KeyCorridorS4R3-v0", "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-KeyCorridorS6R3-v0"]
+            "MiniGrid-KeyCorridorS4R3-v0", "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-KeyCorridorS6R3-v0",
+            "MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
+            "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0"]
 
 
 def main_wide():

@@ -17,6 +17,7 @@ _LIB = None
 # env kinds / object codes (mirror of the enums in minigrid_oracle.c)
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
+K_DYNOBS = 15
 T_WALL, T_LAVA = 2, 9
 
 
@@ -86,12 +87,22 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_MEMORY, width=size, height=size, max_steps=5 * size * size, see_through=0,
                     random_length=int(random_length), missions=["go to the matching object at the end of the hallway"])
 
+    def dynobs(size, n, random_start=False):
+        # dynamicobstacles.py:72-106: n_obstacles clamped (:84-88), see_through_walls=True, max_steps = 4*size**2
+        n = int(n) if n <= size / 2 + 1 else int(size / 2)
+        return dict(kind=K_DYNOBS, width=size, height=size, max_steps=4 * size * size, see_through=1, num_dists=n,
+                    start_x=-1 if random_start else 1, start_y=-1 if random_start else 1, start_dir=0,
+                    missions=["get to the green goal square"])
+
     def keycorridor(room_size, rows):
         # keycorridor.py:75-104: num_cols = 3 (RoomGrid default), max_steps = 30*room_size**2, obj_type "ball"
         return roomgrid(K_KEYCORRIDOR, room_size, rows, 3, 30 * room_size * room_size,
                         [f"pick up the {c} ball" for c in color_names])
 
     table = {
+        "MiniGrid-Dynamic-Obstacles-5x5-v0": dynobs(5, 2), "MiniGrid-Dynamic-Obstacles-Random-5x5-v0": dynobs(5, 2, True),
+        "MiniGrid-Dynamic-Obstacles-6x6-v0": dynobs(6, 3), "MiniGrid-Dynamic-Obstacles-Random-6x6-v0": dynobs(6, 3, True),
+        "MiniGrid-Dynamic-Obstacles-8x8-v0": dynobs(8, 4), "MiniGrid-Dynamic-Obstacles-16x16-v0": dynobs(16, 8),
         **{f"MiniGrid-KeyCorridorS{s_}R{r_}-v0": keycorridor(s_, r_) for s_, r_ in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))},
         "MiniGrid-RedBlueDoors-6x6-v0": redblue(6), "MiniGrid-RedBlueDoors-8x8-v0": redblue(8),
         "MiniGrid-MemoryS17Random-v0": memory(17, True), "MiniGrid-MemoryS13Random-v0": memory(13, True),
