@@ -62,7 +62,9 @@ typedef enum mg_env_kind {
   MG_ENV_BLOCKEDUNLOCKPICKUP = 11,  /* envs/blockedunlockpickup.py:90-119; mission id = colour index * 2 (box)     */
   MG_ENV_REDBLUEDOORS = 12, /* envs/redbluedoors.py:78-126 (width = 2 * height)                                    */
   MG_ENV_MEMORY = 13,       /* envs/memory.py:92-164 (odd size; random_length)                                     */
-  MG_ENV_KEYCORRIDOR = 14   /* envs/keycorridor.py:106-145 (3 x num_rows RoomGrid, connect_all); mission id = ball colour */
+  MG_ENV_KEYCORRIDOR = 14,  /* envs/keycorridor.py:106-145 (3 x num_rows RoomGrid, connect_all); mission id = ball colour */
+  MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
+                               the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;
 
 typedef enum mg_obs_mode {
@@ -100,10 +102,10 @@ typedef struct mg_config {
   int32_t autoreset_mode;     /* mg_autoreset_mode */
   int32_t rng_mode;           /* mg_rng_mode */
   int32_t num_envs;           /* N lockstep envs on this device */
-  int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty / DistShift: fixed start (empty.py:71-72); x < 0 => place_agent() */
+  int32_t agent_start_x, agent_start_y, agent_start_dir; /* Empty / DistShift / DynamicObstacles: fixed start (empty.py:71-72); x < 0 => place_agent() */
   int32_t num_crossings;      /* Crossing (crossing.py:92) */
   int32_t obstacle_type;      /* Crossing / LavaGap: 9 = lava, 2 = wall (crossing.py:93, lavagap.py:69) */
-  int32_t num_dists;          /* GoToRedBall num_dists (goto.py:129); Fetch numObjs (fetch.py:67) */
+  int32_t num_dists;          /* GoToRedBall num_dists (goto.py:129); Fetch numObjs (fetch.py:67); DynamicObstacles n_obstacles */
   int32_t null_stream_sync;   /* library-created stream only: 1 = blocking stream (hipStreamDefault), i.e. ordered
                                  with the legacy NULL stream a framework such as PyTorch launches on; 0 = non-blocking */
   int32_t strip2_row;         /* DistShift (distshift.py:72) */

@@ -31,11 +31,13 @@ struct mg_env {
   int off_grid = 0, off_trow = 0, off_vis = 0, off_T = 0, off_lut = 0, off_act = 0, lds_bytes = 0;
   int wpg = 4;                // wavefronts per group of 64 envs in k_step
   bool static_gen = false;
+  bool live_gen = false;      // DynamicObstacles: step() consumes the stream => resets are drawn right before the step launch
   int rule = RULE_NONE, rule_cell = 0, rule_div = 1;
   // device buffers
   uint8_t *grid = nullptr, *spare_grid = nullptr;
   uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *seeds = nullptr;
   uint8_t *mask = nullptr, *actions = nullptr;
+  uint64_t* obst = nullptr;   // DynamicObstacles: obstacle list per env
   uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
   double *reward = nullptr, *reward_lut = nullptr;
   uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
@@ -98,6 +100,7 @@ static GenArgs gen_args(mg_env* e, bool to_spare) {
   A.queue = nullptr; A.count = nullptr; A.zero_count = nullptr; A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + (e->N + 63) / 64;
+  A.dst_obst = (e->live_gen && !to_spare) ? e->obst : nullptr; A.live = e->live_gen ? 1 : 0;
   return A;
 }
 
@@ -122,7 +125,7 @@ static int launch_generate(mg_env* e, bool to_spare, int queue_slot, const uint8
 // The spares consumed by the most recent k_step launch are refilled by the generator role of the NEXT k_step
 // launch.  Entry points that read or overwrite spares / stream positions first bring them up to date.
 static int flush_refills(mg_env* e) {
-  if (e->static_gen || e->launches == 0) return MG_OK;
+  if (e->static_gen || e->live_gen || e->launches == 0) return MG_OK;
   const int slot = (int)((e->launches - 1) % 3);
   int rc = launch_generate(e, /*to_spare=*/true, slot, nullptr);
   if (rc) return rc;
@@ -140,7 +143,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks;
+  P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks; P.live_gen = e->live_gen ? 1 : 0;
   P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
   P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->obs_bytes;
   P.view = e->cfg.agent_view_size; P.no_death_mask = e->cfg.no_death_mask; P.death_cost = e->cfg.death_cost;
@@ -153,6 +156,26 @@ static int launch_step(mg_env* e, const StepParams& P) {
   // grid = [gen_blocks generator workgroups | one workgroup of wpg wavefronts per 64 consecutive envs].
   // Launch L appends the envs whose spare it consumed to refill queue L%3; its generator role drains queue (L-1)%3
   // and clears the counter of queue (L+1)%3, which nobody touches during launch L.
+  if (e->live_gen) {
+    // (1) draw, in place, the episodes of the envs the previous launch left RESET_PENDING (they come out FRESH and
+    //     are only observed by this launch); (2) before a real step, move the obstacles of everyone else
+    if (e->launches > 0) {
+      const int slot = (int)((e->launches - 1) % 3);
+      int rc = launch_generate(e, /*to_spare=*/false, slot, nullptr);
+      if (rc) return rc;
+      HIP_TRY(e, hipMemsetAsync(e->qcount + QC_STRIDE * slot, 0, sizeof(uint32_t), e->stream));
+    }
+    if (P.phase == PHASE_STEP) {
+      const int tb = 256, nb = (e->N + tb - 1) / tb;
+      if (e->cfg.rng_mode == MG_RNG_PHILOX)
+        hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->obst,
+                           e->N, e->W, e->H, e->CS, e->cfg.num_dists);
+      else
+        hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->obst,
+                           e->N, e->W, e->H, e->CS, e->cfg.num_dists);
+      HIP_TRY(e, hipGetLastError());
+    }
+  }
   const int blocks = (e->N + 63) / 64 + e->gen_blocks;
   dim3 grid(blocks), block(64 * e->wpg);
   const size_t lds = (size_t)e->lds_bytes;
@@ -229,7 +252,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_KEYCORRIDOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_DYNOBS) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_DYNOBS && (cfg->num_dists < 0 || cfg->num_dists > 8 || cfg->width > 16 || cfg->height > 16))
+    return fail(nullptr, MG_ERR_INVALID, "DynamicObstacles supports up to 8 obstacles on grids up to 16 x 16");
   if (cfg->env_kind == MG_ENV_KEYCORRIDOR && (cfg->room_size < 3 || cfg->width != 3 * (cfg->room_size - 1) + 1 ||
       (cfg->height - 1) % (cfg->room_size - 1) != 0 || (cfg->height - 1) / (cfg->room_size - 1) < 1 || (cfg->height - 1) / (cfg->room_size - 1) > 3 || cfg->width > 16 || cfg->height > 16))
     return fail(nullptr, MG_ERR_INVALID, "KeyCorridor is a 3 x (1..3) RoomGrid with room_size >= 3 and a grid of at most 16 x 16");
@@ -254,7 +279,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "GoToRedBall is a single 8x8 room (goto.py:129-131)");
   if (cfg->env_kind == MG_ENV_CROSSING && ((cfg->width & 1) == 0 || (cfg->height & 1) == 0 || cfg->width > 11 || cfg->height > 11))
     return fail(nullptr, MG_ERR_INVALID, "Crossing needs an odd size <= 11 (crossing.py:132 assert)");
-  if ((cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0 &&
+  if ((cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT || cfg->env_kind == MG_ENV_DYNOBS) && cfg->agent_start_x >= 0 &&
       (cfg->agent_start_x >= cfg->width || cfg->agent_start_y < 0 || cfg->agent_start_y >= cfg->height || (unsigned)cfg->agent_start_dir > 3u))
     return fail(nullptr, MG_ERR_INVALID, "agent start outside the grid");
   int ndev = mg_device_count();
@@ -294,7 +319,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
-  if (!e->static_gen) {
+  e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
+  if (!e->static_gen && !e->live_gen) {
     // generator role of k_step: every wave of a generator workgroup draws episodes, each with 1/wpg of the launch's
     // LDS allocation (>= 512 draws: one whole-map attempt of GoToRedBall needs ~60, and an attempt that runs out
     // restarts from its checkpoint, so the buffer size is not a correctness limit)
@@ -309,6 +335,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
+  if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;
   if (cfg->env_kind == MG_ENV_REDBLUEDOORS) e->rule = RULE_REDBLUE;
   if (cfg->env_kind == MG_ENV_MEMORY) e->rule = RULE_MEMORY;
   if (cfg->env_kind == MG_ENV_UNLOCK) { e->rule = RULE_UNLOCK; e->rule_cell = cfg->room_size - 1; }
@@ -336,6 +363,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(dalloc(&e->seeds, N));
   TRY_OR_FREE(dalloc(&e->mask, N));
   TRY_OR_FREE(dalloc(&e->actions, 8 * N));
+  TRY_OR_FREE(dalloc(&e->obst, N));
+  TRY_OR_FREE(hipMemsetAsync(e->obst, 0, N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(dalloc(&e->obs, N * e->obs_bytes + 16));
   TRY_OR_FREE(dalloc(&e->reward, N));
   TRY_OR_FREE(dalloc(&e->term, N));
@@ -387,7 +416,7 @@ int mg_destroy(mg_env* e) {
   if (!e) return MG_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions,
+  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions, e->obst,
                    e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -418,7 +447,11 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     HIP_TRY(e, hipGetLastError());
     int rc = launch_generate(e, /*to_spare=*/false, -1, d_mask);
     if (rc) return rc;
-    rc = launch_generate(e, /*to_spare=*/true, -1, d_mask);
+    if (!e->live_gen) rc = launch_generate(e, /*to_spare=*/true, -1, d_mask);
+    if (rc) return rc;
+  } else if (e->live_gen) {
+    // reset(): continue each env's stream from where its last step left it
+    int rc = launch_generate(e, /*to_spare=*/false, -1, d_mask);
     if (rc) return rc;
   } else {
     // reset(): continue each env's own stream == consume the pre-drawn spare
@@ -532,6 +565,17 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
     ag.step = (uint32_t)o[5]; ag.flags = o[6] ? FLAG_RESET_PENDING : 0u; ag.mission = (uint32_t)o[7];
     a[n] = agent_pack(ag);
   }
+  std::vector<uint64_t> ob;
+  if (e->live_gen) {
+    // the obstacle list order is not part of the exchanged state: rebuilt in cell-index order
+    ob.assign(N, 0);
+    for (size_t n = 0; n < N; n++) {
+      int k = 0;
+      for (int c = 0; c < e->cells && k < 8; c++)
+        if (cell_type(g[n * e->CS + c]) == T_BALL) ob[n] |= (uint64_t)c << (8 * k++);
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->obst, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  }
   HIP_TRY(e, hipMemcpyAsync(e->grid, g.data(), g.size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->agent, a.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -544,7 +588,7 @@ int mg_get_rng(mg_env* e, uint64_t* out) {
   const size_t N = (size_t)e->N;
   { int rc = flush_refills(e); if (rc) return rc; }
   // the reference env's stream position "now" is the state BEFORE the spare episode was drawn
-  const uint64_t* src = e->static_gen ? e->rng : e->rng_snap;
+  const uint64_t* src = (e->static_gen || e->live_gen) ? e->rng : e->rng_snap;
   std::vector<uint64_t> soa(5 * N);
   HIP_TRY(e, hipMemcpyAsync(soa.data(), src, soa.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -562,6 +606,7 @@ int mg_set_rng(mg_env* e, const uint64_t* in) {
   HIP_TRY(e, hipMemcpyAsync(e->rng, soa.data(), soa.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   // re-draw every spare from the injected position
+  if (e->live_gen) return MG_OK;
   return launch_generate(e, /*to_spare=*/true, -1, nullptr);
 }
 

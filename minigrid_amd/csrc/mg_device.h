@@ -39,6 +39,7 @@ constexpr uint32_t CELL_WALL_GREY = make_cell(T_WALL, C_GREY);
 constexpr uint32_t CELL_GOAL = make_cell(T_GOAL, C_GREEN);
 constexpr uint32_t CELL_LAVA = make_cell(T_LAVA, C_RED);
 constexpr uint32_t CELL_BALL_RED = make_cell(T_BALL, C_RED);
+constexpr uint32_t CELL_BALL_BLUE = make_cell(T_BALL, C_BLUE);
 
 // (type, colour, state) of the reference encoding -> cell code.  Mirrors WorldObj.decode (core/world_object.py:69-102):
 // empty/unseen/agent -> None; Goal()/Lava() take their default colours; non-door state is ignored.
@@ -132,6 +133,10 @@ MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; ret
 // agent record: one u64 per env
 //   byte 0 x, 1 y, 2 dir, 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16), 6 flags, 7 mission id
 constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode; NEXT_STEP autoreset is due
+// levels whose env stream is also consumed by step() (DynamicObstacles) cannot pre-draw a spare episode: their resets
+// are drawn by a generator launch right before the step launch, which then only observes the fresh episode
+constexpr uint32_t FLAG_FRESH = 2u;           // regenerated just before this launch: observe, do not step
+constexpr uint32_t FLAG_NOT_CLEAR = 4u;       // DynamicObstacles: the front cell was occupied before the obstacles moved
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };

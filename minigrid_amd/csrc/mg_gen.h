@@ -21,6 +21,7 @@ struct GenParams {
 
 struct GenResult {
   uint32_t ax, ay, dir, mission;
+  uint64_t obst;      // DynamicObstacles: byte i = cell index (y*W+x) of obstacle i, in list order
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
 };
@@ -487,6 +488,24 @@ MG_D void gen_keycorridor(R& rng, GridRef& g, const GenParams& P, GenResult& out
   out.mission = ball_ci;
 }
 
+// envs/dynamicobstacles.py:110-134 (P.num_dists = n_obstacles after the constructor's clamp; grids up to 16x16)
+template <class R>
+MG_D void gen_dynobs(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  g.set(g.W - 2, g.H - 2, CELL_GOAL);
+  if (P.start_x >= 0) { out.ax = P.start_x; out.ay = P.start_y; out.dir = P.start_dir; }
+  else if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  uint64_t obst = 0;
+  const int n = min(P.num_dists, 8);
+  for (int i = 0; i < n; i++) {
+    int x = 0, y = 0;
+    if (!place_obj(rng, g, CELL_BALL_BLUE, 0, 0, g.W, g.H, (int)out.ax, (int)out.ay, false, 100, x, y)) out.failed = true;
+    obst |= (uint64_t)(y * g.W + x) << (8 * i);
+  }
+  out.obst = obst;
+  out.mission = 0;
+}
+
 // envs/redbluedoors.py:78-102 (size = H, width = 2 * size)
 template <class R>
 MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -537,7 +556,7 @@ MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind 
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
-  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false;
+  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.obst = 0;
   if constexpr (GG == GG_LIGHT || GG == GG_ALL) {
     switch (P.kind) {
       case 0: gen_empty(rng, g, P, out); return;
@@ -550,6 +569,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 8: gen_gotodoor(rng, g, P, out); return;
       case 12: gen_redbluedoors(rng, g, P, out); return;
       case 13: gen_memory(rng, g, P, out); return;
+      case 15: if constexpr (GG == GG_ALL) { gen_dynobs(rng, g, P, out); return; } break;   // only ever drawn by k_generate
       default: break;
     }
   }

@@ -28,7 +28,7 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
-              RULE_REDBLUE = 6, RULE_MEMORY = 7 };
+              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8 };
 
 struct StepParams {
   // state
@@ -42,6 +42,7 @@ struct StepParams {
   unsigned long long* counters;
   // config
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen, gen_blocks;
+  int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
   int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
@@ -93,6 +94,9 @@ struct GenArgs {
   int N, CS;
   int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
   int stat_gen_off;                                  // first generator statistics slot in `counters`
+  uint64_t* dst_obst;                                // DynamicObstacles: obstacle list of the generated episode (or null)
+  int live;                                          // 1: queue entries are regenerated IN PLACE (dst = live state): only
+                                                     //    envs still flagged RESET_PENDING are drawn, and come out FRESH
 };
 
 // `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env group |
@@ -162,8 +166,10 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
   uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
   for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
   if (lane == 0) {
-    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.flags = 0; ag.mission = out.mission;
+    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
+    ag.flags = (A.live && A.queue) ? FLAG_FRESH : 0u;
     A.dst_agent[e] = agent_pack(ag);
+    if (A.dst_obst) A.dst_obst[e] = out.obst;
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
@@ -290,6 +296,7 @@ k_step(const StepParams P, const GenArgs A) {
   const uint8_t* mygrid = sgrid + lane * GS;
   uint32_t act = sact[lane];
   if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;     // MemoryEnv.step (memory.py:151-153)
+  if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
   double reward = 0.0;
   uint32_t term = 0, trunc = 0, errbits = 0;
   bool rec_dirty = false;
@@ -309,6 +316,9 @@ k_step(const StepParams P, const GenArgs A) {
         const uint32_t slot = atomicAdd(P.refill_count, 1u);
         P.refill_queue[slot] = (uint32_t)e;
       }
+    } else if (a.flags & FLAG_FRESH) {
+      a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
+      rec_dirty = true;
     } else if (P.phase == PHASE_STEP) {
       // ---- MiniGridEnv.step ----
       rec_dirty = true;
@@ -420,6 +430,12 @@ k_step(const StepParams P, const GenArgs A) {
         }
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
+      if (P.rule == RULE_DYNOBS) {
+        // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
+        // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
+        if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
+        a.flags &= ~FLAG_NOT_CLEAR;
+      }
       if (P.no_death_mask && term) {
         // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
         // cell does not terminate; death_cost is added to the reward instead
@@ -428,7 +444,13 @@ k_step(const StepParams P, const GenArgs A) {
         const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
         if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
       }
-      if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
+      if ((term | trunc) && P.autoreset_next_step) {
+        a.flags |= FLAG_RESET_PENDING;
+        if (P.live_gen && wave == 0) {                 // drawn in place by the generator launch before the next step
+          const uint32_t slot = atomicAdd(P.refill_count, 1u);
+          P.refill_queue[slot] = (uint32_t)e;
+        }
+      }
     }
   }
   if (wave == 0 && P.phase == PHASE_STEP) {
@@ -590,6 +612,49 @@ k_step(const StepParams P, const GenArgs A) {
     for (int c = tid; c < nvec; c += NT) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
     for (int b = (nvec << 4) + tid; b < nbytes; b += NT) obase[b] = sT[b];   // ragged last group only
   }
+}
+
+// DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
+// front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood
+// (place_obj with max_tries=100 on the ENV's stream; an obstacle that finds no place stays).  One lane per env,
+// straight on the HBM state: this level's step consumes the stream, so it is kept out of k_step's register budget.
+template <class RNG>
+__global__ void k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
+                                 int n_obst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  Agent a = agent_unpack(agent[e]);
+  if (a.flags & (FLAG_RESET_PENDING | FLAG_FRESH)) return;          // no step for this env in the coming launch
+  uint8_t* g = grid + (size_t)e * CS;
+  const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+  const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)g[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
+  const bool not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
+  RNG r;
+  r.load(rng, (size_t)N, (size_t)e);
+  uint64_t o = obst[e];
+  for (int i = 0; i < n_obst; i++) {
+    const int idx = (int)((o >> (8 * i)) & 0xFF), ox = idx % W, oy = idx / W;
+    const int topx = max(ox - 1, 0), topy = max(oy - 1, 0), hx = min(topx + 3, W), hy = min(topy + 3, H);
+    int tries = 0, nx = -1, ny = -1;
+    for (;;) {
+      if (tries > 100) break;                                       // RecursionError, swallowed by `except Exception`
+      tries++;
+      const int x = rand_int(r, topx, hx), y = rand_int(r, topy, hy);
+      if (g[y * W + x] != CELL_EMPTY) continue;
+      if (x == (int)a.x && y == (int)a.y) continue;
+      nx = x; ny = y;
+      break;
+    }
+    if (nx >= 0) {
+      g[ny * W + nx] = (uint8_t)CELL_BALL_BLUE;
+      g[idx] = (uint8_t)CELL_EMPTY;
+      o = (o & ~(0xFFull << (8 * i))) | ((uint64_t)(ny * W + nx) << (8 * i));
+    }
+  }
+  r.store(rng, (size_t)N, (size_t)e);
+  obst[e] = o;
+  a.flags = (a.flags & ~FLAG_NOT_CLEAR) | (not_clear ? FLAG_NOT_CLEAR : 0u);
+  agent[e] = agent_pack(a);
 }
 
 // gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)

@@ -14,6 +14,7 @@ from typing import Dict, Tuple
 # mirror of include/minigrid_hip.h enums
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY, ENV_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
+ENV_DYNOBS = 15
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -106,6 +107,16 @@ def _roomgrid_1x2(id_, kind, room_size, max_steps, missions, entry_point):
                    entry_point=entry_point)
 
 
+def _dynobs(id_, size, n_obstacles, random_start=False):
+    # envs/dynamicobstacles.py:72-106: n_obstacles clamped (:84-88), see_through_walls=True, max_steps = 4*size**2;
+    # rows minigrid/__init__.py:120-153.  Actions >= 3 count as 0 ("Invalid action", :137-139): no ValueError here.
+    n = int(n_obstacles) if n_obstacles <= size / 2 + 1 else int(size / 2)
+    return EnvSpec(id_, ENV_DYNOBS, size, size, 4 * size * size, True, ("get to the green goal square",),
+                   agent_start=(-1, -1, 0) if random_start else (1, 1, 0), num_dists=n,
+                   entry_point="minigrid.envs:DynamicObstaclesEnv",
+                   kwargs={"size": size, "n_obstacles": n_obstacles, **({"agent_start_pos": None} if random_start else {})})
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -141,6 +152,9 @@ _ROWS = [
               tuple(f"pick up the {c} ball" for c in _COLOR_NAMES), room_size=rs, entry_point="minigrid.envs:KeyCorridorEnv",
               kwargs={"room_size": rs, "num_rows": rows})
       for rs, rows in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))],
+    _dynobs("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 2), _dynobs("MiniGrid-Dynamic-Obstacles-Random-5x5-v0", 5, 2, True),
+    _dynobs("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3), _dynobs("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 6, 3, True),
+    _dynobs("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4), _dynobs("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8),
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),
