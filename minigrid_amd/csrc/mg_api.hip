@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -397,7 +398,15 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
 #undef MG_K
 #undef MG_KG
     };
-    for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
+    // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
+    static std::mutex lds_mu;
+    static int lds_max[64] = { 0 };
+    std::lock_guard<std::mutex> lk(lds_mu);
+    if (e->lds_bytes > lds_max[device & 63]) {
+      for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+      lds_max[device & 63] = e->lds_bytes;
+    }
   }
 #undef TRY_OR_FREE
   (void)env;

@@ -424,3 +424,15 @@ def test_dict_observation_space_wrapper():
     assert obs["mission"].shape == (4, 50) and list(obs["mission"][0, :10]) == [19, 31, 17, 36, 20, 38, 31, 2, 15, 35]
     assert env.single_observation_space["mission"].shape == (50,)
     env.close()
+
+
+def test_two_handles_with_different_lds_sizes_coexist():
+    """The dynamic-LDS limit is a per-kernel attribute: creating a small-LDS env after a large-LDS one must not break
+    the large one's launches."""
+    big = _mk("MiniGrid-FourRooms-v0", 128, obs_mode="full")        # > 64 KB of LDS per workgroup
+    small = _mk("MiniGrid-DoorKey-8x8-v0", 128, obs_mode="onehot")  # also > 64 KB, but less
+    big.reset(seed=0); small.reset(seed=0)
+    a = np.zeros(128, np.uint8)
+    for _ in range(3):
+        big.step(a); small.step(a)
+    big.close(); small.close()
