@@ -44,7 +44,12 @@ MISSIONS = {
     "MiniGrid-DoorKey": ["use the key to open the door and then get to the goal"],
     "MiniGrid-LavaCrossing": ["avoid the lava and get to the green goal square"],
     "MiniGrid-SimpleCrossing": ["find the opening and get to the green goal square"],
+    "BabyAI-GoToRedBlueBall": ["go to the red ball", "go to the blue ball"],
     "BabyAI-GoToRedBall": ["go to the red ball", "go to a red ball"],
+    "BabyAI-GoToObj": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                       for t in ("key", "ball", "box")],
+    "BabyAI-GoToLocal": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                         for t in ("key", "ball", "box")],
     "MiniGrid-LavaGap": ["avoid the lava and get to the green goal square"],
     "MiniGrid-DistShift": ["get to the green goal square"],
     "MiniGrid-FourRooms": ["reach the goal"],
@@ -137,8 +142,16 @@ def solver_action(env_id, u):
         if not d.is_open:
             p = plan_to_face(u, door)
             return 5 if p == [] else (p[0] if p else None)
-    if env_id.startswith("BabyAI-GoToRedBall"):
-        p = plan_to_face(u, find(u, "ball", "red"))
+    if env_id.startswith("BabyAI-GoTo"):
+        d = u.instrs.desc
+        tgt = find(u, d.type, d.color)
+        if tgt is None:                        # the target is being carried (only when stepping past termination)
+            return 4 if u.grid.get(*u.front_pos) is None else 0
+        p = plan_to_face(u, tgt)
+        if p is None and u.step_count % 3 == 0:
+            return 3                           # blocked: sometimes pick things up / drop them (exercises the drop refresh)
+        if p is None and u.carrying is not None:
+            return 4
         return p[0] if p else None
     if env_id.startswith(("MiniGrid-Unlock", "MiniGrid-BlockedUnlockPickup")):
         door = find(u, "door")
@@ -386,7 +399,37 @@ def make_nodeath_goldens(env_id, seeds, T, death_cost=-1.0):
                 seeds=np.array(seeds, np.uint64), death_cost=np.float64(death_cost))
 
 
+# ---- stepping PAST termination (what DISABLED autoreset exposes): BabyAI's GoToInstr tracks object POSITIONS that go
+#      stale while a tracked object is carried (verifier.py:105-171, roomgrid_level.py:87-104) ----
+NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0"]
+
+
+def make_noreset_goldens(env_id, seeds, T):
+    recs = dict(actions=[], obs=[], reward=[], term=[], trunc=[])
+    for seed in seeds:
+        env = gym.make(env_id)
+        arng = np.random.default_rng(40_000 + seed)
+        obs, _ = env.reset(seed=seed)
+        rec = dict(actions=[], obs=[obs["image"]], reward=[], term=[], trunc=[])
+        for t in range(T):
+            a = int(arng.choice(7, p=[0.12, 0.12, 0.3, 0.2, 0.2, 0.03, 0.03]))
+            if arng.random() < 0.5:
+                sa = solver_action(env_id, env.unwrapped)
+                a = sa if sa is not None else a
+            obs, r, term, trunc, _ = env.step(a)            # never reset: keep stepping the finished episode
+            rec["actions"].append(a); rec["obs"].append(obs["image"]); rec["reward"].append(float(r))
+            rec["term"].append(term); rec["trunc"].append(trunc)
+        for k in recs:
+            recs[k].append(rec[k])
+    return dict(actions=np.array(recs["actions"], np.uint8), obs=np.array(recs["obs"], np.uint8),
+                reward=np.array(recs["reward"], np.float64), term=np.array(recs["term"], bool),
+                trunc=np.array(recs["trunc"], bool), seeds=np.array(seeds, np.uint64))
+
+
 def main_wrappers():
+    for env_id in NORESET_IDS:
+        np.savez_compressed(os.path.join(OUT, f"noreset_{env_id}.npz"), **make_noreset_goldens(env_id, list(range(8)), 150))
+        print("done noreset", env_id, flush=True)
     for env_id in WRAPPER_IDS:
         np.savez_compressed(os.path.join(OUT, f"wrappers_{env_id}.npz"), **make_wrapper_goldens(env_id, [0, 1, 2, 1337], 120))
         print("done wrappers", env_id, flush=True)
@@ -405,7 +448,12 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-MemoryS7-v0", "MiniGrid-KeyCorridorS3R1-v0", "MiniGrid-KeyCorridorS3R2-v0", "MiniGrid-KeyCorridorS3R3-v0",
             "MiniGrid-KeyCorridorS4R3-v0", "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-KeyCorridorS6R3-v0",
             "MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
-            "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0"]
+            "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0",
+            "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
+            "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
+            "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",
+            "BabyAI-GoToLocalS8N2-v0", "BabyAI-GoToLocalS8N3-v0", "BabyAI-GoToLocalS8N4-v0", "BabyAI-GoToLocalS8N5-v0",
+            "BabyAI-GoToLocalS8N6-v0", "BabyAI-GoToLocalS8N7-v0"]
 
 
 def main_wide():

@@ -18,6 +18,7 @@ _LIB = None
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 K_DYNOBS = 15
+K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL = 16, 17, 18, 19
 T_WALL, T_LAVA = 2, 9
 
 
@@ -94,12 +95,29 @@ def spec(env_id: str) -> dict:
                     start_x=-1 if random_start else 1, start_y=-1 if random_start else 1, start_dir=0,
                     missions=["get to the green goal square"])
 
+    def babyai_goto(kind, room_size, num_dists, missions):
+        # RoomGridLevel (roomgrid_level.py:60-85): 1x1 rooms, max_steps = num_navs(1) * room_size**2 per episode
+        return dict(kind=kind, width=room_size, height=room_size, max_steps=room_size * room_size, see_through=0,
+                    num_dists=num_dists, missions=missions)
+
+    goto_obj_missions = [f"go to {art} {c} {t}" for art in ("the", "a") for c in color_names for t in ("key", "ball", "box")]
+
     def keycorridor(room_size, rows):
         # keycorridor.py:75-104: num_cols = 3 (RoomGrid default), max_steps = 30*room_size**2, obj_type "ball"
         return roomgrid(K_KEYCORRIDOR, room_size, rows, 3, 30 * room_size * room_size,
                         [f"pick up the {c} ball" for c in color_names])
 
     table = {
+        # envs/babyai/goto.py: GoToRedBallGrey :63-78, GoToRedBlueBall :657-677, GoToObj :253-260, GoToLocal :329-338;
+        # registry rows minigrid/__init__.py:572-679, 750-753
+        "BabyAI-GoToRedBallGrey-v0": babyai_goto(K_GOTO_REDBALLGREY, 8, 7, ["go to the red ball", "go to a red ball"]),
+        "BabyAI-GoToRedBlueBall-v0": babyai_goto(K_GOTO_REDBLUEBALL, 8, 7, ["go to the red ball", "go to the blue ball"]),
+        "BabyAI-GoToObj-v0": babyai_goto(K_GOTO_OBJ, 8, 1, goto_obj_missions),
+        "BabyAI-GoToObjS4-v0": babyai_goto(K_GOTO_OBJ, 4, 1, goto_obj_missions),
+        "BabyAI-GoToObjS6-v1": babyai_goto(K_GOTO_OBJ, 6, 1, goto_obj_missions),
+        "BabyAI-GoToLocal-v0": babyai_goto(K_GOTO_LOCAL, 8, 8, goto_obj_missions),
+        **{f"BabyAI-GoToLocalS{s_}N{n_}-v0": babyai_goto(K_GOTO_LOCAL, s_, n_, goto_obj_missions)
+           for s_, n_ in ((5, 2), (6, 2), (6, 3), (6, 4), (7, 4), (7, 5), (8, 2), (8, 3), (8, 4), (8, 5), (8, 6), (8, 7))},
         "MiniGrid-Dynamic-Obstacles-5x5-v0": dynobs(5, 2), "MiniGrid-Dynamic-Obstacles-Random-5x5-v0": dynobs(5, 2, True),
         "MiniGrid-Dynamic-Obstacles-6x6-v0": dynobs(6, 3), "MiniGrid-Dynamic-Obstacles-Random-6x6-v0": dynobs(6, 3, True),
         "MiniGrid-Dynamic-Obstacles-8x8-v0": dynobs(8, 4), "MiniGrid-Dynamic-Obstacles-16x16-v0": dynobs(16, 8),

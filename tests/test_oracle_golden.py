@@ -170,3 +170,25 @@ def test_oracle_nodeath_matches_reference(env_id):
     assert cancelled > 10          # the wrapper's branch was actually taken
     _, agent = v.get_state()
     assert (agent[:, :7] == g["agent"][:, -1, :7]).all()
+
+
+NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0"]
+
+
+@pytest.mark.parametrize("env_id", NORESET_IDS)
+def test_oracle_stepping_past_termination_matches_reference(env_id):
+    """DISABLED autoreset: the finished episode keeps being stepped; BabyAI's tracked positions go stale while a
+    target object is carried, and the reward formula runs past max_steps."""
+    g = golden(f"noreset_{env_id}.npz")
+    acts = g["actions"]
+    S, T = acts.shape
+    v = O.OracleVec(env_id, S)
+    obs, _, _ = v.reset(seeds=g["seeds"])
+    assert (obs == g["obs"][:, 0]).all()
+    repeats = 0
+    for t in range(T):
+        obs, rew, term, trunc, _, _ = v.step(acts[:, t], autoreset=0)
+        assert (obs == g["obs"][:, t + 1]).all(), (env_id, t)
+        assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all(), (env_id, t)
+        repeats += int(term.sum())
+    assert repeats > 8              # successes re-fire after the first one
