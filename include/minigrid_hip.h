@@ -63,6 +63,10 @@ typedef enum mg_env_kind {
   MG_ENV_REDBLUEDOORS = 12, /* envs/redbluedoors.py:78-126 (width = 2 * height)                                    */
   MG_ENV_MEMORY = 13,       /* envs/memory.py:92-164 (odd size; random_length)                                     */
   MG_ENV_KEYCORRIDOR = 14,  /* envs/keycorridor.py:106-145 (3 x num_rows RoomGrid, connect_all); mission id = ball colour */
+  MG_ENV_GOTO_REDBALLGREY = 16, MG_ENV_GOTO_REDBLUEBALL = 17, MG_ENV_GOTO_OBJ = 18, MG_ENV_GOTO_LOCAL = 19,
+                            /* envs/babyai/goto.py:67-78, 661-677, 256-260, 333-338: single-room GoToInstr levels
+                               (room_size = width = height in 4..8, num_dists <= 8); GoToObj / GoToLocal mission id =
+                               ("a" ? 18 : 0) + COLOR_NAMES index * 3 + (key 0, ball 1, box 2)                     */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;

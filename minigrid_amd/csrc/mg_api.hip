@@ -38,7 +38,8 @@ struct mg_env {
   uint8_t *grid = nullptr, *spare_grid = nullptr;
   uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *seeds = nullptr;
   uint8_t *mask = nullptr, *actions = nullptr;
-  uint64_t* obst = nullptr;   // DynamicObstacles: obstacle list per env
+  uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
+  bool goto_kind = false;
   uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
   double *reward = nullptr, *reward_lut = nullptr;
   uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
@@ -101,7 +102,8 @@ static GenArgs gen_args(mg_env* e, bool to_spare) {
   A.queue = nullptr; A.count = nullptr; A.zero_count = nullptr; A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + (e->N + 63) / 64;
-  A.dst_obst = (e->live_gen && !to_spare) ? e->obst : nullptr; A.live = e->live_gen ? 1 : 0;
+  A.dst_aux = (e->live_gen && !to_spare) ? e->aux : (e->goto_kind ? (to_spare ? e->spare_aux : e->aux) : nullptr);
+  A.live = e->live_gen ? 1 : 0;
   return A;
 }
 
@@ -136,6 +138,7 @@ static int flush_refills(mg_env* e) {
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.grid = e->grid; P.spare_grid = e->spare_grid; P.agent = e->agent; P.spare_agent = e->spare_agent;
+  P.aux = e->aux; P.spare_aux = e->spare_aux;
   P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
   P.obs = e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
   P.reward_lut = e->reward_lut;
@@ -169,10 +172,10 @@ static int launch_step(mg_env* e, const StepParams& P) {
     if (P.phase == PHASE_STEP) {
       const int tb = 256, nb = (e->N + tb - 1) / tb;
       if (e->cfg.rng_mode == MG_RNG_PHILOX)
-        hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->obst,
+        hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->aux,
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists);
       else
-        hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->obst,
+        hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->aux,
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists);
       HIP_TRY(e, hipGetLastError());
     }
@@ -253,7 +256,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_DYNOBS) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTO_LOCAL) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_GOTO_REDBALLGREY && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 0 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "BabyAI single-room GoTo levels: room_size 4..8, at most 8 distractors");
   if (cfg->env_kind == MG_ENV_DYNOBS && (cfg->num_dists < 0 || cfg->num_dists > 8 || cfg->width > 16 || cfg->height > 16))
     return fail(nullptr, MG_ERR_INVALID, "DynamicObstacles supports up to 8 obstacles on grids up to 16 x 16");
   if (cfg->env_kind == MG_ENV_KEYCORRIDOR && (cfg->room_size < 3 || cfg->width != 3 * (cfg->room_size - 1) + 1 ||
@@ -276,8 +281,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "DistShift needs width >= 7 and the second lava strip inside the grid");
   if (cfg->env_kind == MG_ENV_FOURROOMS && (cfg->width < 7 || cfg->height < 7))
     return fail(nullptr, MG_ERR_INVALID, "FourRooms needs width, height >= 7");
-  if (cfg->env_kind == MG_ENV_GOTO_REDBALL && (cfg->width != 8 || cfg->height != 8))
-    return fail(nullptr, MG_ERR_INVALID, "GoToRedBall is a single 8x8 room (goto.py:129-131)");
+  if (cfg->env_kind == MG_ENV_GOTO_REDBALL && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "GoToRedBall is a single room of size 4..8 with at most 8 distractors (goto.py:129-131)");
   if (cfg->env_kind == MG_ENV_CROSSING && ((cfg->width & 1) == 0 || (cfg->height & 1) == 0 || cfg->width > 11 || cfg->height > 11))
     return fail(nullptr, MG_ERR_INVALID, "Crossing needs an odd size <= 11 (crossing.py:132 assert)");
   if ((cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT || cfg->env_kind == MG_ENV_DYNOBS) && cfg->agent_start_x >= 0 &&
@@ -333,7 +338,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (const char* s = getenv("MG_GEN_BLOCKS")) { int v = atoi(s); if (v >= 1 && v <= 65536) e->gen_blocks = std::min(v, e->N); }
   }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
-  if (cfg->env_kind == MG_ENV_GOTO_REDBALL) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; }
+  // GoToInstr levels: rule_div selects how the described object follows from the mission id (see k_step)
+  if (cfg->env_kind == MG_ENV_GOTO_REDBALL || cfg->env_kind == MG_ENV_GOTO_REDBALLGREY) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; e->rule_div = 0; }
+  if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
+  e->goto_kind = e->rule == RULE_GOTO;
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
   if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;
@@ -364,8 +373,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(dalloc(&e->seeds, N));
   TRY_OR_FREE(dalloc(&e->mask, N));
   TRY_OR_FREE(dalloc(&e->actions, 8 * N));
-  TRY_OR_FREE(dalloc(&e->obst, N));
-  TRY_OR_FREE(hipMemsetAsync(e->obst, 0, N * sizeof(uint64_t), e->stream));
+  TRY_OR_FREE(dalloc(&e->aux, N));
+  TRY_OR_FREE(dalloc(&e->spare_aux, N));
+  TRY_OR_FREE(hipMemsetAsync(e->aux, 0, N * sizeof(uint64_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->spare_aux, 0, N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(dalloc(&e->obs, N * e->obs_bytes + 16));
   TRY_OR_FREE(dalloc(&e->reward, N));
   TRY_OR_FREE(dalloc(&e->term, N));
@@ -425,7 +436,7 @@ int mg_destroy(mg_env* e) {
   if (!e) return MG_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions, e->obst,
+  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions, e->aux, e->spare_aux,
                    e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -575,6 +586,18 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
     a[n] = agent_pack(ag);
   }
   std::vector<uint64_t> ob;
+  if (e->goto_kind) {
+    // GoToInstr's tracked positions are re-found from the grid (their staleness is not part of the exchanged state)
+    ob.assign(N, 0);
+    for (size_t n = 0; n < N; n++) {
+      const uint32_t mis = (uint32_t)agent[n * 8 + 7], m18 = mis % 18u;
+      const uint32_t desc = e->rule_div == 0 ? (uint32_t)e->rule_cell
+                          : e->rule_div == 1 ? make_cell(T_BALL, mis ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+                                             : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+      for (int c = 0; c < e->cells; c++) if (g[n * e->CS + c] == desc) ob[n] |= 1ull << c;
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->aux, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  }
   if (e->live_gen) {
     // the obstacle list order is not part of the exchanged state: rebuilt in cell-index order
     ob.assign(N, 0);
@@ -583,7 +606,7 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
       for (int c = 0; c < e->cells && k < 8; c++)
         if (cell_type(g[n * e->CS + c]) == T_BALL) ob[n] |= (uint64_t)c << (8 * k++);
     }
-    HIP_TRY(e, hipMemcpyAsync(e->obst, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->aux, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   }
   HIP_TRY(e, hipMemcpyAsync(e->grid, g.data(), g.size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->agent, a.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));

@@ -21,7 +21,8 @@ struct GenParams {
 
 struct GenResult {
   uint32_t ax, ay, dir, mission;
-  uint64_t obst;      // DynamicObstacles: byte i = cell index (y*W+x) of obstacle i, in list order
+  uint64_t aux;       // per-env auxiliary word: DynamicObstacles: byte i = cell index (y*W+x) of obstacle i, in list
+                      // order; BabyAI GoTo levels: bitboard (bit y*W+x) of GoToInstr's tracked object positions
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
 };
@@ -42,13 +43,16 @@ struct GridRef {
   }
   // 8x8 grids only (bit index = y*8+x = lane): cells the reachability flood may pass (None or any door), cells
   // holding a non-wall object, and the number of red balls
-  MG_D void reach_masks_8x8(uint64_t& passable, uint64_t& objects, uint32_t& nred) const {
+  // grids of at most 64 cells (bit index = y*W+x = lane): cells the reachability flood may pass (None or any door),
+  // cells holding a non-wall object, and the cells holding exactly `desc`
+  MG_D void reach_masks(uint64_t& passable, uint64_t& objects, uint32_t desc, uint64_t& matches) const {
     MG_WAVE_LDS_SYNC();
-    const uint32_t c = p[lane], t = cell_type(c);
+    const bool in = lane < W * H;
+    const uint32_t c = in ? (uint32_t)p[lane] : (uint32_t)CELL_WALL_GREY, t = cell_type(c);
     const bool pass = c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED;
-    passable = __ballot(pass);
-    objects = __ballot(!pass && t != T_WALL);
-    nred = (uint32_t)__popcll(__ballot(c == CELL_BALL_RED));
+    passable = __ballot(in && pass);
+    objects = __ballot(in && !pass && t != T_WALL);
+    matches = __ballot(in && c == desc);
   }
 };
 
@@ -205,14 +209,22 @@ MG_D void gen_crossing(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = 0;
 }
 
-// BabyAI GoToRedBall: envs/babyai/goto.py:133-141 gen_mission over a 1x1 RoomGrid (core/roomgrid.py:123-179),
+// BabyAI single-room GoTo levels on a 1x1 RoomGrid (core/roomgrid.py:123-179): envs/babyai/goto.py GoToRedBall
+// 133-141 (+NoDists), GoToRedBallGrey 67-78, GoToRedBlueBall 661-677, GoToObj 256-260, GoToLocal 333-338;
 // RoomGrid.place_agent (313-334), add_object/place_in_room (198-228,181-196: reject_next_to, max_tries=1000),
-// add_distractors (396-438, all_unique=False), check_objs_reachable (roomgrid_level.py:250-302) and the
-// regenerate-on-reject loop (roomgrid_level.py:119-144).  Mission surface: verifier.py:73-103.
-// The 8x8 grid is one 64-bit bitboard for the reachability flood.
+// add_distractors (396-438), check_objs_reachable (roomgrid_level.py:250-302) and the regenerate-on-reject loop
+// (roomgrid_level.py:119-144).  Mission surface: verifier.py:73-103.  Grids of at most 64 cells: one 64-bit
+// bitboard for the reachability flood and for GoToInstr's tracked positions (out.aux).
+// Mission ids: red-ball levels 0 "go to the red ball" / 1 "go to a red ball"; GoToRedBlueBall 0 red / 1 blue;
+// GoToObj / GoToLocal (article "a" ? 18 : 0) + COLOR_NAMES index * 3 + (key 0, ball 1, box 2).
+enum : int { GOTO_REDBALL = 3, GOTO_REDBALLGREY = 16, GOTO_REDBLUEBALL = 17, GOTO_OBJ = 18, GOTO_LOCAL = 19 };
 template <class R>
-MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
-  const int W = g.W, H = g.H;
+MG_D void gen_goto(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H, kind = P.kind;
+  // column masks of the W x H bitboard (bit y*W+x)
+  uint64_t col0 = 0, colL = 0, all = 0;
+  for (int y = 0; y < H; y++) { col0 |= 1ull << (y * W); colL |= 1ull << (y * W + W - 1); }
+  all = (W * H >= 64) ? ~0ull : ((1ull << (W * H)) - 1ull);
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();           // a rejected map needs nothing but the stream position: restart point
@@ -226,28 +238,56 @@ MG_D void gen_goto_redball(R& rng, GridRef& g, const GenParams& P, GenResult& ou
     }
     if (!ok) continue;
     int x, y;
-    if (!place_obj(rng, g, CELL_BALL_RED, 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y)) continue;
-    for (int d = 0; d < P.num_dists && ok; d++) {
-      uint32_t color = color_from_sorted((uint32_t)rand_int(rng, 0, 6));
-      uint32_t type = T_KEY + (uint32_t)rand_int(rng, 0, 3);     // ["key", "ball", "box"] = 5, 6, 7
-      ok = place_obj(rng, g, make_cell(type, color), 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y);
+    if (kind == GOTO_REDBALL || kind == GOTO_REDBALLGREY)
+      if (!place_obj(rng, g, CELL_BALL_RED, 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y)) continue;
+    // add_distractors: colour, type, place; remembered in list order (cell index / colour index / type index)
+    uint64_t dpos = 0; uint32_t dcol = 0, dtyp = 0;
+    bool red_or_blue_ball = false;
+    const int ndist = kind == GOTO_OBJ ? 1 : min(P.num_dists, 8);
+    for (int d = 0; d < ndist && ok; d++) {
+      const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);
+      const uint32_t ti = (uint32_t)rand_int(rng, 0, 3);         // ["key", "ball", "box"] = 5, 6, 7
+      const uint32_t color = color_from_sorted(ci);
+      ok = place_obj(rng, g, make_cell(T_KEY + ti, color), 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y);
+      dpos |= (uint64_t)(y * W + x) << (8 * d); dcol |= ci << (4 * d); dtyp |= ti << (4 * d);
+      red_or_blue_ball |= ti == 1u && (color == C_RED || color == C_BLUE);
     }
     if (!ok) continue;
-    // check_objs_reachable: flood from the agent through None/door cells; every non-wall object must be in the
-    // visited set (= passable flood plus its 4-neighbourhood).  Bit index = y*8+x (W == H == 8).
-    uint64_t passable, objects; uint32_t nred;
-    g.reach_masks_8x8(passable, objects, nred);
-    const uint64_t notA = 0xFEFEFEFEFEFEFEFEull, notH = 0x7F7F7F7F7F7F7F7Full;
-    uint64_t reach = 1ull << (out.ay * 8 + out.ax);
-    for (;;) {
-      uint64_t grow = ((reach << 1) & notA) | ((reach >> 1) & notH) | (reach << 8) | (reach >> 8);
-      uint64_t next = reach | (grow & passable);
-      if (next == reach) break;
-      reach = next;
+    uint32_t desc = CELL_BALL_RED;
+    if (kind == GOTO_REDBALLGREY)                                // dist.color = "grey"
+      for (int d = 0; d < ndist; d++) {
+        const int idx = (int)((dpos >> (8 * d)) & 0xFF);
+        g.set(idx % W, idx / W, make_cell(T_KEY + ((dtyp >> (4 * d)) & 15u), C_GREY));
+      }
+    if (kind == GOTO_REDBLUEBALL) {
+      if (red_or_blue_ball) continue;                            // RejectSampling("can only have one blue or red ball")
+      desc = make_cell(T_BALL, rand_int(rng, 0, 2) == 0 ? (uint32_t)C_RED : (uint32_t)C_BLUE);
+      if (!place_obj(rng, g, desc, 0, 0, W, H, (int)out.ax, (int)out.ay, true, 1000, x, y)) continue;
     }
-    uint64_t visited = reach | ((reach << 1) & notA) | ((reach >> 1) & notH) | (reach << 8) | (reach >> 8);
-    if (objects & ~visited) continue;             // RejectSampling("unreachable object")
-    out.mission = nred > 1 ? 1u : 0u;             // "go to the red ball" / "go to a red ball"
+    uint64_t passable, objects, matches;
+    if (kind != GOTO_OBJ) {
+      // check_objs_reachable: flood from the agent through None/door cells; every non-wall object must be in the
+      // visited set (= passable flood plus its 4-neighbourhood)
+      g.reach_masks(passable, objects, desc, matches);
+      uint64_t reach = 1ull << (out.ay * W + out.ax);
+      for (;;) {
+        const uint64_t grow = (((reach & ~colL) << 1) | ((reach & ~col0) >> 1) | (reach << W) | (reach >> W)) & all;
+        const uint64_t next = reach | (grow & passable);
+        if (next == reach) break;
+        reach = next;
+      }
+      const uint64_t visited = (reach | ((reach & ~colL) << 1) | ((reach & ~col0) >> 1) | (reach << W) | (reach >> W)) & all;
+      if (objects & ~visited) continue;           // RejectSampling("unreachable object")
+    }
+    uint32_t k = 0;
+    if (kind == GOTO_LOCAL) k = (uint32_t)rand_int(rng, 0, ndist);                // _rand_elem(objs)
+    if (kind == GOTO_OBJ || kind == GOTO_LOCAL) desc = make_cell(T_KEY + ((dtyp >> (4 * k)) & 15u), color_from_sorted((dcol >> (4 * k)) & 15u));
+    g.reach_masks(passable, objects, desc, matches);
+    out.aux = matches;                            // GoToInstr.reset_verifier -> desc.find_matching_objs: tracked positions
+    const uint32_t many = __popcll(matches) > 1 ? 1u : 0u;
+    if (kind == GOTO_OBJ || kind == GOTO_LOCAL) out.mission = many * 18u + ((dcol >> (4 * k)) & 15u) * 3u + ((dtyp >> (4 * k)) & 15u);
+    else if (kind == GOTO_REDBLUEBALL) out.mission = cell_color(desc) == C_BLUE ? 1u : 0u;
+    else out.mission = many;                      // "go to the red ball" / "go to a red ball"
     return;
   }
   out.failed = true;
@@ -502,7 +542,7 @@ MG_D void gen_dynobs(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
     if (!place_obj(rng, g, CELL_BALL_BLUE, 0, 0, g.W, g.H, (int)out.ax, (int)out.ay, false, 100, x, y)) out.failed = true;
     obst |= (uint64_t)(y * g.W + x) << (8 * i);
   }
-  out.obst = obst;
+  out.aux = obst;
   out.mission = 0;
 }
 
@@ -552,11 +592,11 @@ MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 //   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
 //   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall)
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ALL = 3 };
-MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 19)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
-  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.obst = 0;
+  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
   if constexpr (GG == GG_LIGHT || GG == GG_ALL) {
     switch (P.kind) {
       case 0: gen_empty(rng, g, P, out); return;
@@ -575,7 +615,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
   }
   if constexpr (GG == GG_ROOMGRID || GG == GG_ALL) {
     switch (P.kind) {
-      case 3: gen_goto_redball(rng, g, P, out); return;
+      case 3: case 16: case 17: case 18: case 19: gen_goto(rng, g, P, out); return;
       case 9: gen_unlock_family(rng, g, P, out, 0); return;
       case 10: gen_unlock_family(rng, g, P, out, 1); return;
       case 11: gen_unlock_family(rng, g, P, out, 2); return;

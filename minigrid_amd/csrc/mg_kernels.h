@@ -33,6 +33,7 @@ enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RU
 struct StepParams {
   // state
   uint8_t* grid; const uint8_t* spare_grid; uint64_t* agent; const uint64_t* spare_agent;
+  uint64_t* aux; const uint64_t* spare_aux;      // BabyAI GoTo levels: bitboard of the tracked target positions
   // inputs
   const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t;
   // outputs
@@ -94,7 +95,7 @@ struct GenArgs {
   int N, CS;
   int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
   int stat_gen_off;                                  // first generator statistics slot in `counters`
-  uint64_t* dst_obst;                                // DynamicObstacles: obstacle list of the generated episode (or null)
+  uint64_t* dst_aux;                                 // auxiliary word of the generated episode (GenResult.aux) or null
   int live;                                          // 1: queue entries are regenerated IN PLACE (dst = live state): only
                                                      //    envs still flagged RESET_PENDING are drawn, and come out FRESH
 };
@@ -169,7 +170,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
     ag.flags = (A.live && A.queue) ? FLAG_FRESH : 0u;
     A.dst_agent[e] = agent_pack(ag);
-    if (A.dst_obst) A.dst_obst[e] = out.obst;
+    if (A.dst_aux) A.dst_aux[e] = out.aux;
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
@@ -312,6 +313,7 @@ k_step(const StepParams P, const GenArgs A) {
       a = agent_unpack(P.spare_agent[e]);
       a.carry = 0; a.step = 0; a.flags = 0;
       rec_dirty = true;
+      if (P.rule == RULE_GOTO && wave == 0) P.aux[e] = P.spare_aux[e];
       if (wave == 0 && !P.static_gen) {
         const uint32_t slot = atomicAdd(P.refill_count, 1u);
         P.refill_queue[slot] = (uint32_t)e;
@@ -352,13 +354,26 @@ k_step(const StepParams P, const GenArgs A) {
       }
       trunc = a.step >= (uint32_t)P.max_steps;
       if (P.rule == RULE_GOTO) {
-        // GoToInstr.verify_action on the post-action state: front cell holds a target object
-        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
-          const int gidx = gy * W + gx;
-          const uint32_t G = gidx == dirty_idx ? dirty_code : (uint32_t)mygrid[gidx];
-          if ((int)G == P.rule_cell) { term = 1; success = true; }
+        // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
+        // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
+        // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
+        // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
+        uint64_t targets = P.aux[e];             // loaded here, not up front: keeps it out of everyone's live ranges
+        if (act == A_DROP) {
+          // desc: rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
+          const uint32_t m18 = a.mission % 18u;
+          const uint32_t desc = P.rule_div == 0 ? (uint32_t)P.rule_cell
+                              : P.rule_div == 1 ? make_cell(T_BALL, a.mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+                                                : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+          targets = 0;
+          for (int k = 0; k < P.cells; k++) {
+            const uint32_t c = k == dirty_idx ? dirty_code : (uint32_t)mygrid[k];
+            targets |= (uint64_t)(c == desc) << k;
+          }
+          if (wave == 0) P.aux[e] = targets;
         }
+        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
       }
       if (P.rule == RULE_FETCH && a.carry != 0) {
         // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded

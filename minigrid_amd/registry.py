@@ -15,6 +15,7 @@ from typing import Dict, Tuple
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY, ENV_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 ENV_DYNOBS = 15
+ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL = 16, 17, 18, 19
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -117,6 +118,16 @@ def _dynobs(id_, size, n_obstacles, random_start=False):
                    kwargs={"size": size, "n_obstacles": n_obstacles, **({"agent_start_pos": None} if random_start else {})})
 
 
+_GOTO_OBJ_MISSIONS = tuple(f"go to {a} {c} {t}" for a in ("the", "a") for c in _COLOR_NAMES for t in ("key", "ball", "box"))
+
+
+def _babyai_goto(id_, kind, room_size, num_dists, missions, cls, kwargs=None):
+    # RoomGridLevel (envs/babyai/core/roomgrid_level.py:60-85) on a 1x1 RoomGrid: per-episode max_steps =
+    # num_navs(1) * room_size**2; rows minigrid/__init__.py:572-679, 750-753
+    return EnvSpec(id_, kind, room_size, room_size, room_size * room_size, False, missions, num_dists=num_dists,
+                   entry_point=f"minigrid.envs.babyai:{cls}", kwargs=kwargs or {})
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -152,6 +163,15 @@ _ROWS = [
               tuple(f"pick up the {c} ball" for c in _COLOR_NAMES), room_size=rs, entry_point="minigrid.envs:KeyCorridorEnv",
               kwargs={"room_size": rs, "num_rows": rows})
       for rs, rows in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))],
+    _babyai_goto("BabyAI-GoToRedBallGrey-v0", ENV_GOTO_REDBALLGREY, 8, 7, ("go to the red ball", "go to a red ball"), "GoToRedBallGrey"),
+    _babyai_goto("BabyAI-GoToRedBlueBall-v0", ENV_GOTO_REDBLUEBALL, 8, 7, ("go to the red ball", "go to the blue ball"), "GoToRedBlueBall"),
+    _babyai_goto("BabyAI-GoToObj-v0", ENV_GOTO_OBJ, 8, 1, _GOTO_OBJ_MISSIONS, "GoToObj"),
+    _babyai_goto("BabyAI-GoToObjS4-v0", ENV_GOTO_OBJ, 4, 1, _GOTO_OBJ_MISSIONS, "GoToObj", {"room_size": 4}),
+    _babyai_goto("BabyAI-GoToObjS6-v1", ENV_GOTO_OBJ, 6, 1, _GOTO_OBJ_MISSIONS, "GoToObj", {"room_size": 6}),
+    _babyai_goto("BabyAI-GoToLocal-v0", ENV_GOTO_LOCAL, 8, 8, _GOTO_OBJ_MISSIONS, "GoToLocal"),
+    *[_babyai_goto(f"BabyAI-GoToLocalS{s_}N{n_}-v0", ENV_GOTO_LOCAL, s_, n_, _GOTO_OBJ_MISSIONS, "GoToLocal",
+                   {"room_size": s_, "num_dists": n_})
+      for s_, n_ in ((5, 2), (6, 2), (6, 3), (6, 4), (7, 4), (7, 5), (8, 2), (8, 3), (8, 4), (8, 5), (8, 6), (8, 7))],
     _dynobs("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 2), _dynobs("MiniGrid-Dynamic-Obstacles-Random-5x5-v0", 5, 2, True),
     _dynobs("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3), _dynobs("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 6, 3, True),
     _dynobs("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4), _dynobs("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8),

@@ -436,3 +436,20 @@ def test_two_handles_with_different_lds_sizes_coexist():
     for _ in range(3):
         big.step(a); small.step(a)
     big.close(); small.close()
+
+
+@pytest.mark.parametrize("env_id", ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0"])
+def test_stepping_past_termination_matches_reference_goldens(env_id):
+    """autoreset disabled: the finished episode keeps being stepped (tests/golden/noreset_*.npz from the reference):
+    GoToInstr's tracked positions go stale while a target is carried; rewards are computed past max_steps."""
+    g = golden(f"noreset_{env_id}.npz")
+    acts = g["actions"]
+    S, T = acts.shape
+    env = _mk(env_id, S, autoreset_mode="disabled")
+    obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
+    assert (obs["image"] == g["obs"][:, 0]).all()
+    for t in range(T):
+        obs, rew, term, trunc, _ = env.step(acts[:, t])
+        assert (obs["image"] == g["obs"][:, t + 1]).all(), (env_id, t)
+        assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all(), (env_id, t)
+    env.close()
