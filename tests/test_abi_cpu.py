@@ -156,3 +156,50 @@ def test_dict_observation_space_vocabulary_doctest():
     assert len(minigrid_words()) == 51
     with pytest.raises(ValueError):
         string_to_indices("avoid the dragon")
+
+
+def _cfg(**kw):
+    base = dict(abi_version=B.MG_ABI_VERSION, env_kind=0, width=8, height=8, max_steps=256, see_through_walls=1,
+                agent_view_size=7, obs_mode=0, autoreset_mode=0, rng_mode=0, num_envs=64, agent_start_x=1,
+                agent_start_y=1, agent_start_dir=0)
+    base.update(kw)
+    return B.MgConfig(**base)
+
+
+@pytest.mark.parametrize("bad", [dict(num_envs=0), dict(width=2), dict(width=26), dict(agent_view_size=4),
+                                 dict(agent_view_size=17), dict(max_steps=0), dict(env_kind=99), dict(obs_mode=7),
+                                 dict(abi_version=0), dict(no_death_mask=1 << 8),
+                                 dict(env_kind=2, width=8, height=8),                    # Crossing needs an odd size
+                                 dict(env_kind=13, width=8, height=8),                   # Memory needs an odd size
+                                 dict(env_kind=12, width=8, height=8),                   # RedBlueDoors: width = 2 * height
+                                 dict(env_kind=9, width=11, height=6, room_size=5),      # Unlock: inconsistent room size
+                                 dict(env_kind=19, width=9, height=9, num_dists=3)])     # GoToLocal: room_size <= 8
+def test_mg_create_rejects_bad_configs_before_touching_a_device(bad):
+    """Validation comes first (MG_ERR_INVALID with a message); only a valid config gets as far as the device check,
+    which on this GPU-less box answers MG_ERR_NO_DEVICE -- there is no CPU fallback to fall into."""
+    L = B.load()
+    h = C.c_void_p()
+    cfg = _cfg(**bad)
+    assert L.mg_create(C.byref(cfg), -1, None, C.byref(h)) == B.MG_ERR_INVALID
+    assert not h.value and len(L.mg_last_error(None)) > 10
+
+
+def test_mg_create_valid_config_needs_a_device():
+    L = B.load()
+    if L.mg_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    h = C.c_void_p()
+    cfg = _cfg()
+    assert L.mg_create(C.byref(cfg), -1, None, C.byref(h)) == B.MG_ERR_NO_DEVICE
+    assert b"no CPU fallback" in L.mg_last_error(None)
+    import minigrid_amd as mg
+    with pytest.raises(B.MiniGridHipError):
+        mg.make_vec("MiniGrid-Empty-8x8-v0", 64)
+
+
+def test_registry_rows_are_consistent():
+    import minigrid_amd as mg
+    assert len(mg.registry) == 73
+    for env_id, s in mg.registry.items():
+        assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
+        assert s.entry_point.startswith("minigrid.envs")
