@@ -343,6 +343,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
   e->goto_kind = e->rule == RULE_GOTO;
+  {
+    // k_step compiles each rule only into the variant of its generator group: keep the two tables in step
+    const int rule_group = (e->rule == RULE_GOTO || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
+                         : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? -1 : GG_LIGHT;
+    if (rule_group >= 0 && rule_group != gen_group_of_kind(cfg->env_kind)) { delete e; return fail(nullptr, MG_ERR_INVALID, "internal: rule / generator group mismatch"); }
+  }
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
   if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;

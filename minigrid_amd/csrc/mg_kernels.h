@@ -170,7 +170,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
     ag.flags = (A.live && A.queue) ? FLAG_FRESH : 0u;
     A.dst_agent[e] = agent_pack(ag);
-    if (A.dst_aux) A.dst_aux[e] = out.aux;
+    if constexpr (GG != GG_LIGHT) { if (A.dst_aux) A.dst_aux[e] = out.aux; }     // no GG_LIGHT level has an auxiliary word
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
@@ -269,6 +269,11 @@ k_step(const StepParams P, const GenArgs A) {
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
+  // Every level-specific rule belongs to exactly one generator group (mg_create checks it), so a variant only carries
+  // the rules its levels can have: GG_ROOMGRID GoTo / Unlock / Pickup, GG_LIGHT Fetch / GoToDoor / RedBlueDoors /
+  // Memory, GG_NONE DynamicObstacles.
+  uint64_t targets = 0;                         // BabyAI GoTo levels: tracked positions, issued with the other loads
+  if constexpr (GG == GG_ROOMGRID) targets = (P.rule == RULE_GOTO && active) ? P.aux[e] : 0ull;
 #pragma unroll
   for (int k = tid; k < 256; k += NT) slut[k] = cell_triple((uint32_t)k);
   if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
@@ -296,8 +301,8 @@ k_step(const StepParams P, const GenArgs A) {
   Agent a = agent_unpack(rec);
   const uint8_t* mygrid = sgrid + lane * GS;
   uint32_t act = sact[lane];
-  if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;     // MemoryEnv.step (memory.py:151-153)
-  if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+  if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
+  if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
   double reward = 0.0;
   uint32_t term = 0, trunc = 0, errbits = 0;
   bool rec_dirty = false;
@@ -313,7 +318,7 @@ k_step(const StepParams P, const GenArgs A) {
       a = agent_unpack(P.spare_agent[e]);
       a.carry = 0; a.step = 0; a.flags = 0;
       rec_dirty = true;
-      if (P.rule == RULE_GOTO && wave == 0) P.aux[e] = P.spare_aux[e];
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && wave == 0) P.aux[e] = P.spare_aux[e];
       if (wave == 0 && !P.static_gen) {
         const uint32_t slot = atomicAdd(P.refill_count, 1u);
         P.refill_queue[slot] = (uint32_t)e;
@@ -353,12 +358,11 @@ k_step(const StepParams P, const GenArgs A) {
         if (wave == 0) P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
       }
       trunc = a.step >= (uint32_t)P.max_steps;
-      if (P.rule == RULE_GOTO) {
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
         // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
         // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
         // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
         // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
-        uint64_t targets = P.aux[e];             // loaded here, not up front: keeps it out of everyone's live ranges
         if (act == A_DROP) {
           // desc: rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
           const uint32_t m18 = a.mission % 18u;
@@ -375,14 +379,14 @@ k_step(const StepParams P, const GenArgs A) {
         const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
       }
-      if (P.rule == RULE_FETCH && a.carry != 0) {
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
         // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
         // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
         const uint32_t m12 = a.mission % 12u;
         const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
         term = 1; success = a.carry == target;
       }
-      if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
         // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
         // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
         bool open = false;
@@ -393,17 +397,18 @@ k_step(const StepParams P, const GenArgs A) {
         }
         if (open) { term = 1; success = true; }
       }
-      if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
         // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
         // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
         const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
         if (a.carry == target) { term = 1; success = true; }
       }
-      if (P.rule == RULE_REDBLUE) {
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
         // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
         // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
         bool red_before = false, red_after = false, blue_before = false, blue_after = false;
         const int xr = H / 2, xb = H / 2 + H - 1;
+#pragma unroll 1
         for (int y = 1; y < H - 1; y++) {
           const int ir = y * W + xr, ib = y * W + xb;
           const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
@@ -414,7 +419,7 @@ k_step(const StepParams P, const GenArgs A) {
         if (blue_after) { term = 1; success = red_before; }
         else if (red_after && blue_before) { term = 1; success = false; }
       }
-      if (P.rule == RULE_MEMORY) {
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
         // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
         // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
         // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
@@ -426,14 +431,14 @@ k_step(const StepParams P, const GenArgs A) {
           if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
         }
       }
-      if (P.rule == RULE_GOTODOOR) {
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
         // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
         // door = the door whose colour the mission names (door colours are distinct and doors never move)
         if (act == A_TOGGLE) term = 1;
         if (act == A_DONE) {
           const uint32_t tc = color_from_sorted(a.mission);
           bool next_to = false;
-#pragma unroll
+#pragma unroll 1
           for (int d = 0; d < 4; d++) {
             const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
             if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
@@ -445,7 +450,7 @@ k_step(const StepParams P, const GenArgs A) {
         }
       }
       if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
-      if (P.rule == RULE_DYNOBS) {
+      if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
         // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
         // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
         if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
