@@ -605,21 +605,26 @@ k_step(const StepParams P, const GenArgs A) {
     //      MODE 3: SymbolicObsWrapper.observation: (x, y, type or -1), agent cell type = 10 ----
     uint8_t* myT = sT + lane * obe;
     const int aidx = (int)a.y * W + (int)a.x;
-    for (int x = wave; x < W; x += WPG) {
-      for (int y = 0; y < H; y++) {
-        const int idx = y * W + x;
-        uint32_t c = mygrid[idx];
-        if (idx == dirty_idx) c = dirty_code;
-        uint8_t* o = myT + (x * H + y) * 3;
-        if (MODE == 1) {
-          if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
-          const uint32_t tri = slut[c];
-          o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
-        } else {
-          const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
-          o[0] = (uint8_t)x; o[1] = (uint8_t)y; o[2] = (uint8_t)t;
-        }
+    auto cell_tri = [&](int x, int y) -> uint32_t {
+      const int idx = y * W + x;
+      uint32_t c = mygrid[idx];
+      if (idx == dirty_idx) c = dirty_code;
+      if (MODE == 1) {
+        if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
+        return slut[c];
       }
+      const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
+      return (uint32_t)x | ((uint32_t)y << 8) | (t << 16);
+    };
+    auto put = [&](uint8_t* o, uint32_t tri) { o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16); };
+    for (int x = wave; x < W; x += WPG) {
+      uint8_t* col = myT + x * H * 3;                           // column x of image[x][y][3]
+      int y = 0;
+      for (; y + 4 <= H; y += 4) {                              // four independent grid -> table -> store chains in flight
+        const uint32_t t0 = cell_tri(x, y), t1 = cell_tri(x, y + 1), t2 = cell_tri(x, y + 2), t3 = cell_tri(x, y + 3);
+        put(col + 3 * y, t0); put(col + 3 * y + 3, t1); put(col + 3 * y + 6, t2); put(col + 3 * y + 9, t3);
+      }
+      for (; y < H; y++) put(col + 3 * y, cell_tri(x, y));
     }
   }
   block_sync();
