@@ -67,6 +67,7 @@ typedef enum mg_env_kind {
                             /* envs/babyai/goto.py:67-78, 661-677, 256-260, 333-338: single-room GoToInstr levels
                                (room_size = width = height in 4..8, num_dists <= 8); GoToObj / GoToLocal mission id =
                                ("a" ? 18 : 0) + COLOR_NAMES index * 3 + (key 0, ball 1, box 2)                     */
+  MG_ENV_GOTOOBJECT = 20,   /* envs/gotoobject.py:93-153 (size 4..8, num_dists = numObjs 1..8); mission id = COLOR_NAMES index * 3 + type */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;

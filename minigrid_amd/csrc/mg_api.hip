@@ -256,8 +256,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTO_LOCAL) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
-  if (cfg->env_kind >= MG_ENV_GOTO_REDBALLGREY && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 0 || cfg->num_dists > 8))
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTOOBJECT) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_GOTOOBJECT && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 1 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "GoToObject: size 4..8, numObjs 1..8");
+  if (cfg->env_kind >= MG_ENV_GOTO_REDBALLGREY && cfg->env_kind <= MG_ENV_GOTO_LOCAL && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 0 || cfg->num_dists > 8))
     return fail(nullptr, MG_ERR_INVALID, "BabyAI single-room GoTo levels: room_size 4..8, at most 8 distractors");
   if (cfg->env_kind == MG_ENV_DYNOBS && (cfg->num_dists < 0 || cfg->num_dists > 8 || cfg->width > 16 || cfg->height > 16))
     return fail(nullptr, MG_ERR_INVALID, "DynamicObstacles supports up to 8 obstacles on grids up to 16 x 16");
@@ -342,13 +344,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL || cfg->env_kind == MG_ENV_GOTO_REDBALLGREY) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; e->rule_div = 0; }
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
-  e->goto_kind = e->rule == RULE_GOTO;
-  {
-    // k_step compiles each rule only into the variant of its generator group: keep the two tables in step
-    const int rule_group = (e->rule == RULE_GOTO || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
-                         : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? -1 : GG_LIGHT;
-    if (rule_group >= 0 && rule_group != gen_group_of_kind(cfg->env_kind)) { delete e; return fail(nullptr, MG_ERR_INVALID, "internal: rule / generator group mismatch"); }
-  }
+  if (cfg->env_kind == MG_ENV_GOTOOBJECT) { e->rule = RULE_GOTOOBJ; e->rule_div = 2; }     // same mission id -> (colour, type) coding as GoToObj
+  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ;
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
   if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;
@@ -358,6 +355,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_UNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_KEYCORRIDOR) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BALL; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
+
+  {
+    // k_step compiles each rule only into the variant of its generator group: keep the two tables in step
+    const int rule_group = (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
+                         : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? -1 : GG_LIGHT;
+    if (rule_group >= 0 && rule_group != gen_group_of_kind(cfg->env_kind)) { delete e; return fail(nullptr, MG_ERR_INVALID, "internal: rule / generator group mismatch"); }
+  }
 
   mg_env* env = e;   // for HIP_TRY
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)

@@ -363,6 +363,33 @@ MG_D void gen_fetch(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = syntax * 12u + (uint32_t)((objs >> (8 * t)) & 0xFF);
 }
 
+// envs/gotoobject.py:93-135 (P.num_dists = numObjs <= 8).  Mission id = COLOR_NAMES index * 3 + (key 0 | ball 1 | box 2);
+// out.aux = one-bit board of target_pos, which is a POSITION fixed at reset (the object may be carried away later).
+template <class R>
+MG_D void gen_gotoobject(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  uint64_t objs = 0, poss = 0;                 // byte k = colour index * 3 + type index / cell index of object k
+  uint32_t used = 0;                           // bit (colour index * 3 + type index)
+  int x, y;
+  const int n = min(P.num_dists, 8);
+#pragma unroll 1
+  for (int k = 0; k < n && !rng.dead();) {
+    const uint32_t ty = (uint32_t)rand_int(rng, 0, 3);          // _rand_elem(["key", "ball", "box"])
+    const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);          // _rand_elem(COLOR_NAMES)
+    const uint32_t id = ci * 3u + ty;
+    if ((used >> id) & 1u) continue;                            // gotoobject.py:112-113
+    if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + ty, color_from_sorted(ci)), 0, 0, g.W, g.H, -1, -1, false, -1, x, y)) out.failed = true;
+    used |= 1u << id;
+    objs |= (uint64_t)id << (8 * k);
+    poss |= (uint64_t)(y * g.W + x) << (8 * k);
+    k++;
+  }
+  if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  const int t = rand_int(rng, 0, n);
+  out.mission = (uint32_t)((objs >> (8 * t)) & 0xFF);
+  out.aux = 1ull << ((poss >> (8 * t)) & 63u);
+}
+
 // envs/gotodoor.py:92-131.  The room is w x h <= W x H in the top-left corner; the rest of the grid stays None.
 // Mission id = COLOR_NAMES index of the target door (door colours are distinct, so it identifies the door).
 template <class R>
@@ -590,9 +617,9 @@ MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
 //   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
-//   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall)
+//   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject (needs the aux word)
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ALL = 3 };
-MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 19)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -620,6 +647,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 10: gen_unlock_family(rng, g, P, out, 1); return;
       case 11: gen_unlock_family(rng, g, P, out, 2); return;
       case 14: gen_keycorridor(rng, g, P, out); return;
+      case 20: gen_gotoobject(rng, g, P, out); return;
       default: break;
     }
   }

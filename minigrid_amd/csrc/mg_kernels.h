@@ -28,7 +28,7 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
-              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8 };
+              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9 };
 
 struct StepParams {
   // state
@@ -273,7 +273,7 @@ k_step(const StepParams P, const GenArgs A) {
   // the rules its levels can have: GG_ROOMGRID GoTo / Unlock / Pickup, GG_LIGHT Fetch / GoToDoor / RedBlueDoors /
   // Memory, GG_NONE DynamicObstacles.
   uint64_t targets = 0;                         // BabyAI GoTo levels: tracked positions, issued with the other loads
-  if constexpr (GG == GG_ROOMGRID) targets = (P.rule == RULE_GOTO && active) ? P.aux[e] : 0ull;
+  if constexpr (GG == GG_ROOMGRID) targets = ((P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ) && active) ? P.aux[e] : 0ull;
 #pragma unroll
   for (int k = tid; k < 256; k += NT) slut[k] = cell_triple((uint32_t)k);
   if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
@@ -318,7 +318,7 @@ k_step(const StepParams P, const GenArgs A) {
       a = agent_unpack(P.spare_agent[e]);
       a.carry = 0; a.step = 0; a.flags = 0;
       rec_dirty = true;
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && wave == 0) P.aux[e] = P.spare_aux[e];
+      if constexpr (GG == GG_ROOMGRID) if ((P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ) && wave == 0) P.aux[e] = P.spare_aux[e];
       if (wave == 0 && !P.static_gen) {
         const uint32_t slot = atomicAdd(P.refill_count, 1u);
         P.refill_queue[slot] = (uint32_t)e;
@@ -378,6 +378,16 @@ k_step(const StepParams P, const GenArgs A) {
         }
         const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
+        // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
+        // stands next to target_pos (the one-bit board drawn at reset)
+        if (act == A_TOGGLE) term = 1;
+        if (act == A_DONE) {
+          const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
+          const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
+          term = 1; success = (targets & ring) != 0;
+        }
       }
       if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
         // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded

@@ -15,7 +15,7 @@ from typing import Dict, Tuple
 ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHIFT, ENV_FOURROOMS, ENV_FETCH, ENV_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY, ENV_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 ENV_DYNOBS = 15
-ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL = 16, 17, 18, 19
+ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -118,6 +118,13 @@ def _dynobs(id_, size, n_obstacles, random_start=False):
                    kwargs={"size": size, "n_obstacles": n_obstacles, **({"agent_start_pos": None} if random_start else {})})
 
 
+def _gotoobject(id_, size, n):
+    # envs/gotoobject.py:66-91: see_through_walls=True, max_steps = 5*size**2; rows minigrid/__init__.py:238-251
+    return EnvSpec(id_, ENV_GOTOOBJECT, size, size, 5 * size * size, True,
+                   tuple(f"go to the {c} {t}" for c in _COLOR_NAMES for t in ("key", "ball", "box")), num_dists=n,
+                   entry_point="minigrid.envs:GoToObjectEnv", kwargs={"size": size, "numObjs": n})
+
+
 _GOTO_OBJ_MISSIONS = tuple(f"go to {a} {c} {t}" for a in ("the", "a") for c in _COLOR_NAMES for t in ("key", "ball", "box"))
 
 
@@ -145,6 +152,7 @@ _ROWS = [
     EnvSpec("MiniGrid-FourRooms-v0", ENV_FOURROOMS, 19, 19, 100, False, ("reach the goal",),
             entry_point="minigrid.envs:FourRoomsEnv"),
     _fetch("MiniGrid-Fetch-5x5-N2-v0", 5, 2), _fetch("MiniGrid-Fetch-6x6-N2-v0", 6, 2), _fetch("MiniGrid-Fetch-8x8-N3-v0", 8, 3),
+    _gotoobject("MiniGrid-GoToObject-6x6-N2-v0", 6, 2), _gotoobject("MiniGrid-GoToObject-8x8-N2-v0", 8, 2),
     _gotodoor("MiniGrid-GoToDoor-5x5-v0", 5), _gotodoor("MiniGrid-GoToDoor-6x6-v0", 6), _gotodoor("MiniGrid-GoToDoor-8x8-v0", 8),
     # unlock.py:52-70 (room_size 6, max_steps 8*36), unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (16*36);
     # rows minigrid/__init__.py:17-21,555,560-563

@@ -56,6 +56,7 @@ MISSIONS = {
     # ordered placeholders of the MissionSpace (fetch.py:77-89, gotodoor.py:66-70) with COLOR_NAMES sorted
     "MiniGrid-Fetch": [f"{s} {c} {t}" for s in ("get a", "go get a", "fetch a", "go fetch a", "you must fetch a")
                        for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball")],
+    "MiniGrid-GoToObject": [f"go to the {c} {t}" for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball", "box")],
     "MiniGrid-GoToDoor": [f"go to the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Dynamic-Obstacles": ["get to the green goal square"],
     "MiniGrid-KeyCorridor": [f"pick up the {c} ball" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
@@ -212,6 +213,14 @@ def solver_action(env_id, u):
     if env_id.startswith("MiniGrid-Fetch"):
         p = plan_to_face(u, find(u, u.targetType, u.targetColor))
         return 3 if p == [] else (p[0] if p else None)
+    if env_id.startswith("MiniGrid-GoToObject"):
+        # sometimes move objects around first: target_pos is a position, not the object (gotoobject.py:128)
+        if u.carrying is not None:
+            return 4 if u.grid.get(*u.front_pos) is None else 1
+        if u.step_count % 11 == 5:
+            return 3
+        p = plan_to_face(u, u.target_pos) if u.grid.get(*u.target_pos) is not None else plan_to_face(u, u.target_pos, stand_on=False)
+        return 6 if p == [] else (p[0] if p else 1)
     if env_id.startswith("MiniGrid-GoToDoor"):
         p = plan_to_face(u, u.target_pos)
         return 6 if p == [] else (p[0] if p else None)
@@ -449,6 +458,7 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-KeyCorridorS4R3-v0", "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-KeyCorridorS6R3-v0",
             "MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
             "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0",
+            "MiniGrid-GoToObject-6x6-N2-v0", "MiniGrid-GoToObject-8x8-N2-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",

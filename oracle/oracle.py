@@ -18,7 +18,7 @@ _LIB = None
 K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURROOMS, K_FETCH, K_GOTODOOR = 0, 1, 2, 3, 4, 5, 6, 7, 8
 K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 K_DYNOBS = 15
-K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL = 16, 17, 18, 19
+K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 T_WALL, T_LAVA = 2, 9
 
 
@@ -107,7 +107,13 @@ def spec(env_id: str) -> dict:
         return roomgrid(K_KEYCORRIDOR, room_size, rows, 3, 30 * room_size * room_size,
                         [f"pick up the {c} ball" for c in color_names])
 
+    def gotoobject(size, n):
+        # gotoobject.py:66-91: see_through_walls=True, max_steps = 5*size**2
+        return dict(kind=K_GOTOOBJECT, width=size, height=size, max_steps=5 * size * size, see_through=1, num_dists=n,
+                    missions=[f"go to the {c} {t}" for c in color_names for t in ("key", "ball", "box")])
+
     table = {
+        "MiniGrid-GoToObject-6x6-N2-v0": gotoobject(6, 2), "MiniGrid-GoToObject-8x8-N2-v0": gotoobject(8, 2),
         # envs/babyai/goto.py: GoToRedBallGrey :63-78, GoToRedBlueBall :657-677, GoToObj :253-260, GoToLocal :329-338;
         # registry rows minigrid/__init__.py:572-679, 750-753
         "BabyAI-GoToRedBallGrey-v0": babyai_goto(K_GOTO_REDBALLGREY, 8, 7, ["go to the red ball", "go to a red ball"]),
