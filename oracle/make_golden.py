@@ -435,6 +435,89 @@ def make_noreset_goldens(env_id, seeds, T):
                 trunc=np.array(recs["trunc"], bool), seeds=np.array(seeds, np.uint64))
 
 
+# ---- RGB observation path: every tile Grid.render_tile can produce for the supported tile
+#      sizes, and RGBImgObsWrapper / RGBImgPartialObsWrapper frames along rollouts ----
+RGB_IDS = ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Empty-8x8-v0", "MiniGrid-KeyCorridorS3R3-v0",
+           "BabyAI-GoToLocalS8N7-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-FourRooms-v0", "MiniGrid-DistShift2-v0"]
+RGB_TILE_SIZES = [4, 8, 12, 16]
+
+
+def rgb_tile_keys():
+    """(type, colour, state) of every object MiniGrid can draw; (1, 0, 0) stands for an empty cell (None)."""
+    keys = [(1, 0, 0)]
+    for t in ("wall", "floor", "key", "ball", "box"):
+        keys += [(OBJECT_TO_IDX[t], c, 0) for c in range(6)]
+    keys += [(OBJECT_TO_IDX["door"], c, st) for c in range(6) for st in range(3)]
+    keys += [(OBJECT_TO_IDX["goal"], COLOR_TO_IDX["green"], 0), (OBJECT_TO_IDX["lava"], COLOR_TO_IDX["red"], 0)]
+    return keys
+
+
+def make_rgb_atlas():
+    from minigrid.core.grid import Grid
+    from minigrid.core.world_object import WorldObj
+    keys = rgb_tile_keys()
+    out = dict(keys=np.array(keys, np.uint8), tile_sizes=np.array(RGB_TILE_SIZES))
+    for ts in RGB_TILE_SIZES:
+        tiles = np.zeros((len(keys), 5, 2, ts, ts, 3), np.uint8)          # [key][agent: none, dir 0..3][highlight]
+        for k, (t, c, st) in enumerate(keys):
+            obj = None if t == 1 else WorldObj.decode(t, c, st)
+            for ad in range(5):
+                for hl in range(2):
+                    img = Grid.render_tile(obj, agent_dir=None if ad == 0 else ad - 1, highlight=bool(hl), tile_size=ts)
+                    frame = np.zeros((ts, ts, 3), np.uint8)
+                    frame[:, :, :] = img                                   # the float -> uint8 store of Grid.render (grid.py:236)
+                    tiles[k, ad, hl] = frame
+        out[f"tiles{ts}"] = tiles
+    return out
+
+
+def make_rgb_goldens(env_id, seeds, T, tile_size=8):
+    from minigrid.wrappers import RGBImgObsWrapper, RGBImgPartialObsWrapper
+    out = dict(full=[], partial=[], actions=[], obs=[])
+    for seed in seeds:
+        env = gym.make(env_id)
+        full, part = RGBImgObsWrapper(env, tile_size=tile_size), RGBImgPartialObsWrapper(env, tile_size=tile_size)
+        arng = np.random.default_rng(50_000 + seed)
+        obs, _ = env.reset(seed=seed)
+        rec = {k: [] for k in out}
+        pending = False
+
+        def snap(obs):
+            rec["full"].append(full.observation(dict(obs))["image"])
+            rec["partial"].append(part.observation(dict(obs))["image"])
+            rec["obs"].append(obs["image"])
+        snap(obs)
+        for _ in range(T):
+            a = int(arng.integers(0, 7))
+            if arng.random() < 0.6 and not pending:
+                sa = solver_action(env_id, env.unwrapped)
+                a = sa if sa is not None else a
+            if pending:
+                obs, _ = env.reset()
+                pending = False
+            else:
+                obs, r, term, trunc, _ = env.step(a)
+                pending = bool(term or trunc)
+            rec["actions"].append(a)
+            snap(obs)
+        for k in out:
+            out[k].append(rec[k])
+    res = {k: np.array(v, np.uint8) for k, v in out.items()}
+    res["seeds"] = np.array(seeds, np.uint64)
+    res["tile_size"] = np.int64(tile_size)
+    return res
+
+
+def main_rgb():
+    np.savez_compressed(os.path.join(OUT, "rgb_atlas.npz"), **make_rgb_atlas())
+    print("done rgb atlas", flush=True)
+    for env_id in RGB_IDS:
+        np.savez_compressed(os.path.join(OUT, f"rgb_{env_id}.npz"), **make_rgb_goldens(env_id, [0, 1, 1337], 60))
+        print("done rgb", env_id, flush=True)
+    np.savez_compressed(os.path.join(OUT, "rgb16_MiniGrid-DoorKey-8x8-v0.npz"), **make_rgb_goldens("MiniGrid-DoorKey-8x8-v0", [0, 1], 40, tile_size=16))
+    np.savez_compressed(os.path.join(OUT, "rgb4_MiniGrid-DoorKey-8x8-v0.npz"), **make_rgb_goldens("MiniGrid-DoorKey-8x8-v0", [0, 1], 40, tile_size=4))
+
+
 def main_wrappers():
     for env_id in NORESET_IDS:
         np.savez_compressed(os.path.join(OUT, f"noreset_{env_id}.npz"), **make_noreset_goldens(env_id, list(range(8)), 150))
@@ -479,6 +562,8 @@ def main():
         return main_wide()
     if len(sys.argv) > 1 and sys.argv[1] == "wrappers":
         return main_wrappers()
+    if len(sys.argv) > 1 and sys.argv[1] == "rgb":
+        return main_rgb()
     np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
     main_seeds = list(range(12)) + [100, 243, 500, 1337]
     for env_id in MAIN_IDS:
@@ -492,6 +577,7 @@ def main():
         print("done", env_id, flush=True)
     main_wide()
     main_wrappers()
+    main_rgb()
 
 
 if __name__ == "__main__":

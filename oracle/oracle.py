@@ -202,12 +202,18 @@ class OracleVec:
     """N independent reference-semantics envs stepped in lockstep on the CPU (scalar C)."""
 
     def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, obs: str | None = None, view_size: int = 7,
-                 no_death_types=(), death_cost: float = -1.0, **overrides):
+                 no_death_types=(), death_cost: float = -1.0, tile_size: int = 8, highlight: bool = True, **overrides):
         """obs: "partial" | "full" (FullyObsWrapper) | "onehot" (OneHotPartialObsWrapper) | "symbolic"
         (SymbolicObsWrapper, returned as int8); view_size: ViewSizeWrapper; no_death_types/death_cost: NoDeath."""
         s = dict(spec(env_id))
         s.update(overrides)
         self.missions = s.pop("missions")
+        # "rgb" (RGBImgObsWrapper) / "rgb_partial" (RGBImgPartialObsWrapper): the C core steps with its partial
+        # observation, oracle/render.py draws the frame from the state
+        self.rgb = obs if obs in ("rgb", "rgb_partial") else None
+        self.tile_size, self.highlight = int(tile_size), bool(highlight)
+        if self.rgb:
+            obs = "partial"
         kind = OBS_KINDS[obs] if obs is not None else int(bool(full_obs))
         mask = 0
         for t in no_death_types:
@@ -233,12 +239,21 @@ class OracleVec:
         n = self.n
         return (np.zeros((n,) + self.obs_shape, self.obs_dtype), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
 
+    def _frame(self, obs):
+        if not self.rgb:
+            return obs
+        from . import render
+        if self.rgb == "rgb":
+            grid, agent = self.get_state()
+            return render.render_full(grid, agent, obs, self.tile_size, self.highlight)
+        return render.render_pov(obs, self.tile_size)
+
     def reset(self, seeds=None, mask=None):
         obs, d, m = self._outs()
         sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
         mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().oracle_reset(self.h, _p(sd), _p(mk), _p(obs), _p(d), _p(m))
-        return obs, d, m
+        return self._frame(obs), d, m
 
     def step(self, actions, autoreset: int = 1):
         obs, d, m = self._outs()
@@ -251,7 +266,7 @@ class OracleVec:
             raise ValueError("Unknown action")
         if rc:
             raise AssertionError("front cell out of bounds")
-        return obs, rew, term.astype(bool), trunc.astype(bool), d, m
+        return self._frame(obs), rew, term.astype(bool), trunc.astype(bool), d, m
 
     def get_state(self):
         grid = np.zeros((self.n, self.W, self.H, 3), np.uint8)

@@ -153,6 +153,35 @@ def test_oracle_observation_wrappers_match_reference(env_id, what):
         assert (obs == want[:, t + 1]).all(), (env_id, what, t)
 
 
+# ---- RGB observation path: tiles and frames produced by the reference itself ----
+RGB_IDS = ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Empty-8x8-v0", "MiniGrid-KeyCorridorS3R3-v0",
+           "BabyAI-GoToLocalS8N7-v0", "MiniGrid-RedBlueDoors-8x8-v0", "MiniGrid-FourRooms-v0", "MiniGrid-DistShift2-v0"]
+
+
+def test_oracle_tile_atlas_matches_every_reference_tile():
+    from oracle import render
+    g = golden("rgb_atlas.npz")
+    assert [tuple(k) for k in g["keys"]] == render.tile_keys()
+    for ts in g["tile_sizes"]:
+        atlas, _ = render.tile_atlas(int(ts))
+        assert atlas.shape == g[f"tiles{ts}"].shape and (atlas == g[f"tiles{ts}"]).all(), ts
+
+
+@pytest.mark.parametrize("gold", [f"rgb_{i}" for i in RGB_IDS] + ["rgb16_MiniGrid-DoorKey-8x8-v0", "rgb4_MiniGrid-DoorKey-8x8-v0"])
+@pytest.mark.parametrize("what", ["full", "partial"])
+def test_oracle_rgb_frames_match_reference(gold, what):
+    g = golden(gold + ".npz")
+    env_id = gold.split("_", 1)[1]
+    acts, want = g["actions"], g[what]
+    S, T = acts.shape
+    v = O.OracleVec(env_id, S, obs="rgb" if what == "full" else "rgb_partial", tile_size=int(g["tile_size"]))
+    obs, _, _ = v.reset(seeds=g["seeds"])
+    assert obs.shape == want[:, 0].shape and (obs == want[:, 0]).all()
+    for t in range(T):
+        obs = v.step(acts[:, t])[0]
+        assert (obs == want[:, t + 1]).all(), (gold, what, t)
+
+
 @pytest.mark.parametrize("env_id", NODEATH_IDS)
 def test_oracle_nodeath_matches_reference(env_id):
     g = golden(f"nodeath_{env_id}.npz")
