@@ -77,7 +77,11 @@ typedef enum mg_obs_mode {
                           V = agent_view_size (7, or any odd 3..15 = ViewSizeWrapper, wrappers.py:629-673)                     */
   MG_OBS_FULL = 1,     /* FullyObsWrapper.observation (wrappers.py:419-426): (N,W,H,3) u8                                       */
   MG_OBS_ONEHOT = 2,   /* OneHotPartialObsWrapper.observation (wrappers.py:267-284): (N,V,V,20) u8                              */
-  MG_OBS_SYMBOLIC = 3  /* SymbolicObsWrapper.observation (wrappers.py:763-782): (N,W,H,3) i8 = (x, y, type or -1), agent = 10   */
+  MG_OBS_SYMBOLIC = 3, /* SymbolicObsWrapper.observation (wrappers.py:763-782): (N,W,H,3) i8 = (x, y, type or -1), agent = 10   */
+  MG_OBS_RGB_PARTIAL = 4, /* RGBImgPartialObsWrapper.observation (wrappers.py:376-381) = get_frame(agent_pov=True)
+                             (minigrid_env.py:652-666): (N, V*tile_size, V*tile_size, 3) u8                              */
+  MG_OBS_RGB = 5       /* RGBImgObsWrapper.observation (wrappers.py:325-331) = get_full_render (minigrid_env.py:668-714):
+                          (N, H*tile_size, W*tile_size, 3) u8, the agent's view highlighted when rgb_highlight != 0       */
 } mg_obs_mode;
 
 typedef enum mg_autoreset_mode {
@@ -119,11 +123,13 @@ typedef struct mg_config {
   int32_t room_size;          /* RoomGrid levels (core/roomgrid.py:75)                                                  */
   int32_t random_length;      /* Memory (memory.py:70)                                                                  */
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
+  int32_t tile_size;          /* RGB modes: pixels per cell, 4 | 8 | 12 | 16 (wrappers.py:305, 355: default 8); else ignored */
+  int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
 } mg_config;
 
 /* Borrowed device pointers to the outputs of the last step/reset. */
 typedef struct mg_outputs {
-  uint8_t* obs;         /* (N, V,V,3) | (N, W,H,3) | (N, V,V,20) u8 or (N, W,H,3) i8, C-contiguous     */
+  uint8_t* obs;         /* (N, V,V,3) | (N, W,H,3) | (N, V,V,20) u8, (N, W,H,3) i8 or an RGB frame, C-contiguous */
   double* reward;       /* (N) f64: 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245) */
   uint8_t* terminated;  /* (N) u8 0/1                                                                 */
   uint8_t* truncated;   /* (N) u8 0/1 (minigrid_env.py:587-588)                                       */
@@ -190,6 +196,10 @@ MG_API int mg_device_count(void);
 MG_API int mg_selftest_vis_row(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_vis_row_n(int32_t view, uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_reward_lut(int32_t max_steps, double* out /* [max_steps+1] */);
+/* Grid.render_tile (core/grid.py:145-198) for every tile of the RGB atlas, as the library renders it at mg_create:
+ * out[51][5][2][tile_size][tile_size][3] = [tile key][no agent, agent_dir 0..3][plain, highlighted]; tile keys are
+ * empty 0 | wall 1+c | floor 7+c | key 13+c | ball 19+c | box 25+c | door 31+3c+state | goal 49 | lava 50. */
+MG_API int mg_render_tiles(int32_t tile_size, uint8_t* out);
 MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple);
 
 #ifdef __cplusplus

@@ -10,6 +10,7 @@ HIP/gfx950 only: importing works anywhere, creating an env requires an MI355X.
 from .registry import EnvSpec, registry, spec  # noqa: F401
 from .vector_env import MiniGridVecEnv, make_vec  # noqa: F401
 from .wrappers import (DictObservationSpaceWrapper, FullyObsWrapper, ImgObsWrapper, NoDeath,  # noqa: F401
-                       OneHotPartialObsWrapper, SymbolicObsWrapper, ViewSizeWrapper)
+                       OneHotPartialObsWrapper, RGBImgObsWrapper, RGBImgPartialObsWrapper, SymbolicObsWrapper,
+                       ViewSizeWrapper)
 
 __version__ = "0.1.0"

@@ -9,7 +9,7 @@ from . import build as _build
 
 MG_ABI_VERSION = 1
 MG_OK, MG_ERR_INVALID, MG_ERR_HIP, MG_ERR_BAD_ACTION, MG_ERR_GENERATOR, MG_ERR_NO_DEVICE, MG_ERR_OOB = 0, -1, -2, -3, -4, -5, -6
-OBS_PARTIAL, OBS_FULL, OBS_ONEHOT, OBS_SYMBOLIC = 0, 1, 2, 3
+OBS_PARTIAL, OBS_FULL, OBS_ONEHOT, OBS_SYMBOLIC, OBS_RGB_PARTIAL, OBS_RGB = 0, 1, 2, 3, 4, 5
 AUTORESET_NEXT_STEP, AUTORESET_DISABLED = 0, 1
 RNG_PCG64, RNG_PHILOX = 0, 1
 ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
@@ -20,7 +20,8 @@ class MgConfig(C.Structure):
         "abi_version", "env_kind", "width", "height", "max_steps", "see_through_walls", "agent_view_size",
         "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
         "num_crossings", "obstacle_type", "num_dists", "null_stream_sync", "strip2_row", "no_death_mask")] + [
-        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("env_index_base", C.c_int64)]
+        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("env_index_base", C.c_int64),
+        ("tile_size", C.c_int32), ("rgb_highlight", C.c_int32)]
 
 
 class MgOutputs(C.Structure):
@@ -39,7 +40,7 @@ _lib = None
 SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_get_outputs", "mg_copy_outputs",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
-           "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n"]
+           "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles"]
 
 
 def lib_path() -> str:
@@ -82,6 +83,7 @@ def load():
     L.mg_selftest_vis_row.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mg_selftest_vis_row_n.argtypes = [C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mg_selftest_reward_lut.argtypes = [C.c_int32, vp]
+    L.mg_render_tiles.argtypes = [C.c_int32, C.c_void_p]
     L.mg_selftest_pack_cell.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if L.mg_abi_version() != MG_ABI_VERSION:
         raise MiniGridHipError(f"libminigrid_hip ABI {L.mg_abi_version()} != binding {MG_ABI_VERSION}")

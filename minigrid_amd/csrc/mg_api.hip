@@ -29,6 +29,7 @@ struct mg_env {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
+  int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
   int off_grid = 0, off_trow = 0, off_vis = 0, off_T = 0, off_lut = 0, off_act = 0, lds_bytes = 0;
   int wpg = 4;                // wavefronts per group of 64 envs in k_step
   bool static_gen = false;
@@ -40,6 +41,10 @@ struct mg_env {
   uint8_t *mask = nullptr, *actions = nullptr;
   uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
   bool goto_kind = false;
+  uint8_t* tilemap = nullptr; uint32_t* atlas = nullptr;   // RGB modes: k_step's output / the tile atlas (mg_tiles.h)
+  RenderParams render;        // ... and k_render's launch geometry
+  int render_lds = 0, render_blocks = 0;
+  bool rgb = false;
   uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
   double *reward = nullptr, *reward_lut = nullptr;
   uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
@@ -140,7 +145,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.grid = e->grid; P.spare_grid = e->spare_grid; P.agent = e->agent; P.spare_agent = e->spare_agent;
   P.aux = e->aux; P.spare_aux = e->spare_aux;
   P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
-  P.obs = e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
+  P.obs = e->rgb ? e->tilemap : e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
   P.reward_lut = e->reward_lut;
   P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + QC_STRIDE * (e->launches % 3);
   P.err = e->err; P.counters = e->counters;
@@ -149,7 +154,8 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks; P.live_gen = e->live_gen ? 1 : 0;
   P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
-  P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->obs_bytes;
+  P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->map_bytes;
+  P.rgb_full = e->cfg.obs_mode == MG_OBS_RGB; P.rgb_highlight = e->cfg.rgb_highlight != 0;
   P.view = e->cfg.agent_view_size; P.no_death_mask = e->cfg.no_death_mask; P.death_cost = e->cfg.death_cost;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
@@ -207,11 +213,16 @@ static int launch_step(mg_env* e, const StepParams& P) {
     case MG_OBS_FULL: MG_LAUNCH_STEP(1, 4, 7); break;
     case MG_OBS_SYMBOLIC: MG_LAUNCH_STEP(3, 4, 7); break;
     case MG_OBS_ONEHOT: if (v7) MG_LAUNCH_STEP(2, 4, 7); else MG_LAUNCH_STEP(2, 4, 15); break;
+    case MG_OBS_RGB: case MG_OBS_RGB_PARTIAL: MG_LAUNCH_STEP(4, 4, 7); break;
     default: if (v7) MG_LAUNCH_STEP(0, 4, 7); else MG_LAUNCH_STEP(0, 4, 15); break;
   }
 #undef MG_LAUNCH_STEP_G
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
+  if (e->rgb) {
+    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(RENDER_THREADS), (size_t)e->render_lds, e->stream, e->render);
+    HIP_TRY(e, hipGetLastError());
+  }
   e->launches++;
   if (P.phase == PHASE_STEP) e->env_steps += (uint64_t)e->N;
   return MG_OK;
@@ -226,6 +237,61 @@ static int check_device_errors(mg_env* e) {
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
   if (bits & ERR_OOB) return fail(e, MG_ERR_OOB, "front cell outside the grid (core/grid.py:74-78 assert)");
   return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound");
+}
+
+// ---- RGB modes: the tile atlas and k_render's launch geometry ------------------------------------------------
+static int setup_render(mg_env* e) {
+  const int ts = e->cfg.tile_size, V = e->cfg.agent_view_size;
+  const bool full = e->cfg.obs_mode == MG_OBS_RGB;
+  RenderParams& R = e->render;
+  R.N = e->N; R.ts = ts; R.full = full ? 1 : 0;
+  R.Wt = full ? e->W : V; R.Ht = full ? e->H : V; R.cells = R.Wt * R.Ht;
+  R.tdw_row = ts * 3 / 4; R.tile_dw = ts * R.tdw_row;
+  R.rowdw = R.Wt * R.tdw_row;
+  R.R = R.rowdw % 4 == 0 ? 1 : (R.rowdw % 2 == 0 ? 2 : 4);            // ts % 4 == 0, so R divides ts: a period stays inside one tile row
+  R.cpp = R.R * R.rowdw / 4;
+  R.ppe = R.Ht * ts / R.R;
+  if (R.cpp > RENDER_THREADS) return fail(e, MG_ERR_INVALID, "frame too wide for k_render");
+  R.t_active = RENDER_THREADS / R.cpp * R.cpp;
+  R.pp = R.t_active / R.cpp;
+  // envs per workgroup: as many as keep the LDS footprint (atlas + per-env agent tiles + tile offsets) near 32 KB
+  int epw = 64;
+  auto lds_for = [&](int n) { return (STATIC_TILES + n) * R.tile_dw * 4 + ((n * R.cells * 2 + 15) & ~15); };
+  while (epw > 8 && lds_for(epw) > 40 * 1024) epw >>= 1;
+  R.epw = epw; R.ngroups = (e->N + epw - 1) / epw;
+  R.off_map = (STATIC_TILES + epw) * R.tile_dw * 4;
+  e->render_lds = lds_for(epw);
+  if (e->render_lds > 160 * 1024 || (STATIC_TILES + epw) * R.tile_dw > 65535) return fail(e, MG_ERR_INVALID, "tile atlas too large for the LDS staging");
+  R.log2R = R.R == 1 ? 0 : (R.R == 2 ? 1 : 2);
+  R.magic_ts = (65536u + (uint32_t)ts - 1u) / (uint32_t)ts;
+  for (uint32_t r = 0; r < (uint32_t)(R.Ht * ts); r++)                  // the multiply-shift division is exact over its whole range
+    if (((r * R.magic_ts) >> 16) != r / (uint32_t)ts) return fail(e, MG_ERR_INVALID, "internal: magic_ts");
+  int cus = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(e->render_lds, 1)));
+  e->render_blocks = std::min(R.ngroups, cus * per_cu);
+  if (const char* s = getenv("MG_RENDER_BLOCKS")) { int v = atoi(s); if (v >= 1) e->render_blocks = std::min(v, R.ngroups); }
+
+  // atlas: host-rendered [key][agent][hl] -> device [key][hl] (agent-free) followed by [key][dir][hl]
+  const size_t tb = (size_t)ts * ts * 3;
+  std::vector<uint8_t> all((size_t)TILE_KEYS * 10 * tb), dev((size_t)TILE_KEYS * 10 * tb);
+  tiles::render_all(ts, all.data());
+  for (int k = 0; k < TILE_KEYS; k++)
+    for (int ad = 0; ad < 5; ad++)
+      for (int hl = 0; hl < 2; hl++) {
+        const uint8_t* src = all.data() + (((size_t)k * 5 + ad) * 2 + hl) * tb;
+        const size_t di = ad == 0 ? (size_t)k * 2 + hl : (size_t)STATIC_TILES + ((size_t)k * 4 + (ad - 1)) * 2 + hl;
+        memcpy(dev.data() + di * tb, src, tb);
+      }
+  HIP_TRY(e, hipMalloc((void**)&e->atlas, dev.size()));
+  HIP_TRY(e, hipMemcpy(e->atlas, dev.data(), dev.size(), hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMalloc((void**)&e->tilemap, (size_t)e->N * e->map_bytes + 16));
+  HIP_TRY(e, hipMemsetAsync(e->tilemap, 0, (size_t)e->N * e->map_bytes + 16, e->stream));
+  R.tilemap = e->tilemap; R.agent = e->agent;
+  R.atlas_static = e->atlas; R.atlas_agent = e->atlas + (size_t)STATIC_TILES * R.tile_dw;
+  R.out = (uint4*)e->obs;
+  if (e->render_lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, e->render_lds));
+  return MG_OK;
 }
 
 template <class T>
@@ -253,7 +319,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
   if (cfg->agent_view_size < 3 || cfg->agent_view_size > 15 || (cfg->agent_view_size & 1) == 0)
     return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be odd and in 3..15 (wrappers.py:650-651 asserts odd, >= 3)");
-  if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_SYMBOLIC) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
+  if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_RGB) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
+  const bool rgb = cfg->obs_mode == MG_OBS_RGB || cfg->obs_mode == MG_OBS_RGB_PARTIAL;
+  if (rgb && (cfg->tile_size < 4 || cfg->tile_size > 16 || cfg->tile_size % 4 != 0))
+    return fail(nullptr, MG_ERR_INVALID, "RGB observations: tile_size must be 4, 8, 12 or 16");
+  if (rgb && cfg->agent_view_size != 7)
+    return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTOOBJECT) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
@@ -304,8 +375,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   switch (cfg->obs_mode) {
     case MG_OBS_FULL: case MG_OBS_SYMBOLIC: e->obs_bytes = e->cells * 3; break;
     case MG_OBS_ONEHOT: e->obs_bytes = V * V * 20; break;
+    case MG_OBS_RGB_PARTIAL: e->obs_bytes = V * V * cfg->tile_size * cfg->tile_size * 3; break;
+    case MG_OBS_RGB: e->obs_bytes = e->cells * cfg->tile_size * cfg->tile_size * 3; break;
     default: e->obs_bytes = V * V * 3; break;
   }
+  e->rgb = rgb;
+  e->map_bytes = !rgb ? e->obs_bytes : (cfg->obs_mode == MG_OBS_RGB ? e->cells : V * V);
   {
     // LDS carve-up of k_step (bytes): guard | 64 staged grids | guard | opacity rows | visibility masks |
     // observation bytes in output order | decode table | actions.  The guard bands cover the furthest a view cell
@@ -315,7 +390,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_trow = (guard + 64 * e->GS + guard + 15) & ~15;
     e->off_vis = e->off_trow + 64 * 32;                     // one u16 per view row and env (one u8 for V == 7)
     e->off_T = e->off_vis + 64 * 8;
-    e->off_lut = e->off_T + ((64 * e->obs_bytes + 15) & ~15);
+    e->off_lut = e->off_T + ((64 * e->map_bytes + 15) & ~15);
     e->off_act = e->off_lut + 256 * 4;
     e->lds_bytes = e->off_act + 64;
   }
@@ -388,6 +463,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(hipMemsetAsync(e->aux, 0, N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_aux, 0, N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(dalloc(&e->obs, N * e->obs_bytes + 16));
+  if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
   TRY_OR_FREE(dalloc(&e->reward, N));
   TRY_OR_FREE(dalloc(&e->term, N));
   TRY_OR_FREE(dalloc(&e->trunc, N));
@@ -415,7 +491,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     const void* fns[] = {
 #define MG_KG(MODE, WPG, VT, GG) (const void*)k_step<MODE, WPG, WavePcg64, VT, GG>, (const void*)k_step<MODE, WPG, WavePhilox, VT, GG>
 #define MG_K(MODE, WPG, VT) MG_KG(MODE, WPG, VT, GG_NONE), MG_KG(MODE, WPG, VT, GG_LIGHT), MG_KG(MODE, WPG, VT, GG_ROOMGRID)
-      MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7)
+      MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7), MG_K(4, 4, 7)
 #undef MG_K
 #undef MG_KG
     };
@@ -447,7 +523,8 @@ int mg_destroy(mg_env* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions, e->aux, e->spare_aux,
-                   e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters };
+                   e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters,
+                   e->tilemap, e->atlas };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -703,6 +780,12 @@ int mg_selftest_reward_lut(int32_t max_steps, double* out) {
   build_reward_lut(max_steps, out);
   return MG_OK;
 }
+int mg_render_tiles(int32_t tile_size, uint8_t* out) {
+  if (!out || tile_size < 1 || tile_size > 64) return MG_ERR_INVALID;
+  tiles::render_all(tile_size, out);
+  return MG_OK;
+}
+
 int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple) {
   if (!code || !triple) return MG_ERR_INVALID;
   *code = cell_from_triple((uint32_t)type, (uint32_t)color, (uint32_t)state);

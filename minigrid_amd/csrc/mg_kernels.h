@@ -17,6 +17,7 @@
 #pragma once
 #include "mg_device.h"
 #include "mg_gen.h"
+#include "mg_tiles.h"
 #include "mg_rng.h"
 
 namespace mg {
@@ -48,6 +49,7 @@ struct StepParams {
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
+  int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
   long long env_base;
 };
 
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
 // verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
 // FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
-// MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3.
+// MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3,
+// 4 = tile map for k_render (RGBImgPartialObsWrapper: VxV bytes; RGBImgObsWrapper: WxH bytes), byte = tile key * 2 + highlight.
 // WPG = wavefronts per group of 64 envs (1, 2 or 4).  VT = 7 (default view, unrolled) or 15 (run-time V <= 15).
 // GG = generator group compiled into the generator role (mg_gen.h; GG_NONE for levels whose reset draws nothing).
 //
@@ -275,7 +278,7 @@ k_step(const StepParams P, const GenArgs A) {
   uint64_t targets = 0;                         // BabyAI GoTo levels: tracked positions, issued with the other loads
   if constexpr (GG == GG_ROOMGRID) targets = ((P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ) && active) ? P.aux[e] : 0ull;
 #pragma unroll
-  for (int k = tid; k < 256; k += NT) slut[k] = cell_triple((uint32_t)k);
+  for (int k = tid; k < 256; k += NT) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
   if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
   {
     // stage the 64 grids: 16 B per lane, fully coalesced; an env whose previous step ended its episode takes the
@@ -498,7 +501,7 @@ k_step(const StepParams P, const GenArgs A) {
   }
 
   const int obe = P.OBE;
-  if (MODE == 0 || MODE == 2) {
+  if (MODE == 0 || MODE == 2 || MODE == 4) {
     // ---- gen_obs_grid(V): closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
     //      view cell (vx,vy) is world cell agent + f*(V-1-vy) + r*(vx-V/2), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
     //      outside the grid -> grey wall (grid.py:136-139).  wx depends on only one of vx/vy and wy on the other,
@@ -595,6 +598,12 @@ k_step(const StepParams P, const GenArgs A) {
           if (VT == 7 || vx < V) {
             uint32_t c = mycell[r][vx];
             if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+            if (MODE == 4) {
+              // get_pov_render (minigrid_env.py:652-666): process_vis has blanked the invisible cells (grid.py:324-327),
+              // so they are empty un-highlighted tiles (byte 0); visible ones are highlighted.  Image order [vy][vx].
+              if (!P.rgb_full) myT[vy * V + vx] = (uint8_t)(slut[c] & (0u - ((vrow >> vx) & 1u)));
+              continue;
+            }
             const uint32_t tri = slut[c & (0u - ((vrow >> vx) & 1u))];
             if (MODE == 0) {
               uint8_t* o = myT + (vx * V + vy) * 3;
@@ -606,6 +615,26 @@ k_step(const StepParams P, const GenArgs A) {
               o4[0] = 0; o4[1] = 0; o4[2] = 0; o4[3] = 0; o4[4] = 0;
               o[tri & 0xFF] = 1; o[11 + ((tri >> 8) & 0xFF)] = 1; o[17 + (tri >> 16)] = 1;
             }
+          }
+        }
+      }
+    }
+    if (MODE == 4 && VT == 7) {
+      if (P.rgb_full) {
+        // get_full_render (minigrid_env.py:668-714): every grid cell, highlighted where the agent's view sees it.
+        // World cell (x, y) is view cell (HV + d.r, V-1 - d.f) with d = (x, y) - agent: the inverse of the gather above.
+        const uint32_t hl_on = P.rgb_highlight ? 1u : 0u;
+        for (int y = wave; y < H; y += WPG) {
+          const int dy = y - (int)a.y;
+#pragma unroll 4
+          for (int x = 0; x < W; x++) {
+            const int idx = y * W + x, dx = x - (int)a.x;
+            uint32_t c = mygrid[idx];
+            if (idx == dirty_idx) c = dirty_code;
+            const int fwd = dx * fxv + dy * fyv, side = dx * rx + dy * ry + HV;
+            const bool inside = (unsigned)fwd < (unsigned)V && (unsigned)side < (unsigned)V;
+            const uint32_t bit = inside ? (uint32_t)(vis >> (7 * (V - 1 - fwd) + side)) & hl_on : 0u;
+            myT[idx] = (uint8_t)(slut[c] - 1u + bit);
           }
         }
       }
@@ -709,6 +738,102 @@ __global__ void k_mark_pending(uint64_t* agent, const uint8_t* mask, int N) {
   Agent a = agent_unpack(agent[e]);
   a.flags |= FLAG_RESET_PENDING;
   agent[e] = agent_pack(a);
+}
+
+// ======================================================================================================
+// k_render: RGBImgObsWrapper / RGBImgPartialObsWrapper (wrappers.py:287-380) = Grid.render (grid.py:200-242): the
+// frame is a mosaic of pre-rendered tiles (mg_tiles.h).  Input: k_step's tile map (one byte per cell = tile key * 2 +
+// highlight) and, for the full render, the agent record; output: [N][Ht*ts][Wt*ts][3] bytes.
+//
+// HBM-write bound (9-12 KB per env against ~60 B read), so the kernel is organised around the store stream: a
+// workgroup's EPW consecutive frames are ONE contiguous byte range, dealt out as 16 B chunks, thread t taking chunks
+// t, t + T, t + 2T, ... with T a multiple of the chunks per "period" (R pixel rows, R the smallest count whose dwords
+// divide by 4).  A thread's position inside its period -- which tile columns and which dword of the tile row its
+// four dwords come from -- is therefore loop-invariant; per chunk only the period index is decomposed into env /
+// tile row / pixel row, incrementally and with 24-bit multiplies.  Tiles are read from LDS: the 102 agent-free tiles are staged once per
+// workgroup, the one agent tile of each env (cell kind x direction x highlight) once per env.
+// ======================================================================================================
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int RENDER_THREADS = 256;
+constexpr int STATIC_TILES = 2 * TILE_KEYS;          // [key][highlight]
+
+struct RenderParams {
+  const uint8_t* tilemap; const uint64_t* agent;
+  const uint32_t* atlas_static;    // [key][hl][ts][ts*3/4] dwords
+  const uint32_t* atlas_agent;     // [key][dir][hl][...]
+  uint4* out;
+  int N, Wt, Ht, cells, ts, full, epw, ngroups;
+  int tile_dw, tdw_row, rowdw, R, cpp, ppe, t_active, pp;      // see above; ppe = periods per env, pp = periods per sweep
+  int log2R; uint32_t magic_ts;                                // R = 1 << log2R; magic_ts = ceil(2^16 / ts)
+  int off_map;                                                 // LDS: [atlas dwords | u16 tile offsets per cell]
+};
+
+__global__ void __launch_bounds__(RENDER_THREADS) k_render(const RenderParams R) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* satlas = (uint32_t*)smem;
+  uint16_t* smap = (uint16_t*)(smem + R.off_map);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < STATIC_TILES * R.tile_dw; i += RENDER_THREADS) satlas[i] = R.atlas_static[i];
+
+  // loop-invariant position of this thread's four dwords inside a period
+  const bool worker = tid < R.t_active;
+  const int cidx = tid % R.cpp, p0 = tid / R.cpp;
+  int txj[4], srcj[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int dw = cidx * 4 + j, dr = dw / R.rowdw, col = dw - dr * R.rowdw;
+    txj[j] = col / R.tdw_row;
+    srcj[j] = dr * R.tdw_row + (col - txj[j] * R.tdw_row);
+  }
+  const int img_chunks = R.ppe * R.cpp;
+
+  for (int g = blockIdx.x; g < R.ngroups; g += gridDim.x) {
+    const int env0 = g * R.epw, nv = min(R.epw, R.N - env0);
+    __syncthreads();                                   // the previous group's blit is done with smap / the agent tiles
+    const uint8_t* tm = R.tilemap + (size_t)env0 * R.cells;
+    for (int i = tid; i < nv * R.cells; i += RENDER_THREADS) smap[i] = (uint16_t)((uint32_t)tm[i] * (uint32_t)R.tile_dw);
+    __syncthreads();
+    for (int el = wave; el < nv; el += RENDER_THREADS / 64) {
+      // the agent's cell: POV = bottom centre facing up (minigrid_env.py:659-663); full = its position and direction
+      int cell, dir;
+      if (R.full) {
+        const Agent a = agent_unpack(R.agent[env0 + el]);
+        cell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
+      } else { cell = (R.Ht - 1) * R.Wt + (R.Wt >> 1); dir = 3; }
+      const uint32_t b = tm[el * R.cells + cell];
+      const uint32_t* src = R.atlas_agent + (size_t)(((b >> 1) * 4u + (uint32_t)dir) * 2u + (b & 1u)) * R.tile_dw;
+      uint32_t* dst = satlas + (STATIC_TILES + el) * R.tile_dw;
+      for (int k = lane; k < R.tile_dw; k += 64) dst[k] = src[k];
+      if (lane == 0) smap[el * R.cells + cell] = (uint16_t)((STATIC_TILES + el) * R.tile_dw);
+    }
+    __syncthreads();
+    if (worker) {
+      // period p = p0, p0 + pp, ...: (env, period inside the env) advance by constant steps with one conditional
+      // wrap; the rest is 24-bit multiplies of small numbers (full rate), no division
+      u32x4* out = (u32x4*)R.out + (size_t)env0 * img_chunks + (uint32_t)(p0 * R.cpp + cidx);
+      const int total = nv * R.ppe, d_el = R.pp / R.ppe, d_pr = R.pp - d_el * R.ppe;
+      const uint32_t ostep = (uint32_t)(R.pp * R.cpp);
+      int el = p0 / R.ppe, pr = p0 - el * R.ppe;
+      int mb = el * R.cells;
+      const int d_mb = d_el * R.cells;
+#pragma unroll 2
+      for (int p = p0; p < total; p += R.pp) {
+        const uint32_t row0 = (uint32_t)pr << R.log2R;
+        const uint32_t ty = __umul24(row0, R.magic_ts) >> 16;
+        const uint32_t rowoff = __umul24(row0 - __umul24(ty, (uint32_t)R.ts), (uint32_t)R.tdw_row);
+        const uint16_t* m = smap + mb + __umul24(ty, (uint32_t)R.Wt);
+        u32x4 v;
+        v.x = satlas[(uint32_t)m[txj[0]] + rowoff + srcj[0]];
+        v.y = satlas[(uint32_t)m[txj[1]] + rowoff + srcj[1]];
+        v.z = satlas[(uint32_t)m[txj[2]] + rowoff + srcj[2]];
+        v.w = satlas[(uint32_t)m[txj[3]] + rowoff + srcj[3]];
+        __builtin_nontemporal_store(v, out);          // written once, never re-read by this kernel
+        out += ostep;
+        el += d_el; pr += d_pr; mb += d_mb;
+        if (pr >= R.ppe) { pr -= R.ppe; el++; mb += R.cells; }
+      }
+    }
+  }
 }
 
 }  // namespace mg

@@ -30,7 +30,8 @@ except Exception:
         pass
 
 _AUTORESET = {"next_step": B.AUTORESET_NEXT_STEP, "disabled": B.AUTORESET_DISABLED}
-_OBS_MODES = {"partial": B.OBS_PARTIAL, "full": B.OBS_FULL, "onehot": B.OBS_ONEHOT, "symbolic": B.OBS_SYMBOLIC}
+_OBS_MODES = {"partial": B.OBS_PARTIAL, "full": B.OBS_FULL, "onehot": B.OBS_ONEHOT, "symbolic": B.OBS_SYMBOLIC,
+              "rgb_partial": B.OBS_RGB_PARTIAL, "rgb": B.OBS_RGB}
 # minigrid/core/constants.py:25-37
 OBJECT_TO_IDX = {"unseen": 0, "empty": 1, "wall": 2, "floor": 3, "door": 4, "key": 5, "ball": 6, "box": 7, "goal": 8,
                  "lava": 9, "agent": 10}
@@ -53,7 +54,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                  autoreset_mode: str = "next_step", rng: str = "pcg64", env_index_base: int = 0,
                  max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
                  image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
-                 death_cost: float = -1.0, dict_mission: bool = False):
+                 death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True):
         if obs_mode not in _OBS_MODES:
             raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
         # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
@@ -95,7 +96,8 @@ class MiniGridVecEnv(_VectorEnvBase):
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
-            env_index_base=self.env_index_base)
+            env_index_base=self.env_index_base, tile_size=int(tile_size), rgb_highlight=int(bool(highlight)))
+        self.tile_size, self.highlight = int(tile_size), bool(highlight)
         if output == "torch" and stream is None:
             # outputs are handed out as torch tensors: run stream-ordered with torch.  A non-default current stream is
             # borrowed; the legacy NULL stream (torch's default) cannot be passed as a handle, so the library's own
@@ -117,7 +119,10 @@ class MiniGridVecEnv(_VectorEnvBase):
         self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
         v = self.agent_view_size
         self.image_shape = {"partial": (v, v, 3), "full": (s.width, s.height, 3), "onehot": (v, v, 20),
-                            "symbolic": (s.width, s.height, 3)}[obs_mode]
+                            "symbolic": (s.width, s.height, 3),
+                            # RGBImgPartialObsWrapper / RGBImgObsWrapper spaces (wrappers.py:357-368, 307-323): rows x columns x 3
+                            "rgb_partial": (v * self.tile_size, v * self.tile_size, 3),
+                            "rgb": (s.height * self.tile_size, s.width * self.tile_size, 3)}[obs_mode]
         self._missions = np.asarray(s.missions)
         # DictObservationSpaceWrapper (wrappers.py:429-554): mission string -> padded word-index vector, per mission id
         self._mission_tokens = np.asarray([string_to_indices(m) for m in s.missions], np.int64)

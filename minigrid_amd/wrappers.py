@@ -18,7 +18,7 @@ def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
               rng="philox" if env._cfg.rng_mode == 1 else "pcg64", env_index_base=env.env_index_base,
               max_steps=env.max_steps, output=env.output, image_only=env.image_only,
               agent_view_size=env.agent_view_size, no_death_types=env.no_death_types, death_cost=env.death_cost,
-              dict_mission=env.dict_mission)
+              dict_mission=env.dict_mission, tile_size=env.tile_size, highlight=env.highlight)
     kw.update(changes)
     new = MiniGridVecEnv(env.env_id, env.num_envs, **kw)
     env.close()
@@ -28,6 +28,18 @@ def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
 def ImgObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
     """Use the image as the only observation output, no language/mission (wrappers.py:187-214)."""
     return _rebuild(env, image_only=True)
+
+
+def RGBImgObsWrapper(env: MiniGridVecEnv, tile_size: int = 8) -> MiniGridVecEnv:
+    """Fully observable RGB image as observation (wrappers.py:287-331): get_frame(highlight=env.highlight, tile_size),
+    (height*tile_size, width*tile_size, 3) uint8, blitted on the device from the pre-rendered tile atlas."""
+    return _rebuild(env, obs_mode="rgb", agent_view_size=7, tile_size=tile_size)
+
+
+def RGBImgPartialObsWrapper(env: MiniGridVecEnv, tile_size: int = 8) -> MiniGridVecEnv:
+    """Partially observable RGB image as observation (wrappers.py:334-381): get_frame(tile_size, agent_pov=True),
+    (view*tile_size, view*tile_size, 3) uint8."""
+    return _rebuild(env, obs_mode="rgb_partial", tile_size=tile_size)
 
 
 def FullyObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:

@@ -22,9 +22,11 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_config_struct_layout_matches_header():
-    # 18 int32 + 6 reserved int32 + one int64 = 104 bytes, int64 8-aligned at offset 96
-    assert C.sizeof(B.MgConfig) == 104
+    # 20 int32, double at 80, 2 int32, int64 at 96, 2 int32 = 112 bytes
+    assert C.sizeof(B.MgConfig) == 112
+    assert B.MgConfig.death_cost.offset == 80
     assert B.MgConfig.env_index_base.offset == 96
+    assert B.MgConfig.tile_size.offset == 104 and B.MgConfig.rgb_highlight.offset == 108
     assert C.sizeof(B.MgOutputs) == 64
 
 
@@ -203,3 +205,17 @@ def test_registry_rows_are_consistent():
     for env_id, s in mg.registry.items():
         assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
         assert s.entry_point.startswith("minigrid.envs")
+
+
+def test_library_tile_atlas_matches_every_reference_tile():
+    """mg_render_tiles is the host routine mg_create fills the RGB atlas with (mg_tiles.h): all 510 tiles x 4 tile sizes
+    against tiles rendered by the reference's Grid.render_tile (tests/golden/rgb_atlas.npz)."""
+    from conftest import golden
+    L = B.load()
+    g = golden("rgb_atlas.npz")
+    for ts in g["tile_sizes"]:
+        want = g[f"tiles{ts}"]
+        out = np.zeros(want.shape, np.uint8)
+        assert L.mg_render_tiles(int(ts), out.ctypes.data) == 0
+        assert (out == want).all(), ts
+    assert L.mg_render_tiles(0, out.ctypes.data) != 0

@@ -453,3 +453,105 @@ def test_stepping_past_termination_matches_reference_goldens(env_id):
         assert (obs["image"] == g["obs"][:, t + 1]).all(), (env_id, t)
         assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all(), (env_id, t)
     env.close()
+
+
+# ---- RGB observation path: k_step tile map + k_render blit ----
+RGB_GOLDENS = [f"rgb_{i}" for i in ("MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Empty-8x8-v0",
+                                    "MiniGrid-KeyCorridorS3R3-v0", "BabyAI-GoToLocalS8N7-v0", "MiniGrid-RedBlueDoors-8x8-v0",
+                                    "MiniGrid-FourRooms-v0", "MiniGrid-DistShift2-v0")] + \
+              ["rgb16_MiniGrid-DoorKey-8x8-v0", "rgb4_MiniGrid-DoorKey-8x8-v0"]
+
+
+def _rgb(env_id, n, what, tile_size=8, **kw):
+    import minigrid_amd as mg
+    wrap = mg.RGBImgObsWrapper if what == "full" else mg.RGBImgPartialObsWrapper
+    return wrap(_mk(env_id, n, **kw), tile_size=tile_size)
+
+
+@pytest.mark.parametrize("gold", RGB_GOLDENS)
+@pytest.mark.parametrize("what", ["full", "partial"])
+def test_rgb_frames_match_reference_goldens(gold, what):
+    g = golden(gold + ".npz")
+    env_id = gold.split("_", 1)[1]
+    acts, want = g["actions"], g[what]
+    S, T = acts.shape
+    env = _rgb(env_id, S, what, tile_size=int(g["tile_size"]))
+    _assert_native_loaded()
+    obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
+    assert obs["image"].dtype == np.uint8 and obs["image"].shape == want[:, 0].shape
+    assert env.single_observation_space["image"].shape == want.shape[2:]
+    assert (obs["image"] == want[:, 0]).all()
+    for t in range(T):
+        obs = env.step(acts[:, t])[0]
+        assert (obs["image"] == want[:, t + 1]).all(), (gold, what, t)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,what,ts", [("MiniGrid-DoorKey-8x8-v0", "full", 8), ("MiniGrid-DoorKey-8x8-v0", "partial", 8),
+                                            ("MiniGrid-KeyCorridorS3R3-v0", "full", 8), ("BabyAI-GoToLocalS8N7-v0", "partial", 8),
+                                            ("MiniGrid-LavaCrossingS9N1-v0", "full", 12), ("MiniGrid-Fetch-8x8-N3-v0", "partial", 16),
+                                            ("MiniGrid-FourRooms-v0", "full", 4), ("MiniGrid-Dynamic-Obstacles-6x6-v0", "full", 16),
+                                            ("MiniGrid-Empty-Random-5x5-v0", "full", 4)])
+def test_rgb_vs_oracle_2048_envs(env_id, what, ts):
+    from oracle import oracle as O
+    n = 2048
+    env = _rgb(env_id, n, what, tile_size=ts)
+    orc = O.OracleVec(env_id, n, obs="rgb" if what == "full" else "rgb_partial", tile_size=ts)
+    obs, _ = env.reset(seed=21)
+    o_obs, _, _ = orc.reset(seeds=np.arange(21, 21 + n, dtype=np.uint64))
+    assert (obs["image"] == o_obs).all()
+    rng = np.random.default_rng(6)
+    for t in range(80):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, _, _ = orc.step(a)
+        assert (obs["image"] == oo).all(), (env_id, what, t)
+        assert rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all()
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 65, 200])
+def test_rgb_ragged_batch_sizes_and_no_highlight(n):
+    from oracle import oracle as O
+    for what, hl in (("full", True), ("full", False), ("partial", True)):
+        env = _rgb("MiniGrid-DoorKey-6x6-v0", n, what, highlight=hl)
+        orc = O.OracleVec("MiniGrid-DoorKey-6x6-v0", n, obs="rgb" if what == "full" else "rgb_partial", highlight=hl)
+        obs, _ = env.reset(seed=4)
+        assert (obs["image"] == orc.reset(seeds=np.arange(4, 4 + n, dtype=np.uint64))[0]).all()
+        rng = np.random.default_rng(n)
+        for t in range(30):
+            a = rng.integers(0, 7, n, dtype=np.uint8)
+            obs = env.step(a)[0]
+            assert (obs["image"] == orc.step(a)[0]).all(), (what, hl, n, t)
+        env.close()
+
+
+def test_rgb_65536_envs_sampled_against_oracle():
+    """BASELINE-size batch (65536 envs = 805 MB of frames per step): a strided sample of the frames against the oracle
+    stepped from the same state, and the mosaic property on ALL frames (every 8x8 block is one of the atlas tiles)."""
+    from oracle import oracle as O
+    from oracle import render
+    n = 65536
+    env = _rgb("MiniGrid-Empty-8x8-v0", n, "full")
+    env.reset(seed=0)
+    rng = np.random.default_rng(1)
+    for t in range(8):                       # the goal is >= 11 actions away: nobody finishes, no reset draws
+        env.step(rng.integers(0, 3, n, dtype=np.uint8))
+    grid, agent = env.get_state()
+    sel = np.arange(0, n, 257)
+    orc = O.OracleVec("MiniGrid-Empty-8x8-v0", len(sel), obs="rgb")
+    orc.set_state(grid[sel], agent[sel])
+    a = rng.integers(0, 3, n, dtype=np.uint8)
+    obs = env.step(a)[0]["image"]
+    assert obs.shape == (n, 64, 64, 3)
+    assert (obs[sel] == orc.step(a[sel])[0]).all()
+    atlas, _ = render.tile_atlas(8)
+    w = np.random.default_rng(0).integers(1, 2**63, 24, dtype=np.uint64) | np.uint64(1)
+    fold = lambda b: (np.ascontiguousarray(b).view(np.uint64).reshape(-1, 24) * w).sum(axis=1, dtype=np.uint64)
+    known = set(fold(atlas.reshape(-1, 192)).tolist())
+    seen = set()
+    for lo in range(0, n, 4096):
+        blk = obs[lo:lo + 4096].reshape(-1, 8, 8, 8, 8, 3).transpose(0, 1, 3, 2, 4, 5).reshape(-1, 192)
+        seen |= set(np.unique(fold(blk)).tolist())
+    assert len(seen) >= 8 and seen <= known
+    env.close()
