@@ -34,14 +34,23 @@ WORKLOADS = {
     "doorkey8x8": ("MiniGrid-DoorKey-8x8-v0", 262144, "partial"),       # configs[2]
     "lavacrossing_full": ("MiniGrid-LavaCrossingS9N1-v0", 131072, "full"),  # configs[3], per-GPU shard of 1 048 576
     "gotoredball": ("BabyAI-GoToRedBall-v0", 32768, "partial"),         # configs[4], per-GPU shard of 262 144
+    # SURVEY.md §8(f) rank 4 -- what the stock benchmark.py times: RGBImgObsWrapper / RGBImgPartialObsWrapper frames
+    "empty8x8_rgb": ("MiniGrid-Empty-8x8-v0", 65536, "rgb"),            # 64x64x3 frame per env-step (805 MB per step)
+    "doorkey8x8_rgb_partial": ("MiniGrid-DoorKey-8x8-v0", 65536, "rgb_partial"),   # 56x56x3 agent-POV frame
 }
 
 
 def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, view: int = 7) -> int:
     """action 1 + grid read (49 view cells or W*H cells) x 3 B + agent record r/w 8+8 +
     cell write-back 3 + image out + reward 8 + terminated 1 + truncated 1 (+ direction 1 + mission id 1 for BabyAI)."""
-    cells = W * H if obs_mode in ("full", "symbolic") else view * view
+    cells = W * H if obs_mode in ("full", "symbolic", "rgb") else view * view
     out_per_cell = 20 if obs_mode == "onehot" else 3
+    if obs_mode in ("rgb", "rgb_partial"):
+        # k_step reads the view (and, for the full frame, the whole grid) and writes a 1 B/cell tile map; k_render reads
+        # it back (+ the agent record for the full frame) and writes tile_size^2 x 3 bytes per cell (tile_size = 8)
+        read_cells = view * view + (W * H if obs_mode == "rgb" else 0)
+        out_per_cell = 1 + 1 + 8 * 8 * 3
+        return 1 + read_cells * 3 + 8 + 8 + 3 + cells * out_per_cell + (8 if obs_mode == "rgb" else 0) + 8 + 1 + 1
     b = 1 + cells * 3 + 8 + 8 + 3 + cells * out_per_cell + 8 + 1 + 1
     if env_id.startswith("BabyAI"):
         b += 2
@@ -66,13 +75,51 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int):
             if not os.path.exists(f):
                 break
             for line in open(f):
-                m = re.match(rf"{c},void mg::k_step<[^>]*>,calls=\d+,mean=([0-9.]+)", line)
-                if m:
-                    vals[c] = float(m.group(1))
-                    break
+                m = re.match(rf"{c},(?:void )?mg::(k_step<[^>]*>|k_render),calls=\d+,mean=([0-9.]+)", line)
+                if m:                            # RGB workloads: k_step + k_render make one step
+                    vals[c] = vals.get(c, 0.0) + float(m.group(2))
         if len(vals) == 2:
             best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return best
+
+
+def cpu_baseline_rgb(env_id: str, obs_mode: str, budget_s: float = 10.0):
+    """RGB workloads: the oracle's C port steps, oracle/render.py (numpy) draws every frame; one batch per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    from oracle import oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    n_per = 256
+    vecs = [O.OracleVec(env_id, n_per, obs=obs_mode) for _ in range(cores)]
+    for i, v in enumerate(vecs):
+        v.reset(seeds=range(i * n_per, (i + 1) * n_per))
+
+    def work(args):
+        v, T, seed = args
+        rng = np.random.default_rng(seed)
+        for _ in range(T):
+            v.step(rng.integers(0, 7, n_per, dtype=np.uint8))
+
+    def timed(T):
+        with ThreadPoolExecutor(cores) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(work, [(v, T, i) for i, v in enumerate(vecs)]))
+            return time.perf_counter() - t0
+
+    timed(2)
+    T, dt, chunk = 0, 0.0, 20
+    while dt < budget_s and T < 100_000:
+        dt += timed(chunk)
+        T += chunk
+    return {"value": cores * n_per * T / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {n_per} envs x {T} steps of {env_id} ({obs_mode} frames), oracle C port + "
+                      f"numpy tile mosaic (oracle/render.py), random actions, NEXT_STEP autoreset, {dt:.1f}s"}
 
 
 def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
@@ -116,7 +163,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--fused", type=int, default=0, help="use the fused multi-step rollout kernel")
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
-    ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic")
+    ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic|rgb|rgb_partial")
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -210,14 +257,17 @@ def main():
                        "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
                        "launch": "fused-rollout" if args.fused else "one k_step launch per step",
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
-            "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes_per_launch": bpe * n_per_gpu,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(env_id, obs_mode if obs_mode in ("partial", "full") else "partial")
+            if obs_mode.startswith("rgb"):
+                out["cpu_baseline"] = cpu_baseline_rgb(env_id, obs_mode)
+            else:
+                out["cpu_baseline"] = cpu_baseline(env_id, obs_mode if obs_mode in ("partial", "full") else "partial")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -43,7 +43,7 @@ struct mg_env {
   bool goto_kind = false;
   uint8_t* tilemap = nullptr; uint32_t* atlas = nullptr;   // RGB modes: k_step's output / the tile atlas (mg_tiles.h)
   RenderParams render;        // ... and k_render's launch geometry
-  int render_lds = 0, render_blocks = 0;
+  int render_lds = 0, render_blocks = 0, render_threads = 256;
   bool rgb = false;
   uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
   double *reward = nullptr, *reward_lut = nullptr;
@@ -220,7 +220,7 @@ static int launch_step(mg_env* e, const StepParams& P) {
 #undef MG_LAUNCH_STEP
   HIP_TRY(e, hipGetLastError());
   if (e->rgb) {
-    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(RENDER_THREADS), (size_t)e->render_lds, e->stream, e->render);
+    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
   }
   e->launches++;
@@ -251,25 +251,31 @@ static int setup_render(mg_env* e) {
   R.R = R.rowdw % 4 == 0 ? 1 : (R.rowdw % 2 == 0 ? 2 : 4);            // ts % 4 == 0, so R divides ts: a period stays inside one tile row
   R.cpp = R.R * R.rowdw / 4;
   R.ppe = R.Ht * ts / R.R;
-  if (R.cpp > RENDER_THREADS) return fail(e, MG_ERR_INVALID, "frame too wide for k_render");
-  R.t_active = RENDER_THREADS / R.cpp * R.cpp;
-  R.pp = R.t_active / R.cpp;
   // envs per workgroup: as many as keep the LDS footprint (atlas + per-env agent tiles + tile offsets) near 32 KB
-  int epw = 64;
+  int epw = 16;                     // measured best on MI355X together with 8 (profiles/r1_final/render_sweep.txt); tuning aid: MG_RENDER_EPW
   auto lds_for = [&](int n) { return (STATIC_TILES + n) * R.tile_dw * 4 + ((n * R.cells * 2 + 15) & ~15); };
   while (epw > 8 && lds_for(epw) > 40 * 1024) epw >>= 1;
+  if (const char* s = getenv("MG_RENDER_EPW")) { int v = atoi(s); if (v >= 1 && v <= 64 && lds_for(v) <= 160 * 1024) epw = v; }
   R.epw = epw; R.ngroups = (e->N + epw - 1) / epw;
   R.off_map = (STATIC_TILES + epw) * R.tile_dw * 4;
   e->render_lds = lds_for(epw);
   if (e->render_lds > 160 * 1024 || (STATIC_TILES + epw) * R.tile_dw > 65535) return fail(e, MG_ERR_INVALID, "tile atlas too large for the LDS staging");
   R.log2R = R.R == 1 ? 0 : (R.R == 2 ? 1 : 2);
   R.magic_ts = (65536u + (uint32_t)ts - 1u) / (uint32_t)ts;
+  R.magic_tdw = (65536u + (uint32_t)R.tile_dw - 1u) / (uint32_t)R.tile_dw;
+  for (uint32_t t = 0; t < (uint32_t)STATIC_TILES; t++)
+    if (((t * (uint32_t)R.tile_dw * R.magic_tdw) >> 16) != t) return fail(e, MG_ERR_INVALID, "internal: magic_tdw");
   for (uint32_t r = 0; r < (uint32_t)(R.Ht * ts); r++)                  // the multiply-shift division is exact over its whole range
     if (((r * R.magic_ts) >> 16) != r / (uint32_t)ts) return fail(e, MG_ERR_INVALID, "internal: magic_ts");
+  // big tiles (16 px: 84 KB of atlas): one 1024-thread workgroup per CU instead of one 256-thread one
+  e->render_threads = e->render_lds > 40 * 1024 ? RENDER_MAX_THREADS : 256;
+  if (R.cpp > e->render_threads) return fail(e, MG_ERR_INVALID, "frame too wide for k_render");
+  R.t_active = e->render_threads / R.cpp * R.cpp;
+  R.pp = R.t_active / R.cpp;
   int cus = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
-  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(e->render_lds, 1)));
-  e->render_blocks = std::min(R.ngroups, cus * per_cu);
+  const int per_cu = std::max(1, std::min(2048 / e->render_threads, (160 * 1024) / std::max(e->render_lds, 1)));
+  e->render_blocks = std::min(R.ngroups, cus * per_cu);              // persistent: the atlas is staged once per workgroup
   if (const char* s = getenv("MG_RENDER_BLOCKS")) { int v = atoi(s); if (v >= 1) e->render_blocks = std::min(v, R.ngroups); }
 
   // atlas: host-rendered [key][agent][hl] -> device [key][hl] (agent-free) followed by [key][dir][hl]

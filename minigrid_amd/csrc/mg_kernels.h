@@ -745,16 +745,19 @@ __global__ void k_mark_pending(uint64_t* agent, const uint8_t* mask, int N) {
 // frame is a mosaic of pre-rendered tiles (mg_tiles.h).  Input: k_step's tile map (one byte per cell = tile key * 2 +
 // highlight) and, for the full render, the agent record; output: [N][Ht*ts][Wt*ts][3] bytes.
 //
-// HBM-write bound (9-12 KB per env against ~60 B read), so the kernel is organised around the store stream: a
-// workgroup's EPW consecutive frames are ONE contiguous byte range, dealt out as 16 B chunks, thread t taking chunks
-// t, t + T, t + 2T, ... with T a multiple of the chunks per "period" (R pixel rows, R the smallest count whose dwords
-// divide by 4).  A thread's position inside its period -- which tile columns and which dword of the tile row its
-// four dwords come from -- is therefore loop-invariant; per chunk only the period index is decomposed into env /
-// tile row / pixel row, incrementally and with 24-bit multiplies.  Tiles are read from LDS: the 102 agent-free tiles are staged once per
-// workgroup, the one agent tile of each env (cell kind x direction x highlight) once per env.
+// HBM-write bound (9-12 KB written per env against ~60 B read), so the kernel is organised around the store stream:
+//  * A workgroup's EPW consecutive frames are ONE contiguous byte range, dealt out as 16 B chunks, thread t taking
+//    chunks t, t + T, t + 2T, ... with T a multiple of the chunks per "period" (R pixel rows, R the smallest count
+//    whose dwords divide by 4).  A thread's position inside its period -- which tile columns and which dword of the
+//    tile row its four dwords come from -- is therefore loop-invariant; per chunk only the period index is
+//    decomposed into env / tile row / pixel row, incrementally and with 24-bit multiplies.
+//  * Tiles are read from LDS: the 102 agent-free tiles are staged once per workgroup (which then loops over groups
+//    of EPW envs), the one agent tile of each env (cell kind x direction x highlight) once per env.
+// Measured (profiles/r1_final/render_*.txt): the kernel runs at the speed of its own bare store loop; the write order
+// (contiguous per workgroup vs. all workgroups sweeping adjacent frames) made no difference on MI355X.
 // ======================================================================================================
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int RENDER_THREADS = 256;
+constexpr int RENDER_MAX_THREADS = 1024;          // 256 per workgroup while the LDS footprint lets >= 4 workgroups share a CU, else 1024
 constexpr int STATIC_TILES = 2 * TILE_KEYS;          // [key][highlight]
 
 struct RenderParams {
@@ -764,16 +767,16 @@ struct RenderParams {
   uint4* out;
   int N, Wt, Ht, cells, ts, full, epw, ngroups;
   int tile_dw, tdw_row, rowdw, R, cpp, ppe, t_active, pp;      // see above; ppe = periods per env, pp = periods per sweep
-  int log2R; uint32_t magic_ts;                                // R = 1 << log2R; magic_ts = ceil(2^16 / ts)
+  int log2R; uint32_t magic_ts, magic_tdw;                     // R = 1 << log2R; magic_x = ceil(2^16 / x)
   int off_map;                                                 // LDS: [atlas dwords | u16 tile offsets per cell]
 };
 
-__global__ void __launch_bounds__(RENDER_THREADS) k_render(const RenderParams R) {
+__global__ void __launch_bounds__(RENDER_MAX_THREADS) k_render(const RenderParams R) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* satlas = (uint32_t*)smem;
   uint16_t* smap = (uint16_t*)(smem + R.off_map);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < STATIC_TILES * R.tile_dw; i += RENDER_THREADS) satlas[i] = R.atlas_static[i];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = (int)blockDim.x;
+  for (int i = tid; i < STATIC_TILES * R.tile_dw; i += nthreads) satlas[i] = R.atlas_static[i];
 
   // loop-invariant position of this thread's four dwords inside a period
   const bool worker = tid < R.t_active;
@@ -789,30 +792,33 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(const RenderParams R)
 
   for (int g = blockIdx.x; g < R.ngroups; g += gridDim.x) {
     const int env0 = g * R.epw, nv = min(R.epw, R.N - env0);
-    __syncthreads();                                   // the previous group's blit is done with smap / the agent tiles
-    const uint8_t* tm = R.tilemap + (size_t)env0 * R.cells;
-    for (int i = tid; i < nv * R.cells; i += RENDER_THREADS) smap[i] = (uint16_t)((uint32_t)tm[i] * (uint32_t)R.tile_dw);
-    __syncthreads();
-    for (int el = wave; el < nv; el += RENDER_THREADS / 64) {
+    __syncthreads();                                                 // the previous group's blit is done with smap / the agent tiles
+    for (int el = wave; el < nv; el += nthreads >> 6) {
+      const int env = env0 + el;
       // the agent's cell: POV = bottom centre facing up (minigrid_env.py:659-663); full = its position and direction
-      int cell, dir;
+      int cell = (R.Ht - 1) * R.Wt + (R.Wt >> 1), dir = 3;
       if (R.full) {
-        const Agent a = agent_unpack(R.agent[env0 + el]);
+        const Agent a = agent_unpack(R.agent[env]);
         cell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
-      } else { cell = (R.Ht - 1) * R.Wt + (R.Wt >> 1); dir = 3; }
-      const uint32_t b = tm[el * R.cells + cell];
-      const uint32_t* src = R.atlas_agent + (size_t)(((b >> 1) * 4u + (uint32_t)dir) * 2u + (b & 1u)) * R.tile_dw;
+      }
+      const uint8_t* tm = R.tilemap + (size_t)env * R.cells;
+      uint16_t* m = smap + el * R.cells;
+      for (int k = lane; k < R.cells; k += 64) m[k] = (uint16_t)__umul24((uint32_t)tm[k], (uint32_t)R.tile_dw);
+      MG_WAVE_LDS_SYNC();
+      const uint32_t tb = (__umul24((uint32_t)m[cell], R.magic_tdw) >> 16);          // the tile byte under the agent
+      const uint32_t* src = R.atlas_agent + (size_t)(((tb >> 1) * 4u + (uint32_t)dir) * 2u + (tb & 1u)) * R.tile_dw;
       uint32_t* dst = satlas + (STATIC_TILES + el) * R.tile_dw;
       for (int k = lane; k < R.tile_dw; k += 64) dst[k] = src[k];
-      if (lane == 0) smap[el * R.cells + cell] = (uint16_t)((STATIC_TILES + el) * R.tile_dw);
+      MG_WAVE_LDS_SYNC();
+      if (lane == 0) m[cell] = (uint16_t)((STATIC_TILES + el) * R.tile_dw);
     }
     __syncthreads();
     if (worker) {
       // period p = p0, p0 + pp, ...: (env, period inside the env) advance by constant steps with one conditional
       // wrap; the rest is 24-bit multiplies of small numbers (full rate), no division
       u32x4* out = (u32x4*)R.out + (size_t)env0 * img_chunks + (uint32_t)(p0 * R.cpp + cidx);
-      const int total = nv * R.ppe, d_el = R.pp / R.ppe, d_pr = R.pp - d_el * R.ppe;
       const uint32_t ostep = (uint32_t)(R.pp * R.cpp);
+      const int total = nv * R.ppe, d_el = R.pp / R.ppe, d_pr = R.pp - d_el * R.ppe;
       int el = p0 / R.ppe, pr = p0 - el * R.ppe;
       int mb = el * R.cells;
       const int d_mb = d_el * R.cells;
@@ -827,10 +833,10 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(const RenderParams R)
         v.y = satlas[(uint32_t)m[txj[1]] + rowoff + srcj[1]];
         v.z = satlas[(uint32_t)m[txj[2]] + rowoff + srcj[2]];
         v.w = satlas[(uint32_t)m[txj[3]] + rowoff + srcj[3]];
-        __builtin_nontemporal_store(v, out);          // written once, never re-read by this kernel
+        *out = v;
         out += ostep;
-        el += d_el; pr += d_pr; mb += d_mb;
-        if (pr >= R.ppe) { pr -= R.ppe; el++; mb += R.cells; }
+        pr += d_pr; mb += d_mb;
+        if (pr >= R.ppe) { pr -= R.ppe; mb += R.cells; }
       }
     }
   }

@@ -7,7 +7,7 @@ import re
 t = open('/tmp/mg_regstats/dev.s').read()
 for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.wavefront_size', t, re.S):
     n, b = m.group(1), m.group(2)
-    if 'k_step' not in n and 'k_generate' not in n and 'k_move' not in n: continue
+    if not any(k in n for k in ('k_step', 'k_generate', 'k_move', 'k_render')): continue
     g = lambda k: re.search(k + r':\s+(\d+)', b).group(1)
     print(f"{n[:70]:70s} scratch {g('.private_segment_fixed_size'):>4s}  sgpr {g('.sgpr_count'):>3s}  vgpr {g('.vgpr_count'):>3s}  spills {g('.vgpr_spill_count')}")
 PY
