@@ -64,6 +64,10 @@ MISSIONS = {
     "MiniGrid-Memory": ["go to the matching object at the end of the hallway"],
     "MiniGrid-UnlockPickup": [f"pick up the {c} box" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Unlock-": ["open the door"],
+    "MiniGrid-LockedRoom": [f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
+                            for a in ("blue", "green", "grey", "purple", "red", "yellow") for b in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "MiniGrid-Playground": [""],
+    "MiniGrid-MultiRoom": ["traverse the rooms to get to the goal"],
     "MiniGrid-BlockedUnlockPickup": [f"pick up the {c} {t}" for c in ("blue", "green", "grey", "purple", "red", "yellow")
                                      for t in ("box", "key")],
 }
@@ -132,8 +136,37 @@ def find(u, type_, color=None):
     return None
 
 
+def _door_action(u, locked_ok):
+    """Head for / toggle a closed door the BFS can reach (it treats closed doors as walls), or None."""
+    for i in range(u.width):
+        for j in range(u.height):
+            c = u.grid.get(i, j)
+            if c is not None and c.type == "door" and not c.is_open and (locked_ok or not c.is_locked):
+                q = plan_to_face(u, (i, j))
+                if q is not None:
+                    return 5 if q == [] else q[0]
+    return None
+
+
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
+    if env_id.startswith(("MiniGrid-MultiRoom", "MiniGrid-LockedRoom", "MiniGrid-Playground")):
+        goal = find(u, "goal")
+        if goal is not None:
+            p = plan_to_face(u, goal, stand_on=True)
+            if p:
+                return p[0]
+        if env_id.startswith("MiniGrid-LockedRoom"):
+            if u.carrying is not None and u.carrying.type == "key":
+                a = _door_action(u, True)
+                if a is not None:
+                    return a
+            else:
+                key = find(u, "key")
+                p = plan_to_face(u, key) if key is not None else None
+                if p is not None:
+                    return 3 if p == [] else p[0]
+        return _door_action(u, False)
     if env_id.startswith("MiniGrid-DoorKey"):
         door = find(u, "door")
         d = u.grid.get(*door)
@@ -542,6 +575,8 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
             "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0",
             "MiniGrid-GoToObject-6x6-N2-v0", "MiniGrid-GoToObject-8x8-N2-v0",
+            "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0", "MiniGrid-MultiRoom-N2-S4-v0", "MiniGrid-MultiRoom-N4-S5-v0",
+            "MiniGrid-MultiRoom-N4-S5-v1", "MiniGrid-MultiRoom-N6-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",

@@ -19,6 +19,7 @@ K_EMPTY, K_DOORKEY, K_CROSSING, K_GOTO_REDBALL, K_LAVAGAP, K_DISTSHIFT, K_FOURRO
 K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
+K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 T_WALL, T_LAVA = 2, 9
 
 
@@ -112,7 +113,19 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_GOTOOBJECT, width=size, height=size, max_steps=5 * size * size, see_through=1, num_dists=n,
                     missions=[f"go to the {c} {t}" for c in color_names for t in ("key", "ball", "box")])
 
+    def multiroom(lo, hi, max_size):
+        # multiroom.py:79-112: 25x25, max_steps = maxNumRooms * 20; rows minigrid/__init__.py:359-386
+        return dict(kind=K_MULTIROOM, width=25, height=25, max_steps=hi * 20, see_through=0, num_crossings=lo, num_dists=hi,
+                    room_size=max_size, missions=["traverse the rooms to get to the goal"])
+
     table = {
+        # lockedroom.py:82-102: size 19, max_steps = 10*size; playground.py:16-25: 19x19, max_steps 100
+        "MiniGrid-LockedRoom-v0": dict(kind=K_LOCKEDROOM, width=19, height=19, max_steps=190, see_through=0,
+                                       missions=[f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
+                                                 for a in color_names for b in color_names]),
+        "MiniGrid-Playground-v0": dict(kind=K_PLAYGROUND, width=19, height=19, max_steps=100, see_through=0, missions=[""]),
+        "MiniGrid-MultiRoom-N2-S4-v0": multiroom(2, 2, 4), "MiniGrid-MultiRoom-N4-S5-v0": multiroom(6, 6, 5),
+        "MiniGrid-MultiRoom-N4-S5-v1": multiroom(4, 4, 5), "MiniGrid-MultiRoom-N6-v0": multiroom(6, 6, 10),
         "MiniGrid-GoToObject-6x6-N2-v0": gotoobject(6, 2), "MiniGrid-GoToObject-8x8-N2-v0": gotoobject(8, 2),
         # envs/babyai/goto.py: GoToRedBallGrey :63-78, GoToRedBlueBall :657-677, GoToObj :253-260, GoToLocal :329-338;
         # registry rows minigrid/__init__.py:572-679, 750-753
