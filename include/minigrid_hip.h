@@ -68,6 +68,10 @@ typedef enum mg_env_kind {
                                (room_size = width = height in 4..8, num_dists <= 8); GoToObj / GoToLocal mission id =
                                ("a" ? 18 : 0) + COLOR_NAMES index * 3 + (key 0, ball 1, box 2)                     */
   MG_ENV_GOTOOBJECT = 20,   /* envs/gotoobject.py:93-153 (size 4..8, num_dists = numObjs 1..8); mission id = COLOR_NAMES index * 3 + type */
+  MG_ENV_LOCKEDROOM = 21,   /* envs/lockedroom.py:104-176 (19 x 19); mission id = locked room's colour index * 6 + key room's            */
+  MG_ENV_PLAYGROUND = 22,   /* envs/playground.py:31-91 (19 x 19; no goal: episodes only end by truncation)                              */
+  MG_ENV_MULTIROOM = 23,    /* envs/multiroom.py:118-300 (25 x 25): num_crossings = minNumRooms, num_dists = maxNumRooms <= 6,
+                               room_size = maxRoomSize                                                                               */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;

@@ -204,6 +204,7 @@ static int launch_step(mg_env* e, const StepParams& P) {
   do {                                                                                   \
     if (e->gen_group == GG_NONE) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_NONE);               \
     else if (e->gen_group == GG_LIGHT) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_LIGHT);        \
+    else if (e->gen_group == GG_ROOMS) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_ROOMS);        \
     else MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_ROOMGRID);                                   \
   } while (0)
   // instantiated variants (each carries its generator group's code, so the list is kept short): 4 waves per
@@ -333,7 +334,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTOOBJECT) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_MULTIROOM) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if ((cfg->env_kind == MG_ENV_LOCKEDROOM || cfg->env_kind == MG_ENV_PLAYGROUND) && (cfg->width != cfg->height || cfg->width < 13 || cfg->width > 25))
+    return fail(nullptr, MG_ERR_INVALID, "LockedRoom / Playground: square grid of 13..25 cells (the registered size is 19)");
+  if (cfg->env_kind == MG_ENV_MULTIROOM && (cfg->width < 6 || cfg->height < 6 || cfg->width > 25 || cfg->height > 25 || cfg->room_size < 4 || cfg->room_size > 15 ||
+      cfg->num_crossings < 1 || cfg->num_dists < cfg->num_crossings || cfg->num_dists > 6))
+    return fail(nullptr, MG_ERR_INVALID, "MultiRoom: grid up to 25 x 25, maxRoomSize 4..15, 1 <= minNumRooms <= maxNumRooms <= 6 (multiroom.py:89-91)");
   if (cfg->env_kind == MG_ENV_GOTOOBJECT && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 1 || cfg->num_dists > 8))
     return fail(nullptr, MG_ERR_INVALID, "GoToObject: size 4..8, numObjs 1..8");
   if (cfg->env_kind >= MG_ENV_GOTO_REDBALLGREY && cfg->env_kind <= MG_ENV_GOTO_LOCAL && (cfg->width != cfg->height || cfg->width < 4 || cfg->width > 8 || cfg->num_dists < 0 || cfg->num_dists > 8))
@@ -415,7 +421,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // restarts from its checkpoint, so the buffer size is not a correctness limit)
     const int min_lds = e->wpg * gen_wave_lds_bytes(e->CS, 512);
     if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
-    e->gen_cap_words = std::min(2048, (e->lds_bytes / e->wpg - e->CS - GEN_SBASE_BYTES) / 4 - 4) & ~3;
+    e->gen_cap_words = std::min(2048, (e->lds_bytes / e->wpg - e->CS - GEN_SBASE_BYTES - GEN_SCRATCH_BYTES) / 4 - 4) & ~3;
     e->gen_blocks = std::min(1024, e->N);
     e->gen_group = gen_group_of_kind(cfg->env_kind);
     if (const char* s = getenv("MG_GEN_BLOCKS")) { int v = atoi(s); if (v >= 1 && v <= 65536) e->gen_blocks = std::min(v, e->N); }
@@ -496,7 +502,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->lds_bytes > 64 * 1024) {
     const void* fns[] = {
 #define MG_KG(MODE, WPG, VT, GG) (const void*)k_step<MODE, WPG, WavePcg64, VT, GG>, (const void*)k_step<MODE, WPG, WavePhilox, VT, GG>
-#define MG_K(MODE, WPG, VT) MG_KG(MODE, WPG, VT, GG_NONE), MG_KG(MODE, WPG, VT, GG_LIGHT), MG_KG(MODE, WPG, VT, GG_ROOMGRID)
+#define MG_K(MODE, WPG, VT) MG_KG(MODE, WPG, VT, GG_NONE), MG_KG(MODE, WPG, VT, GG_LIGHT), MG_KG(MODE, WPG, VT, GG_ROOMGRID), MG_KG(MODE, WPG, VT, GG_ROOMS)
       MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7), MG_K(4, 4, 7)
 #undef MG_K
 #undef MG_KG

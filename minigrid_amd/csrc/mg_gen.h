@@ -17,6 +17,7 @@ struct GenParams {
   int strip2_row;                    // DistShift
   int room_size;                     // RoomGrid levels
   int random_length;                 // Memory
+  int scratch_off;                   // byte offset from the wave's grid to GEN_SCRATCH_BYTES of LDS that outlive a checkpoint restart
 };
 
 struct GenResult {
@@ -25,6 +26,7 @@ struct GenResult {
                       // order; BabyAI GoTo levels: bitboard (bit y*W+x) of GoToInstr's tracked object positions
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
+  uint32_t resume;    // set by generate_one: this pass restarts from the generator's last checkpoint (state in the wave's scratch words)
 };
 
 // Byte grid owned by one wave, row-major index y*W+x (core/grid.py:28-35,65-78).  get/set take wave-uniform
@@ -39,6 +41,13 @@ struct GridRef {
     const bool edge_x = lane == 0 || lane == W - 1;
     for (int y = 0; y < H; y++)                      // one row per instruction (W <= 25 lanes busy), no division
       if (lane < W) p[y * W + lane] = (uint8_t)((edge_x || y == 0 || y == H - 1) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+  }
+  // Grid(width, height) alone: every cell None (core/grid.py:28-35)
+  MG_D void clear_empty() {
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < H; y++)
+      if (lane < W) p[y * W + lane] = (uint8_t)CELL_EMPTY;
     MG_WAVE_LDS_SYNC();
   }
   // 8x8 grids only (bit index = y*8+x = lane): cells the reachability flood may pass (None or any door), cells
@@ -613,13 +622,192 @@ MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = 0;
 }
 
+// envs/lockedroom.py:104-176 (19x19: six rooms off a central hallway, one locked with the goal inside, the key of its
+// colour in another room).  Mission id = COLOR_NAMES index of the locked room * 6 + COLOR_NAMES index of the key room.
+template <class R>
+MG_D void gen_lockedroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H;
+  g.clear_with_walls();
+  const int lw = W / 2 - 2, rw = W / 2 + 2, third = H / 3;
+  for (int j = 0; j < H; j++) { g.set(lw, j, CELL_WALL_GREY); g.set(rw, j, CELL_WALL_GREY); }
+#pragma unroll 1
+  for (int n = 0; n < 3; n++) {
+    const int j = n * third;
+    for (int i = 0; i < lw; i++) g.set(i, j, CELL_WALL_GREY);
+    for (int i = rw; i < W; i++) g.set(i, j, CELL_WALL_GREY);
+  }
+  // room r = 2n + side: top = (side ? rw : 0, n * third), size (lw + 1, third + 1), door (side ? rw : lw, n * third + 3)
+  const int room_w = lw + 1, room_h = third + 1;
+  const int locked = rand_int(rng, 0, 6);
+  {
+    const int tx = (locked & 1) ? rw : 0, ty = (locked >> 1) * third;
+    const int gx = rand_int(rng, tx + 1, tx + room_w - 1);          // LockedRoom.rand_pos = _rand_pos: x, then y
+    const int gy = rand_int(rng, ty + 1, ty + room_h - 1);
+    g.set(gx, gy, CELL_GOAL);
+  }
+  uint32_t avail = 0x543210u, colors = 0;       // sorted(colors) still unassigned, one nibble each; nibble r = colour of room r
+#pragma unroll 1
+  for (int r = 0, na = 6; r < 6; r++, na--) {
+    const int k = rand_int(rng, 0, na);
+    const uint32_t ci = (avail >> (4 * k)) & 15u;
+    const uint32_t lo = avail & ((1u << (4 * k)) - 1u);
+    avail = lo | ((avail >> (4 * (k + 1))) << (4 * k));
+    colors |= ci << (4 * r);
+    g.set((r & 1) ? rw : lw, (r >> 1) * third + 3, make_cell(r == locked ? (uint32_t)T_DOOR_LOCKED : (uint32_t)T_DOOR_CLOSED, color_from_sorted(ci)));
+  }
+  int key_room = locked;
+  while (key_room == locked && !rng.dead()) key_room = rand_int(rng, 0, 6);
+  const uint32_t lc = (colors >> (4 * locked)) & 15u, kc = (colors >> (4 * key_room)) & 15u;
+  {
+    const int tx = (key_room & 1) ? rw : 0, ty = (key_room >> 1) * third;
+    const int kx = rand_int(rng, tx + 1, tx + room_w - 1);
+    const int ky = rand_int(rng, ty + 1, ty + room_h - 1);
+    g.set(kx, ky, make_cell(T_KEY, color_from_sorted(lc)));
+  }
+  if (!place_agent(rng, g, lw, 0, rw - lw, H, -1, out)) out.failed = true;
+  out.mission = lc * 6u + kc;
+}
+
+// envs/playground.py:31-91: 3x3 rooms, one door per shared wall, 12 random objects; no goal, one (empty) mission
+template <class R>
+MG_D void gen_playground(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H;
+  g.clear_with_walls();
+  const int room_w = W / 3, room_h = H / 3;
+#pragma unroll 1
+  for (int j = 0; j < 3; j++) {
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+      const int xL = i * room_w, yT = j * room_h, xR = xL + room_w, yB = yT + room_h;
+      if (i + 1 < 3) {
+        for (int k = 0; k < room_h; k++) g.set(xR, yT + k, CELL_WALL_GREY);
+        const int py = rand_int(rng, yT + 1, yB - 1);
+        const uint32_t c = (uint32_t)rand_int(rng, 0, 6);
+        g.set(xR, py, make_cell(T_DOOR_CLOSED, color_from_sorted(c)));
+      }
+      if (j + 1 < 3) {
+        for (int k = 0; k < room_w; k++) g.set(xL + k, yB, CELL_WALL_GREY);
+        const int px = rand_int(rng, xL + 1, xR - 1);
+        const uint32_t c = (uint32_t)rand_int(rng, 0, 6);
+        g.set(px, yB, make_cell(T_DOOR_CLOSED, color_from_sorted(c)));
+      }
+    }
+  }
+  if (!place_agent(rng, g, 0, 0, W, H, -1, out)) out.failed = true;
+  int x, y;
+#pragma unroll 1
+  for (int k = 0; k < 12; k++) {
+    const uint32_t t = (uint32_t)rand_int(rng, 0, 3), c = (uint32_t)rand_int(rng, 0, 6);
+    if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + t, color_from_sorted(c)), 0, 0, W, H, (int)out.ax, (int)out.ay, false, -1, x, y)) out.failed = true;
+  }
+  out.mission = 0;
+}
+
+// envs/multiroom.py:118-300 (P.num_crossings = minNumRooms, P.num_dists = maxNumRooms <= 6, P.room_size = maxRoomSize).
+// _placeRoom's recursion is a chain: a placed room makes up to 8 attempts at the next one and stops at the first that
+// fits (a child that was appended always returns True, :293-296); rooms are never removed; the outer loop keeps the
+// longest chain until one has numRooms rooms.  A room is one word: tx | ty << 5 | sx << 10 | sy << 14 | ex << 18 |
+// ey << 23.  The chain being built lives at the start of the (not yet drawn) grid; what has to survive a restart from
+// a checkpoint -- numRooms, the best chain -- in the wave's scratch words: an N6 map can take > 1000 draws, more than one buffer.
+MG_D uint32_t mr_pack(int tx, int ty, int sx, int sy, int ex, int ey) {
+  return (uint32_t)tx | ((uint32_t)ty << 5) | ((uint32_t)sx << 10) | ((uint32_t)sy << 14) | ((uint32_t)ex << 18) | ((uint32_t)ey << 23);
+}
+template <class R>
+MG_D bool mr_try_room(R& rng, const GridRef& g, const GenParams& P, uint32_t* cur, int& n, int wall, int ex, int ey) {
+  const int sx = rand_int(rng, 4, P.room_size + 1), sy = rand_int(rng, 4, P.room_size + 1);
+  int tx, ty;
+  if (n == 0) { tx = ex; ty = ey; }
+  else if (wall == 0) { tx = ex - sx + 1; ty = rand_int(rng, ey - sy + 2, ey); }
+  else if (wall == 1) { tx = rand_int(rng, ex - sx + 2, ex); ty = ey - sy + 1; }
+  else if (wall == 2) { tx = ex; ty = rand_int(rng, ey - sy + 2, ey); }
+  else { tx = rand_int(rng, ex - sx + 2, ex); ty = ey; }
+  if (tx < 0 || ty < 0) return false;
+  if (tx + sx > g.W || ty + sy >= g.H) return false;
+#pragma unroll 1
+  for (int k = 0; k + 1 < n; k++) {                    // roomList[:-1]
+    const uint32_t r = uni32(cur[k]);
+    const int rtx = (int)(r & 31u), rty = (int)((r >> 5) & 31u), rsx = (int)((r >> 10) & 15u), rsy = (int)((r >> 14) & 15u);
+    const bool non_overlap = tx + sx < rtx || rtx + rsx <= tx || ty + sy < rty || rty + rsy <= ty;
+    if (!non_overlap) return false;
+  }
+  cur[n++] = mr_pack(tx, ty, sx, sy, ex, ey);
+  return true;
+}
+template <class R>
+MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W;
+  uint32_t* cur = (uint32_t*)g.p;               // the chain under construction (<= 6 words)
+  uint32_t* st = (uint32_t*)(g.p + P.scratch_off);   // [0] numRooms, [1] rooms in the best chain, [2..7] the best chain
+  int num_rooms, nbest;
+  if (!out.resume) {
+    num_rooms = rand_int(rng, P.num_crossings, P.num_dists + 1);
+    nbest = 0;
+    st[0] = (uint32_t)num_rooms; st[1] = 0u;
+  } else { num_rooms = (int)uni32(st[0]); nbest = (int)uni32(st[1]); }
+  while (nbest < num_rooms && !rng.dead()) {
+    rng.checkpoint();                           // st[] is consistent with the stream position here
+    int n = 0, wall = 2;                        // entryDoorWall of the newest room
+    const int ex = rand_int(rng, 0, W - 2), ey = rand_int(rng, 0, W - 2);
+    if (mr_try_room(rng, g, P, cur, n, wall, ex, ey)) {
+      while (n < num_rooms && !rng.dead()) {
+        const uint32_t r = uni32(cur[n - 1]);
+        const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
+        bool placed = false;
+#pragma unroll 1
+        for (int i = 0; i < 8 && !placed && !rng.dead(); i++) {
+          const int k = rand_int(rng, 0, 3);                       // _rand_elem(sorted({0,1,2,3} - {entryDoorWall}))
+          const int exit_wall = k >= wall ? k + 1 : k, next_entry = (exit_wall + 2) & 3;
+          int dx, dy;
+          if (exit_wall == 0) { dx = tx + sx - 1; dy = ty + rand_int(rng, 1, sy - 1); }
+          else if (exit_wall == 1) { dx = tx + rand_int(rng, 1, sx - 1); dy = ty + sy - 1; }
+          else if (exit_wall == 2) { dx = tx; dy = ty + rand_int(rng, 1, sy - 1); }
+          else { dx = tx + rand_int(rng, 1, sx - 1); dy = ty; }
+          if (mr_try_room(rng, g, P, cur, n, next_entry, dx, dy)) { placed = true; wall = next_entry; }
+        }
+        if (!placed) break;
+      }
+    }
+    if (rng.dead()) return;                     // out of buffered draws inside this attempt: restart it from the checkpoint
+    if (n > nbest) {
+#pragma unroll 1
+      for (int k = 0; k < n; k++) st[2 + k] = uni32(cur[k]);
+      nbest = n; st[1] = (uint32_t)n;
+    }
+  }
+  if (rng.dead()) return;
+  rng.checkpoint();                             // the chain is final: from here on only the drawing below is replayed
+  g.clear_empty();
+  uint32_t prev = 6u;                           // COLOR_NAMES index of the previous door, 6 = none yet
+#pragma unroll 1
+  for (int idx = 0; idx < nbest; idx++) {
+    const uint32_t r = uni32(st[2 + idx]);
+    const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
+    for (int i = 0; i < sx; i++) { g.set(tx + i, ty, CELL_WALL_GREY); g.set(tx + i, ty + sy - 1, CELL_WALL_GREY); }
+    for (int j = 0; j < sy; j++) { g.set(tx, ty + j, CELL_WALL_GREY); g.set(tx + sx - 1, ty + j, CELL_WALL_GREY); }
+    if (idx > 0) {
+      const uint32_t k = (uint32_t)rand_int(rng, 0, prev < 6u ? 5 : 6);        // sorted(COLOR_NAMES - {prevDoorColor})
+      const uint32_t c = (prev < 6u && k >= prev) ? k + 1u : k;
+      g.set((int)((r >> 18) & 31u), (int)((r >> 23) & 31u), make_cell(T_DOOR_CLOSED, color_from_sorted(c)));
+      prev = c;
+    }
+  }
+  const uint32_t r0 = uni32(st[2]), rl = uni32(st[2 + nbest - 1]);
+  if (!place_agent(rng, g, (int)(r0 & 31u), (int)((r0 >> 5) & 31u), (int)((r0 >> 10) & 15u), (int)((r0 >> 14) & 15u), -1, out)) out.failed = true;
+  int x, y;
+  if (!place_obj(rng, g, CELL_GOAL, (int)(rl & 31u), (int)((rl >> 5) & 31u), (int)((rl >> 10) & 15u), (int)((rl >> 14) & 15u),
+                 (int)out.ax, (int)out.ay, false, -1, x, y)) out.failed = true;
+  out.mission = 0;
+}
+
+
 // Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
 //   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
 //   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject (needs the aux word)
-enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ALL = 3 };
-MG_HD int gen_group_of_kind(int kind) { return (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+//   GG_ROOMS the 19x19 / 25x25 multi-room maps without a step rule: LockedRoom, Playground, MultiRoom
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 23) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -648,6 +836,14 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 11: gen_unlock_family(rng, g, P, out, 2); return;
       case 14: gen_keycorridor(rng, g, P, out); return;
       case 20: gen_gotoobject(rng, g, P, out); return;
+      default: break;
+    }
+  }
+  if constexpr (GG == GG_ROOMS || GG == GG_ALL) {
+    switch (P.kind) {
+      case 21: gen_lockedroom(rng, g, P, out); return;
+      case 22: gen_playground(rng, g, P, out); return;
+      case 23: gen_multiroom(rng, g, P, out); return;
       default: break;
     }
   }

@@ -117,7 +117,8 @@ constexpr uint32_t STAT_GEN_SLOTS = 4096;
 MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4]; }
 
 constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
-MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4; }
+constexpr int GEN_SCRATCH_BYTES = 64;   // generator state that must survive a restart from a checkpoint (MultiRoom's room lists), at the end
+MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4 + GEN_SCRATCH_BYTES; }
 
 // wave-cooperative: all 64 lanes of one wave call this with the same `e`; `lds` = gen_wave_lds_bytes() of LDS
 template <int GG, class RNG>
@@ -140,6 +141,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
   const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
   const uint32_t budget0 = A.gp.kind == 3 ? ((384u + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords : RNG::kRefillWords;
   uint32_t budget = budget0, retries_before = 0;
+  out.resume = 0;
   for (;;) {
     budget = min(budget, cap);
     while (rng.limit < rng.off + budget) rng.refill();
@@ -149,15 +151,16 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70, i.e.
     // 256 B/lane of scratch on every wave of a k_step launch under its register budget.
     GenParams gp = A.gp;
+    gp.scratch_off = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
     asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
-    asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length));
+    asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length), "+s"(gp.scratch_off));
     g.W = gp.W; g.H = gp.H;
     asm volatile("" : "+v"(g.p), "+v"(g.lane));
     generate_episode<GG>(rng, g, gp, out);
     MG_STAMP(4);
     out.retries += retries_before;
     if (!rng.dead()) break;
-    if (rng.ck != 0) { retries_before = out.retries; rng.rebase_to_checkpoint(); budget = budget0; continue; }
+    if (rng.ck != 0) { retries_before = out.retries; rng.rebase_to_checkpoint(); budget = budget0; out.resume = 1; continue; }
     if (budget >= cap) { out.failed = true; break; }
     budget *= 2u;
   }
@@ -172,7 +175,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
     ag.flags = (A.live && A.queue) ? FLAG_FRESH : 0u;
     A.dst_agent[e] = agent_pack(ag);
-    if constexpr (GG != GG_LIGHT) { if (A.dst_aux) A.dst_aux[e] = out.aux; }     // no GG_LIGHT level has an auxiliary word
+    if constexpr (GG != GG_LIGHT && GG != GG_ROOMS) { if (A.dst_aux) A.dst_aux[e] = out.aux; }     // no GG_LIGHT / GG_ROOMS level has an auxiliary word
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave

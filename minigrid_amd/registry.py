@@ -16,6 +16,7 @@ ENV_EMPTY, ENV_DOORKEY, ENV_CROSSING, ENV_GOTO_REDBALL, ENV_LAVAGAP, ENV_DISTSHI
 ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEMORY, ENV_KEYCORRIDOR = 9, 10, 11, 12, 13, 14
 ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
+ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -125,6 +126,15 @@ def _gotoobject(id_, size, n):
                    entry_point="minigrid.envs:GoToObjectEnv", kwargs={"size": size, "numObjs": n})
 
 
+def _multiroom(id_, lo, hi, max_size=10):
+    # envs/multiroom.py:79-112: 25x25, max_steps = maxNumRooms * 20; rows minigrid/__init__.py:359-386
+    kw = {"minNumRooms": lo, "maxNumRooms": hi}
+    if max_size != 10:
+        kw["maxRoomSize"] = max_size
+    return EnvSpec(id_, ENV_MULTIROOM, 25, 25, hi * 20, False, ("traverse the rooms to get to the goal",),
+                   num_crossings=lo, num_dists=hi, room_size=max_size, entry_point="minigrid.envs:MultiRoomEnv", kwargs=kw)
+
+
 _GOTO_OBJ_MISSIONS = tuple(f"go to {a} {c} {t}" for a in ("the", "a") for c in _COLOR_NAMES for t in ("key", "ball", "box"))
 
 
@@ -152,6 +162,14 @@ _ROWS = [
     EnvSpec("MiniGrid-FourRooms-v0", ENV_FOURROOMS, 19, 19, 100, False, ("reach the goal",),
             entry_point="minigrid.envs:FourRoomsEnv"),
     _fetch("MiniGrid-Fetch-5x5-N2-v0", 5, 2), _fetch("MiniGrid-Fetch-6x6-N2-v0", 6, 2), _fetch("MiniGrid-Fetch-8x8-N3-v0", 8, 3),
+    # envs/lockedroom.py:82-102 (size 19, max_steps = 10 * size); row minigrid/__init__.py:312-319
+    EnvSpec("MiniGrid-LockedRoom-v0", ENV_LOCKEDROOM, 19, 19, 190, False,
+            tuple(f"get the {a} key from the {b} room, unlock the {a} door and go to the goal" for a in _COLOR_NAMES for b in _COLOR_NAMES),
+            entry_point="minigrid.envs:LockedRoomEnv", kwargs={}),
+    # envs/playground.py:16-29 (19x19, max_steps 100, the mission is the empty string); row minigrid/__init__.py:516-523
+    EnvSpec("MiniGrid-Playground-v0", ENV_PLAYGROUND, 19, 19, 100, False, ("",), entry_point="minigrid.envs:PlaygroundEnv", kwargs={}),
+    _multiroom("MiniGrid-MultiRoom-N2-S4-v0", 2, 2, 4), _multiroom("MiniGrid-MultiRoom-N4-S5-v0", 6, 6, 5),
+    _multiroom("MiniGrid-MultiRoom-N4-S5-v1", 4, 4, 5), _multiroom("MiniGrid-MultiRoom-N6-v0", 6, 6),
     _gotoobject("MiniGrid-GoToObject-6x6-N2-v0", 6, 2), _gotoobject("MiniGrid-GoToObject-8x8-N2-v0", 8, 2),
     _gotodoor("MiniGrid-GoToDoor-5x5-v0", 5), _gotodoor("MiniGrid-GoToDoor-6x6-v0", 6), _gotodoor("MiniGrid-GoToDoor-8x8-v0", 8),
     # unlock.py:52-70 (room_size 6, max_steps 8*36), unlockpickup.py:57-80, blockedunlockpickup.py:65-88 (16*36);

@@ -5,7 +5,7 @@ Everything is bit-exact (u8 obs, f64 reward compared by bytes, flags)."""
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, WIDE_IDS, golden
+from conftest import ALL_IDS, MAIN_IDS, WIDE_IDS, full_obs_supported, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,10 @@ def test_generators_match_reference_goldens(env_id):
 @pytest.mark.parametrize("mode", ["random", "solver"])
 @pytest.mark.parametrize("full", [False, True])
 def test_rollouts_match_reference_goldens(env_id, mode, full):
+    if full and not full_obs_supported(env_id):
+        with pytest.raises(Exception, match="too large for the LDS staging"):
+            _mk(env_id, 4, obs_mode="full")
+        return
     g = golden(f"rollout_{env_id}.npz")
     acts = g[f"{mode}_actions"]
     S, T = acts.shape
@@ -104,6 +108,8 @@ def test_vs_oracle_4096_envs_multi_episode(env_id, full):
 @pytest.mark.parametrize("env_id", WIDE_IDS)
 @pytest.mark.parametrize("full", [False, True])
 def test_vs_oracle_widened_ids_2048_envs_multi_episode(env_id, full):
+    if full and not full_obs_supported(env_id):
+        pytest.skip("FullyObs of a 25 x 25 grid exceeds the LDS staging (documented limit)")
     from oracle import oracle as O
     ms = O.spec(env_id)["max_steps"]
     T = max(260, ms + 20) if ms <= 600 else 300          # run past max_steps where that is affordable
