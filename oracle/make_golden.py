@@ -64,6 +64,11 @@ MISSIONS = {
     "MiniGrid-Memory": ["go to the matching object at the end of the hallway"],
     "MiniGrid-UnlockPickup": [f"pick up the {c} box" for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Unlock-": ["open the door"],
+    "BabyAI-PickupDist": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                          for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
+    "BabyAI-OneRoom": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                       for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
+    "BabyAI-OpenRedDoor": ["open the red door"],
     "MiniGrid-LockedRoom": [f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
                             for a in ("blue", "green", "grey", "purple", "red", "yellow") for b in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Playground": [""],
@@ -176,6 +181,28 @@ def solver_action(env_id, u):
         if not d.is_open:
             p = plan_to_face(u, door)
             return 5 if p == [] else (p[0] if p else None)
+    if env_id.startswith(("BabyAI-PickupDist", "BabyAI-OneRoom")):
+        d = u.instrs.desc
+        if u.carrying is not None:             # holding a wrong object (non-strict level): put it down again
+            return 4 if u.grid.get(*u.front_pos) is None else 0
+        wrong_first = u.step_count < 6 and (u.step_count + u.agent_pos[0]) % 5 == 0     # now and then grab something else
+        best = None
+        for i in range(u.width):
+            for j in range(u.height):
+                c = u.grid.get(i, j)
+                if c is None or c.type not in ("key", "ball", "box"):
+                    continue
+                ok = (d.type is None or c.type == d.type) and (d.color is None or c.color == d.color)
+                if ok != wrong_first:
+                    p = plan_to_face(u, (i, j))
+                    if p is not None and (best is None or len(p) < len(best)):
+                        best = p
+        if best is None:
+            return None
+        return 3 if best == [] else best[0]
+    if env_id.startswith("BabyAI-OpenRedDoor"):
+        p = plan_to_face(u, find(u, "door"))
+        return 5 if p == [] else (p[0] if p else None)
     if env_id.startswith("BabyAI-GoTo"):
         d = u.instrs.desc
         tgt = find(u, d.type, d.color)
@@ -443,7 +470,8 @@ def make_nodeath_goldens(env_id, seeds, T, death_cost=-1.0):
 
 # ---- stepping PAST termination (what DISABLED autoreset exposes): BabyAI's GoToInstr tracks object POSITIONS that go
 #      stale while a tracked object is carried (verifier.py:105-171, roomgrid_level.py:87-104) ----
-NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0"]
+NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0", "BabyAI-PickupDist-v0",
+               "BabyAI-PickupDistDebug-v0", "BabyAI-OpenRedDoor-v0"]
 
 
 def make_noreset_goldens(env_id, seeds, T):
@@ -577,6 +605,8 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-GoToObject-6x6-N2-v0", "MiniGrid-GoToObject-8x8-N2-v0",
             "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0", "MiniGrid-MultiRoom-N2-S4-v0", "MiniGrid-MultiRoom-N4-S5-v0",
             "MiniGrid-MultiRoom-N4-S5-v1", "MiniGrid-MultiRoom-N6-v0",
+            "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OneRoomS8-v0", "BabyAI-OneRoomS12-v0",
+            "BabyAI-OneRoomS16-v0", "BabyAI-OneRoomS20-v0", "BabyAI-OpenRedDoor-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",

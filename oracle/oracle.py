@@ -20,6 +20,7 @@ K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEY
 K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
+K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG = 24, 25, 26, 27
 T_WALL, T_LAVA = 2, 9
 
 
@@ -118,7 +119,22 @@ def spec(env_id: str) -> dict:
         return dict(kind=K_MULTIROOM, width=25, height=25, max_steps=hi * 20, see_through=0, num_crossings=lo, num_dists=hi,
                     room_size=max_size, missions=["traverse the rooms to get to the goal"])
 
+    # "pick up " + ObjDesc.surface (verifier.py:73-103): article x (no colour | colour) x ("object" | type)
+    pickup_missions = ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                       for c in [""] + color_names for t in ("object", "key", "ball", "box")]
+
+    def babyai_pickup(kind, room_size):
+        # pickup.py:272-274 (PickupDist: room_size 7), other.py:326-327 (OneRoomS8 and room_size 12/16/20)
+        return dict(kind=kind, width=room_size, height=room_size, max_steps=room_size * room_size, see_through=0,
+                    room_size=room_size, missions=pickup_missions)
+
     table = {
+        "BabyAI-PickupDist-v0": babyai_pickup(K_PICKUPDIST, 7), "BabyAI-PickupDistDebug-v0": babyai_pickup(K_PICKUPDIST_DEBUG, 7),
+        "BabyAI-OneRoomS8-v0": babyai_pickup(K_ONEROOM, 8), "BabyAI-OneRoomS12-v0": babyai_pickup(K_ONEROOM, 12),
+        "BabyAI-OneRoomS16-v0": babyai_pickup(K_ONEROOM, 16), "BabyAI-OneRoomS20-v0": babyai_pickup(K_ONEROOM, 20),
+        # open.py:140-146: 1 x 2 rooms of size 5 -> 9 x 5 grid, max_steps = 1 * 25 * 2
+        "BabyAI-OpenRedDoor-v0": dict(kind=K_OPENREDDOOR, width=9, height=5, max_steps=50, see_through=0, room_size=5,
+                                      missions=["open the red door"]),
         # lockedroom.py:82-102: size 19, max_steps = 10*size; playground.py:16-25: 19x19, max_steps 100
         "MiniGrid-LockedRoom-v0": dict(kind=K_LOCKEDROOM, width=19, height=19, max_steps=190, see_through=0,
                                        missions=[f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"

@@ -201,7 +201,8 @@ def test_oracle_nodeath_matches_reference(env_id):
     assert (agent[:, :7] == g["agent"][:, -1, :7]).all()
 
 
-NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0"]
+NORESET_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToObjS4-v0", "BabyAI-PickupDist-v0",
+               "BabyAI-PickupDistDebug-v0", "BabyAI-OpenRedDoor-v0"]
 
 
 @pytest.mark.parametrize("env_id", NORESET_IDS)
