@@ -72,6 +72,11 @@ typedef enum mg_env_kind {
   MG_ENV_PLAYGROUND = 22,   /* envs/playground.py:31-91 (19 x 19; no goal: episodes only end by truncation)                              */
   MG_ENV_MULTIROOM = 23,    /* envs/multiroom.py:118-300 (25 x 25): num_crossings = minNumRooms, num_dists = maxNumRooms <= 6,
                                room_size = maxRoomSize                                                                               */
+  MG_ENV_PICKUPDIST = 24,   /* envs/babyai/pickup.py:215-290 (one 7x7 room, 5 distractors, PickupInstr); mission id = article * 28 +
+                               (no colour 0 | COLOR_NAMES index + 1) * 4 + ("object" 0 | key 1 | ball 2 | box 3)                 */
+  MG_ENV_ONEROOM = 25,      /* envs/babyai/other.py:275-332 (OneRoomS8/S12/S16/S20: width = height = room_size)                   */
+  MG_ENV_OPENREDDOOR = 26,  /* envs/babyai/open.py:89-146 (1 x 2 rooms, room_size 5, OpenInstr)                                   */
+  MG_ENV_PICKUPDIST_DEBUG = 27, /* PickupDist(debug=True): strict PickupInstr, a wrong pickup ends the episode (verifier.py:356-359) */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;

@@ -622,6 +622,76 @@ MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   out.mission = 0;
 }
 
+// BabyAI levels with a single ActionInstr on small RoomGrids and no check_objs_reachable in their gen_mission:
+// PickupDist / PickupDistDebug (envs/babyai/pickup.py:276-290: 7x7 room, add_distractors(5, all_unique) then
+// place_agent(0, 0)), OneRoomS8..S20 (other.py:329-332: add_object(0, 0, "ball") then place_agent()).
+// Mission id of "pick up " + ObjDesc.surface (verifier.py:73-103): article ("the" 0 | "a" 1) * 28 +
+// (no colour 0 | COLOR_NAMES index + 1) * 4 + ("object" 0 | key 1 | ball 2 | box 3).
+enum : int { KIND_PICKUPDIST = 24, KIND_ONEROOM = 25, KIND_OPENREDDOOR = 26, KIND_PICKUPDIST_DEBUG = 27 };
+template <class R>
+MG_D void gen_pickup_level(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H, mid = W / 2;      // 1x1 RoomGrid: the provisional agent_pos reject_next_to sees (roomgrid.py:174-179)
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();                           // a RecursionError regenerates from the current stream position
+    g.clear_with_walls();
+    uint32_t dcol = 0, dtyp = 0, used = 0;      // nibble k = colour / type index of object k; bit colour * 3 + type
+    int n = 0, x, y;
+    bool ok = true;
+    if (P.kind == KIND_ONEROOM) {
+      dcol = (uint32_t)rand_int(rng, 0, 6); dtyp = 1u; n = 1;       // add_object(kind="ball"): _rand_color(), then place_in_room
+      ok = place_obj(rng, g, make_cell(T_BALL, color_from_sorted(dcol)), 0, 0, W, H, mid, mid, true, 1000, x, y);
+    } else {
+      while (n < 5 && ok && !rng.dead()) {                           // add_distractors (roomgrid.py:396-438)
+        const uint32_t ci = (uint32_t)rand_int(rng, 0, 6), ti = (uint32_t)rand_int(rng, 0, 3), id = ci * 3u + ti;
+        if ((used >> id) & 1u) continue;
+        ok = place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), 0, 0, W, H, mid, mid, true, 1000, x, y);
+        used |= 1u << id; dcol |= ci << (4 * n); dtyp |= ti << (4 * n); n++;
+      }
+    }
+    if (!ok) continue;
+    if (!rg_place_agent(rng, g, 0, 0, W, out)) continue;
+    uint32_t ci = 0, ti = 2;                                          // OneRoom: ObjDesc("ball")
+    if (P.kind != KIND_ONEROOM) {
+      const int k = rand_int(rng, 0, n);
+      const int sel = rand_int(rng, 0, 3);                            // _rand_elem(["type", "color", "both"])
+      ci = sel == 0 ? 0u : ((dcol >> (4 * k)) & 15u) + 1u;
+      ti = sel == 1 ? 0u : ((dtyp >> (4 * k)) & 15u) + 1u;
+    }
+    uint32_t matches = 0;
+    for (int k = 0; k < n; k++)
+      matches += (ci == 0u || ((dcol >> (4 * k)) & 15u) == ci - 1u) && (ti == 0u || ((dtyp >> (4 * k)) & 15u) == ti - 1u) ? 1u : 0u;
+    if (ti == 0u && ci == 3u) matches += 2u;    // "grey" without a type also matches every wall (verifier.py:139-146)
+    out.mission = (matches > 1u ? 28u : 0u) + ci * 4u + ti;
+    (void)H;
+    return;
+  }
+  out.failed = true;
+}
+// envs/babyai/open.py:143-146 (OpenRedDoor: 1 x 2 rooms of size 5; add_door(0, 0, 0, "red", locked=False); place_agent(0, 0))
+template <class R>
+MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int rs = P.room_size, W = g.W, H = g.H;
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < H; y++)
+      if (g.lane < W) {
+        const bool wall = y == 0 || y == H - 1 || (g.lane % (rs - 1)) == 0;
+        g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
+      }
+    MG_WAVE_LDS_SYNC();
+    const int door_y = rand_int(rng, 1, rs - 1);                      // room (0,0).door_pos[0] (roomgrid.py:158-163)
+    g.set(rs - 1, door_y, make_cell(T_DOOR_CLOSED, C_RED));
+    if (!rg_place_agent(rng, g, 0, 0, rs, out)) continue;
+    out.mission = 0;
+    return;
+  }
+  out.failed = true;
+}
+
+
 // envs/lockedroom.py:104-176 (19x19: six rooms off a central hallway, one locked with the goal inside, the key of its
 // colour in another room).  Mission id = COLOR_NAMES index of the locked room * 6 + COLOR_NAMES index of the key room.
 template <class R>
@@ -805,9 +875,10 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
 //   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
 //   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject (needs the aux word)
-//   GG_ROOMS the 19x19 / 25x25 multi-room maps without a step rule: LockedRoom, Playground, MultiRoom
+//   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
+//            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 23) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 27) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -844,6 +915,8 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 21: gen_lockedroom(rng, g, P, out); return;
       case 22: gen_playground(rng, g, P, out); return;
       case 23: gen_multiroom(rng, g, P, out); return;
+      case 24: case 25: case 27: gen_pickup_level(rng, g, P, out); return;
+      case 26: gen_openreddoor(rng, g, P, out); return;
       default: break;
     }
   }

@@ -29,7 +29,8 @@ constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
-              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9 };
+              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
+              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11 };
 
 struct StepParams {
   // state
@@ -418,6 +419,22 @@ k_step(const StepParams P, const GenArgs A) {
         // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
         const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
         if (a.carry == target) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
+        // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
+        // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
+        // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
+        // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
+        const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
+        const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
+                           (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
+        if (newF != F && match) { term = 1; success = true; }
+        else if (P.rule_div == 2) term = 1;
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
+        // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
+        // and it is open after the toggle
+        if (inb && cell_type(newF) == T_DOOR) { term = 1; success = true; }
       }
       if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
         // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.

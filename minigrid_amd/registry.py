@@ -17,6 +17,7 @@ ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEM
 ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
+ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG = 24, 25, 26, 27
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -145,6 +146,18 @@ def _babyai_goto(id_, kind, room_size, num_dists, missions, cls, kwargs=None):
                    entry_point=f"minigrid.envs.babyai:{cls}", kwargs=kwargs or {})
 
 
+# "pick up " + ObjDesc.surface (envs/babyai/core/verifier.py:73-103): article x (no colour | colour) x ("object" | type)
+_PICKUP_MISSIONS = tuple("pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                         for c in ("",) + _COLOR_NAMES for t in ("object", "key", "ball", "box"))
+
+
+def _babyai_pickup(id_, kind, room_size, cls, kwargs=None):
+    # one-room RoomGridLevel with a PickupInstr: max_steps = room_size**2 (roomgrid_level.py:71-85);
+    # rows minigrid/__init__.py:865-873, 1060-1080
+    return EnvSpec(id_, kind, room_size, room_size, room_size * room_size, False, _PICKUP_MISSIONS, room_size=room_size,
+                   entry_point=f"minigrid.envs.babyai:{cls}", kwargs=kwargs or {})
+
+
 _ROWS = [
     _empty("MiniGrid-Empty-5x5-v0", 5), _empty("MiniGrid-Empty-Random-5x5-v0", 5, True),
     _empty("MiniGrid-Empty-6x6-v0", 6), _empty("MiniGrid-Empty-Random-6x6-v0", 6, True),
@@ -189,6 +202,13 @@ _ROWS = [
               tuple(f"pick up the {c} ball" for c in _COLOR_NAMES), room_size=rs, entry_point="minigrid.envs:KeyCorridorEnv",
               kwargs={"room_size": rs, "num_rows": rows})
       for rs, rows in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))],
+    _babyai_pickup("BabyAI-PickupDist-v0", ENV_PICKUPDIST, 7, "PickupDist"),
+    _babyai_pickup("BabyAI-PickupDistDebug-v0", ENV_PICKUPDIST_DEBUG, 7, "PickupDist", {"debug": True}),
+    _babyai_pickup("BabyAI-OneRoomS8-v0", ENV_ONEROOM, 8, "OneRoomS8"),
+    *[_babyai_pickup(f"BabyAI-OneRoomS{s_}-v0", ENV_ONEROOM, s_, "OneRoomS8", {"room_size": s_}) for s_ in (12, 16, 20)],
+    # envs/babyai/open.py:140-146: 1 x 2 rooms of size 5, max_steps = 1 * 25 * 2; row minigrid/__init__.py:773-776
+    EnvSpec("BabyAI-OpenRedDoor-v0", ENV_OPENREDDOOR, 9, 5, 50, False, ("open the red door",), room_size=5,
+            entry_point="minigrid.envs.babyai:OpenRedDoor", kwargs={}),
     _babyai_goto("BabyAI-GoToRedBallGrey-v0", ENV_GOTO_REDBALLGREY, 8, 7, ("go to the red ball", "go to a red ball"), "GoToRedBallGrey"),
     _babyai_goto("BabyAI-GoToRedBlueBall-v0", ENV_GOTO_REDBLUEBALL, 8, 7, ("go to the red ball", "go to the blue ball"), "GoToRedBlueBall"),
     _babyai_goto("BabyAI-GoToObj-v0", ENV_GOTO_OBJ, 8, 1, _GOTO_OBJ_MISSIONS, "GoToObj"),
