@@ -668,6 +668,77 @@ MG_D void gen_pickup_level(R& rng, GridRef& g, const GenParams& P, GenResult& ou
   }
   out.failed = true;
 }
+// envs/babyai/other.py:169-177 (FindObjS5/S6/S7) on RoomGrid._gen_grid / add_object / place_agent / connect_all
+// (core/roomgrid.py:123-394) for 3 x 3 rooms: a random object in a random room, the agent in the middle room, doors added
+// at random until every room is reachable; PickupInstr(ObjDesc(obj.type)) -> mission "pick up the <type>".
+// Room bookkeeping: the door offsets inside the room (1 .. rs-2: a nibble each; S7's absolute coordinates reach 17) and
+// one bit per (room, wall) for Room.doors.
+template <class R>
+MG_D void gen_findobj(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();                           // a RecursionError regenerates from the current stream position
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < H; y++)
+      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+    uint64_t right_y = 0, down_x = 0, doors = 0;
+#pragma unroll 1
+    for (int j = 0; j < 3; j++)
+#pragma unroll 1
+      for (int i = 0; i < 3; i++) {
+        const int r = j * 3 + i, tx = i * st, ty = j * st;
+        if (i < 2) right_y |= (uint64_t)(rand_int(rng, ty + 1, ty + rs - 1) - ty) << (4 * r);
+        if (j < 2) down_x |= (uint64_t)(rand_int(rng, tx + 1, tx + rs - 1) - tx) << (4 * r);
+      }
+    const int mid = st + rs / 2;                // provisional agent_pos = middle of the middle room (roomgrid.py:174-179)
+    const int oi = rand_int(rng, 0, 3), oj = rand_int(rng, 0, 3);                 // get_room(i, j): i is the column
+    const uint32_t ti = (uint32_t)rand_int(rng, 0, 3), ci = (uint32_t)rand_int(rng, 0, 6);      // add_object: kind, then colour
+    int x, y;
+    if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), oi * st, oj * st, rs, rs, mid, mid, true, 1000, x, y)) continue;
+    if (!rg_place_agent(rng, g, st, st, rs, out)) continue;
+    // connect_all (roomgrid.py:336-394)
+    const int start = ((int)out.ay / st) * 3 + (int)out.ax / st;
+    bool fail = false;
+    for (int itr = 0; !rng.dead(); itr++) {
+      if (itr > 5000) { fail = true; break; }
+      uint32_t reach = 1u << start;
+      for (;;) {
+        uint32_t next = reach;
+#pragma unroll 1
+        for (int r = 0; r < 9; r++)
+          if ((reach >> r) & 1u) {
+            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
+            if (d & 1u) next |= 1u << (r + 1);
+            if (d & 2u) next |= 1u << (r + 3);
+            if (d & 4u) next |= 1u << (r - 1);
+            if (d & 8u) next |= 1u << (r - 3);
+          }
+        if (next == reach) break;
+        reach = next;
+      }
+      if (reach == 0x1FFu) break;
+      const int i = rand_int(rng, 0, 3), j = rand_int(rng, 0, 3), k = rand_int(rng, 0, 4);
+      const bool has_nb = k == 0 ? i < 2 : k == 1 ? j < 2 : k == 2 ? i > 0 : j > 0;
+      const int r = j * 3 + i;
+      if (!has_nb || ((doors >> (r * 4 + k)) & 1ull)) continue;
+      const uint32_t dc = (uint32_t)rand_int(rng, 0, 6);
+      // Room.door_pos[k] (roomgrid.py:158-171): the left / up door is the neighbour's right / down door
+      const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * 3 + ri;
+      const bool vertical_wall = k == 0 || k == 2;
+      const int dx = vertical_wall ? ri * st + st : ri * st + (int)((down_x >> (4 * rr)) & 15u);
+      const int dy = vertical_wall ? rj * st + (int)((right_y >> (4 * rr)) & 15u) : rj * st + st;
+      g.set(dx, dy, make_cell(T_DOOR_CLOSED, color_from_sorted(dc)));
+      const int nr = r + (k == 0 ? 1 : k == 1 ? 3 : k == 2 ? -1 : -3);
+      doors |= (1ull << (r * 4 + k)) | (1ull << (nr * 4 + ((k + 2) & 3)));
+    }
+    if (fail) continue;
+    out.mission = ti + 1u;                      // "pick up the key / ball / box"
+    return;
+  }
+  out.failed = true;
+}
 // envs/babyai/open.py:143-146 (OpenRedDoor: 1 x 2 rooms of size 5; add_door(0, 0, 0, "red", locked=False); place_agent(0, 0))
 template <class R>
 MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -878,7 +949,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 27) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 28) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -917,6 +988,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 23: gen_multiroom(rng, g, P, out); return;
       case 24: case 25: case 27: gen_pickup_level(rng, g, P, out); return;
       case 26: gen_openreddoor(rng, g, P, out); return;
+      case 28: gen_findobj(rng, g, P, out); return;
       default: break;
     }
   }

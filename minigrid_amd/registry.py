@@ -17,7 +17,7 @@ ENV_UNLOCK, ENV_UNLOCKPICKUP, ENV_BLOCKEDUNLOCKPICKUP, ENV_REDBLUEDOORS, ENV_MEM
 ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
-ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG = 24, 25, 26, 27
+ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -206,6 +206,10 @@ _ROWS = [
     _babyai_pickup("BabyAI-PickupDistDebug-v0", ENV_PICKUPDIST_DEBUG, 7, "PickupDist", {"debug": True}),
     _babyai_pickup("BabyAI-OneRoomS8-v0", ENV_ONEROOM, 8, "OneRoomS8"),
     *[_babyai_pickup(f"BabyAI-OneRoomS{s_}-v0", ENV_ONEROOM, s_, "OneRoomS8", {"room_size": s_}) for s_ in (12, 16, 20)],
+    # envs/babyai/other.py:163-177: 3 x 3 rooms, max_steps = 20 * room_size**2; rows minigrid/__init__.py:1001-1016
+    *[EnvSpec(f"BabyAI-FindObjS{rs}-v0", ENV_FINDOBJ, 3 * (rs - 1) + 1, 3 * (rs - 1) + 1, 20 * rs * rs, False, _PICKUP_MISSIONS,
+              room_size=rs, entry_point="minigrid.envs.babyai:FindObjS5", kwargs={} if rs == 5 else {"room_size": rs})
+      for rs in (5, 6, 7)],
     # envs/babyai/open.py:140-146: 1 x 2 rooms of size 5, max_steps = 1 * 25 * 2; row minigrid/__init__.py:773-776
     EnvSpec("BabyAI-OpenRedDoor-v0", ENV_OPENREDDOOR, 9, 5, 50, False, ("open the red door",), room_size=5,
             entry_point="minigrid.envs.babyai:OpenRedDoor", kwargs={}),

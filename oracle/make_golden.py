@@ -69,6 +69,8 @@ MISSIONS = {
     "BabyAI-OneRoom": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
+    "BabyAI-FindObj": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                       for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "MiniGrid-LockedRoom": [f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
                             for a in ("blue", "green", "grey", "purple", "red", "yellow") for b in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Playground": [""],
@@ -181,6 +183,13 @@ def solver_action(env_id, u):
         if not d.is_open:
             p = plan_to_face(u, door)
             return 5 if p == [] else (p[0] if p else None)
+    if env_id.startswith("BabyAI-FindObj"):
+        d = u.instrs.desc
+        tgt = find(u, d.type)
+        p = plan_to_face(u, tgt) if tgt is not None else None
+        if p is not None:
+            return 3 if p == [] else p[0]
+        return _door_action(u, False)
     if env_id.startswith(("BabyAI-PickupDist", "BabyAI-OneRoom")):
         d = u.instrs.desc
         if u.carrying is not None:             # holding a wrong object (non-strict level): put it down again
@@ -607,6 +616,7 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "MiniGrid-MultiRoom-N4-S5-v1", "MiniGrid-MultiRoom-N6-v0",
             "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OneRoomS8-v0", "BabyAI-OneRoomS12-v0",
             "BabyAI-OneRoomS16-v0", "BabyAI-OneRoomS20-v0", "BabyAI-OpenRedDoor-v0",
+            "BabyAI-FindObjS5-v0", "BabyAI-FindObjS6-v0", "BabyAI-FindObjS7-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",

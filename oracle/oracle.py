@@ -20,7 +20,7 @@ K_UNLOCK, K_UNLOCKPICKUP, K_BLOCKEDUNLOCKPICKUP, K_REDBLUEDOORS, K_MEMORY, K_KEY
 K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
-K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG = 24, 25, 26, 27
+K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
 T_WALL, T_LAVA = 2, 9
 
 
@@ -129,6 +129,9 @@ def spec(env_id: str) -> dict:
                     room_size=room_size, missions=pickup_missions)
 
     table = {
+        # other.py:163-167: 3 x 3 rooms, max_steps = 20 * room_size**2 (fixed)
+        **{f"BabyAI-FindObjS{rs}-v0": dict(kind=K_FINDOBJ, width=3 * (rs - 1) + 1, height=3 * (rs - 1) + 1, max_steps=20 * rs * rs,
+                                          see_through=0, room_size=rs, missions=pickup_missions) for rs in (5, 6, 7)},
         "BabyAI-PickupDist-v0": babyai_pickup(K_PICKUPDIST, 7), "BabyAI-PickupDistDebug-v0": babyai_pickup(K_PICKUPDIST_DEBUG, 7),
         "BabyAI-OneRoomS8-v0": babyai_pickup(K_ONEROOM, 8), "BabyAI-OneRoomS12-v0": babyai_pickup(K_ONEROOM, 12),
         "BabyAI-OneRoomS16-v0": babyai_pickup(K_ONEROOM, 16), "BabyAI-OneRoomS20-v0": babyai_pickup(K_ONEROOM, 20),
