@@ -78,6 +78,8 @@ typedef enum mg_env_kind {
   MG_ENV_OPENREDDOOR = 26,  /* envs/babyai/open.py:89-146 (1 x 2 rooms, room_size 5, OpenInstr)                                   */
   MG_ENV_PICKUPDIST_DEBUG = 27, /* PickupDist(debug=True): strict PickupInstr, a wrong pickup ends the episode (verifier.py:356-359) */
   MG_ENV_FINDOBJ = 28,      /* envs/babyai/other.py:109-177 (FindObjS5/S6/S7: 3 x 3 rooms, connect_all, PickupInstr by type)             */
+  MG_ENV_UNLOCKLOCAL = 29,  /* envs/babyai/unlock.py:114-174 (3 x 3 rooms of room_size 8; num_dists = 0 | 3 distractors = UnlockLocalDist)  */
+  MG_ENV_BABYAI_KEYCORRIDOR = 30, /* envs/babyai/other.py:180-272: MG_ENV_KEYCORRIDOR's map with PickupInstr(ObjDesc("ball"))           */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;

@@ -334,12 +334,15 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_FINDOBJ) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BABYAI_KEYCORRIDOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if ((cfg->env_kind == MG_ENV_LOCKEDROOM || cfg->env_kind == MG_ENV_PLAYGROUND) && (cfg->width != cfg->height || cfg->width < 13 || cfg->width > 25))
     return fail(nullptr, MG_ERR_INVALID, "LockedRoom / Playground: square grid of 13..25 cells (the registered size is 19)");
   if ((cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG || cfg->env_kind == MG_ENV_ONEROOM) &&
       (cfg->width != cfg->height || cfg->width < 5 || cfg->width > 25))
     return fail(nullptr, MG_ERR_INVALID, "PickupDist / OneRoom: one square room of 5..25 cells");
+  if (cfg->env_kind == MG_ENV_UNLOCKLOCAL && (cfg->room_size < 5 || cfg->room_size > 9 || cfg->width != 3 * (cfg->room_size - 1) + 1 || cfg->height != cfg->width ||
+      cfg->num_dists < 0 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "UnlockLocal is a 3 x 3 RoomGrid: width = height = 3*(room_size-1)+1, room_size 5..9, at most 8 distractors");
   if (cfg->env_kind == MG_ENV_FINDOBJ && (cfg->room_size < 4 || cfg->room_size > 9 || cfg->width != 3 * (cfg->room_size - 1) + 1 || cfg->height != cfg->width))
     return fail(nullptr, MG_ERR_INVALID, "FindObj is a 3 x 3 RoomGrid: width = height = 3*(room_size-1)+1, room_size 4..9");
   if (cfg->env_kind == MG_ENV_OPENREDDOOR && (cfg->room_size < 4 || cfg->room_size > 13 || cfg->width != 2 * (cfg->room_size - 1) + 1 || cfg->height != cfg->room_size))
@@ -353,7 +356,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "BabyAI single-room GoTo levels: room_size 4..8, at most 8 distractors");
   if (cfg->env_kind == MG_ENV_DYNOBS && (cfg->num_dists < 0 || cfg->num_dists > 8 || cfg->width > 16 || cfg->height > 16))
     return fail(nullptr, MG_ERR_INVALID, "DynamicObstacles supports up to 8 obstacles on grids up to 16 x 16");
-  if (cfg->env_kind == MG_ENV_KEYCORRIDOR && (cfg->room_size < 3 || cfg->width != 3 * (cfg->room_size - 1) + 1 ||
+  if ((cfg->env_kind == MG_ENV_KEYCORRIDOR || cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) && (cfg->room_size < 3 || cfg->width != 3 * (cfg->room_size - 1) + 1 ||
       (cfg->height - 1) % (cfg->room_size - 1) != 0 || (cfg->height - 1) / (cfg->room_size - 1) < 1 || (cfg->height - 1) / (cfg->room_size - 1) > 3 || cfg->width > 16 || cfg->height > 16))
     return fail(nullptr, MG_ERR_INVALID, "KeyCorridor is a 3 x (1..3) RoomGrid with room_size >= 3 and a grid of at most 16 x 16");
   if (cfg->env_kind == MG_ENV_REDBLUEDOORS && (cfg->width != 2 * cfg->height || cfg->height < 4))
@@ -440,9 +443,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
   if (cfg->env_kind == MG_ENV_GOTOOBJECT) { e->rule = RULE_GOTOOBJ; e->rule_div = 2; }     // same mission id -> (colour, type) coding as GoToObj
   e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ;
-  if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||
+      cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG) { e->rule = RULE_PICKUPDESC; e->rule_div = 2; }      // strict
-  if (cfg->env_kind == MG_ENV_OPENREDDOOR) e->rule = RULE_OPENFRONT;
+  if (cfg->env_kind == MG_ENV_OPENREDDOOR || cfg->env_kind == MG_ENV_UNLOCKLOCAL) e->rule = RULE_OPENFRONT;
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
   if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;

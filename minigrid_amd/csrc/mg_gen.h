@@ -739,6 +739,52 @@ MG_D void gen_findobj(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
   }
   out.failed = true;
 }
+// envs/babyai/unlock.py:167-174 (UnlockLocal / UnlockLocalDist: 3 x 3 rooms; a locked door on a random wall of the middle
+// room, its key and P.num_dists (0 | 3) distractors in that room, the agent too; OpenInstr(ObjDesc("door")) -> "open the door")
+template <class R>
+MG_D void gen_unlocklocal(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < H; y++)
+      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+    uint64_t right_y = 0, down_x = 0;           // RoomGrid._gen_grid: one door offset per room and shared wall (roomgrid.py:158-171)
+#pragma unroll 1
+    for (int j = 0; j < 3; j++)
+#pragma unroll 1
+      for (int i = 0; i < 3; i++) {
+        const int r = j * 3 + i, tx = i * st, ty = j * st;
+        if (i < 2) right_y |= (uint64_t)(rand_int(rng, ty + 1, ty + rs - 1) - ty) << (4 * r);
+        if (j < 2) down_x |= (uint64_t)(rand_int(rng, tx + 1, tx + rs - 1) - tx) << (4 * r);
+      }
+    const int mid = st + rs / 2;
+    // add_door(1, 1, locked=True): the first door_idx drawn is valid (four neighbours, no door yet), then the colour
+    const int k = rand_int(rng, 0, 4);
+    const uint32_t dc = (uint32_t)rand_int(rng, 0, 6);
+    const int ri = k == 2 ? 0 : 1, rj = k == 3 ? 0 : 1, rr = rj * 3 + ri;
+    const bool vertical_wall = k == 0 || k == 2;
+    const int dx = vertical_wall ? ri * st + st : ri * st + (int)((down_x >> (4 * rr)) & 15u);
+    const int dy = vertical_wall ? rj * st + (int)((right_y >> (4 * rr)) & 15u) : rj * st + st;
+    g.set(dx, dy, make_cell(T_DOOR_LOCKED, color_from_sorted(dc)));
+    int x, y;
+    bool ok = place_obj(rng, g, make_cell(T_KEY, color_from_sorted(dc)), st, st, rs, rs, mid, mid, true, 1000, x, y);
+    uint32_t used = 1u << (dc * 3u);            // add_distractors: (type, colour) pairs already in some room.objs
+    for (int n = 0; n < P.num_dists && ok && !rng.dead();) {
+      const uint32_t ci = (uint32_t)rand_int(rng, 0, 6), ti = (uint32_t)rand_int(rng, 0, 3), id = ci * 3u + ti;
+      if ((used >> id) & 1u) continue;
+      ok = place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), st, st, rs, rs, mid, mid, true, 1000, x, y);
+      used |= 1u << id; n++;
+    }
+    if (!ok) continue;
+    if (!rg_place_agent(rng, g, st, st, rs, out)) continue;
+    out.mission = 0;
+    return;
+  }
+  out.failed = true;
+}
 // envs/babyai/open.py:143-146 (OpenRedDoor: 1 x 2 rooms of size 5; add_door(0, 0, 0, "red", locked=False); place_agent(0, 0))
 template <class R>
 MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -949,7 +995,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 28) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 30) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -989,6 +1035,8 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 24: case 25: case 27: gen_pickup_level(rng, g, P, out); return;
       case 26: gen_openreddoor(rng, g, P, out); return;
       case 28: gen_findobj(rng, g, P, out); return;
+      case 29: gen_unlocklocal(rng, g, P, out); return;
+      case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
       default: break;
     }
   }

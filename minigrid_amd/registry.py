@@ -18,6 +18,7 @@ ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
+ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR = 29, 30
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -210,6 +211,17 @@ _ROWS = [
     *[EnvSpec(f"BabyAI-FindObjS{rs}-v0", ENV_FINDOBJ, 3 * (rs - 1) + 1, 3 * (rs - 1) + 1, 20 * rs * rs, False, _PICKUP_MISSIONS,
               room_size=rs, entry_point="minigrid.envs.babyai:FindObjS5", kwargs={} if rs == 5 else {"room_size": rs})
       for rs in (5, 6, 7)],
+    # envs/babyai/unlock.py:163-174: RoomGridLevel defaults (3 x 3 rooms of size 8), max_steps = 1 * 64 * 9; rows minigrid/__init__.py:956-965
+    EnvSpec("BabyAI-UnlockLocal-v0", ENV_UNLOCKLOCAL, 22, 22, 576, False, ("open the door",), room_size=8, num_dists=0,
+            entry_point="minigrid.envs.babyai:UnlockLocal", kwargs={}),
+    EnvSpec("BabyAI-UnlockLocalDist-v0", ENV_UNLOCKLOCAL, 22, 22, 576, False, ("open the door",), room_size=8, num_dists=3,
+            entry_point="minigrid.envs.babyai:UnlockLocal", kwargs={"distractors": True}),
+    # envs/babyai/other.py:231-250: 3 columns x num_rows rooms, max_steps = 30 * room_size**2; rows minigrid/__init__.py:1018-1057
+    *[EnvSpec(name, ENV_BABYAI_KEYCORRIDOR, 3 * (rs - 1) + 1, rows * (rs - 1) + 1, 30 * rs * rs, False, _PICKUP_MISSIONS, room_size=rs,
+              entry_point="minigrid.envs.babyai:KeyCorridor", kwargs=kw)
+      for name, rs, rows, kw in (("BabyAI-KeyCorridor-v0", 6, 3, {}),
+                                 *[(f"BabyAI-KeyCorridorS{a}R{b}-v0", a, b, {"room_size": a, "num_rows": b})
+                                   for a, b in ((3, 1), (3, 2), (3, 3), (4, 3), (5, 3), (6, 3))])],
     # envs/babyai/open.py:140-146: 1 x 2 rooms of size 5, max_steps = 1 * 25 * 2; row minigrid/__init__.py:773-776
     EnvSpec("BabyAI-OpenRedDoor-v0", ENV_OPENREDDOOR, 9, 5, 50, False, ("open the red door",), room_size=5,
             entry_point="minigrid.envs.babyai:OpenRedDoor", kwargs={}),

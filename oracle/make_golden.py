@@ -69,6 +69,9 @@ MISSIONS = {
     "BabyAI-OneRoom": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
+    "BabyAI-UnlockLocal": ["open the door"],
+    "BabyAI-KeyCorridor": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                           for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-FindObj": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "MiniGrid-LockedRoom": [f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
@@ -223,6 +226,16 @@ def solver_action(env_id, u):
         if p is None and u.carrying is not None:
             return 4
         return p[0] if p else None
+    if env_id.startswith("BabyAI-UnlockLocal"):
+        door = find(u, "door")
+        d = u.grid.get(*door)
+        if d.is_locked and (u.carrying is None or u.carrying.type != "key" or u.carrying.color != d.color):
+            if u.carrying is not None:
+                return 4 if u.grid.get(*u.front_pos) is None else 0
+            p = plan_to_face(u, find(u, "key", d.color))
+            return 3 if p == [] else (p[0] if p else None)
+        p = plan_to_face(u, door)
+        return 5 if p == [] else (p[0] if p else None)
     if env_id.startswith(("MiniGrid-Unlock", "MiniGrid-BlockedUnlockPickup")):
         door = find(u, "door")
         d = u.grid.get(*door)
@@ -245,28 +258,20 @@ def solver_action(env_id, u):
             p = plan_to_face(u, box)
             return 3 if p == [] else (p[0] if p else None)
         return None
-    if env_id.startswith("MiniGrid-KeyCorridor"):
-        # key -> doors -> ball; the BFS treats closed doors as walls, so open the reachable ones on the way
-        def reachable_closed_door(locked_ok):
-            for i in range(u.width):
-                for j in range(u.height):
-                    c = u.grid.get(i, j)
-                    if c is not None and c.type == "door" and not c.is_open and (locked_ok or not c.is_locked):
-                        q = plan_to_face(u, (i, j))
-                        if q is not None:
-                            return 5 if q == [] else q[0]
-            return None
-        tgt = find(u, "ball")
+    if env_id.startswith(("MiniGrid-KeyCorridor", "BabyAI-KeyCorridor")):
+        # key -> locked door -> put the key down -> ball; the BFS treats closed doors as walls, so reachable ones get opened
+        locked = any(c is not None and c.type == "door" and c.is_locked for c in u.grid.grid)
         if u.carrying is None:
-            key = find(u, "key")
-            p = plan_to_face(u, key if key is not None else tgt)
+            p = plan_to_face(u, find(u, "key") if locked else find(u, "ball"))
             if p is None:
-                return reachable_closed_door(False)
+                return _door_action(u, False)
             return 3 if p == [] else p[0]
         if u.carrying.type == "key":
-            if plan_to_face(u, tgt) is None:
-                return reachable_closed_door(True)
-            return 4 if u.grid.get(*u.front_pos) is None else 0      # way to the ball is open: put the key down
+            if locked:
+                return _door_action(u, True)
+            if u.grid.get(*u.front_pos) is None:
+                return 4
+            return 2 if u.step_count % 3 == 0 else 0       # find a free cell to put the key down
         return None
     if env_id.startswith("MiniGrid-RedBlueDoors"):
         door = u.red_door if not u.red_door.is_open else u.blue_door
@@ -617,6 +622,9 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OneRoomS8-v0", "BabyAI-OneRoomS12-v0",
             "BabyAI-OneRoomS16-v0", "BabyAI-OneRoomS20-v0", "BabyAI-OpenRedDoor-v0",
             "BabyAI-FindObjS5-v0", "BabyAI-FindObjS6-v0", "BabyAI-FindObjS7-v0",
+            "BabyAI-UnlockLocal-v0", "BabyAI-UnlockLocalDist-v0", "BabyAI-KeyCorridor-v0", "BabyAI-KeyCorridorS3R1-v0",
+            "BabyAI-KeyCorridorS3R2-v0", "BabyAI-KeyCorridorS3R3-v0", "BabyAI-KeyCorridorS4R3-v0", "BabyAI-KeyCorridorS5R3-v0",
+            "BabyAI-KeyCorridorS6R3-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",

@@ -21,6 +21,7 @@ K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
+K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR = 29, 30
 T_WALL, T_LAVA = 2, 9
 
 
@@ -132,6 +133,17 @@ def spec(env_id: str) -> dict:
         # other.py:163-167: 3 x 3 rooms, max_steps = 20 * room_size**2 (fixed)
         **{f"BabyAI-FindObjS{rs}-v0": dict(kind=K_FINDOBJ, width=3 * (rs - 1) + 1, height=3 * (rs - 1) + 1, max_steps=20 * rs * rs,
                                           see_through=0, room_size=rs, missions=pickup_missions) for rs in (5, 6, 7)},
+        # unlock.py:163-174: default RoomGridLevel geometry (3 x 3 rooms of size 8), max_steps = 1 * 64 * 9
+        "BabyAI-UnlockLocal-v0": dict(kind=K_UNLOCKLOCAL, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=0,
+                                      missions=["open the door"]),
+        "BabyAI-UnlockLocalDist-v0": dict(kind=K_UNLOCKLOCAL, width=22, height=22, max_steps=576, see_through=0, room_size=8,
+                                          num_dists=3, missions=["open the door"]),
+        # other.py:231-250: 3 columns x num_rows rooms, max_steps = 30 * room_size**2
+        **{name: dict(kind=K_BABYAI_KEYCORRIDOR, width=3 * (rs - 1) + 1, height=rows * (rs - 1) + 1, max_steps=30 * rs * rs,
+                      see_through=0, room_size=rs, missions=pickup_missions)
+           for name, rs, rows in (("BabyAI-KeyCorridor-v0", 6, 3), ("BabyAI-KeyCorridorS3R1-v0", 3, 1), ("BabyAI-KeyCorridorS3R2-v0", 3, 2),
+                                  ("BabyAI-KeyCorridorS3R3-v0", 3, 3), ("BabyAI-KeyCorridorS4R3-v0", 4, 3),
+                                  ("BabyAI-KeyCorridorS5R3-v0", 5, 3), ("BabyAI-KeyCorridorS6R3-v0", 6, 3))},
         "BabyAI-PickupDist-v0": babyai_pickup(K_PICKUPDIST, 7), "BabyAI-PickupDistDebug-v0": babyai_pickup(K_PICKUPDIST_DEBUG, 7),
         "BabyAI-OneRoomS8-v0": babyai_pickup(K_ONEROOM, 8), "BabyAI-OneRoomS12-v0": babyai_pickup(K_ONEROOM, 12),
         "BabyAI-OneRoomS16-v0": babyai_pickup(K_ONEROOM, 16), "BabyAI-OneRoomS20-v0": babyai_pickup(K_ONEROOM, 20),

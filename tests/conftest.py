@@ -30,6 +30,9 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OneRoomS8-v0", "BabyAI-OneRoomS12-v0",
             "BabyAI-OneRoomS16-v0", "BabyAI-OneRoomS20-v0", "BabyAI-OpenRedDoor-v0",
             "BabyAI-FindObjS5-v0", "BabyAI-FindObjS6-v0", "BabyAI-FindObjS7-v0",
+            "BabyAI-UnlockLocal-v0", "BabyAI-UnlockLocalDist-v0", "BabyAI-KeyCorridor-v0", "BabyAI-KeyCorridorS3R1-v0",
+            "BabyAI-KeyCorridorS3R2-v0", "BabyAI-KeyCorridorS3R3-v0", "BabyAI-KeyCorridorS4R3-v0", "BabyAI-KeyCorridorS5R3-v0",
+            "BabyAI-KeyCorridorS6R3-v0",
             "BabyAI-GoToRedBallGrey-v0", "BabyAI-GoToRedBlueBall-v0", "BabyAI-GoToObj-v0", "BabyAI-GoToObjS4-v0",
             "BabyAI-GoToObjS6-v1", "BabyAI-GoToLocal-v0", "BabyAI-GoToLocalS5N2-v0", "BabyAI-GoToLocalS6N2-v0",
             "BabyAI-GoToLocalS6N3-v0", "BabyAI-GoToLocalS6N4-v0", "BabyAI-GoToLocalS7N4-v0", "BabyAI-GoToLocalS7N5-v0",
