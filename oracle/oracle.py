@@ -21,7 +21,7 @@ K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
-K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR = 29, 30
+K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE = 29, 30, 31
 T_WALL, T_LAVA = 2, 9
 
 
@@ -129,7 +129,27 @@ def spec(env_id: str) -> dict:
         return dict(kind=kind, width=room_size, height=room_size, max_steps=room_size * room_size, see_through=0,
                     room_size=room_size, missions=pickup_missions)
 
+    def obstructedmaze(rows, cols, rooms_visited, key_in_box, blocked, num_quarters=1, agent_room=(0, 0), v1=False, one_d=False):
+        # obstructedmaze.py:80-106: room_size 6, max_steps = 4 * num_rooms_visited * 36; flags in num_crossings (see the C file)
+        return dict(kind=K_OBSTRUCTEDMAZE, width=cols * 5 + 1, height=rows * 5 + 1, max_steps=4 * rooms_visited * 36, see_through=0,
+                    room_size=6, num_crossings=int(key_in_box) | int(blocked) << 1 | int(v1) << 2 | int(one_d) << 3,
+                    num_dists=num_quarters, start_x=agent_room[0], start_y=agent_room[1], missions=["pick up the blue ball"])
+
     table = {
+        # rows minigrid/__init__.py:390-515 (NOT yet on the device: oracle groundwork for the next widening step)
+        "MiniGrid-ObstructedMaze-1Dl-v0": obstructedmaze(1, 2, 2, False, False, one_d=True),
+        "MiniGrid-ObstructedMaze-1Dlh-v0": obstructedmaze(1, 2, 2, True, False, one_d=True),
+        "MiniGrid-ObstructedMaze-1Dlhb-v0": obstructedmaze(1, 2, 2, True, True, one_d=True),
+        "MiniGrid-ObstructedMaze-2Dl-v0": obstructedmaze(3, 3, 4, False, False, 1, (2, 1)),
+        "MiniGrid-ObstructedMaze-2Dlh-v0": obstructedmaze(3, 3, 4, True, False, 1, (2, 1)),
+        "MiniGrid-ObstructedMaze-2Dlhb-v0": obstructedmaze(3, 3, 4, True, True, 1, (2, 1)),
+        "MiniGrid-ObstructedMaze-1Q-v0": obstructedmaze(3, 3, 5, True, True, 1, (1, 1)),
+        "MiniGrid-ObstructedMaze-2Q-v0": obstructedmaze(3, 3, 11, True, True, 2, (2, 1)),
+        "MiniGrid-ObstructedMaze-Full-v0": obstructedmaze(3, 3, 25, True, True, 4, (1, 1)),
+        "MiniGrid-ObstructedMaze-2Dlhb-v1": obstructedmaze(3, 3, 4, True, True, 1, (2, 1), v1=True),
+        "MiniGrid-ObstructedMaze-1Q-v1": obstructedmaze(3, 3, 5, True, True, 1, (1, 1), v1=True),
+        "MiniGrid-ObstructedMaze-2Q-v1": obstructedmaze(3, 3, 11, True, True, 2, (2, 1), v1=True),
+        "MiniGrid-ObstructedMaze-Full-v1": obstructedmaze(3, 3, 25, True, True, 4, (1, 1), v1=True),
         # other.py:163-167: 3 x 3 rooms, max_steps = 20 * room_size**2 (fixed)
         **{f"BabyAI-FindObjS{rs}-v0": dict(kind=K_FINDOBJ, width=3 * (rs - 1) + 1, height=3 * (rs - 1) + 1, max_steps=20 * rs * rs,
                                           see_through=0, room_size=rs, missions=pickup_missions) for rs in (5, 6, 7)},

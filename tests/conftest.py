@@ -50,6 +50,14 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+# restated and pinned in the oracle only (oracle groundwork for the next widening step): not in the GPU lists
+ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0", "MiniGrid-ObstructedMaze-1Dlhb-v0",
+                   "MiniGrid-ObstructedMaze-2Dl-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0",
+                   "MiniGrid-ObstructedMaze-1Q-v0", "MiniGrid-ObstructedMaze-2Q-v0", "MiniGrid-ObstructedMaze-Full-v0",
+                   "MiniGrid-ObstructedMaze-2Dlhb-v1", "MiniGrid-ObstructedMaze-1Q-v1", "MiniGrid-ObstructedMaze-2Q-v1",
+                   "MiniGrid-ObstructedMaze-Full-v1"]
+
+
 def full_obs_supported(env_id: str) -> bool:
     """FullyObs / Symbolic observations of the 25 x 25 MultiRoom maps need 165 KB of LDS staging per 64 envs, 1.3 KB more
     than a CU has: mg_create refuses that combination (documented limit); partial and RGB observations are fine."""

@@ -6,7 +6,7 @@ These tests run on CPU (no GPU marker): if they fail, no GPU parity claim means 
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, golden
+from conftest import ALL_IDS, MAIN_IDS, golden, ORACLE_ONLY_IDS
 from oracle import oracle as O
 
 
@@ -62,7 +62,7 @@ def test_reference_doctest_first_obs_column():
     assert (obs[0, 0] == np.array([2, 5, 0], np.uint8)).all()
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS)
+@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS)
 def test_generators_match_reference(env_id):
     g = golden(f"gen_{env_id}.npz")
     n, episodes = g["grid"].shape[:2]
@@ -75,7 +75,7 @@ def test_generators_match_reference(env_id):
         assert (mission == g["mission"][:, ep]).all()
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS)
+@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS)
 @pytest.mark.parametrize("mode", ["random", "solver"])
 @pytest.mark.parametrize("full", [False, True])
 def test_rollouts_match_reference(env_id, mode, full):
