@@ -75,6 +75,9 @@ MISSIONS = {
     "BabyAI-FindObj": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "MiniGrid-ObstructedMaze": ["pick up the blue ball"],
+    "MiniGrid-PutNear": [f"put the {mc} {mt} near the {tc} {tt}" for mc in ("blue", "green", "grey", "purple", "red", "yellow")
+                         for mt in ("key", "ball", "box") for tc in ("blue", "green", "grey", "purple", "red", "yellow")
+                         for tt in ("key", "ball", "box")],
     "MiniGrid-LockedRoom": [f"get the {a} key from the {b} room, unlock the {a} door and go to the goal"
                             for a in ("blue", "green", "grey", "purple", "red", "yellow") for b in ("blue", "green", "grey", "purple", "red", "yellow")],
     "MiniGrid-Playground": [""],
@@ -174,6 +177,27 @@ def _reachable(u, pred):
 
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
+    if env_id.startswith("MiniGrid-PutNear"):
+        # fetch the object to move, carry it next to the target; now and then grab the wrong one / drop it early
+        if u.carrying is None:
+            wrong = u.step_count % 9 == 4
+            p = _reachable(u, lambda c, pos: c.type in ("key", "ball", "box") and
+                           ((c.type == u.move_type and c.color == u.moveColor) != wrong))
+            return (3 if p == [] else p[0]) if p is not None else None
+        tx, ty = u.target_pos
+        fx, fy = u.front_pos
+        if u.grid.get(fx, fy) is None and ((abs(fx - tx) <= 1 and abs(fy - ty) <= 1) or u.step_count % 13 == 7):
+            return 4
+        best = None
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                cell = (tx + dx, ty + dy)
+                if (dx or dy) and 0 < cell[0] < u.width - 1 and 0 < cell[1] < u.height - 1 and u.grid.get(*cell) is None \
+                        and tuple(u.agent_pos) != cell:
+                    p = plan_to_face(u, cell)
+                    if p is not None and (best is None or len(p) < len(best)):
+                        best = p
+        return (4 if best == [] else best[0]) if best is not None else None
     if env_id.startswith("MiniGrid-ObstructedMaze"):
         # blue ball if reachable; else open doors, carry blocking balls away, open boxes, fetch keys, unlock doors
         hands = u.carrying
@@ -395,7 +419,7 @@ def make_rollouts(env_id, seeds, T):
         out[f"{mode}_obs"] = np.array([r["obs"] for r in recs], np.uint8)
         out[f"{mode}_full"] = np.array([r["full"] for r in recs], np.uint8)
         out[f"{mode}_dir"] = np.array([r["dir"] for r in recs], np.uint8)
-        out[f"{mode}_mission"] = np.array([r["mission"] for r in recs], np.uint8)
+        out[f"{mode}_mission"] = np.array([r["mission"] for r in recs], np.uint8 if max(max(r["mission"]) for r in recs) < 256 else np.uint16)
         out[f"{mode}_reward"] = np.array([r["reward"] for r in recs], np.float64)
         out[f"{mode}_term"] = np.array([r["term"] for r in recs], bool)
         out[f"{mode}_trunc"] = np.array([r["trunc"] for r in recs], bool)
@@ -420,7 +444,8 @@ def make_gen(env_id, nseeds, episodes=3):
         grids.append(g)
         agents.append(a)
         missions.append(m)
-    return dict(grid=np.array(grids, np.uint8), agent=np.array(agents, np.int32), mission=np.array(missions, np.uint8))
+    return dict(grid=np.array(grids, np.uint8), agent=np.array(agents, np.int32),
+                mission=np.array(missions, np.uint8 if max(map(max, missions)) < 256 else np.uint16))
 
 
 def make_rng_kat():
@@ -685,7 +710,7 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "MiniGrid-ObstructedMaze-2Dl-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0",
                    "MiniGrid-ObstructedMaze-1Q-v0", "MiniGrid-ObstructedMaze-2Q-v0", "MiniGrid-ObstructedMaze-Full-v0",
                    "MiniGrid-ObstructedMaze-2Dlhb-v1", "MiniGrid-ObstructedMaze-1Q-v1", "MiniGrid-ObstructedMaze-2Q-v1",
-                   "MiniGrid-ObstructedMaze-Full-v1"]
+                   "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0"]
 
 
 def main_oracle_only():

@@ -21,7 +21,7 @@ K_DYNOBS = 15
 K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT = 16, 17, 18, 19, 20
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
-K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE = 29, 30, 31
+K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE, K_PUTNEAR = 29, 30, 31, 32
 T_WALL, T_LAVA = 2, 9
 
 
@@ -136,6 +136,11 @@ def spec(env_id: str) -> dict:
                     num_dists=num_quarters, start_x=agent_room[0], start_y=agent_room[1], missions=["pick up the blue ball"])
 
     table = {
+        # putnear.py:68-93: see_through_walls=True, max_steps = 5 * size; rows minigrid/__init__.py:526-537 (oracle only so far)
+        **{name: dict(kind=K_PUTNEAR, width=size, height=size, max_steps=5 * size, see_through=1, num_dists=n,
+                      missions=[f"put the {mc} {mt} near the {tc} {tt}" for mc in color_names for mt in ("key", "ball", "box")
+                                for tc in color_names for tt in ("key", "ball", "box")])
+           for name, size, n in (("MiniGrid-PutNear-6x6-N2-v0", 6, 2), ("MiniGrid-PutNear-8x8-N3-v0", 8, 3))},
         # rows minigrid/__init__.py:390-515 (NOT yet on the device: oracle groundwork for the next widening step)
         "MiniGrid-ObstructedMaze-1Dl-v0": obstructedmaze(1, 2, 2, False, False, one_d=True),
         "MiniGrid-ObstructedMaze-1Dlh-v0": obstructedmaze(1, 2, 2, True, False, one_d=True),
@@ -247,7 +252,7 @@ def lib():
         L.oracle_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         for f in (L.oracle_get_state, L.oracle_set_state):
             f.argtypes = [vp, vp, vp]
-        for f in (L.oracle_get_rng, L.oracle_set_rng):
+        for f in (L.oracle_get_rng, L.oracle_set_rng, L.oracle_get_missions):
             f.argtypes = [vp, vp]
         L.oracle_rng_kat.argtypes = [C.c_uint64, vp, vp, C.c_int, vp, C.c_int, C.c_int64]
         L.oracle_shuffle_kat.argtypes = [C.c_uint64, vp, C.c_int]
@@ -303,6 +308,14 @@ class OracleVec:
         n = self.n
         return (np.zeros((n,) + self.obs_shape, self.obs_dtype), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
 
+    def _missions(self, m):
+        """Mission ids: the C core reports a byte per env; levels with more than 256 missions are re-read as int32."""
+        if len(self.missions) <= 256:
+            return m
+        out = np.zeros(self.n, np.int32)
+        lib().oracle_get_missions(self.h, _p(out))
+        return out.astype(np.uint16)
+
     def _frame(self, obs):
         if not self.rgb:
             return obs
@@ -317,7 +330,7 @@ class OracleVec:
         sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
         mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         lib().oracle_reset(self.h, _p(sd), _p(mk), _p(obs), _p(d), _p(m))
-        return self._frame(obs), d, m
+        return self._frame(obs), d, self._missions(m)
 
     def step(self, actions, autoreset: int = 1):
         obs, d, m = self._outs()
@@ -330,7 +343,7 @@ class OracleVec:
             raise ValueError("Unknown action")
         if rc:
             raise AssertionError("front cell out of bounds")
-        return self._frame(obs), rew, term.astype(bool), trunc.astype(bool), d, m
+        return self._frame(obs), rew, term.astype(bool), trunc.astype(bool), d, self._missions(m)
 
     def get_state(self):
         grid = np.zeros((self.n, self.W, self.H, 3), np.uint8)
