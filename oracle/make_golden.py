@@ -48,6 +48,10 @@ MISSIONS = {
     "BabyAI-GoToRedBall": ["go to the red ball", "go to a red ball"],
     "BabyAI-GoToObj": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
                        for t in ("key", "ball", "box")],
+    "BabyAI-GoTo-": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                     for t in ("key", "ball", "box")],
+    "BabyAI-GoToOpen": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                        for t in ("key", "ball", "box")],
     "BabyAI-GoToLocal": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
                          for t in ("key", "ball", "box")],
     "MiniGrid-LavaGap": ["avoid the lava and get to the green goal square"],
@@ -69,6 +73,9 @@ MISSIONS = {
     "BabyAI-OneRoom": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
+    "BabyAI-Open-": [f"open {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "BabyAI-Pickup-": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                       for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-UnlockLocal": ["open the door"],
     "BabyAI-KeyCorridor": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                            for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
@@ -287,6 +294,21 @@ def solver_action(env_id, u):
     if env_id.startswith("BabyAI-OpenRedDoor"):
         p = plan_to_face(u, find(u, "door"))
         return 5 if p == [] else (p[0] if p else None)
+    if env_id.startswith(("BabyAI-GoTo-", "BabyAI-GoToOpen", "BabyAI-GoToObjMaze", "BabyAI-Pickup-", "BabyAI-Open-")):
+        d = u.instrs.desc
+        if u.carrying is not None:
+            return 4 if u.grid.get(*u.front_pos) is None else 0
+        if d.type == "door":
+            p = _reachable(u, lambda c, pos: c.type == "door" and c.color == d.color and not c.is_open)
+            if p is not None:
+                return 5 if p == [] else p[0]
+            return _door_action(u, False)
+        p = _reachable(u, lambda c, pos: c.type == d.type and c.color == d.color)
+        if p is not None:
+            if env_id.startswith("BabyAI-Pickup-"):
+                return 3 if p == [] else p[0]
+            return p[0] if p else None
+        return _door_action(u, False)
     if env_id.startswith("BabyAI-GoTo"):
         d = u.instrs.desc
         tgt = find(u, d.type, d.color)
@@ -710,7 +732,10 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "MiniGrid-ObstructedMaze-2Dl-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0",
                    "MiniGrid-ObstructedMaze-1Q-v0", "MiniGrid-ObstructedMaze-2Q-v0", "MiniGrid-ObstructedMaze-Full-v0",
                    "MiniGrid-ObstructedMaze-2Dlhb-v1", "MiniGrid-ObstructedMaze-1Q-v1", "MiniGrid-ObstructedMaze-2Q-v1",
-                   "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0"]
+                   "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
+                   "BabyAI-GoTo-v0", "BabyAI-GoToOpen-v0", "BabyAI-GoToObjMaze-v0", "BabyAI-GoToObjMazeOpen-v0",
+                   "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
+                   "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0"]
 
 
 def main_oracle_only():

@@ -22,6 +22,7 @@ K_GOTO_REDBALLGREY, K_GOTO_REDBLUEBALL, K_GOTO_OBJ, K_GOTO_LOCAL, K_GOTOOBJECT =
 K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
 K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE, K_PUTNEAR = 29, 30, 31, 32
+K_BABYAI_GOTO, K_BABYAI_PICKUP, K_BABYAI_OPEN = 33, 34, 35
 T_WALL, T_LAVA = 2, 9
 
 
@@ -136,6 +137,20 @@ def spec(env_id: str) -> dict:
                     num_dists=num_quarters, start_x=agent_room[0], start_y=agent_room[1], missions=["pick up the blue ball"])
 
     table = {
+        # multi-room BabyAI levels with one instruction (oracle only so far): goto.py:403-426, pickup.py:66-72, open.py:69-86;
+        # max_steps = 1 * room_size**2 * rows * cols (roomgrid_level.py:71-85); rows minigrid/__init__.py:681-731, 760-763, 848-851
+        **{name: dict(kind=K_BABYAI_GOTO, width=cols * (rs - 1) + 1, height=rows * (rs - 1) + 1, max_steps=rs * rs * rows * cols,
+                      see_through=0, room_size=rs, num_dists=nd, num_crossings=int(opened), missions=goto_obj_missions)
+           for name, rs, rows, cols, nd, opened in (
+               ("BabyAI-GoTo-v0", 8, 3, 3, 18, False), ("BabyAI-GoToOpen-v0", 8, 3, 3, 18, True),
+               ("BabyAI-GoToObjMaze-v0", 8, 3, 3, 1, False), ("BabyAI-GoToObjMazeOpen-v0", 8, 3, 3, 1, True),
+               ("BabyAI-GoToObjMazeS4R2-v0", 4, 2, 2, 1, False), ("BabyAI-GoToObjMazeS4-v0", 4, 3, 3, 1, False),
+               ("BabyAI-GoToObjMazeS5-v0", 5, 3, 3, 1, False), ("BabyAI-GoToObjMazeS6-v0", 6, 3, 3, 1, False),
+               ("BabyAI-GoToObjMazeS7-v0", 7, 3, 3, 1, False))},
+        "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
+                                 missions=pickup_missions),
+        "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
+                               missions=[f"open {art} {c} door" for art in ("the", "a") for c in color_names]),
         # putnear.py:68-93: see_through_walls=True, max_steps = 5 * size; rows minigrid/__init__.py:526-537 (oracle only so far)
         **{name: dict(kind=K_PUTNEAR, width=size, height=size, max_steps=5 * size, see_through=1, num_dists=n,
                       missions=[f"put the {mc} {mt} near the {tc} {tt}" for mc in color_names for mt in ("key", "ball", "box")
