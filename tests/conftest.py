@@ -13,7 +13,8 @@ MAIN_IDS = ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCr
 EXTRA_IDS = ["MiniGrid-Empty-5x5-v0", "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-Empty-16x16-v0",
              "MiniGrid-DoorKey-5x5-v0", "MiniGrid-DoorKey-6x6-v0", "MiniGrid-DoorKey-16x16-v0",
              "MiniGrid-LavaCrossingS9N2-v0", "MiniGrid-LavaCrossingS9N3-v0", "MiniGrid-LavaCrossingS11N5-v0",
-             "MiniGrid-SimpleCrossingS9N1-v0", "MiniGrid-SimpleCrossingS11N5-v0", "BabyAI-GoToRedBallNoDists-v0"]
+             "MiniGrid-SimpleCrossingS9N1-v0", "MiniGrid-SimpleCrossingS11N5-v0", "BabyAI-GoToRedBallNoDists-v0",
+             "MiniGrid-Empty-6x6-v0", "MiniGrid-Empty-Random-5x5-v0", "MiniGrid-SimpleCrossingS9N2-v0", "MiniGrid-SimpleCrossingS9N3-v0"]
 WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS7-v0", "MiniGrid-DistShift1-v0",
             "MiniGrid-DistShift2-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-5x5-N2-v0", "MiniGrid-Fetch-6x6-N2-v0",
             "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-5x5-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToDoor-8x8-v0",
