@@ -73,6 +73,14 @@ MISSIONS = {
     "BabyAI-OneRoom": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
+    "BabyAI-KeyInBox": ["open the door"],
+    "BabyAI-Unlock-": [f"open {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "BabyAI-UnlockPickup": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                            for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
+    "BabyAI-BlockedUnlockPickup": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                                   for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
+    "BabyAI-UnlockToUnlock": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                              for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-Open-": [f"open {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "BabyAI-Pickup-": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
@@ -182,6 +190,45 @@ def _reachable(u, pred):
     return best
 
 
+def _key_door_solver(u, is_target, target_action=3):
+    """Reach an object (pick it up / toggle it) behind locked doors: open doors, carry blocking balls away, open boxes, fetch
+    keys, unlock.  is_target(c, pos) selects the goal object."""
+    hands = u.carrying
+    doors = [(i, j) for i in range(u.width) for j in range(u.height)
+             if u.grid.get(i, j) is not None and u.grid.get(i, j).type == "door"]
+    near_door = lambda pos: any(abs(pos[0] - d[0]) + abs(pos[1] - d[1]) <= 1 for d in doors)
+    blocking = lambda: _reachable(u, lambda c, pos: c.type == "ball" and near_door(pos) and not is_target(c, pos))
+    free_front = u.grid.get(*u.front_pos) is None
+    wander = 2 if (free_front and u.step_count % 3) else 1
+    p = _reachable(u, is_target)
+    if hands is None:
+        if p is not None:
+            return target_action if p == [] else p[0]
+        a = _door_action(u, False)
+        if a is not None:
+            return a
+        q = blocking()
+        if q is not None:
+            return 3 if q == [] else q[0]
+        q = _reachable(u, lambda c, pos: c.type == "box" and not is_target(c, pos))
+        if q is not None:
+            return 5 if q == [] else q[0]
+        locked = {c.color for c in u.grid.grid if c is not None and c.type == "door" and c.is_locked}
+        q = _reachable(u, lambda c, pos: c.type == "key" and c.color in locked)
+        if q is not None:
+            return 3 if q == [] else q[0]
+        return None
+    if hands.type == "key" and (p is None or target_action == 5):
+        q = _reachable(u, lambda c, pos: c.type == "door" and c.is_locked and c.color == hands.color)
+        if q is not None:
+            return 5 if q == [] else q[0]
+        if blocking() is None and _door_action(u, False) is not None:
+            return _door_action(u, False)
+    if free_front and not near_door(tuple(u.front_pos)):       # something to put down: not next to a door
+        return 4
+    return wander
+
+
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
     if env_id.startswith("MiniGrid-PutNear"):
@@ -206,39 +253,15 @@ def solver_action(env_id, u):
                         best = p
         return (4 if best == [] else best[0]) if best is not None else None
     if env_id.startswith("MiniGrid-ObstructedMaze"):
-        # blue ball if reachable; else open doors, carry blocking balls away, open boxes, fetch keys, unlock doors
-        hands = u.carrying
-        doors = [(i, j) for i in range(u.width) for j in range(u.height)
-                 if u.grid.get(i, j) is not None and u.grid.get(i, j).type == "door"]
-        near_door = lambda pos: any(abs(pos[0] - d[0]) + abs(pos[1] - d[1]) <= 1 for d in doors)
-        blocking = lambda: _reachable(u, lambda c, pos: c.type == "ball" and c.color == "green" and near_door(pos))
-        free_front = u.grid.get(*u.front_pos) is None
-        wander = 2 if (free_front and u.step_count % 3) else 1
-        p = _reachable(u, lambda c, pos: c.type == "ball" and c.color == "blue")
-        if hands is None:
-            if p is not None:
-                return 3 if p == [] else p[0]
-            a = _door_action(u, False)
-            if a is not None:
-                return a
-            for q in (blocking(), _reachable(u, lambda c, pos: c.type == "box")):
-                if q is not None:
-                    return (3 if q is not None and u.grid.get(*u.front_pos).type == "ball" else 5) if q == [] else q[0]
-            locked = {c.color for c in u.grid.grid if c is not None and c.type == "door" and c.is_locked}
-            q = _reachable(u, lambda c, pos: c.type == "key" and c.color in locked)
-            if q is not None:
-                return 3 if q == [] else q[0]
-            return None
-        if hands.type == "key" and p is None:
-            q = _reachable(u, lambda c, pos: c.type == "door" and c.is_locked and c.color == hands.color)
-            if q is not None:
-                return 5 if q == [] else q[0]
-            if blocking() is None and _door_action(u, False) is not None:
-                return _door_action(u, False)
-        # something to put down: not next to a door
-        if free_front and not near_door(tuple(u.front_pos)):
-            return 4
-        return wander
+        return _key_door_solver(u, lambda c, pos: c.type == "ball" and c.color == "blue")
+    if env_id.startswith(("BabyAI-UnlockPickup", "BabyAI-BlockedUnlockPickup", "BabyAI-UnlockToUnlock")):
+        d = u.instrs.desc
+        return _key_door_solver(u, lambda c, pos: c.type == d.type and (d.color is None or c.color == d.color))
+    if env_id.startswith(("BabyAI-KeyInBox", "BabyAI-Unlock-")):
+        d = u.instrs.desc
+        return _key_door_solver(u, lambda c, pos: c.type == "door" and (d.color is None or c.color == d.color) and not c.is_open
+                                and (not c.is_locked or (u.carrying is not None and u.carrying.type == "key" and u.carrying.color == c.color)),
+                                target_action=5)
     if env_id.startswith(("MiniGrid-MultiRoom", "MiniGrid-LockedRoom", "MiniGrid-Playground")):
         goal = find(u, "goal")
         if goal is not None:
@@ -736,7 +759,9 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
                    "BabyAI-GoTo-v0", "BabyAI-GoToOpen-v0", "BabyAI-GoToObjMaze-v0", "BabyAI-GoToObjMazeOpen-v0",
                    "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
-                   "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0"]
+                   "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
+                   "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0",
+                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0"]
 
 
 def main_oracle_only():

@@ -23,6 +23,7 @@ K_LOCKEDROOM, K_PLAYGROUND, K_MULTIROOM = 21, 22, 23
 K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 26, 27, 28
 K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE, K_PUTNEAR = 29, 30, 31, 32
 K_BABYAI_GOTO, K_BABYAI_PICKUP, K_BABYAI_OPEN = 33, 34, 35
+K_BABYAI_UNLOCKPICKUP, K_BABYAI_BLOCKEDUNLOCKPICKUP, K_UNLOCKTOUNLOCK, K_KEYINBOX, K_BABYAI_UNLOCK = 36, 37, 38, 39, 40
 T_WALL, T_LAVA = 2, 9
 
 
@@ -147,6 +148,19 @@ def spec(env_id: str) -> dict:
                ("BabyAI-GoToObjMazeS4R2-v0", 4, 2, 2, 1, False), ("BabyAI-GoToObjMazeS4-v0", 4, 3, 3, 1, False),
                ("BabyAI-GoToObjMazeS5-v0", 5, 3, 3, 1, False), ("BabyAI-GoToObjMazeS6-v0", 6, 3, 3, 1, False),
                ("BabyAI-GoToObjMazeS7-v0", 7, 3, 3, 1, False))},
+        # unlock.py: UnlockPickup(-Dist) 1 x 2 rooms of 6, max_steps per episode = 1 * 36 * 2 (the `if max is None` slip at :299
+        # leaves it to RoomGridLevel.reset); BlockedUnlockPickup 16 * 36; UnlockToUnlock 1 x 3 rooms, 30 * 36; KeyInBox / Unlock defaults
+        "BabyAI-UnlockPickup-v0": dict(kind=K_BABYAI_UNLOCKPICKUP, width=11, height=6, max_steps=72, see_through=0, room_size=6, num_dists=0,
+                                       missions=pickup_missions),
+        "BabyAI-UnlockPickupDist-v0": dict(kind=K_BABYAI_UNLOCKPICKUP, width=11, height=6, max_steps=72, see_through=0, room_size=6,
+                                           num_dists=4, missions=pickup_missions),
+        "BabyAI-BlockedUnlockPickup-v0": dict(kind=K_BABYAI_BLOCKEDUNLOCKPICKUP, width=11, height=6, max_steps=576, see_through=0,
+                                              room_size=6, missions=pickup_missions),
+        "BabyAI-UnlockToUnlock-v0": dict(kind=K_UNLOCKTOUNLOCK, width=16, height=6, max_steps=1080, see_through=0, room_size=6,
+                                         missions=pickup_missions),
+        "BabyAI-KeyInBox-v0": dict(kind=K_KEYINBOX, width=22, height=22, max_steps=576, see_through=0, room_size=8, missions=["open the door"]),
+        "BabyAI-Unlock-v0": dict(kind=K_BABYAI_UNLOCK, width=22, height=22, max_steps=576, see_through=0, room_size=8,
+                                 missions=[f"open {art} {c} door" for art in ("the", "a") for c in color_names]),
         "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
                                  missions=pickup_missions),
         "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,

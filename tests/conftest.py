@@ -59,7 +59,9 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
                    "BabyAI-GoTo-v0", "BabyAI-GoToOpen-v0", "BabyAI-GoToObjMaze-v0", "BabyAI-GoToObjMazeOpen-v0",
                    "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
-                   "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0"]
+                   "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
+                   "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0",
+                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0"]
 
 
 def full_obs_supported(env_id: str) -> bool:
