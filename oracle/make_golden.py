@@ -74,6 +74,15 @@ MISSIONS = {
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
     "BabyAI-KeyInBox": ["open the door"],
+    "BabyAI-GoToDoor": [f"go to {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
+    "BabyAI-GoToObjDoor": [f"go to {art} {c} {t}" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                           for t in ("key", "ball", "box", "door")],
+    "BabyAI-GoToImpUnlock": [f"go to {a} {c} {t}" for a in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
+                             for t in ("key", "ball", "box")],
+    "BabyAI-UnblockPickup": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                            for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
+    "BabyAI-PickupAbove": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
+                            for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-Unlock-": [f"open {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "BabyAI-UnlockPickup": ["pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                             for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
@@ -103,7 +112,7 @@ MISSIONS = {
 
 
 def mission_id(env_id, s):
-    for k, v in MISSIONS.items():
+    for k, v in sorted(MISSIONS.items(), key=lambda kv: -len(kv[0])):        # longest matching prefix wins
         if env_id.startswith(k):
             return v.index(s)
     raise KeyError(env_id)
@@ -317,18 +326,29 @@ def solver_action(env_id, u):
     if env_id.startswith("BabyAI-OpenRedDoor"):
         p = plan_to_face(u, find(u, "door"))
         return 5 if p == [] else (p[0] if p else None)
-    if env_id.startswith(("BabyAI-GoTo-", "BabyAI-GoToOpen", "BabyAI-GoToObjMaze", "BabyAI-Pickup-", "BabyAI-Open-")):
+    if env_id.startswith(("BabyAI-GoToImpUnlock", "BabyAI-UnblockPickup")):
+        d = u.instrs.desc
+        pick = env_id.startswith("BabyAI-UnblockPickup")
+        if pick:
+            return _key_door_solver(u, lambda c, pos: c.type == d.type and c.color == d.color)
+        # go to: reach the object's room (unlocking on the way), then face it
+        p = _reachable(u, lambda c, pos: c.type == d.type and c.color == d.color)
+        if p is not None and u.carrying is None:
+            return p[0] if p else None
+        return _key_door_solver(u, lambda c, pos: False)
+    if env_id.startswith(("BabyAI-GoTo-", "BabyAI-GoToOpen", "BabyAI-GoToObjMaze", "BabyAI-Pickup-", "BabyAI-Open-", "BabyAI-GoToDoor",
+                          "BabyAI-GoToObjDoor", "BabyAI-PickupAbove")):
         d = u.instrs.desc
         if u.carrying is not None:
             return 4 if u.grid.get(*u.front_pos) is None else 0
-        if d.type == "door":
+        if d.type == "door" and env_id.startswith("BabyAI-Open-"):
             p = _reachable(u, lambda c, pos: c.type == "door" and c.color == d.color and not c.is_open)
             if p is not None:
                 return 5 if p == [] else p[0]
             return _door_action(u, False)
         p = _reachable(u, lambda c, pos: c.type == d.type and c.color == d.color)
         if p is not None:
-            if env_id.startswith("BabyAI-Pickup-"):
+            if env_id.startswith(("BabyAI-Pickup-", "BabyAI-PickupAbove")):
                 return 3 if p == [] else p[0]
             return p[0] if p else None
         return _door_action(u, False)
@@ -761,7 +781,8 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
                    "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
                    "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0",
-                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0"]
+                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0",
+                   "BabyAI-GoToDoor-v0", "BabyAI-GoToObjDoor-v0", "BabyAI-GoToImpUnlock-v0", "BabyAI-UnblockPickup-v0", "BabyAI-PickupAbove-v0"]
 
 
 def main_oracle_only():

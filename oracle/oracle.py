@@ -24,6 +24,7 @@ K_PICKUPDIST, K_ONEROOM, K_OPENREDDOOR, K_PICKUPDIST_DEBUG, K_FINDOBJ = 24, 25, 
 K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE, K_PUTNEAR = 29, 30, 31, 32
 K_BABYAI_GOTO, K_BABYAI_PICKUP, K_BABYAI_OPEN = 33, 34, 35
 K_BABYAI_UNLOCKPICKUP, K_BABYAI_BLOCKEDUNLOCKPICKUP, K_UNLOCKTOUNLOCK, K_KEYINBOX, K_BABYAI_UNLOCK = 36, 37, 38, 39, 40
+K_BABYAI_GOTODOOR, K_GOTOOBJDOOR, K_UNBLOCKPICKUP, K_PICKUPABOVE, K_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
 T_WALL, T_LAVA = 2, 9
 
 
@@ -161,6 +162,18 @@ def spec(env_id: str) -> dict:
         "BabyAI-KeyInBox-v0": dict(kind=K_KEYINBOX, width=22, height=22, max_steps=576, see_through=0, room_size=8, missions=["open the door"]),
         "BabyAI-Unlock-v0": dict(kind=K_BABYAI_UNLOCK, width=22, height=22, max_steps=576, see_through=0, room_size=8,
                                  missions=[f"open {art} {c} door" for art in ("the", "a") for c in color_names]),
+        # goto.py:727-740 (room_size 7), :797-813, :486-531; pickup.py:128-140, :346-362 (room_size 6, max_steps 8 * 36)
+        "BabyAI-GoToDoor-v0": dict(kind=K_BABYAI_GOTODOOR, width=19, height=19, max_steps=441, see_through=0, room_size=7,
+                                   missions=[f"go to {art} {c} door" for art in ("the", "a") for c in color_names]),
+        "BabyAI-GoToObjDoor-v0": dict(kind=K_GOTOOBJDOOR, width=22, height=22, max_steps=576, see_through=0, room_size=8,
+                                      missions=[f"go to {art} {c} {t}" for art in ("the", "a") for c in color_names
+                                                for t in ("key", "ball", "box", "door")]),
+        "BabyAI-GoToImpUnlock-v0": dict(kind=K_GOTOIMPUNLOCK, width=22, height=22, max_steps=576, see_through=0, room_size=8,
+                                        missions=goto_obj_missions),
+        "BabyAI-UnblockPickup-v0": dict(kind=K_UNBLOCKPICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8,
+                                        missions=pickup_missions),
+        "BabyAI-PickupAbove-v0": dict(kind=K_PICKUPABOVE, width=16, height=16, max_steps=288, see_through=0, room_size=6,
+                                      missions=pickup_missions),
         "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
                                  missions=pickup_missions),
         "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,

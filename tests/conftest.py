@@ -61,7 +61,8 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
                    "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
                    "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0",
-                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0"]
+                   "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0",
+                   "BabyAI-GoToDoor-v0", "BabyAI-GoToObjDoor-v0", "BabyAI-GoToImpUnlock-v0", "BabyAI-UnblockPickup-v0", "BabyAI-PickupAbove-v0"]
 
 
 def full_obs_supported(env_id: str) -> bool:
