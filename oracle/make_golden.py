@@ -74,6 +74,14 @@ MISSIONS = {
                        for c in ("", "blue", "green", "grey", "purple", "red", "yellow") for t in ("object", "key", "ball", "box")],
     "BabyAI-OpenRedDoor": ["open the red door"],
     "BabyAI-KeyInBox": ["open the door"],
+    "BabyAI-PutNext": [f"put the {c1} {t1} next to the {c2} {t2}" for c1 in ("blue", "green", "grey", "purple", "red", "yellow")
+                       for t1 in ("key", "ball", "box") for c2 in ("blue", "green", "grey", "purple", "red", "yellow")
+                       for t2 in ("key", "ball", "box")],
+    "BabyAI-ActionObjDoor": [f"{verb} {art} {c} {t}" for verb in ("go to", "pick up", "open") for art in ("the", "a")
+                             for c in ("blue", "green", "grey", "purple", "red", "yellow") for t in ("key", "ball", "box", "door")],
+    "BabyAI-OpenDoor": [f"open the {c} door" for c in ("blue", "green", "grey", "purple", "red", "yellow")] +
+                       [f"open {art} door {loc}" for art in ("the", "a")
+                        for loc in ("on your left", "on your right", "in front of you", "behind you")],
     "BabyAI-GoToDoor": [f"go to {art} {c} door" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")],
     "BabyAI-GoToObjDoor": [f"go to {art} {c} {t}" for art in ("the", "a") for c in ("blue", "green", "grey", "purple", "red", "yellow")
                            for t in ("key", "ball", "box", "door")],
@@ -240,6 +248,45 @@ def _key_door_solver(u, is_target, target_action=3):
 
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
+    if env_id.startswith("BabyAI-PutNext"):
+        ins = u.instrs
+        is_a = lambda c, pos=None: c.type == ins.desc_move.type and c.color == ins.desc_move.color
+        if u.carrying is None:
+            p = _reachable(u, is_a)
+            return (3 if p == [] else p[0]) if p is not None else None
+        if not is_a(u.carrying):
+            return 4 if u.grid.get(*u.front_pos) is None else 1
+        fixed = find(u, ins.desc_fixed.type, ins.desc_fixed.color)
+        if fixed is None:
+            return None
+        best = None
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            cell = (fixed[0] + dx, fixed[1] + dy)
+            if 0 < cell[0] < u.width - 1 and 0 < cell[1] < u.height - 1 and u.grid.get(*cell) is None and tuple(u.agent_pos) != cell:
+                p = plan_to_face(u, cell)
+                if p is not None and (best is None or len(p) < len(best)):
+                    best = p
+        if u.step_count % 17 == 9 and u.grid.get(*u.front_pos) is None:
+            return 4                                   # now and then drop it early, somewhere else
+        return (4 if best == [] else best[0]) if best is not None else None
+    if env_id.startswith("BabyAI-ActionObjDoor"):
+        ins = u.instrs
+        d = ins.desc
+        p = _reachable(u, lambda c, pos: c.type == d.type and c.color == d.color and not (type(ins).__name__ == "OpenInstr" and c.is_open))
+        if p is None:
+            return None
+        act = {"GoToInstr": None, "PickupInstr": 3, "OpenInstr": 5}[type(ins).__name__]
+        if p == []:
+            return act
+        return p[0]
+    if env_id.startswith("BabyAI-OpenDoor"):
+        ins = u.instrs
+        wrong = u.step_count % 11 == 3
+        targets = [tuple(o.cur_pos) for o in ins.desc.obj_set]
+        p = _reachable(u, lambda c, pos: c.type == "door" and ((pos in targets) != wrong) and not c.is_open)
+        if p is None:
+            return None
+        return 5 if p == [] else p[0]
     if env_id.startswith("MiniGrid-PutNear"):
         # fetch the object to move, carry it next to the target; now and then grab the wrong one / drop it early
         if u.carrying is None:
@@ -782,7 +829,12 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
                    "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0",
                    "BabyAI-KeyInBox-v0", "BabyAI-Unlock-v0",
-                   "BabyAI-GoToDoor-v0", "BabyAI-GoToObjDoor-v0", "BabyAI-GoToImpUnlock-v0", "BabyAI-UnblockPickup-v0", "BabyAI-PickupAbove-v0"]
+                   "BabyAI-GoToDoor-v0", "BabyAI-GoToObjDoor-v0", "BabyAI-GoToImpUnlock-v0", "BabyAI-UnblockPickup-v0", "BabyAI-PickupAbove-v0",
+                   "BabyAI-PutNextLocal-v0", "BabyAI-PutNextLocalS5N3-v0", "BabyAI-PutNextLocalS6N4-v0", "BabyAI-PutNextS4N1-v0",
+                   "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
+                   "BabyAI-PutNextS5N2Carrying-v0", "BabyAI-PutNextS6N3Carrying-v0", "BabyAI-PutNextS7N4Carrying-v0",
+                   "BabyAI-ActionObjDoor-v0", "BabyAI-OpenDoor-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-OpenDoorColor-v0",
+                   "BabyAI-OpenDoorLoc-v0"]
 
 
 def main_oracle_only():

@@ -25,6 +25,7 @@ K_UNLOCKLOCAL, K_BABYAI_KEYCORRIDOR, K_OBSTRUCTEDMAZE, K_PUTNEAR = 29, 30, 31, 3
 K_BABYAI_GOTO, K_BABYAI_PICKUP, K_BABYAI_OPEN = 33, 34, 35
 K_BABYAI_UNLOCKPICKUP, K_BABYAI_BLOCKEDUNLOCKPICKUP, K_UNLOCKTOUNLOCK, K_KEYINBOX, K_BABYAI_UNLOCK = 36, 37, 38, 39, 40
 K_BABYAI_GOTODOOR, K_GOTOOBJDOOR, K_UNBLOCKPICKUP, K_PICKUPABOVE, K_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
+K_PUTNEXTLOCAL, K_PUTNEXT, K_ACTIONOBJDOOR, K_OPENDOOR = 46, 47, 48, 49
 T_WALL, T_LAVA = 2, 9
 
 
@@ -138,6 +139,9 @@ def spec(env_id: str) -> dict:
                     room_size=6, num_crossings=int(key_in_box) | int(blocked) << 1 | int(v1) << 2 | int(one_d) << 3,
                     num_dists=num_quarters, start_x=agent_room[0], start_y=agent_room[1], missions=["pick up the blue ball"])
 
+    putnext_missions = [f"put the {c1} {t1} next to the {c2} {t2}" for c1 in color_names for t1 in ("key", "ball", "box")
+                        for c2 in color_names for t2 in ("key", "ball", "box")]
+
     table = {
         # multi-room BabyAI levels with one instruction (oracle only so far): goto.py:403-426, pickup.py:66-72, open.py:69-86;
         # max_steps = 1 * room_size**2 * rows * cols (roomgrid_level.py:71-85); rows minigrid/__init__.py:681-731, 760-763, 848-851
@@ -174,6 +178,25 @@ def spec(env_id: str) -> dict:
                                         missions=pickup_missions),
         "BabyAI-PickupAbove-v0": dict(kind=K_PICKUPABOVE, width=16, height=16, max_steps=288, see_through=0, room_size=6,
                                       missions=pickup_missions),
+        # putnext.py:68-80 (one room), :148-166 (1 x 2 rooms, max_steps 8 * room_size**2); other.py:83-106; open.py:203-229
+        **{name: dict(kind=K_PUTNEXTLOCAL, width=rs, height=rs, max_steps=2 * rs * rs, see_through=0, room_size=rs, num_dists=n,
+                      missions=putnext_missions)
+           for name, rs, n in (("BabyAI-PutNextLocal-v0", 8, 8), ("BabyAI-PutNextLocalS5N3-v0", 5, 3), ("BabyAI-PutNextLocalS6N4-v0", 6, 4))},
+        **{name: dict(kind=K_PUTNEXT, width=2 * (rs - 1) + 1, height=rs, max_steps=8 * rs * rs, see_through=0, room_size=rs, num_dists=n,
+                      num_crossings=int(carrying), missions=putnext_missions)
+           for name, rs, n, carrying in (("BabyAI-PutNextS4N1-v0", 4, 1, False), ("BabyAI-PutNextS5N2-v0", 5, 2, False),
+                                         ("BabyAI-PutNextS5N1-v0", 5, 1, False), ("BabyAI-PutNextS6N3-v0", 6, 3, False),
+                                         ("BabyAI-PutNextS7N4-v0", 7, 4, False), ("BabyAI-PutNextS5N2Carrying-v0", 5, 2, True),
+                                         ("BabyAI-PutNextS6N3Carrying-v0", 6, 3, True), ("BabyAI-PutNextS7N4Carrying-v0", 7, 4, True))},
+        "BabyAI-ActionObjDoor-v0": dict(kind=K_ACTIONOBJDOOR, width=19, height=19, max_steps=441, see_through=0, room_size=7,
+                                        missions=[f"{verb} {art} {c} {t}" for verb in ("go to", "pick up", "open") for art in ("the", "a")
+                                                  for c in color_names for t in ("key", "ball", "box", "door")]),
+        **{name: dict(kind=K_OPENDOOR, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_crossings=sel, strip2_row=int(dbg),
+                      missions=[f"open the {c} door" for c in color_names] +
+                               [f"open {art} door {loc}" for art in ("the", "a")
+                                for loc in ("on your left", "on your right", "in front of you", "behind you")])
+           for name, sel, dbg in (("BabyAI-OpenDoor-v0", 0, False), ("BabyAI-OpenDoorDebug-v0", 0, True),
+                                  ("BabyAI-OpenDoorColor-v0", 1, False), ("BabyAI-OpenDoorLoc-v0", 2, False))},
         "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
                                  missions=pickup_missions),
         "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
