@@ -119,7 +119,14 @@ MISSIONS = {
 }
 
 
+# levels whose mission space does not enumerate (sequences, random instructions): the goldens keep the strings themselves
+STRING_MISSION_PREFIXES = ("BabyAI-OpenTwoDoors", "BabyAI-OpenRedBlueDoors", "BabyAI-OpenDoorsOrder", "BabyAI-MoveTwoAcross",
+                           "BabyAI-PickupLoc", "BabyAI-GoToSeq", "BabyAI-Synth", "BabyAI-MiniBossLevel", "BabyAI-BossLevel")
+
+
 def mission_id(env_id, s):
+    if env_id.startswith(STRING_MISSION_PREFIXES):
+        return 0
     for k, v in sorted(MISSIONS.items(), key=lambda kv: -len(kv[0])):        # longest matching prefix wins
         if env_id.startswith(k):
             return v.index(s)
@@ -248,6 +255,36 @@ def _key_door_solver(u, is_target, target_action=3):
 
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
+    if env_id.startswith(("BabyAI-OpenTwoDoors", "BabyAI-OpenRedBlueDoors", "BabyAI-OpenDoorsOrder", "BabyAI-MoveTwoAcross")):
+        ins = u.instrs
+        if hasattr(ins, "instr_a"):        # the sub-instruction that is due (now and then the other one: the strict / order paths)
+            first, second = (ins.instr_a, ins.instr_b) if type(ins).__name__ == "BeforeInstr" else (ins.instr_b, ins.instr_a)
+            done_first = (ins.a_done if type(ins).__name__ == "BeforeInstr" else ins.b_done) == "success"
+            cur = second if done_first else first
+            if u.step_count % 13 == 5 and not done_first:
+                cur = second
+        else:
+            cur = ins
+        if type(cur).__name__ == "OpenInstr":
+            p = _reachable(u, lambda c, pos: c.type == "door" and c.color == cur.desc.color and not c.is_open)
+            if p is None:                  # already open: close it again so that it can be opened
+                p = _reachable(u, lambda c, pos: c.type == "door" and c.color == cur.desc.color)
+            return (5 if p == [] else p[0]) if p is not None else None
+        is_a = lambda c, pos=None: c.type == cur.desc_move.type and c.color == cur.desc_move.color
+        if u.carrying is None:
+            p = _reachable(u, is_a)
+            return (3 if p == [] else p[0]) if p is not None else None
+        if not is_a(u.carrying):
+            return 4 if u.grid.get(*u.front_pos) is None else 1
+        fixed = find(u, cur.desc_fixed.type, cur.desc_fixed.color)
+        best = None
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            cell = (fixed[0] + dx, fixed[1] + dy) if fixed is not None else (0, 0)
+            if 0 < cell[0] < u.width - 1 and 0 < cell[1] < u.height - 1 and u.grid.get(*cell) is None and tuple(u.agent_pos) != cell:
+                p = plan_to_face(u, cell)
+                if p is not None and (best is None or len(p) < len(best)):
+                    best = p
+        return (4 if best == [] else best[0]) if best is not None else None
     if env_id.startswith("BabyAI-PutNext"):
         ins = u.instrs
         is_a = lambda c, pos=None: c.type == ins.desc_move.type and c.color == ins.desc_move.color
@@ -495,7 +532,8 @@ def rollout(env_id, seed, T, mode, noise=0.25):
     arng = np.random.default_rng(10_000 + seed)
     obs, _ = env.reset(seed=seed)
     rec = dict(actions=[], obs=[obs["image"]], full=[fo.observation(obs)["image"]], dir=[obs["direction"]],
-               mission=[mission_id(env_id, obs["mission"])], reward=[], term=[], trunc=[], agent=[agent_record(env, 0)])
+               mission=[mission_id(env_id, obs["mission"])], mission_str=[obs["mission"]], reward=[], term=[], trunc=[],
+               agent=[agent_record(env, 0)])
     pending = False
     for _ in range(T):
         a = int(arng.integers(0, 7))
@@ -516,6 +554,7 @@ def rollout(env_id, seed, T, mode, noise=0.25):
         rec["full"].append(fo.observation(obs)["image"])
         rec["dir"].append(obs["direction"])
         rec["mission"].append(mission_id(env_id, obs["mission"]))
+        rec["mission_str"].append(obs["mission"])
         rec["reward"].append(float(r))
         rec["term"].append(term)
         rec["trunc"].append(trunc)
@@ -532,6 +571,8 @@ def make_rollouts(env_id, seeds, T):
         out[f"{mode}_full"] = np.array([r["full"] for r in recs], np.uint8)
         out[f"{mode}_dir"] = np.array([r["dir"] for r in recs], np.uint8)
         out[f"{mode}_mission"] = np.array([r["mission"] for r in recs], np.uint8 if max(max(r["mission"]) for r in recs) < 256 else np.uint16)
+        if env_id.startswith(STRING_MISSION_PREFIXES):
+            out[f"{mode}_mission_str"] = np.array([r["mission_str"] for r in recs])
         out[f"{mode}_reward"] = np.array([r["reward"] for r in recs], np.float64)
         out[f"{mode}_term"] = np.array([r["term"] for r in recs], bool)
         out[f"{mode}_trunc"] = np.array([r["trunc"] for r in recs], bool)
@@ -545,19 +586,24 @@ def make_rollouts(env_id, seeds, T):
 
 def make_gen(env_id, nseeds, episodes=3):
     env = gym.make(env_id)
-    grids, agents, missions = [], [], []
+    grids, agents, missions, strs = [], [], [], []
     for s in range(nseeds):
-        g, a, m = [], [], []
+        g, a, m, ms = [], [], [], []
         for ep in range(episodes):
             obs, _ = env.reset(seed=s) if ep == 0 else env.reset()
             g.append(env.unwrapped.grid.encode())
             a.append(agent_record(env, 0))
             m.append(mission_id(env_id, obs["mission"]))
+            ms.append(obs["mission"])
         grids.append(g)
         agents.append(a)
         missions.append(m)
-    return dict(grid=np.array(grids, np.uint8), agent=np.array(agents, np.int32),
-                mission=np.array(missions, np.uint8 if max(map(max, missions)) < 256 else np.uint16))
+        strs.append(ms)
+    out = dict(grid=np.array(grids, np.uint8), agent=np.array(agents, np.int32),
+               mission=np.array(missions, np.uint8 if max(map(max, missions)) < 256 else np.uint16))
+    if env_id.startswith(STRING_MISSION_PREFIXES):
+        out["mission_str"] = np.array(strs)
+    return out
 
 
 def make_rng_kat():
@@ -834,7 +880,10 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
                    "BabyAI-PutNextS5N2Carrying-v0", "BabyAI-PutNextS6N3Carrying-v0", "BabyAI-PutNextS7N4Carrying-v0",
                    "BabyAI-ActionObjDoor-v0", "BabyAI-OpenDoor-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-OpenDoorColor-v0",
-                   "BabyAI-OpenDoorLoc-v0"]
+                   "BabyAI-OpenDoorLoc-v0",
+                   "BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
+                   "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0",
+                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0"]
 
 
 def main_oracle_only():

@@ -26,6 +26,7 @@ K_BABYAI_GOTO, K_BABYAI_PICKUP, K_BABYAI_OPEN = 33, 34, 35
 K_BABYAI_UNLOCKPICKUP, K_BABYAI_BLOCKEDUNLOCKPICKUP, K_UNLOCKTOUNLOCK, K_KEYINBOX, K_BABYAI_UNLOCK = 36, 37, 38, 39, 40
 K_BABYAI_GOTODOOR, K_GOTOOBJDOOR, K_UNBLOCKPICKUP, K_PICKUPABOVE, K_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
 K_PUTNEXTLOCAL, K_PUTNEXT, K_ACTIONOBJDOOR, K_OPENDOOR = 46, 47, 48, 49
+K_OPENTWODOORS, K_OPENDOORSORDER, K_MOVETWOACROSS, K_LEVELGEN = 50, 51, 52, 53
 T_WALL, T_LAVA = 2, 9
 
 
@@ -197,6 +198,19 @@ def spec(env_id: str) -> dict:
                                 for loc in ("on your left", "on your right", "in front of you", "behind you")])
            for name, sel, dbg in (("BabyAI-OpenDoor-v0", 0, False), ("BabyAI-OpenDoorDebug-v0", 0, True),
                                   ("BabyAI-OpenDoorColor-v0", 1, False), ("BabyAI-OpenDoorLoc-v0", 2, False))},
+        # open.py:289-325, :383-425 (room_size 6, max_steps 20 * 36); other.py:388-428 (1 x 2 rooms, max_steps 16 * room_size**2).
+        # Their missions are sentences ("..., then ...", "... after you ..."): OracleVec.mission_strings()
+        **{name: dict(kind=K_OPENTWODOORS, width=16, height=16, max_steps=720, see_through=0, room_size=6, start_x=c1, start_y=c2,
+                      strip2_row=int(strict), missions=[""])
+           for name, c1, c2, strict in (("BabyAI-OpenTwoDoors-v0", -1, -1, False), ("BabyAI-OpenRedBlueDoors-v0", 4, 0, False),
+                                        ("BabyAI-OpenRedBlueDoorsDebug-v0", 4, 0, True))},
+        **{name: dict(kind=K_OPENDOORSORDER, width=16, height=16, max_steps=720, see_through=0, room_size=6, num_dists=n,
+                      strip2_row=int(dbg), missions=[""])
+           for name, n, dbg in (("BabyAI-OpenDoorsOrderN2-v0", 2, False), ("BabyAI-OpenDoorsOrderN4-v0", 4, False),
+                                ("BabyAI-OpenDoorsOrderN2Debug-v0", 2, True), ("BabyAI-OpenDoorsOrderN4Debug-v0", 4, True))},
+        **{name: dict(kind=K_MOVETWOACROSS, width=2 * (rs - 1) + 1, height=rs, max_steps=16 * rs * rs, see_through=0, room_size=rs,
+                      num_dists=n, missions=[""])
+           for name, rs, n in (("BabyAI-MoveTwoAcrossS5N2-v0", 5, 2), ("BabyAI-MoveTwoAcrossS8N9-v0", 8, 9))},
         "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
                                  missions=pickup_missions),
         "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
@@ -317,7 +331,7 @@ def lib():
         L.oracle_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         for f in (L.oracle_get_state, L.oracle_set_state):
             f.argtypes = [vp, vp, vp]
-        for f in (L.oracle_get_rng, L.oracle_set_rng, L.oracle_get_missions):
+        for f in (L.oracle_get_rng, L.oracle_set_rng, L.oracle_get_missions, L.oracle_get_mission_strs):
             f.argtypes = [vp, vp]
         L.oracle_rng_kat.argtypes = [C.c_uint64, vp, vp, C.c_int, vp, C.c_int, C.c_int64]
         L.oracle_shuffle_kat.argtypes = [C.c_uint64, vp, C.c_int]
@@ -380,6 +394,12 @@ class OracleVec:
         out = np.zeros(self.n, np.int32)
         lib().oracle_get_missions(self.h, _p(out))
         return out.astype(np.uint16)
+
+    def mission_strings(self):
+        """Instr.surface() per env, for the levels whose missions are sentences (kinds on the general verifier)."""
+        buf = np.zeros((self.n, 256), np.uint8)
+        lib().oracle_get_mission_strs(self.h, _p(buf))
+        return np.array([bytes(r).split(b"\0", 1)[0].decode() for r in buf])
 
     def _frame(self, obs):
         if not self.rgb:

@@ -67,7 +67,10 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
                    "BabyAI-PutNextS5N2Carrying-v0", "BabyAI-PutNextS6N3Carrying-v0", "BabyAI-PutNextS7N4Carrying-v0",
                    "BabyAI-ActionObjDoor-v0", "BabyAI-OpenDoor-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-OpenDoorColor-v0",
-                   "BabyAI-OpenDoorLoc-v0"]
+                   "BabyAI-OpenDoorLoc-v0",
+                   "BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
+                   "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0",
+                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0"]
 
 
 def full_obs_supported(env_id: str) -> bool:

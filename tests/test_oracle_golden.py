@@ -73,6 +73,8 @@ def test_generators_match_reference(env_id):
         assert (grid == g["grid"][:, ep]).all(), (env_id, ep)
         assert (agent[:, :6] == g["agent"][:, ep, :6]).all(), (env_id, ep)
         assert (mission == g["mission"][:, ep]).all()
+        if "mission_str" in g:
+            assert (v.mission_strings() == g["mission_str"][:, ep]).all(), (env_id, ep)
 
 
 @pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS)
@@ -97,6 +99,8 @@ def test_rollouts_match_reference(env_id, mode, full):
         assert (d == g[f"{mode}_dir"][:, t + 1]).all() and (m == g[f"{mode}_mission"][:, t + 1]).all()
         _, agent = v.get_state()
         assert (agent[:, :7] == g[f"{mode}_agent"][:, t + 1, :7]).all(), (env_id, t)
+        if f"{mode}_mission_str" in g:
+            assert (v.mission_strings() == g[f"{mode}_mission_str"][:, t + 1]).all(), (env_id, t)
 
 
 @pytest.mark.parametrize("env_id", MAIN_IDS)
