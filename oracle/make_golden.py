@@ -191,27 +191,55 @@ def find(u, type_, color=None):
 
 def _door_action(u, locked_ok):
     """Head for / toggle a closed door the BFS can reach (it treats closed doors as walls), or None."""
+    targets = set()
     for i in range(u.width):
         for j in range(u.height):
             c = u.grid.get(i, j)
             if c is not None and c.type == "door" and not c.is_open and (locked_ok or not c.is_locked):
-                q = plan_to_face(u, (i, j))
-                if q is not None:
-                    return 5 if q == [] else q[0]
-    return None
+                targets.add((i, j))
+    q = plan_to_face_any(u, targets)
+    if q is None:
+        return None
+    return 5 if q == [] else q[0]
+
+
+def plan_to_face_any(u, targets):
+    """One BFS over (x, y, dir) to the nearest state facing any cell of `targets` (a set).  Returns a list of actions."""
+    if not targets:
+        return None
+    DIRS = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+    start = (int(u.agent_pos[0]), int(u.agent_pos[1]), int(u.agent_dir))
+    prev = {start: None}
+    q = deque([start])
+    while q:
+        s = q.popleft()
+        x, y, d = s
+        if (x + DIRS[d][0], y + DIRS[d][1]) in targets:
+            break
+        for a, ns in ((0, (x, y, (d + 3) % 4)), (1, (x, y, (d + 1) % 4)), (2, (x + DIRS[d][0], y + DIRS[d][1], d))):
+            if a == 2 and not (0 <= ns[0] < u.width and 0 <= ns[1] < u.height and _passable(u, ns[0], ns[1])):
+                continue
+            if ns not in prev:
+                prev[ns] = (s, a)
+                q.append(ns)
+    else:
+        return None
+    acts = []
+    while prev[s] is not None:
+        s, a = prev[s]
+        acts.append(a)
+    return acts[::-1]
 
 
 def _reachable(u, pred):
-    """Plan to face the nearest cell whose object satisfies pred, or None."""
-    best = None
+    """Plan to face the nearest cell whose object satisfies pred, or None (one BFS for all candidates)."""
+    targets = set()
     for i in range(u.width):
         for j in range(u.height):
             c = u.grid.get(i, j)
             if c is not None and pred(c, (i, j)):
-                p = plan_to_face(u, (i, j))
-                if p is not None and (best is None or len(p) < len(best)):
-                    best = p
-    return best
+                targets.add((i, j))
+    return plan_to_face_any(u, targets)
 
 
 def _key_door_solver(u, is_target, target_action=3):
@@ -255,6 +283,48 @@ def _key_door_solver(u, is_target, target_action=3):
 
 def solver_action(env_id, u):
     """Next scripted action for the current state, or None."""
+    if env_id.startswith(("BabyAI-PickupLoc", "BabyAI-GoToSeq", "BabyAI-Synth", "BabyAI-MiniBossLevel", "BabyAI-BossLevel")):
+        def due(ins):                      # the action instruction the verifier is waiting for
+            name = type(ins).__name__
+            if name == "BeforeInstr":
+                return due(ins.instr_b) if ins.a_done == "success" else due(ins.instr_a)
+            if name == "AfterInstr":
+                return due(ins.instr_a) if ins.b_done == "success" else due(ins.instr_b)
+            if name == "AndInstr":
+                return due(ins.instr_b) if ins.a_done == "success" else due(ins.instr_a)
+            return ins
+        cur = due(u.instrs)
+        name = type(cur).__name__
+        in_set = lambda objs: (lambda c, pos: any(c is o for o in objs))
+        if name == "PutNextInstr":
+            movable = cur.desc_move.obj_set
+            if u.carrying is None or not any(u.carrying is o for o in movable):
+                if u.carrying is not None:
+                    return 4 if u.grid.get(*u.front_pos) is None else 1
+                return _key_door_solver(u, in_set(movable))
+            best = None
+            for fx_, fy_ in cur.desc_fixed.obj_poss:
+                for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                    cell = (fx_ + dx, fy_ + dy)
+                    if 0 < cell[0] < u.width - 1 and 0 < cell[1] < u.height - 1 and u.grid.get(*cell) is None and tuple(u.agent_pos) != cell:
+                        p = plan_to_face(u, cell)
+                        if p is not None and (best is None or len(p) < len(best)):
+                            best = p
+            if best is not None:
+                return 4 if best == [] else best[0]
+            return _door_action(u, False)
+        objs = cur.desc.obj_set
+        if name == "GoToInstr":
+            p = _reachable(u, in_set(objs))
+            if p is not None and u.carrying is None:
+                return p[0] if p else 1
+            return _key_door_solver(u, lambda c, pos: False)
+        if name == "PickupInstr":
+            return _key_door_solver(u, in_set(objs))
+        # OpenInstr: a door of the set that is not open yet (with the key in hand when it is locked)
+        return _key_door_solver(u, lambda c, pos: any(c is o for o in objs) and not c.is_open
+                                and (not c.is_locked or (u.carrying is not None and u.carrying.type == "key" and u.carrying.color == c.color)),
+                                target_action=5)
     if env_id.startswith(("BabyAI-OpenTwoDoors", "BabyAI-OpenRedBlueDoors", "BabyAI-OpenDoorsOrder", "BabyAI-MoveTwoAcross")):
         ins = u.instrs
         if hasattr(ins, "instr_a"):        # the sub-instruction that is due (now and then the other one: the strict / order paths)
@@ -532,7 +602,7 @@ def rollout(env_id, seed, T, mode, noise=0.25):
     arng = np.random.default_rng(10_000 + seed)
     obs, _ = env.reset(seed=seed)
     rec = dict(actions=[], obs=[obs["image"]], full=[fo.observation(obs)["image"]], dir=[obs["direction"]],
-               mission=[mission_id(env_id, obs["mission"])], mission_str=[obs["mission"]], reward=[], term=[], trunc=[],
+               mission=[mission_id(env_id, obs["mission"])], mission_str=[obs["mission"]], max_steps_t=[env.unwrapped.max_steps], reward=[], term=[], trunc=[],
                agent=[agent_record(env, 0)])
     pending = False
     for _ in range(T):
@@ -555,6 +625,7 @@ def rollout(env_id, seed, T, mode, noise=0.25):
         rec["dir"].append(obs["direction"])
         rec["mission"].append(mission_id(env_id, obs["mission"]))
         rec["mission_str"].append(obs["mission"])
+        rec["max_steps_t"].append(env.unwrapped.max_steps)
         rec["reward"].append(float(r))
         rec["term"].append(term)
         rec["trunc"].append(trunc)
@@ -573,6 +644,7 @@ def make_rollouts(env_id, seeds, T):
         out[f"{mode}_mission"] = np.array([r["mission"] for r in recs], np.uint8 if max(max(r["mission"]) for r in recs) < 256 else np.uint16)
         if env_id.startswith(STRING_MISSION_PREFIXES):
             out[f"{mode}_mission_str"] = np.array([r["mission_str"] for r in recs])
+            out[f"{mode}_max_steps"] = np.array([r["max_steps_t"] for r in recs], np.int32)
         out[f"{mode}_reward"] = np.array([r["reward"] for r in recs], np.float64)
         out[f"{mode}_term"] = np.array([r["term"] for r in recs], bool)
         out[f"{mode}_trunc"] = np.array([r["trunc"] for r in recs], bool)
@@ -585,9 +657,9 @@ def make_rollouts(env_id, seeds, T):
 
 
 def make_gen(env_id, nseeds, episodes=3):
-    env = gym.make(env_id)
     grids, agents, missions, strs = [], [], [], []
     for s in range(nseeds):
+        env = gym.make(env_id)          # one env per seed, like one slot of the vector env (LevelGen keeps state across resets)
         g, a, m, ms = [], [], [], []
         for ep in range(episodes):
             obs, _ = env.reset(seed=s) if ep == 0 else env.reset()
@@ -883,7 +955,10 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
                    "BabyAI-OpenDoorLoc-v0",
                    "BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
                    "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0",
-                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0"]
+                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0",
+                   "BabyAI-PickupLoc-v0", "BabyAI-GoToSeq-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-Synth-v0",
+                   "BabyAI-SynthLoc-v0", "BabyAI-SynthSeq-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-BossLevel-v0",
+                   "BabyAI-BossLevelNoUnlock-v0"]
 
 
 def main_oracle_only():

@@ -140,6 +140,12 @@ def spec(env_id: str) -> dict:
                     room_size=6, num_crossings=int(key_in_box) | int(blocked) << 1 | int(v1) << 2 | int(one_d) << 3,
                     num_dists=num_quarters, start_x=agent_room[0], start_y=agent_room[1], missions=["pick up the blue ball"])
 
+    def levelgen(rs, rows, cols, num_dists, action_kinds, instr_kinds, locations, unblocking, implicit_unlock, locked_pct):
+        return dict(kind=K_LEVELGEN, width=cols * (rs - 1) + 1, height=rows * (rs - 1) + 1, max_steps=rs * rs * rows * cols, see_through=0,
+                    room_size=rs, num_dists=num_dists, strip2_row=locked_pct,
+                    num_crossings=action_kinds | instr_kinds << 4 | int(locations) << 7 | int(unblocking) << 8 | int(implicit_unlock) << 9,
+                    missions=[""])
+
     putnext_missions = [f"put the {c1} {t1} next to the {c2} {t2}" for c1 in color_names for t1 in ("key", "ball", "box")
                         for c2 in color_names for t2 in ("key", "ball", "box")]
 
@@ -211,6 +217,20 @@ def spec(env_id: str) -> dict:
         **{name: dict(kind=K_MOVETWOACROSS, width=2 * (rs - 1) + 1, height=rs, max_steps=16 * rs * rs, see_through=0, room_size=rs,
                       num_dists=n, missions=[""])
            for name, rs, n in (("BabyAI-MoveTwoAcrossS5N2-v0", 5, 2), ("BabyAI-MoveTwoAcrossS8N9-v0", 8, 9))},
+        # LevelGen (levelgen.py:24-80) configurations: pickup.py:198-213, goto.py:590-606, synth.py:83-97, :168-178, :274-281,
+        # :374-382, :476-480, :570-576.  max_steps is per episode (num_navs * room_size**2 * rooms); the value here is the 1-nav one
+        **{name: levelgen(rs, rows, cols, nd, acts, kinds, loc, unb, imp, prob)
+           for name, rs, rows, cols, nd, acts, kinds, loc, unb, imp, prob in (
+               ("BabyAI-PickupLoc-v0", 8, 1, 1, 8, 0b0010, 0b001, True, False, True, 0),
+               ("BabyAI-GoToSeq-v0", 8, 3, 3, 18, 0b0001, 0b111, False, False, True, 0),
+               ("BabyAI-GoToSeqS5R2-v0", 5, 2, 2, 4, 0b0001, 0b111, False, False, True, 0),
+               ("BabyAI-Synth-v0", 8, 3, 3, 18, 0b1111, 0b001, False, True, False, 50),
+               ("BabyAI-SynthS5R2-v0", 5, 2, 3, 18, 0b1111, 0b001, False, True, False, 50),
+               ("BabyAI-SynthLoc-v0", 8, 3, 3, 18, 0b1111, 0b001, True, True, False, 50),
+               ("BabyAI-SynthSeq-v0", 8, 3, 3, 18, 0b1111, 0b111, True, True, False, 50),
+               ("BabyAI-MiniBossLevel-v0", 5, 2, 2, 7, 0b1111, 0b111, True, True, True, 25),
+               ("BabyAI-BossLevel-v0", 8, 3, 3, 18, 0b1111, 0b111, True, True, True, 50),
+               ("BabyAI-BossLevelNoUnlock-v0", 8, 3, 3, 18, 0b1111, 0b111, True, True, False, 0))},
         "BabyAI-Pickup-v0": dict(kind=K_BABYAI_PICKUP, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,
                                  missions=pickup_missions),
         "BabyAI-Open-v0": dict(kind=K_BABYAI_OPEN, width=22, height=22, max_steps=576, see_through=0, room_size=8, num_dists=18,

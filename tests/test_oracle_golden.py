@@ -87,7 +87,8 @@ def test_rollouts_match_reference(env_id, mode, full):
     S, T = acts.shape
     want_obs = g[f"{mode}_full"] if full else g[f"{mode}_obs"]
     v = O.OracleVec(env_id, S, full_obs=full)
-    assert v.cfg.max_steps == int(g["max_steps"])
+    if f"{mode}_max_steps" not in g:              # LevelGen levels recompute max_steps per episode from the instruction
+        assert v.cfg.max_steps == int(g["max_steps"])
     obs, d, m = v.reset(seeds=seeds)
     assert (obs == want_obs[:, 0]).all()
     assert (d == g[f"{mode}_dir"][:, 0]).all() and (m == g[f"{mode}_mission"][:, 0]).all()
