@@ -245,6 +245,18 @@ _ROWS = [
                   "minigrid.envs:BlockedUnlockPickupEnv"),
 ]
 
+# registrations that rely on the classes' defaults (minigrid/__init__.py:36-39, 226-229, 240-244, 131-134, 584-587): the rows
+# above spell the defaults out; the registered kwargs / entry points are these
+_AS_REGISTERED = {
+    "MiniGrid-Empty-8x8-v0": ("minigrid.envs:EmptyEnv", {}),
+    "MiniGrid-Fetch-8x8-N3-v0": ("minigrid.envs:FetchEnv", {}),
+    "MiniGrid-GoToObject-6x6-N2-v0": ("minigrid.envs:GoToObjectEnv", {}),
+    "MiniGrid-GoToDoor-5x5-v0": ("minigrid.envs:GoToDoorEnv", {}),
+    "MiniGrid-Dynamic-Obstacles-8x8-v0": ("minigrid.envs:DynamicObstaclesEnv", {}),
+    "BabyAI-GoToRedBallNoDists-v0": ("minigrid.envs.babyai:GoToRedBallNoDists", {}),
+}
+_ROWS = [replace(r, entry_point=_AS_REGISTERED[r.id][0], kwargs=_AS_REGISTERED[r.id][1]) if r.id in _AS_REGISTERED else r for r in _ROWS]
+
 registry: Dict[str, EnvSpec] = {r.id: r for r in _ROWS}
 
 

@@ -968,6 +968,27 @@ def main_oracle_only():
         print("done", env_id, flush=True)
 
 
+def main_registry():
+    """tests/golden/reference_registry.json: every registered id with its entry point, kwargs and the geometry of an
+    instantiated env -- what minigrid_amd/registry.py and oracle.spec() are checked against."""
+    import json
+    from gymnasium.envs.registration import registry
+    rows = {}
+    for env_id, spec in sorted(registry.items()):
+        if not env_id.startswith(("MiniGrid-", "BabyAI-")) or "WFC" in env_id or env_id == "BabyAI-SynthS5R2-v0":
+            # WFC needs the absent imageio package (out of scope, SURVEY.md); SynthS5R2: the reference can hang (DESIGN.md)
+            continue
+        u = gym.make(env_id).unwrapped
+        dynamic = hasattr(u, "fixed_max_steps") and not u.fixed_max_steps      # RoomGridLevel.reset recomputes it from the instruction
+        u.reset(seed=0)
+        rows[env_id] = dict(entry_point=spec.entry_point, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in spec.kwargs.items()},
+                            width=int(u.width), height=int(u.height), max_steps=int(u.max_steps), max_steps_per_episode=bool(dynamic),
+                            see_through_walls=bool(u.see_through_walls), agent_view_size=int(u.agent_view_size))
+    with open(os.path.join(OUT, "reference_registry.json"), "w") as f:
+        json.dump(rows, f, indent=0, sort_keys=True)
+    print("registry rows", len(rows))
+
+
 def main_wide():
     for env_id in WIDE_IDS:
         np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 3, 1337], 260))
@@ -983,6 +1004,8 @@ def main():
         return main_wrappers()
     if len(sys.argv) > 1 and sys.argv[1] == "rgb":
         return main_rgb()
+    if len(sys.argv) > 1 and sys.argv[1] == "registry":
+        return main_registry()
     if len(sys.argv) > 1 and sys.argv[1] == "oracle_only":
         return main_oracle_only()
     np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
@@ -1000,6 +1023,7 @@ def main():
     main_wrappers()
     main_rgb()
     main_oracle_only()
+    main_registry()
 
 
 if __name__ == "__main__":

@@ -207,6 +207,29 @@ def test_registry_rows_are_consistent():
         assert s.entry_point.startswith("minigrid.envs")
 
 
+def test_registry_and_oracle_tables_match_the_reference_registry():
+    """tests/golden/reference_registry.json is written by oracle/make_golden.py from the reference's own registry and
+    instantiated envs: entry point, kwargs, grid size, max_steps, see_through_walls of every id."""
+    import json
+    import os
+
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_registry.json")))
+    assert len(ref) == 171
+    for env_id, s in mg.registry.items():
+        r = ref[env_id]
+        assert s.entry_point == r["entry_point"], env_id
+        assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in s.kwargs.items()} == r["kwargs"], (env_id, s.kwargs, r["kwargs"])
+        assert (s.width, s.height, s.max_steps, bool(s.see_through_walls)) == (r["width"], r["height"], r["max_steps"], r["see_through_walls"]), env_id
+        assert r["agent_view_size"] == 7
+    for env_id, r in ref.items():
+        o = O.spec(env_id)
+        assert (o["width"], o["height"], bool(o["see_through"])) == (r["width"], r["height"], r["see_through_walls"]), env_id
+        if o["kind"] != O.K_LEVELGEN:                     # LevelGen levels: max_steps depends on the drawn instruction
+            assert o["max_steps"] == r["max_steps"], (env_id, o["max_steps"], r["max_steps"])
+
+
 def test_library_tile_atlas_matches_every_reference_tile():
     """mg_render_tiles is the host routine mg_create fills the RGB atlas with (mg_tiles.h): all 510 tiles x 4 tile sizes
     against tiles rendered by the reference's Grid.render_tile (tests/golden/rgb_atlas.npz)."""
