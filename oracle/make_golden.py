@@ -981,7 +981,13 @@ def main_registry():
         u = gym.make(env_id).unwrapped
         dynamic = hasattr(u, "fixed_max_steps") and not u.fixed_max_steps      # RoomGridLevel.reset recomputes it from the instruction
         u.reset(seed=0)
-        rows[env_id] = dict(entry_point=spec.entry_point, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in spec.kwargs.items()},
+        seen = {}
+        if not env_id.startswith(STRING_MISSION_PREFIXES):      # mission id (position in the tables here) -> the reference's string
+            env = gym.make(env_id)
+            for sd in range(48):
+                obs, _ = env.reset(seed=sd)
+                seen[str(mission_id(env_id, obs["mission"]))] = obs["mission"]
+        rows[env_id] = dict(missions_seen=seen, entry_point=spec.entry_point, kwargs={k: (list(v) if isinstance(v, tuple) else v) for k, v in spec.kwargs.items()},
                             width=int(u.width), height=int(u.height), max_steps=int(u.max_steps), max_steps_per_episode=bool(dynamic),
                             see_through_walls=bool(u.see_through_walls), agent_view_size=int(u.agent_view_size))
     with open(os.path.join(OUT, "reference_registry.json"), "w") as f:

@@ -223,8 +223,12 @@ def test_registry_and_oracle_tables_match_the_reference_registry():
         assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in s.kwargs.items()} == r["kwargs"], (env_id, s.kwargs, r["kwargs"])
         assert (s.width, s.height, s.max_steps, bool(s.see_through_walls)) == (r["width"], r["height"], r["max_steps"], r["see_through_walls"]), env_id
         assert r["agent_view_size"] == 7
+        for mid, text in r["missions_seen"].items():      # the mission strings the reference produced, by mission id
+            assert s.missions[int(mid)] == text, (env_id, mid)
     for env_id, r in ref.items():
         o = O.spec(env_id)
+        for mid, text in r["missions_seen"].items():
+            assert o["missions"][int(mid)] == text, (env_id, mid)
         assert (o["width"], o["height"], bool(o["see_through"])) == (r["width"], r["height"], r["see_through_walls"]), env_id
         if o["kind"] != O.K_LEVELGEN:                     # LevelGen levels: max_steps depends on the drawn instruction
             assert o["max_steps"] == r["max_steps"], (env_id, o["max_steps"], r["max_steps"])
