@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="empty8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--fused", type=int, default=0, help="use the fused multi-step rollout kernel")
+    ap.add_argument("--fused", type=int, default=0, help="accepted for compatibility: the library always launches one k_step per step")
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
     ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic|rgb|rgb_partial")
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
@@ -255,7 +255,7 @@ def main():
             "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
                        "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
-                       "launch": "fused-rollout" if args.fused else "one k_step launch per step",
+                       "launch": "one k_step launch per step" + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
