@@ -175,7 +175,16 @@ def _cfg(**kw):
                                  dict(env_kind=13, width=8, height=8),                   # Memory needs an odd size
                                  dict(env_kind=12, width=8, height=8),                   # RedBlueDoors: width = 2 * height
                                  dict(env_kind=9, width=11, height=6, room_size=5),      # Unlock: inconsistent room size
-                                 dict(env_kind=19, width=9, height=9, num_dists=3)])     # GoToLocal: room_size <= 8
+                                 dict(env_kind=19, width=9, height=9, num_dists=3),      # GoToLocal: room_size <= 8
+                                 dict(obs_mode=5, tile_size=6),                          # RGB: tile_size in 4, 8, 12, 16
+                                 dict(obs_mode=4, tile_size=8, agent_view_size=5),       # RGB: default view only
+                                 dict(env_kind=23, width=25, height=25, room_size=10, num_crossings=2, num_dists=7),   # MultiRoom: <= 6 rooms
+                                 dict(env_kind=23, width=25, height=25, room_size=3, num_crossings=2, num_dists=2),    # maxRoomSize >= 4
+                                 dict(env_kind=28, width=13, height=13, room_size=6),    # FindObj: 3*(room_size-1)+1
+                                 dict(env_kind=26, width=9, height=6, room_size=5),      # OpenRedDoor: height = room_size
+                                 dict(env_kind=24, width=7, height=8),                   # PickupDist: one square room
+                                 dict(env_kind=29, width=22, height=22, room_size=8, num_dists=9),      # UnlockLocal: <= 8 distractors
+                                 dict(env_kind=20, width=8, height=8, num_dists=0)])     # GoToObject: numObjs >= 1
 def test_mg_create_rejects_bad_configs_before_touching_a_device(bad):
     """Validation comes first (MG_ERR_INVALID with a message); only a valid config gets as far as the device check,
     which on this GPU-less box answers MG_ERR_NO_DEVICE -- there is no CPU fallback to fall into."""
