@@ -255,3 +255,22 @@ def test_library_tile_atlas_matches_every_reference_tile():
         assert L.mg_render_tiles(int(ts), out.ctypes.data) == 0
         assert (out == want).all(), ts
     assert L.mg_render_tiles(0, out.ctypes.data) != 0
+
+
+def test_golden_generator_id_lists_match_the_test_lists():
+    """oracle/make_golden.py (which needs the reference to import) and tests/conftest.py each spell the env id lists out:
+    read the generator's lists with ast and compare."""
+    import ast
+    import os
+
+    import conftest
+    src = open(os.path.join(os.path.dirname(__file__), "..", "oracle", "make_golden.py")).read()
+    lists = {}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            name = node.targets[0].id
+            if name in ("MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "ORACLE_ONLY_IDS"):
+                lists[name] = ast.literal_eval(node.value)
+    for name, ids in lists.items():
+        assert ids == getattr(conftest, name), name
+    assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "ORACLE_ONLY_IDS"}
