@@ -154,6 +154,13 @@ def cpu_baseline(env_id: str, obs_mode: str, budget_s: float = 10.0):
                       f"(oracle/minigrid_oracle.c), xorshift random actions, NEXT_STEP autoreset, {dt:.1f}s"}
 
 
+def np_prod(shape):
+    p = 1
+    for v in shape:
+        p *= int(v)
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,7 +168,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="empty8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
-    ap.add_argument("--fused", type=int, default=0, help="accepted for compatibility: the library always launches one k_step per step")
+    ap.add_argument("--fused", type=int, default=1, help="1: the fused rollout kernel (up to max_fused_steps steps per k_step launch, "
+                    "grids resident in LDS, every step's outputs to its own trajectory slot); 0: one k_step launch per step")
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
     ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic|rgb|rgb_partial")
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
@@ -207,12 +215,14 @@ def main():
     else:
         senv = None
         env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
+    fused = bool(args.fused) and not gather
+    spl = env.max_fused_steps if fused else 1          # steps per k_step launch
     env.reset(seed=0)
     env.sync()
 
     def run(k, seed):
         if not gather:
-            env.rollout(k, action_seed=seed, fused=bool(args.fused))
+            env.rollout(k, action_seed=seed, fused=fused)
         else:
             img = env.torch_outputs()["image"]
             for _ in range(k):
@@ -246,8 +256,14 @@ def main():
         total_envs = n_per_gpu * world
         value = total_envs * args.steps / dt
         bpe = algorithmic_bytes_per_env_step(env_id, obs_mode, env.width, env.height, args.view)
-        launch_s = (ev_ms / 1e3) / args.steps           # average k_step launch period on its stream (HIP events)
-        achieved = n_per_gpu * bpe / launch_s / 1e9
+        n_launch = -(-args.steps // spl)
+        launch_s = (ev_ms / 1e3) / n_launch             # average k_step launch period on its stream (HIP events)
+        step_s = (ev_ms / 1e3) / args.steps
+        achieved = n_per_gpu * bpe / step_s / 1e9       # = algorithmic bytes per launch / launch period
+        obe = int(np_prod(env.image_shape))
+        # what a fused launch has to move per env-step: the outputs (obs + reward 8 + 5 flag/id bytes); the grid and the
+        # agent record are read and written once per launch, not per step
+        hbm_min = obe + 13 + (2 * (env.width * env.height) + 16) / spl
         out = {
             "metric": "env-steps/s (random policy)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -255,13 +271,20 @@ def main():
             "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
                        "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
-                       "launch": "one k_step launch per step" + (" + one k_render" if obs_mode.startswith("rgb") else ""),
+                       "launch": (f"fused: {spl} steps per k_step launch, state resident in LDS, each step's outputs to its own trajectory slot"
+                                  if spl > 1 else "one k_step launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
+                       "steps_per_launch": spl,
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
                          "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_bytes_per_launch": bpe * n_per_gpu,
-                         "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6},
+                         "algorithmic_bytes_per_launch": bpe * n_per_gpu * spl,
+                         "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
+                         "hbm_bytes_per_env_step_this_kernel": hbm_min,
+                         "frac_of_peak_on_actual_bytes": n_per_gpu * hbm_min / step_s / 1e9 / HBM_PEAK_GBPS,
+                         "note": "achieved/frac price the SURVEY 8(d) algorithmic bytes (the reference's 3 B/cell grid re-read "
+                                 "every step); the fused kernel keeps the grid in LDS, so its real HBM traffic per env-step is "
+                                 "hbm_bytes_per_env_step_this_kernel and the bound it actually runs against is the HBM WRITE stream"},
         }
         if not args.no_cpu_baseline and world == 1:
             if obs_mode.startswith("rgb"):

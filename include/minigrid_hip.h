@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MG_API __attribute__((visibility("default")))
@@ -137,9 +137,15 @@ typedef struct mg_config {
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
   int32_t tile_size;          /* RGB modes: pixels per cell, 4 | 8 | 12 | 16 (wrappers.py:305, 355: default 8); else ignored */
   int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
+  int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..64); 0 = default (16)                */
+  int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (16, fewer when a slot is large)     */
 } mg_config;
 
-/* Borrowed device pointers to the outputs of the last step/reset. */
+/* Borrowed device pointers to the outputs of the last step/reset = slot 0 of the trajectory ring.  The ring has
+ * traj_slots slots of slot_bytes each; slot k holds the outputs of the step k calls before the last one (as far as
+ * the last mg_rollout / mg_step_many call reaches), at every pointer below + k * slot_bytes.  The first record_bytes of a
+ * slot, starting at `obs`, are one contiguous record {obs | reward | terminated | truncated | direction | mission_id |
+ * action}: a multi-GPU consumer moves a whole step with ONE all-gather. */
 typedef struct mg_outputs {
   uint8_t* obs;         /* (N, V,V,3) | (N, W,H,3) | (N, V,V,20) u8, (N, W,H,3) i8 or an RGB frame, C-contiguous */
   double* reward;       /* (N) f64: 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245) */
@@ -149,6 +155,11 @@ typedef struct mg_outputs {
   uint8_t* mission_id;  /* (N) u8 index into the config's mission-string table (obs["mission"])       */
   int64_t obs_bytes_per_env;
   int64_t num_envs;
+  uint8_t* action;      /* (N) u8 the action the step applied (device-policy rollouts record it here)   */
+  int64_t traj_slots;
+  int64_t slot_bytes;
+  int64_t record_bytes;
+  int64_t max_fused_steps; /* steps one k_step launch of mg_rollout(fused) / mg_step_many runs */
 } mg_outputs;
 
 typedef struct mg_env mg_env;
@@ -169,17 +180,23 @@ MG_API int mg_reset(mg_env* env, const uint64_t* seeds, const uint8_t* mask);
 MG_API int mg_step(mg_env* env, const void* actions, int dtype, int on_device);
 
 /* T steps under a uniform-random policy generated on the device (Philox4x32-10 keyed by action_seed, global env
- * index and step number) — the benchmark loop of minigrid/benchmark.py:39-40 with random actions.
- * Every step writes its full outputs exactly as mg_step does (one k_step launch per step, so a policy could read
- * them between steps).  `fused` is reserved for a multi-step single-launch variant and is currently ignored. */
+ * index and step number) — the benchmark loop of minigrid/benchmark.py:36-43 with random actions.
+ * fused = 0: one k_step launch per step, every step writing slot 0 exactly as mg_step does.
+ * fused = 1: up to max_fused_steps steps per launch with the grids resident in LDS; step j of the call writes its full
+ * outputs (and the action it applied) to trajectory slot (T-1-j) mod traj_slots, so the last step is in slot 0. */
 MG_API int mg_rollout(mg_env* env, int T, uint64_t action_seed, int fused);
+/* The same fused loop for actions the caller supplies: u8 [T][N], host or device.  Identical results to T mg_step calls. */
+MG_API int mg_step_many(mg_env* env, const uint8_t* actions, int T, int on_device);
 
 MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
 /* Synchronises the stream, then copies whichever destinations are non-NULL to host memory.
  * Also surfaces device-side error flags (MG_ERR_BAD_ACTION / MG_ERR_GENERATOR / MG_ERR_OOB). */
 MG_API int mg_copy_outputs(mg_env* env, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
                     uint8_t* direction, uint8_t* mission_id);
-MG_API int mg_sync(mg_env* env);        /* hipStreamSynchronize + error-flag check */
+/* mg_copy_outputs for trajectory slot `slot` (0 = the last step), plus the recorded actions. */
+MG_API int mg_copy_slot(mg_env* env, int slot, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
+                 uint8_t* direction, uint8_t* mission_id, uint8_t* action);
+MG_API int mg_sync(mg_env* env);        /* synchronises the handle's streams (steps AND episode generation) + error-flag check */
 
 /* State exchange (checkpoint/resume and parity-harness state injection).
  *   grid : (N, W, H, 3) u8 in Grid.encode() layout (core/grid.py:244-268), decoded like Grid.decode (270-289)
@@ -208,6 +225,9 @@ MG_API int mg_device_count(void);
 MG_API int mg_selftest_vis_row(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_vis_row_n(int32_t view, uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_reward_lut(int32_t max_steps, double* out /* [max_steps+1] */);
+/* k_step's observation stream packer (StreamEmit, mg_kernels.h) run lane by lane on the host: `in` = nenv x obe bytes,
+ * each env's bytes handed over as little-endian dwords; `out` must reproduce them as one contiguous stream. */
+MG_API int mg_selftest_stream(int32_t obe, int32_t nenv, const uint8_t* in, uint8_t* out);
 /* Grid.render_tile (core/grid.py:145-198) for every tile of the RGB atlas, as the library renders it at mg_create:
  * out[51][5][2][tile_size][tile_size][3] = [tile key][no agent, agent_dir 0..3][plain, highlighted]; tile keys are
  * empty 0 | wall 1+c | floor 7+c | key 13+c | ball 19+c | box 25+c | door 31+3c+state | goal 49 | lava 50. */

@@ -7,7 +7,7 @@ import os
 
 from . import build as _build
 
-MG_ABI_VERSION = 1
+MG_ABI_VERSION = 2
 MG_OK, MG_ERR_INVALID, MG_ERR_HIP, MG_ERR_BAD_ACTION, MG_ERR_GENERATOR, MG_ERR_NO_DEVICE, MG_ERR_OOB = 0, -1, -2, -3, -4, -5, -6
 OBS_PARTIAL, OBS_FULL, OBS_ONEHOT, OBS_SYMBOLIC, OBS_RGB_PARTIAL, OBS_RGB = 0, 1, 2, 3, 4, 5
 AUTORESET_NEXT_STEP, AUTORESET_DISABLED = 0, 1
@@ -21,13 +21,14 @@ class MgConfig(C.Structure):
         "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
         "num_crossings", "obstacle_type", "num_dists", "null_stream_sync", "strip2_row", "no_death_mask")] + [
         ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("env_index_base", C.c_int64),
-        ("tile_size", C.c_int32), ("rgb_highlight", C.c_int32)]
+        ("tile_size", C.c_int32), ("rgb_highlight", C.c_int32), ("spare_ring", C.c_int32), ("traj_slots", C.c_int32)]
 
 
 class MgOutputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
                 ("direction", C.c_void_p), ("mission_id", C.c_void_p), ("obs_bytes_per_env", C.c_int64),
-                ("num_envs", C.c_int64)]
+                ("num_envs", C.c_int64), ("action", C.c_void_p), ("traj_slots", C.c_int64), ("slot_bytes", C.c_int64),
+                ("record_bytes", C.c_int64), ("max_fused_steps", C.c_int64)]
 
 
 class MiniGridHipError(RuntimeError):
@@ -36,8 +37,9 @@ class MiniGridHipError(RuntimeError):
 
 _lib = None
 
-# every symbol include/minigrid_hip.h declares (tests/test_abi.py checks the built library exports all of them)
-SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_get_outputs", "mg_copy_outputs",
+# every symbol include/minigrid_hip.h declares (tests/test_abi_cpu.py checks the built library exports all of them)
+SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
+           "mg_copy_slot", "mg_selftest_stream",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
            "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles"]
@@ -59,8 +61,9 @@ def load():
         except Exception:
             pass
     path = os.environ.get("MINIGRID_AMD_LIB") or _build.LIB      # override: an alternative build of the same ABI
-    if path == _build.LIB and (not os.path.exists(path) or os.environ.get("MINIGRID_AMD_REBUILD", "0") == "1"):
-        path = _build.build()
+    if path == _build.LIB:
+        # no-op when the library is newer than every source it is built from; a box without hipcc uses the shipped .so
+        path = _build.build(force=os.environ.get("MINIGRID_AMD_REBUILD", "0") == "1", missing_hipcc_ok=True)
     L = C.CDLL(path)
     vp, i, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.mg_create.argtypes = [C.POINTER(MgConfig), i, vp, C.POINTER(vp)]
@@ -68,6 +71,9 @@ def load():
     L.mg_reset.argtypes = [vp, vp, vp]
     L.mg_step.argtypes = [vp, vp, i, i]
     L.mg_rollout.argtypes = [vp, i, u64, i]
+    L.mg_step_many.argtypes = [vp, vp, i, i]
+    L.mg_copy_slot.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    L.mg_selftest_stream.argtypes = [C.c_int32, C.c_int32, vp, vp]
     L.mg_get_outputs.argtypes = [vp, C.POINTER(MgOutputs)]
     L.mg_copy_outputs.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.mg_sync.argtypes = [vp]

@@ -17,22 +17,35 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminigrid_hip.so")
 SOURCES = ["mg_api.hip"]
-HEADERS = ["mg_device.h", "mg_rng.h", "mg_gen.h", "mg_kernels.h", os.path.join("..", "..", "include", "minigrid_hip.h")]
+HEADERS = ["mg_device.h", "mg_rng.h", "mg_gen.h", "mg_kernels.h", "mg_tiles.h", os.path.join("..", "..", "include", "minigrid_hip.h")]
+
+
+STAMP = LIB + ".srchash"      # sha256 of the sources the library was built from (travels with the .so; mtimes do not)
+
+
+def _source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_hash()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
+        if missing_hipcc_ok and os.path.exists(LIB):
+            return LIB                      # a deployed tree: use the library it was shipped with
         raise RuntimeError("hipcc not found: cannot build libminigrid_hip.so (no CPU fallback exists)")
     rocm_lib = os.environ.get("ROCM_PATH", "/opt/rocm") + "/lib"
     # DT_NEEDED must read "libamdhip64.so" (no version suffix): that is the name PyTorch-ROCm's bundled runtime is
@@ -51,6 +64,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash())
     return LIB
 
 

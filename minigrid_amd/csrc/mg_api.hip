@@ -18,26 +18,40 @@ using namespace mg;
 
 static thread_local std::string g_create_error;
 
-// the three refill-queue counters live on separate 256-byte lines: one is hammered by atomics while another is read
-constexpr int QC_STRIDE = 64;
+// Spare-episode ring and refill batches (see mg_kernels.h).  A BATCH is a run of consecutive step launches whose
+// refill requests are served by ONE k_refill launch on the generator stream.  With R ring slots per env and at most
+// cb = R/4 spares consumed per env and batch (a reset call consumes one; among n consecutive step calls at most
+// ceil(n/2) do: a step that ends an episode sits between two consuming calls), a slot consumed in batch b is needed again
+// in batch b+4 at the earliest, so the first launch of batch b waits (event) for the refill of batch b-4: the generator
+// has three whole batches to finish, and never delays a step launch unless it falls that far behind.
+constexpr int REFILL_LAG = 4;               // batch b waits for refill(b - REFILL_LAG)
+constexpr int QSETS = REFILL_LAG + 1;       // request-segment sets / event pairs in rotation
 
 struct mg_env {
   mg_config cfg;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, gen_stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_step[QSETS] = {}, ev_gen[QSETS] = {};
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
   int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
-  int off_grid = 0, off_trow = 0, off_vis = 0, off_T = 0, off_lut = 0, off_act = 0, lds_bytes = 0;
-  int wpg = 4;                // wavefronts per group of 64 envs in k_step
+  int off_grid = 0, off_shadow = 0, off_trow = 0, off_T = 0, lds_bytes = 0, lds_bytes_shadow = 0;
+  int nwaves = 0;             // 64-env groups = k_step workgroups = refill request segments
   bool static_gen = false;
   bool live_gen = false;      // DynamicObstacles: step() consumes the stream => resets are drawn right before the step launch
   int rule = RULE_NONE, rule_cell = 0, rule_div = 1;
+  int rule_group = GG_NONE;   // which level rules the k_step variant carries (mg_gen.h groups)
+  // spare ring
+  int R = 1, cb = 1;          // ring slots per env; spares one env may consume per batch
+  int seg_cap = 64;
+  uint32_t batch_id = 0; int batch_obs = 0, batch_steps = 0; bool batch_open = false;
+  int max_fused = 1;          // steps per fused launch
   // device buffers
   uint8_t *grid = nullptr, *spare_grid = nullptr;
-  uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *seeds = nullptr;
+  uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *rng_tmp = nullptr, *seeds = nullptr;
+  uint32_t *head = nullptr, *tail = nullptr, *claim = nullptr, *seg = nullptr, *seg_count = nullptr;
   uint8_t *mask = nullptr, *actions = nullptr;
   uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
   bool goto_kind = false;
@@ -45,17 +59,16 @@ struct mg_env {
   RenderParams render;        // ... and k_render's launch geometry
   int render_lds = 0, render_blocks = 0, render_threads = 256;
   bool rgb = false;
-  uint8_t *obs = nullptr, *term = nullptr, *trunc = nullptr, *dir = nullptr, *mission = nullptr;
-  double *reward = nullptr, *reward_lut = nullptr;
-  uint32_t *queue = nullptr, *qcount = nullptr, *err = nullptr;
+  // trajectory ring: S slots of { obs | reward | terminated | truncated | direction | mission | action }
+  uint8_t* out = nullptr;
+  int S = 1;
+  size_t slot_bytes = 0, record_bytes = 0, off_reward = 0, off_term = 0, off_trunc = 0, off_dir = 0, off_mission = 0, off_action = 0;
+  double* reward_lut = nullptr;
+  uint32_t* err = nullptr;
   unsigned long long* counters = nullptr;
   size_t ncounters = 0;
-  uint64_t env_steps = 0;     // env-steps executed (host-side count: N per PHASE_STEP launch)
-  // bookkeeping
-  uint32_t launches = 0;      // k_step launches so far (refill queue slot = launches % 3)
-  int gen_blocks = 0;         // generator workgroups at the head of every k_step launch
-  int gen_group = GG_NONE;    // which generators the k_step variant carries (mg_gen.h)
-  int gen_cap_words = 0;      // their draw-buffer capacity (words), limited by the launch's LDS size
+  uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
+  uint32_t launches = 0;      // k_step launches so far
   uint32_t t = 0;             // rollout step counter (Philox action counter)
   std::string last_error;
 };
@@ -96,32 +109,33 @@ static GenParams gen_params(const mg_env* e) {
 }
 
 // ---- launches -------------------------------------------------------------------------------------------
-// GenArgs common to the stand-alone generator launches and the generator role inside k_step
-static GenArgs gen_args(mg_env* e, bool to_spare) {
+// GenArgs common to the direct generator launches (slot: ring slot to fill, < 0 = the live state) and the refill launches
+static GenArgs gen_args(mg_env* e, int slot) {
   GenArgs A;
+  const bool to_spare = slot >= 0;
+  const size_t N = (size_t)e->N, s = to_spare ? (size_t)slot : 0;
   A.gp = gen_params(e);
-  A.dst_grid = to_spare ? e->spare_grid : e->grid;
-  A.dst_agent = to_spare ? e->spare_agent : e->agent;
+  A.dst_grid = to_spare ? e->spare_grid + s * N * e->CS : e->grid;
+  A.dst_agent = to_spare ? e->spare_agent + s * N : e->agent;
   A.rng = e->rng;
-  A.rng_snap = to_spare ? e->rng_snap : nullptr;
-  A.queue = nullptr; A.count = nullptr; A.zero_count = nullptr; A.mask = nullptr;
+  A.rng_snap = to_spare ? e->rng_snap + s * 5 * N : nullptr;
+  A.dst_aux = (e->live_gen && !to_spare) ? e->aux : (e->goto_kind ? (to_spare ? e->spare_aux + s * N : e->aux) : nullptr);
+  A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
-  A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + (e->N + 63) / 64;
-  A.dst_aux = (e->live_gen && !to_spare) ? e->aux : (e->goto_kind ? (to_spare ? e->spare_aux : e->aux) : nullptr);
-  A.live = e->live_gen ? 1 : 0;
+  A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + e->nwaves;
+  A.live = 0;
+  A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap;
+  A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
 }
 
-// Stand-alone generator launch.  queue_slot < 0: direct mode over all envs (optionally masked);
-// otherwise: process refill queue `queue_slot` (its length is only known on the device).
-static int launch_generate(mg_env* e, bool to_spare, int queue_slot, const uint8_t* d_mask) {
-  GenArgs A = gen_args(e, to_spare);
-  const bool queue_mode = queue_slot >= 0;
-  if (queue_mode) { A.queue = e->queue + (size_t)queue_slot * e->N; A.count = e->qcount + QC_STRIDE * queue_slot; }
+// Direct generator launch over all envs (optionally masked), on the main stream.
+static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
+  GenArgs A = gen_args(e, slot);
   A.mask = d_mask;
   const int wpb = GEN_THREADS / 64;
-  int blocks = std::min((e->N + wpb - 1) / wpb, queue_mode ? 1024 : 8192);
-  size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words);
+  const int blocks = std::min((e->N + wpb - 1) / wpb, 8192);
+  const size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
     hipLaunchKernelGGL(k_generate<WavePhilox>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
   else
@@ -130,31 +144,88 @@ static int launch_generate(mg_env* e, bool to_spare, int queue_slot, const uint8
   return MG_OK;
 }
 
-// The spares consumed by the most recent k_step launch are refilled by the generator role of the NEXT k_step
-// launch.  Entry points that read or overwrite spares / stream positions first bring them up to date.
-static int flush_refills(mg_env* e) {
-  if (e->static_gen || e->live_gen || e->launches == 0) return MG_OK;
-  const int slot = (int)((e->launches - 1) % 3);
-  int rc = launch_generate(e, /*to_spare=*/true, slot, nullptr);
+// Refill launch for request-segment set `set`: one workgroup per step-wave segment.
+static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStream_t st) {
+  GenArgs A = live ? gen_args(e, -1) : gen_args(e, 0);
+  // the ring slot is chosen per request on the device: pass slot 0's pointers, generate_one offsets them
+  A.live = live ? 1 : 0;
+  A.seg = e->seg + (size_t)set * e->nwaves * e->seg_cap;
+  A.seg_count = e->seg_count + (size_t)set * e->nwaves;
+  A.epoch = epoch;
+  A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
+  const size_t lds = (size_t)(GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, A.cap_words);
+  if (e->cfg.rng_mode == MG_RNG_PHILOX)
+    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves), dim3(GEN_THREADS), lds, st, A);
+  else
+    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves), dim3(GEN_THREADS), lds, st, A);
+  HIP_TRY(e, hipGetLastError());
+  return MG_OK;
+}
+
+static bool uses_ring(const mg_env* e) { return !e->static_gen && !e->live_gen; }
+
+// close the open batch: its refill runs on the generator stream as soon as the batch's last step launch has finished
+static int close_batch(mg_env* e) {
+  if (!uses_ring(e) || !e->batch_open) return MG_OK;
+  const int set = (int)(e->batch_id % QSETS);
+  HIP_TRY(e, hipEventRecord(e->ev_step[set], e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_step[set], 0));
+  int rc = launch_refill(e, set, e->batch_id + 1u, false, e->gen_stream);
   if (rc) return rc;
-  HIP_TRY(e, hipMemsetAsync(e->qcount + QC_STRIDE * slot, 0, sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipEventRecord(e->ev_gen[set], e->gen_stream));
+  e->batch_id++; e->batch_open = false; e->batch_obs = 0; e->batch_steps = 0;
+  return MG_OK;
+}
+
+// account a launch (an OBSERVE launch, or T step calls) to the open batch, closing / opening batches as needed
+static int batch_admit(mg_env* e, int phase, int T) {
+  if (!uses_ring(e)) return MG_OK;
+  const int add_obs = phase == PHASE_OBSERVE ? 1 : 0, add_steps = phase == PHASE_STEP ? T : 0;
+  if (e->batch_open && (e->batch_obs + add_obs) + (e->batch_steps + add_steps + 1) / 2 > e->cb) {
+    int rc = close_batch(e);
+    if (rc) return rc;
+  }
+  if (!e->batch_open) {
+    if (e->batch_id >= (uint32_t)REFILL_LAG)
+      HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gen[(e->batch_id - REFILL_LAG) % QSETS], 0));
+    e->batch_open = true;
+  }
+  e->batch_obs += add_obs; e->batch_steps += add_steps;
+  return MG_OK;
+}
+
+// Entry points that read or overwrite spares / stream positions first bring every ring up to date: all requests
+// served (tail = head + R for every env), and the main stream ordered after the generator stream.
+static int flush_refills(mg_env* e) {
+  if (!uses_ring(e)) return MG_OK;
+  int rc = close_batch(e);
+  if (rc) return rc;
+  if (e->batch_id > 0) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gen[(e->batch_id - 1) % QSETS], 0));
   return MG_OK;
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
-  P.grid = e->grid; P.spare_grid = e->spare_grid; P.agent = e->agent; P.spare_agent = e->spare_agent;
-  P.aux = e->aux; P.spare_aux = e->spare_aux;
-  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t = 0;
-  P.obs = e->rgb ? e->tilemap : e->obs; P.reward = e->reward; P.term = e->term; P.trunc = e->trunc; P.dir_out = e->dir; P.mission_out = e->mission;
+  P.grid = e->grid; P.agent = e->agent; P.aux = e->aux;
+  P.spare_grid = e->spare_grid; P.spare_agent = e->spare_agent; P.spare_aux = e->spare_aux;
+  P.head = uses_ring(e) ? e->head : nullptr; P.ring_mask = (uint32_t)(e->R - 1);
+  const int set = e->live_gen ? 0 : (int)(e->batch_id % QSETS);
+  P.seg = e->static_gen ? nullptr : e->seg + (size_t)set * e->nwaves * e->seg_cap;
+  P.seg_count = e->static_gen ? nullptr : e->seg_count + (size_t)set * e->nwaves;
+  P.seg_cap = e->seg_cap;
+  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0;
+  P.obs_mask = nullptr;
+  P.out = e->out; P.slot_bytes = e->slot_bytes;
+  P.obs = e->rgb ? e->tilemap : e->out; P.obs_stride = e->rgb ? 0ull : (unsigned long long)e->slot_bytes;
+  P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
+  P.off_mission = e->off_mission; P.off_action = e->off_action;
+  P.T = 1; P.slot0 = 0; P.S = e->S;
   P.reward_lut = e->reward_lut;
-  P.refill_queue = e->queue + (size_t)(e->launches % 3) * e->N; P.refill_count = e->qcount + QC_STRIDE * (e->launches % 3);
   P.err = e->err; P.counters = e->counters;
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.phase = phase; P.static_gen = e->static_gen; P.gen_blocks = e->gen_blocks; P.live_gen = e->live_gen ? 1 : 0;
-  P.off_grid = e->off_grid; P.off_trow = e->off_trow; P.off_vis = e->off_vis; P.off_T = e->off_T;
-  P.off_lut = e->off_lut; P.off_act = e->off_act; P.OBE = e->map_bytes;
+  P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
+  P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_trow = e->off_trow; P.off_T = e->off_T; P.OBE = e->map_bytes;
   P.rgb_full = e->cfg.obs_mode == MG_OBS_RGB; P.rgb_highlight = e->cfg.rgb_highlight != 0;
   P.view = e->cfg.agent_view_size; P.no_death_mask = e->cfg.no_death_mask; P.death_cost = e->cfg.death_cost;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
@@ -162,18 +233,18 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.env_base = e->cfg.env_index_base;
 }
 
-static int launch_step(mg_env* e, const StepParams& P) {
-  // grid = [gen_blocks generator workgroups | one workgroup of wpg wavefronts per 64 consecutive envs].
-  // Launch L appends the envs whose spare it consumed to refill queue L%3; its generator role drains queue (L-1)%3
-  // and clears the counter of queue (L+1)%3, which nobody touches during launch L.
+// every k_step instantiation the library launches: (MODE, FAST7) x rule group
+#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG) X(0, false, GG) X(1, false, GG) X(2, false, GG) X(3, false, GG) X(4, false, GG)
+#define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
+
+static int launch_step(mg_env* e, StepParams& P) {
+  // grid = one 64-lane workgroup (one autonomous wavefront) per 64 consecutive envs; P.T steps per launch
   if (e->live_gen) {
     // (1) draw, in place, the episodes of the envs the previous launch left RESET_PENDING (they come out FRESH and
     //     are only observed by this launch); (2) before a real step, move the obstacles of everyone else
     if (e->launches > 0) {
-      const int slot = (int)((e->launches - 1) % 3);
-      int rc = launch_generate(e, /*to_spare=*/false, slot, nullptr);
+      int rc = launch_refill(e, 0, e->launches + 1u, true, e->stream);
       if (rc) return rc;
-      HIP_TRY(e, hipMemsetAsync(e->qcount + QC_STRIDE * slot, 0, sizeof(uint32_t), e->stream));
     }
     if (P.phase == PHASE_STEP) {
       const int tb = 256, nb = (e->N + tb - 1) / tb;
@@ -186,46 +257,36 @@ static int launch_step(mg_env* e, const StepParams& P) {
       HIP_TRY(e, hipGetLastError());
     }
   }
-  const int blocks = (e->N + 63) / 64 + e->gen_blocks;
-  dim3 grid(blocks), block(64 * e->wpg);
-  const size_t lds = (size_t)e->lds_bytes;
-  const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-  GenArgs A = gen_args(e, /*to_spare=*/true);
-  const uint32_t L = e->launches;
-  A.queue = e->queue + (size_t)((L + 2) % 3) * e->N; A.count = e->qcount + QC_STRIDE * ((L + 2) % 3);
-  A.zero_count = e->qcount + QC_STRIDE * ((L + 1) % 3);
-  A.cap_words = e->gen_cap_words;
-#define MG_LAUNCH_STEP_G(MODE, WPG, VT, GG)                                                                       \
-  do {                                                                                                            \
-    if (philox) hipLaunchKernelGGL((k_step<MODE, WPG, WavePhilox, VT, GG>), grid, block, lds, e->stream, P, A);   \
-    else hipLaunchKernelGGL((k_step<MODE, WPG, WavePcg64, VT, GG>), grid, block, lds, e->stream, P, A);           \
-  } while (0)
-#define MG_LAUNCH_STEP(MODE, WPG, VT)                                                    \
-  do {                                                                                   \
-    if (e->gen_group == GG_NONE) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_NONE);               \
-    else if (e->gen_group == GG_LIGHT) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_LIGHT);        \
-    else if (e->gen_group == GG_ROOMS) MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_ROOMS);        \
-    else MG_LAUNCH_STEP_G(MODE, WPG, VT, GG_ROOMGRID);                                   \
-  } while (0)
-  // instantiated variants (each carries its generator group's code, so the list is kept short): 4 waves per
-  // group only -- 1 and 2 were measured slower at every batch size (profiles/r1_baseline/sweep_wpg.txt)
-  const bool v7 = e->cfg.agent_view_size == 7;
-  switch (e->cfg.obs_mode) {
-    case MG_OBS_FULL: MG_LAUNCH_STEP(1, 4, 7); break;
-    case MG_OBS_SYMBOLIC: MG_LAUNCH_STEP(3, 4, 7); break;
-    case MG_OBS_ONEHOT: if (v7) MG_LAUNCH_STEP(2, 4, 7); else MG_LAUNCH_STEP(2, 4, 15); break;
-    case MG_OBS_RGB: case MG_OBS_RGB_PARTIAL: MG_LAUNCH_STEP(4, 4, 7); break;
-    default: if (v7) MG_LAUNCH_STEP(0, 4, 7); else MG_LAUNCH_STEP(0, 4, 15); break;
+  { int rc = batch_admit(e, P.phase, P.T); if (rc) return rc; }
+  {
+    // the batch this launch files its refill requests under (batch_admit may have moved on to the next one)
+    const int set = e->live_gen ? 0 : (int)(e->batch_id % QSETS);
+    if (!e->static_gen) { P.seg = e->seg + (size_t)set * e->nwaves * e->seg_cap; P.seg_count = e->seg_count + (size_t)set * e->nwaves; }
   }
-#undef MG_LAUNCH_STEP_G
-#undef MG_LAUNCH_STEP
+  // fused launches stage every env's next spare episode in LDS next to its grid when that fits
+  P.use_shadow = (P.T > 1 && e->lds_bytes_shadow <= 160 * 1024) ? 1 : 0;
+  const size_t lds = (size_t)(P.use_shadow ? e->lds_bytes_shadow : e->lds_bytes);
+  dim3 grid(e->nwaves), block(64);
+  const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && e->cfg.agent_view_size == 7;
+  const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
+                 : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
+  const int gg = e->rule_group;
+  bool launched = false;
+#define MG_TRY_LAUNCH(MODE, FAST, GG)                                                              \
+  if (!launched && mode == MODE && fast7 == FAST && gg == GG) {                                    \
+    hipLaunchKernelGGL((k_step<MODE, FAST, GG>), grid, block, lds, e->stream, P);                  \
+    launched = true;                                                                               \
+  }
+  MG_FOR_STEP_GROUPS(MG_TRY_LAUNCH)
+#undef MG_TRY_LAUNCH
+  if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
   if (e->rgb) {
     hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
   }
   e->launches++;
-  if (P.phase == PHASE_STEP) e->env_steps += (uint64_t)e->N;
+  if (P.phase == PHASE_STEP) e->env_steps += (uint64_t)e->N * (uint64_t)P.T;
   return MG_OK;
 }
 
@@ -296,7 +357,7 @@ static int setup_render(mg_env* e) {
   HIP_TRY(e, hipMemsetAsync(e->tilemap, 0, (size_t)e->N * e->map_bytes + 16, e->stream));
   R.tilemap = e->tilemap; R.agent = e->agent;
   R.atlas_static = e->atlas; R.atlas_agent = e->atlas + (size_t)STATIC_TILES * R.tile_dw;
-  R.out = (uint4*)e->obs;
+  R.out = (uint4*)e->out;
   if (e->render_lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, e->render_lds));
   return MG_OK;
 }
@@ -403,40 +464,51 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   e->rgb = rgb;
   e->map_bytes = !rgb ? e->obs_bytes : (cfg->obs_mode == MG_OBS_RGB ? e->cells : V * V);
+  e->nwaves = (e->N + 63) / 64;
   {
-    // LDS carve-up of k_step (bytes): guard | 64 staged grids | guard | opacity rows | visibility masks |
-    // observation bytes in output order | decode table | actions.  The guard bands cover the furthest a view cell
-    // can lie outside an env's own grid (V-1 rows + V-1 cells): such reads are masked, they only have to stay in LDS.
+    // LDS carve-up of k_step (bytes), per 64-env wavefront: decode table | guard | 64 staged grids | guard | visibility
+    // rows | observation byte stream in output order | [shadow: the 64 next spare episodes (fused launches)].  The guard
+    // bands cover the furthest a view cell can lie outside an env's own grid (V-1 rows + V-1 cells): such reads are
+    // masked, they only have to stay inside the allocation.
     const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
-    e->off_grid = guard;
-    e->off_trow = (guard + 64 * e->GS + guard + 15) & ~15;
-    e->off_vis = e->off_trow + 64 * 32;                     // one u16 per view row and env (one u8 for V == 7)
-    e->off_T = e->off_vis + 64 * 8;
-    e->off_lut = e->off_T + ((64 * e->map_bytes + 15) & ~15);
-    e->off_act = e->off_lut + 256 * 4;
-    e->lds_bytes = e->off_act + 64;
-  }
-  {
-    // waves per 64-env group.  Measured on MI355X (profiles/r1_baseline/sweep_wpg.txt): 4 wins at every batch size
-    // from 32 Ki to 256 Ki envs -- fewer waves issue fewer instructions (1 wave: -22 % VALU) but the kernel is bound by
-    // dependent LDS/HBM latency per wave, not by issue slots.  k_step keeps WPG as a template parameter; only 4 is built.
-    e->wpg = 4;
+    e->off_grid = 1024 + guard;
+    e->off_trow = (e->off_grid + 64 * e->GS + guard + 15) & ~15;
+    e->off_T = e->off_trow + 64 * 32;                       // one u16 per view row and env
+    e->off_shadow = e->off_T + ((64 * e->map_bytes + 15) & ~15) + 16;
+    e->lds_bytes = e->off_shadow;
+    e->lds_bytes_shadow = e->off_shadow + ((64 * e->GS + 15) & ~15);
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
-  if (!e->static_gen && !e->live_gen) {
-    // generator role of k_step: every wave of a generator workgroup draws episodes, each with 1/wpg of the launch's
-    // LDS allocation (>= 512 draws: one whole-map attempt of GoToRedBall needs ~60, and an attempt that runs out
-    // restarts from its checkpoint, so the buffer size is not a correctness limit)
-    const int min_lds = e->wpg * gen_wave_lds_bytes(e->CS, 512);
-    if (e->lds_bytes < min_lds) e->lds_bytes = min_lds;
-    e->gen_cap_words = std::min(2048, (e->lds_bytes / e->wpg - e->CS - GEN_SBASE_BYTES - GEN_SCRATCH_BYTES) / 4 - 4) & ~3;
-    e->gen_blocks = std::min(1024, e->N);
-    e->gen_group = gen_group_of_kind(cfg->env_kind);
-    if (const char* s = getenv("MG_GEN_BLOCKS")) { int v = atoi(s); if (v >= 1 && v <= 65536) e->gen_blocks = std::min(v, e->N); }
-  }
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
+  {
+    // spare ring depth R (power of two).  Levels that draw nothing keep ONE constant spare; DynamicObstacles draws in
+    // place (no ring).  Default 16: with cb = R/4 = 4 a fused launch runs 8 steps, and the generator may lag three
+    // batches (24 steps) behind before a step launch has to wait for it.  Sized for 288 GB of HBM: 16 spare maps of
+    // 64 B are 1 KB per env; very large maps x batches are capped at 8 GB of ring.
+    int R = 1;
+    if (!e->static_gen && !e->live_gen) {
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : 16;
+      if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
+      if (R < 4 || R > 64 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..64"); }
+      while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
+    }
+    e->R = R; e->cb = std::max(1, R / REFILL_LAG);
+    e->seg_cap = e->live_gen ? 64 : 64 * 2 * e->cb;          // at most 2*cb launches per batch, 64 requests each
+    // trajectory slots S: default 16 (fused launches write every step of the launch to its own slot), fewer when one
+    // slot is large (RGB frames: a single slot)
+    const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
+    int S = cfg->traj_slots > 0 ? cfg->traj_slots : 16;
+    if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
+    if (S > 4096) { delete e; return fail(nullptr, MG_ERR_INVALID, "traj_slots must be <= 4096"); }
+    if (rgb) S = 1;
+    if (cfg->traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
+    e->S = S;
+    // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
+    e->max_fused = (rgb || e->live_gen) ? 1 : std::min(S, e->static_gen ? 32 : 2 * e->cb);
+    if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
+  }
   // GoToInstr levels: rule_div selects how the described object follows from the mission id (see k_step)
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL || cfg->env_kind == MG_ENV_GOTO_REDBALLGREY) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; e->rule_div = 0; }
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
@@ -457,12 +529,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_KEYCORRIDOR) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BALL; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
 
-  {
-    // k_step compiles each rule only into the variant of its generator group: keep the two tables in step
-    const int rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
-                         : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? -1 : GG_LIGHT;
-    if (rule_group >= 0 && rule_group != gen_group_of_kind(cfg->env_kind)) { delete e; return fail(nullptr, MG_ERR_INVALID, "internal: rule / generator group mismatch"); }
-  }
+  // k_step compiles each level rule only into the variant of its rule group
+  e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
+                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
+                : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)
@@ -472,63 +542,84 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipStreamCreateWithFlags(&e->stream, cfg->null_stream_sync ? hipStreamDefault : hipStreamNonBlocking));
     e->own_stream = true;
   }
+  TRY_OR_FREE(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking));
   TRY_OR_FREE(hipEventCreate(&e->ev0));
   TRY_OR_FREE(hipEventCreate(&e->ev1));
-  const size_t N = (size_t)e->N;
+  for (int i = 0; i < QSETS; i++) {
+    TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_step[i], hipEventDisableTiming));
+    TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_gen[i], hipEventDisableTiming));
+  }
+  const size_t N = (size_t)e->N, R = (size_t)e->R;
   TRY_OR_FREE(dalloc(&e->grid, N * e->CS));
-  TRY_OR_FREE(dalloc(&e->spare_grid, N * e->CS));
+  TRY_OR_FREE(dalloc(&e->spare_grid, R * N * e->CS));
   TRY_OR_FREE(dalloc(&e->agent, N));
-  TRY_OR_FREE(dalloc(&e->spare_agent, N));
+  TRY_OR_FREE(dalloc(&e->spare_agent, R * N));
   TRY_OR_FREE(dalloc(&e->rng, 5 * N));
-  TRY_OR_FREE(dalloc(&e->rng_snap, 5 * N));
+  TRY_OR_FREE(dalloc(&e->rng_snap, R * 5 * N));
+  TRY_OR_FREE(dalloc(&e->rng_tmp, 5 * N));
   TRY_OR_FREE(dalloc(&e->seeds, N));
   TRY_OR_FREE(dalloc(&e->mask, N));
   TRY_OR_FREE(dalloc(&e->actions, 8 * N));
   TRY_OR_FREE(dalloc(&e->aux, N));
-  TRY_OR_FREE(dalloc(&e->spare_aux, N));
+  TRY_OR_FREE(dalloc(&e->spare_aux, R * N));
+  TRY_OR_FREE(dalloc(&e->head, N));
+  TRY_OR_FREE(dalloc(&e->tail, N));
+  TRY_OR_FREE(dalloc(&e->claim, N));
+  const size_t nseg = (size_t)(e->live_gen ? 1 : QSETS) * e->nwaves;
+  TRY_OR_FREE(dalloc(&e->seg, nseg * e->seg_cap));
+  TRY_OR_FREE(dalloc(&e->seg_count, nseg));
   TRY_OR_FREE(hipMemsetAsync(e->aux, 0, N * sizeof(uint64_t), e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->spare_aux, 0, N * sizeof(uint64_t), e->stream));
-  TRY_OR_FREE(dalloc(&e->obs, N * e->obs_bytes + 16));
+  TRY_OR_FREE(hipMemsetAsync(e->spare_aux, 0, R * N * sizeof(uint64_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->head, 0, N * sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->tail, 0, N * sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->claim, 0, N * sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->seg_count, 0, nseg * sizeof(uint32_t), e->stream));
+  {
+    // one trajectory slot = one contiguous record: obs | reward | terminated | truncated | direction | mission | action
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    e->off_reward = up(N * e->obs_bytes + 16);
+    e->off_term = e->off_reward + up(N * 8);
+    e->off_trunc = e->off_term + up(N);
+    e->off_dir = e->off_trunc + up(N);
+    e->off_mission = e->off_dir + up(N);
+    e->off_action = e->off_mission + up(N);
+    e->record_bytes = e->off_action + N;
+    e->slot_bytes = up(e->record_bytes);
+    TRY_OR_FREE(dalloc(&e->out, e->slot_bytes * (size_t)e->S));
+    TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
+  }
   if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
-  TRY_OR_FREE(dalloc(&e->reward, N));
-  TRY_OR_FREE(dalloc(&e->term, N));
-  TRY_OR_FREE(dalloc(&e->trunc, N));
-  TRY_OR_FREE(dalloc(&e->dir, N));
-  TRY_OR_FREE(dalloc(&e->mission, N));
   TRY_OR_FREE(dalloc(&e->reward_lut, (size_t)cfg->max_steps + 1));
-  TRY_OR_FREE(dalloc(&e->queue, 3 * N));
-  TRY_OR_FREE(dalloc(&e->qcount, 3 * QC_STRIDE));
   TRY_OR_FREE(dalloc(&e->err, 1));
-  e->ncounters = (size_t)STAT_EPISODES + (size_t)(e->N + 63) / 64 + 2 * (size_t)STAT_GEN_SLOTS;
+  e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
   TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
-  TRY_OR_FREE(hipMemsetAsync(e->qcount, 0, 3 * QC_STRIDE * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, N * e->CS, e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, R * N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->obs, 0, N * e->obs_bytes + 16, e->stream));
   {
     std::vector<double> lut((size_t)cfg->max_steps + 1);
     build_reward_lut(cfg->max_steps, lut.data());
     TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
   }
-  if (e->lds_bytes > 64 * 1024) {
-    const void* fns[] = {
-#define MG_KG(MODE, WPG, VT, GG) (const void*)k_step<MODE, WPG, WavePcg64, VT, GG>, (const void*)k_step<MODE, WPG, WavePhilox, VT, GG>
-#define MG_K(MODE, WPG, VT) MG_KG(MODE, WPG, VT, GG_NONE), MG_KG(MODE, WPG, VT, GG_LIGHT), MG_KG(MODE, WPG, VT, GG_ROOMGRID), MG_KG(MODE, WPG, VT, GG_ROOMS)
-      MG_K(0, 4, 7), MG_K(0, 4, 15), MG_K(1, 4, 7), MG_K(2, 4, 7), MG_K(2, 4, 15), MG_K(3, 4, 7), MG_K(4, 4, 7)
-#undef MG_K
-#undef MG_KG
-    };
-    // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
-    // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
-    static std::mutex lds_mu;
-    static int lds_max[64] = { 0 };
-    std::lock_guard<std::mutex> lk(lds_mu);
-    if (e->lds_bytes > lds_max[device & 63]) {
-      for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
-      lds_max[device & 63] = e->lds_bytes;
+  {
+    const int need = std::max(e->lds_bytes, e->lds_bytes_shadow <= 160 * 1024 ? e->lds_bytes_shadow : 0);
+    if (need > 64 * 1024) {
+      const void* fns[] = {
+#define MG_FN(MODE, FAST, GG) (const void*)k_step<MODE, FAST, GG>,
+        MG_FOR_STEP_GROUPS(MG_FN)
+#undef MG_FN
+      };
+      // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
+      // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
+      static std::mutex lds_mu;
+      static int lds_max[64] = { 0 };
+      std::lock_guard<std::mutex> lk(lds_mu);
+      if (need > lds_max[device & 63]) {
+        for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+        lds_max[device & 63] = need;
+      }
     }
   }
 #undef TRY_OR_FREE
@@ -548,14 +639,32 @@ int mg_destroy(mg_env* e) {
   if (!e) return MG_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
-  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->seeds, e->mask, e->actions, e->aux, e->spare_aux,
-                   e->obs, e->reward, e->term, e->trunc, e->dir, e->mission, e->reward_lut, e->queue, e->qcount, e->err, e->counters,
+  if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
+  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
+                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->reward_lut, e->err, e->counters,
                    e->tilemap, e->atlas };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (int i = 0; i < QSETS; i++) {
+    if (e->ev_step[i]) (void)hipEventDestroy(e->ev_step[i]);
+    if (e->ev_gen[i]) (void)hipEventDestroy(e->ev_gen[i]);
+  }
+  if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
+  return MG_OK;
+}
+
+// draw every ring slot of the selected envs from their current stream position (head = 0, tail = R)
+static int refill_whole_ring(mg_env* e, const uint8_t* d_mask) {
+  if (e->live_gen) return MG_OK;
+  const int tb = 256, nb = (e->N + tb - 1) / tb;
+  if (uses_ring(e)) {
+    hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, e->stream, e->head, e->tail, d_mask, (uint32_t)e->R, e->N);
+    HIP_TRY(e, hipGetLastError());
+  }
+  for (int s = 0; s < e->R; s++) { int rc = launch_generate(e, s, d_mask); if (rc) return rc; }
   return MG_OK;
 }
 
@@ -569,30 +678,31 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     d_mask = e->mask;
   }
   const int tb = 256, nb = (N + tb - 1) / tb;
-  { int rc = flush_refills(e); if (rc) return rc; }
   if (seeds) {
-    // reset(seed=s): reseed, draw this episode, then draw the spare (episode 2 of the same stream)
+    // reset(seed=s): reseed, draw this episode, then the ring of spares (episodes 2, 3, ... of the same stream)
+    { int rc = flush_refills(e); if (rc) return rc; }
     HIP_TRY(e, hipMemcpyAsync(e->seeds, seeds, (size_t)N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     if (e->cfg.rng_mode == MG_RNG_PHILOX)
       hipLaunchKernelGGL(k_seed<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
     else
       hipLaunchKernelGGL(k_seed<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
     HIP_TRY(e, hipGetLastError());
-    int rc = launch_generate(e, /*to_spare=*/false, -1, d_mask);
+    int rc = launch_generate(e, -1, d_mask);
     if (rc) return rc;
-    if (!e->live_gen) rc = launch_generate(e, /*to_spare=*/true, -1, d_mask);
+    rc = refill_whole_ring(e, d_mask);
     if (rc) return rc;
   } else if (e->live_gen) {
     // reset(): continue each env's stream from where its last step left it
-    int rc = launch_generate(e, /*to_spare=*/false, -1, d_mask);
+    int rc = launch_generate(e, -1, d_mask);
     if (rc) return rc;
   } else {
-    // reset(): continue each env's own stream == consume the pre-drawn spare
+    // reset(): continue each env's own stream == take the next pre-drawn spare
     hipLaunchKernelGGL(k_mark_pending, dim3(nb), dim3(tb), 0, e->stream, e->agent, d_mask, N);
     HIP_TRY(e, hipGetLastError());
   }
   StepParams P;
   fill_step_params(e, P, PHASE_OBSERVE);
+  P.obs_mask = d_mask;       // a masked reset() leaves the other envs alone, autoreset-pending ones included
   return launch_step(e, P);
 }
 
@@ -614,41 +724,81 @@ int mg_step(mg_env* e, const void* actions, int dtype, int on_device) {
 
 int mg_rollout(mg_env* e, int T, uint64_t action_seed, int fused) {
   if (!e || T < 0) return MG_ERR_INVALID;
-  (void)fused;
   HIP_TRY(e, hipSetDevice(e->device));
-  for (int i = 0; i < T; i++) {
+  // step j of the call goes to trajectory slot (T-1-j) mod S: the last step always lands in slot 0 (mg_get_outputs),
+  // slot k holds the step k calls before it.  fused: up to max_fused steps per k_step launch, else one launch per step.
+  const int chunk = fused ? e->max_fused : 1;
+  for (int j = 0; j < T;) {
+    const int tc = std::min(chunk, T - j);
     StepParams P;
     fill_step_params(e, P, PHASE_STEP);
-    P.act_src = ACT_SRC_PHILOX; P.action_seed = action_seed; P.t = e->t++;
+    P.act_src = ACT_SRC_PHILOX; P.action_seed = action_seed; P.t0 = e->t; P.T = tc;
+    P.slot0 = fused ? (T - 1 - j) % e->S : 0;
+    e->t += (uint32_t)tc;
     int rc = launch_step(e, P);
     if (rc) return rc;
+    j += tc;
+  }
+  return MG_OK;
+}
+
+int mg_step_many(mg_env* e, const uint8_t* actions, int T, int on_device) {
+  if (!e || !actions || T < 0) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  for (int j = 0; j < T;) {
+    const int tc = std::min(std::min(e->max_fused, on_device ? e->max_fused : 8), T - j);   // host staging holds 8 steps
+    StepParams P;
+    fill_step_params(e, P, PHASE_STEP);
+    P.act_dtype = MG_ACT_U8; P.T = tc; P.slot0 = (T - 1 - j) % e->S;
+    if (on_device) P.actions = actions + (size_t)j * N;
+    else {
+      HIP_TRY(e, hipMemcpyAsync(e->actions, actions + (size_t)j * N, (size_t)tc * N, hipMemcpyHostToDevice, e->stream));
+      P.actions = e->actions;
+    }
+    int rc = launch_step(e, P);
+    if (rc) return rc;
+    j += tc;
   }
   return MG_OK;
 }
 
 int mg_get_outputs(mg_env* e, mg_outputs* o) {
   if (!e || !o) return MG_ERR_INVALID;
-  o->obs = e->obs; o->reward = e->reward; o->terminated = e->term; o->truncated = e->trunc;
-  o->direction = e->dir; o->mission_id = e->mission; o->obs_bytes_per_env = e->obs_bytes; o->num_envs = e->N;
+  o->obs = e->out; o->reward = (double*)(e->out + e->off_reward); o->terminated = e->out + e->off_term;
+  o->truncated = e->out + e->off_trunc; o->direction = e->out + e->off_dir; o->mission_id = e->out + e->off_mission;
+  o->obs_bytes_per_env = e->obs_bytes; o->num_envs = e->N;
+  o->action = e->out + e->off_action; o->traj_slots = e->S; o->slot_bytes = (int64_t)e->slot_bytes; o->record_bytes = (int64_t)e->record_bytes;
+  o->max_fused_steps = e->max_fused;
   return MG_OK;
 }
 
 int mg_copy_outputs(mg_env* e, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint8_t* mission) {
-  if (!e) return MG_ERR_INVALID;
+  return mg_copy_slot(e, 0, obs, reward, term, trunc, dir, mission, nullptr);
+}
+
+int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint8_t* mission,
+                 uint8_t* action) {
+  if (!e || slot < 0 || slot >= e->S) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
-  if (obs) HIP_TRY(e, hipMemcpyAsync(obs, e->obs, N * e->obs_bytes, hipMemcpyDeviceToHost, e->stream));
-  if (reward) HIP_TRY(e, hipMemcpyAsync(reward, e->reward, N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  if (term) HIP_TRY(e, hipMemcpyAsync(term, e->term, N, hipMemcpyDeviceToHost, e->stream));
-  if (trunc) HIP_TRY(e, hipMemcpyAsync(trunc, e->trunc, N, hipMemcpyDeviceToHost, e->stream));
-  if (dir) HIP_TRY(e, hipMemcpyAsync(dir, e->dir, N, hipMemcpyDeviceToHost, e->stream));
-  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, e->mission, N, hipMemcpyDeviceToHost, e->stream));
+  const uint8_t* b = e->out + (size_t)slot * e->slot_bytes;
+  if (obs) HIP_TRY(e, hipMemcpyAsync(obs, b, N * e->obs_bytes, hipMemcpyDeviceToHost, e->stream));
+  if (reward) HIP_TRY(e, hipMemcpyAsync(reward, b + e->off_reward, N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (term) HIP_TRY(e, hipMemcpyAsync(term, b + e->off_term, N, hipMemcpyDeviceToHost, e->stream));
+  if (trunc) HIP_TRY(e, hipMemcpyAsync(trunc, b + e->off_trunc, N, hipMemcpyDeviceToHost, e->stream));
+  if (dir) HIP_TRY(e, hipMemcpyAsync(dir, b + e->off_dir, N, hipMemcpyDeviceToHost, e->stream));
+  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, b + e->off_mission, N, hipMemcpyDeviceToHost, e->stream));
+  if (action) HIP_TRY(e, hipMemcpyAsync(action, b + e->off_action, N, hipMemcpyDeviceToHost, e->stream));
   return check_device_errors(e);
 }
 
 int mg_sync(mg_env* e) {
   if (!e) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
+  // the generator stream runs ahead-of-need work for the episodes to come: a sync covers it too, so that a timed
+  // region bracketed by mg_sync pays for every episode drawn inside it
+  if (e->gen_stream) HIP_TRY(e, hipStreamSynchronize(e->gen_stream));
   return check_device_errors(e);
 }
 
@@ -732,8 +882,14 @@ int mg_get_rng(mg_env* e, uint64_t* out) {
   HIP_TRY(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->N;
   { int rc = flush_refills(e); if (rc) return rc; }
-  // the reference env's stream position "now" is the state BEFORE the spare episode was drawn
-  const uint64_t* src = (e->static_gen || e->live_gen) ? e->rng : e->rng_snap;
+  // the reference env's stream position "now" is the state BEFORE its next unconsumed spare episode was drawn
+  const uint64_t* src = e->rng;
+  if (uses_ring(e)) {
+    const int tb = 256, nb = (e->N + tb - 1) / tb;
+    hipLaunchKernelGGL(k_gather_rng, dim3(nb), dim3(tb), 0, e->stream, e->rng_snap, e->head, (uint32_t)(e->R - 1), e->rng_tmp, e->N);
+    HIP_TRY(e, hipGetLastError());
+    src = e->rng_tmp;
+  }
   std::vector<uint64_t> soa(5 * N);
   HIP_TRY(e, hipMemcpyAsync(soa.data(), src, soa.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
@@ -751,8 +907,7 @@ int mg_set_rng(mg_env* e, const uint64_t* in) {
   HIP_TRY(e, hipMemcpyAsync(e->rng, soa.data(), soa.size() * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
   // re-draw every spare from the injected position
-  if (e->live_gen) return MG_OK;
-  return launch_generate(e, /*to_spare=*/true, -1, nullptr);
+  return refill_whole_ring(e, nullptr);
 }
 
 int mg_timer_start(mg_env* e) {
@@ -774,7 +929,7 @@ int mg_get_counters(mg_env* e, uint64_t out[4]) {
   std::vector<uint64_t> c(e->ncounters);
   HIP_TRY(e, hipMemcpyAsync(c.data(), e->counters, c.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  const size_t groups = (size_t)(e->N + 63) / 64, g0 = (size_t)STAT_EPISODES + groups;
+  const size_t groups = (size_t)e->nwaves, g0 = (size_t)STAT_EPISODES + groups;
   out[0] = e->env_steps; out[1] = out[2] = out[3] = 0;
   for (size_t k = 0; k < groups; k++) out[1] += c[STAT_EPISODES + k];
   for (size_t k = 0; k < STAT_GEN_SLOTS; k++) { out[2] += c[g0 + 2 * k]; out[3] += c[g0 + 2 * k + 1]; }
@@ -804,6 +959,26 @@ int mg_selftest_vis_row_n(int32_t view, uint32_t m, uint32_t t, uint32_t* m_out,
 int mg_selftest_reward_lut(int32_t max_steps, double* out) {
   if (!out || max_steps < 1) return MG_ERR_INVALID;
   build_reward_lut(max_steps, out);
+  return MG_OK;
+}
+int mg_selftest_stream(int32_t obe, int32_t nenv, const uint8_t* in, uint8_t* out) {
+  if (!in || !out || obe < 5 || nenv < 1 || nenv > 64) return MG_ERR_INVALID;
+  const uint32_t nd = ((uint32_t)obe + 3u) >> 2;
+  std::vector<uint32_t> stream(((size_t)nenv * obe + 3) / 4 + 2, 0xDEADBEEFu);
+  auto dword = [&](int l, uint32_t i) {                 // D[i] of lane l, garbage in the bytes past the env's end
+    uint32_t d = 0xA5A5A5A5u;
+    for (uint32_t b = 0; b < 4 && 4 * i + b < (uint32_t)obe; b++) d = (d & ~(0xFFu << (8 * b))) | ((uint32_t)in[(size_t)l * obe + 4 * i + b] << (8 * b));
+    return d;
+  };
+  for (int l = 0; l < nenv; l++) {
+    StreamEmit em;
+    em.setup(stream.data(), (uint32_t)l, (uint32_t)obe);
+    const uint32_t next0 = l + 1 < nenv ? dword(l + 1, 0) : 0u;
+    em.first(dword(l, 0));
+    for (uint32_t i = 1; i + 1 < nd; i++) em.put(dword(l, i));
+    em.put_last(dword(l, nd - 1), next0);
+  }
+  memcpy(out, stream.data(), (size_t)nenv * obe);
   return MG_OK;
 }
 int mg_render_tiles(int32_t tile_size, uint8_t* out) {

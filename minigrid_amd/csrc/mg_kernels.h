@@ -1,19 +1,24 @@
-// mg_kernels.h — HIP kernels for gfx950 (MI355X): the lockstep MiniGridEnv.step()/gen_obs()/FullyObs hot path,
-// the queue-driven episode generator, and seeding.  One wavefront lane per environment.
+// mg_kernels.h — HIP kernels for gfx950 (MI355X): the lockstep MiniGridEnv.step()/gen_obs()/FullyObs hot path as a
+// T-step fused rollout kernel, the asynchronous episode generator that keeps a ring of spare episodes per env full,
+// and seeding.  One wavefront lane per environment; one wavefront = 64 consecutive envs = one workgroup.
 //
 // HBM layout (all per mg_env handle; N envs, env-major):
-//   grid        u8  [N][CS]   one byte per cell (mg_device.h), row-major y*W+x, CS = W*H rounded up to 16
-//   spare_grid  u8  [N][CS]   the NEXT episode's map, generated ahead of time (see below)
-//   agent       u64 [N]       packed agent record (x, y, dir, carrying, step_count, flags, mission)
-//   spare_agent u64 [N]
-//   rng / rng_snap u64 [5][N] SoA generator state (current, and as it was before the spare was drawn)
-//   obs u8 [N][147 | W*H*3], reward f64 [N], terminated/truncated/direction/mission u8 [N]
+//   grid        u8  [N][CS]      one byte per cell (mg_device.h), row-major y*W+x, CS = W*H rounded up to 16
+//   spare_grid  u8  [R][N][CS]   ring of R pre-generated NEXT episodes per env (R = 1 for levels that draw nothing)
+//   agent       u64 [N]          packed agent record (x, y, dir, carrying, step_count, flags, mission)
+//   spare_agent u64 [R][N], spare_aux u64 [R][N]
+//   head / tail u32 [N]          spares consumed / generated so far; slot = count & (R-1); after a flush tail = head + R
+//   rng u64 [5][N]               generator state after the last generated spare; rng_snap u64 [R][5][N] = as it was
+//                                before slot s was drawn (what the reference env's np_random would hold at that point)
+//   out         [S] slots of { obs u8 [N][obe] | reward f64 [N] | terminated, truncated, direction, mission, action u8 [N] }:
+//               the trajectory ring; slot 0 is always the most recent step (mg_get_outputs), slot k the step k calls ago
 //
-// Why a spare episode: in the reference an env's np_random stream is consumed ONLY by reset() on this path, so the
-// map of episode k+1 can be drawn any time after episode k's map without changing the stream.  The step kernel
-// therefore never runs a generator: on (auto)reset it copies the pre-generated spare (CS bytes) and enqueues the
-// env id; a separate generator kernel (one wavefront per enqueued env, see mg_gen.h) refills those spares.  The
-// sequential PCG64 + rejection-sampling code stays off the step critical path.
+// Why spare episodes: in the reference an env's np_random stream is consumed ONLY by reset() on this path, so the
+// maps of episodes k+1, k+2, ... can be drawn any time after episode k's map without changing the stream.  The step
+// kernel therefore never runs a generator: on (auto)reset it takes the next spare out of the ring and files a refill
+// request; a generator kernel on a SECOND stream (one wavefront per request, mg_gen.h) refills the ring while later
+// step launches run.  The host orders the two streams with events so that a slot is never consumed before its refill
+// completed (mg_api.hip: batches); the sequential PCG64 + rejection-sampling code is off the step critical path.
 #pragma once
 #include "mg_device.h"
 #include "mg_gen.h"
@@ -33,20 +38,26 @@ enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RU
               RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11 };
 
 struct StepParams {
-  // state
-  uint8_t* grid; const uint8_t* spare_grid; uint64_t* agent; const uint64_t* spare_agent;
-  uint64_t* aux; const uint64_t* spare_aux;      // BabyAI GoTo levels: bitboard of the tracked target positions
-  // inputs
-  const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t;
-  // outputs
-  uint8_t* obs; double* reward; uint8_t* term; uint8_t* trunc; uint8_t* dir_out; uint8_t* mission_out;
-  // tables / bookkeeping
-  const double* reward_lut; uint32_t* refill_queue; uint32_t* refill_count; uint32_t* err;
-  unsigned long long* counters;
-  // config
-  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen, gen_blocks;
+  // ---- state ----
+  uint8_t* grid; uint64_t* agent;
+  uint64_t* aux;                                  // BabyAI GoTo levels: bitboard of the tracked target positions
+  const uint8_t* spare_grid; const uint64_t* spare_agent; const uint64_t* spare_aux;   // rings [R][N]...
+  uint32_t* head; uint32_t ring_mask;             // spares consumed per env; slot = head & ring_mask
+  uint32_t* seg; uint32_t* seg_count; int seg_cap;   // this batch's refill requests: one segment of seg_cap env ids per wave
+  // ---- inputs ----
+  const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t0;   // buffer: [T][N] of act_dtype
+  const uint8_t* obs_mask;                        // PHASE_OBSERVE of a masked reset(): only these envs take a new episode
+  // ---- outputs: slot s of the trajectory ring starts at out + s * slot_bytes; step j of this launch -> slot slot0 - j (mod S) ----
+  uint8_t* out; unsigned long long slot_bytes, off_reward, off_term, off_trunc, off_dir, off_mission, off_action;
+  uint8_t* obs; unsigned long long obs_stride;    // observation stream of slot s at obs + s * obs_stride (= out / slot_bytes, or the RGB tile map)
+  int T, slot0, S;
+  // ---- tables / bookkeeping ----
+  const double* reward_lut; uint32_t* err; unsigned long long* counters;
+  // ---- config ----
+  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen;
   int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
-  int off_grid, off_trow, off_vis, off_T, off_lut, off_act, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
+  int use_shadow;         // the next spare of every env is staged in LDS at launch start (fused launches)
+  int off_grid, off_shadow, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
@@ -62,16 +73,18 @@ MG_D double reward_exact(uint32_t step, int max_steps) {
   return __dsub_rn(1.0, p);
 }
 
-MG_D uint32_t load_action(const StepParams& P, int e) {
-  if (P.act_src == ACT_SRC_PHILOX) {
-    uint64_t gi = (uint64_t)(P.env_base + e);
-    uint32_t c[4] = { (uint32_t)gi, (uint32_t)(gi >> 32), P.t, 0x41435431u };
-    philox4x32_10(c, (uint32_t)P.action_seed, (uint32_t)(P.action_seed >> 32));
-    return (uint32_t)(((uint64_t)c[0] * 7u) >> 32);      // uniform over Discrete(7) (minigrid_env.py:63)
-  }
-  if (P.act_dtype == 0) return ((const uint8_t*)P.actions)[e];
-  if (P.act_dtype == 1) return (uint32_t)((const int32_t*)P.actions)[e];
-  long long v = ((const long long*)P.actions)[e];
+// Uniform-random policy on the device: Philox4x32-10 keyed by action_seed, counter = (global env index, t / 4); the
+// four output words are the actions of steps 4*(t/4) .. 4*(t/4)+3, each mapped to Discrete(7) (minigrid_env.py:63).
+MG_D void philox_action_block(const StepParams& P, int e, uint32_t tblk, uint32_t w[4]) {
+  const uint64_t gi = (uint64_t)(P.env_base + e);
+  w[0] = (uint32_t)gi; w[1] = (uint32_t)(gi >> 32); w[2] = tblk; w[3] = 0x41435431u;
+  philox4x32_10(w, (uint32_t)P.action_seed, (uint32_t)(P.action_seed >> 32));
+}
+MG_D uint32_t load_action(const StepParams& P, int e, int j) {
+  const size_t i = (size_t)j * (size_t)P.N + (size_t)e;
+  if (P.act_dtype == 0) return ((const uint8_t*)P.actions)[i];
+  if (P.act_dtype == 1) { const int32_t v = ((const int32_t*)P.actions)[i]; return (v < 0 || v > 255) ? 255u : (uint32_t)v; }
+  const long long v = ((const long long*)P.actions)[i];
   return (v < 0 || v > 255) ? 255u : (uint32_t)v;
 }
 
@@ -84,26 +97,69 @@ MG_D uint32_t inb_mask_v(int c0, int s, int L, int V) {
 }
 
 // ======================================================================================================
+// Observation byte stream.  The 64 envs of a wave produce ONE contiguous byte stream (env-major, obe bytes per env) that
+// is staged in LDS and copied out with 16 B per lane.  obe is odd (147, 243, ...), so an env's bytes do not start on a
+// dword of the stream; byte stores at a 147-byte lane stride were the LDS-conflict hot spot of the previous kernel.
+// Here every lane packs its env's bytes into dwords IN REGISTERS (D[0], D[1], ...: little-endian, stream order) and
+// hands them to StreamEmit, which shifts them by the env's phase and writes only whole, aligned stream dwords:
+//   B = l * obe                     first stream byte of lane l's env
+//   q = (-B) & 3                    leading bytes that belong to the last dword STARTING in env l-1
+//   lane l writes the dwords starting inside its env: indices ceil(B/4) .. ceil((B+obe)/4) - 1
+//   E[i] = bytes [q+4i, q+4i+4) of the env's stream continued by the next env's = funnel(D[i+1] : D[i], q)
+// The one dword a lane cannot complete alone is its last: it ends with the first bytes of the next env, fetched from
+// lane l+1's D[0] by the caller.  Host-callable so that the CPU suite can check it for every obe (mg_selftest_stream).
+// ======================================================================================================
+MG_HD uint32_t funnel_bytes(uint32_t hi, uint32_t lo, uint32_t q) {      // ({hi:lo} >> 8q), q in 0..3
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __funnelshift_r(lo, hi, 8u * q);
+#else
+  return q ? (lo >> (8u * q)) | (hi << (32u - 8u * q)) : lo;
+#endif
+}
+struct StreamEmit {
+  uint32_t* p;        // next aligned dword of the group's stream this lane writes
+  uint32_t prev;      // last dword handed in, not yet written out
+  uint32_t q;
+  uint32_t tb;        // valid bytes of the env's last dword D[ND-1] (1..4)
+  MG_HD void setup(uint32_t* stream, uint32_t l, uint32_t obe) {
+    const uint32_t B = l * obe;
+    q = (0u - B) & 3u;
+    p = stream + ((B + q) >> 2);
+    const uint32_t nd = (obe + 3u) >> 2;
+    tb = obe - 4u * (nd - 1u);
+  }
+  MG_HD void first(uint32_t d0) { prev = d0; }
+  MG_HD void put(uint32_t d) { *p++ = funnel_bytes(d, prev, q); prev = d; }
+  // the env's last dword (tb valid bytes), completed with the first bytes of the next env's stream (next0 = its D[0])
+  MG_HD void put_last(uint32_t d, uint32_t next0) {
+    const uint32_t xl = tb < 4u ? ((d & ((1u << (8u * tb)) - 1u)) | (next0 << (8u * tb))) : d;
+    const uint32_t xa = tb < 4u ? (next0 >> (32u - 8u * tb)) : next0;
+    put(xl);
+    if (q < tb) *p = funnel_bytes(xa, prev, q);          // one more dword starts inside this env
+  }
+};
+
+// ======================================================================================================
 // Episode generation (the reference's _gen_grid, see mg_gen.h): one wavefront draws one episode.
-// Work list: the refill queue written by k_step, or all envs selected by `mask` (explicit reset(seed=...)).
 // ======================================================================================================
 struct GenArgs {
   GenParams gp;
-  uint8_t* dst_grid; uint64_t* dst_agent;
-  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state there first
-  const uint32_t* queue; const uint32_t* count;      // queue mode (count read on device)
-  uint32_t* zero_count;                              // a queue counter nobody uses during this launch: cleared
+  uint8_t* dst_grid; uint64_t* dst_agent;            // slot 0 of the destination (ring or live state)
+  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state of slot s there first
+  uint64_t* dst_aux;                                 // auxiliary word of the generated episode (GenResult.aux) or null
   const uint8_t* mask;                               // direct mode: optional per-env mask
   uint32_t* err; unsigned long long* counters;
   int N, CS;
   int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
   int stat_gen_off;                                  // first generator statistics slot in `counters`
-  uint64_t* dst_aux;                                 // auxiliary word of the generated episode (GenResult.aux) or null
-  int live;                                          // 1: queue entries are regenerated IN PLACE (dst = live state): only
+  int live;                                          // 1: requests are regenerated IN PLACE (dst = live state): only
                                                      //    envs still flagged RESET_PENDING are drawn, and come out FRESH
+  // refill mode (k_refill): request segments of one batch, ring bookkeeping
+  const uint32_t* seg; uint32_t* seg_count; int seg_cap;
+  const uint32_t* head; uint32_t* tail; uint32_t* claim; uint32_t epoch; uint32_t ring_mask;
 };
 
-// `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env group |
+// `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env wave |
 // STAT_GEN_SLOTS x {maps generated, whole-map retries}; mg_get_counters sums them on the host
 constexpr int STAT_EPISODES = 16;
 constexpr uint32_t STAT_GEN_SLOTS = 4096;
@@ -121,16 +177,17 @@ constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
 constexpr int GEN_SCRATCH_BYTES = 64;   // generator state that must survive a restart from a checkpoint (MultiRoom's room lists), at the end
 MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4 + GEN_SCRATCH_BYTES; }
 
-// wave-cooperative: all 64 lanes of one wave call this with the same `e`; `lds` = gen_wave_lds_bytes() of LDS
+// wave-cooperative: all 64 lanes of one wave call this with the same `e` and ring slot; `lds` = gen_wave_lds_bytes() of LDS
 template <int GG, class RNG>
-MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t* lds) {
+MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_t flags_out, uint32_t lane, uint8_t* lds) {
   const size_t N = (size_t)A.N;
+  const size_t se = (size_t)slot * N + (size_t)e;      // index of (slot, env) in the [R][N] arrays
 
   uint8_t* mygrid = lds;
   MG_STAMP(1);
   rng.load(A.rng, N, (size_t)e, lds + A.CS);
   MG_STAMP(2);
-  if (A.rng_snap && lane < 5u) A.rng_snap[lane * N + (size_t)e] = pick5(rng.w_in, lane);
+  if (A.rng_snap && lane < 5u) A.rng_snap[(size_t)slot * 5u * N + lane * N + (size_t)e] = pick5(rng.w_in, lane);
   GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
   for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
   GenResult out;
@@ -149,8 +206,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
     MG_STAMP(3);
     rng.begin_pass();
     // The generator parameters are made opaque per pass: otherwise every switch case's loop-invariant set-up is
-    // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70, i.e.
-    // 256 B/lane of scratch on every wave of a k_step launch under its register budget.
+    // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70.
     GenParams gp = A.gp;
     gp.scratch_off = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
     asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
@@ -170,13 +226,13 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
   MG_STAMP(5);
   if (lane < 5u) A.rng[lane * N + (size_t)e] = pick5(w, lane);
   MG_WAVE_LDS_SYNC();
-  uint4* dst = (uint4*)(A.dst_grid + (size_t)e * A.CS);
+  uint4* dst = (uint4*)(A.dst_grid + se * A.CS);
   for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
   if (lane == 0) {
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
-    ag.flags = (A.live && A.queue) ? FLAG_FRESH : 0u;
-    A.dst_agent[e] = agent_pack(ag);
-    if constexpr (GG != GG_LIGHT && GG != GG_ROOMS) { if (A.dst_aux) A.dst_aux[e] = out.aux; }     // no GG_LIGHT / GG_ROOMS level has an auxiliary word
+    ag.flags = flags_out;
+    A.dst_agent[se] = agent_pack(ag);
+    if (A.dst_aux) A.dst_aux[se] = out.aux;
     if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
@@ -186,7 +242,8 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t lane, uint8_t
   MG_WAVE_LDS_SYNC();
 }
 
-// stand-alone launch: 4 generating waves per workgroup (explicit resets, flushes of a pending refill queue)
+// Direct launch over all envs (optionally masked): explicit reset(seed=...), mg_set_rng.  4 generating waves per workgroup.
+// The destination pointers are pre-offset to the ring slot by the host.
 constexpr int GEN_THREADS = 256;
 template <class RNG>
 __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
@@ -194,509 +251,650 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   const uint32_t lane = threadIdx.x & 63u;
   const int wave = (int)(threadIdx.x >> 6);
   MG_STAMP(0);
-  if (A.zero_count && blockIdx.x == 0 && threadIdx.x == 0) *A.zero_count = 0u;
   RNG rng;
   rng.prefetch(lane);
-  const int total = A.queue ? (int)uni32(*A.count) : A.N;
   uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
   const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
-  for (int i = (int)blockIdx.x * (GEN_THREADS / 64) + wave; i < total; i += nwaves) {
-    const int e = A.queue ? (int)uni32(A.queue[i]) : i;
-    if (!A.queue && A.mask && !uni32(A.mask[e])) continue;
-    generate_one<GG_ALL, RNG>(A, rng, e, lane, lds);
+  for (int e = (int)blockIdx.x * (GEN_THREADS / 64) + wave; e < A.N; e += nwaves) {
+    if (A.mask && !uni32(A.mask[e])) continue;
+    generate_one<GG_ALL, RNG>(A, rng, e, 0u, 0u, lane, lds);
   }
 }
 
+// Refill launch (second stream): workgroup b serves the request segment of step-wave b -- the envs of that 64-env group
+// that took a spare out of their ring during the batch.  A request is an env id; an env may be listed more than once
+// (several launches of one batch), the first wave to raise claim[e] to this batch's epoch serves it: it draws episodes
+// into the consumed slots tail .. head-1 in stream order.  head[] may already be ahead of what the batch consumed
+// (later step launches run concurrently): those slots are free as well, and drawing them early is harmless.
+// live = 1 (DynamicObstacles, same stream, right before the step launch): requests are the envs whose episode ended;
+// they are redrawn IN PLACE if they are still waiting for a reset, and come out FRESH (observed, not stepped).
+template <class RNG>
+__global__ void __launch_bounds__(GEN_THREADS) k_refill(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const int wave = (int)(threadIdx.x >> 6);
+  const int cnt = (int)uni32(A.seg_count[blockIdx.x]);
+  if (cnt == 0) return;
+  RNG rng;
+  rng.prefetch(lane);
+  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
+  const uint32_t* seg = A.seg + (size_t)blockIdx.x * A.seg_cap;
+  for (int k = wave; k < cnt; k += GEN_THREADS / 64) {
+    const int e = (int)uni32(seg[k]);
+    uint32_t old = 0;
+    if (lane == 0) old = atomicMax(&A.claim[e], A.epoch);
+    if (uni32(old) >= A.epoch) continue;                       // another request of this batch already covers the env
+    if (A.live) {
+      const uint32_t fl = (uint32_t)(uni64(A.dst_agent[e]) >> 48) & 0xFFu;
+      if (!(fl & FLAG_RESET_PENDING)) continue;                // an explicit reset() has drawn this env in the meantime
+      generate_one<GG_ALL, RNG>(A, rng, e, 0u, FLAG_FRESH, lane, lds);
+      continue;
+    }
+    const uint32_t h = uni32(A.head[e]) + A.ring_mask + 1u;    // every slot below head + R is free to fill
+    uint32_t t = uni32(A.tail[e]);
+    if (h - t > A.ring_mask + 1u) { if (lane == 0) atomicOr(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
+    while (t != h) {
+      generate_one<GG_ALL, RNG>(A, rng, e, t & A.ring_mask, 0u, lane, lds);
+      t++;
+    }
+    if (lane == 0) A.tail[e] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) A.seg_count[blockIdx.x] = 0u;          // the segment is reused QSETS batches later
+}
+
+// mg_get_rng: the reference env's stream position "now" = the state before its next unconsumed spare was drawn
+__global__ void k_gather_rng(const uint64_t* rng_snap, const uint32_t* head, uint32_t ring_mask, uint64_t* out, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const size_t s = head ? (size_t)(head[e] & ring_mask) : 0;
+  for (int k = 0; k < 5; k++) out[(size_t)k * N + e] = rng_snap[(s * 5 + k) * (size_t)N + e];
+}
+
+// reset(seed=...): the ring of the selected envs restarts (head = 0; the host then draws all R slots, tail = R)
+__global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* mask, uint32_t R, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N || (mask && !mask[e])) return;
+  head[e] = 0u; tail[e] = R;
+}
+
 // ======================================================================================================
-// k_step: MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr (roomgrid_level.py:87-104,
-// verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/encode) or
-// FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset.
+// k_step: T lockstep steps of MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr
+// (roomgrid_level.py:87-104, verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/
+// encode) or FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset -- the loop of
+// minigrid/benchmark.py:36-43 for 64 envs per wavefront.  T = 1 is Env.step(); T > 1 is the fused rollout.
 // MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3,
 // 4 = tile map for k_render (RGBImgPartialObsWrapper: VxV bytes; RGBImgObsWrapper: WxH bytes), byte = tile key * 2 + highlight.
-// WPG = wavefronts per group of 64 envs (1, 2 or 4).  VT = 7 (default view, unrolled) or 15 (run-time V <= 15).
-// GG = generator group compiled into the generator role (mg_gen.h; GG_NONE for levels whose reset draws nothing).
+// FAST7: MODE 0 with the reference's default 7x7 view, fully unrolled.  GG = rule group compiled in (mg_gen.h).
 //
-// One workgroup = 64 consecutive envs; lane l of EVERY wave is env l.  The kernel is VALU-issue bound (profiles/),
-// so the split is chosen to minimise instructions while keeping the chip full: the per-env scalar dynamics (~150
-// instructions) are recomputed by each wave; view rows / grid columns are dealt round-robin to the waves; the
-// sequential process_vis pass runs in ONE wave and is shared through LDS; the host picks WPG so that a launch has
-// >= ~4 waves per SIMD (small batches: 4, large batches: 1 = no redundant work at all).
-// LDS: the 64 staged grids (coalesced 16 B/lane loads) between two guard bands so that out-of-grid view cells
-// need no address clamp, per-env opacity rows, the visibility mask, the observation as final output bytes (copied
-// out with 16 B/lane stores), and a 256-entry cell code -> (type,colour,state) table.
+// A wavefront is autonomous: lane l = env env0 + l, no workgroup barrier anywhere.  Launch start: the 64 grids are staged
+// into LDS with 16 B/lane coalesced loads (and, for fused launches, each env's next spare episode into a shadow copy).
+// Per step, all in registers + LDS: Philox action, dynamics (the one modified cell is written in place), view gather
+// through a guard-banded layout (out-of-grid cells need no address clamp, only a mask), process_vis as bit-parallel rows,
+// encode through a 256-entry LDS table, the wave's observations packed into aligned stream dwords (StreamEmit) and
+// copied out with 16 B/lane stores, scalars with one coalesced store each.  HBM traffic per env-step in the loop: the
+// outputs only (obe + 13 bytes written); the grid is read once and written back once per launch.
 // ======================================================================================================
-template <int MODE, int WPG, class RNG, int VT, int GG>
-__global__ void __launch_bounds__(64 * WPG) __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs: no scratch in any 7x7 variant; measured best
-k_step(const StepParams P, const GenArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  constexpr int NT = 64 * WPG;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  // ---- generator role: the FIRST gen_blocks workgroups refill the spare episodes that the PREVIOUS launch
-  //      consumed (its refill queue), one generating wave per workgroup, concurrently with this launch's step
-  //      groups.  Disjointness: an env consumed its spare in launch L-1 without stepping, so it cannot be due for
-  //      a reset in launch L; the step groups of launch L therefore never read the spares written here, and launch
-  //      L+1 starts after this one has completed. ----
-  if (GG != GG_NONE && (int)blockIdx.x < P.gen_blocks) {
-    MG_STAMP(0);
-    __builtin_amdgcn_s_setprio(3);      // few, latency-critical scalar waves: issue ahead of the step waves
-    if (blockIdx.x == 0 && lane == 0) *A.zero_count = 0u;
-    // the queue slot, the queue length and the jump table are loaded together (one memory round trip, not three);
-    // a slot beyond the queue's length holds a stale env id that is simply not used
-    // Entry i of the queue goes to wave (i / gen_blocks) % WPG of workgroup i % gen_blocks: a short queue is served
-    // by the wave 0s of as many workgroups as possible, a synchronized truncation burst by all waves.
-    RNG rng;
-    rng.prefetch((uint32_t)lane);
-    const int first = (int)blockIdx.x + wave * P.gen_blocks;
-    int e = first < A.N ? (int)A.queue[first] : 0;
-    const int total = (int)uni32(*A.count);
-    uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
-    for (int i = first; i < total; i += P.gen_blocks * WPG) {
-      if (i != first) e = (int)A.queue[i];
-      generate_one<GG, RNG>(A, rng, (int)uni32((uint32_t)e), (uint32_t)lane, lds);
+template <bool SEE_THROUGH>
+MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
+                    int lane, int nvalid) {
+  const int W = P.W, H = P.H;
+  constexpr int V = 7, HV = 3;
+  const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
+  const int rx = -fyv, ry = fxv;
+  const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
+  const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
+  const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
+  const int SR = ry * W + rx;                                 // linear index step per vx
+  const int SU = -(fyv * W + fxv);                            // linear index step per vy
+  // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
+  const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
+  uint32_t code[VIEW_CELLS];                                  // output order k = vx * 7 + vy
+  uint32_t trow[V];
+#pragma unroll
+  for (int vy = 0; vy < V; vy++) {
+    const uint8_t* rowp = vbase + vy * SU;
+    const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
+    uint32_t opq = 0;
+#pragma unroll
+    for (int vx = 0; vx < V; vx++) {
+      const uint32_t raw = rowp[vx * SR];
+      const uint32_t valid = 0u - ((cm >> vx) & 1u);
+      const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+      code[vx * V + vy] = c;
+      opq |= (c >> 7) << vx;
     }
-    return;
+    trow[vy] = ~opq & 0x7Fu;
   }
-  const int env0 = ((int)blockIdx.x - P.gen_blocks) * 64;
+  // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6
+  unsigned long long vis = ~0ull;
+  if (!SEE_THROUGH) {
+    uint32_t m = 1u << HV;
+    vis = 0;
+#pragma unroll
+    for (int j = V - 1; j >= 0; j--) {
+      uint32_t vr, up;
+      vis_row(m, trow[j], &vr, &up);
+      vis |= (unsigned long long)vr << (7 * j);
+      m = up;
+    }
+  }
+  // Grid.encode(vis_mask) (grid.py:244-268) in image[vx][vy][c] order; invisible -> (0,0,0); the agent's own cell shows
+  // what it carries (minigrid_env.py:623-630).  4 cells = 12 bytes = 3 stream dwords.
+  auto tri_of = [&](int k) -> uint32_t {
+    const int vx = k / V, vy = k % V;
+    uint32_t c = code[k];
+    if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+    if (SEE_THROUGH) return slut[c];
+    return slut[c & (0u - ((uint32_t)(vis >> (7 * vy + vx)) & 1u))];
+  };
+  StreamEmit em;
+  em.setup(stream, (uint32_t)lane, (uint32_t)PARTIAL_OBS_BYTES);
+  uint32_t next0 = 0;
+#pragma unroll
+  for (int g = 0; g < 12; g++) {
+    const uint32_t t0 = tri_of(4 * g), t1 = tri_of(4 * g + 1), t2 = tri_of(4 * g + 2), t3 = tri_of(4 * g + 3);
+    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
+    if (g == 0) {
+      em.first(d0);
+      next0 = (uint32_t)__shfl_down((int)d0, 1);
+      if (lane >= nvalid - 1) next0 = 0u;
+    } else em.put(d0);
+    em.put(d1); em.put(d2);
+  }
+  em.put_last(tri_of(48), next0);
+}
+
+// The same for any odd view size V <= 15 (ViewSizeWrapper), the one-hot encode (MODE 2) and the RGB tile map (MODE 4):
+// run-time loops, visibility rows kept in LDS (16 x u16 per env), bytes stored straight at their stream position.
+template <int MODE>
+MG_D void obs_view_generic(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint16_t* rows,
+                           uint8_t* myT, bool active) {
+  const int W = P.W, H = P.H;
+  const int V = P.view, HV = V >> 1;
+  const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
+  const int rx = -fyv, ry = fxv;
+  const bool horiz = fyv == 0;
+  const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
+  const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
+  const int SR = ry * W + rx, SU = -(fyv * W + fxv);
+  const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
+  const uint32_t full = (1u << V) - 1u;
+  auto cell_at = [&](int vx, int vy) -> uint32_t {
+    const uint32_t raw = vbase[vy * SU + vx * SR];
+    const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
+    return ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
+  };
+  if (!P.see_through) {
+#pragma unroll 1
+    for (int vy = 0; vy < V; vy++) {
+      uint32_t opq = 0;
+      for (int vx = 0; vx < V; vx++) opq |= (cell_at(vx, vy) >> 7) << vx;
+      rows[vy] = (uint16_t)(~opq & full);
+    }
+    uint32_t m = 1u << HV;
+#pragma unroll 1
+    for (int j = V - 1; j >= 0; j--) {
+      uint32_t vr, up;
+      vis_row_n(m, rows[j], V, &vr, &up);
+      rows[j] = (uint16_t)vr;
+      m = up;
+    }
+  }
+#pragma unroll 1
+  for (int vy = 0; vy < V; vy++) {
+    const uint32_t vrow = P.see_through ? full : (uint32_t)rows[vy];
+    for (int vx = 0; vx < V; vx++) {
+      uint32_t c = cell_at(vx, vy);
+      if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+      const uint32_t bit = (vrow >> vx) & 1u;
+      if (MODE == 4) {
+        // get_pov_render (minigrid_env.py:652-666): process_vis has blanked the invisible cells (grid.py:324-327),
+        // so they are empty un-highlighted tiles (byte 0); visible ones are highlighted.  Image order [vy][vx].
+        if (!P.rgb_full) myT[vy * V + vx] = (uint8_t)(slut[c] & (0u - bit));
+        continue;
+      }
+      const uint32_t tri = slut[c & (0u - bit)];
+      if (MODE == 0) {
+        uint8_t* o = myT + (vx * V + vy) * 3;
+        o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
+      } else if (active) {
+        // OneHotPartialObsWrapper (wrappers.py:267-284): 20 bytes per cell, one 1 in each of the type / colour / state
+        // groups.  Lanes past the batch end hold stale LDS "cells": their codes could index past the 20 bytes.
+        uint8_t* o = myT + (vx * V + vy) * 20;
+        uint32_t* o4 = (uint32_t*)o;
+        o4[0] = 0; o4[1] = 0; o4[2] = 0; o4[3] = 0; o4[4] = 0;
+        o[tri & 0xFF] = 1; o[11 + ((tri >> 8) & 0xFF)] = 1; o[17 + (tri >> 16)] = 1;
+      }
+    }
+  }
+  if (MODE == 4 && P.rgb_full) {
+    // get_full_render (minigrid_env.py:668-714): every grid cell, highlighted where the agent's view sees it.
+    // World cell (x, y) is view cell (HV + d.r, V-1 - d.f) with d = (x, y) - agent: the inverse of the gather above.
+    const uint32_t hl_on = P.rgb_highlight ? 1u : 0u;
+#pragma unroll 1
+    for (int y = 0; y < H; y++) {
+      const int dy = y - (int)a.y;
+      for (int x = 0; x < W; x++) {
+        const int idx = y * W + x, dx = x - (int)a.x;
+        const uint32_t c = mygrid[idx];
+        const int fwd = dx * fxv + dy * fyv, side = dx * rx + dy * ry + HV;
+        const bool inside = (unsigned)fwd < (unsigned)V && (unsigned)side < (unsigned)V;
+        const uint32_t vrow = P.see_through ? full : (uint32_t)rows[inside ? V - 1 - fwd : 0];
+        const uint32_t bit = inside ? ((vrow >> side) & hl_on) : 0u;
+        myT[idx] = (uint8_t)(slut[c] - 1u + bit);
+      }
+    }
+  }
+}
+
+// MODE 1: FullyObsWrapper.observation (wrappers.py:419-426): grid.encode() in image[x][y] order, agent cell = (10, 0, dir).
+// MODE 3: SymbolicObsWrapper.observation (wrappers.py:763-782): (x, y, type or -1), agent cell type = 10.
+// Three bytes per cell in x-major order: 4 cells = 3 stream dwords, like the partial view.
+template <int MODE>
+MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
+                   int lane, int nvalid) {
+  const int W = P.W, H = P.H, cells = P.cells;
+  const int aidx = (int)a.y * W + (int)a.x;
+  int x = 0, y = 0;
+  auto next_tri = [&]() -> uint32_t {
+    const int idx = y * W + x;
+    uint32_t c = mygrid[idx], r;
+    if (MODE == 1) {
+      if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
+      r = slut[c];
+    } else {
+      const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
+      r = (uint32_t)x | ((uint32_t)y << 8) | (t << 16);
+    }
+    if (++y == H) { y = 0; x++; }
+    return r;
+  };
+  StreamEmit em;
+  em.setup(stream, (uint32_t)lane, (uint32_t)(cells * 3));
+  uint32_t next0;
+  const int rem = cells & 3, nunits = cells >> 2;            // cells >= 9
+  {
+    const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
+    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
+    em.first(d0);
+    next0 = (uint32_t)__shfl_down((int)d0, 1);
+    if (lane >= nvalid - 1) next0 = 0u;
+    em.put(d1);
+    if (nunits == 1 && rem == 0) { em.put_last(d2, next0); return; }
+    em.put(d2);
+  }
+#pragma unroll 1
+  for (int u = 1; u < nunits; u++) {
+    const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
+    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
+    em.put(d0); em.put(d1);
+    if (u == nunits - 1 && rem == 0) { em.put_last(d2, next0); return; }
+    em.put(d2);
+  }
+  if (rem == 1) { em.put_last(next_tri(), next0); }
+  else if (rem == 2) { const uint32_t t0 = next_tri(), t1 = next_tri(); em.put(t0 | (t1 << 24)); em.put_last(t1 >> 8, next0); }
+  else { const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(); em.put(t0 | (t1 << 24)); em.put((t1 >> 8) | (t2 << 16)); em.put_last(t2 >> 16, next0); }
+}
+
+template <int MODE, bool FAST7, int GG>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))    // one autonomous wave per workgroup; LDS, not registers, bounds the occupancy
+k_step(const StepParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const int wg = blockIdx.x;
+  const int env0 = wg * 64;
   const int e = env0 + lane;
   const bool active = e < P.N;
   const int nvalid = min(64, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
+  const size_t N = (size_t)P.N;
+  uint32_t* slut = (uint32_t*)smem;                              // 256-entry cell code -> (type, colour, state) / tile key table
   uint8_t* sgrid = smem + P.off_grid;
-  uint8_t* strow = smem + P.off_trow;
-  unsigned long long* svis = (unsigned long long*)(smem + P.off_vis);
+  uint8_t* sshadow = smem + P.off_shadow;
+  uint16_t* srows = (uint16_t*)(smem + P.off_trow) + lane * 16;
   uint8_t* sT = smem + P.off_T;
-  uint32_t* slut = (uint32_t*)(smem + P.off_lut);
-  uint8_t* sact = smem + P.off_act;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  auto block_sync = [&]() {
-    if constexpr (WPG == 1) { MG_WAVE_LDS_SYNC(); } else { __syncthreads(); }
-  };
+  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ);
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
-  // Every level-specific rule belongs to exactly one generator group (mg_create checks it), so a variant only carries
-  // the rules its levels can have: GG_ROOMGRID GoTo / Unlock / Pickup, GG_LIGHT Fetch / GoToDoor / RedBlueDoors /
-  // Memory, GG_NONE DynamicObstacles.
-  uint64_t targets = 0;                         // BabyAI GoTo levels: tracked positions, issued with the other loads
-  if constexpr (GG == GG_ROOMGRID) targets = ((P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ) && active) ? P.aux[e] : 0ull;
+  uint64_t targets = (goto_rule && active) ? P.aux[e] : 0ull;   // BabyAI GoTo levels: tracked positions
+  uint32_t h = (P.head && active) ? P.head[e] : 0u;
+  const uint32_t h_in = h;
+  uint32_t qn = P.seg_count ? uni32(P.seg_count[wg]) : 0u;
+  const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
+  uint64_t sp_rec = 0, sp_aux = 0;
+  bool shadow_valid = false;
+  if (P.use_shadow && active) {
+    const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
+    sp_rec = P.spare_agent[se];
+    if (goto_rule) sp_aux = P.spare_aux[se];
+    shadow_valid = true;
+  }
 #pragma unroll
-  for (int k = tid; k < 256; k += NT) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
-  if (wave == 0) sact[lane] = (uint8_t)((active && P.phase == PHASE_STEP) ? load_action(P, e) : (uint32_t)A_DONE);
+  for (int k = lane; k < 256; k += 64) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
+  const int cpe = CS >> 4;
+  const int nchunks = nvalid * cpe;
   {
-    // stage the 64 grids: 16 B per lane, fully coalesced; an env whose previous step ended its episode takes the
-    // pre-generated spare episode instead (MiniGridEnv.reset, minigrid_env.py:119-157) and makes it the live grid
-    const int cpe = CS >> 4;
-    const int nchunks = nvalid * cpe;
+    // stage the 64 grids: 16 B per lane, fully coalesced (and the next spare episode of every env next to it)
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
-    for (int c = tid; c < nchunks; c += NT) {
+    for (int c = lane; c < nchunks; c += 64) {
       const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
       const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
-      const uint64_t srec = P.agent[env0 + el];
-      uint4 v = live[c];
-      if (((uint32_t)(srec >> 48) & FLAG_RESET_PENDING) && reset_enabled) {
-        v = ((const uint4*)(P.spare_grid + (size_t)env0 * CS))[c];
-        ((uint4*)(P.grid + (size_t)env0 * CS))[c] = v;
-      }
+      const uint4 v = live[c];
       uint32_t* dst = (uint32_t*)(sgrid + el * GS + part * 16);
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      if (P.use_shadow) {
+        const uint32_t slot = (uint32_t)__shfl((int)h, (int)el) & P.ring_mask;
+        const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + el) * CS))[part];
+        uint32_t* d2 = (uint32_t*)(sshadow + el * GS + part * 16);
+        d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
+      }
     }
   }
-  block_sync();
+  MG_WAVE_LDS_SYNC();
 
   Agent a = agent_unpack(rec);
-  const uint8_t* mygrid = sgrid + lane * GS;
-  uint32_t act = sact[lane];
-  if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
-  if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
-  double reward = 0.0;
-  uint32_t term = 0, trunc = 0, errbits = 0;
-  bool rec_dirty = false;
-  // The staged LDS grid is READ-ONLY after the barrier: the waves recompute the dynamics redundantly, so a wave
-  // that wrote the toggled/picked/dropped cell back into LDS would be seen by a slower wave as its *input*.
-  // Instead the one cell an action can change is patched on the fly.  It can only change under pickup/drop/toggle,
-  // which leave the pose alone, so it is always the cell straight ahead: view cell (3,5).
-  int dirty_idx = -1;              // linear index of the modified cell, -1 = none
-  uint32_t dirty_code = 0;
+  uint8_t* mygrid = sgrid + lane * GS;
+  bool rec_dirty = false, aux_dirty = false, wb_all = false;
+  uint32_t errbits = 0, fin_total = 0;
+  uint32_t pw[4] = { 0, 0, 0, 0 };
 
-  if (active) {
-    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled) {
-      a = agent_unpack(P.spare_agent[e]);
-      a.carry = 0; a.step = 0; a.flags = 0;
-      rec_dirty = true;
-      if constexpr (GG == GG_ROOMGRID) if ((P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ) && wave == 0) P.aux[e] = P.spare_aux[e];
-      if (wave == 0 && !P.static_gen) {
-        const uint32_t slot = atomicAdd(P.refill_count, 1u);
-        P.refill_queue[slot] = (uint32_t)e;
-      }
-    } else if (a.flags & FLAG_FRESH) {
-      a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
-      rec_dirty = true;
-    } else if (P.phase == PHASE_STEP) {
-      // ---- MiniGridEnv.step ----
-      rec_dirty = true;
-      a.step = min(a.step + 1u, 0xFFFFu);
-      const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-      const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
-      if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
-      const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
-      const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
-      uint32_t newF = F;
-      const uint32_t ftype = cell_type(F);
-      bool success = false;
-      if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
-      else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
-      else if (act == A_FORWARD) {
-        if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
-        if (ftype == T_GOAL) { term = 1; success = true; }
-        if (ftype == T_LAVA) term = 1;
-      } else if (act == A_PICKUP) {
-        if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
-      } else if (act == A_DROP) {
-        if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
-      } else if (act == A_TOGGLE) {
-        newF = cell_toggle(F, a.carry);
-      } else if (act != A_DONE) {
-        errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
-      }
-      if (newF != F && inb) {
-        dirty_idx = (int)fidx; dirty_code = newF;
-        if (wave == 0) P.grid[(size_t)e * CS + fidx] = (uint8_t)newF;
-      }
-      trunc = a.step >= (uint32_t)P.max_steps;
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
-        // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
-        // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
-        // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
-        // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
-        if (act == A_DROP) {
-          // desc: rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
-          const uint32_t m18 = a.mission % 18u;
-          const uint32_t desc = P.rule_div == 0 ? (uint32_t)P.rule_cell
-                              : P.rule_div == 1 ? make_cell(T_BALL, a.mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-                                                : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
-          targets = 0;
-          for (int k = 0; k < P.cells; k++) {
-            const uint32_t c = k == dirty_idx ? dirty_code : (uint32_t)mygrid[k];
-            targets |= (uint64_t)(c == desc) << k;
+  for (int j = 0; j < P.T; j++) {
+    int slot_out = P.slot0 - j;
+    while (slot_out < 0) slot_out += P.S;
+    uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
+    // ---- action ----
+    uint32_t act = A_DONE;
+    if (P.phase == PHASE_STEP) {
+      if (P.act_src == ACT_SRC_PHILOX) {
+        const uint32_t t = P.t0 + (uint32_t)j;
+        if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
+        const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
+        act = (uint32_t)(((uint64_t)w * 7u) >> 32);
+      } else if (active) act = load_action(P, e, j);
+    }
+    const uint32_t act_in = act;
+    if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
+    if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+    double reward = 0.0;
+    uint32_t term = 0, trunc = 0;
+    // The one cell an action can change: it can only change under pickup/drop/toggle, which leave the pose alone, so it
+    // is always the cell straight ahead.  The level rules below see the grid as it was BEFORE the action plus this patch
+    // (RedBlueDoors compares both states); it is written into the LDS grid after them.
+    int dirty_idx = -1;              // linear index of the modified cell, -1 = none
+    uint32_t dirty_code = 0;
+
+    if (active) {
+      if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
+        // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
+        if (shadow_valid) {
+          const uint32_t* s = (const uint32_t*)(sshadow + lane * GS);
+          uint32_t* d = (uint32_t*)mygrid;
+          for (int k = 0; k < (CS >> 2); k++) d[k] = s[k];
+          a = agent_unpack(sp_rec);
+          if (goto_rule) { targets = sp_aux; aux_dirty = true; }
+          shadow_valid = false;
+        } else {
+          const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
+          const uint4* src = (const uint4*)(P.spare_grid + se * CS);
+          for (int c = 0; c < cpe; c++) {
+            const uint4 v = src[c];
+            uint32_t* d = (uint32_t*)(mygrid + c * 16);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
           }
-          if (wave == 0) P.aux[e] = targets;
+          a = agent_unpack(P.spare_agent[se]);
+          if (goto_rule) { targets = P.spare_aux[se]; aux_dirty = true; }
         }
-        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
-      }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
-        // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
-        // stands next to target_pos (the one-bit board drawn at reset)
-        if (act == A_TOGGLE) term = 1;
-        if (act == A_DONE) {
-          const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
-          const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
-          term = 1; success = (targets & ring) != 0;
+        a.carry = 0; a.step = 0; a.flags = 0;
+        rec_dirty = true; wb_all = true;
+        if (!P.static_gen) h++;
+      } else if (a.flags & FLAG_FRESH) {
+        a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
+        rec_dirty = true;
+      } else if (P.phase == PHASE_STEP) {
+        // ---- MiniGridEnv.step ----
+        rec_dirty = true;
+        a.step = min(a.step + 1u, 0xFFFFu);
+        const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+        const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
+        if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
+        const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
+        const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
+        uint32_t newF = F;
+        const uint32_t ftype = cell_type(F);
+        bool success = false;
+        if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
+        else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
+        else if (act == A_FORWARD) {
+          if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
+          if (ftype == T_GOAL) { term = 1; success = true; }
+          if (ftype == T_LAVA) term = 1;
+        } else if (act == A_PICKUP) {
+          if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
+        } else if (act == A_DROP) {
+          if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
+        } else if (act == A_TOGGLE) {
+          newF = cell_toggle(F, a.carry);
+        } else if (act != A_DONE) {
+          errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
         }
-      }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
-        // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
-        // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
-        const uint32_t m12 = a.mission % 12u;
-        const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
-        term = 1; success = a.carry == target;
-      }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
-        // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
-        // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
-        bool open = false;
-        for (int y = 1; y < H - 1; y++) {
-          const int idx = y * W + P.rule_cell;
-          const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
-          open |= cell_type(c) == T_DOOR;
+        if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
+        trunc = a.step >= (uint32_t)P.max_steps;
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+          // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
+          // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
+          // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
+          // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
+          if (act == A_DROP) {
+            // desc: rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
+            const uint32_t m18 = a.mission % 18u;
+            const uint32_t desc = P.rule_div == 0 ? (uint32_t)P.rule_cell
+                                : P.rule_div == 1 ? make_cell(T_BALL, a.mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+                                                  : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+            targets = 0;
+            for (int k = 0; k < P.cells; k++) {
+              const uint32_t c = k == dirty_idx ? dirty_code : (uint32_t)mygrid[k];
+              targets |= (uint64_t)(c == desc) << k;
+            }
+            aux_dirty = true;
+          }
+          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
         }
-        if (open) { term = 1; success = true; }
-      }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
-        // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
-        // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
-        const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
-        if (a.carry == target) { term = 1; success = true; }
-      }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
-        // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
-        // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
-        // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
-        // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
-        const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
-        const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
-                           (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
-        if (newF != F && match) { term = 1; success = true; }
-        else if (P.rule_div == 2) term = 1;
-      }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
-        // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
-        // and it is open after the toggle
-        if (inb && cell_type(newF) == T_DOOR) { term = 1; success = true; }
-      }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
-        // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
-        // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
-        bool red_before = false, red_after = false, blue_before = false, blue_after = false;
-        const int xr = H / 2, xb = H / 2 + H - 1;
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
+          // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
+          // stands next to target_pos (the one-bit board drawn at reset)
+          if (act == A_TOGGLE) term = 1;
+          if (act == A_DONE) {
+            const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
+            const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
+            term = 1; success = (targets & ring) != 0;
+          }
+        }
+        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
+          // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
+          // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
+          const uint32_t m12 = a.mission % 12u;
+          const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
+          term = 1; success = a.carry == target;
+        }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
+          // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
+          // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
+          bool open = false;
+          for (int y = 1; y < H - 1; y++) {
+            const int idx = y * W + P.rule_cell;
+            const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
+            open |= cell_type(c) == T_DOOR;
+          }
+          if (open) { term = 1; success = true; }
+        }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
+          // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
+          // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
+          const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
+          if (a.carry == target) { term = 1; success = true; }
+        }
+        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
+          // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
+          // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
+          // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
+          // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
+          const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
+          const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
+                             (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
+          if (newF != F && match) { term = 1; success = true; }
+          else if (P.rule_div == 2) term = 1;
+        }
+        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
+          // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
+          // and it is open after the toggle
+          if (inb && cell_type(newF) == T_DOOR) { term = 1; success = true; }
+        }
+        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
+          // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
+          // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
+          bool red_before = false, red_after = false, blue_before = false, blue_after = false;
+          const int xr = H / 2, xb = H / 2 + H - 1;
 #pragma unroll 1
-        for (int y = 1; y < H - 1; y++) {
-          const int ir = y * W + xr, ib = y * W + xb;
-          const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
-          const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
-          red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
-          blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
+          for (int y = 1; y < H - 1; y++) {
+            const int ir = y * W + xr, ib = y * W + xb;
+            const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
+            const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
+            red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
+            blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
+          }
+          if (blue_after) { term = 1; success = red_before; }
+          else if (red_after && blue_before) { term = 1; success = false; }
         }
-        if (blue_after) { term = 1; success = red_before; }
-        else if (red_after && blue_before) { term = 1; success = false; }
-      }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
-        // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
-        // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
-        // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
-        // the start-room object at (1, H/2 - 1)
-        const int mid = H / 2;
-        const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
-        if (oy >= 0) {
-          const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
-          if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
+        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
+          // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
+          // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
+          // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
+          // the start-room object at (1, H/2 - 1)
+          const int mid = H / 2;
+          const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
+          if (oy >= 0) {
+            const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
+            if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
+          }
         }
-      }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
-        // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
-        // door = the door whose colour the mission names (door colours are distinct and doors never move)
-        if (act == A_TOGGLE) term = 1;
-        if (act == A_DONE) {
-          const uint32_t tc = color_from_sorted(a.mission);
-          bool next_to = false;
+        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
+          // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
+          // door = the door whose colour the mission names (door colours are distinct and doors never move)
+          if (act == A_TOGGLE) term = 1;
+          if (act == A_DONE) {
+            const uint32_t tc = color_from_sorted(a.mission);
+            bool next_to = false;
 #pragma unroll 1
-          for (int d = 0; d < 4; d++) {
-            const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
-            if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
-              const uint32_t c = mygrid[ny * W + nx];
-              next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
+            for (int d = 0; d < 4; d++) {
+              const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
+              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
+                const uint32_t c = mygrid[ny * W + nx];
+                next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
+              }
             }
+            term = 1; success = next_to;
           }
-          term = 1; success = next_to;
         }
-      }
-      if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
-      if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
-        // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
-        // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
-        if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
-        a.flags &= ~FLAG_NOT_CLEAR;
-      }
-      if (P.no_death_mask && term) {
-        // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
-        // cell does not terminate; death_cost is added to the reward instead
-        const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
-        const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
-        const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
-        if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
-      }
-      if ((term | trunc) && P.autoreset_next_step) {
-        a.flags |= FLAG_RESET_PENDING;
-        if (P.live_gen && wave == 0) {                 // drawn in place by the generator launch before the next step
-          const uint32_t slot = atomicAdd(P.refill_count, 1u);
-          P.refill_queue[slot] = (uint32_t)e;
+        if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
+        if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
+          // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
+          // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
+          if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
+          a.flags &= ~FLAG_NOT_CLEAR;
+        }
+        if (P.no_death_mask && term) {
+          // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
+          // cell does not terminate; death_cost is added to the reward instead
+          const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
+          const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
+          const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
+          if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
+        }
+        if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
+        if (dirty_idx >= 0) {
+          mygrid[dirty_idx] = (uint8_t)dirty_code;
+          if (P.T == 1) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code;
+          else wb_all = true;
         }
       }
     }
-  }
-  if (wave == 0 && P.phase == PHASE_STEP) {
-    const unsigned long long fin = __ballot(active && (term | trunc));   // episodes finished in this group
-    // statistics go to a slot owned by this workgroup: atomics contended on ONE line cost 4-12 us per launch here
-    if (fin && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + (env0 >> 6)], (unsigned long long)__popcll(fin));
+    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));   // episodes finished in this wave
+    MG_WAVE_LDS_SYNC();
+
+    // ---- per-env scalar outputs: one coalesced store each ----
+    if (active) {
+      ((double*)(ob + P.off_reward))[e] = reward;
+      (ob + P.off_term)[e] = (uint8_t)term;
+      (ob + P.off_trunc)[e] = (uint8_t)trunc;
+      (ob + P.off_dir)[e] = (uint8_t)a.dir;
+      (ob + P.off_mission)[e] = (uint8_t)a.mission;
+      (ob + P.off_action)[e] = (uint8_t)act_in;
+    }
+
+    // ---- observation -> the wave's byte stream in LDS ----
+    const int obe = P.OBE;
+    if constexpr (FAST7) {
+      if (P.see_through) obs_view7<true>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
+      else obs_view7<false>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
+    } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
+      obs_view_generic<MODE>(P, a, mygrid, slut, srows, sT + lane * obe, active);
+    } else {
+      obs_full<MODE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
+    }
+    MG_WAVE_LDS_SYNC();
+
+    // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
+    {
+      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)obe;    // 64*obe is a multiple of 16
+      const int nbytes = nvalid * obe;
+      const int nvec = nbytes >> 4;
+      for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
+      for (int b = (nvec << 4) + lane; b < nbytes; b += 64) obase[b] = sT[b];   // ragged last group only
+    }
+    MG_WAVE_LDS_SYNC();
   }
 
-  // per-env scalar outputs, spread over the waves (each wave holds identical values)
+  // ---- launch end: state back to HBM, refill requests, statistics ----
   if (active) {
-    if (wave == 0) { if (rec_dirty) P.agent[e] = agent_pack(a); if (errbits) atomicOr(P.err, errbits); }
-    if (wave == 1 % WPG) P.reward[e] = reward;
-    if (wave == 2 % WPG) { P.term[e] = (uint8_t)term; P.trunc[e] = (uint8_t)trunc; }
-    if (wave == 3 % WPG) { P.dir_out[e] = (uint8_t)a.dir; P.mission_out[e] = (uint8_t)a.mission; }
+    if (rec_dirty) P.agent[e] = agent_pack(a);
+    if (goto_rule && aux_dirty) P.aux[e] = targets;
+    if (h != h_in) P.head[e] = h;
+    if (errbits) atomicOr(P.err, errbits);
   }
-
-  const int obe = P.OBE;
-  if (MODE == 0 || MODE == 2 || MODE == 4) {
-    // ---- gen_obs_grid(V): closed form of get_view_exts + slice + rotate_left^(dir+1) (453-484, grid.py:110-143):
-    //      view cell (vx,vy) is world cell agent + f*(V-1-vy) + r*(vx-V/2), f = DIR_TO_VEC[dir], r = (-f.y, f.x);
-    //      outside the grid -> grey wall (grid.py:136-139).  wx depends on only one of vx/vy and wy on the other,
-    //      so in-bounds-ness is (column mask)[vx] & (row mask)[vy].
-    //      VT == 7: the reference's default view, fully unrolled.  VT == 15: ViewSizeWrapper (any odd V <= 15),
-    //      same code with the loops guarded by the run-time V. ----
-    const int V = VT == 7 ? 7 : P.view;
-    const int HV = V >> 1;
-    constexpr int RPW = (VT + WPG - 1) / WPG;                   // view rows per wave: rows wave, wave+WPG, ...
-    const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
-    const int rx = -fyv, ry = fxv;
-    const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
-    const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
-    const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
-    const int SR = ry * W + rx;                                 // linear index step per vx
-    const int SU = -(fyv * W + fxv);                            // linear index step per vy
-    // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
-    const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
-    const uint32_t full = (1u << V) - 1u;
-    uint32_t mycell[RPW][VT];
-#pragma unroll
-    for (int r = 0; r < RPW; r++) {
-      const int vy = wave + WPG * r;
-      if (vy < V) {
-        const uint8_t* rowp = vbase + vy * SU;
-        const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
-        uint32_t opq = 0;
-#pragma unroll
-        for (int vx = 0; vx < VT; vx++) {
-          if (VT == 7 || vx < V) {
-            const uint32_t raw = rowp[vx * SR];
-            const uint32_t valid = 0u - ((cm >> vx) & 1u);
-            uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-            if (vx == HV && vy == V - 2) c = dirty_idx >= 0 ? dirty_code : c;   // the cell straight ahead
-            mycell[r][vx] = c;
-            opq |= (c >> 7) << vx;
-          }
-        }
-        if (!P.see_through) {                                    // transparency bits of this view row
-          if (VT == 7) strow[lane * 8 + vy] = (uint8_t)(~opq & 0x7Fu);
-          else ((uint16_t*)strow)[lane * 16 + vy] = (uint16_t)(~opq & full);
-        }
-      }
-    }
-    // ---- process_vis (grid.py:291-328), bit-parallel rows bottom-up, in ONE wave; shared through LDS ----
-    unsigned long long vis = ~0ull;                              // VT == 7: 49 bits, row j at bits 7j..7j+6
-    if (!P.see_through) {
-      block_sync();
-      if (VT == 7) {
-        if (wave == WPG - 1) {
-          const uint2 tw = *(const uint2*)(strow + lane * 8);
-          uint32_t m = 1u << (VIEW / 2);
-          vis = 0;
-#pragma unroll
-          for (int j = VIEW - 1; j >= 0; j--) {
-            const uint32_t t = ((j < 4 ? tw.x : tw.y) >> (8 * (j & 3))) & 0x7Fu;
-            uint32_t vr, up;
-            vis_row(m, t, &vr, &up);
-            vis |= (unsigned long long)vr << (7 * j);
-            m = up;
-          }
-          if (WPG > 1) svis[lane] = vis;
-        }
-        if (WPG > 1) { block_sync(); vis = svis[lane]; }
-      } else {
-        // wider views: one 16-bit mask per row, written back over the transparency rows
-        if (wave == WPG - 1) {
-          uint16_t* rows = (uint16_t*)strow + lane * 16;
-          uint32_t m = 1u << HV;
-          for (int j = V - 1; j >= 0; j--) {
-            uint32_t vr, up;
-            vis_row_n(m, rows[j], V, &vr, &up);
-            rows[j] = (uint16_t)vr;
-            m = up;
-          }
-        }
-        block_sync();
-      }
-    }
-    // ---- Grid.encode(vis_mask) (grid.py:244-268) straight into the output byte image [vx][vy][...]; invisible ->
-    //      (0,0,0); the agent's own cell shows what it carries (minigrid_env.py:623-630).
-    //      MODE 2: OneHotPartialObsWrapper (wrappers.py:267-284): 20 bytes per cell, one 1 in each of the type /
-    //      colour / state groups. ----
-    uint8_t* myT = sT + lane * obe;
-#pragma unroll
-    for (int r = 0; r < RPW; r++) {
-      const int vy = wave + WPG * r;
-      if (vy < V) {
-        uint32_t vrow;
-        if (VT == 7) vrow = (uint32_t)(vis >> (7 * vy)) & 0x7Fu;
-        else vrow = P.see_through ? full : (uint32_t)((const uint16_t*)strow)[lane * 16 + vy];
-#pragma unroll
-        for (int vx = 0; vx < VT; vx++) {
-          if (VT == 7 || vx < V) {
-            uint32_t c = mycell[r][vx];
-            if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-            if (MODE == 4) {
-              // get_pov_render (minigrid_env.py:652-666): process_vis has blanked the invisible cells (grid.py:324-327),
-              // so they are empty un-highlighted tiles (byte 0); visible ones are highlighted.  Image order [vy][vx].
-              if (!P.rgb_full) myT[vy * V + vx] = (uint8_t)(slut[c] & (0u - ((vrow >> vx) & 1u)));
-              continue;
-            }
-            const uint32_t tri = slut[c & (0u - ((vrow >> vx) & 1u))];
-            if (MODE == 0) {
-              uint8_t* o = myT + (vx * V + vy) * 3;
-              o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
-            } else if (active) {
-              // lanes past the batch end hold stale LDS "cells": their codes could index past the 20 bytes
-              uint8_t* o = myT + (vx * V + vy) * 20;
-              uint32_t* o4 = (uint32_t*)o;
-              o4[0] = 0; o4[1] = 0; o4[2] = 0; o4[3] = 0; o4[4] = 0;
-              o[tri & 0xFF] = 1; o[11 + ((tri >> 8) & 0xFF)] = 1; o[17 + (tri >> 16)] = 1;
-            }
-          }
-        }
-      }
-    }
-    if (MODE == 4 && VT == 7) {
-      if (P.rgb_full) {
-        // get_full_render (minigrid_env.py:668-714): every grid cell, highlighted where the agent's view sees it.
-        // World cell (x, y) is view cell (HV + d.r, V-1 - d.f) with d = (x, y) - agent: the inverse of the gather above.
-        const uint32_t hl_on = P.rgb_highlight ? 1u : 0u;
-        for (int y = wave; y < H; y += WPG) {
-          const int dy = y - (int)a.y;
-#pragma unroll 4
-          for (int x = 0; x < W; x++) {
-            const int idx = y * W + x, dx = x - (int)a.x;
-            uint32_t c = mygrid[idx];
-            if (idx == dirty_idx) c = dirty_code;
-            const int fwd = dx * fxv + dy * fyv, side = dx * rx + dy * ry + HV;
-            const bool inside = (unsigned)fwd < (unsigned)V && (unsigned)side < (unsigned)V;
-            const uint32_t bit = inside ? (uint32_t)(vis >> (7 * (V - 1 - fwd) + side)) & hl_on : 0u;
-            myT[idx] = (uint8_t)(slut[c] - 1u + bit);
-          }
-        }
-      }
-    }
-  } else {
-    // ---- MODE 1: FullyObsWrapper.observation: grid.encode() in image[x][y] order, agent cell = (10, 0, dir)
-    //      MODE 3: SymbolicObsWrapper.observation: (x, y, type or -1), agent cell type = 10 ----
-    uint8_t* myT = sT + lane * obe;
-    const int aidx = (int)a.y * W + (int)a.x;
-    auto cell_tri = [&](int x, int y) -> uint32_t {
-      const int idx = y * W + x;
-      uint32_t c = mygrid[idx];
-      if (idx == dirty_idx) c = dirty_code;
-      if (MODE == 1) {
-        if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
-        return slut[c];
-      }
-      const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
-      return (uint32_t)x | ((uint32_t)y << 8) | (t << 16);
-    };
-    auto put = [&](uint8_t* o, uint32_t tri) { o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16); };
-    for (int x = wave; x < W; x += WPG) {
-      uint8_t* col = myT + x * H * 3;                           // column x of image[x][y][3]
-      int y = 0;
-      for (; y + 4 <= H; y += 4) {                              // four independent grid -> table -> store chains in flight
-        const uint32_t t0 = cell_tri(x, y), t1 = cell_tri(x, y + 1), t2 = cell_tri(x, y + 2), t3 = cell_tri(x, y + 3);
-        put(col + 3 * y, t0); put(col + 3 * y + 3, t1); put(col + 3 * y + 6, t2); put(col + 3 * y + 9, t3);
-      }
-      for (; y < H; y++) put(col + 3 * y, cell_tri(x, y));
-    }
-  }
-  block_sync();
-
-  // ---- the group's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
   {
-    uint8_t* obase = P.obs + (size_t)env0 * (size_t)obe;          // 64*obe is a multiple of 16
-    const int nbytes = nvalid * obe;
-    const int nvec = nbytes >> 4;
-    for (int c = tid; c < nvec; c += NT) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
-    for (int b = (nvec << 4) + tid; b < nbytes; b += NT) obase[b] = sT[b];   // ragged last group only
+    const unsigned long long wb = __ballot(active && wb_all);      // envs whose whole live grid changed (new episode, fused launch)
+    if (wb) {
+      uint4* live = (uint4*)(P.grid + (size_t)env0 * CS);
+      for (int c = lane; c < nchunks; c += 64) {
+        const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
+        const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
+        if ((wb >> el) & 1ull) {
+          const uint32_t* s = (const uint32_t*)(sgrid + el * GS + part * 16);
+          uint4 v; v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
+          live[c] = v;
+        }
+      }
+    }
   }
+  if (P.seg_count) {
+    // one refill request per env that took a spare (however many): the generator draws head - tail episodes for it.
+    // live_gen (DynamicObstacles): the request is "this env's episode ended", served in place before the next step.
+    const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (h != h_in));
+    const unsigned long long m = __ballot(want);
+    if (m) {
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (want && qn + rank < (uint32_t)P.seg_cap) P.seg[(size_t)wg * P.seg_cap + qn + rank] = (uint32_t)e;
+      qn = min(qn + (uint32_t)__popcll(m), (uint32_t)P.seg_cap);
+      if (lane == 0) P.seg_count[wg] = qn;
+    }
+  }
+  if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
 }
+
 
 // DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
 // front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood

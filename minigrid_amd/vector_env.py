@@ -54,7 +54,8 @@ class MiniGridVecEnv(_VectorEnvBase):
                  autoreset_mode: str = "next_step", rng: str = "pcg64", env_index_base: int = 0,
                  max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
                  image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
-                 death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True):
+                 death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True,
+                 spare_ring: int = 0, traj_slots: int = 0):
         if obs_mode not in _OBS_MODES:
             raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
         # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
@@ -96,8 +97,12 @@ class MiniGridVecEnv(_VectorEnvBase):
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
-            env_index_base=self.env_index_base, tile_size=int(tile_size), rgb_highlight=int(bool(highlight)))
+            env_index_base=self.env_index_base, tile_size=int(tile_size), rgb_highlight=int(bool(highlight)),
+            spare_ring=int(spare_ring), traj_slots=int(traj_slots))
         self.tile_size, self.highlight = int(tile_size), bool(highlight)
+        self.spare_ring, self.traj_slots_arg = int(spare_ring), int(traj_slots)
+        self.rng_kind = rng
+        self._stream_arg = stream
         if output == "torch" and stream is None:
             # outputs are handed out as torch tensors: run stream-ordered with torch.  A non-default current stream is
             # borrowed; the legacy NULL stream (torch's default) cannot be passed as a handle, so the library's own
@@ -113,9 +118,17 @@ class MiniGridVecEnv(_VectorEnvBase):
         rc = self._lib.mg_create(C.byref(cfg), -1 if device is None else int(device), stream, C.byref(h))
         B.check(rc, None)
         self._h = h
+        if device is None:
+            try:
+                import torch
+                device = torch.cuda.current_device()
+            except Exception:
+                device = 0
+        self.device = int(device)
         outs = B.MgOutputs()
         B.check(self._lib.mg_get_outputs(self._h, C.byref(outs)), self._h)
         self._outs = outs
+        self.traj_slots, self.max_fused_steps = int(outs.traj_slots), int(outs.max_fused_steps)
         self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
         v = self.agent_view_size
         self.image_shape = {"partial": (v, v, 3), "full": (s.width, s.height, 3), "onehot": (v, v, 20),
@@ -168,23 +181,49 @@ class MiniGridVecEnv(_VectorEnvBase):
     def _p(self, a):
         return a.ctypes.data_as(C.c_void_p)
 
-    def device_outputs(self) -> dict:
-        """Zero-copy device views of the output buffers (valid until close(); rewritten by every step/reset)."""
-        n, o = self.num_envs, self._outs
-        return {"image": _DeviceArray(o.obs, (n,) + self.image_shape, "|i1" if self.obs_mode == "symbolic" else "|u1", self),
-                "reward": _DeviceArray(o.reward, (n,), "<f8", self),
-                "terminated": _DeviceArray(o.terminated, (n,), "|u1", self),
-                "truncated": _DeviceArray(o.truncated, (n,), "|u1", self),
-                "direction": _DeviceArray(o.direction, (n,), "|u1", self),
-                "mission_id": _DeviceArray(o.mission_id, (n,), "|u1", self)}
+    def device_outputs(self, slot: int = 0) -> dict:
+        """Zero-copy device views of the output buffers (valid until close(); rewritten by every step/reset).
+        `slot` k of the trajectory ring = the step k calls before the last one (rollout(fused=True) / step_many)."""
+        if not 0 <= slot < self.traj_slots:
+            raise ValueError(f"slot must be in 0..{self.traj_slots - 1}")
+        n, o, off = self.num_envs, self._outs, slot * int(self._outs.slot_bytes)
+        return {"image": _DeviceArray(o.obs + off, (n,) + self.image_shape, "|i1" if self.obs_mode == "symbolic" else "|u1", self),
+                "reward": _DeviceArray(o.reward + off, (n,), "<f8", self),
+                "terminated": _DeviceArray(o.terminated + off, (n,), "|u1", self),
+                "truncated": _DeviceArray(o.truncated + off, (n,), "|u1", self),
+                "direction": _DeviceArray(o.direction + off, (n,), "|u1", self),
+                "mission_id": _DeviceArray(o.mission_id + off, (n,), "|u1", self),
+                "action": _DeviceArray(o.action + off, (n,), "|u1", self),
+                # the whole step as ONE contiguous byte record (obs | reward | terminated | truncated | direction |
+                # mission | action): what a multi-GPU consumer all-gathers (minigrid_amd/sharded.py)
+                "record": _DeviceArray(o.obs + off, (int(o.record_bytes),), "|u1", self)}
 
-    def torch_outputs(self) -> dict:
+    def record_layout(self) -> dict:
+        """Byte offsets of the fields inside a step record (device_outputs()["record"])."""
+        o = self._outs
+        return {"image": 0, "reward": o.reward - o.obs, "terminated": o.terminated - o.obs, "truncated": o.truncated - o.obs,
+                "direction": o.direction - o.obs, "mission_id": o.mission_id - o.obs, "action": o.action - o.obs,
+                "record_bytes": int(o.record_bytes)}
+
+    def torch_outputs(self, slot: int = 0) -> dict:
         """The same buffers as torch CUDA tensors (no copy)."""
         if self._torch_views is None:
+            self._torch_views = {}
+        if slot not in self._torch_views:
             import torch
-            dev = torch.device("cuda", torch.cuda.current_device())
-            self._torch_views = {k: torch.as_tensor(v, device=dev) for k, v in self.device_outputs().items()}
-        return self._torch_views
+            dev = torch.device("cuda", self.device)
+            self._torch_views[slot] = {k: torch.as_tensor(v, device=dev) for k, v in self.device_outputs(slot).items()}
+        return self._torch_views[slot]
+
+    def trajectory(self, slot: int):
+        """Host copy of trajectory slot `slot`: (image, reward, terminated, truncated, direction, mission_id, action)."""
+        n = self.num_envs
+        img = np.empty((n,) + self.image_shape, np.int8 if self.obs_mode == "symbolic" else np.uint8)
+        rew = np.empty(n, np.float64)
+        u8 = [np.empty(n, np.uint8) for _ in range(5)]
+        rc = self._lib.mg_copy_slot(self._h, int(slot), self._p(img), self._p(rew), *[self._p(a) for a in u8])
+        B.check(rc, self._h)
+        return img, rew, u8[0].astype(bool), u8[1].astype(bool), u8[2], u8[3], u8[4]
 
     def sync(self):
         B.check(self._lib.mg_sync(self._h), self._h)
@@ -273,8 +312,32 @@ class MiniGridVecEnv(_VectorEnvBase):
         return obs, rew, term, trunc, {}
 
     def rollout(self, steps: int, action_seed: int = 0, fused: bool = False):
-        """`steps` lockstep steps under a uniform-random policy generated on the device (benchmark loop)."""
+        """`steps` lockstep steps under a uniform-random policy generated on the device (the loop of
+        minigrid/benchmark.py:36-43).  fused: up to `max_fused_steps` steps per kernel launch, the grids resident in
+        LDS; step j writes trajectory slot (steps-1-j) % traj_slots, so slot 0 is the last step."""
         B.check(self._lib.mg_rollout(self._h, int(steps), int(action_seed), int(fused)), self._h)
+
+    def step_many(self, actions):
+        """The fused loop for caller-supplied actions: uint8 (T, num_envs), numpy or a CUDA tensor.  Identical to T
+        step() calls; outputs of the step k calls before the last are in trajectory slot k (trajectory() /
+        torch_outputs(k))."""
+        if hasattr(actions, "data_ptr"):
+            import torch
+            a = actions
+            if a.dtype != torch.uint8 or a.dim() != 2 or a.shape[1] != self.num_envs or not a.is_contiguous():
+                raise ValueError("actions must be a contiguous uint8 tensor of shape (T, num_envs)")
+            rc = self._lib.mg_step_many(self._h, C.c_void_p(a.data_ptr()), int(a.shape[0]), 1 if a.is_cuda else 0)
+            self._last_actions = a
+        else:
+            a = np.ascontiguousarray(actions, dtype=np.uint8)
+            if a.ndim != 2 or a.shape[1] != self.num_envs:
+                raise ValueError("actions must have shape (T, num_envs)")
+            self._last_actions = a
+            rc = self._lib.mg_step_many(self._h, self._p(a), int(a.shape[0]), 0)
+            B.check(rc, self._h)
+            self.sync()                    # the staged host buffer is reused chunk by chunk
+            return
+        B.check(rc, self._h)
 
     def close(self, **kwargs):
         if getattr(self, "_h", None):

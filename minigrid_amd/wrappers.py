@@ -14,13 +14,22 @@ from .vector_env import MiniGridVecEnv
 
 
 def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
+    """The reference's wrappers wrap the SAME env object (wrappers.py:187-214): whatever state it is in -- mid-episode,
+    its np_random position -- is what the wrapped env continues from.  Here an observation wrapper is a different
+    encode inside the step kernel, i.e. a handle with another obs_mode; the live state (grids, agent records, step
+    counts, missions) and every env's generator position are carried across, on the same device and stream."""
     kw = dict(obs_mode=env.obs_mode, autoreset_mode=env.metadata["autoreset_mode"],
-              rng="philox" if env._cfg.rng_mode == 1 else "pcg64", env_index_base=env.env_index_base,
+              rng=env.rng_kind, env_index_base=env.env_index_base,
               max_steps=env.max_steps, output=env.output, image_only=env.image_only,
               agent_view_size=env.agent_view_size, no_death_types=env.no_death_types, death_cost=env.death_cost,
-              dict_mission=env.dict_mission, tile_size=env.tile_size, highlight=env.highlight)
+              dict_mission=env.dict_mission, tile_size=env.tile_size, highlight=env.highlight,
+              device=env.device, stream=env._stream_arg, spare_ring=env.spare_ring, traj_slots=env.traj_slots_arg)
     kw.update(changes)
     new = MiniGridVecEnv(env.env_id, env.num_envs, **kw)
+    if env._seeded:
+        new.set_rng_state(env.get_rng_state())     # also re-draws the spare episodes from that position
+        new.set_state(*env.get_state())
+        new._seeded = True
     env.close()
     return new
 

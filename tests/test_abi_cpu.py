@@ -22,12 +22,26 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_config_struct_layout_matches_header():
-    # 20 int32, double at 80, 2 int32, int64 at 96, 2 int32 = 112 bytes
-    assert C.sizeof(B.MgConfig) == 112
+    # 20 int32, double at 80, 2 int32, int64 at 96, 4 int32 = 120 bytes
+    assert C.sizeof(B.MgConfig) == 120
     assert B.MgConfig.death_cost.offset == 80
     assert B.MgConfig.env_index_base.offset == 96
     assert B.MgConfig.tile_size.offset == 104 and B.MgConfig.rgb_highlight.offset == 108
-    assert C.sizeof(B.MgOutputs) == 64
+    assert B.MgConfig.spare_ring.offset == 112 and B.MgConfig.traj_slots.offset == 116
+    assert C.sizeof(B.MgOutputs) == 104 and B.MgOutputs.action.offset == 64 and B.MgOutputs.max_fused_steps.offset == 96
+
+
+@pytest.mark.parametrize("obe", [147, 243, 27, 75, 363, 507, 675, 192, 980, 49, 64, 361 * 3, 5, 6, 7, 8, 9])
+def test_observation_stream_packer_reproduces_the_byte_stream(obe):
+    """k_step writes a wave's observations as whole aligned dwords of ONE contiguous byte stream although an env's
+    obe bytes (147, 243, ...) start at any byte phase: StreamEmit (mg_kernels.h) run lane by lane on the host."""
+    L = B.load()
+    rng = np.random.default_rng(obe)
+    for nenv in (1, 2, 3, 4, 5, 63, 64):
+        src = rng.integers(0, 256, (nenv, obe), dtype=np.uint8)
+        out = np.zeros(nenv * obe, np.uint8)
+        assert L.mg_selftest_stream(obe, nenv, src.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out, src.reshape(-1)), (obe, nenv)
 
 
 def _vis_row_literal(m, t):

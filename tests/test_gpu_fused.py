@@ -1,0 +1,216 @@
+"""GPU parity of the round-2 machinery: the fused T-step rollout (grids resident in LDS, trajectory ring), the spare-episode
+ring with its asynchronous refill stream, and the regimes VERDICT r1 listed as untested (wrapping a live env, masked
+resets next to autoreset-pending envs, DynamicObstacles reset after a terminal step)."""
+import numpy as np
+import pytest
+
+from conftest import MAIN_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(env_id, n, **kw):
+    import minigrid_amd as mg
+    return mg.make_vec(env_id, n, **kw)
+
+
+def _fused_vs_oracle(env_id, n, T, full, chunk=16, seed0=5, action_seed=9, **over):
+    """rollout(fused=True) in calls of `chunk` steps; every step of every call is read back from the trajectory ring
+    (oldest first) and replayed on the oracle with the actions the device recorded."""
+    from oracle import oracle as O
+    env = _mk(env_id, n, obs_mode="full" if full else "partial", traj_slots=chunk, **over)
+    orc = O.OracleVec(env_id, n, full_obs=full, **over)
+    assert env.traj_slots == chunk
+    obs, _ = env.reset(seed=seed0)
+    o_obs, _, _ = orc.reset(seeds=np.arange(seed0, seed0 + n, dtype=np.uint64))
+    assert (obs["image"] == o_obs).all()
+    nterm = ntrunc = 0
+    hist = np.zeros(7, np.int64)
+    for c in range(T // chunk):
+        env.rollout(chunk, action_seed=action_seed, fused=True)
+        for k in reversed(range(chunk)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act)
+            t = c * chunk + (chunk - 1 - k)
+            assert (img == oo).all(), (env_id, t, np.argwhere((img != oo).reshape(n, -1).any(1))[:5].ravel())
+            assert rew.tobytes() == orew.tobytes(), (env_id, t)
+            assert (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+            assert (d == od).all() and (m == om).all(), (env_id, t)
+            nterm += int(term.sum()); ntrunc += int(trunc.sum())
+            hist += np.bincount(act, minlength=7)[:7]
+        # slot 0 is what mg_get_outputs / step() consumers see
+        assert (env.trajectory(0)[0] == oo).all()
+    g1, a1 = env.get_state()
+    g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    assert env.counters()["env_steps"] == n * (T // chunk) * chunk
+    assert hist.min() > 0.8 * hist.sum() / 7            # the device policy is uniform over Discrete(7)
+    env.close()
+    return nterm, ntrunc
+
+
+@pytest.mark.parametrize("env_id", MAIN_IDS)
+@pytest.mark.parametrize("full", [False, True])
+def test_fused_rollout_equals_oracle_over_320_steps(env_id, full):
+    # 320 steps: Empty-8x8 passes its synchronized step-256 truncation burst (every env resets in the same step)
+    nterm, ntrunc = _fused_vs_oracle(env_id, 2048 + 37, 320, full)
+    assert nterm + ntrunc >= 2048
+
+
+@pytest.mark.parametrize("env_id,max_steps", [("MiniGrid-DoorKey-8x8-v0", 2), ("MiniGrid-DoorKey-8x8-v0", 5),
+                                              ("BabyAI-GoToRedBall-v0", 3), ("MiniGrid-LavaCrossingS9N1-v0", 1),
+                                              ("MiniGrid-KeyCorridorS3R3-v0", 7), ("MiniGrid-MultiRoom-N4-S5-v0", 4)])
+def test_fused_rollout_spare_ring_under_maximum_reset_rate(env_id, max_steps):
+    """Episodes of 1-7 steps: every env takes a spare out of its ring every few steps, several per launch, so the ring
+    wraps many times and the refill stream has to keep up (or the step stream has to wait for it: the batch events)."""
+    nterm, ntrunc = _fused_vs_oracle(env_id, 1024 + 5, 192, False, chunk=16, max_steps=max_steps)
+    assert ntrunc > 1024 * 192 // (2 * (max_steps + 1))
+
+
+def test_unfused_steps_wrap_the_spare_ring_too():
+    # step() x 200 with max_steps 2: ~67 resets per env through a ring of 16 spares
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n, T = 777, 200
+    env = mg.make_vec("MiniGrid-DoorKey-8x8-v0", n, max_steps=2)
+    orc = O.OracleVec("MiniGrid-DoorKey-8x8-v0", n, max_steps=2)
+    obs, _ = env.reset(seed=11)
+    assert (obs["image"] == orc.reset(seeds=np.arange(11, 11 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(3)
+    for t in range(T):
+        a = rng.integers(0, 7, n, dtype=np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a)
+        assert (obs["image"] == oo).all() and (trunc == otrunc).all() and (term == oterm).all(), t
+        if t % 37 == 0:
+            assert (env.get_rng_state() == orc.get_rng()).all(), t      # flushes the ring mid-flight
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,full", [("MiniGrid-DoorKey-8x8-v0", False), ("MiniGrid-LavaCrossingS9N1-v0", True),
+                                         ("BabyAI-GoToRedBall-v0", False), ("MiniGrid-FourRooms-v0", False),
+                                         ("BabyAI-GoToLocalS8N7-v0", False), ("MiniGrid-RedBlueDoors-8x8-v0", False),
+                                         ("MiniGrid-MemoryS13Random-v0", False), ("BabyAI-UnlockLocalDist-v0", False)])
+def test_step_many_equals_step_by_step(env_id, full):
+    """mg_step_many (fused launches, caller-supplied actions) == the same actions through step(), output by output."""
+    n, T = 1500, 96
+    mode = "full" if full else "partial"
+    a_env, b_env = _mk(env_id, n, obs_mode=mode, traj_slots=32), _mk(env_id, n, obs_mode=mode)
+    a_env.reset(seed=21); b_env.reset(seed=21)
+    rng = np.random.default_rng(1)
+    for rnd in range(T // 32):
+        acts = rng.choice(7, size=(32, n), p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        a_env.step_many(acts)
+        for j in range(32):
+            obs, rew, term, trunc, _ = b_env.step(acts[j])
+            img, r2, t2, u2, d2, m2, act = a_env.trajectory(31 - j)
+            assert (img == obs["image"]).all(), (env_id, rnd, j)
+            assert r2.tobytes() == rew.tobytes() and (t2 == term).all() and (u2 == trunc).all()
+            assert (d2 == obs["direction"]).all() and (act == acts[j]).all()
+    ga, aa = a_env.get_state(); gb, ab = b_env.get_state()
+    assert (ga == gb).all() and (aa == ab).all()
+    assert (a_env.get_rng_state() == b_env.get_rng_state()).all()
+    a_env.close(); b_env.close()
+
+
+def test_fused_rollout_full_size_config2_empty8x8_65536_envs():
+    """BASELINE configs[1] at its full size through the fused path: every env, sampled steps, plus the final state."""
+    nterm, ntrunc = _fused_vs_oracle("MiniGrid-Empty-8x8-v0", 65536, 288, False, chunk=16)
+    assert ntrunc >= 65536
+
+
+def test_wrapping_a_live_env_keeps_its_state_and_stream():
+    """The reference's wrappers wrap the same env object (wrappers.py:187-214): wrapping mid-episode continues that
+    episode and that np_random stream."""
+    import minigrid_amd as mg
+    from minigrid_amd.wrappers import FullyObsWrapper, ImgObsWrapper
+    from oracle import oracle as O
+    n = 1000
+    env = mg.make_vec("MiniGrid-DoorKey-8x8-v0", n)
+    orc_p = O.OracleVec("MiniGrid-DoorKey-8x8-v0", n)
+    env.reset(seed=4); orc_p.reset(seeds=np.arange(4, 4 + n, dtype=np.uint64))
+    rng = np.random.default_rng(2)
+    for _ in range(40):
+        a = rng.integers(0, 7, n, dtype=np.uint8)
+        env.step(a); orc_p.step(a)
+    env = FullyObsWrapper(env)                       # mid-episode
+    orc = O.OracleVec("MiniGrid-DoorKey-8x8-v0", n, full_obs=True)
+    orc.set_state(*orc_p.get_state()); orc.set_rng(orc_p.get_rng())
+    for t in range(700):                             # past max_steps: the carried stream draws the next episodes
+        a = rng.integers(0, 7, n, dtype=np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, _, _ = orc.step(a)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (trunc == otrunc).all(), t
+    env = ImgObsWrapper(env)
+    a = rng.integers(0, 7, n, dtype=np.uint8)
+    img, rew, term, trunc, _ = env.step(a)
+    assert (img == orc.step(a)[0]).all()
+    env.close()
+
+
+def test_masked_reset_leaves_autoreset_pending_envs_alone():
+    """gymnasium's reset_mask: unmasked sub-envs are untouched, also those waiting for their NEXT_STEP autoreset."""
+    import minigrid_amd as mg
+    n = 512
+    env = mg.make_vec("MiniGrid-LavaCrossingS9N1-v0", n, max_steps=3)
+    env.reset(seed=0)
+    for _ in range(3):
+        obs, rew, term, trunc, _ = env.step(np.zeros(n, np.uint8))          # turn left x3: everyone truncates
+    assert trunc.all()
+    _, ag = env.get_state()
+    assert (ag[:, 6] == 1).all() and (ag[:, 5] == 3).all()
+    mask = np.zeros(n, np.uint8); mask[::2] = 1
+    env.reset(options={"reset_mask": mask})
+    _, ag = env.get_state()
+    assert (ag[::2, 6] == 0).all() and (ag[::2, 5] == 0).all()             # masked: new episode
+    assert (ag[1::2, 6] == 1).all() and (ag[1::2, 5] == 3).all()           # unmasked: still pending, untouched
+    obs, rew, term, trunc, _ = env.step(np.full(n, 2, np.uint8))
+    _, ag = env.get_state()
+    assert (ag[::2, 5] == 1).all() and (ag[1::2, 5] == 0).all()            # masked stepped; the others took their autoreset
+    env.close()
+
+
+def test_dynamic_obstacles_reset_after_a_terminal_step_draws_one_episode():
+    """reset() right after a step that ended episodes must not draw those envs twice."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 600
+    for seed_again in (None, 123):
+        env = mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", n)
+        orc = O.OracleVec("MiniGrid-Dynamic-Obstacles-6x6-v0", n)
+        env.reset(seed=1); orc.reset(seeds=np.arange(1, 1 + n, dtype=np.uint64))
+        rng = np.random.default_rng(0)
+        ended = 0
+        for _ in range(12):
+            a = rng.choice(3, size=n, p=[0.1, 0.1, 0.8]).astype(np.uint8)
+            obs, rew, term, trunc, _ = env.step(a); orc.step(a)
+            ended = int((term | trunc).sum())
+            if ended > 20:
+                break
+        assert ended > 20
+        if seed_again is None:
+            obs, _ = env.reset(); oo = orc.reset()[0]
+        else:
+            obs, _ = env.reset(seed=seed_again); oo = orc.reset(seeds=np.arange(seed_again, seed_again + n, dtype=np.uint64))[0]
+        assert (obs["image"] == oo).all()
+        g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+        assert (g1 == g2).all() and (a1[:, :6] == a2[:, :6]).all()
+        assert (env.get_rng_state() == orc.get_rng()).all()
+        for _ in range(20):
+            a = rng.integers(0, 3, n, dtype=np.uint8)
+            obs, rew, term, trunc, _ = env.step(a)
+            oo, orew, oterm, otrunc, _, _ = orc.step(a)
+            assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all()
+        env.close()
+
+
+def test_int32_actions_outside_a_byte_raise_like_the_reference():
+    import minigrid_amd as mg
+    env = mg.make_vec("MiniGrid-Empty-8x8-v0", 100)
+    env.reset(seed=0)
+    a = np.zeros(100, np.int32); a[17] = 258                 # would alias to `forward` modulo 256
+    with pytest.raises(ValueError):
+        env.step(a)
+    env.close()
