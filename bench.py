@@ -83,6 +83,35 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int):
     return best
 
 
+def reference_python_baseline(workload: str):
+    """The reference's own CPU path (unmodified /root/reference, minigrid/benchmark.py:32-43 plumbing with random actions),
+    timed by profiles/ref_python_baseline.py in the build container -- /root/reference does not exist on the GPU box, so
+    this is the committed measurement of that script, quoted with its hardware and source file."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "reference_python_baseline.json"))):
+        try:
+            d = json.load(open(f))
+            w = d["workloads"].get(workload)
+            if w:
+                best = {"one_core": w["one_core"]["value"], "all_cores": w["all_cores"]["value"], "cores": w["all_cores"]["cores"],
+                        "unit": "env-steps/s", "wrapper": w["wrapper"], "hardware": d["hardware"],
+                        "source": os.path.relpath(f, ROOT) + "@" + d.get("git_head", "?"),
+                        "how": "profiles/ref_python_baseline.py: unmodified reference via oracle/gym_shim, BASELINE.md section 3 loop"}
+        except Exception:
+            pass
+    return best
+
+
+def pmc_traffic_source(workload: str):
+    import glob
+    src = None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+        if all(os.path.exists(os.path.join(d, f"pmc_{c}_{workload}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
+            src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}.txt"
+    return src
+
+
 def cpu_baseline_rgb(env_id: str, obs_mode: str, budget_s: float = 10.0):
     """RGB workloads: the oracle's C port steps, oracle/render.py (numpy) draws every frame; one batch per thread."""
     from concurrent.futures import ThreadPoolExecutor
@@ -224,11 +253,9 @@ def main():
         if not gather:
             env.rollout(k, action_seed=seed, fused=fused)
         else:
-            img = env.torch_outputs()["image"]
             for _ in range(k):
                 env.rollout(1, action_seed=seed)
-                env.sync()                       # the env runs on its own HIP stream; RCCL on torch's
-                senv.all_gather(img)
+                senv.gather_record()             # ONE all_gather_into_tensor of the step record, stream-ordered (no host sync)
 
     def barrier():
         if world > 1:
@@ -277,7 +304,8 @@ def main():
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "traffic_unit": "bytes per step (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
+                         "traffic_source": pmc_traffic_source(args.workload),
                          "algorithmic_bytes_per_launch": bpe * n_per_gpu * spl,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
                          "hbm_bytes_per_env_step_this_kernel": hbm_min,
@@ -291,6 +319,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_rgb(env_id, obs_mode)
             else:
                 out["cpu_baseline"] = cpu_baseline(env_id, obs_mode if obs_mode in ("partial", "full") else "partial")
+            out["cpu_baseline"]["reference_python"] = reference_python_baseline(args.workload)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -583,8 +583,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_dir = e->off_trunc + up(N);
     e->off_mission = e->off_dir + up(N);
     e->off_action = e->off_mission + up(N);
-    e->record_bytes = e->off_action + N;
-    e->slot_bytes = up(e->record_bytes);
+    e->record_bytes = up(e->off_action + N);
+    e->slot_bytes = e->record_bytes;
     TRY_OR_FREE(dalloc(&e->out, e->slot_bytes * (size_t)e->S));
     TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
   }

@@ -335,6 +335,12 @@ __global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* ma
 // copied out with 16 B/lane stores, scalars with one coalesced store each.  HBM traffic per env-step in the loop: the
 // outputs only (obe + 13 bytes written); the grid is read once and written back once per launch.
 // ======================================================================================================
+// LDS hand-off inside one wave for the step loop.  MG_WAVE_LDS_SYNC's release fence also waits for vmcnt(0) on gfx950 -- i.e.
+// for every global store still in flight: inside the T-step loop that would serialise each step behind the previous step's
+// observation stores (measured: 4.2 us per step instead of the store stream's own pace).  DS operations of one wave
+// execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
+#define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 template <bool SEE_THROUGH>
 MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
                     int lane, int nvalid) {
@@ -593,7 +599,7 @@ k_step(const StepParams P) {
       }
     }
   }
-  MG_WAVE_LDS_SYNC();
+  MG_LDS_SYNC();
 
   Agent a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + lane * GS;
@@ -823,7 +829,7 @@ k_step(const StepParams P) {
       }
     }
     if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));   // episodes finished in this wave
-    MG_WAVE_LDS_SYNC();
+    MG_LDS_SYNC();
 
     // ---- per-env scalar outputs: one coalesced store each ----
     if (active) {
@@ -845,17 +851,27 @@ k_step(const StepParams P) {
     } else {
       obs_full<MODE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
     }
-    MG_WAVE_LDS_SYNC();
+    MG_LDS_SYNC();
 
     // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
     {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)obe;    // 64*obe is a multiple of 16
       const int nbytes = nvalid * obe;
       const int nvec = nbytes >> 4;
-      for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
-      for (int b = (nvec << 4) + lane; b < nbytes; b += 64) obase[b] = sT[b];   // ragged last group only
+      if (FAST7 && nvalid == 64) {
+        // 588 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
+        uint4 v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int c = lane + 64 * i; if (i < 9 || c < 588) v[i] = ((const uint4*)sT)[c]; }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int c = lane + 64 * i; if (i < 9 || c < 588) ((uint4*)obase)[c] = v[i]; }
+      } else {
+#pragma unroll 4
+        for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
+        for (int b = (nvec << 4) + lane; b < nbytes; b += 64) obase[b] = sT[b];   // ragged last group only
+      }
     }
-    MG_WAVE_LDS_SYNC();
+    MG_LDS_SYNC();
   }
 
   // ---- launch end: state back to HBM, refill requests, statistics ----

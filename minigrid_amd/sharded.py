@@ -3,9 +3,17 @@
 Environments never interact (the reference's `MiniGridEnv` instances share nothing on this path), so the batch
 shards with NO data-path collective: rank g owns the contiguous global env indices [lo_g, hi_g) and seeds env i of
 the whole batch with `seed + i` exactly like a single-process batch would (`gymnasium.vector.VectorEnv.reset(seed=int)`
-semantics), which makes every result independent of the number of ranks.  The only exchange is optional: an
-all-gather of the per-step outputs when ONE consumer needs the whole batch on every rank (RCCL over xGMI under
-`torch.distributed` backend "nccl"; the same code runs on the "gloo" backend with CPU tensors in the test-suite).
+semantics), which makes every result independent of the number of ranks.  The only exchange is optional and is exactly
+ONE collective per step: an all-gather of the step RECORD when one consumer needs the whole batch on every rank.  The
+step kernel writes a step's outputs as one contiguous record {image | reward f64 | terminated | truncated | direction |
+mission id | action} (mg_outputs in include/minigrid_hip.h), so the record is gathered zero-copy with a single
+`all_gather_into_tensor` (RCCL over xGMI under `torch.distributed` backend "nccl"; the same code runs on the "gloo"
+backend with CPU tensors in the test-suite) and the per-field tensors are views into the gathered buffer.
+
+Stream ordering, no host synchronisation: with `output="torch"` the shard's HIP stream is created BLOCKING when torch's
+current stream is the legacy NULL stream (vector_env.py), i.e. NULL-stream work -- which is what RCCL's launch is ordered
+against -- starts after the step kernel, and the next step kernel starts after the NULL stream has waited for the
+collective.  A shard on a non-blocking private stream is synchronised explicitly instead.
 
     dist.init_process_group("nccl")                      # one process per GPU, torch.distributed.run / torchrun
     envs = ShardedVecEnv("MiniGrid-LavaCrossingS9N1-v0", 1_048_576, obs_mode="full", gather=True)
@@ -28,6 +36,21 @@ def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     base, extra = divmod(num_envs, world_size)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def record_layout(n: int, obs_bytes: int) -> dict:
+    """Byte offsets of the fields of one step record for a shard of n envs -- the layout mg_create gives a trajectory slot
+    (minigrid_amd/csrc/mg_api.hip: every field starts on a 256-byte boundary; tests check it against mg_get_outputs)."""
+    up = lambda v: (v + 255) & ~255
+    off = {"image": 0}
+    off["reward"] = up(n * obs_bytes + 16)
+    off["terminated"] = off["reward"] + up(n * 8)
+    off["truncated"] = off["terminated"] + up(n)
+    off["direction"] = off["truncated"] + up(n)
+    off["mission_id"] = off["direction"] + up(n)
+    off["action"] = off["mission_id"] + up(n)
+    off["record_bytes"] = up(off["action"] + n)
+    return off
 
 
 def _to_tensor(x):
@@ -62,6 +85,11 @@ class ShardedVecEnv:
             kwargs.setdefault("output", "torch")
         self.local = make(env_id, self.local_num_envs, env_index_base=self.lo, **kwargs)
         self._missions = np.asarray(getattr(self.local, "_missions", ()))
+        self._mission_index = {m: i for i, m in enumerate(self._missions.tolist())}
+        self._zero_copy = hasattr(self.local, "torch_outputs") and getattr(self.local, "output", "") == "torch"
+        self._image_shape = None
+        self._image_dtype = None
+        self.collectives = 0               # all-gathers issued so far (tests: exactly one per step / reset)
 
     # ---- the one collective on the path -------------------------------------------------------------------
     def all_gather(self, x):
@@ -71,6 +99,7 @@ class ShardedVecEnv:
         x = _to_tensor(x).contiguous()
         if self.world_size == 1:
             return x
+        self.collectives += 1
         tail = tuple(x.shape[1:])
         if self.num_envs % self.world_size == 0:
             out = torch.empty((self.num_envs,) + tail, dtype=x.dtype, device=x.device)
@@ -86,20 +115,87 @@ class ShardedVecEnv:
             parts.append(out[r * self._max_local: r * self._max_local + (hi - lo)])
         return torch.cat(parts, 0)
 
-    def _gather_obs(self, obs):
-        if not self.gather:
-            return obs
+    def _local_record(self, obs, rew, term, trunc):
+        """This rank's step as one contiguous u8 record.  HIP shard: the kernel already wrote it (zero-copy view of
+        trajectory slot 0); any other shard (the CPU stand-in of the test-suite): packed here into the same layout."""
+        import torch
+        image = obs["image"] if isinstance(obs, dict) else obs
+        image = _to_tensor(image)
+        self._image_shape, self._image_dtype = tuple(image.shape[1:]), image.dtype
+        obs_bytes = int(np.prod(self._image_shape)) * image.element_size()
+        if self._zero_copy:
+            if getattr(self.local._cfg, "null_stream_sync", 0) != 1 and not getattr(self.local, "_stream_arg", None):
+                self.local.sync()          # private non-blocking stream: nothing orders it with the collective's stream
+            return self.local.torch_outputs()["record"], obs_bytes
+        n = self.local_num_envs
+        lay = record_layout(n, obs_bytes)
+        rec = torch.zeros(lay["record_bytes"], dtype=torch.uint8)
+
+        def put(name, t):
+            b = _to_tensor(t).contiguous().view(torch.uint8).reshape(-1)
+            rec[lay[name]: lay[name] + b.numel()] = b
+        put("image", image)
+        put("reward", _to_tensor(rew).to(torch.float64))
+        put("terminated", _to_tensor(np.asarray(term, np.uint8)))
+        put("truncated", _to_tensor(np.asarray(trunc, np.uint8)))
         if isinstance(obs, dict):
-            out = {}
-            for k, v in obs.items():
-                if k == "mission":          # strings do not travel: gather the ids, map back on every rank
-                    index = {m: i for i, m in enumerate(self._missions.tolist())}
-                    ids = np.fromiter((index[m] for m in np.asarray(v).tolist()), np.uint8, len(v))
-                    out[k] = self._missions[self.all_gather(ids).cpu().numpy()]
-                else:
-                    out[k] = self.all_gather(v)
-            return out
-        return self.all_gather(obs)
+            put("direction", _to_tensor(np.asarray(obs["direction"], np.uint8)))
+            mis = obs.get("mission_id")
+            if mis is None:
+                mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint8, n)
+            put("mission_id", _to_tensor(np.asarray(mis, np.uint8)))
+        return rec, obs_bytes
+
+    def gather_record(self, rec=None, obs_bytes=None):
+        """The collective itself: this rank's record -> (world_size, record_bytes) u8 on every rank."""
+        import torch
+        if rec is None:
+            rec = self.local.torch_outputs()["record"]
+            obs_bytes = int(np.prod(self.local.image_shape))
+        W = self.world_size
+        max_bytes = record_layout(self._max_local, obs_bytes)["record_bytes"]
+        if W == 1:
+            return rec.reshape(1, -1)
+        self.collectives += 1
+        if rec.numel() != max_bytes:                        # ragged shard: pad to the largest record
+            pad = torch.zeros(max_bytes, dtype=torch.uint8, device=rec.device)
+            pad[: rec.numel()] = rec
+            rec = pad
+        if getattr(self, "_gbuf", None) is None or self._gbuf.shape != (W, max_bytes) or self._gbuf.device != rec.device:
+            self._gbuf = torch.empty((W, max_bytes), dtype=torch.uint8, device=rec.device)
+        self._dist.all_gather_into_tensor(self._gbuf.reshape(-1), rec.contiguous(), group=self.group)
+        return self._gbuf
+
+    def _gather_step(self, obs, rew, term, trunc):
+        """ONE all_gather_into_tensor of the step record; the global per-field tensors are views of its result."""
+        import torch
+        rec, obs_bytes = self._local_record(obs, rew, term, trunc)
+        W = self.world_size
+        buf = self.gather_record(rec, obs_bytes)
+
+        def field(name, dtype, tail=()):
+            parts = []
+            esz = torch.empty(0, dtype=dtype).element_size() * int(np.prod(tail)) if tail else torch.empty(0, dtype=dtype).element_size()
+            for r in range(W):
+                lo, hi = shard_range(self.num_envs, r, W)
+                n = hi - lo
+                lay = record_layout(n, obs_bytes)
+                raw = buf[r, lay[name]: lay[name] + n * esz]
+                parts.append(raw.view(dtype).reshape((n,) + tuple(tail)))
+            return parts[0] if W == 1 else torch.cat(parts, 0)
+        image = field("image", self._image_dtype, self._image_shape)
+        rew_g = field("reward", torch.float64)
+        term_g = field("terminated", torch.uint8).bool()
+        trunc_g = field("truncated", torch.uint8).bool()
+        if isinstance(obs, dict):
+            ids = field("mission_id", torch.uint8)
+            out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}
+            if "mission_id" in obs:
+                out["mission_id"] = ids
+            else:
+                out["mission"] = self._missions[ids.cpu().numpy()]   # strings do not travel: ids do, mapped back on every rank
+            return out, rew_g, term_g, trunc_g
+        return image, rew_g, term_g, trunc_g
 
     # ---- Gymnasium VectorEnv surface ----------------------------------------------------------------------
     def _local_slice(self, seq, what):
@@ -116,14 +212,19 @@ class ShardedVecEnv:
         if options and options.get("reset_mask") is not None:
             options = dict(options, reset_mask=np.asarray(self._local_slice(np.asarray(options["reset_mask"]), "reset_mask")))
         obs, info = self.local.reset(seed=seed, options=options)     # int seed: the shard adds its env_index_base
-        return self._gather_obs(obs), info
+        if not self.gather:
+            return obs, info
+        n = self.local_num_envs
+        z = np.zeros(n, np.uint8)
+        return self._gather_step(obs, np.zeros(n, np.float64), z, z)[0], info
 
     def step(self, actions):
         a = self._local_slice(actions, "actions")
         obs, rew, term, trunc, info = self.local.step(a)
-        if self.gather:
-            rew, term, trunc = self.all_gather(rew), self.all_gather(term), self.all_gather(trunc)
-        return self._gather_obs(obs), rew, term, trunc, info
+        if not self.gather:
+            return obs, rew, term, trunc, info
+        obs, rew, term, trunc = self._gather_step(obs, rew, term, trunc)
+        return obs, rew, term, trunc, info
 
     def close(self):
         self.local.close()

@@ -102,7 +102,6 @@ class MiniGridVecEnv(_VectorEnvBase):
         self.tile_size, self.highlight = int(tile_size), bool(highlight)
         self.spare_ring, self.traj_slots_arg = int(spare_ring), int(traj_slots)
         self.rng_kind = rng
-        self._stream_arg = stream
         if output == "torch" and stream is None:
             # outputs are handed out as torch tensors: run stream-ordered with torch.  A non-default current stream is
             # borrowed; the legacy NULL stream (torch's default) cannot be passed as a handle, so the library's own
@@ -114,6 +113,7 @@ class MiniGridVecEnv(_VectorEnvBase):
             else:
                 cfg.null_stream_sync = 1
         self._cfg = cfg
+        self._stream_arg = stream
         h = C.c_void_p()
         rc = self._lib.mg_create(C.byref(cfg), -1 if device is None else int(device), stream, C.byref(h))
         B.check(rc, None)

@@ -55,7 +55,8 @@ def _fused_vs_oracle(env_id, n, T, full, chunk=16, seed0=5, action_seed=9, **ove
 def test_fused_rollout_equals_oracle_over_320_steps(env_id, full):
     # 320 steps: Empty-8x8 passes its synchronized step-256 truncation burst (every env resets in the same step)
     nterm, ntrunc = _fused_vs_oracle(env_id, 2048 + 37, 320, full)
-    assert nterm + ntrunc >= 2048
+    if "DoorKey" not in env_id:                     # max_steps 640: few DoorKey episodes end within 320 random steps
+        assert nterm + ntrunc >= 2048
 
 
 @pytest.mark.parametrize("env_id,max_steps", [("MiniGrid-DoorKey-8x8-v0", 2), ("MiniGrid-DoorKey-8x8-v0", 5),
