@@ -38,7 +38,8 @@ struct mg_env {
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
   int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
   int off_grid = 0, off_shadow = 0, off_trow = 0, off_T = 0, lds_bytes = 0, lds_bytes_shadow = 0;
-  int nwaves = 0;             // 64-env groups = k_step workgroups = refill request segments
+  int lpe = 1, epw = 64;      // lanes per env in k_step (1 or 4), envs per wavefront = 64 / lpe
+  int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
   bool static_gen = false;
   bool live_gen = false;      // DynamicObstacles: step() consumes the stream => resets are drawn right before the step launch
   int rule = RULE_NONE, rule_cell = 0, rule_div = 1;
@@ -234,7 +235,8 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 }
 
 // every k_step instantiation the library launches: (MODE, FAST7) x rule group
-#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG) X(0, false, GG) X(1, false, GG) X(2, false, GG) X(3, false, GG) X(4, false, GG)
+#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
+  X(2, false, GG, 1) X(3, false, GG, 1) X(4, false, GG, 1)
 #define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
 
 static int launch_step(mg_env* e, StepParams& P) {
@@ -272,9 +274,9 @@ static int launch_step(mg_env* e, StepParams& P) {
                  : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
   const int gg = e->rule_group;
   bool launched = false;
-#define MG_TRY_LAUNCH(MODE, FAST, GG)                                                              \
-  if (!launched && mode == MODE && fast7 == FAST && gg == GG) {                                    \
-    hipLaunchKernelGGL((k_step<MODE, FAST, GG>), grid, block, lds, e->stream, P);                  \
+#define MG_TRY_LAUNCH(MODE, FAST, GG, LPE)                                                         \
+  if (!launched && mode == MODE && fast7 == FAST && gg == GG && e->lpe == LPE) {                   \
+    hipLaunchKernelGGL((k_step<MODE, FAST, GG, LPE>), grid, block, lds, e->stream, P);             \
     launched = true;                                                                               \
   }
   MG_FOR_STEP_GROUPS(MG_TRY_LAUNCH)
@@ -464,7 +466,15 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   e->rgb = rgb;
   e->map_bytes = !rgb ? e->obs_bytes : (cfg->obs_mode == MG_OBS_RGB ? e->cells : V * V);
-  e->nwaves = (e->N + 63) / 64;
+  {
+    // lanes per env: 4 wherever the encode supports it (default 7x7 partial view, FullyObs) -- four times the wavefronts for
+    // the same batch (16 envs each), each a quarter of the LDS: the step loop is latency-bound per wave, not issue-bound
+    const bool fast7 = cfg->obs_mode == MG_OBS_PARTIAL && V == 7;
+    e->lpe = (fast7 || (cfg->obs_mode == MG_OBS_FULL && e->cells >= 32)) ? 4 : 1;
+    if (const char* s = getenv("MG_LPE")) { int v = atoi(s); if (v == 1 || (v == 4 && e->lpe == 4)) e->lpe = v; }
+    e->epw = 64 / e->lpe;
+  }
+  e->nwaves = (e->N + e->epw - 1) / e->epw;
   {
     // LDS carve-up of k_step (bytes), per 64-env wavefront: decode table | guard | 64 staged grids | guard | visibility
     // rows | observation byte stream in output order | [shadow: the 64 next spare episodes (fused launches)].  The guard
@@ -472,11 +482,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // masked, they only have to stay inside the allocation.
     const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
     e->off_grid = 1024 + guard;
-    e->off_trow = (e->off_grid + 64 * e->GS + guard + 15) & ~15;
-    e->off_T = e->off_trow + 64 * 32;                       // one u16 per view row and env
-    e->off_shadow = e->off_T + ((64 * e->map_bytes + 15) & ~15) + 16;
+    e->off_trow = (e->off_grid + e->epw * e->GS + guard + 15) & ~15;
+    e->off_T = e->off_trow + e->epw * 32;                   // one u16 per view row and env
+    e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
     e->lds_bytes = e->off_shadow;
-    e->lds_bytes_shadow = e->off_shadow + ((64 * e->GS + 15) & ~15);
+    e->lds_bytes_shadow = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -495,11 +505,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
-    e->seg_cap = e->live_gen ? 64 : 64 * 2 * e->cb;          // at most 2*cb launches per batch, 64 requests each
-    // trajectory slots S: default 16 (fused launches write every step of the launch to its own slot), fewer when one
+    e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each
+    // trajectory slots S: default 16, 32 for levels without a generator (fused launches write every step of the launch to its own slot), fewer when one
     // slot is large (RGB frames: a single slot)
     const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
-    int S = cfg->traj_slots > 0 ? cfg->traj_slots : 16;
+    int S = cfg->traj_slots > 0 ? cfg->traj_slots : (e->static_gen ? 32 : 16);
     if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
     if (S > 4096) { delete e; return fail(nullptr, MG_ERR_INVALID, "traj_slots must be <= 4096"); }
     if (rgb) S = 1;
@@ -607,7 +617,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     const int need = std::max(e->lds_bytes, e->lds_bytes_shadow <= 160 * 1024 ? e->lds_bytes_shadow : 0);
     if (need > 64 * 1024) {
       const void* fns[] = {
-#define MG_FN(MODE, FAST, GG) (const void*)k_step<MODE, FAST, GG>,
+#define MG_FN(MODE, FAST, GG, LPE) (const void*)k_step<MODE, FAST, GG, LPE>,
         MG_FOR_STEP_GROUPS(MG_FN)
 #undef MG_FN
       };

@@ -90,7 +90,7 @@ MG_HD uint32_t cell_toggle(uint32_t code, uint32_t carry) {
 // i+1 in this row and i, i+1 in row j-1), then i = 6..1 right-to-left (lights i-1 / i-1, i above), each sweep
 // seeing its own writes.  A sweep is a one-directional occluded fill, done here with Kogge-Stone steps.
 // Returns the final row mask in *m_out and the bits contributed to row j-1 in *up_out.
-// tests/test_vis_row.py checks all 2^14 inputs against the literal loops.
+// tests/test_abi_cpu.py (test_vis_row_bit_parallel_equals_reference_loops_exhaustively) checks all 2^14 inputs against the literal loops.
 MG_HD void vis_row(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
   // Both sweeps start from the same seeds: a cell lit by sweep 1 is reached through transparent cells from a seed
   // s, so sweeping left from it only re-walks the run back to s and then continues as s itself would.  Hence the

@@ -102,7 +102,7 @@ MG_D uint32_t inb_mask_v(int c0, int s, int L, int V) {
 // dword of the stream; byte stores at a 147-byte lane stride were the LDS-conflict hot spot of the previous kernel.
 // Here every lane packs its env's bytes into dwords IN REGISTERS (D[0], D[1], ...: little-endian, stream order) and
 // hands them to StreamEmit, which shifts them by the env's phase and writes only whole, aligned stream dwords:
-//   B = l * obe                     first stream byte of lane l's env
+//   B                               first stream byte of the lane's byte range (l * obe with one lane per env)
 //   q = (-B) & 3                    leading bytes that belong to the last dword STARTING in env l-1
 //   lane l writes the dwords starting inside its env: indices ceil(B/4) .. ceil((B+obe)/4) - 1
 //   E[i] = bytes [q+4i, q+4i+4) of the env's stream continued by the next env's = funnel(D[i+1] : D[i], q)
@@ -121,12 +121,12 @@ struct StreamEmit {
   uint32_t prev;      // last dword handed in, not yet written out
   uint32_t q;
   uint32_t tb;        // valid bytes of the env's last dword D[ND-1] (1..4)
-  MG_HD void setup(uint32_t* stream, uint32_t l, uint32_t obe) {
-    const uint32_t B = l * obe;
+  // this lane's bytes are [B, B + len) of the stream (one env, or with several lanes per env its share of the env's cells)
+  MG_HD void setup(uint32_t* stream, uint32_t B, uint32_t len) {
     q = (0u - B) & 3u;
     p = stream + ((B + q) >> 2);
-    const uint32_t nd = (obe + 3u) >> 2;
-    tb = obe - 4u * (nd - 1u);
+    const uint32_t nd = (len + 3u) >> 2;
+    tb = len - 4u * (nd - 1u);
   }
   MG_HD void first(uint32_t d0) { prev = d0; }
   MG_HD void put(uint32_t d) { *p++ = funnel_bytes(d, prev, q); prev = d; }
@@ -341,11 +341,17 @@ __global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* ma
 // execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
 #define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool SEE_THROUGH>
+template <bool SEE_THROUGH, int LPE>
 MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
-                    int lane, int nvalid) {
+                    int lane, int nlanes) {
+  // LPE lanes per env: the 49 cells in output order k = vx * 7 + vy are dealt out as 12 units of 4 cells (12 bytes = 3 stream
+  // dwords each) -- 12 / LPE consecutive units per lane -- plus cell 48, which goes to the env's last lane.  A lane's bytes are
+  // one contiguous range of the stream, so StreamEmit works per lane exactly as it does per env.
   const int W = P.W, H = P.H;
-  constexpr int V = 7, HV = 3;
+  constexpr int V = 7, HV = 3, UPL = 12 / LPE, NC = UPL * 4;
+  const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
+  const bool last_sub = sub == LPE - 1;
+  const int k0 = sub * NC;
   const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
   const int rx = -fyv, ry = fxv;
   const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
@@ -355,60 +361,73 @@ MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, 
   const int SU = -(fyv * W + fxv);                            // linear index step per vy
   // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
   const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
-  uint32_t code[VIEW_CELLS];                                  // output order k = vx * 7 + vy
-  uint32_t trow[V];
+  uint32_t code[NC + 1];                                      // this lane's cells (+ cell 48, used by the last lane only)
+  unsigned long long opq49 = 0;                               // opacity bits of this lane's cells, bit 7 * vy + vx
+  const int vx0 = LPE == 1 ? 0 : (k0 * 37) >> 8, vy0 = LPE == 1 ? 0 : k0 - 7 * vx0;
+  {
+    int vx = vx0, vy = vy0;
 #pragma unroll
-  for (int vy = 0; vy < V; vy++) {
-    const uint8_t* rowp = vbase + vy * SU;
-    const uint32_t cm = ((rowmask >> vy) & 1u) ? colmask : 0u;
-    uint32_t opq = 0;
-#pragma unroll
-    for (int vx = 0; vx < V; vx++) {
-      const uint32_t raw = rowp[vx * SR];
-      const uint32_t valid = 0u - ((cm >> vx) & 1u);
+    for (int i = 0; i <= NC; i++) {
+      if (LPE == 1) { vx = i / V; vy = i % V; }
+      if (i == NC && LPE == 1) { vx = 6; vy = 6; }
+      const uint32_t raw = vbase[vy * SU + vx * SR];
+      const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
       const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-      code[vx * V + vy] = c;
-      opq |= (c >> 7) << vx;
+      code[i] = c;
+      if (!SEE_THROUGH) opq49 |= (unsigned long long)(c >> 7) << (7 * vy + vx);      // the extra cell's bit is its owner's bit too
+      if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
     }
-    trow[vy] = ~opq & 0x7Fu;
   }
-  // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6
+  // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6 (every lane of the env)
   unsigned long long vis = ~0ull;
   if (!SEE_THROUGH) {
+    if (LPE > 1) {
+      uint32_t lo = (uint32_t)opq49, hi = (uint32_t)(opq49 >> 32);
+#pragma unroll
+      for (int d = 1; d < LPE; d <<= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d); hi |= (uint32_t)__shfl_xor((int)hi, d); }
+      opq49 = ((unsigned long long)hi << 32) | lo;
+    }
     uint32_t m = 1u << HV;
     vis = 0;
 #pragma unroll
     for (int j = V - 1; j >= 0; j--) {
       uint32_t vr, up;
-      vis_row(m, trow[j], &vr, &up);
+      vis_row(m, ~(uint32_t)(opq49 >> (7 * j)) & 0x7Fu, &vr, &up);
       vis |= (unsigned long long)vr << (7 * j);
       m = up;
     }
   }
   // Grid.encode(vis_mask) (grid.py:244-268) in image[vx][vy][c] order; invisible -> (0,0,0); the agent's own cell shows
   // what it carries (minigrid_env.py:623-630).  4 cells = 12 bytes = 3 stream dwords.
-  auto tri_of = [&](int k) -> uint32_t {
-    const int vx = k / V, vy = k % V;
-    uint32_t c = code[k];
+  int evx = vx0, evy = vy0;
+  auto tri_of = [&](int i) -> uint32_t {
+    int vx = evx, vy = evy;
+    if (LPE == 1) { vx = i / V; vy = i % V; if (i == NC) { vx = 6; vy = 6; } }
+    uint32_t c = code[i];
     if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
+    if (LPE != 1) { if (++evy == V) { evy = 0; evx++; } }
     if (SEE_THROUGH) return slut[c];
     return slut[c & (0u - ((uint32_t)(vis >> (7 * vy + vx)) & 1u))];
   };
   StreamEmit em;
-  em.setup(stream, (uint32_t)lane, (uint32_t)PARTIAL_OBS_BYTES);
-  uint32_t next0 = 0;
+  em.setup(stream, (uint32_t)(el * PARTIAL_OBS_BYTES + k0 * 3), (uint32_t)(NC * 3 + (last_sub ? 3 : 0)));
+  uint32_t next0 = 0, dlast = 0;
 #pragma unroll
-  for (int g = 0; g < 12; g++) {
+  for (int g = 0; g < UPL; g++) {
     const uint32_t t0 = tri_of(4 * g), t1 = tri_of(4 * g + 1), t2 = tri_of(4 * g + 2), t3 = tri_of(4 * g + 3);
     const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
     if (g == 0) {
       em.first(d0);
       next0 = (uint32_t)__shfl_down((int)d0, 1);
-      if (lane >= nvalid - 1) next0 = 0u;
+      if (lane >= nlanes - 1) next0 = 0u;
     } else em.put(d0);
-    em.put(d1); em.put(d2);
+    em.put(d1);
+    if (g < UPL - 1) em.put(d2); else dlast = d2;
   }
-  em.put_last(tri_of(48), next0);
+  const uint32_t t48 = tri_of(NC);
+  if (LPE == 1) { em.put(dlast); em.put_last(t48, next0); }
+  else if (last_sub) { em.put(dlast); em.put_last(t48, next0); }
+  else em.put_last(dlast, next0);
 }
 
 // The same for any odd view size V <= 15 (ViewSizeWrapper), the one-hot encode (MODE 2) and the RGB tile map (MODE 4):
@@ -496,13 +515,20 @@ MG_D void obs_view_generic(const StepParams& P, const Agent& a, const uint8_t* m
 
 // MODE 1: FullyObsWrapper.observation (wrappers.py:419-426): grid.encode() in image[x][y] order, agent cell = (10, 0, dir).
 // MODE 3: SymbolicObsWrapper.observation (wrappers.py:763-782): (x, y, type or -1), agent cell type = 10.
-// Three bytes per cell in x-major order: 4 cells = 3 stream dwords, like the partial view.
-template <int MODE>
+// Three bytes per cell in x-major order: 4 cells = 3 stream dwords, like the partial view.  LPE lanes per env: the
+// cells / 4 units are dealt out in LPE consecutive runs (upl units each), the env's last lane also takes what is left over.
+template <int MODE, int LPE>
 MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
-                   int lane, int nvalid) {
+                   int lane, int nlanes) {
   const int W = P.W, H = P.H, cells = P.cells;
+  const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
+  const bool last_sub = sub == LPE - 1;
+  const int units = cells >> 2, upl = units / LPE;               // host guarantees upl >= 1
+  const int kc0 = sub * upl * 4;                                  // this lane's first cell (output order k = x * H + y)
+  const int nunits = last_sub ? units - (LPE - 1) * upl : upl;
+  const int rem = last_sub ? (cells & 3) : 0;
   const int aidx = (int)a.y * W + (int)a.x;
-  int x = 0, y = 0;
+  int x = LPE == 1 ? 0 : kc0 / H, y = LPE == 1 ? 0 : kc0 - x * H;
   auto next_tri = [&]() -> uint32_t {
     const int idx = y * W + x;
     uint32_t c = mygrid[idx], r;
@@ -517,48 +543,52 @@ MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, c
     return r;
   };
   StreamEmit em;
-  em.setup(stream, (uint32_t)lane, (uint32_t)(cells * 3));
+  em.setup(stream, (uint32_t)(el * cells * 3 + kc0 * 3), (uint32_t)(nunits * 12 + rem * 3));
   uint32_t next0;
-  const int rem = cells & 3, nunits = cells >> 2;            // cells >= 9
   {
     const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
     const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
     em.first(d0);
     next0 = (uint32_t)__shfl_down((int)d0, 1);
-    if (lane >= nvalid - 1) next0 = 0u;
+    if (lane >= nlanes - 1) next0 = 0u;
     em.put(d1);
-    if (nunits == 1 && rem == 0) { em.put_last(d2, next0); return; }
-    em.put(d2);
+    if (nunits == 1 && rem == 0) em.put_last(d2, next0); else em.put(d2);
   }
 #pragma unroll 1
   for (int u = 1; u < nunits; u++) {
     const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
     const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
     em.put(d0); em.put(d1);
-    if (u == nunits - 1 && rem == 0) { em.put_last(d2, next0); return; }
-    em.put(d2);
+    if (u == nunits - 1 && rem == 0) em.put_last(d2, next0); else em.put(d2);
   }
   if (rem == 1) { em.put_last(next_tri(), next0); }
   else if (rem == 2) { const uint32_t t0 = next_tri(), t1 = next_tri(); em.put(t0 | (t1 << 24)); em.put_last(t1 >> 8, next0); }
-  else { const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(); em.put(t0 | (t1 << 24)); em.put((t1 >> 8) | (t2 << 16)); em.put_last(t2 >> 16, next0); }
+  else if (rem == 3) { const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(); em.put(t0 | (t1 << 24)); em.put((t1 >> 8) | (t2 << 16)); em.put_last(t2 >> 16, next0); }
 }
 
-template <int MODE, bool FAST7, int GG>
+template <int MODE, bool FAST7, int GG, int LPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))    // one autonomous wave per workgroup; LDS, not registers, bounds the occupancy
 k_step(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // LPE lanes per env (1 or 4): lane = el * LPE + sub.  The LPE lanes of an env hold the same agent state and compute the
+  // same dynamics (free in SIMD terms); they share the observation work (cells dealt out in stream order) and sub-lane 0
+  // does the env's stores.  Fewer envs per wave = more waves for the same batch: latency hiding without any barrier.
+  constexpr int EPW = 64 / LPE;
   const int lane = threadIdx.x;
+  const int el = LPE == 1 ? lane : lane / LPE, sub = LPE == 1 ? 0 : (lane & (LPE - 1));
+  const bool lead = sub == 0;
   const int wg = blockIdx.x;
-  const int env0 = wg * 64;
-  const int e = env0 + lane;
+  const int env0 = wg * EPW;
+  const int e = env0 + el;
   const bool active = e < P.N;
-  const int nvalid = min(64, P.N - env0);
+  const int nvalid = min(EPW, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;                              // 256-entry cell code -> (type, colour, state) / tile key table
   uint8_t* sgrid = smem + P.off_grid;
   uint8_t* sshadow = smem + P.off_shadow;
-  uint16_t* srows = (uint16_t*)(smem + P.off_trow) + lane * 16;
+  uint16_t* srows = (uint16_t*)(smem + P.off_trow) + el * 16;
+  uint8_t* sslot = smem + P.off_trow;                            // staging only: ring slot of each env's next spare
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ);
@@ -582,19 +612,20 @@ k_step(const StepParams P) {
   for (int k = lane; k < 256; k += 64) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
   const int cpe = CS >> 4;
   const int nchunks = nvalid * cpe;
+  if (P.use_shadow) { if (lead) sslot[el] = (uint8_t)(h & P.ring_mask); MG_LDS_SYNC(); }
   {
     // stage the 64 grids: 16 B per lane, fully coalesced (and the next spare episode of every env next to it)
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
     for (int c = lane; c < nchunks; c += 64) {
-      const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
-      const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
+      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20;
+      const uint32_t part = (uint32_t)c - ce * (uint32_t)cpe;
       const uint4 v = live[c];
-      uint32_t* dst = (uint32_t*)(sgrid + el * GS + part * 16);
+      uint32_t* dst = (uint32_t*)(sgrid + ce * GS + part * 16);
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
       if (P.use_shadow) {
-        const uint32_t slot = (uint32_t)__shfl((int)h, (int)el) & P.ring_mask;
-        const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + el) * CS))[part];
-        uint32_t* d2 = (uint32_t*)(sshadow + el * GS + part * 16);
+        const uint32_t slot = sslot[ce];         // (not a __shfl: lanes past the last chunk are off here, and read as 0)
+        const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
+        uint32_t* d2 = (uint32_t*)(sshadow + ce * GS + part * 16);
         d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
       }
     }
@@ -602,7 +633,7 @@ k_step(const StepParams P) {
   MG_LDS_SYNC();
 
   Agent a = agent_unpack(rec);
-  uint8_t* mygrid = sgrid + lane * GS;
+  uint8_t* mygrid = sgrid + el * GS;
   bool rec_dirty = false, aux_dirty = false, wb_all = false;
   uint32_t errbits = 0, fin_total = 0;
   uint32_t pw[4] = { 0, 0, 0, 0 };
@@ -636,16 +667,16 @@ k_step(const StepParams P) {
       if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
         // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
         if (shadow_valid) {
-          const uint32_t* s = (const uint32_t*)(sshadow + lane * GS);
+          const uint32_t* s = (const uint32_t*)(sshadow + el * GS);
           uint32_t* d = (uint32_t*)mygrid;
-          for (int k = 0; k < (CS >> 2); k++) d[k] = s[k];
+          for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
           a = agent_unpack(sp_rec);
           if (goto_rule) { targets = sp_aux; aux_dirty = true; }
           shadow_valid = false;
         } else {
           const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
           const uint4* src = (const uint4*)(P.spare_grid + se * CS);
-          for (int c = 0; c < cpe; c++) {
+          for (int c = sub; c < cpe; c += LPE) {
             const uint4 v = src[c];
             uint32_t* d = (uint32_t*)(mygrid + c * 16);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -822,17 +853,17 @@ k_step(const StepParams P) {
         }
         if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
         if (dirty_idx >= 0) {
-          mygrid[dirty_idx] = (uint8_t)dirty_code;
-          if (P.T == 1) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code;
+          if (lead) mygrid[dirty_idx] = (uint8_t)dirty_code;
+          if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
           else wb_all = true;
         }
       }
     }
-    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));   // episodes finished in this wave
+    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && lead && (term | trunc)));   // episodes finished in this wave
     MG_LDS_SYNC();
 
     // ---- per-env scalar outputs: one coalesced store each ----
-    if (active) {
+    if (active && lead) {
       ((double*)(ob + P.off_reward))[e] = reward;
       (ob + P.off_term)[e] = (uint8_t)term;
       (ob + P.off_trunc)[e] = (uint8_t)trunc;
@@ -844,12 +875,13 @@ k_step(const StepParams P) {
     // ---- observation -> the wave's byte stream in LDS ----
     const int obe = P.OBE;
     if constexpr (FAST7) {
-      if (P.see_through) obs_view7<true>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
-      else obs_view7<false>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
+      if (P.see_through) obs_view7<true, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
+      else obs_view7<false, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
-      obs_view_generic<MODE>(P, a, mygrid, slut, srows, sT + lane * obe, active);
+      static_assert(FAST7 || MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
+      obs_view_generic<MODE>(P, a, mygrid, slut, srows, sT + el * obe, active);
     } else {
-      obs_full<MODE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid);
+      obs_full<MODE, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     }
     MG_LDS_SYNC();
 
@@ -858,13 +890,14 @@ k_step(const StepParams P) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)obe;    // 64*obe is a multiple of 16
       const int nbytes = nvalid * obe;
       const int nvec = nbytes >> 4;
-      if (FAST7 && nvalid == 64) {
-        // 588 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
-        uint4 v[10];
+      if (FAST7 && nvalid == EPW) {
+        // EPW * 147 / 16 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
+        constexpr int NCH = EPW * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;
+        uint4 v[NIT];
 #pragma unroll
-        for (int i = 0; i < 10; i++) { const int c = lane + 64 * i; if (i < 9 || c < 588) v[i] = ((const uint4*)sT)[c]; }
+        for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) v[i] = ((const uint4*)sT)[c]; }
 #pragma unroll
-        for (int i = 0; i < 10; i++) { const int c = lane + 64 * i; if (i < 9 || c < 588) ((uint4*)obase)[c] = v[i]; }
+        for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) ((uint4*)obase)[c] = v[i]; }
       } else {
 #pragma unroll 4
         for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
@@ -875,21 +908,21 @@ k_step(const StepParams P) {
   }
 
   // ---- launch end: state back to HBM, refill requests, statistics ----
-  if (active) {
+  if (active && lead) {
     if (rec_dirty) P.agent[e] = agent_pack(a);
     if (goto_rule && aux_dirty) P.aux[e] = targets;
     if (h != h_in) P.head[e] = h;
     if (errbits) atomicOr(P.err, errbits);
   }
   {
-    const unsigned long long wb = __ballot(active && wb_all);      // envs whose whole live grid changed (new episode, fused launch)
+    const unsigned long long wb = __ballot(active && lead && wb_all);      // envs whose whole live grid changed (new episode, fused launch)
     if (wb) {
       uint4* live = (uint4*)(P.grid + (size_t)env0 * CS);
       for (int c = lane; c < nchunks; c += 64) {
-        const uint32_t el = ((uint32_t)c * P.cpe_magic) >> 20;
-        const uint32_t part = (uint32_t)c - el * (uint32_t)cpe;
-        if ((wb >> el) & 1ull) {
-          const uint32_t* s = (const uint32_t*)(sgrid + el * GS + part * 16);
+        const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20;
+        const uint32_t part = (uint32_t)c - ce * (uint32_t)cpe;
+        if ((wb >> (ce * LPE)) & 1ull) {
+          const uint32_t* s = (const uint32_t*)(sgrid + ce * GS + part * 16);
           uint4 v; v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
           live[c] = v;
         }
@@ -899,7 +932,7 @@ k_step(const StepParams P) {
   if (P.seg_count) {
     // one refill request per env that took a spare (however many): the generator draws head - tail episodes for it.
     // live_gen (DynamicObstacles): the request is "this env's episode ended", served in place before the next step.
-    const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (h != h_in));
+    const bool want = active && lead && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (h != h_in));
     const unsigned long long m = __ballot(want);
     if (m) {
       const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
