@@ -37,7 +37,7 @@ struct mg_env {
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
   int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
-  int off_grid = 0, off_shadow = 0, off_trow = 0, off_T = 0, lds_bytes = 0, lds_bytes_shadow = 0;
+  int off_grid = 0, off_shadow = 0, off_spr = 0, off_act = 0, off_trow = 0, off_T = 0, lds_bytes = 0;
   int lpe = 1, epw = 64;      // lanes per env in k_step (1 or 4), envs per wavefront = 64 / lpe
   int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
   bool static_gen = false;
@@ -64,7 +64,6 @@ struct mg_env {
   uint8_t* out = nullptr;
   int S = 1;
   size_t slot_bytes = 0, record_bytes = 0, off_reward = 0, off_term = 0, off_trunc = 0, off_dir = 0, off_mission = 0, off_action = 0;
-  double* reward_lut = nullptr;
   uint32_t* err = nullptr;
   unsigned long long* counters = nullptr;
   size_t ncounters = 0;
@@ -86,8 +85,10 @@ static int fail(mg_env* env, int code, const char* fmt, ...) {
     if (_e != hipSuccess) return fail(env, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
   } while (0)
 
-// _reward LUT on the host: three separately rounded IEEE f64 operations (no contraction: built with
-// -ffp-contract=off and volatile temporaries), identical to CPython's `1 - 0.9 * (step_count / max_steps)`.
+// _reward on the host: three separately rounded IEEE f64 operations (no contraction: built with -ffp-contract=off and
+// volatile temporaries), identical to CPython's `1 - 0.9 * (step_count / max_steps)`.  The device computes the same
+// three operations (reward_exact in mg_kernels.h: __ddiv_rn / __dmul_rn / __dsub_rn); this table is the CPU-side check
+// of that arithmetic (mg_selftest_reward_lut) and what the GPU parity tests compare rewards against, byte for byte.
 static void build_reward_lut(int max_steps, double* out) {
   for (int t = 0; t <= max_steps; t++) {
     volatile double q = (double)t / (double)max_steps;
@@ -220,13 +221,13 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
-  P.reward_lut = e->reward_lut;
   P.err = e->err; P.counters = e->counters;
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
-  P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_trow = e->off_trow; P.off_T = e->off_T; P.OBE = e->map_bytes;
+  P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
+  P.off_T = e->off_T; P.OBE = e->map_bytes;
   P.rgb_full = e->cfg.obs_mode == MG_OBS_RGB; P.rgb_highlight = e->cfg.rgb_highlight != 0;
   P.view = e->cfg.agent_view_size; P.no_death_mask = e->cfg.no_death_mask; P.death_cost = e->cfg.death_cost;
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
@@ -236,7 +237,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 
 // every k_step instantiation the library launches: (MODE, FAST7) x rule group
 #define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
-  X(2, false, GG, 1) X(3, false, GG, 1) X(4, false, GG, 1)
+  X(2, false, GG, 1) X(3, false, GG, 1) X(3, false, GG, 4) X(4, false, GG, 1)
 #define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
 
 static int launch_step(mg_env* e, StepParams& P) {
@@ -265,9 +266,9 @@ static int launch_step(mg_env* e, StepParams& P) {
     const int set = e->live_gen ? 0 : (int)(e->batch_id % QSETS);
     if (!e->static_gen) { P.seg = e->seg + (size_t)set * e->nwaves * e->seg_cap; P.seg_count = e->seg_count + (size_t)set * e->nwaves; }
   }
-  // fused launches stage every env's next spare episode in LDS next to its grid when that fits
-  P.use_shadow = (P.T > 1 && e->lds_bytes_shadow <= 160 * 1024) ? 1 : 0;
-  const size_t lds = (size_t)(P.use_shadow ? e->lds_bytes_shadow : e->lds_bytes);
+  // fused launches stage every env's next spare episode in its LDS shadow slot at launch start
+  P.use_shadow = P.T > 1 ? 1 : 0;
+  const size_t lds = (size_t)e->lds_bytes;
   dim3 grid(e->nwaves), block(64);
   const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && e->cfg.agent_view_size == 7;
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
@@ -470,23 +471,26 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // lanes per env: 4 wherever the encode supports it (default 7x7 partial view, FullyObs) -- four times the wavefronts for
     // the same batch (16 envs each), each a quarter of the LDS: the step loop is latency-bound per wave, not issue-bound
     const bool fast7 = cfg->obs_mode == MG_OBS_PARTIAL && V == 7;
-    e->lpe = (fast7 || (cfg->obs_mode == MG_OBS_FULL && e->cells >= 32)) ? 4 : 1;
-    if (const char* s = getenv("MG_LPE")) { int v = atoi(s); if (v == 1 || (v == 4 && e->lpe == 4)) e->lpe = v; }
+    const bool fullish = (cfg->obs_mode == MG_OBS_FULL || cfg->obs_mode == MG_OBS_SYMBOLIC) && e->cells >= 32;
+    e->lpe = fullish ? 4 : 1;                                 // measured (profiles/r2): 4 wins for FullyObs, 1 for the 7x7 view
+    if (fast7 && getenv("MG_LPE") && atoi(getenv("MG_LPE")) == 4) e->lpe = 4;
+    if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
   }
   e->nwaves = (e->N + e->epw - 1) / e->epw;
   {
-    // LDS carve-up of k_step (bytes), per 64-env wavefront: decode table | guard | 64 staged grids | guard | visibility
-    // rows | observation byte stream in output order | [shadow: the 64 next spare episodes (fused launches)].  The guard
-    // bands cover the furthest a view cell can lie outside an env's own grid (V-1 rows + V-1 cells): such reads are
-    // masked, they only have to stay inside the allocation.
+    // LDS carve-up of k_step (bytes), per wavefront of epw envs: decode table | guard | staged grids | guard | visibility
+    // rows | observation byte stream in output order | shadow slots: every env's next spare episode (grid, agent record,
+    // auxiliary word) | the caller's actions for the launch's steps.  The guard bands cover the furthest a view cell can
+    // lie outside an env's own grid (V-1 rows + V-1 cells): such reads are masked, they only have to stay inside the allocation.
     const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
     e->off_grid = 1024 + guard;
     e->off_trow = (e->off_grid + e->epw * e->GS + guard + 15) & ~15;
     e->off_T = e->off_trow + e->epw * 32;                   // one u16 per view row and env
     e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
-    e->lds_bytes = e->off_shadow;
-    e->lds_bytes_shadow = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
+    e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
+    e->off_act = e->off_spr + e->epw * 16;
+    e->lds_bytes = e->off_act + 32 * e->epw;                // at most 32 steps per launch
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -595,11 +599,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_action = e->off_mission + up(N);
     e->record_bytes = up(e->off_action + N);
     e->slot_bytes = e->record_bytes;
+    if (e->slot_bytes >= ((size_t)1 << 32)) { mg_destroy(e); return fail(nullptr, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)"); }
     TRY_OR_FREE(dalloc(&e->out, e->slot_bytes * (size_t)e->S));
     TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
   }
   if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
-  TRY_OR_FREE(dalloc(&e->reward_lut, (size_t)cfg->max_steps + 1));
   TRY_OR_FREE(dalloc(&e->err, 1));
   e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
   TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
@@ -609,12 +613,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, R * N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
   {
-    std::vector<double> lut((size_t)cfg->max_steps + 1);
-    build_reward_lut(cfg->max_steps, lut.data());
-    TRY_OR_FREE(hipMemcpy(e->reward_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice));
-  }
-  {
-    const int need = std::max(e->lds_bytes, e->lds_bytes_shadow <= 160 * 1024 ? e->lds_bytes_shadow : 0);
+    const int need = e->lds_bytes;
     if (need > 64 * 1024) {
       const void* fns[] = {
 #define MG_FN(MODE, FAST, GG, LPE) (const void*)k_step<MODE, FAST, GG, LPE>,
@@ -651,7 +650,7 @@ int mg_destroy(mg_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
   void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
-                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->reward_lut, e->err, e->counters,
+                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->err, e->counters,
                    e->tilemap, e->atlas };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);

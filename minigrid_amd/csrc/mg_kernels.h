@@ -52,12 +52,12 @@ struct StepParams {
   uint8_t* obs; unsigned long long obs_stride;    // observation stream of slot s at obs + s * obs_stride (= out / slot_bytes, or the RGB tile map)
   int T, slot0, S;
   // ---- tables / bookkeeping ----
-  const double* reward_lut; uint32_t* err; unsigned long long* counters;
+  uint32_t* err; unsigned long long* counters;
   // ---- config ----
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen;
   int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
-  int use_shadow;         // the next spare of every env is staged in LDS at launch start (fused launches)
-  int off_grid, off_shadow, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
+  int use_shadow;         // the next spare of every env is staged in LDS (its shadow slot) at launch start (fused launches)
+  int off_grid, off_shadow, off_spr, off_act, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
@@ -80,7 +80,7 @@ MG_D void philox_action_block(const StepParams& P, int e, uint32_t tblk, uint32_
   w[0] = (uint32_t)gi; w[1] = (uint32_t)(gi >> 32); w[2] = tblk; w[3] = 0x41435431u;
   philox4x32_10(w, (uint32_t)P.action_seed, (uint32_t)(P.action_seed >> 32));
 }
-MG_D uint32_t load_action(const StepParams& P, int e, int j) {
+MG_D uint32_t load_action(const StepParams& P, int e, int j) {      // prologue only: the loop reads the staged copy from LDS
   const size_t i = (size_t)j * (size_t)P.N + (size_t)e;
   if (P.act_dtype == 0) return ((const uint8_t*)P.actions)[i];
   if (P.act_dtype == 1) { const int32_t v = ((const int32_t*)P.actions)[i]; return (v < 0 || v > 255) ? 255u : (uint32_t)v; }
@@ -341,7 +341,7 @@ __global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* ma
 // execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
 #define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool SEE_THROUGH, int LPE>
+template <int LPE>
 MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
                     int lane, int nlanes) {
   // LPE lanes per env: the 49 cells in output order k = vx * 7 + vy are dealt out as 12 units of 4 cells (12 bytes = 3 stream
@@ -349,6 +349,7 @@ MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, 
   // one contiguous range of the stream, so StreamEmit works per lane exactly as it does per env.
   const int W = P.W, H = P.H;
   constexpr int V = 7, HV = 3, UPL = 12 / LPE, NC = UPL * 4;
+  const bool SEE_THROUGH = P.see_through != 0;
   const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
   const bool last_sub = sub == LPE - 1;
   const int k0 = sub * NC;
@@ -362,25 +363,32 @@ MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, 
   // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
   const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
   uint32_t code[NC + 1];                                      // this lane's cells (+ cell 48, used by the last lane only)
-  unsigned long long opq49 = 0;                               // opacity bits of this lane's cells, bit 7 * vy + vx
   const int vx0 = LPE == 1 ? 0 : (k0 * 37) >> 8, vy0 = LPE == 1 ? 0 : k0 - 7 * vx0;
   {
     int vx = vx0, vy = vy0;
 #pragma unroll
     for (int i = 0; i <= NC; i++) {
       if (LPE == 1) { vx = i / V; vy = i % V; }
-      if (i == NC && LPE == 1) { vx = 6; vy = 6; }
       const uint32_t raw = vbase[vy * SU + vx * SR];
       const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
       const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
       code[i] = c;
-      if (!SEE_THROUGH) opq49 |= (unsigned long long)(c >> 7) << (7 * vy + vx);      // the extra cell's bit is its owner's bit too
       if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
     }
   }
   // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6 (every lane of the env)
   unsigned long long vis = ~0ull;
   if (!SEE_THROUGH) {
+    unsigned long long opq49 = 0;                             // opacity bits of this lane's cells, bit 7 * vy + vx
+    {
+      int vx = vx0, vy = vy0;
+#pragma unroll
+      for (int i = 0; i <= NC; i++) {                         // (the extra cell's bit is its owner's bit too)
+        if (LPE == 1) { vx = i / V; vy = i % V; }
+        opq49 |= (unsigned long long)(code[i] >> 7) << (7 * vy + vx);
+        if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
+      }
+    }
     if (LPE > 1) {
       uint32_t lo = (uint32_t)opq49, hi = (uint32_t)(opq49 >> 32);
 #pragma unroll
@@ -406,7 +414,6 @@ MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, 
     uint32_t c = code[i];
     if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
     if (LPE != 1) { if (++evy == V) { evy = 0; evx++; } }
-    if (SEE_THROUGH) return slut[c];
     return slut[c & (0u - ((uint32_t)(vis >> (7 * vy + vx)) & 1u))];
   };
   StreamEmit em;
@@ -589,6 +596,8 @@ k_step(const StepParams P) {
   uint8_t* sshadow = smem + P.off_shadow;
   uint16_t* srows = (uint16_t*)(smem + P.off_trow) + el * 16;
   uint8_t* sslot = smem + P.off_trow;                            // staging only: ring slot of each env's next spare
+  uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + el * 2;       // shadow slot: the spare's agent record and auxiliary word
+  uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ);
@@ -600,14 +609,18 @@ k_step(const StepParams P) {
   const uint32_t h_in = h;
   uint32_t qn = P.seg_count ? uni32(P.seg_count[wg]) : 0u;
   const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
-  uint64_t sp_rec = 0, sp_aux = 0;
-  bool shadow_valid = false;
-  if (P.use_shadow && active) {
+  // No global LOAD may sit in the step loop or feed a value that is live across it: on gfx950 loads and stores share vmcnt,
+  // so the s_waitcnt a (even conditional, even never-taken) load needs at its join point waits for every observation store
+  // still in flight -- one HBM round trip per step.  Everything the loop may read is staged in LDS here: the grids, the
+  // next spare episode (shadow slot), the caller's actions; the success reward is computed, not looked up.
+  bool shadow_valid = P.use_shadow != 0;
+  if (shadow_valid && active && lead) {
     const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
-    sp_rec = P.spare_agent[se];
-    if (goto_rule) sp_aux = P.spare_aux[se];
-    shadow_valid = true;
+    sspr[0] = P.spare_agent[se];
+    sspr[1] = goto_rule ? P.spare_aux[se] : 0ull;
   }
+  if (P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER && active && lead)
+    for (int j = 0; j < P.T; j++) sact[j * EPW + el] = (uint8_t)load_action(P, e, j);
 #pragma unroll
   for (int k = lane; k < 256; k += 64) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
   const int cpe = CS >> 4;
@@ -634,6 +647,11 @@ k_step(const StepParams P) {
 
   Agent a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + el * GS;
+  // per-lane byte offsets of this env's scalars inside a trajectory slot (slot_bytes < 4 GB): vector registers, so that
+  // the loop does not carry six 64-bit field offsets in scalar registers (the kernel is at the SGPR limit)
+  const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
+                 o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
+                 o_mis = (uint32_t)P.off_mission + (uint32_t)e, o_act = (uint32_t)P.off_action + (uint32_t)e;
   bool rec_dirty = false, aux_dirty = false, wb_all = false;
   uint32_t errbits = 0, fin_total = 0;
   uint32_t pw[4] = { 0, 0, 0, 0 };
@@ -650,7 +668,7 @@ k_step(const StepParams P) {
         if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
         const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
         act = (uint32_t)(((uint64_t)w * 7u) >> 32);
-      } else if (active) act = load_action(P, e, j);
+      } else act = sact[j * EPW + el];
     }
     const uint32_t act_in = act;
     if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
@@ -666,23 +684,26 @@ k_step(const StepParams P) {
     if (active) {
       if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
         // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
-        if (shadow_valid) {
-          const uint32_t* s = (const uint32_t*)(sshadow + el * GS);
-          uint32_t* d = (uint32_t*)mygrid;
-          for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
-          a = agent_unpack(sp_rec);
-          if (goto_rule) { targets = sp_aux; aux_dirty = true; }
-          shadow_valid = false;
-        } else {
+        if (!shadow_valid) {
+          // not staged (single-step launch, or the env's second reset within a fused launch): fetch the spare into the
+          // shadow slot first -- the loads and their wait stay inside this branch
           const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
           const uint4* src = (const uint4*)(P.spare_grid + se * CS);
           for (int c = sub; c < cpe; c += LPE) {
             const uint4 v = src[c];
-            uint32_t* d = (uint32_t*)(mygrid + c * 16);
+            uint32_t* d = (uint32_t*)(sshadow + el * GS + c * 16);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
           }
-          a = agent_unpack(P.spare_agent[se]);
-          if (goto_rule) { targets = P.spare_aux[se]; aux_dirty = true; }
+          if (lead) { sspr[0] = P.spare_agent[se]; sspr[1] = goto_rule ? P.spare_aux[se] : 0ull; }
+          MG_LDS_SYNC();
+        }
+        {
+          const uint32_t* s = (const uint32_t*)(sshadow + el * GS);
+          uint32_t* d = (uint32_t*)mygrid;
+          for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
+          a = agent_unpack(sspr[0]);
+          if (goto_rule) { targets = sspr[1]; aux_dirty = true; }
+          shadow_valid = false;
         }
         a.carry = 0; a.step = 0; a.flags = 0;
         rec_dirty = true; wb_all = true;
@@ -836,7 +857,7 @@ k_step(const StepParams P) {
             term = 1; success = next_to;
           }
         }
-        if (success) reward = a.step <= (uint32_t)P.max_steps ? P.reward_lut[a.step] : reward_exact(a.step, P.max_steps);
+        if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
         if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
           // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
           // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
@@ -864,19 +885,18 @@ k_step(const StepParams P) {
 
     // ---- per-env scalar outputs: one coalesced store each ----
     if (active && lead) {
-      ((double*)(ob + P.off_reward))[e] = reward;
-      (ob + P.off_term)[e] = (uint8_t)term;
-      (ob + P.off_trunc)[e] = (uint8_t)trunc;
-      (ob + P.off_dir)[e] = (uint8_t)a.dir;
-      (ob + P.off_mission)[e] = (uint8_t)a.mission;
-      (ob + P.off_action)[e] = (uint8_t)act_in;
+      *(double*)(ob + o_rew) = reward;
+      ob[o_term] = (uint8_t)term;
+      ob[o_trunc] = (uint8_t)trunc;
+      ob[o_dir] = (uint8_t)a.dir;
+      ob[o_mis] = (uint8_t)a.mission;
+      ob[o_act] = (uint8_t)act_in;
     }
 
     // ---- observation -> the wave's byte stream in LDS ----
     const int obe = P.OBE;
     if constexpr (FAST7) {
-      if (P.see_through) obs_view7<true, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
-      else obs_view7<false, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
+      obs_view7<LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
       static_assert(FAST7 || MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
       obs_view_generic<MODE>(P, a, mygrid, slut, srows, sT + el * obe, active);
@@ -893,9 +913,9 @@ k_step(const StepParams P) {
       if (FAST7 && nvalid == EPW) {
         // EPW * 147 / 16 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
         constexpr int NCH = EPW * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;
-        uint4 v[NIT];
+        uint4 v[NIT];                       // (unconditional, clamped reads: a conditionally written array goes to scratch)
 #pragma unroll
-        for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) v[i] = ((const uint4*)sT)[c]; }
+        for (int i = 0; i < NIT; i++) v[i] = ((const uint4*)sT)[min(lane + 64 * i, NCH - 1)];
 #pragma unroll
         for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) ((uint4*)obase)[c] = v[i]; }
       } else {

@@ -40,10 +40,6 @@ def test_generators_match_reference_goldens(env_id):
 @pytest.mark.parametrize("mode", ["random", "solver"])
 @pytest.mark.parametrize("full", [False, True])
 def test_rollouts_match_reference_goldens(env_id, mode, full):
-    if full and not full_obs_supported(env_id):
-        with pytest.raises(Exception, match="too large for the LDS staging"):
-            _mk(env_id, 4, obs_mode="full")
-        return
     g = golden(f"rollout_{env_id}.npz")
     acts = g[f"{mode}_actions"]
     S, T = acts.shape
