@@ -304,7 +304,7 @@ def main():
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
-                         "traffic_unit": "bytes per step (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
+                         "traffic_unit": "bytes per k_step launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
                          "traffic_source": pmc_traffic_source(args.workload),
                          "algorithmic_bytes_per_launch": bpe * n_per_gpu * spl,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,

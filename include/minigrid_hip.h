@@ -80,6 +80,9 @@ typedef enum mg_env_kind {
   MG_ENV_FINDOBJ = 28,      /* envs/babyai/other.py:109-177 (FindObjS5/S6/S7: 3 x 3 rooms, connect_all, PickupInstr by type)             */
   MG_ENV_UNLOCKLOCAL = 29,  /* envs/babyai/unlock.py:114-174 (3 x 3 rooms of room_size 8; num_dists = 0 | 3 distractors = UnlockLocalDist)  */
   MG_ENV_BABYAI_KEYCORRIDOR = 30, /* envs/babyai/other.py:180-272: MG_ENV_KEYCORRIDOR's map with PickupInstr(ObjDesc("ball"))           */
+  MG_ENV_OBSTRUCTEDMAZE = 31, /* envs/obstructedmaze.py:111-270, obstructedmaze_v1.py:37-100 (room_size 6; 1 x 2 or 3 x 3 rooms): num_crossings =
+                               flags (1 key_in_box | 2 blocked | 4 the v1 class | 8 ObstructedMaze_1Dlhb), num_dists = num_quarters,
+                               agent_start_x / agent_start_y = agent_room                                                             */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;
@@ -226,8 +229,9 @@ MG_API int mg_selftest_vis_row(uint32_t mask_in, uint32_t transparent, uint32_t*
 MG_API int mg_selftest_vis_row_n(int32_t view, uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_reward_lut(int32_t max_steps, double* out /* [max_steps+1] */);
 /* k_step's observation stream packer (StreamEmit, mg_kernels.h) run lane by lane on the host: `in` = nenv x obe bytes,
- * each env's bytes handed over as little-endian dwords; `out` must reproduce them as one contiguous stream. */
-MG_API int mg_selftest_stream(int32_t obe, int32_t nenv, const uint8_t* in, uint8_t* out);
+ * each env's bytes split over lanes_per_env lanes as in the kernel and handed over as little-endian dwords; `out` must
+ * reproduce them as one contiguous stream. */
+MG_API int mg_selftest_stream(int32_t obe, int32_t nenv, int32_t lanes_per_env, const uint8_t* in, uint8_t* out);
 /* Grid.render_tile (core/grid.py:145-198) for every tile of the RGB atlas, as the library renders it at mg_create:
  * out[51][5][2][tile_size][tile_size][3] = [tile key][no agent, agent_dir 0..3][plain, highlighted]; tile keys are
  * empty 0 | wall 1+c | floor 7+c | key 13+c | ball 19+c | box 25+c | door 31+3c+state | goal 49 | lava 50. */

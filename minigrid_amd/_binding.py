@@ -73,7 +73,7 @@ def load():
     L.mg_rollout.argtypes = [vp, i, u64, i]
     L.mg_step_many.argtypes = [vp, vp, i, i]
     L.mg_copy_slot.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
-    L.mg_selftest_stream.argtypes = [C.c_int32, C.c_int32, vp, vp]
+    L.mg_selftest_stream.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.mg_get_outputs.argtypes = [vp, C.POINTER(MgOutputs)]
     L.mg_copy_outputs.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.mg_sync.argtypes = [vp]

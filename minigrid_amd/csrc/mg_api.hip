@@ -268,7 +268,7 @@ static int launch_step(mg_env* e, StepParams& P) {
   }
   // fused launches stage every env's next spare episode in its LDS shadow slot at launch start
   P.use_shadow = P.T > 1 ? 1 : 0;
-  const size_t lds = (size_t)e->lds_bytes;
+  const size_t lds = (size_t)(P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP ? e->lds_bytes : e->off_act);
   dim3 grid(e->nwaves), block(64);
   const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && e->cfg.agent_view_size == 7;
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
@@ -398,7 +398,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BABYAI_KEYCORRIDOR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_OBSTRUCTEDMAZE) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_OBSTRUCTEDMAZE && (cfg->room_size != 6 || !((cfg->width == 11 && cfg->height == 6) || (cfg->width == 16 && cfg->height == 16)) ||
+      cfg->num_dists < 1 || cfg->num_dists > 4 || (unsigned)cfg->num_crossings > 15u || (unsigned)cfg->agent_start_x > 2u || (unsigned)cfg->agent_start_y > 2u))
+    return fail(nullptr, MG_ERR_INVALID, "ObstructedMaze: room_size 6, 1 x 2 (11 x 6) or 3 x 3 (16 x 16) rooms, num_quarters 1..4, agent_room inside the room grid");
   if ((cfg->env_kind == MG_ENV_LOCKEDROOM || cfg->env_kind == MG_ENV_PLAYGROUND) && (cfg->width != cfg->height || cfg->width < 13 || cfg->width > 25))
     return fail(nullptr, MG_ERR_INVALID, "LockedRoom / Playground: square grid of 13..25 cells (the registered size is 19)");
   if ((cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG || cfg->env_kind == MG_ENV_ONEROOM) &&
@@ -486,11 +489,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
     e->off_grid = 1024 + guard;
     e->off_trow = (e->off_grid + e->epw * e->GS + guard + 15) & ~15;
-    e->off_T = e->off_trow + e->epw * 32;                   // one u16 per view row and env
+    const bool generic_view = !(cfg->obs_mode == MG_OBS_PARTIAL && V == 7) && cfg->obs_mode != MG_OBS_FULL && cfg->obs_mode != MG_OBS_SYMBOLIC;
+    e->off_T = e->off_trow + (generic_view ? e->epw * 32 : 64);   // one u16 per view row and env (generic view encode); staging scratch
     e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
     e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
     e->off_act = e->off_spr + e->epw * 16;
-    e->lds_bytes = e->off_act + 32 * e->epw;                // at most 32 steps per launch
+    e->lds_bytes = e->off_act + 32 * e->epw;                // the actions (at most 32 steps per launch) only when the caller supplies them
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -541,6 +545,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_UNLOCK) { e->rule = RULE_UNLOCK; e->rule_cell = cfg->room_size - 1; }
   if (cfg->env_kind == MG_ENV_UNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_KEYCORRIDOR) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BALL; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_OBSTRUCTEDMAZE) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BALL; e->rule_div = 1; }   // THE blue ball: mission id 0 = COLOR_NAMES[0]
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
 
   // k_step compiles each level rule only into the variant of its rule group
@@ -830,7 +835,7 @@ int mg_get_state(mg_env* e, uint8_t* grid, int32_t* agent) {
     int32_t* o = agent + n * 8;
     o[0] = (int32_t)ag.x; o[1] = (int32_t)ag.y; o[2] = (int32_t)ag.dir;
     o[3] = ag.carry ? (int32_t)(cell_triple(ag.carry) & 0xFF) : 0;
-    o[4] = ag.carry ? (int32_t)cell_color(ag.carry) : 0;
+    o[4] = ag.carry ? (int32_t)((cell_triple(ag.carry) >> 8) & 0xFF) : 0;
     o[5] = (int32_t)ag.step; o[6] = (int32_t)(ag.flags & FLAG_RESET_PENDING); o[7] = (int32_t)ag.mission;
   }
   return MG_OK;
@@ -970,22 +975,35 @@ int mg_selftest_reward_lut(int32_t max_steps, double* out) {
   build_reward_lut(max_steps, out);
   return MG_OK;
 }
-int mg_selftest_stream(int32_t obe, int32_t nenv, const uint8_t* in, uint8_t* out) {
-  if (!in || !out || obe < 5 || nenv < 1 || nenv > 64) return MG_ERR_INVALID;
-  const uint32_t nd = ((uint32_t)obe + 3u) >> 2;
+int mg_selftest_stream(int32_t obe, int32_t nenv, int32_t lpe, const uint8_t* in, uint8_t* out) {
+  // lpe lanes per env: the env's obe / 3 cells are dealt out as in k_step -- (cells / 4) / lpe units of 12 bytes per lane, the
+  // env's last lane also takes what is left over -- and every lane emits its contiguous byte range
+  if (!in || !out || obe < 5 || nenv < 1 || lpe < 1 || lpe > 4 || nenv * lpe > 64) return MG_ERR_INVALID;
+  const int upl = lpe == 1 ? 0 : ((obe / 3) / 4) / lpe;
+  if (lpe > 1 && upl < 1) return MG_ERR_INVALID;
   std::vector<uint32_t> stream(((size_t)nenv * obe + 3) / 4 + 2, 0xDEADBEEFu);
-  auto dword = [&](int l, uint32_t i) {                 // D[i] of lane l, garbage in the bytes past the env's end
+  const int nl = nenv * lpe;
+  auto range = [&](int l, uint32_t& B, uint32_t& len) {
+    const int e = l / lpe, s = l % lpe;
+    B = (uint32_t)(e * obe + s * upl * 12);
+    len = (uint32_t)(lpe == 1 ? obe : (s == lpe - 1 ? obe - (lpe - 1) * upl * 12 : upl * 12));
+  };
+  auto dword = [&](int l, uint32_t i) {                 // D[i] of lane l, garbage in the bytes past the lane's range
+    uint32_t B, len; range(l, B, len);
     uint32_t d = 0xA5A5A5A5u;
-    for (uint32_t b = 0; b < 4 && 4 * i + b < (uint32_t)obe; b++) d = (d & ~(0xFFu << (8 * b))) | ((uint32_t)in[(size_t)l * obe + 4 * i + b] << (8 * b));
+    for (uint32_t b = 0; b < 4 && 4 * i + b < len; b++) d = (d & ~(0xFFu << (8 * b))) | ((uint32_t)in[B + 4 * i + b] << (8 * b));
     return d;
   };
-  for (int l = 0; l < nenv; l++) {
+  for (int l = 0; l < nl; l++) {
+    uint32_t B, len; range(l, B, len);
+    const uint32_t nd = (len + 3u) >> 2;
     StreamEmit em;
-    em.setup(stream.data(), (uint32_t)l, (uint32_t)obe);
-    const uint32_t next0 = l + 1 < nenv ? dword(l + 1, 0) : 0u;
+    em.setup(stream.data(), B, len);
+    const uint32_t next0 = l + 1 < nl ? dword(l + 1, 0) : 0u;
     em.first(dword(l, 0));
     for (uint32_t i = 1; i + 1 < nd; i++) em.put(dword(l, i));
-    em.put_last(dword(l, nd - 1), next0);
+    if (nd > 1) em.put_last(dword(l, nd - 1), next0);
+    else return MG_ERR_INVALID;
   }
   memcpy(out, stream.data(), (size_t)nenv * obe);
   return MG_OK;

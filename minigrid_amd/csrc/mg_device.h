@@ -25,7 +25,11 @@ enum : uint32_t { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP =
 //           that the visibility pass reads it with one bit-field extract; make_cell() is the only place that sets it
 //   0x00 is "no object" for the carrying slot.
 //   type 13 (internal) marks the agent's own cell in the FullyObs encode: colour field = agent_dir.
+//   type 14 (internal) is a GREY box whose `contains` is a key (Box.contains, world_object.py:272-293; ObstructedMaze hides
+//           every key in a box of colour COLOR_NAMES[2] = grey, obstructedmaze.py:120,161-164): colour field = the KEY's colour.
+//           It encodes, renders and is picked up as the grey box; toggling it leaves the key in its place.
 constexpr uint32_t T_AGENT_MARK = 13;
+constexpr uint32_t T_BOX_KEY = 14;
 constexpr uint32_t OPAQUE_TYPES = (1u << T_WALL) | (1u << 11) | (1u << 12);
 constexpr uint32_t OPAQUE_BIT = 0x80u;
 
@@ -55,6 +59,7 @@ MG_HD uint32_t cell_from_triple(uint32_t type, uint32_t color, uint32_t state) {
 MG_HD uint32_t cell_triple(uint32_t code) {
   uint32_t t = code & 15u, c = (code >> 4) & 7u;
   if (t == T_AGENT_MARK) return (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | (c << 16);   // wrappers.py:422-424
+  if (t == T_BOX_KEY) return (uint32_t)T_BOX | ((uint32_t)C_GREY << 8);
   uint32_t st = t >= T_DOOR_CLOSED ? t - 10u : 0u;
   t = t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t;
   return t | (c << 8) | (st << 16);
@@ -64,7 +69,7 @@ MG_HD uint32_t cell_triple(uint32_t code) {
 // can_overlap (world_object.py:113,128,141,177-179): goal, floor, lava, OPEN door; None (empty) is walkable too
 constexpr uint32_t WALKABLE_MASK = (1u << T_EMPTY) | (1u << T_FLOOR) | (1u << T_DOOR) | (1u << T_GOAL) | (1u << T_LAVA);
 // can_pickup (world_object.py:243,265,277)
-constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX);
+constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX) | (1u << T_BOX_KEY);
 
 MG_HD bool cell_walkable(uint32_t code) { return (WALKABLE_MASK >> (code & 15u)) & 1u; }
 MG_HD bool cell_pickable(uint32_t code) { return (PICKUP_MASK >> (code & 15u)) & 1u; }
@@ -81,6 +86,7 @@ MG_HD uint32_t cell_toggle(uint32_t code, uint32_t carry) {
   if (t == T_DOOR) return make_cell(T_DOOR_CLOSED, col);
   if (t == T_DOOR_CLOSED) return make_cell(T_DOOR, col);
   if (t == T_BOX) return CELL_EMPTY;
+  if (t == T_BOX_KEY) return make_cell(T_KEY, col);       // Box.toggle: replaced by what it contains (world_object.py:290-293)
   return code;
 }
 
@@ -128,7 +134,7 @@ MG_HD uint32_t color_from_sorted(uint32_t i) {
 }
 
 // reference OBJECT_TO_IDX of a cell code (the internal closed/locked door types are doors)
-MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t; }
+MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t == T_BOX_KEY ? (uint32_t)T_BOX : (t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t); }
 
 // agent record: one u64 per env
 //   byte 0 x, 1 y, 2 dir, 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16), 6 flags, 7 mission id
@@ -137,6 +143,7 @@ constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode
 // are drawn by a generator launch right before the step launch, which then only observes the fresh episode
 constexpr uint32_t FLAG_FRESH = 2u;           // regenerated just before this launch: observe, do not step
 constexpr uint32_t FLAG_NOT_CLEAR = 4u;       // DynamicObstacles: the front cell was occupied before the obstacles moved
+constexpr uint32_t FLAG_TARGETS_STALE = 8u;   // BabyAI GoTo levels: a described object moved since GoToInstr's positions were refreshed
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };

@@ -785,6 +785,81 @@ MG_D void gen_unlocklocal(R& rng, GridRef& g, const GenParams& P, GenResult& out
   }
   out.failed = true;
 }
+// envs/obstructedmaze.py:111-270 and envs/obstructedmaze_v1.py:37-100 on RoomGrid._gen_grid / add_door / add_object /
+// place_in_room / place_agent (no connect_all).  room_size 6; P.num_crossings = flags (1 key_in_box, 2 blocked, 4 the v1
+// class, 8 the 1 x 2 class ObstructedMaze_1Dlhb); P.num_dists = num_quarters; P.start_x / start_y = agent_room.  The ball
+// to find is COLOR_NAMES[0] (blue), blocking balls COLOR_NAMES[1] (green), boxes COLOR_NAMES[2] (grey).
+template <class R>
+MG_D void gen_obstructedmaze(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  RoomGridState S;
+  S.rs = P.room_size; S.ncols = (g.W - 1) / (S.rs - 1); S.nrows = (g.H - 1) / (S.rs - 1);
+  S.right_y = 0; S.down_x = 0; S.doors = 0; S.locked = 0;
+  const int rs = S.rs, st = rs - 1, W = g.W, H = g.H;
+  const int flags = P.num_crossings;
+  const bool key_in_box = flags & 1, blocked = (flags >> 1) & 1, v1 = (flags >> 2) & 1, one_d = (flags >> 3) & 1;
+  MG_WAVE_LDS_SYNC();
+  for (int y = 0; y < H; y++)
+    if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+  MG_WAVE_LDS_SYNC();
+#pragma unroll 1
+  for (int j = 0; j < S.nrows; j++)
+#pragma unroll 1
+    for (int i = 0; i < S.ncols; i++) {
+      const int tx = i * st, ty = j * st, r = S.room(i, j);
+      if (i < S.ncols - 1) S.right_y |= (uint64_t)rand_int(rng, ty + 1, ty + rs - 1) << (4 * r);
+      if (j < S.nrows - 1) S.down_x |= (uint64_t)rand_int(rng, tx + 1, tx + rs - 1) << (4 * r);
+    }
+  const int mid_x = (S.ncols / 2) * st + rs / 2, mid_y = (S.nrows / 2) * st + rs / 2;       // provisional agent_pos
+  // door_colors = _rand_subset(COLOR_NAMES, 6) (minigrid_env.py:277-292): six draws without replacement, 4 bits each
+  uint32_t door_colors = 0, avail = 0x543210u;
+#pragma unroll 1
+  for (int n = 0, na = 6; n < 6; n++, na--) {
+    const int k = rand_int(rng, 0, na);
+    door_colors |= ((avail >> (4 * k)) & 15u) << (4 * n);
+    const uint32_t lowmask = (1u << (4 * k)) - 1u;
+    avail = (avail & lowmask) | ((avail >> 4) & ~lowmask);
+  }
+  bool ok = true;
+  auto add_key = [&](int i, int j, uint32_t ci) {                          // place_in_room(i, j, key or box(key))
+    const uint32_t col = color_from_sorted(ci);
+    const uint32_t cell = key_in_box ? make_cell(T_BOX_KEY, col) : make_cell(T_KEY, col);
+    int x, y;
+    if (!place_obj(rng, g, cell, i * st, j * st, rs, rs, mid_x, mid_y, true, 1000, x, y)) ok = false;
+  };
+  auto add_door = [&](int i, int j, int k, uint32_t ci, bool locked, bool with_key) {
+    int x, y;
+    S.door_pos(i, j, k, x, y);
+    g.set(x, y, make_cell(locked ? (uint32_t)T_DOOR_LOCKED : (uint32_t)T_DOOR_CLOSED, color_from_sorted(ci)));
+    S.mark(i, j, k);
+    if (locked && blocked) g.set(x - dir_dx((uint32_t)k), y - dir_dy((uint32_t)k), make_cell(T_BALL, color_from_sorted(1u)));
+    if (locked && with_key) add_key(i, j, ci);
+  };
+  int x, y;
+  if (one_d) {
+    add_door(0, 0, 0, door_colors & 15u, true, true);
+    if (!place_obj(rng, g, make_cell(T_BALL, color_from_sorted(0u)), st, 0, rs, rs, mid_x, mid_y, true, 1000, x, y)) ok = false;
+    if (!rg_place_agent(rng, g, 0, 0, rs, out)) ok = false;
+  } else {
+    const int nq = P.num_dists;
+#pragma unroll 1
+    for (int i = 0; i < nq; i++) {
+      const int si = i == 0 ? 2 : (i == 2 ? 0 : 1), sj = i == 1 ? 2 : (i == 3 ? 0 : 1);      // side_rooms (2,1) (1,2) (0,1) (1,0)
+      add_door(1, 1, i, (door_colors >> (4 * i)) & 15u, false, false);
+#pragma unroll 1
+      for (int k = -1; k <= 1; k += 2)
+        add_door(si, sj, (i + k + 4) % 4, (door_colors >> (4 * ((i + k + 6) % 6))) & 15u, true, !v1);
+      if (v1)                                                                 // v1: keys after both doors and their blocking balls
+        for (int k = -1; k <= 1; k += 2) add_key(si, sj, (door_colors >> (4 * ((i + k + 6) % 6))) & 15u);
+    }
+    const int c = rand_int(rng, 0, nq);                                       // corners (2,0) (2,2) (0,2) (0,0)
+    const int ci = c < 2 ? 2 : 0, cj = (c == 1 || c == 2) ? 2 : 0;
+    if (!place_obj(rng, g, make_cell(T_BALL, color_from_sorted(0u)), ci * st, cj * st, rs, rs, mid_x, mid_y, true, 1000, x, y)) ok = false;
+    if (!rg_place_agent(rng, g, P.start_x * st, P.start_y * st, rs, out)) ok = false;
+  }
+  if (!ok) out.failed = true;
+  out.mission = 0;
+}
+
 // envs/babyai/open.py:143-146 (OpenRedDoor: 1 x 2 rooms of size 5; add_door(0, 0, 0, "red", locked=False); place_agent(0, 0))
 template <class R>
 MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -995,7 +1070,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 30) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 32) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -1037,6 +1112,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 28: gen_findobj(rng, g, P, out); return;
       case 29: gen_unlocklocal(rng, g, P, out); return;
       case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
+      case 31: gen_obstructedmaze(rng, g, P, out); return;
       default: break;
     }
   }

@@ -647,6 +647,24 @@ k_step(const StepParams P) {
 
   Agent a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + el * GS;
+  // BabyAI GoTo levels (RoomGridLevel.step + GoToInstr): `targets` = the TRACKED positions of the described objects, which the
+  // reference refreshes from the grid on every drop ACTION (update_objs_poss, roomgrid_level.py:92-93) and never otherwise;
+  // `cur` = where the described objects are on the grid right now, kept up to date cell change by cell change, so that the
+  // refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
+  // differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
+  auto goto_desc = [&](uint32_t mission) -> uint32_t {
+    // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
+    const uint32_t m18 = mission % 18u;
+    return P.rule_div == 0 ? (uint32_t)P.rule_cell
+         : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+                           : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+  };
+  uint64_t cur = targets;
+  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
+    const uint32_t desc = goto_desc(a.mission);
+    cur = 0;
+    for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
+  }
   // per-lane byte offsets of this env's scalars inside a trajectory slot (slot_bytes < 4 GB): vector registers, so that
   // the loop does not carry six 64-bit field offsets in scalar registers (the kernel is at the SGPR limit)
   const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
@@ -702,7 +720,7 @@ k_step(const StepParams P) {
           uint32_t* d = (uint32_t*)mygrid;
           for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
           a = agent_unpack(sspr[0]);
-          if (goto_rule) { targets = sspr[1]; aux_dirty = true; }
+          if (goto_rule) { targets = sspr[1]; cur = targets; aux_dirty = true; }
           shadow_valid = false;
         }
         a.carry = 0; a.step = 0; a.flags = 0;
@@ -745,19 +763,12 @@ k_step(const StepParams P) {
           // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
           // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
           // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
-          if (act == A_DROP) {
-            // desc: rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
-            const uint32_t m18 = a.mission % 18u;
-            const uint32_t desc = P.rule_div == 0 ? (uint32_t)P.rule_cell
-                                : P.rule_div == 1 ? make_cell(T_BALL, a.mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-                                                  : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
-            targets = 0;
-            for (int k = 0; k < P.cells; k++) {
-              const uint32_t c = k == dirty_idx ? dirty_code : (uint32_t)mygrid[k];
-              targets |= (uint64_t)(c == desc) << k;
-            }
-            aux_dirty = true;
+          if (dirty_idx >= 0) {
+            const uint32_t desc = goto_desc(a.mission);
+            if (F == desc) cur &= ~(1ull << dirty_idx);
+            if (newF == desc) cur |= 1ull << dirty_idx;
           }
+          if (act == A_DROP && targets != cur) { targets = cur; aux_dirty = true; }
           const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
           if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
         }
@@ -928,6 +939,10 @@ k_step(const StepParams P) {
   }
 
   // ---- launch end: state back to HBM, refill requests, statistics ----
+  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+    const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (cur != targets ? FLAG_TARGETS_STALE : 0u);
+    if (fl != a.flags) { a.flags = fl; rec_dirty = true; }
+  }
   if (active && lead) {
     if (rec_dirty) P.agent[e] = agent_pack(a);
     if (goto_rule && aux_dirty) P.aux[e] = targets;

@@ -18,7 +18,7 @@ ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
-ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR = 29, 30
+ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE = 29, 30, 31
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -49,6 +49,20 @@ def _empty(id_, size, random_start=False):
     return EnvSpec(id_, ENV_EMPTY, size, size, 4 * size * size, True, ("get to the green goal square",),
                    agent_start=(-1, -1, 0) if random_start else (1, 1, 0), entry_point="minigrid.envs:EmptyEnv",
                    kwargs={"size": size, **({"agent_start_pos": None} if random_start else {})})
+
+
+def _obstructedmaze(name, rows, cols, rooms_visited, key_in_box, blocked, num_quarters, agent_room, v1, one_d):
+    flags = int(key_in_box) | int(blocked) << 1 | int(v1) << 2 | int(one_d) << 3
+    if one_d:       # minigrid/__init__.py:390-406: class ObstructedMaze_1Dlhb; the registered kwargs, 1Dlhb relies on the defaults
+        kw = {} if (key_in_box and blocked) else {"key_in_box": key_in_box, "blocked": blocked}
+        ep = "minigrid.envs:ObstructedMaze_1Dlhb"
+    else:           # :408-515; the Full rows rely on the class defaults
+        kw = {} if name.startswith("Full") else {"agent_room": agent_room, "key_in_box": key_in_box, "blocked": blocked,
+                                                 "num_quarters": num_quarters, "num_rooms_visited": rooms_visited}
+        ep = "minigrid.envs:ObstructedMaze_Full_V1" if v1 else "minigrid.envs:ObstructedMaze_Full"
+    return EnvSpec(f"MiniGrid-ObstructedMaze-{name}", ENV_OBSTRUCTEDMAZE, cols * 5 + 1, rows * 5 + 1, 4 * rooms_visited * 36, False,
+                   ("pick up the blue ball",), agent_start=(agent_room[0], agent_room[1], 0), num_crossings=flags,
+                   num_dists=num_quarters, room_size=6, entry_point=ep, kwargs=kw)
 
 
 def _doorkey(id_, size):
@@ -237,6 +251,16 @@ _ROWS = [
     _dynobs("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 2), _dynobs("MiniGrid-Dynamic-Obstacles-Random-5x5-v0", 5, 2, True),
     _dynobs("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3), _dynobs("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 6, 3, True),
     _dynobs("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4), _dynobs("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8),
+    # envs/obstructedmaze.py:80-106, obstructedmaze_v1.py: room_size 6, max_steps = 4 * num_rooms_visited * 36; rows
+    # minigrid/__init__.py:390-515.  flags (num_crossings) = key_in_box | blocked << 1 | v1 class << 2 | 1 x 2 class << 3
+    *[_obstructedmaze(*r) for r in (
+        ("1Dl-v0", 1, 2, 2, False, False, 1, (0, 0), False, True), ("1Dlh-v0", 1, 2, 2, True, False, 1, (0, 0), False, True),
+        ("1Dlhb-v0", 1, 2, 2, True, True, 1, (0, 0), False, True),
+        ("2Dl-v0", 3, 3, 4, False, False, 1, (2, 1), False, False), ("2Dlh-v0", 3, 3, 4, True, False, 1, (2, 1), False, False),
+        ("2Dlhb-v0", 3, 3, 4, True, True, 1, (2, 1), False, False), ("1Q-v0", 3, 3, 5, True, True, 1, (1, 1), False, False),
+        ("2Q-v0", 3, 3, 11, True, True, 2, (2, 1), False, False), ("Full-v0", 3, 3, 25, True, True, 4, (1, 1), False, False),
+        ("2Dlhb-v1", 3, 3, 4, True, True, 1, (2, 1), True, False), ("1Q-v1", 3, 3, 5, True, True, 1, (1, 1), True, False),
+        ("2Q-v1", 3, 3, 11, True, True, 2, (2, 1), True, False), ("Full-v1", 3, 3, 25, True, True, 4, (1, 1), True, False))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),

@@ -936,12 +936,15 @@ WIDE_IDS = ["MiniGrid-LavaGapS5-v0", "MiniGrid-LavaGapS6-v0", "MiniGrid-LavaGapS
             "BabyAI-GoToLocalS8N6-v0", "BabyAI-GoToLocalS8N7-v0"]
 
 
+# ids moved from the oracle-only list onto the device in round 2 (same 400-step goldens)
+WIDE2_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0", "MiniGrid-ObstructedMaze-1Dlhb-v0",
+             "MiniGrid-ObstructedMaze-2Dl-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0",
+             "MiniGrid-ObstructedMaze-1Q-v0", "MiniGrid-ObstructedMaze-2Q-v0", "MiniGrid-ObstructedMaze-Full-v0",
+             "MiniGrid-ObstructedMaze-2Dlhb-v1", "MiniGrid-ObstructedMaze-1Q-v1", "MiniGrid-ObstructedMaze-2Q-v1",
+             "MiniGrid-ObstructedMaze-Full-v1"]
+
 # restated and pinned in the oracle, not yet built on the device (kept out of the GPU test lists)
-ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0", "MiniGrid-ObstructedMaze-1Dlhb-v0",
-                   "MiniGrid-ObstructedMaze-2Dl-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0",
-                   "MiniGrid-ObstructedMaze-1Q-v0", "MiniGrid-ObstructedMaze-2Q-v0", "MiniGrid-ObstructedMaze-Full-v0",
-                   "MiniGrid-ObstructedMaze-2Dlhb-v1", "MiniGrid-ObstructedMaze-1Q-v1", "MiniGrid-ObstructedMaze-2Q-v1",
-                   "MiniGrid-ObstructedMaze-Full-v1", "MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
+ORACLE_ONLY_IDS = ["MiniGrid-PutNear-6x6-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
                    "BabyAI-GoTo-v0", "BabyAI-GoToOpen-v0", "BabyAI-GoToObjMaze-v0", "BabyAI-GoToObjMazeOpen-v0",
                    "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
                    "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
@@ -962,7 +965,7 @@ ORACLE_ONLY_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1D
 
 
 def main_oracle_only():
-    for env_id in ORACLE_ONLY_IDS:
+    for env_id in WIDE2_IDS + ORACLE_ONLY_IDS:
         np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 3, 1337], 400))
         np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
         print("done", env_id, flush=True)

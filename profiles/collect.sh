@@ -19,7 +19,7 @@ PY
 done
 cd /tmp
 for w in $PROF_WL; do
-  CMD="python $ROOT/bench.py --workload $w --steps 500 --warmup 100 --no-cpu-baseline"
+  CMD="python $ROOT/bench.py --workload $w --steps 512 --warmup 128 --no-cpu-baseline"   # whole fused launches only
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- $CMD > $OUT/prof_$w.log 2>&1
   cp $(find $OUT/prof_$w -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_$w.csv
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -37,11 +37,14 @@ def test_observation_stream_packer_reproduces_the_byte_stream(obe):
     obe bytes (147, 243, ...) start at any byte phase: StreamEmit (mg_kernels.h) run lane by lane on the host."""
     L = B.load()
     rng = np.random.default_rng(obe)
-    for nenv in (1, 2, 3, 4, 5, 63, 64):
-        src = rng.integers(0, 256, (nenv, obe), dtype=np.uint8)
-        out = np.zeros(nenv * obe, np.uint8)
-        assert L.mg_selftest_stream(obe, nenv, src.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
-        assert np.array_equal(out, src.reshape(-1)), (obe, nenv)
+    for lpe in (1, 4):
+        if lpe == 4 and (obe % 3 or obe // 12 < 4):
+            continue                         # 4 lanes per env: three-byte cells, at least one 12-byte unit per lane
+        for nenv in (1, 2, 3, 4, 5, 15, 16) if lpe == 4 else (1, 2, 3, 4, 5, 63, 64):
+            src = rng.integers(0, 256, (nenv, obe), dtype=np.uint8)
+            out = np.zeros(nenv * obe, np.uint8)
+            assert L.mg_selftest_stream(obe, nenv, lpe, src.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(out, src.reshape(-1)), (obe, nenv, lpe)
 
 
 def _vis_row_literal(m, t):
@@ -224,7 +227,7 @@ def test_mg_create_valid_config_needs_a_device():
 
 def test_registry_rows_are_consistent():
     import minigrid_amd as mg
-    assert len(mg.registry) == 100
+    assert len(mg.registry) == 113
     for env_id, s in mg.registry.items():
         assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
         assert s.entry_point.startswith("minigrid.envs")
@@ -283,8 +286,8 @@ def test_golden_generator_id_lists_match_the_test_lists():
     for node in ast.parse(src).body:
         if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
             name = node.targets[0].id
-            if name in ("MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "ORACLE_ONLY_IDS"):
+            if name in ("MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "ORACLE_ONLY_IDS"):
                 lists[name] = ast.literal_eval(node.value)
     for name, ids in lists.items():
         assert ids == getattr(conftest, name), name
-    assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "ORACLE_ONLY_IDS"}
+    assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "ORACLE_ONLY_IDS"}

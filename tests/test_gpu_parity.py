@@ -5,7 +5,7 @@ Everything is bit-exact (u8 obs, f64 reward compared by bytes, flags)."""
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, WIDE_IDS, full_obs_supported, golden
+from conftest import ALL_IDS, MAIN_IDS, WIDE_IDS, WIDE2_IDS, full_obs_supported, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -101,7 +101,7 @@ def test_vs_oracle_4096_envs_multi_episode(env_id, full):
     assert nterm > 50
 
 
-@pytest.mark.parametrize("env_id", WIDE_IDS)
+@pytest.mark.parametrize("env_id", WIDE_IDS + WIDE2_IDS)
 @pytest.mark.parametrize("full", [False, True])
 def test_vs_oracle_widened_ids_2048_envs_multi_episode(env_id, full):
     if full and not full_obs_supported(env_id):
