@@ -83,6 +83,8 @@ typedef enum mg_env_kind {
   MG_ENV_OBSTRUCTEDMAZE = 31, /* envs/obstructedmaze.py:111-270, obstructedmaze_v1.py:37-100 (room_size 6; 1 x 2 or 3 x 3 rooms): num_crossings =
                                flags (1 key_in_box | 2 blocked | 4 the v1 class | 8 ObstructedMaze_1Dlhb), num_dists = num_quarters,
                                agent_start_x / agent_start_y = agent_room                                                             */
+  MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =
+                               ((move colour * 3 + move type) * 6 + target colour) * 3 + target type                                  */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
                                the obstacles on the env's own stream, so resets are drawn just in time, not ahead      */
 } mg_env_kind;
@@ -155,7 +157,7 @@ typedef struct mg_outputs {
   uint8_t* terminated;  /* (N) u8 0/1                                                                 */
   uint8_t* truncated;   /* (N) u8 0/1 (minigrid_env.py:587-588)                                       */
   uint8_t* direction;   /* (N) u8 agent_dir 0..3 (obs["direction"], minigrid_env.py:648)              */
-  uint8_t* mission_id;  /* (N) u8 index into the config's mission-string table (obs["mission"])       */
+  uint16_t* mission_id; /* (N) u16 index into the config's mission-string table (obs["mission"])      */
   int64_t obs_bytes_per_env;
   int64_t num_envs;
   uint8_t* action;      /* (N) u8 the action the step applied (device-policy rollouts record it here)   */
@@ -195,10 +197,10 @@ MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
 /* Synchronises the stream, then copies whichever destinations are non-NULL to host memory.
  * Also surfaces device-side error flags (MG_ERR_BAD_ACTION / MG_ERR_GENERATOR / MG_ERR_OOB). */
 MG_API int mg_copy_outputs(mg_env* env, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
-                    uint8_t* direction, uint8_t* mission_id);
+                    uint8_t* direction, uint16_t* mission_id);
 /* mg_copy_outputs for trajectory slot `slot` (0 = the last step), plus the recorded actions. */
 MG_API int mg_copy_slot(mg_env* env, int slot, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
-                 uint8_t* direction, uint8_t* mission_id, uint8_t* action);
+                 uint8_t* direction, uint16_t* mission_id, uint8_t* action);
 MG_API int mg_sync(mg_env* env);        /* synchronises the handle's streams (steps AND episode generation) + error-flag check */
 
 /* State exchange (checkpoint/resume and parity-harness state injection).

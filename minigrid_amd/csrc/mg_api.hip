@@ -155,11 +155,11 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.seg_count = e->seg_count + (size_t)set * e->nwaves;
   A.epoch = epoch;
   A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
-  const size_t lds = (size_t)(GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, A.cap_words);
+  const size_t lds = (size_t)(REFILL_THREADS / 64) * gen_wave_lds_bytes(e->CS, A.cap_words);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
-    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves), dim3(GEN_THREADS), lds, st, A);
+    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves), dim3(REFILL_THREADS), lds, st, A);
   else
-    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves), dim3(GEN_THREADS), lds, st, A);
+    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves), dim3(REFILL_THREADS), lds, st, A);
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
 }
@@ -398,7 +398,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_OBSTRUCTEDMAZE) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_PUTNEAR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind == MG_ENV_PUTNEAR && (cfg->width != cfg->height || cfg->width < 5 || cfg->width > 8 || cfg->num_dists < 2 || cfg->num_dists > 8))
+    return fail(nullptr, MG_ERR_INVALID, "PutNear: size 5..8, numObjs 2..8");
   if (cfg->env_kind == MG_ENV_OBSTRUCTEDMAZE && (cfg->room_size != 6 || !((cfg->width == 11 && cfg->height == 6) || (cfg->width == 16 && cfg->height == 16)) ||
       cfg->num_dists < 1 || cfg->num_dists > 4 || (unsigned)cfg->num_crossings > 15u || (unsigned)cfg->agent_start_x > 2u || (unsigned)cfg->agent_start_y > 2u))
     return fail(nullptr, MG_ERR_INVALID, "ObstructedMaze: room_size 6, 1 x 2 (11 x 6) or 3 x 3 (16 x 16) rooms, num_quarters 1..4, agent_room inside the room grid");
@@ -532,7 +534,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
   if (cfg->env_kind == MG_ENV_GOTOOBJECT) { e->rule = RULE_GOTOOBJ; e->rule_div = 2; }     // same mission id -> (colour, type) coding as GoToObj
-  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ;
+  if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
+  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR;
   if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||
       cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG) { e->rule = RULE_PICKUPDESC; e->rule_div = 2; }      // strict
@@ -550,7 +553,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
 
   // k_step compiles each level rule only into the variant of its rule group
   e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
-                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP) ? GG_ROOMGRID
+                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR) ? GG_ROOMGRID
                 : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
@@ -561,7 +564,14 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipStreamCreateWithFlags(&e->stream, cfg->null_stream_sync ? hipStreamDefault : hipStreamNonBlocking));
     e->own_stream = true;
   }
-  TRY_OR_FREE(hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking));
+  {
+    // the generator stream outranks the step stream: its workgroups are few and short, and whenever step workgroups retire the
+    // dispatcher should hand the freed LDS / wave slots to a waiting refill first (a step launch at full residency otherwise
+    // starves the refill until the launch drains: measured 161 us per LavaCrossing refill at equal priority)
+    int lo = 0, hi = 0;
+    TRY_OR_FREE(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TRY_OR_FREE(hipStreamCreateWithPriority(&e->gen_stream, hipStreamNonBlocking, hi));
+  }
   TRY_OR_FREE(hipEventCreate(&e->ev0));
   TRY_OR_FREE(hipEventCreate(&e->ev1));
   for (int i = 0; i < QSETS; i++) {
@@ -601,7 +611,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_trunc = e->off_term + up(N);
     e->off_dir = e->off_trunc + up(N);
     e->off_mission = e->off_dir + up(N);
-    e->off_action = e->off_mission + up(N);
+    e->off_action = e->off_mission + up(2 * N);
     e->record_bytes = up(e->off_action + N);
     e->slot_bytes = e->record_bytes;
     if (e->slot_bytes >= ((size_t)1 << 32)) { mg_destroy(e); return fail(nullptr, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)"); }
@@ -780,18 +790,18 @@ int mg_step_many(mg_env* e, const uint8_t* actions, int T, int on_device) {
 int mg_get_outputs(mg_env* e, mg_outputs* o) {
   if (!e || !o) return MG_ERR_INVALID;
   o->obs = e->out; o->reward = (double*)(e->out + e->off_reward); o->terminated = e->out + e->off_term;
-  o->truncated = e->out + e->off_trunc; o->direction = e->out + e->off_dir; o->mission_id = e->out + e->off_mission;
+  o->truncated = e->out + e->off_trunc; o->direction = e->out + e->off_dir; o->mission_id = (uint16_t*)(e->out + e->off_mission);
   o->obs_bytes_per_env = e->obs_bytes; o->num_envs = e->N;
   o->action = e->out + e->off_action; o->traj_slots = e->S; o->slot_bytes = (int64_t)e->slot_bytes; o->record_bytes = (int64_t)e->record_bytes;
   o->max_fused_steps = e->max_fused;
   return MG_OK;
 }
 
-int mg_copy_outputs(mg_env* e, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint8_t* mission) {
+int mg_copy_outputs(mg_env* e, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint16_t* mission) {
   return mg_copy_slot(e, 0, obs, reward, term, trunc, dir, mission, nullptr);
 }
 
-int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint8_t* mission,
+int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint16_t* mission,
                  uint8_t* action) {
   if (!e || slot < 0 || slot >= e->S) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -802,7 +812,7 @@ int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* ter
   if (term) HIP_TRY(e, hipMemcpyAsync(term, b + e->off_term, N, hipMemcpyDeviceToHost, e->stream));
   if (trunc) HIP_TRY(e, hipMemcpyAsync(trunc, b + e->off_trunc, N, hipMemcpyDeviceToHost, e->stream));
   if (dir) HIP_TRY(e, hipMemcpyAsync(dir, b + e->off_dir, N, hipMemcpyDeviceToHost, e->stream));
-  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, b + e->off_mission, N, hipMemcpyDeviceToHost, e->stream));
+  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, b + e->off_mission, 2 * N, hipMemcpyDeviceToHost, e->stream));
   if (action) HIP_TRY(e, hipMemcpyAsync(action, b + e->off_action, N, hipMemcpyDeviceToHost, e->stream));
   return check_device_errors(e);
 }
@@ -853,7 +863,7 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
       g[n * e->CS + (size_t)y * e->W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
     }
     const int32_t* o = agent + n * 8;
-    if (o[0] < 0 || o[0] >= e->W || o[1] < 0 || o[1] >= e->H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535)
+    if (o[0] < 0 || o[0] >= e->W || o[1] < 0 || o[1] >= e->H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u)
       return fail(e, MG_ERR_INVALID, "agent record %zu out of range", n);
     Agent ag;
     ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];

@@ -137,7 +137,8 @@ MG_HD uint32_t color_from_sorted(uint32_t i) {
 MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t == T_BOX_KEY ? (uint32_t)T_BOX : (t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t); }
 
 // agent record: one u64 per env
-//   byte 0 x, 1 y, 2 dir, 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16), 6 flags, 7 mission id
+//   byte 0 x, 1 y, 2 dir (bits 0-1) | mission id bits 8-13 (bits 2-7), 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16),
+//   6 flags, 7 mission id bits 0-7.  Mission ids are 14 bits: PutNear has 324 missions (putnear.py:72-80).
 constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode; NEXT_STEP autoreset is due
 // levels whose env stream is also consumed by step() (DynamicObstacles) cannot pre-draw a spare episode: their resets
 // are drawn by a generator launch right before the step launch, which then only observes the fresh episode
@@ -149,13 +150,13 @@ struct Agent {
 };
 MG_HD Agent agent_unpack(uint64_t r) {
   Agent a;
-  a.x = (uint32_t)(r & 0xFF); a.y = (uint32_t)((r >> 8) & 0xFF); a.dir = (uint32_t)((r >> 16) & 0xFF);
+  a.x = (uint32_t)(r & 0xFF); a.y = (uint32_t)((r >> 8) & 0xFF); a.dir = (uint32_t)((r >> 16) & 3u);
   a.carry = (uint32_t)((r >> 24) & 0xFF); a.step = (uint32_t)((r >> 32) & 0xFFFF);
-  a.flags = (uint32_t)((r >> 48) & 0xFF); a.mission = (uint32_t)((r >> 56) & 0xFF);
+  a.flags = (uint32_t)((r >> 48) & 0xFF); a.mission = (uint32_t)((r >> 56) & 0xFF) | ((uint32_t)((r >> 18) & 0x3Fu) << 8);
   return a;
 }
 MG_HD uint64_t agent_pack(const Agent& a) {
-  return (uint64_t)(a.x & 0xFF) | ((uint64_t)(a.y & 0xFF) << 8) | ((uint64_t)(a.dir & 0xFF) << 16) |
+  return (uint64_t)(a.x & 0xFF) | ((uint64_t)(a.y & 0xFF) << 8) | ((uint64_t)((a.dir & 3u) | (((a.mission >> 8) & 0x3Fu) << 2)) << 16) |
          ((uint64_t)(a.carry & 0xFF) << 24) | ((uint64_t)(a.step & 0xFFFF) << 32) |
          ((uint64_t)(a.flags & 0xFF) << 48) | ((uint64_t)(a.mission & 0xFF) << 56);
 }

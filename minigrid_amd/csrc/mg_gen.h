@@ -399,6 +399,50 @@ MG_D void gen_gotoobject(R& rng, GridRef& g, const GenParams& P, GenResult& out)
   out.aux = 1ull << ((poss >> (8 * t)) & 63u);
 }
 
+// envs/putnear.py:101-175 (P.num_dists = numObjs <= 8).  Objects with distinct (type, colour), none within Chebyshev
+// distance 1 of an earlier one (place_obj's reject_fn near_obj; no max_tries); then the agent, the object to move and a
+// different target object.  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type over
+// COLOR_NAMES x [key, ball, box] (the order of putnear.py:72-80's placeholders); out.aux = one-bit board of target_pos.
+template <class R>
+MG_D void gen_putnear(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  g.clear_with_walls();
+  uint64_t objs = 0, poss = 0;                 // byte k = colour index * 3 + type index / cell index of object k
+  uint32_t used = 0;
+  const int n = min(P.num_dists, 8);
+#pragma unroll 1
+  for (int k = 0; k < n && !rng.dead();) {
+    const uint32_t ty = (uint32_t)rand_int(rng, 0, 3);          // _rand_elem(types)
+    const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);          // _rand_elem(COLOR_NAMES)
+    const uint32_t id = ci * 3u + ty;
+    if ((used >> id) & 1u) continue;                            // putnear.py:130-131
+    int x = 0, y = 0;
+#pragma unroll 1
+    for (;;) {                                                  // place_obj over the whole grid (agent_pos is (-1, -1) here)
+      if (rng.dead()) break;
+      x = rand_int(rng, 0, g.W); y = rand_int(rng, 0, g.H);
+      if (g.get(x, y) != CELL_EMPTY) continue;
+      bool near = false;
+      for (int j = 0; j < k; j++) {
+        const int q = (int)((poss >> (8 * j)) & 0xFF), px = q % g.W, py = q / g.W;
+        near |= abs(x - px) <= 1 && abs(y - py) <= 1;
+      }
+      if (!near) break;
+    }
+    g.set(x, y, make_cell((uint32_t)T_KEY + ty, color_from_sorted(ci)));
+    used |= 1u << id;
+    objs |= (uint64_t)id << (8 * k);
+    poss |= (uint64_t)(y * g.W + x) << (8 * k);
+    k++;
+  }
+  if (!place_agent(rng, g, 0, 0, g.W, g.H, -1, out)) out.failed = true;
+  const int mv = rand_int(rng, 0, n);
+  int tg = mv;
+  while (tg == mv && !rng.dead()) tg = rand_int(rng, 0, n);
+  const uint32_t idm = (uint32_t)((objs >> (8 * mv)) & 0xFF), idt = (uint32_t)((objs >> (8 * tg)) & 0xFF);
+  out.mission = idm * 18u + idt;               // ((cm * 3 + tm) * 6 + ct) * 3 + tt
+  out.aux = 1ull << ((poss >> (8 * tg)) & 63u);
+}
+
 // envs/gotodoor.py:92-131.  The room is w x h <= W x H in the top-left corner; the rest of the grid stays None.
 // Mission id = COLOR_NAMES index of the target door (door colours are distinct, so it identifies the door).
 template <class R>
@@ -1113,6 +1157,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 29: gen_unlocklocal(rng, g, P, out); return;
       case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
       case 31: gen_obstructedmaze(rng, g, P, out); return;
+      case 32: gen_putnear(rng, g, P, out); return;
       default: break;
     }
   }

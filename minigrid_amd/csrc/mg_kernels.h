@@ -35,7 +35,7 @@ enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
               RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
-              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11 };
+              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12 };
 
 struct StepParams {
   // ---- state ----
@@ -268,8 +268,9 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // (later step launches run concurrently): those slots are free as well, and drawing them early is harmless.
 // live = 1 (DynamicObstacles, same stream, right before the step launch): requests are the envs whose episode ended;
 // they are redrawn IN PLACE if they are still waiting for a reset, and come out FRESH (observed, not stepped).
+constexpr int REFILL_THREADS = 512;    // 8 generating waves per request segment: a GoToRedBall batch files ~9 requests per segment
 template <class RNG>
-__global__ void __launch_bounds__(GEN_THREADS) k_refill(const GenArgs A) {
+__global__ void __launch_bounds__(REFILL_THREADS) k_refill(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t lane = threadIdx.x & 63u;
   const int wave = (int)(threadIdx.x >> 6);
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_refill(const GenArgs A) {
   rng.prefetch(lane);
   uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
   const uint32_t* seg = A.seg + (size_t)blockIdx.x * A.seg_cap;
-  for (int k = wave; k < cnt; k += GEN_THREADS / 64) {
+  for (int k = wave; k < cnt; k += REFILL_THREADS / 64) {
     const int e = (int)uni32(seg[k]);
     uint32_t old = 0;
     if (lane == 0) old = atomicMax(&A.claim[e], A.epoch);
@@ -600,7 +601,7 @@ k_step(const StepParams P) {
   uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ);
+  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR);   // levels with an auxiliary word
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
@@ -669,7 +670,7 @@ k_step(const StepParams P) {
   // the loop does not carry six 64-bit field offsets in scalar registers (the kernel is at the SGPR limit)
   const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
                  o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
-                 o_mis = (uint32_t)P.off_mission + (uint32_t)e, o_act = (uint32_t)P.off_action + (uint32_t)e;
+                 o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
   bool rec_dirty = false, aux_dirty = false, wb_all = false;
   uint32_t errbits = 0, fin_total = 0;
   uint32_t pw[4] = { 0, 0, 0, 0 };
@@ -732,6 +733,7 @@ k_step(const StepParams P) {
       } else if (P.phase == PHASE_STEP) {
         // ---- MiniGridEnv.step ----
         rec_dirty = true;
+        const uint32_t pre_carry = a.carry;
         a.step = min(a.step + 1u, 0xFFFFu);
         const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
         const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
@@ -780,6 +782,20 @@ k_step(const StepParams P) {
             const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
             const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
             term = 1; success = (targets & ring) != 0;
+          }
+        }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEAR) {
+          // PutNearEnv.step (putnear.py:177-199).  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type
+          // (COLOR_NAMES / [key, ball, box] indices); target_pos is a POSITION fixed at reset: the one-bit board `targets`.
+          const uint32_t mv = a.mission / 18u;
+          const uint32_t move = make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u));
+          if (act == A_PICKUP && a.carry != 0 && a.carry != move) term = 1;           // picked up the wrong object
+          if (act == A_DROP && pre_carry != 0) {
+            if (newF != F && inb && targets) {                                        // `grid.get(ox, oy) is preCarrying`: the drop happened
+              const int tidx = __ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
+              if (abs(fx - tx) <= 1 && abs(fy - ty) <= 1) success = true;
+            }
+            term = 1;
           }
         }
         if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
@@ -900,7 +916,7 @@ k_step(const StepParams P) {
       ob[o_term] = (uint8_t)term;
       ob[o_trunc] = (uint8_t)trunc;
       ob[o_dir] = (uint8_t)a.dir;
-      ob[o_mis] = (uint8_t)a.mission;
+      *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
       ob[o_act] = (uint8_t)act_in;
     }
 

@@ -18,7 +18,7 @@ ENV_DYNOBS = 15
 ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GOTOOBJECT = 16, 17, 18, 19, 20
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
-ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE = 29, 30, 31
+ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE, ENV_PUTNEAR = 29, 30, 31, 32
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -261,6 +261,13 @@ _ROWS = [
         ("2Q-v0", 3, 3, 11, True, True, 2, (2, 1), False, False), ("Full-v0", 3, 3, 25, True, True, 4, (1, 1), False, False),
         ("2Dlhb-v1", 3, 3, 4, True, True, 1, (2, 1), True, False), ("1Q-v1", 3, 3, 5, True, True, 1, (1, 1), True, False),
         ("2Q-v1", 3, 3, 11, True, True, 2, (2, 1), True, False), ("Full-v1", 3, 3, 25, True, True, 4, (1, 1), True, False))],
+    # envs/putnear.py:68-93: see_through_walls=True, max_steps = 5 * size; rows minigrid/__init__.py:526-537.  324 missions in the
+    # order of the placeholders (move colour, move type, target colour, target type): 16-bit mission ids
+    *[EnvSpec(name, ENV_PUTNEAR, size, size, 5 * size, True,
+              tuple(f"put the {mc} {mt} near the {tc} {tt}" for mc in _COLOR_NAMES for mt in ("key", "ball", "box")
+                    for tc in _COLOR_NAMES for tt in ("key", "ball", "box")),
+              num_dists=n, entry_point="minigrid.envs:PutNearEnv", kwargs={} if size == 6 else {"size": size, "numObjs": n})
+      for name, size, n in (("MiniGrid-PutNear-6x6-N2-v0", 6, 2), ("MiniGrid-PutNear-8x8-N3-v0", 8, 3))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),

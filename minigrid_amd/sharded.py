@@ -48,7 +48,7 @@ def record_layout(n: int, obs_bytes: int) -> dict:
     off["truncated"] = off["terminated"] + up(n)
     off["direction"] = off["truncated"] + up(n)
     off["mission_id"] = off["direction"] + up(n)
-    off["action"] = off["mission_id"] + up(n)
+    off["action"] = off["mission_id"] + up(2 * n)
     off["record_bytes"] = up(off["action"] + n)
     return off
 
@@ -142,8 +142,8 @@ class ShardedVecEnv:
             put("direction", _to_tensor(np.asarray(obs["direction"], np.uint8)))
             mis = obs.get("mission_id")
             if mis is None:
-                mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint8, n)
-            put("mission_id", _to_tensor(np.asarray(mis, np.uint8)))
+                mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint16, n)
+            put("mission_id", _to_tensor(np.asarray(mis, np.uint16).view(np.uint8)))
         return rec, obs_bytes
 
     def gather_record(self, rec=None, obs_bytes=None):
@@ -188,7 +188,7 @@ class ShardedVecEnv:
         term_g = field("terminated", torch.uint8).bool()
         trunc_g = field("truncated", torch.uint8).bool()
         if isinstance(obs, dict):
-            ids = field("mission_id", torch.uint8)
+            ids = field("mission_id", torch.int16)
             out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}
             if "mission_id" in obs:
                 out["mission_id"] = ids

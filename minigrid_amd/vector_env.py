@@ -166,7 +166,7 @@ class MiniGridVecEnv(_VectorEnvBase):
         self._h_term = np.empty(n, np.uint8)
         self._h_trunc = np.empty(n, np.uint8)
         self._h_dir = np.empty(n, np.uint8)
-        self._h_mis = np.empty(n, np.uint8)
+        self._h_mis = np.empty(n, np.uint16)
         self._torch_views = None
 
     # ------------------------------------------------------------------ helpers
@@ -192,7 +192,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                 "terminated": _DeviceArray(o.terminated + off, (n,), "|u1", self),
                 "truncated": _DeviceArray(o.truncated + off, (n,), "|u1", self),
                 "direction": _DeviceArray(o.direction + off, (n,), "|u1", self),
-                "mission_id": _DeviceArray(o.mission_id + off, (n,), "|u1", self),
+                "mission_id": _DeviceArray(o.mission_id + off, (n,), "<i2", self),     # 14-bit ids; int16 is the portable 2-byte dtype
                 "action": _DeviceArray(o.action + off, (n,), "|u1", self),
                 # the whole step as ONE contiguous byte record (obs | reward | terminated | truncated | direction |
                 # mission | action): what a multi-GPU consumer all-gathers (minigrid_amd/sharded.py)
@@ -220,7 +220,7 @@ class MiniGridVecEnv(_VectorEnvBase):
         n = self.num_envs
         img = np.empty((n,) + self.image_shape, np.int8 if self.obs_mode == "symbolic" else np.uint8)
         rew = np.empty(n, np.float64)
-        u8 = [np.empty(n, np.uint8) for _ in range(5)]
+        u8 = [np.empty(n, np.uint16 if k == 3 else np.uint8) for k in range(5)]      # mission ids are 16 bits wide
         rc = self._lib.mg_copy_slot(self._h, int(slot), self._p(img), self._p(rew), *[self._p(a) for a in u8])
         B.check(rc, self._h)
         return img, rew, u8[0].astype(bool), u8[1].astype(bool), u8[2], u8[3], u8[4]
