@@ -273,9 +273,14 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = env.timer_stop()
 
+    per_rank_us = [dt / args.steps * 1e6]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, t)                       # every rank's own clock ...
+        per_rank_us = [float(x) / args.steps * 1e6 for x in allt.cpu()]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # ... and the job's: the slowest rank
         dt = float(t.item())
     counters = env.counters()
 
@@ -301,7 +306,11 @@ def main():
                        "launch": (f"fused: {spl} steps per k_step launch, state resident in LDS, each step's outputs to its own trajectory slot"
                                   if spl > 1 else "one k_step launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "steps_per_launch": spl,
-                       "gather_obs": gather, "episodes_finished_rank0": counters["episodes"]},
+                       "gather_obs": gather, "episodes_finished_rank0": counters["episodes"],
+                       "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
+                                       "backend": (dist.get_backend() if world > 1 else None),
+                                       "per_rank_us_per_step": per_rank_us,
+                                       "collective": ("one all_gather_into_tensor of the step record per step" if gather else "none on the data path")}},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
                          "traffic_unit": "bytes per k_step launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",

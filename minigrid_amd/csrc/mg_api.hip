@@ -126,7 +126,7 @@ static GenArgs gen_args(mg_env* e, int slot) {
   A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + e->nwaves;
   A.live = 0;
-  A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap;
+  A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
 }
@@ -155,12 +155,14 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.seg_count = e->seg_count + (size_t)set * e->nwaves;
   A.epoch = epoch;
   A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
-  const size_t lds = (size_t)(REFILL_THREADS / 64) * gen_wave_lds_bytes(e->CS, A.cap_words);
+  A.wps = std::max(1, e->epw / 8);            // a batch files ~EPW/7 requests per segment at the highest reset rates of the BASELINE configs
+  const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
-    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves), dim3(REFILL_THREADS), lds, st, A);
+    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
   else
-    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves), dim3(REFILL_THREADS), lds, st, A);
+    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
   HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemsetAsync(A.seg_count, 0, (size_t)e->nwaves * sizeof(uint32_t), st));
   return MG_OK;
 }
 

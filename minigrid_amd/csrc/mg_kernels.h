@@ -156,6 +156,7 @@ struct GenArgs {
                                                      //    envs still flagged RESET_PENDING are drawn, and come out FRESH
   // refill mode (k_refill): request segments of one batch, ring bookkeeping
   const uint32_t* seg; uint32_t* seg_count; int seg_cap;
+  int wps;                                           // generating workgroups (one wavefront each) per request segment
   const uint32_t* head; uint32_t* tail; uint32_t* claim; uint32_t epoch; uint32_t ring_mask;
 };
 
@@ -268,19 +269,22 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // (later step launches run concurrently): those slots are free as well, and drawing them early is harmless.
 // live = 1 (DynamicObstacles, same stream, right before the step launch): requests are the envs whose episode ended;
 // they are redrawn IN PLACE if they are still waiting for a reset, and come out FRESH (observed, not stepped).
-constexpr int REFILL_THREADS = 512;    // 8 generating waves per request segment: a GoToRedBall batch files ~9 requests per segment
+// Launch geometry: ONE generating wavefront per workgroup, A.wps workgroups per request segment (workgroup b serves requests
+// b % wps, b % wps + wps, ... of segment b / wps).  Single-wave workgroups keep the LDS footprint at one draw buffer (5 KB), so
+// a CU holds 32 generating waves; multi-wave workgroups held their whole allocation until the slowest wave finished and
+// capped the chip at ~1000 concurrent generations (LavaCrossing refill: 210 us -> measured in profiles/r2).
 template <class RNG>
-__global__ void __launch_bounds__(REFILL_THREADS) k_refill(const GenArgs A) {
+__global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const int wave = (int)(threadIdx.x >> 6);
-  const int cnt = (int)uni32(A.seg_count[blockIdx.x]);
-  if (cnt == 0) return;
+  const uint32_t lane = threadIdx.x;
+  const int sidx = (int)(blockIdx.x / (uint32_t)A.wps), wave = (int)(blockIdx.x % (uint32_t)A.wps);
+  const int cnt = (int)uni32(A.seg_count[sidx]);
+  if (wave >= cnt) return;
   RNG rng;
   rng.prefetch(lane);
-  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
-  const uint32_t* seg = A.seg + (size_t)blockIdx.x * A.seg_cap;
-  for (int k = wave; k < cnt; k += REFILL_THREADS / 64) {
+  uint8_t* lds = smem;
+  const uint32_t* seg = A.seg + (size_t)sidx * A.seg_cap;
+  for (int k = wave; k < cnt; k += A.wps) {
     const int e = (int)uni32(seg[k]);
     uint32_t old = 0;
     if (lane == 0) old = atomicMax(&A.claim[e], A.epoch);
@@ -300,8 +304,7 @@ __global__ void __launch_bounds__(REFILL_THREADS) k_refill(const GenArgs A) {
     }
     if (lane == 0) A.tail[e] = t;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) A.seg_count[blockIdx.x] = 0u;          // the segment is reused QSETS batches later
+  // (the host clears the segment counters on the same stream after this launch; the set is reused QSETS batches later)
 }
 
 // mg_get_rng: the reference env's stream position "now" = the state before its next unconsumed spare was drawn
