@@ -155,7 +155,8 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.seg_count = e->seg_count + (size_t)set * e->nwaves;
   A.epoch = epoch;
   A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
-  A.wps = std::max(1, e->epw / 8);            // a batch files ~EPW/7 requests per segment at the highest reset rates of the BASELINE configs
+  A.wps = std::max(1, e->epw / 4);            // a GoToRedBall batch files ~EPW/7 requests per segment (Poisson: some segments twice that)
+  if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
     hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
@@ -479,7 +480,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // the same batch (16 envs each), each a quarter of the LDS: the step loop is latency-bound per wave, not issue-bound
     const bool fast7 = cfg->obs_mode == MG_OBS_PARTIAL && V == 7;
     const bool fullish = (cfg->obs_mode == MG_OBS_FULL || cfg->obs_mode == MG_OBS_SYMBOLIC) && e->cells >= 32;
-    e->lpe = fullish ? 4 : 1;                                 // measured (profiles/r2): 4 wins for FullyObs, 1 for the 7x7 view
+    // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
+    // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
+    e->lpe = (fullish || (fast7 && cfg->num_envs <= 40000)) ? 4 : 1;
     if (fast7 && getenv("MG_LPE") && atoi(getenv("MG_LPE")) == 4) e->lpe = 4;
     if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
