@@ -57,6 +57,8 @@ struct mg_env {
   uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
   bool goto_kind = false;
   uint8_t* tilemap = nullptr; uint32_t* atlas = nullptr;   // RGB modes: k_step's output / the tile atlas (mg_tiles.h)
+  uint8_t* st_grid = nullptr; int32_t* st_agent = nullptr;   // state-exchange staging (mg_get_state / mg_set_state), on first use
+  uint32_t* claim_bad() { return err + 1; }                // second word of the error buffer: mg_set_state's validation flag
   RenderParams render;        // ... and k_render's launch geometry
   int render_lds = 0, render_blocks = 0, render_threads = 256;
   bool rgb = false;
@@ -239,7 +241,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 }
 
 // every k_step instantiation the library launches: (MODE, FAST7) x rule group
-#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
+#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 2) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
   X(2, false, GG, 1) X(3, false, GG, 1) X(3, false, GG, 4) X(4, false, GG, 1)
 #define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
 
@@ -288,7 +290,13 @@ static int launch_step(mg_env* e, StepParams& P) {
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
   if (e->rgb) {
-    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
+    static const bool small = !(getenv("MG_RENDER_SMALL") && atoi(getenv("MG_RENDER_SMALL")) == 0);
+    if (small) {
+      const RenderParams& R = e->render;
+      const int frame_chunks = R.Ht * R.ts * R.rowdw / 4, bpe = (frame_chunks + 255) / 256;
+      hipLaunchKernelGGL(k_render_small, dim3((unsigned)((size_t)e->N * bpe)), dim3(256), 0, e->stream, e->render, frame_chunks, bpe);
+    } else
+      hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
   }
   e->launches++;
@@ -483,7 +491,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
     // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
     e->lpe = (fullish || (fast7 && cfg->num_envs <= 40000)) ? 4 : 1;
-    if (fast7 && getenv("MG_LPE") && atoi(getenv("MG_LPE")) == 4) e->lpe = 4;
+    if (fast7 && getenv("MG_LPE") && (atoi(getenv("MG_LPE")) == 4 || atoi(getenv("MG_LPE")) == 2)) e->lpe = atoi(getenv("MG_LPE"));
     if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
   }
@@ -509,12 +517,14 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   {
     // spare ring depth R (power of two).  Levels that draw nothing keep ONE constant spare; DynamicObstacles draws in
-    // place (no ring).  Default 16: with cb = R/4 = 4 a fused launch runs 8 steps, and the generator may lag three
-    // batches (24 steps) behind before a step launch has to wait for it.  Sized for 288 GB of HBM: 16 spare maps of
-    // 64 B are 1 KB per env; very large maps x batches are capped at 8 GB of ring.
+    // place (no ring).  Default 32: with cb = R/4 = 8 a fused launch runs 16 steps, and the generator may lag three
+    // batches (48 steps) behind before a step launch has to wait for it.  A refill's duration is set by its longest chain
+    // of whole-map retries (GoToRedBall: 70-100 us), not by its size, so longer batches amortise it: measured 11.1 us per
+    // step with R = 16, 7.4 with R = 32 (profiles/r2).  Sized for 288 GB of HBM: 32 spare maps of 64 B are 2 KB per env;
+    // very large maps x batches are capped at 8 GB of ring.
     int R = 1;
     if (!e->static_gen && !e->live_gen) {
-      R = cfg->spare_ring > 0 ? cfg->spare_ring : 16;
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : 32;
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 64 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..64"); }
       while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
@@ -624,10 +634,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
   }
   if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
-  TRY_OR_FREE(dalloc(&e->err, 1));
+  TRY_OR_FREE(dalloc(&e->err, 2));
   e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
   TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
-  TRY_OR_FREE(hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
+  TRY_OR_FREE(hipMemsetAsync(e->err, 0, 2 * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, R * N * e->CS, e->stream));
@@ -671,7 +681,7 @@ int mg_destroy(mg_env* e) {
   if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
   void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
                    e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->err, e->counters,
-                   e->tilemap, e->atlas };
+                   e->tilemap, e->atlas, e->st_grid, e->st_agent };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -831,78 +841,52 @@ int mg_sync(mg_env* e) {
   return check_device_errors(e);
 }
 
+// staging buffers of the state exchange, allocated on first use: (N, W, H, 3) u8 + (N, 8) i32
+static int state_staging(mg_env* e) {
+  if (e->st_grid) return MG_OK;
+  const size_t N = (size_t)e->N;
+  HIP_TRY(e, hipMalloc((void**)&e->st_grid, N * e->cells * 3));
+  HIP_TRY(e, hipMalloc((void**)&e->st_agent, N * 8 * sizeof(int32_t)));
+  return MG_OK;
+}
+
 int mg_get_state(mg_env* e, uint8_t* grid, int32_t* agent) {
   if (!e || !grid || !agent) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
-  const size_t N = (size_t)e->N;
-  std::vector<uint8_t> g(N * e->CS);
-  std::vector<uint64_t> a(N);
-  HIP_TRY(e, hipMemcpyAsync(g.data(), e->grid, g.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(a.data(), e->agent, N * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+  { int rc = state_staging(e); if (rc) return rc; }
+  const size_t N = (size_t)e->N, total = N * e->cells;
+  const int tb = 256;
+  hipLaunchKernelGGL(k_state_encode, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, e->stream, e->grid, e->agent, e->st_grid, e->st_agent,
+                     e->N, e->W, e->H, e->CS);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(grid, e->st_grid, total * 3, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(agent, e->st_agent, N * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  for (size_t n = 0; n < N; n++) {
-    for (int x = 0; x < e->W; x++) for (int y = 0; y < e->H; y++) {
-      uint32_t tri = cell_triple(g[n * e->CS + (size_t)y * e->W + x]);
-      uint8_t* p = grid + ((n * e->W + x) * e->H + y) * 3;
-      p[0] = (uint8_t)tri; p[1] = (uint8_t)(tri >> 8); p[2] = (uint8_t)(tri >> 16);
-    }
-    Agent ag = agent_unpack(a[n]);
-    int32_t* o = agent + n * 8;
-    o[0] = (int32_t)ag.x; o[1] = (int32_t)ag.y; o[2] = (int32_t)ag.dir;
-    o[3] = ag.carry ? (int32_t)(cell_triple(ag.carry) & 0xFF) : 0;
-    o[4] = ag.carry ? (int32_t)((cell_triple(ag.carry) >> 8) & 0xFF) : 0;
-    o[5] = (int32_t)ag.step; o[6] = (int32_t)(ag.flags & FLAG_RESET_PENDING); o[7] = (int32_t)ag.mission;
-  }
   return MG_OK;
 }
 
 int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
   if (!e || !grid || !agent) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
-  const size_t N = (size_t)e->N;
-  std::vector<uint8_t> g(N * e->CS, 0);
-  std::vector<uint64_t> a(N);
-  for (size_t n = 0; n < N; n++) {
-    for (int x = 0; x < e->W; x++) for (int y = 0; y < e->H; y++) {
-      const uint8_t* p = grid + ((n * e->W + x) * e->H + y) * 3;
-      g[n * e->CS + (size_t)y * e->W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
-    }
-    const int32_t* o = agent + n * 8;
-    if (o[0] < 0 || o[0] >= e->W || o[1] < 0 || o[1] >= e->H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u)
-      return fail(e, MG_ERR_INVALID, "agent record %zu out of range", n);
-    Agent ag;
-    ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];
-    ag.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
-    if (ag.carry == CELL_EMPTY) ag.carry = 0;
-    ag.step = (uint32_t)o[5]; ag.flags = o[6] ? FLAG_RESET_PENDING : 0u; ag.mission = (uint32_t)o[7];
-    a[n] = agent_pack(ag);
+  { int rc = state_staging(e); if (rc) return rc; }
+  const size_t N = (size_t)e->N, total = N * e->cells;
+  const int tb = 256;
+  HIP_TRY(e, hipMemcpyAsync(e->st_grid, grid, total * 3, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemcpyAsync(e->st_agent, agent, N * 8 * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(e, hipMemsetAsync(e->claim_bad(), 0, sizeof(uint32_t), e->stream));
+  hipLaunchKernelGGL(k_state_decode, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, e->stream, e->st_grid, e->st_agent, e->grid, e->agent,
+                     e->claim_bad(), e->N, e->W, e->H, e->CS);
+  HIP_TRY(e, hipGetLastError());
+  if (e->goto_kind || e->live_gen) {
+    // GoToInstr's tracked positions / the obstacle list are re-found from the grid (not part of the exchanged state)
+    hipLaunchKernelGGL(k_aux_rebuild, dim3((e->N + tb - 1) / tb), dim3(tb), 0, e->stream, e->grid, e->agent, e->aux, e->N, e->cells, e->CS,
+                       e->live_gen ? 2 : 1, e->rule_div, e->rule_cell);
+    HIP_TRY(e, hipGetLastError());
   }
-  std::vector<uint64_t> ob;
-  if (e->goto_kind) {
-    // GoToInstr's tracked positions are re-found from the grid (their staleness is not part of the exchanged state)
-    ob.assign(N, 0);
-    for (size_t n = 0; n < N; n++) {
-      const uint32_t mis = (uint32_t)agent[n * 8 + 7], m18 = mis % 18u;
-      const uint32_t desc = e->rule_div == 0 ? (uint32_t)e->rule_cell
-                          : e->rule_div == 1 ? make_cell(T_BALL, mis ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-                                             : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
-      for (int c = 0; c < e->cells; c++) if (g[n * e->CS + c] == desc) ob[n] |= 1ull << c;
-    }
-    HIP_TRY(e, hipMemcpyAsync(e->aux, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-  }
-  if (e->live_gen) {
-    // the obstacle list order is not part of the exchanged state: rebuilt in cell-index order
-    ob.assign(N, 0);
-    for (size_t n = 0; n < N; n++) {
-      int k = 0;
-      for (int c = 0; c < e->cells && k < 8; c++)
-        if (cell_type(g[n * e->CS + c]) == T_BALL) ob[n] |= (uint64_t)c << (8 * k++);
-    }
-    HIP_TRY(e, hipMemcpyAsync(e->aux, ob.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-  }
-  HIP_TRY(e, hipMemcpyAsync(e->grid, g.data(), g.size(), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemcpyAsync(e->agent, a.data(), N * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  uint32_t bad = 0;
+  HIP_TRY(e, hipMemcpyAsync(&bad, e->claim_bad(), sizeof bad, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (bad) return fail(e, MG_ERR_INVALID, "an agent record is out of range (position outside the grid, dir > 3, step_count or mission id too large)");
   return MG_OK;
 }
 

@@ -1163,4 +1163,100 @@ __global__ void __launch_bounds__(RENDER_MAX_THREADS) k_render(const RenderParam
   }
 }
 
+// ======================================================================================================
+// State exchange on the device (mg_get_state / mg_set_state): Grid.encode() layout (N, W, H, 3) <-> the one-byte-per-cell
+// row-major grids, and the (N, 8) i32 agent records <-> the packed u64 records.  One thread per (env, cell) / per env.
+// ======================================================================================================
+__global__ void k_state_encode(const uint8_t* grid, const uint64_t* agent, uint8_t* out_grid, int32_t* out_agent, int N, int W, int H, int CS) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cells = (size_t)W * H;
+  if (i >= (size_t)N * cells) return;
+  const size_t n = i / cells;
+  const int k = (int)(i - n * cells), x = k / H, y = k - x * H;             // output order image[x][y]
+  const uint32_t tri = cell_triple(grid[n * CS + (size_t)y * W + x]);
+  uint8_t* p = out_grid + i * 3;
+  p[0] = (uint8_t)tri; p[1] = (uint8_t)(tri >> 8); p[2] = (uint8_t)(tri >> 16);
+  if (k == 0) {
+    const Agent ag = agent_unpack(agent[n]);
+    int32_t* o = out_agent + n * 8;
+    o[0] = (int32_t)ag.x; o[1] = (int32_t)ag.y; o[2] = (int32_t)ag.dir;
+    o[3] = ag.carry ? (int32_t)(cell_triple(ag.carry) & 0xFF) : 0;
+    o[4] = ag.carry ? (int32_t)((cell_triple(ag.carry) >> 8) & 0xFF) : 0;
+    o[5] = (int32_t)ag.step; o[6] = (int32_t)(ag.flags & FLAG_RESET_PENDING); o[7] = (int32_t)ag.mission;
+  }
+}
+__global__ void k_state_decode(const uint8_t* in_grid, const int32_t* in_agent, uint8_t* grid, uint64_t* agent, uint32_t* bad, int N, int W, int H, int CS) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t cells = (size_t)W * H;
+  if (i >= (size_t)N * cells) return;
+  const size_t n = i / cells;
+  const int k = (int)(i - n * cells), x = k / H, y = k - x * H;
+  const uint8_t* p = in_grid + i * 3;
+  grid[n * CS + (size_t)y * W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
+  if (k == 0) {
+    const int32_t* o = in_agent + n * 8;
+    if (o[0] < 0 || o[0] >= W || o[1] < 0 || o[1] >= H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u) { atomicOr(bad, 1u); return; }
+    Agent ag;
+    ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];
+    ag.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
+    if (ag.carry == CELL_EMPTY) ag.carry = 0;
+    ag.step = (uint32_t)o[5]; ag.flags = o[6] ? FLAG_RESET_PENDING : 0u; ag.mission = (uint32_t)o[7];
+    agent[n] = agent_pack(ag);
+    for (int c = (int)cells; c < CS; c++) grid[n * CS + c] = 0;
+  }
+}
+// the auxiliary word is not part of the exchanged state: it is re-derived from the injected grid.  mode 1: GoToInstr's tracked
+// positions / target_pos = the cells holding the described object (desc from the mission id, see k_step); mode 2:
+// DynamicObstacles' obstacle list, rebuilt in cell-index order
+__global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64_t* aux, int N, int cells, int CS, int mode, int rule_div, int rule_cell) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const uint8_t* g = grid + (size_t)n * CS;
+  uint64_t w = 0;
+  if (mode == 1) {
+    const uint32_t mis = agent_unpack(agent[n]).mission, m18 = mis % 18u;
+    const uint32_t desc = rule_div == 0 ? (uint32_t)rule_cell
+                        : rule_div == 1 ? make_cell(T_BALL, mis ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+                                        : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+    for (int c = 0; c < cells && c < 64; c++) if (g[c] == desc) w |= 1ull << c;
+  } else {
+    int k = 0;
+    for (int c = 0; c < cells && k < 8; c++) if (cell_type(g[c]) == T_BALL) w |= (uint64_t)c << (8 * k++);
+  }
+  aux[n] = w;
+}
+
+// k_render_small: the same frames from SHORT-LIVED workgroups -- one 16 B chunk per thread, 256 consecutive chunks of one
+// env's frame per workgroup, tiles read straight from the atlas in global memory (20 KB: L1/L2 resident), no LDS staging.
+// Why: profiles/r2/storebench.txt -- a bare 16 B/lane store stream reaches the fill kernel's 6.9 TB/s only from short-lived
+// workgroups that each write ONE small contiguous piece (4 KB: 6.88 TB/s; 16 KB: 6.08; 64 KB or persistent loops: 4.4-5.5);
+// k_render's persistent workgroups sit in the slow regime whatever their mosaic logic costs.
+__global__ void __launch_bounds__(256) k_render_small(const RenderParams R, int frame_chunks, int bpe) {
+  const int env = (int)(blockIdx.x / (uint32_t)bpe);
+  const int c = (int)(blockIdx.x % (uint32_t)bpe) * 256 + (int)threadIdx.x;
+  if (c >= frame_chunks) return;
+  int acell = (R.Ht - 1) * R.Wt + (R.Wt >> 1), dir = 3;            // POV: bottom centre, facing up (minigrid_env.py:659-663)
+  if (R.full) {
+    const Agent a = agent_unpack(R.agent[env]);
+    acell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
+  }
+  const uint8_t* tm = R.tilemap + (size_t)env * R.cells;
+  uint32_t q = (uint32_t)c * 4u;
+  uint32_t prow = q / (uint32_t)R.rowdw, col = q - prow * (uint32_t)R.rowdw;
+  uint32_t v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t ty = __umul24(prow, R.magic_ts) >> 16, pr = prow - __umul24(ty, (uint32_t)R.ts);
+    const uint32_t tx = col / (uint32_t)R.tdw_row, cd = col - tx * (uint32_t)R.tdw_row;
+    const int cell = (int)(ty * (uint32_t)R.Wt + tx);
+    const uint32_t tb = tm[cell];                                  // tile key * 2 + highlight
+    const uint32_t* src = cell == acell ? R.atlas_agent + (size_t)(((tb >> 1) * 4u + (uint32_t)dir) * 2u + (tb & 1u)) * R.tile_dw
+                                        : R.atlas_static + (size_t)tb * R.tile_dw;
+    v[j] = src[pr * (uint32_t)R.tdw_row + cd];
+    if (++col == (uint32_t)R.rowdw) { col = 0; prow++; }
+  }
+  u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+  ((u32x4*)R.out)[(size_t)env * frame_chunks + c] = o;
+}
+
 }  // namespace mg
