@@ -241,7 +241,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
 }
 
 // every k_step instantiation the library launches: (MODE, FAST7) x rule group
-#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 2) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
+#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
   X(2, false, GG, 1) X(3, false, GG, 1) X(3, false, GG, 4) X(4, false, GG, 1)
 #define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
 
@@ -290,13 +290,7 @@ static int launch_step(mg_env* e, StepParams& P) {
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
   if (e->rgb) {
-    static const bool small = !(getenv("MG_RENDER_SMALL") && atoi(getenv("MG_RENDER_SMALL")) == 0);
-    if (small) {
-      const RenderParams& R = e->render;
-      const int frame_chunks = R.Ht * R.ts * R.rowdw / 4, bpe = (frame_chunks + 255) / 256;
-      hipLaunchKernelGGL(k_render_small, dim3((unsigned)((size_t)e->N * bpe)), dim3(256), 0, e->stream, e->render, frame_chunks, bpe);
-    } else
-      hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
+    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
   }
   e->launches++;
@@ -491,7 +485,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
     // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
     e->lpe = (fullish || (fast7 && cfg->num_envs <= 40000)) ? 4 : 1;
-    if (fast7 && getenv("MG_LPE") && (atoi(getenv("MG_LPE")) == 4 || atoi(getenv("MG_LPE")) == 2)) e->lpe = atoi(getenv("MG_LPE"));
+    if (fast7 && getenv("MG_LPE") && atoi(getenv("MG_LPE")) == 4) e->lpe = 4;
     if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
   }

@@ -1226,37 +1226,4 @@ __global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64
   aux[n] = w;
 }
 
-// k_render_small: the same frames from SHORT-LIVED workgroups -- one 16 B chunk per thread, 256 consecutive chunks of one
-// env's frame per workgroup, tiles read straight from the atlas in global memory (20 KB: L1/L2 resident), no LDS staging.
-// Why: profiles/r2/storebench.txt -- a bare 16 B/lane store stream reaches the fill kernel's 6.9 TB/s only from short-lived
-// workgroups that each write ONE small contiguous piece (4 KB: 6.88 TB/s; 16 KB: 6.08; 64 KB or persistent loops: 4.4-5.5);
-// k_render's persistent workgroups sit in the slow regime whatever their mosaic logic costs.
-__global__ void __launch_bounds__(256) k_render_small(const RenderParams R, int frame_chunks, int bpe) {
-  const int env = (int)(blockIdx.x / (uint32_t)bpe);
-  const int c = (int)(blockIdx.x % (uint32_t)bpe) * 256 + (int)threadIdx.x;
-  if (c >= frame_chunks) return;
-  int acell = (R.Ht - 1) * R.Wt + (R.Wt >> 1), dir = 3;            // POV: bottom centre, facing up (minigrid_env.py:659-663)
-  if (R.full) {
-    const Agent a = agent_unpack(R.agent[env]);
-    acell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
-  }
-  const uint8_t* tm = R.tilemap + (size_t)env * R.cells;
-  uint32_t q = (uint32_t)c * 4u;
-  uint32_t prow = q / (uint32_t)R.rowdw, col = q - prow * (uint32_t)R.rowdw;
-  uint32_t v[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t ty = __umul24(prow, R.magic_ts) >> 16, pr = prow - __umul24(ty, (uint32_t)R.ts);
-    const uint32_t tx = col / (uint32_t)R.tdw_row, cd = col - tx * (uint32_t)R.tdw_row;
-    const int cell = (int)(ty * (uint32_t)R.Wt + tx);
-    const uint32_t tb = tm[cell];                                  // tile key * 2 + highlight
-    const uint32_t* src = cell == acell ? R.atlas_agent + (size_t)(((tb >> 1) * 4u + (uint32_t)dir) * 2u + (tb & 1u)) * R.tile_dw
-                                        : R.atlas_static + (size_t)tb * R.tile_dw;
-    v[j] = src[pr * (uint32_t)R.tdw_row + cd];
-    if (++col == (uint32_t)R.rowdw) { col = 0; prow++; }
-  }
-  u32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-  ((u32x4*)R.out)[(size_t)env * frame_chunks + c] = o;
-}
-
 }  // namespace mg
