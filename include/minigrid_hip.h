@@ -42,7 +42,9 @@ typedef enum mg_status {
   MG_ERR_GENERATOR = -4,   /* map generation exhausted its retry bound (reference: RecursionError,
                               minigrid_env.py:342-343; roomgrid_level.py:131-134 retries instead)            */
   MG_ERR_NO_DEVICE = -5,   /* no usable HIP device                                                            */
-  MG_ERR_OOB = -6          /* front cell outside the grid (reference: AssertionError, core/grid.py:74-78)     */
+  MG_ERR_OOB = -6,         /* front cell outside the grid (reference: AssertionError, core/grid.py:74-78)     */
+  MG_ERR_TRACKED = -7      /* multi-room GoTo: more than four described objects were removed from the grid between two drop actions
+                              (the device keeps four stale tracked positions; reported, never silently dropped)              */
 } mg_status;
 
 /* Map generators = the reference's `_gen_grid` implementations on the path. */
@@ -83,6 +85,10 @@ typedef enum mg_env_kind {
   MG_ENV_OBSTRUCTEDMAZE = 31, /* envs/obstructedmaze.py:111-270, obstructedmaze_v1.py:37-100 (room_size 6; 1 x 2 or 3 x 3 rooms): num_crossings =
                                flags (1 key_in_box | 2 blocked | 4 the v1 class | 8 ObstructedMaze_1Dlhb), num_dists = num_quarters,
                                agent_start_x / agent_start_y = agent_room                                                             */
+  MG_ENV_BABYAI_GOTO = 33, MG_ENV_BABYAI_PICKUP = 34, MG_ENV_BABYAI_OPEN = 35,
+                            /* envs/babyai/goto.py:403-426 (GoTo, GoToOpen, GoToObjMaze*: num_crossings = doors_open), pickup.py:66-72,
+                               open.py:69-86: num_cols x num_rows rooms (2 x 2 / 3 x 3) of room_size 4..8, num_dists distractors over all
+                               rooms; mission ids as GoToObj / PickupDist / article * 6 + colour                                  */
   MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =
                                ((move colour * 3 + move type) * 6 + target colour) * 3 + target type                                  */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves

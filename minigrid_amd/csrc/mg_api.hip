@@ -58,7 +58,10 @@ struct mg_env {
   bool goto_kind = false;
   uint8_t* tilemap = nullptr; uint32_t* atlas = nullptr;   // RGB modes: k_step's output / the tile atlas (mg_tiles.h)
   uint8_t* st_grid = nullptr; int32_t* st_agent = nullptr;   // state-exchange staging (mg_get_state / mg_set_state), on first use
-  uint32_t* claim_bad() { return err + 1; }                // second word of the error buffer: mg_set_state's validation flag
+  uint32_t* claim_bad() { return err + 4; }                // last word of the error buffer: mg_set_state's validation flag
+  volatile uint32_t* err_host = nullptr;                   // the error words live in mapped pinned host memory: the kernels store into
+                                                           // them (only when something is wrong), the host reads them after a stream sync
+                                                           // without a device-to-host copy (a 4-byte copy costs ~10 us per mg_sync)
   RenderParams render;        // ... and k_render's launch geometry
   int render_lds = 0, render_blocks = 0, render_threads = 256;
   bool rgb = false;
@@ -300,12 +303,12 @@ static int launch_step(mg_env* e, StepParams& P) {
 
 static int check_device_errors(mg_env* e) {
   uint32_t bits = 0;
-  HIP_TRY(e, hipMemcpyAsync(&bits, e->err, sizeof bits, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 4; k++) if (e->err_host[k]) { bits |= 1u << k; e->err_host[k] = 0u; }
   if (!bits) return MG_OK;
-  HIP_TRY(e, hipMemsetAsync(e->err, 0, sizeof(uint32_t), e->stream));
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
   if (bits & ERR_OOB) return fail(e, MG_ERR_OOB, "front cell outside the grid (core/grid.py:74-78 assert)");
+  if (bits & ERR_TRACKED) return fail(e, MG_ERR_TRACKED, "GoToInstr: more than four stale tracked positions between two drop actions");
   return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound");
 }
 
@@ -403,7 +406,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_PUTNEAR) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BABYAI_OPEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_BABYAI_GOTO && cfg->env_kind <= MG_ENV_BABYAI_OPEN) {
+    const int st = cfg->room_size - 1;
+    if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || (cfg->width - 1) / st < 2 || (cfg->width - 1) / st > 3 ||
+        (cfg->height - 1) / st < 2 || (cfg->height - 1) / st > 3 || cfg->num_dists < 1 || cfg->num_dists > 21)
+      return fail(nullptr, MG_ERR_INVALID, "BabyAI maze levels: 2..3 x 2..3 rooms of room_size 4..8, 1..21 distractors");
+  }
   if (cfg->env_kind == MG_ENV_PUTNEAR && (cfg->width != cfg->height || cfg->width < 5 || cfg->width > 8 || cfg->num_dists < 2 || cfg->num_dists > 8))
     return fail(nullptr, MG_ERR_INVALID, "PutNear: size 5..8, numObjs 2..8");
   if (cfg->env_kind == MG_ENV_OBSTRUCTEDMAZE && (cfg->room_size != 6 || !((cfg->width == 11 && cfg->height == 6) || (cfg->width == 16 && cfg->height == 16)) ||
@@ -543,8 +552,11 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_GOTO_OBJ || cfg->env_kind == MG_ENV_GOTO_LOCAL) { e->rule = RULE_GOTO; e->rule_div = 2; }
   if (cfg->env_kind == MG_ENV_GOTOOBJECT) { e->rule = RULE_GOTOOBJ; e->rule_div = 2; }     // same mission id -> (colour, type) coding as GoToObj
+  if (cfg->env_kind == MG_ENV_BABYAI_GOTO) { e->rule = RULE_GOTO_BIG; e->rule_div = 2; }   // (colour, type) from the mission id, like GoToObj
+  if (cfg->env_kind == MG_ENV_BABYAI_PICKUP) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_BABYAI_OPEN) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
   if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
-  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR;
+  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG;
   if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||
       cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG) { e->rule = RULE_PICKUPDESC; e->rule_div = 2; }      // strict
@@ -562,7 +574,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
 
   // k_step compiles each level rule only into the variant of its rule group
   e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
-                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR) ? GG_ROOMGRID
+                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG) ? GG_ROOMGRID
                 : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
@@ -628,10 +640,15 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
   }
   if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
-  TRY_OR_FREE(dalloc(&e->err, 2));
+  {
+    void* h = nullptr;
+    TRY_OR_FREE(hipHostMalloc(&h, ERR_WORDS * sizeof(uint32_t), hipHostMallocMapped));
+    e->err_host = (volatile uint32_t*)h;
+    for (int k = 0; k < ERR_WORDS; k++) e->err_host[k] = 0u;
+    TRY_OR_FREE(hipHostGetDevicePointer((void**)&e->err, h, 0));
+  }
   e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
   TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
-  TRY_OR_FREE(hipMemsetAsync(e->err, 0, 2 * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, R * N * e->CS, e->stream));
@@ -674,9 +691,10 @@ int mg_destroy(mg_env* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
   void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
-                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->err, e->counters,
+                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->counters,
                    e->tilemap, e->atlas, e->st_grid, e->st_agent };
   for (void* b : bufs) if (b) (void)hipFree(b);
+  if (e->err_host) (void)hipHostFree((void*)e->err_host);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   for (int i = 0; i < QSETS; i++) {
@@ -867,20 +885,19 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
   const int tb = 256;
   HIP_TRY(e, hipMemcpyAsync(e->st_grid, grid, total * 3, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(e, hipMemcpyAsync(e->st_agent, agent, N * 8 * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(e, hipMemsetAsync(e->claim_bad(), 0, sizeof(uint32_t), e->stream));
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  e->err_host[4] = 0u;
   hipLaunchKernelGGL(k_state_decode, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, e->stream, e->st_grid, e->st_agent, e->grid, e->agent,
                      e->claim_bad(), e->N, e->W, e->H, e->CS);
   HIP_TRY(e, hipGetLastError());
   if (e->goto_kind || e->live_gen) {
     // GoToInstr's tracked positions / the obstacle list are re-found from the grid (not part of the exchanged state)
     hipLaunchKernelGGL(k_aux_rebuild, dim3((e->N + tb - 1) / tb), dim3(tb), 0, e->stream, e->grid, e->agent, e->aux, e->N, e->cells, e->CS,
-                       e->live_gen ? 2 : 1, e->rule_div, e->rule_cell);
+                       e->live_gen ? 2 : (e->rule == RULE_GOTO_BIG ? 3 : 1), e->rule_div, e->rule_cell);
     HIP_TRY(e, hipGetLastError());
   }
-  uint32_t bad = 0;
-  HIP_TRY(e, hipMemcpyAsync(&bad, e->claim_bad(), sizeof bad, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));
-  if (bad) return fail(e, MG_ERR_INVALID, "an agent record is out of range (position outside the grid, dir > 3, step_count or mission id too large)");
+  if (e->err_host[4]) return fail(e, MG_ERR_INVALID, "an agent record is out of range (position outside the grid, dir > 3, step_count or mission id too large)");
   return MG_OK;
 }
 

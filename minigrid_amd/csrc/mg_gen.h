@@ -1106,6 +1106,183 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 }
 
 
+// ---- the multi-room BabyAI levels with one instruction about one described object (first multi-room slice) ----
+// envs/babyai/goto.py:403-426 (GoTo, GoToOpen, GoToObjMaze*; P.num_crossings = doors_open), pickup.py:66-72 (Pickup), open.py:69-86
+// (Open) on RoomGrid._gen_grid / place_agent(random room) / connect_all / add_distractors(all_unique=False, random rooms) /
+// check_objs_reachable, inside RoomGridLevel's retry loop (roomgrid_level.py:119-144).  nc x nr rooms (2 x 2 or 3 x 3) of size
+// P.room_size on a grid of up to 22 x 22.  Mission ids: GoTo as GoToObj (article * 18 + colour * 3 + type); Pickup in the
+// "pick up" table (article * 28 + (colour + 1) * 4 + type + 1); Open = article * 6 + colour.
+//
+// check_objs_reachable (roomgrid_level.py:250-302) on a grid wider than one 64-bit board: lane y holds ROW y as bit masks
+// (passable = None or any door; objects = everything else but walls; reached).  One flood iteration = step one row up / down
+// (two lane shuffles) + an occluded fill along the row (Kogge-Stone, like vis_row), repeated until no row changes; an object
+// is reachable when it lies in or next to the reached set.
+MG_D bool maze_objs_reachable(GridRef& g, int ax, int ay) {
+  MG_WAVE_LDS_SYNC();
+  const int W = g.W, H = g.H;
+  uint32_t pass = 0, obj = 0;
+  if (g.lane < H)
+    for (int x = 0; x < W; x++) {
+      const uint32_t c = g.p[g.lane * W + x], t = cell_type(c);
+      const bool p = c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED;
+      pass |= (uint32_t)p << x;
+      obj |= (uint32_t)(!p && t != T_WALL) << x;
+    }
+  uint32_t R = g.lane == ay ? 1u << ax : 0u;
+  for (int it = 0; it < 1024; it++) {
+    uint32_t up = (uint32_t)__shfl_up((int)R, 1), dn = (uint32_t)__shfl_down((int)R, 1);
+    if (g.lane == 0) up = 0u;
+    if (g.lane == 63) dn = 0u;
+    const uint32_t seed = (R | up | dn) & pass;
+    uint32_t fr = seed, pr = pass, fl = seed, pl = pass;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) { fr |= pr & (fr << s); pr &= pr << s; fl |= pl & (fl >> s); pl &= pl >> s; }
+    const uint32_t Rn = R | fr | fl;
+    const bool changed = __ballot(Rn != R) != 0ull;
+    R = Rn;
+    if (!changed) break;
+  }
+  uint32_t up = (uint32_t)__shfl_up((int)R, 1), dn = (uint32_t)__shfl_down((int)R, 1);
+  if (g.lane == 0) up = 0u;
+  if (g.lane == 63) dn = 0u;
+  const uint32_t near = R | (R << 1) | (R >> 1) | up | dn;
+  return __ballot((obj & ~near) != 0u) == 0ull;
+}
+enum : int { KIND_BABYAI_GOTO = 33, KIND_BABYAI_PICKUP = 34, KIND_BABYAI_OPEN = 35 };
+MG_D uint32_t sorted_from_color(uint32_t c) {       // inverse of color_from_sorted: COLOR_TO_IDX -> position in the sorted COLOR_NAMES
+  const uint32_t packed = (4u << (4 * C_RED)) | (1u << (4 * C_GREEN)) | (0u << (4 * C_BLUE)) | (3u << (4 * C_PURPLE)) | (5u << (4 * C_YELLOW)) | (2u << (4 * C_GREY));
+  return (packed >> (4u * c)) & 15u;
+}
+template <class R>
+MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
+  const int nc = (W - 1) / st, nr = (H - 1) / st, nrooms = nc * nr;
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();                           // RecursionError / RejectSampling regenerate from the current stream position
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < H; y++)
+      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+    uint64_t right_y = 0, down_x = 0, doors = 0;     // nibble per room (r = j * nc + i): door offsets inside the room; bit 4r+k: room r has a door on side k
+#pragma unroll 1
+    for (int j = 0; j < nr; j++)
+#pragma unroll 1
+      for (int i = 0; i < nc; i++) {
+        const int r = j * nc + i, tx = i * st, ty = j * st;
+        if (i < nc - 1) right_y |= (uint64_t)(rand_int(rng, ty + 1, ty + rs - 1) - ty) << (4 * r);
+        if (j < nr - 1) down_x |= (uint64_t)(rand_int(rng, tx + 1, tx + rs - 1) - tx) << (4 * r);
+      }
+    // RoomGrid.place_agent(i=None, j=None) (roomgrid.py:313-334): a random room, then until the front cell is free
+    const int ai = rand_int(rng, 0, nc), aj = rand_int(rng, 0, nr);
+    if (!rg_place_agent(rng, g, ai * st, aj * st, rs, out)) continue;
+    const int ax = (int)out.ax, ay = (int)out.ay;
+    // connect_all (roomgrid.py:336-394)
+    const int start = (ay / st) * nc + ax / st;
+    bool fail = false;
+    auto door_xy = [&](int i, int j, int k, int& dx, int& dy) {      // Room.door_pos[k]: the left / up door is the neighbour's right / down door
+      const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * nc + ri;
+      const bool vertical_wall = k == 0 || k == 2;
+      dx = vertical_wall ? ri * st + st : ri * st + (int)((down_x >> (4 * rr)) & 15u);
+      dy = vertical_wall ? rj * st + (int)((right_y >> (4 * rr)) & 15u) : rj * st + st;
+    };
+    for (int itr = 0; !rng.dead(); itr++) {
+      if (itr > 5000) { fail = true; break; }
+      uint32_t reach = 1u << start;
+      for (;;) {
+        uint32_t next = reach;
+#pragma unroll 1
+        for (int r = 0; r < nrooms; r++)
+          if ((reach >> r) & 1u) {
+            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
+            if (d & 1u) next |= 1u << (r + 1);
+            if (d & 2u) next |= 1u << (r + nc);
+            if (d & 4u) next |= 1u << (r - 1);
+            if (d & 8u) next |= 1u << (r - nc);
+          }
+        if (next == reach) break;
+        reach = next;
+      }
+      if (reach == (1u << nrooms) - 1u) break;
+      const int i = rand_int(rng, 0, nc), j = rand_int(rng, 0, nr), k = rand_int(rng, 0, 4);
+      const bool has_nb = k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0;
+      const int r = j * nc + i;
+      if (!has_nb || ((doors >> (r * 4 + k)) & 1ull)) continue;
+      const uint32_t dc = (uint32_t)rand_int(rng, 0, 6);
+      int dx, dy;
+      door_xy(i, j, k, dx, dy);
+      g.set(dx, dy, make_cell(T_DOOR_CLOSED, color_from_sorted(dc)));
+      const int nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
+      doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
+    }
+    if (fail || rng.dead()) continue;
+    // add_distractors(num_distractors, all_unique=False) (roomgrid.py:396-438): colour, type, then a random room; reject_next_to
+    // sees the agent where it now stands
+    uint64_t ocol = 0, otyp = 0;                 // 3 / 2 bits per object
+    const int nd = min(P.num_dists, 21);
+    bool ok = true;
+    int x, y;
+#pragma unroll 1
+    for (int n = 0; n < nd && ok && !rng.dead(); n++) {
+      const uint32_t ci = (uint32_t)rand_int(rng, 0, 6), ti = (uint32_t)rand_int(rng, 0, 3);
+      const int ri = rand_int(rng, 0, nc), rj = rand_int(rng, 0, nr);
+      ok = place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), ri * st, rj * st, rs, rs, ax, ay, true, 1000, x, y);
+      ocol |= (uint64_t)ci << (3 * n); otyp |= (uint64_t)ti << (2 * n);
+    }
+    if (!ok || rng.dead()) continue;
+    if (!maze_objs_reachable(g, ax, ay)) continue;                   // RejectSampling
+    if (P.kind == KIND_BABYAI_OPEN) {
+      // Open.gen_mission (open.py:69-86): every room's doors in (column, row, right/down/left/up) order -- each door once per side --
+      // one of them picked; the description is its colour; "a" when another door has that colour
+      int cnt = 0;
+      for (int r = 0; r < nrooms; r++) cnt += __popc((uint32_t)(doors >> (4 * r)) & 15u);
+      const int pick = rand_int(rng, 0, cnt);
+      uint32_t pc = 0;
+      int seen = 0;
+#pragma unroll 1
+      for (int i = 0; i < nc; i++)
+#pragma unroll 1
+        for (int j = 0; j < nr; j++)
+#pragma unroll 1
+          for (int k = 0; k < 4; k++)
+            if ((doors >> ((j * nc + i) * 4 + k)) & 1ull) {
+              if (seen == pick) { int dx, dy; door_xy(i, j, k, dx, dy); pc = cell_color(g.get(dx, dy)); }
+              seen++;
+            }
+      MG_WAVE_LDS_SYNC();
+      uint32_t same = 0;
+      for (int base = 0; base < W * H; base += 64) {
+        const int q = base + g.lane;
+        const uint32_t c = q < W * H ? (uint32_t)g.p[q] : 0u;
+        same += (uint32_t)__popcll(__ballot(q < W * H && cell_ref_type(c) == T_DOOR && cell_type(c) != T_BOX_KEY && cell_color(c) == pc));
+      }
+      out.mission = (same > 1u ? 6u : 0u) + sorted_from_color(pc);
+      out.aux = ~0ull;
+      return;
+    }
+    const int k = rand_int(rng, 0, nd);
+    const uint32_t kc = (uint32_t)(ocol >> (3 * k)) & 7u, kt = (uint32_t)(otyp >> (2 * k)) & 3u;
+    uint32_t matches = 0;
+    for (int n = 0; n < nd; n++) matches += (((uint32_t)(ocol >> (3 * n)) & 7u) == kc && ((uint32_t)(otyp >> (2 * n)) & 3u) == kt) ? 1u : 0u;
+    if (P.kind == KIND_BABYAI_GOTO) {
+      out.mission = (matches > 1u ? 18u : 0u) + kc * 3u + kt;
+      if (P.num_crossings) {                                         // open_all_doors (roomgrid_level.py:238-248)
+        MG_WAVE_LDS_SYNC();
+        for (int base = 0; base < W * H; base += 64) {
+          const int q = base + g.lane;
+          if (q < W * H && cell_type(g.p[q]) == T_DOOR_CLOSED) g.p[q] = (uint8_t)make_cell(T_DOOR, cell_color(g.p[q]));
+        }
+        MG_WAVE_LDS_SYNC();
+      }
+    } else {
+      out.mission = (matches > 1u ? 28u : 0u) + (kc + 1u) * 4u + (kt + 1u);
+    }
+    out.aux = ~0ull;                            // GoToInstr on a large grid: no stale tracked position yet (see k_step, RULE_GOTO_BIG)
+    return;
+  }
+  out.failed = true;
+}
+
 // Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
@@ -1114,7 +1291,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 32) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 35) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -1158,6 +1335,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
       case 31: gen_obstructedmaze(rng, g, P, out); return;
       case 32: gen_putnear(rng, g, P, out); return;
+      case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
       default: break;
     }
   }

@@ -35,7 +35,7 @@ enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
               RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
-              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12 };
+              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13 };
 
 struct StepParams {
   // ---- state ----
@@ -234,7 +234,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     ag.flags = flags_out;
     A.dst_agent[se] = agent_pack(ag);
     if (A.dst_aux) A.dst_aux[se] = out.aux;
-    if (out.failed) atomicOr(A.err, (uint32_t)ERR_GENERATOR);
+    if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
     if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
     }
     const uint32_t h = uni32(A.head[e]) + A.ring_mask + 1u;    // every slot below head + R is free to fill
     uint32_t t = uni32(A.tail[e]);
-    if (h - t > A.ring_mask + 1u) { if (lane == 0) atomicOr(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
+    if (h - t > A.ring_mask + 1u) { if (lane == 0) report_errors(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
     while (t != h) {
       generate_one<GG_ALL, RNG>(A, rng, e, t & A.ring_mask, 0u, lane, lds);
       t++;
@@ -604,7 +604,7 @@ k_step(const StepParams P) {
   uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR);   // levels with an auxiliary word
+  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR || P.rule == RULE_GOTO_BIG);   // levels with an auxiliary word
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
@@ -777,6 +777,32 @@ k_step(const StepParams P) {
           const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
           if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
         }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO_BIG) {
+          // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
+          // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
+          // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
+          // or a box toggled away): at most one pickup plus the toggled boxes.  `targets` = S as four 16-bit cell indices
+          // (0xFFFF = free); a fifth is reported as ERR_TRACKED instead of being dropped silently.
+          const uint32_t desc = goto_desc(a.mission);
+          if (dirty_idx >= 0 && F == desc && newF != desc) {
+            int slot = -1;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) if (((targets >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
+            if (slot < 0) errbits |= ERR_TRACKED;
+            else targets = (targets & ~(0xFFFFull << (16 * slot))) | ((uint64_t)dirty_idx << (16 * slot));
+            aux_dirty = true;
+          }
+          if (act == A_DROP && targets != ~0ull) { targets = ~0ull; aux_dirty = true; }           // update_objs_poss
+          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
+            const int gi = gy * W + gx;
+            const uint32_t c = gi == dirty_idx ? dirty_code : (uint32_t)mygrid[gi];
+            bool hit = c == desc;
+#pragma unroll
+            for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
+            if (hit) { term = 1; success = true; }
+          }
+        }
         if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
           // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
           // stands next to target_pos (the one-bit board drawn at reset)
@@ -839,7 +865,8 @@ k_step(const StepParams P) {
         if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
           // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
           // and it is open after the toggle
-          if (inb && cell_type(newF) == T_DOOR) { term = 1; success = true; }
+          // (rule_div == 6: the description names a colour -- mission id % 6 -- and any door of that colour counts)
+          if (inb && cell_type(newF) == T_DOOR && (P.rule_div != 6 || cell_color(newF) == color_from_sorted(a.mission % 6u))) { term = 1; success = true; }
         }
         if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
           // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
@@ -966,7 +993,7 @@ k_step(const StepParams P) {
     if (rec_dirty) P.agent[e] = agent_pack(a);
     if (goto_rule && aux_dirty) P.aux[e] = targets;
     if (h != h_in) P.head[e] = h;
-    if (errbits) atomicOr(P.err, errbits);
+    if (errbits) report_errors(P.err, errbits);
   }
   {
     const unsigned long long wb = __ballot(active && lead && wb_all);      // envs whose whole live grid changed (new episode, fused launch)
@@ -1195,7 +1222,7 @@ __global__ void k_state_decode(const uint8_t* in_grid, const int32_t* in_agent, 
   grid[n * CS + (size_t)y * W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
   if (k == 0) {
     const int32_t* o = in_agent + n * 8;
-    if (o[0] < 0 || o[0] >= W || o[1] < 0 || o[1] >= H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u) { atomicOr(bad, 1u); return; }
+    if (o[0] < 0 || o[0] >= W || o[1] < 0 || o[1] >= H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u) { *bad = 1u; return; }
     Agent ag;
     ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];
     ag.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
@@ -1219,6 +1246,8 @@ __global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64
                         : rule_div == 1 ? make_cell(T_BALL, mis ? (uint32_t)C_BLUE : (uint32_t)C_RED)
                                         : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
     for (int c = 0; c < cells && c < 64; c++) if (g[c] == desc) w |= 1ull << c;
+  } else if (mode == 3) {
+    w = ~0ull;                                       // RULE_GOTO_BIG: no stale tracked position
   } else {
     int k = 0;
     for (int c = 0; c < cells && k < 8; c++) if (cell_type(g[c]) == T_BALL) w |= (uint64_t)c << (8 * k++);

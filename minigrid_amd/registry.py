@@ -19,6 +19,7 @@ ENV_GOTO_REDBALLGREY, ENV_GOTO_REDBLUEBALL, ENV_GOTO_OBJ, ENV_GOTO_LOCAL, ENV_GO
 ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
 ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE, ENV_PUTNEAR = 29, 30, 31, 32
+ENV_BABYAI_GOTO, ENV_BABYAI_PICKUP, ENV_BABYAI_OPEN = 33, 34, 35
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -268,6 +269,21 @@ _ROWS = [
                     for tc in _COLOR_NAMES for tt in ("key", "ball", "box")),
               num_dists=n, entry_point="minigrid.envs:PutNearEnv", kwargs={} if size == 6 else {"size": size, "numObjs": n})
       for name, size, n in (("MiniGrid-PutNear-6x6-N2-v0", 6, 2), ("MiniGrid-PutNear-8x8-N3-v0", 8, 3))],
+    # the multi-room BabyAI levels with one instruction: goto.py:403-426 (GoTo), pickup.py:66-72, open.py:69-86; max_steps =
+    # room_size**2 * rows * cols (roomgrid_level.py:71-85, one instruction); rows minigrid/__init__.py:681-731, 760-763, 848-851
+    *[EnvSpec(name, ENV_BABYAI_GOTO, cols * (rs - 1) + 1, rows * (rs - 1) + 1, rs * rs * rows * cols, False, _GOTO_OBJ_MISSIONS,
+              num_crossings=int(opened), num_dists=nd, room_size=rs, entry_point="minigrid.envs.babyai:GoTo", kwargs=kw)
+      for name, rs, rows, cols, nd, opened, kw in (
+          ("BabyAI-GoTo-v0", 8, 3, 3, 18, False, {}), ("BabyAI-GoToOpen-v0", 8, 3, 3, 18, True, {"doors_open": True}),
+          ("BabyAI-GoToObjMaze-v0", 8, 3, 3, 1, False, {"num_dists": 1, "doors_open": False}),
+          ("BabyAI-GoToObjMazeOpen-v0", 8, 3, 3, 1, True, {"num_dists": 1, "doors_open": True}),
+          ("BabyAI-GoToObjMazeS4R2-v0", 4, 2, 2, 1, False, {"num_dists": 1, "room_size": 4, "num_rows": 2, "num_cols": 2}),
+          *[(f"BabyAI-GoToObjMazeS{s_}-v0", s_, 3, 3, 1, False, {"num_dists": 1, "room_size": s_}) for s_ in (4, 5, 6, 7)])],
+    EnvSpec("BabyAI-Pickup-v0", ENV_BABYAI_PICKUP, 22, 22, 576, False, _PICKUP_MISSIONS, num_dists=18, room_size=8,
+            entry_point="minigrid.envs.babyai:Pickup", kwargs={}),
+    EnvSpec("BabyAI-Open-v0", ENV_BABYAI_OPEN, 22, 22, 576, False,
+            tuple(f"open {art} {c} door" for art in ("the", "a") for c in _COLOR_NAMES), num_dists=18, room_size=8,
+            entry_point="minigrid.envs.babyai:Open", kwargs={}),
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),
