@@ -1114,7 +1114,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 // "pick up" table (article * 28 + (colour + 1) * 4 + type + 1); Open = article * 6 + colour.
 //
 // check_objs_reachable (roomgrid_level.py:250-302) on a grid wider than one 64-bit board: lane y holds ROW y as bit masks
-// (passable = None or any door; objects = everything else but walls; reached).  One flood iteration = step one row up / down
+// (passable = None or any door; objects = every cell that is neither None nor a wall, doors included; reached).  One flood iteration = step one row up / down
 // (two lane shuffles) + an occluded fill along the row (Kogge-Stone, like vis_row), repeated until no row changes; an object
 // is reachable when it lies in or next to the reached set.
 MG_D bool maze_objs_reachable(GridRef& g, int ax, int ay) {
@@ -1126,7 +1126,7 @@ MG_D bool maze_objs_reachable(GridRef& g, int ax, int ay) {
       const uint32_t c = g.p[g.lane * W + x], t = cell_type(c);
       const bool p = c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED;
       pass |= (uint32_t)p << x;
-      obj |= (uint32_t)(!p && t != T_WALL) << x;
+      obj |= (uint32_t)(c != CELL_EMPTY && t != T_WALL) << x;      // doors have to be reached as well (roomgrid_level.py:292-300)
     }
   uint32_t R = g.lane == ay ? 1u << ax : 0u;
   for (int it = 0; it < 1024; it++) {
