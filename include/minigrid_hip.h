@@ -89,6 +89,15 @@ typedef enum mg_env_kind {
                             /* envs/babyai/goto.py:403-426 (GoTo, GoToOpen, GoToObjMaze*: num_crossings = doors_open), pickup.py:66-72,
                                open.py:69-86: num_cols x num_rows rooms (2 x 2 / 3 x 3) of room_size 4..8, num_dists distractors over all
                                rooms; mission ids as GoToObj / PickupDist / article * 6 + colour                                  */
+  MG_ENV_BABYAI_UNLOCKPICKUP = 36,        /* envs/babyai/unlock.py:307-319 (1 x 2 rooms; num_dists = 0 | 4 = UnlockPickupDist)               */
+  MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP = 37, /* unlock.py:380-393 (1 x 2 rooms)                                                             */
+  MG_ENV_UNLOCKTOUNLOCK = 38,             /* unlock.py:452-474 (1 x 3 rooms)                                                             */
+  MG_ENV_BABYAI_UNLOCK = 40,              /* unlock.py:67-112 (3 x 3 rooms, OpenInstr about a door colour; id = article * 6 + colour)    */
+  MG_ENV_BABYAI_GOTODOOR = 41,            /* goto.py:730-740 (GoToInstr about a door colour; id = article * 6 + colour)                  */
+  MG_ENV_GOTOOBJDOOR = 42,                /* goto.py:800-813 (id = article * 24 + colour * 4 + (key, ball, box, door))                   */
+  MG_ENV_UNBLOCKPICKUP = 43,              /* pickup.py:128-140 (20 distractors, rejected while every object is reachable)                */
+  MG_ENV_PICKUPABOVE = 44,                /* pickup.py:354-362                                                                           */
+  MG_ENV_GOTOIMPUNLOCK = 45,              /* goto.py:486-531 (ids as GoToObj).  36..45: RoomGrids of 1..3 x 1..3 rooms of room_size 4..8 */
   MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =
                                ((move colour * 3 + move type) * 6 + target colour) * 3 + target type                                  */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves

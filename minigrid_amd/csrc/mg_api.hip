@@ -406,7 +406,16 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_BABYAI_OPEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTOIMPUNLOCK || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_BABYAI_UNLOCKPICKUP && cfg->env_kind <= MG_ENV_GOTOIMPUNLOCK) {
+    const int st = cfg->room_size - 1, k = cfg->env_kind;
+    const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
+    const int want_c = (k == MG_ENV_BABYAI_UNLOCKPICKUP || k == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP) ? 2 : 3;
+    const int want_r = (k == MG_ENV_BABYAI_UNLOCKPICKUP || k == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP || k == MG_ENV_UNLOCKTOUNLOCK) ? 1 : 3;
+    if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || nc != want_c || nr != want_r ||
+        cfg->num_dists < 0 || cfg->num_dists > 8)
+      return fail(nullptr, MG_ERR_INVALID, "BabyAI unlock / goto-door / pickup levels: the class's room grid (1 x 2, 1 x 3 or 3 x 3 rooms) of room_size 4..8");
+  }
   if (cfg->env_kind >= MG_ENV_BABYAI_GOTO && cfg->env_kind <= MG_ENV_BABYAI_OPEN) {
     const int st = cfg->room_size - 1;
     if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || (cfg->width - 1) / st < 2 || (cfg->width - 1) / st > 3 ||
@@ -555,6 +564,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_BABYAI_GOTO) { e->rule = RULE_GOTO_BIG; e->rule_div = 2; }   // (colour, type) from the mission id, like GoToObj
   if (cfg->env_kind == MG_ENV_BABYAI_PICKUP) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BABYAI_OPEN) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
+  if (cfg->env_kind == MG_ENV_GOTOIMPUNLOCK) { e->rule = RULE_GOTO_BIG; e->rule_div = 2; }
+  if (cfg->env_kind == MG_ENV_BABYAI_GOTODOOR) { e->rule = RULE_GOTO_BIG; e->rule_div = 3; }      // a door by colour, in any state
+  if (cfg->env_kind == MG_ENV_GOTOOBJDOOR) { e->rule = RULE_GOTO_BIG; e->rule_div = 4; }          // (colour, key | ball | box | door)
+  if (cfg->env_kind == MG_ENV_BABYAI_UNLOCKPICKUP || cfg->env_kind == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP || cfg->env_kind == MG_ENV_UNLOCKTOUNLOCK ||
+      cfg->env_kind == MG_ENV_UNBLOCKPICKUP || cfg->env_kind == MG_ENV_PICKUPABOVE) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
+  if (cfg->env_kind == MG_ENV_BABYAI_UNLOCK) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
   if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
   e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG;
   if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||

@@ -1283,6 +1283,285 @@ MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out
   out.failed = true;
 }
 
+// ---- general RoomGrid helpers for the BabyAI levels below (core/roomgrid.py; the oracle's rg_* functions are the same restated in C) ----
+// nc x nr rooms of size rs; nibble r of right_off / down_off = offset of room r's right / down door position inside the room
+// (Room.door_pos, roomgrid.py:158-171), bit 4r+k of doors = room r has a door (or no wall) on side k = right, down, left, up;
+// bit r of locked = Room.locked.  (ax, ay) = env.agent_pos as reject_next_to sees it: the middle of the grid until place_agent.
+struct RG {
+  int rs, st, nc, nr, ax, ay;
+  uint64_t right_off, down_off, doors;
+  uint32_t locked;
+  bool ok;                                          // false after a RecursionError (place_obj ran out of tries): regenerate
+  MG_D int room(int i, int j) const { return j * nc + i; }
+  MG_D bool has_nb(int i, int j, int k) const { return k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0; }
+  MG_D void door_xy(int i, int j, int k, int& dx, int& dy) const {
+    const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * nc + ri;
+    const bool vertical_wall = k == 0 || k == 2;
+    dx = vertical_wall ? ri * st + st : ri * st + (int)((down_off >> (4 * rr)) & 15u);
+    dy = vertical_wall ? rj * st + (int)((right_off >> (4 * rr)) & 15u) : rj * st + st;
+  }
+  MG_D void mark(int i, int j, int k) {
+    const int r = room(i, j), nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
+    doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
+  }
+  // RoomGrid._gen_grid (roomgrid.py:123-179)
+  template <class R> MG_D void gen_grid(R& rng, GridRef& g, int room_size) {
+    rs = room_size; st = rs - 1; nc = (g.W - 1) / st; nr = (g.H - 1) / st;
+    right_off = 0; down_off = 0; doors = 0; locked = 0; ok = true;
+    MG_WAVE_LDS_SYNC();
+    for (int y = 0; y < g.H; y++)
+      if (g.lane < g.W) g.p[y * g.W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+    MG_WAVE_LDS_SYNC();
+#pragma unroll 1
+    for (int j = 0; j < nr; j++)
+#pragma unroll 1
+      for (int i = 0; i < nc; i++) {
+        const int r = room(i, j), tx = i * st, ty = j * st;
+        if (i < nc - 1) right_off |= (uint64_t)(rand_int(rng, ty + 1, ty + rs - 1) - ty) << (4 * r);
+        if (j < nr - 1) down_off |= (uint64_t)(rand_int(rng, tx + 1, tx + rs - 1) - tx) << (4 * r);
+      }
+    ax = (nc / 2) * st + rs / 2; ay = (nr / 2) * st + rs / 2;
+  }
+  // RoomGrid.add_door (roomgrid.py:230-277); k / ci / locked < 0 = draw it.  Returns the COLOR_NAMES index used.
+  template <class R> MG_D int add_door(R& rng, GridRef& g, int i, int j, int k, int ci, int lock, int& dx, int& dy) {
+    if (k < 0)
+      for (;;) { k = rand_int(rng, 0, 4); if (rng.dead() || (has_nb(i, j, k) && !((doors >> (room(i, j) * 4 + k)) & 1ull))) break; }
+    if (ci < 0) ci = rand_int(rng, 0, 6);                         // _rand_color()
+    if (lock < 0) lock = rand_int(rng, 0, 2) == 0;                // _rand_bool()
+    if (lock) locked |= 1u << room(i, j);
+    else locked &= ~(1u << room(i, j));                           // (add_door assigns room.locked = locked)
+    door_xy(i, j, k, dx, dy);
+    g.set(dx, dy, make_cell(lock ? (uint32_t)T_DOOR_LOCKED : (uint32_t)T_DOOR_CLOSED, color_from_sorted((uint32_t)ci)));
+    mark(i, j, k);
+    return ci;
+  }
+  // RoomGrid.add_object / place_in_room (roomgrid.py:181-228); ti / ci < 0 = draw (kind first, then colour)
+  template <class R> MG_D void add_object(R& rng, GridRef& g, int i, int j, int ti, int ci, int& ti_out, int& ci_out) {
+    if (ti < 0) ti = rand_int(rng, 0, 3);
+    if (ci < 0) ci = rand_int(rng, 0, 6);
+    int x, y;
+    if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + (uint32_t)ti, color_from_sorted((uint32_t)ci)), i * st, j * st, rs, rs, ax, ay, true, 1000, x, y)) ok = false;
+    ti_out = ti; ci_out = ci;
+  }
+  // RoomGrid.place_agent(i, j) (roomgrid.py:313-334)
+  template <class R> MG_D void place_agent_in(R& rng, GridRef& g, int i, int j, GenResult& out) {
+    if (!rg_place_agent(rng, g, i * st, j * st, rs, out)) { ok = false; return; }
+    ax = (int)out.ax; ay = (int)out.ay;
+  }
+  // RoomGrid.connect_all (roomgrid.py:336-394) with door_colors = COLOR_NAMES without index `exclude` (< 0: all six)
+  template <class R> MG_D void connect_all(R& rng, GridRef& g, int exclude) {
+    const int start = (ay / st) * nc + ax / st, nrooms = nc * nr;
+    for (int itr = 0; !rng.dead(); itr++) {
+      if (itr > 5000) { ok = false; return; }
+      uint32_t reach = 1u << start;
+      for (;;) {
+        uint32_t next = reach;
+#pragma unroll 1
+        for (int r = 0; r < nrooms; r++)
+          if ((reach >> r) & 1u) {
+            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
+            if (d & 1u) next |= 1u << (r + 1);
+            if (d & 2u) next |= 1u << (r + nc);
+            if (d & 4u) next |= 1u << (r - 1);
+            if (d & 8u) next |= 1u << (r - nc);
+          }
+        if (next == reach) break;
+        reach = next;
+      }
+      if (reach == (1u << nrooms) - 1u) return;
+      const int i = rand_int(rng, 0, nc), j = rand_int(rng, 0, nr), k = rand_int(rng, 0, 4);
+      if (!has_nb(i, j, k) || ((doors >> (room(i, j) * 4 + k)) & 1ull)) continue;
+      const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+      if (((locked >> room(i, j)) | (locked >> room(ni, nj))) & 1u) continue;
+      int ci = rand_int(rng, 0, exclude >= 0 ? 5 : 6), dx, dy;
+      if (exclude >= 0 && ci >= exclude) ci++;
+      const uint32_t keep = locked;                                // connect_all's add_door(..., locked=False) on an unlocked room
+      add_door(rng, g, i, j, k, ci, 0, dx, dy);
+      locked = keep;
+    }
+  }
+};
+// number of cells on the grid that hold a door of COLOR_TO_IDX colour c / exactly the cell code `code`
+MG_D uint32_t count_cells(GridRef& g, bool doors_of_color, uint32_t c) {
+  MG_WAVE_LDS_SYNC();
+  uint32_t n = 0;
+  for (int base = 0; base < g.W * g.H; base += 64) {
+    const int q = base + g.lane;
+    const uint32_t v = q < g.W * g.H ? (uint32_t)g.p[q] : 0u;
+    const bool hit = q < g.W * g.H && (doors_of_color ? (cell_ref_type(v) == T_DOOR && cell_color(v) == c) : v == c);
+    n += (uint32_t)__popcll(__ballot(hit));
+  }
+  return n;
+}
+
+enum : int { KIND_BABYAI_UNLOCKPICKUP = 36, KIND_BABYAI_BLOCKEDUNLOCKPICKUP = 37, KIND_UNLOCKTOUNLOCK = 38, KIND_BABYAI_UNLOCK = 40,
+             KIND_BABYAI_GOTODOOR = 41, KIND_GOTOOBJDOOR = 42, KIND_UNBLOCKPICKUP = 43, KIND_PICKUPABOVE = 44, KIND_GOTOIMPUNLOCK = 45 };
+// envs/babyai/unlock.py: UnlockPickup (:307-319; P.num_dists = 0 | 4 distractors = UnlockPickupDist), BlockedUnlockPickup (:380-393),
+// UnlockToUnlock (:452-474), Unlock (:67-112); goto.py: GoToDoor (:730-740), GoToObjDoor (:800-813), GoToImpUnlock (:486-531);
+// pickup.py: UnblockPickup (:128-140), PickupAbove (:354-362).  One PickupInstr / OpenInstr / GoToInstr about one description.
+// Mission ids: "pick up" table (article * 28 + (colour + 1) * 4 + type + 1); Unlock / GoToDoor article * 6 + colour;
+// GoToObjDoor article * 24 + colour * 4 + (key, ball, box, door); GoToImpUnlock as GoToObj.
+template <class R>
+MG_D void gen_babyai_levels(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    RG rg;
+    rg.gen_grid(rng, g, P.room_size);
+    int dx, dy, ti, ci;
+    out.aux = ~0ull;
+    if (P.kind == KIND_BABYAI_UNLOCKPICKUP) {
+      int oc, dc;
+      rg.add_object(rng, g, 1, 0, 2, -1, ti, oc);                             // the box
+      dc = rg.add_door(rng, g, 0, 0, 0, -1, 1, dx, dy);
+      rg.add_object(rng, g, 0, 0, 0, dc, ti, ci);                             // its key
+      uint32_t used = (1u << (oc * 3 + 2)) | (1u << (dc * 3 + 0));           // add_distractors(num_distractors, all_unique): random rooms
+      for (int n = 0; n < P.num_dists && rg.ok && !rng.dead();) {
+        const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+        if ((used >> (c2 * 3 + t2)) & 1u) continue;
+        const int ri = rand_int(rng, 0, rg.nc), rj = rand_int(rng, 0, rg.nr);
+        rg.add_object(rng, g, ri, rj, t2, c2, ti, ci);
+        used |= 1u << (c2 * 3 + t2); n++;
+      }
+      if (!rg.ok || rng.dead()) continue;
+      rg.place_agent_in(rng, g, 0, 0, out);
+      if (!rg.ok || rng.dead()) continue;
+      out.mission = (uint32_t)(oc + 1) * 4u + 3u;                             // "pick up the {colour} box"
+      return;
+    }
+    if (P.kind == KIND_BABYAI_BLOCKEDUNLOCKPICKUP) {
+      int oc;
+      rg.add_object(rng, g, 1, 0, 2, -1, ti, oc);
+      const int dc = rg.add_door(rng, g, 0, 0, 0, -1, 1, dx, dy);
+      const int bc = rand_int(rng, 0, 6);
+      g.set(dx - 1, dy, make_cell(T_BALL, color_from_sorted((uint32_t)bc)));
+      rg.add_object(rng, g, 0, 0, 0, dc, ti, ci);
+      rg.place_agent_in(rng, g, 0, 0, out);
+      if (!rg.ok || rng.dead()) continue;
+      out.mission = 3u;                                                       // "pick up the box"
+      return;
+    }
+    if (P.kind == KIND_UNLOCKTOUNLOCK) {
+      uint32_t avail = 0x543210u;                                             // _rand_subset(COLOR_NAMES, 2)
+      int colors[2];
+      for (int n = 0, na = 6; n < 2; n++, na--) {
+        const int k = rand_int(rng, 0, na);
+        colors[n] = (int)((avail >> (4 * k)) & 15u);
+        const uint32_t lowmask = (1u << (4 * k)) - 1u;
+        avail = (avail & lowmask) | ((avail >> 4) & ~lowmask);
+      }
+      rg.add_door(rng, g, 0, 0, 0, colors[0], 1, dx, dy);
+      rg.add_object(rng, g, 2, 0, 0, colors[0], ti, ci);
+      rg.add_door(rng, g, 1, 0, 0, colors[1], 1, dx, dy);
+      rg.add_object(rng, g, 1, 0, 0, colors[1], ti, ci);
+      rg.add_object(rng, g, 0, 0, 1, -1, ti, ci);
+      rg.place_agent_in(rng, g, 1, 0, out);
+      if (!rg.ok || rng.dead()) continue;
+      out.mission = 2u;                                                       // "pick up the ball"
+      return;
+    }
+    if (P.kind == KIND_BABYAI_GOTODOOR || P.kind == KIND_GOTOOBJDOOR) {
+      uint64_t ocol = 0, otyp = 0;                                            // 3 / 2 bits per entry; type index 3 = door
+      int n = 0;
+      if (P.kind == KIND_GOTOOBJDOOR) {
+        rg.place_agent_in(rng, g, 1, 1, out);
+        for (; n < 8 && rg.ok && !rng.dead(); n++) {                          // add_distractors(1, 1, 8, all_unique=False)
+          const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+          rg.add_object(rng, g, 1, 1, t2, c2, ti, ci);
+          ocol |= (uint64_t)c2 << (3 * n); otyp |= (uint64_t)t2 << (2 * n);
+        }
+        if (!rg.ok || rng.dead()) continue;
+      }
+      for (int d = 0; d < 4 && !rng.dead(); d++) {
+        const int c2 = rg.add_door(rng, g, 1, 1, -1, -1, -1, dx, dy);
+        ocol |= (uint64_t)c2 << (3 * n); otyp |= 3ull << (2 * n); n++;
+      }
+      if (P.kind == KIND_BABYAI_GOTODOOR) rg.place_agent_in(rng, g, 1, 1, out);
+      if (!rg.ok || rng.dead()) continue;
+      if (P.kind == KIND_GOTOOBJDOOR && !maze_objs_reachable(g, rg.ax, rg.ay)) continue;
+      const int k = rand_int(rng, 0, n);
+      const uint32_t kc = (uint32_t)(ocol >> (3 * k)) & 7u, kt = (uint32_t)(otyp >> (2 * k)) & 3u;
+      const uint32_t nposs = kt == 3u ? count_cells(g, true, color_from_sorted(kc)) : count_cells(g, false, make_cell((uint32_t)T_KEY + kt, color_from_sorted(kc)));
+      out.mission = P.kind == KIND_BABYAI_GOTODOOR ? (nposs > 1u ? 6u : 0u) + kc : (nposs > 1u ? 24u : 0u) + kc * 4u + kt;
+      return;
+    }
+    if (P.kind == KIND_UNBLOCKPICKUP) {
+      const int ai = rand_int(rng, 0, rg.nc), aj = rand_int(rng, 0, rg.nr);
+      rg.place_agent_in(rng, g, ai, aj, out);
+      if (!rg.ok || rng.dead()) continue;
+      rg.connect_all(rng, g, -1);
+      if (!rg.ok || rng.dead()) continue;
+      uint64_t ocol = 0, otyp = 0;
+      for (int n = 0; n < 20 && rg.ok && !rng.dead(); n++) {                  // add_distractors(num_distractors=20, all_unique=False)
+        const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+        const int ri = rand_int(rng, 0, rg.nc), rj = rand_int(rng, 0, rg.nr);
+        rg.add_object(rng, g, ri, rj, t2, c2, ti, ci);
+        ocol |= (uint64_t)c2 << (3 * n); otyp |= (uint64_t)t2 << (2 * n);
+      }
+      if (!rg.ok || rng.dead()) continue;
+      if (maze_objs_reachable(g, rg.ax, rg.ay)) continue;                     // RejectSampling("all objects reachable")
+      const int k = rand_int(rng, 0, 20);
+      const uint32_t kc = (uint32_t)(ocol >> (3 * k)) & 7u, kt = (uint32_t)(otyp >> (2 * k)) & 3u;
+      uint32_t matches = 0;
+      for (int d = 0; d < 20; d++) matches += (((uint32_t)(ocol >> (3 * d)) & 7u) == kc && ((uint32_t)(otyp >> (2 * d)) & 3u) == kt) ? 1u : 0u;
+      out.mission = (matches > 1u ? 28u : 0u) + (kc + 1u) * 4u + (kt + 1u);
+      return;
+    }
+    if (P.kind == KIND_PICKUPABOVE) {
+      int ot, oc;
+      rg.add_object(rng, g, 1, 0, -1, -1, ot, oc);
+      rg.add_door(rng, g, 1, 1, 3, -1, 0, dx, dy);
+      rg.place_agent_in(rng, g, 1, 1, out);
+      if (!rg.ok || rng.dead()) continue;
+      rg.connect_all(rng, g, -1);
+      if (!rg.ok || rng.dead()) continue;
+      out.mission = (uint32_t)(oc + 1) * 4u + (uint32_t)(ot + 1);
+      return;
+    }
+    // Unlock (unlock.py:67-112) and GoToImpUnlock (goto.py:486-531): a locked room, its key anywhere (the reference compares numpy
+    // integers by identity -- `ik is id` --, which is never true: the key may land in the locked room itself, and distractors go
+    // into every room), distractors in every room, the agent outside the locked room
+    const int id = rand_int(rng, 0, rg.nc), jd = rand_int(rng, 0, rg.nr);
+    const int dc = rg.add_door(rng, g, id, jd, -1, -1, 1, dx, dy);
+    { const int ik = rand_int(rng, 0, rg.nc), jk = rand_int(rng, 0, rg.nr); rg.add_object(rng, g, ik, jk, 0, dc, ti, ci); }
+    if (!rg.ok || rng.dead()) continue;
+    if (P.kind == KIND_BABYAI_UNLOCK) { if (rand_int(rng, 0, 2) == 0) rg.connect_all(rng, g, dc); else rg.connect_all(rng, g, -1); }      // _rand_bool()
+    else rg.connect_all(rng, g, -1);
+    if (!rg.ok || rng.dead()) continue;
+    const int per_room = P.kind == KIND_BABYAI_UNLOCK ? 3 : 2;
+#pragma unroll 1
+    for (int i = 0; i < rg.nc && rg.ok && !rng.dead(); i++)
+#pragma unroll 1
+      for (int j = 0; j < rg.nr && rg.ok && !rng.dead(); j++)
+        for (int n = 0; n < per_room && rg.ok && !rng.dead(); n++) {          // add_distractors(i, j, per_room, all_unique=False)
+          const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+          rg.add_object(rng, g, i, j, t2, c2, ti, ci);
+        }
+    if (!rg.ok || rng.dead()) continue;
+    for (;;) {                                                                // place_agent() until it is not in the locked room
+      const int ai = rand_int(rng, 0, rg.nc), aj = rand_int(rng, 0, rg.nr);
+      rg.place_agent_in(rng, g, ai, aj, out);
+      if (!rg.ok || rng.dead()) break;
+      if (rg.ax / rg.st == id && rg.ay / rg.st == jd) continue;
+      break;
+    }
+    if (!rg.ok || rng.dead()) continue;
+    if (!maze_objs_reachable(g, rg.ax, rg.ay)) continue;
+    if (P.kind == KIND_BABYAI_UNLOCK) {
+      const uint32_t count = count_cells(g, true, color_from_sorted((uint32_t)dc));
+      out.mission = (count > 1u ? 6u : 0u) + (uint32_t)dc;
+      return;
+    }
+    const int c3 = rand_int(rng, 0, 6), t3 = rand_int(rng, 0, 3);             // GoToImpUnlock: the target goes into the locked room
+    rg.add_object(rng, g, id, jd, t3, c3, ti, ci);
+    if (!rg.ok || rng.dead()) continue;
+    const uint32_t nposs = count_cells(g, false, make_cell((uint32_t)T_KEY + (uint32_t)t3, color_from_sorted((uint32_t)c3)));
+    out.mission = (nposs > 1u ? 18u : 0u) + (uint32_t)c3 * 3u + (uint32_t)t3;
+    return;
+  }
+  out.failed = true;
+}
+
 // Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
@@ -1291,7 +1570,7 @@ MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 35) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 45) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -1336,6 +1615,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 31: gen_obstructedmaze(rng, g, P, out); return;
       case 32: gen_putnear(rng, g, P, out); return;
       case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
+      case 36: case 37: case 38: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
       default: break;
     }
   }

@@ -657,11 +657,18 @@ k_step(const StepParams P) {
   // refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
   // differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
   auto goto_desc = [&](uint32_t mission) -> uint32_t {
-    // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id
-    const uint32_t m18 = mission % 18u;
+    // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
+    // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
+    // is returned as the OPEN door's code and matches the door in any state (desc_match).
+    const uint32_t m18 = mission % 18u, m24 = mission % 24u;
     return P.rule_div == 0 ? (uint32_t)P.rule_cell
          : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-                           : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
+         : P.rule_div == 2 ? make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u))
+         : P.rule_div == 3 ? make_cell(T_DOOR, color_from_sorted(mission % 6u))
+                           : make_cell((m24 & 3u) == 3u ? (uint32_t)T_DOOR : (uint32_t)T_KEY + (m24 & 3u), color_from_sorted(m24 >> 2));
+  };
+  auto desc_match = [&](uint32_t c, uint32_t desc) -> bool {
+    return c == desc || (cell_type(desc) == T_DOOR && cell_ref_type(c) == T_DOOR && cell_color(c) == cell_color(desc));
   };
   uint64_t cur = targets;
   if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
@@ -784,7 +791,7 @@ k_step(const StepParams P) {
           // or a box toggled away): at most one pickup plus the toggled boxes.  `targets` = S as four 16-bit cell indices
           // (0xFFFF = free); a fifth is reported as ERR_TRACKED instead of being dropped silently.
           const uint32_t desc = goto_desc(a.mission);
-          if (dirty_idx >= 0 && F == desc && newF != desc) {
+          if (dirty_idx >= 0 && desc_match(F, desc) && !desc_match(newF, desc)) {
             int slot = -1;
 #pragma unroll
             for (int k = 3; k >= 0; k--) if (((targets >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
@@ -797,7 +804,7 @@ k_step(const StepParams P) {
           if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
             const int gi = gy * W + gx;
             const uint32_t c = gi == dirty_idx ? dirty_code : (uint32_t)mygrid[gi];
-            bool hit = c == desc;
+            bool hit = desc_match(c, desc);
 #pragma unroll
             for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
             if (hit) { term = 1; success = true; }

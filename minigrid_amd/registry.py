@@ -20,6 +20,8 @@ ENV_LOCKEDROOM, ENV_PLAYGROUND, ENV_MULTIROOM = 21, 22, 23
 ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ = 24, 25, 26, 27, 28
 ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE, ENV_PUTNEAR = 29, 30, 31, 32
 ENV_BABYAI_GOTO, ENV_BABYAI_PICKUP, ENV_BABYAI_OPEN = 33, 34, 35
+ENV_BABYAI_UNLOCKPICKUP, ENV_BABYAI_BLOCKEDUNLOCKPICKUP, ENV_UNLOCKTOUNLOCK, ENV_BABYAI_UNLOCK = 36, 37, 38, 40
+ENV_BABYAI_GOTODOOR, ENV_GOTOOBJDOOR, ENV_UNBLOCKPICKUP, ENV_PICKUPABOVE, ENV_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -284,6 +286,25 @@ _ROWS = [
     EnvSpec("BabyAI-Open-v0", ENV_BABYAI_OPEN, 22, 22, 576, False,
             tuple(f"open {art} {c} door" for art in ("the", "a") for c in _COLOR_NAMES), num_dists=18, room_size=8,
             entry_point="minigrid.envs.babyai:Open", kwargs={}),
+    # envs/babyai/unlock.py (UnlockPickup(-Dist) :307-319, BlockedUnlockPickup :380-393, UnlockToUnlock :452-474, Unlock :67-112),
+    # goto.py (GoToDoor :730-740, GoToObjDoor :800-813, GoToImpUnlock :486-531), pickup.py (UnblockPickup :128-140, PickupAbove
+    # :354-362); rows minigrid/__init__.py.  max_steps: the class's own value, or room_size**2 * rooms for one instruction
+    *[EnvSpec(name, kind, cols * (rs - 1) + 1, rows * (rs - 1) + 1, ms, False, missions, num_dists=nd, room_size=rs,
+              entry_point="minigrid.envs.babyai:" + cls, kwargs=kw)
+      for name, kind, cls, rs, rows, cols, ms, nd, missions, kw in (
+          ("BabyAI-UnlockPickup-v0", ENV_BABYAI_UNLOCKPICKUP, "UnlockPickup", 6, 1, 2, 72, 0, _PICKUP_MISSIONS, {}),
+          ("BabyAI-UnlockPickupDist-v0", ENV_BABYAI_UNLOCKPICKUP, "UnlockPickup", 6, 1, 2, 72, 4, _PICKUP_MISSIONS, {"distractors": True}),
+          ("BabyAI-BlockedUnlockPickup-v0", ENV_BABYAI_BLOCKEDUNLOCKPICKUP, "BlockedUnlockPickup", 6, 1, 2, 576, 0, _PICKUP_MISSIONS, {}),
+          ("BabyAI-UnlockToUnlock-v0", ENV_UNLOCKTOUNLOCK, "UnlockToUnlock", 6, 1, 3, 1080, 0, _PICKUP_MISSIONS, {}),
+          ("BabyAI-Unlock-v0", ENV_BABYAI_UNLOCK, "Unlock", 8, 3, 3, 576, 0,
+           tuple(f"open {art} {c} door" for art in ("the", "a") for c in _COLOR_NAMES), {}),
+          ("BabyAI-GoToDoor-v0", ENV_BABYAI_GOTODOOR, "GoToDoor", 7, 3, 3, 441, 0,
+           tuple(f"go to {art} {c} door" for art in ("the", "a") for c in _COLOR_NAMES), {}),
+          ("BabyAI-GoToObjDoor-v0", ENV_GOTOOBJDOOR, "GoToObjDoor", 8, 3, 3, 576, 0,
+           tuple(f"go to {art} {c} {t}" for art in ("the", "a") for c in _COLOR_NAMES for t in ("key", "ball", "box", "door")), {}),
+          ("BabyAI-GoToImpUnlock-v0", ENV_GOTOIMPUNLOCK, "GoToImpUnlock", 8, 3, 3, 576, 0, _GOTO_OBJ_MISSIONS, {}),
+          ("BabyAI-UnblockPickup-v0", ENV_UNBLOCKPICKUP, "UnblockPickup", 8, 3, 3, 576, 0, _PICKUP_MISSIONS, {}),
+          ("BabyAI-PickupAbove-v0", ENV_PICKUPABOVE, "PickupAbove", 6, 3, 3, 288, 0, _PICKUP_MISSIONS, {}))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),
