@@ -98,6 +98,11 @@ typedef enum mg_env_kind {
   MG_ENV_UNBLOCKPICKUP = 43,              /* pickup.py:128-140 (20 distractors, rejected while every object is reachable)                */
   MG_ENV_PICKUPABOVE = 44,                /* pickup.py:354-362                                                                           */
   MG_ENV_GOTOIMPUNLOCK = 45,              /* goto.py:486-531 (ids as GoToObj).  36..45: RoomGrids of 1..3 x 1..3 rooms of room_size 4..8 */
+  MG_ENV_PUTNEXTLOCAL = 46,               /* envs/babyai/putnext.py:72-80 (one room, num_dists objects; 324 mission ids)                 */
+  MG_ENV_PUTNEXT = 47,                    /* putnext.py:168-214 (1 x 2 rooms, num_dists objects per room; num_crossings = start_carrying) */
+  MG_ENV_ACTIONOBJDOOR = 48,              /* other.py:86-106 (id = verb * 48 + article * 24 + colour * 4 + (key, ball, box, door))        */
+  MG_ENV_OPENDOOR = 49,                   /* open.py:209-229 (num_crossings = select_by: 0 random | 1 colour | 2 location; strip2_row = strict;
+                                             id = colour, or 6 + article * 4 + (left, right, front, behind))                            */
   MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =
                                ((move colour * 3 + move type) * 6 + target colour) * 3 + target type                                  */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves

@@ -406,7 +406,17 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_GOTOIMPUNLOCK || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_OPENDOOR || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_PUTNEXTLOCAL && cfg->env_kind <= MG_ENV_OPENDOOR) {
+    const int st = cfg->room_size - 1, k = cfg->env_kind;
+    const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
+    const int want_c = k == MG_ENV_PUTNEXTLOCAL ? 1 : k == MG_ENV_PUTNEXT ? 2 : 3, want_r = (k == MG_ENV_PUTNEXTLOCAL || k == MG_ENV_PUTNEXT) ? 1 : 3;
+    if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || nc != want_c || nr != want_r)
+      return fail(nullptr, MG_ERR_INVALID, "PutNextLocal (1 room), PutNext (1 x 2 rooms), ActionObjDoor / OpenDoor (3 x 3 rooms): room_size 4..8");
+    if ((k == MG_ENV_PUTNEXTLOCAL && (cfg->num_dists < 2 || cfg->num_dists > 8)) || (k == MG_ENV_PUTNEXT && (cfg->num_dists < 1 || cfg->num_dists > 4)))
+      return fail(nullptr, MG_ERR_INVALID, "PutNextLocal: 2..8 objects; PutNext: 1..4 objects per room");
+    if ((unsigned)cfg->num_crossings > 2u) return fail(nullptr, MG_ERR_INVALID, "num_crossings: PutNext start_carrying 0 | 1, OpenDoor select_by 0 | 1 | 2");
+  }
   if (cfg->env_kind >= MG_ENV_BABYAI_UNLOCKPICKUP && cfg->env_kind <= MG_ENV_GOTOIMPUNLOCK) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;
     const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
@@ -571,7 +581,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       cfg->env_kind == MG_ENV_UNBLOCKPICKUP || cfg->env_kind == MG_ENV_PICKUPABOVE) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BABYAI_UNLOCK) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
   if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
-  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG;
+  if (cfg->env_kind == MG_ENV_PUTNEXTLOCAL || cfg->env_kind == MG_ENV_PUTNEXT) e->rule = RULE_PUTNEXT;
+  if (cfg->env_kind == MG_ENV_ACTIONOBJDOOR) { e->rule = RULE_GOTO_BIG; e->rule_div = 5; }        // verb = mission id / 48: go to | pick up | open
+  if (cfg->env_kind == MG_ENV_OPENDOOR) { e->rule = RULE_OPENDOOR; e->rule_div = cfg->strip2_row ? 1 : 0; }   // strip2_row = strict (OpenDoorDebug)
+  e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR;
   if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||
       cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG) { e->rule = RULE_PICKUPDESC; e->rule_div = 2; }      // strict
@@ -589,7 +602,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
 
   // k_step compiles each level rule only into the variant of its rule group
   e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
-                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG) ? GG_ROOMGRID
+                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR) ? GG_ROOMGRID
                 : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
@@ -908,7 +921,7 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
   if (e->goto_kind || e->live_gen) {
     // GoToInstr's tracked positions / the obstacle list are re-found from the grid (not part of the exchanged state)
     hipLaunchKernelGGL(k_aux_rebuild, dim3((e->N + tb - 1) / tb), dim3(tb), 0, e->stream, e->grid, e->agent, e->aux, e->N, e->cells, e->CS,
-                       e->live_gen ? 2 : (e->rule == RULE_GOTO_BIG ? 3 : 1), e->rule_div, e->rule_cell);
+                       e->live_gen ? 2 : ((e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT) ? 3 : e->rule == RULE_OPENDOOR ? 4 : 1), e->rule_div, e->rule_cell);
     HIP_TRY(e, hipGetLastError());
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));

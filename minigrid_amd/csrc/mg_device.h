@@ -145,6 +145,7 @@ constexpr uint32_t FLAG_RESET_PENDING = 1u;   // previous step ended the episode
 constexpr uint32_t FLAG_FRESH = 2u;           // regenerated just before this launch: observe, do not step
 constexpr uint32_t FLAG_NOT_CLEAR = 4u;       // DynamicObstacles: the front cell was occupied before the obstacles moved
 constexpr uint32_t FLAG_TARGETS_STALE = 8u;   // BabyAI GoTo levels: a described object moved since GoToInstr's positions were refreshed
+constexpr uint32_t FLAG_SHOW_TAKEN = 16u;     // PutNext(start_carrying): the episode's first observation shows the carried object where it was taken from
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };

@@ -24,6 +24,7 @@ struct GenResult {
   uint32_t ax, ay, dir, mission;
   uint64_t aux;       // per-env auxiliary word: DynamicObstacles: byte i = cell index (y*W+x) of obstacle i, in list
                       // order; BabyAI GoTo levels: bitboard (bit y*W+x) of GoToInstr's tracked object positions
+  uint32_t carry;     // cell code the agent starts with in its hands (PutNext start_carrying), 0 = nothing
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
   uint32_t resume;    // set by generate_one: this pass restarts from the generator's last checkpoint (state in the wave's scratch words)
@@ -1562,6 +1563,122 @@ MG_D void gen_babyai_levels(R& rng, GridRef& g, const GenParams& P, GenResult& o
   out.failed = true;
 }
 
+enum : int { KIND_PUTNEXTLOCAL = 46, KIND_PUTNEXT = 47, KIND_ACTIONOBJDOOR = 48, KIND_OPENDOOR = 49 };
+// envs/babyai/putnext.py: PutNextLocal (:72-80), PutNext (:168-214; P.num_crossings = start_carrying); other.py:86-106 ActionObjDoor;
+// open.py:209-229 OpenDoor (P.num_crossings = select_by: 0 random, 1 colour, 2 location; the strict / debug variant differs in the
+// step rule only).  Mission ids: PutNext (move colour * 3 + move type) * 18 + fixed colour * 3 + fixed type; ActionObjDoor
+// verb * 48 + article * 24 + colour * 4 + (key, ball, box, door), verb = go to | pick up | open; OpenDoor colour (0..5) or
+// 6 + article * 4 + (left, right, front, behind).  out.aux: PutNext = the cell the carried object came from (start_carrying);
+// ActionObjDoor = no stale tracked position (RULE_GOTO_BIG); OpenDoor = COLOR_TO_IDX bit mask of the described doors.
+template <class R>
+MG_D void gen_babyai_put_open(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    RG rg;
+    rg.gen_grid(rng, g, P.room_size);
+    int dx, dy, ti, ci;
+    out.aux = ~0ull; out.carry = 0;
+    if (P.kind == KIND_PUTNEXTLOCAL || P.kind == KIND_PUTNEXT) {
+      const int per = P.num_dists, rooms = P.kind == KIND_PUTNEXT ? 2 : 1;
+      rg.place_agent_in(rng, g, 0, 0, out);                   // place_agent() of a 1 x 1 room grid draws no room index either
+      uint64_t opos = 0;                                      // byte n = x | y << 4 of object n
+      uint64_t okind = 0; uint32_t used = 0;                  // byte n = colour * 3 + type of object n; bit per used (colour, type)
+      int n = 0;
+      for (int room = 0; room < rooms && rg.ok && !rng.dead(); room++)
+        for (int k = 0; k < per && rg.ok && !rng.dead();) {   // add_distractors(room, 0, per): unique over every room's objects
+          const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+          if ((used >> (c2 * 3 + t2)) & 1u) continue;
+          int x, y;
+          if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + (uint32_t)t2, color_from_sorted((uint32_t)c2)), room * rg.st, 0, rg.rs, rg.rs, rg.ax, rg.ay, true, 1000, x, y)) { rg.ok = false; break; }
+          used |= 1u << (c2 * 3 + t2);
+          if (n < 8) { opos |= (uint64_t)(x | (y << 4)) << (8 * n); okind |= (uint64_t)(c2 * 3 + t2) << (8 * n); }
+          n++; k++;
+        }
+      if (!rg.ok || rng.dead()) continue;
+      int a, b;
+      if (P.kind == KIND_PUTNEXTLOCAL) {
+        if (!maze_objs_reachable(g, rg.ax, rg.ay)) continue;
+        a = rand_int(rng, 0, n);                              // _rand_subset(objs, 2)
+        b = rand_int(rng, 0, n - 1); if (b >= a) b++;
+      } else {
+        MG_WAVE_LDS_SYNC();                                   // remove_wall(0, 0, 0) (roomgrid.py:279-311)
+        if (g.lane >= 1 && g.lane < rg.rs - 1) g.p[g.lane * g.W + rg.st] = (uint8_t)CELL_EMPTY;
+        MG_WAVE_LDS_SYNC();
+        a = rand_int(rng, 0, per);
+        b = per + rand_int(rng, 0, per);
+        if (rand_int(rng, 0, 2) == 0) { const int t = a; a = b; b = t; }
+      }
+      if (rng.dead()) continue;
+      const int pa = (int)(opos >> (8 * a)) & 255, pb = (int)(opos >> (8 * b)) & 255;
+      if (abs((pa & 15) - (pb & 15)) + abs((pa >> 4) - (pb >> 4)) == 1) continue;      // validate_instrs: "objs already next to each other"
+      out.mission = ((uint32_t)(okind >> (8 * a)) & 31u) * 18u + ((uint32_t)(okind >> (8 * b)) & 31u);
+      if (P.kind == KIND_PUTNEXT && P.num_crossings) {        // PutNext.reset (:205-214): the object to move starts in the agent's hands;
+        out.carry = g.get(pa & 15, pa >> 4);                  // the reset observation still shows it on the grid (FLAG_SHOW_TAKEN)
+        g.set(pa & 15, pa >> 4, CELL_EMPTY);
+        out.aux = (uint64_t)((pa >> 4) * g.W + (pa & 15));
+      }
+      return;
+    }
+    if (P.kind == KIND_ACTIONOBJDOOR) {
+      uint64_t ocol = 0, otyp = 0;
+      uint32_t used = 0;
+      int n = 0;
+      while (n < 5 && rg.ok && !rng.dead()) {                 // add_distractors(1, 1, 5): unique
+        const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+        if ((used >> (c2 * 3 + t2)) & 1u) continue;
+        rg.add_object(rng, g, 1, 1, t2, c2, ti, ci);
+        used |= 1u << (c2 * 3 + t2);
+        ocol |= (uint64_t)c2 << (3 * n); otyp |= (uint64_t)t2 << (2 * n); n++;
+      }
+      if (!rg.ok || rng.dead()) continue;
+      for (int d = 0; d < 4 && !rng.dead(); d++) {
+        const int c2 = rg.add_door(rng, g, 1, 1, -1, -1, 0, dx, dy);
+        ocol |= (uint64_t)c2 << (3 * n); otyp |= 3ull << (2 * n); n++;
+      }
+      rg.place_agent_in(rng, g, 1, 1, out);
+      if (!rg.ok || rng.dead()) continue;
+      const int k = rand_int(rng, 0, n);
+      const bool first = rand_int(rng, 0, 2) == 0;
+      const uint32_t kc = (uint32_t)(ocol >> (3 * k)) & 7u, kt = (uint32_t)(otyp >> (2 * k)) & 3u;
+      uint32_t matches = 0;
+      for (int d = 0; d < n; d++) matches += (((uint32_t)(ocol >> (3 * d)) & 7u) == kc && ((uint32_t)(otyp >> (2 * d)) & 3u) == kt) ? 1u : 0u;
+      const uint32_t verb = first ? 0u : (kt == 3u ? 2u : 1u);
+      out.mission = verb * 48u + (matches > 1u ? 24u : 0u) + kc * 4u + kt;
+      return;
+    }
+    // OpenDoor
+    uint32_t avail = 0x543210u;                               // _rand_subset(COLOR_NAMES, 4)
+    int colors[4], doorx[4], doory[4];
+    for (int n = 0, na = 6; n < 4; n++, na--) {
+      const int k = rand_int(rng, 0, na);
+      colors[n] = (int)((avail >> (4 * k)) & 15u);
+      const uint32_t lowmask = (1u << (4 * k)) - 1u;
+      avail = (avail & lowmask) | ((avail >> 4) & ~lowmask);
+    }
+    for (int d = 0; d < 4; d++) rg.add_door(rng, g, 1, 1, d, colors[d], 0, doorx[d], doory[d]);
+    const bool by_loc = P.num_crossings == 2 || (P.num_crossings == 0 && rand_int(rng, 0, 2) == 1);      // _rand_elem(["color", "loc"])
+    const int loc = by_loc ? rand_int(rng, 0, 4) : -1;        // LOC_NAMES = left, right, front, behind
+    rg.place_agent_in(rng, g, 1, 1, out);
+    if (!rg.ok || rng.dead()) continue;
+    uint32_t mask = 0, count = 0;
+    for (int d = 0; d < 4; d++) {
+      bool match;
+      if (!by_loc) match = d == 0;
+      else {                                                  // ObjDesc.find_matching_objs with a location (verifier.py:139-160)
+        const int vx = doorx[d] - rg.ax, vy = doory[d] - rg.ay, d1x = dir_dx(out.dir), d1y = dir_dy(out.dir), d2x = -d1y, d2y = d1x;
+        const int side = vx * d2x + vy * d2y, ahead = vx * d1x + vy * d1y;
+        match = loc == 0 ? side < 0 : loc == 1 ? side > 0 : loc == 2 ? ahead > 0 : ahead < 0;
+      }
+      if (match) { mask |= 1u << color_from_sorted((uint32_t)colors[d]); count++; }
+    }
+    out.aux = (uint64_t)mask;
+    out.mission = by_loc ? 6u + (count > 1u ? 4u : 0u) + (uint32_t)loc : (uint32_t)colors[0];
+    return;
+  }
+  out.failed = true;
+}
+
 // Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
@@ -1570,7 +1687,7 @@ MG_D void gen_babyai_levels(R& rng, GridRef& g, const GenParams& P, GenResult& o
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 45) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -1616,6 +1733,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 32: gen_putnear(rng, g, P, out); return;
       case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
       case 36: case 37: case 38: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
+      case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
       default: break;
     }
   }

@@ -35,7 +35,7 @@ enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
               RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
-              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13 };
+              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13, RULE_PUTNEXT = 14, RULE_OPENDOOR = 15 };
 
 struct StepParams {
   // ---- state ----
@@ -202,6 +202,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   uint32_t budget = budget0, retries_before = 0;
   out.resume = 0;
   for (;;) {
+    out.carry = 0;
     budget = min(budget, cap);
     while (rng.limit < rng.off + budget) rng.refill();
     MG_STAMP(3);
@@ -230,8 +231,8 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   uint4* dst = (uint4*)(A.dst_grid + se * A.CS);
   for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
   if (lane == 0) {
-    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission;
-    ag.flags = flags_out;
+    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = out.carry; ag.step = 0; ag.mission = out.mission;
+    ag.flags = flags_out | (out.carry ? FLAG_SHOW_TAKEN : 0u);
     A.dst_agent[se] = agent_pack(ag);
     if (A.dst_aux) A.dst_aux[se] = out.aux;
     if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
@@ -604,7 +605,7 @@ k_step(const StepParams P) {
   uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR || P.rule == RULE_GOTO_BIG);   // levels with an auxiliary word
+  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR || P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR);   // levels with an auxiliary word
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
@@ -659,7 +660,7 @@ k_step(const StepParams P) {
   auto goto_desc = [&](uint32_t mission) -> uint32_t {
     // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
     // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
-    // is returned as the OPEN door's code and matches the door in any state (desc_match).
+    // is returned as the OPEN door's code and matches the door in any state (desc_match).  5 = ActionObjDoor: as 4; id / 48 = the verb.
     const uint32_t m18 = mission % 18u, m24 = mission % 24u;
     return P.rule_div == 0 ? (uint32_t)P.rule_cell
          : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
@@ -734,7 +735,7 @@ k_step(const StepParams P) {
           if (goto_rule) { targets = sspr[1]; cur = targets; aux_dirty = true; }
           shadow_valid = false;
         }
-        a.carry = 0; a.step = 0; a.flags = 0;
+        a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
         rec_dirty = true; wb_all = true;
         if (!P.static_gen) h++;
       } else if (a.flags & FLAG_FRESH) {
@@ -807,8 +808,37 @@ k_step(const StepParams P) {
             bool hit = desc_match(c, desc);
 #pragma unroll
             for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
-            if (hit) { term = 1; success = true; }
+            if (hit && (P.rule_div != 5 || a.mission < 48u)) { term = 1; success = true; }
           }
+          if (P.rule_div == 5 && a.mission >= 48u) {
+            // ActionObjDoor (other.py:86-106): PickupInstr / OpenInstr about the same description (verifier.py:343-363, 270-287)
+            if (a.mission < 96u) { if (act == A_PICKUP && pre_carry == 0 && a.carry == desc) { term = 1; success = true; } }
+            else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
+          }
+        }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
+          // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
+          // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
+          // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
+          // that fails leaves cur_pos at (-1, -1) or -- start_carrying -- at the initial cell, which validate_instrs made non-adjacent
+          // to the fixed object, and that object cannot have moved while the hands were full.
+          const uint32_t mv = a.mission / 18u, fo = a.mission % 18u;
+          if (pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
+            const uint32_t fixed = make_cell((uint32_t)T_KEY + fo % 3u, color_from_sorted(fo / 3u));
+            bool next = false;
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) {
+              const int nx = fx + dir_dx((uint32_t)d), ny = fy + dir_dy((uint32_t)d);
+              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) next |= (uint32_t)mygrid[ny * W + nx] == fixed;
+            }
+            if (next) { term = 1; success = true; }
+          }
+        }
+        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
+          // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
+          // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
+          if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
+          else if (P.rule_div == 1 && cell_ref_type(newF) == T_DOOR) term = 1;
         }
         if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
           // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
@@ -959,15 +989,26 @@ k_step(const StepParams P) {
 
     // ---- observation -> the wave's byte stream in LDS ----
     const int obe = P.OBE;
+    Agent av = a;
+    bool show_taken = false;
+    if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
+      // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER the reset observation was made:
+      // the episode's first observation shows it where it was, and empty hands
+      show_taken = true; av.carry = 0;
+      if (lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)a.carry;
+      a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
+    }
+    if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
     if constexpr (FAST7) {
-      obs_view7<LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
+      obs_view7<LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
       static_assert(FAST7 || MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
-      obs_view_generic<MODE>(P, a, mygrid, slut, srows, sT + el * obe, active);
+      obs_view_generic<MODE>(P, av, mygrid, slut, srows, sT + el * obe, active);
     } else {
-      obs_full<MODE, LPE>(P, a, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
+      obs_full<MODE, LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     }
     MG_LDS_SYNC();
+    if constexpr (GG == GG_ROOMGRID) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
 
     // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
     {
@@ -1254,7 +1295,13 @@ __global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64
                                         : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
     for (int c = 0; c < cells && c < 64; c++) if (g[c] == desc) w |= 1ull << c;
   } else if (mode == 3) {
-    w = ~0ull;                                       // RULE_GOTO_BIG: no stale tracked position
+    w = ~0ull;                                       // RULE_GOTO_BIG: no stale tracked position; PutNext: not used once an episode runs
+  } else if (mode == 4) {
+    // OpenDoor: the described doors.  A colour description follows from the mission id; a location description ("the door on
+    // your left") was resolved against the agent's pose at reset and is not part of the exchanged state: the env's set is kept.
+    const uint32_t mis = agent_unpack(agent[n]).mission;
+    if (mis >= 6u) return;
+    w = 1ull << color_from_sorted(mis);
   } else {
     int k = 0;
     for (int c = 0; c < cells && k < 8; c++) if (cell_type(g[c]) == T_BALL) w |= (uint64_t)c << (8 * k++);

@@ -22,6 +22,7 @@ ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE, ENV_PUTNEAR = 29, 3
 ENV_BABYAI_GOTO, ENV_BABYAI_PICKUP, ENV_BABYAI_OPEN = 33, 34, 35
 ENV_BABYAI_UNLOCKPICKUP, ENV_BABYAI_BLOCKEDUNLOCKPICKUP, ENV_UNLOCKTOUNLOCK, ENV_BABYAI_UNLOCK = 36, 37, 38, 40
 ENV_BABYAI_GOTODOOR, ENV_GOTOOBJDOOR, ENV_UNBLOCKPICKUP, ENV_PICKUPABOVE, ENV_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
+ENV_PUTNEXTLOCAL, ENV_PUTNEXT, ENV_ACTIONOBJDOOR, ENV_OPENDOOR = 46, 47, 48, 49
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -165,6 +166,8 @@ def _babyai_goto(id_, kind, room_size, num_dists, missions, cls, kwargs=None):
 
 
 # "pick up " + ObjDesc.surface (envs/babyai/core/verifier.py:73-103): article x (no colour | colour) x ("object" | type)
+_PUTNEXT_MISSIONS = tuple(f"put the {c1} {t1} next to the {c2} {t2}" for c1 in _COLOR_NAMES for t1 in ("key", "ball", "box")
+                          for c2 in _COLOR_NAMES for t2 in ("key", "ball", "box"))
 _PICKUP_MISSIONS = tuple("pick up " + art + " " + (c + " " if c else "") + t for art in ("the", "a")
                          for c in ("",) + _COLOR_NAMES for t in ("object", "key", "ball", "box"))
 
@@ -305,6 +308,26 @@ _ROWS = [
           ("BabyAI-GoToImpUnlock-v0", ENV_GOTOIMPUNLOCK, "GoToImpUnlock", 8, 3, 3, 576, 0, _GOTO_OBJ_MISSIONS, {}),
           ("BabyAI-UnblockPickup-v0", ENV_UNBLOCKPICKUP, "UnblockPickup", 8, 3, 3, 576, 0, _PICKUP_MISSIONS, {}),
           ("BabyAI-PickupAbove-v0", ENV_PICKUPABOVE, "PickupAbove", 6, 3, 3, 288, 0, _PICKUP_MISSIONS, {}))],
+    # envs/babyai/putnext.py:68-80 (PutNextLocal: one room, max_steps = 2 * room_size**2 for its one PutNextInstr), :148-214 (PutNext: 1 x 2
+    # rooms, max_steps = 8 * room_size**2); 324 missions = (move colour, move type, fixed colour, fixed type); rows minigrid/__init__.py
+    *[EnvSpec(name, ENV_PUTNEXTLOCAL, rs, rs, 2 * rs * rs, False, _PUTNEXT_MISSIONS, num_dists=n, room_size=rs,
+              entry_point="minigrid.envs.babyai:PutNextLocal", kwargs=kw)
+      for name, rs, n, kw in (("BabyAI-PutNextLocal-v0", 8, 8, {}), ("BabyAI-PutNextLocalS5N3-v0", 5, 3, {"room_size": 5, "num_objs": 3}),
+                              ("BabyAI-PutNextLocalS6N4-v0", 6, 4, {"room_size": 6, "num_objs": 4}))],
+    *[EnvSpec(f"BabyAI-PutNextS{rs}N{n}{'Carrying' if carrying else ''}-v0", ENV_PUTNEXT, 2 * (rs - 1) + 1, rs, 8 * rs * rs, False, _PUTNEXT_MISSIONS,
+              num_dists=n, room_size=rs, num_crossings=int(carrying), entry_point="minigrid.envs.babyai:PutNext",
+              kwargs={"room_size": rs, "objs_per_room": n, **({"start_carrying": True} if carrying else {})})
+      for rs, n, carrying in ((4, 1, False), (5, 2, False), (5, 1, False), (6, 3, False), (7, 4, False), (5, 2, True), (6, 3, True), (7, 4, True))],
+    # envs/babyai/other.py:83-106 (room_size 7), open.py:203-229 (select_by None | "color" | "loc"; debug = strict OpenInstr)
+    EnvSpec("BabyAI-ActionObjDoor-v0", ENV_ACTIONOBJDOOR, 19, 19, 441, False,
+            tuple(f"{verb} {art} {c} {t}" for verb in ("go to", "pick up", "open") for art in ("the", "a") for c in _COLOR_NAMES
+                  for t in ("key", "ball", "box", "door")), room_size=7, entry_point="minigrid.envs.babyai:ActionObjDoor", kwargs={}),
+    *[EnvSpec(name, ENV_OPENDOOR, 22, 22, 576, False,
+              tuple(f"open the {c} door" for c in _COLOR_NAMES) +
+              tuple(f"open {art} door {loc}" for art in ("the", "a") for loc in ("on your left", "on your right", "in front of you", "behind you")),
+              room_size=8, num_crossings=sel, strip2_row=int(dbg), entry_point="minigrid.envs.babyai:OpenDoor", kwargs=kw)
+      for name, sel, dbg, kw in (("BabyAI-OpenDoor-v0", 0, False, {}), ("BabyAI-OpenDoorDebug-v0", 0, True, {"debug": True, "select_by": None}),
+                                 ("BabyAI-OpenDoorColor-v0", 1, False, {"select_by": "color"}), ("BabyAI-OpenDoorLoc-v0", 2, False, {"select_by": "loc"}))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),
