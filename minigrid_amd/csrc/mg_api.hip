@@ -581,7 +581,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       cfg->env_kind == MG_ENV_UNBLOCKPICKUP || cfg->env_kind == MG_ENV_PICKUPABOVE) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BABYAI_UNLOCK) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
   if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
-  if (cfg->env_kind == MG_ENV_PUTNEXTLOCAL || cfg->env_kind == MG_ENV_PUTNEXT) e->rule = RULE_PUTNEXT;
+  if (cfg->env_kind == MG_ENV_PUTNEXTLOCAL || cfg->env_kind == MG_ENV_PUTNEXT) { e->rule = RULE_PUTNEXT; e->rule_div = cfg->env_kind == MG_ENV_PUTNEXT && cfg->num_crossings ? 1 : 0; }
   if (cfg->env_kind == MG_ENV_ACTIONOBJDOOR) { e->rule = RULE_GOTO_BIG; e->rule_div = 5; }        // verb = mission id / 48: go to | pick up | open
   if (cfg->env_kind == MG_ENV_OPENDOOR) { e->rule = RULE_OPENDOOR; e->rule_div = cfg->strip2_row ? 1 : 0; }   // strip2_row = strict (OpenDoorDebug)
   e->goto_kind = e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR;

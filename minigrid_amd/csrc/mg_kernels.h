@@ -822,8 +822,10 @@ k_step(const StepParams P) {
           // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
           // that fails leaves cur_pos at (-1, -1) or -- start_carrying -- at the initial cell, which validate_instrs made non-adjacent
           // to the fixed object, and that object cannot have moved while the hands were full.
+          // start_carrying (rule_div == 1): the verifier was reset before the object was handed over, so at the episode's first
+          // step its preCarrying is still None
           const uint32_t mv = a.mission / 18u, fo = a.mission % 18u;
-          if (pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
+          if (!(P.rule_div == 1 && a.step == 1u) && pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
             const uint32_t fixed = make_cell((uint32_t)T_KEY + fo % 3u, color_from_sorted(fo / 3u));
             bool next = false;
 #pragma unroll 1
@@ -992,10 +994,13 @@ k_step(const StepParams P) {
     Agent av = a;
     bool show_taken = false;
     if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
-      // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER the reset observation was made:
-      // the episode's first observation shows it where it was, and empty hands
-      show_taken = true; av.carry = 0;
-      if (lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)a.carry;
+      // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER MiniGridEnv.reset made the
+      // observation: the episode's first core observation (and what OneHotPartialObsWrapper makes of it) shows it where it was, and
+      // empty hands.  The wrappers that look at the env when they are called (FullyObs, Symbolic, RGBImg*) see the state after.
+      if constexpr (MODE == 0 || MODE == 2) {
+        show_taken = true; av.carry = 0;
+        if (lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)a.carry;
+      }
       a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
     }
     if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();

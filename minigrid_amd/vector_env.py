@@ -137,8 +137,9 @@ class MiniGridVecEnv(_VectorEnvBase):
                             "rgb_partial": (v * self.tile_size, v * self.tile_size, 3),
                             "rgb": (s.height * self.tile_size, s.width * self.tile_size, 3)}[obs_mode]
         self._missions = np.asarray(s.missions)
-        # DictObservationSpaceWrapper (wrappers.py:429-554): mission string -> padded word-index vector, per mission id
-        self._mission_tokens = np.asarray([string_to_indices(m) for m in s.missions], np.int64)
+        # DictObservationSpaceWrapper (wrappers.py:429-554): mission string -> padded word-index vector, per mission id.  Its fixed
+        # vocabulary lacks some BabyAI words ("next", "on", "left", ...): like the reference, wrapping such a level raises ValueError
+        self._mission_tokens = np.asarray([string_to_indices(m) for m in s.missions], np.int64) if self.dict_mission else None
         self._seeded = False
         # spaces (minigrid_env.py:63, 72-84; FullyObsWrapper wrappers.py:404-417; ImgObsWrapper :211)
         # image spaces as the reference wrappers declare them (wrappers.py:263-267, 404-411, 655-662, 749-758)
