@@ -5,6 +5,7 @@
 // Tuning aid only (never linked into the product).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -14,6 +15,28 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: persistent, workgroup b sweeps pieces b, b + B, ... (fill order)      MODE 1: persistent, contiguous 1/B per workgroup
 // MODE 2: short-lived, one piece of `per_wg` chunks per workgroup (grid = total / per_wg)
+// MODE 0 / 1 with at most K + 1 stores in flight per wave (s_waitcnt vmcnt(K) after every store): does the fill rate of the
+// short-lived geometry come from each of its waves having ONE store in flight, i.e. from a tight chip-wide address window?
+template <int ORDER, int K>
+__global__ void k_store_throttled(u32x4* out, size_t total) {
+  const size_t T = blockDim.x, B = gridDim.x, b = blockIdx.x, t = threadIdx.x;
+  u32x4 v; v.x = (unsigned)t; v.y = (unsigned)b; v.z = 0; v.w = 1;
+  if (ORDER == 0) for (size_t c = b * T + t; c < total; c += B * T) { out[c] = v; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory"); }
+  else { const size_t per = total / B; for (size_t c = t; c < per; c += T) { out[b * per + c] = v; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory"); } }
+}
+template <int ORDER, int K>
+static float run_throttled(u32x4* buf, size_t total, int blocks, int threads) {
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_store_throttled<ORDER, K>), dim3(blocks), dim3(threads), 0, 0, buf, total);
+  (void)hipEventRecord(a, 0);
+  const int reps = 20;
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_store_throttled<ORDER, K>), dim3(blocks), dim3(threads), 0, 0, buf, total);
+  (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+  float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return ms * 1e3f / reps;
+}
+
 template <int MODE, bool NT, int WIDTH>
 __global__ void k_store(u32x4* out, size_t total, int per_wg) {
   extern __shared__ unsigned char lds[];        // only to limit occupancy like k_render's atlas does
@@ -76,6 +99,16 @@ int main() {
     else if (c.mode == 1) { us[0] = run<1, false, 16>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); us[1] = run<1, true, 16>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); us[2] = run<1, false, 8>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); }
     else { us[0] = run<2, false, 16>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); us[1] = run<2, true, 16>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); us[2] = run<2, false, 8>(buf, total, c.blocks, c.threads, c.lds, c.per_wg); }
     printf("%-50s x4 %7.1f us %5.2f TB/s | x4 nt %7.1f us | 2 x x2 %7.1f us\n", c.name, us[0], bytes / us[0] / 1e6, us[1], us[2]);
+  }
+  {
+    const int geos[][2] = { { 1024, 256 }, { 2048, 256 }, { 4096, 256 }, { 2048, 64 }, { 8192, 64 } };
+    for (auto& g : geos) {
+      const float f0 = run_throttled<0, 0>(buf, total, g[0], g[1]), f1 = run_throttled<0, 1>(buf, total, g[0], g[1]), f3 = run_throttled<0, 3>(buf, total, g[0], g[1]),
+                  f7 = run_throttled<0, 7>(buf, total, g[0], g[1]);
+      const float c0 = run_throttled<1, 0>(buf, total, g[0], g[1]), c1 = run_throttled<1, 1>(buf, total, g[0], g[1]), c3 = run_throttled<1, 3>(buf, total, g[0], g[1]);
+      printf("throttled persistent %5d x %4d: fill order vmcnt(0/1/3/7) %6.1f %6.1f %6.1f %6.1f us (best %4.2f TB/s) | contiguous vmcnt(0/1/3) %6.1f %6.1f %6.1f us\n",
+             g[0], g[1], f0, f1, f3, f7, bytes / fminf(fminf(f0, f1), fminf(f3, f7)) / 1e6, c0, c1, c3);
+    }
   }
   (void)hipFree(buf);
   return 0;
