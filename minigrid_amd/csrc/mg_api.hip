@@ -2,6 +2,10 @@
 // exchange.  No CPU fallback exists: every entry point that computes needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -389,8 +393,38 @@ int mg_device_count(void) {
 
 const char* mg_last_error(mg_env* env) { return env ? env->last_error.c_str() : g_create_error.c_str(); }
 
+// Diagnostic aid (MG_ABORT_BACKTRACE=1, set by tests/conftest.py): a SIGABRT anywhere in the process -- the HIP / HSA runtime aborts
+// without a message on some queue errors -- first prints the native backtrace of the aborting thread to stderr, then takes the
+// previous disposition (Python's faulthandler, or the default core dump).
+static struct sigaction g_prev_abrt;
+static void on_abort(int sig, siginfo_t* info, void* ctx) {
+  static const char msg[] = "\n[libminigrid_hip] SIGABRT -- native backtrace of the aborting thread:\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  sigaction(SIGABRT, &g_prev_abrt, nullptr);
+  if ((g_prev_abrt.sa_flags & SA_SIGINFO) && g_prev_abrt.sa_sigaction) g_prev_abrt.sa_sigaction(sig, info, ctx);
+  else if (g_prev_abrt.sa_handler != SIG_DFL && g_prev_abrt.sa_handler != SIG_IGN && g_prev_abrt.sa_handler) g_prev_abrt.sa_handler(sig);
+  raise(SIGABRT);
+}
+static void install_abort_backtrace() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* s = getenv("MG_ABORT_BACKTRACE");
+    if (!s || atoi(s) != 1) return;
+    void* warm[4]; (void)backtrace(warm, 4);           // loads libgcc now, not inside the handler
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = on_abort; sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGABRT, &sa, &g_prev_abrt);
+  });
+}
+
 int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (!cfg || !out) return fail(nullptr, MG_ERR_INVALID, "null argument");
+  install_abort_backtrace();
   *out = nullptr;
   if (cfg->abi_version != MG_ABI_VERSION) return fail(nullptr, MG_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, MG_ABI_VERSION);
   if (cfg->num_envs < 1) return fail(nullptr, MG_ERR_INVALID, "num_envs must be >= 1");

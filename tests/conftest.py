@@ -57,6 +57,10 @@ WIDE2_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0"
 ALL_IDS = MAIN_IDS + EXTRA_IDS + WIDE_IDS + WIDE2_IDS
 
 
+# an abort inside the HIP / HSA runtime leaves no message: have the library print the native backtrace first (mg_api.hip)
+os.environ.setdefault("MG_ABORT_BACKTRACE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
