@@ -103,6 +103,15 @@ typedef enum mg_env_kind {
   MG_ENV_ACTIONOBJDOOR = 48,              /* other.py:86-106 (id = verb * 48 + article * 24 + colour * 4 + (key, ball, box, door))        */
   MG_ENV_OPENDOOR = 49,                   /* open.py:209-229 (num_crossings = select_by: 0 random | 1 colour | 2 location; strip2_row = strict;
                                              id = colour, or 6 + article * 4 + (left, right, front, behind))                            */
+  MG_ENV_OPENTWODOORS = 50,               /* envs/babyai/open.py:306-325 (agent_start_x / agent_start_y = first / second door colour as a COLOR_NAMES
+                                             index or -1 = drawn; strip2_row = strict): "open the X door, then open the Y door"           */
+  MG_ENV_OPENDOORSORDER = 51,             /* open.py:399-425 (num_dists = num_doors 2..4, strip2_row = debug)                            */
+  MG_ENV_MOVETWOACROSS = 52,              /* other.py:404-428 (1 x 2 rooms, num_dists = objs_per_room)                                   */
+  MG_ENV_LEVELGEN = 53,                   /* envs/babyai/core/levelgen.py:24-211 (PickupLoc, GoToSeq, Synth*, MiniBossLevel, BossLevel*):
+                                             num_crossings = action kinds (bit 0 goto, 1 pickup, 2 open, 3 putnext) | instr kinds (bit 4
+                                             action, 5 and, 6 seq) | bit 7 locations | bit 8 unblocking | bit 9 implicit_unlock;
+                                             strip2_row = locked_room_prob in percent; num_dists distractors.  50..53 are the "sentence
+                                             levels": the mission is an instruction tree (mg_outputs.sentence), max_steps is per episode */
   MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =
                                ((move colour * 3 + move type) * 6 + target colour) * 3 + target type                                  */
   MG_ENV_DYNOBS = 15        /* envs/dynamicobstacles.py:110-167 (num_dists = n_obstacles <= 8, grid <= 16x16); step() moves
@@ -185,6 +194,11 @@ typedef struct mg_outputs {
   int64_t slot_bytes;
   int64_t record_bytes;
   int64_t max_fused_steps; /* steps one k_step launch of mg_rollout(fused) / mg_step_many runs */
+  uint64_t* sentence;   /* sentence levels (MG_ENV_OPENTWODOORS .. MG_ENV_LEVELGEN): (N, 2) u64, the mission as data -- word 0: bits [20k, 20k+20)
+                           = leaf k (k < 3), [60:63) root; word 1: [0:20) leaf 3, [20:44) three nodes of 8 bits = kind (1 ", then " 2 " after
+                           you " 3 " and ") | a << 2 | b << 5, children 0..3 = leaves, 4..6 = nodes.  leaf = verb (go to, pick up, open, put) |
+                           desc << 2 | fixed desc << 11 (put X next to Y); desc = type (door key ball box) | colour << 2 (0 none, COLOR_TO_IDX
+                           + 1) | loc << 5 (0 none, left right front behind) | article << 8 (1 = "a").  NULL for every other level.        */
 } mg_outputs;
 
 typedef struct mg_env mg_env;
@@ -219,6 +233,8 @@ MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
 MG_API int mg_copy_outputs(mg_env* env, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
                     uint8_t* direction, uint16_t* mission_id);
 /* mg_copy_outputs for trajectory slot `slot` (0 = the last step), plus the recorded actions. */
+/* sentence levels: the (N, 2) u64 mission words of trajectory slot `slot` (see mg_outputs.sentence) to the host */
+MG_API int mg_copy_sentence(mg_env* env, int slot, uint64_t* out);
 MG_API int mg_copy_slot(mg_env* env, int slot, uint8_t* obs, double* reward, uint8_t* terminated, uint8_t* truncated,
                  uint8_t* direction, uint16_t* mission_id, uint8_t* action);
 MG_API int mg_sync(mg_env* env);        /* synchronises the handle's streams (steps AND episode generation) + error-flag check */

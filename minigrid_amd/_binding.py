@@ -28,7 +28,7 @@ class MgOutputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
                 ("direction", C.c_void_p), ("mission_id", C.c_void_p), ("obs_bytes_per_env", C.c_int64),
                 ("num_envs", C.c_int64), ("action", C.c_void_p), ("traj_slots", C.c_int64), ("slot_bytes", C.c_int64),
-                ("record_bytes", C.c_int64), ("max_fused_steps", C.c_int64)]
+                ("record_bytes", C.c_int64), ("max_fused_steps", C.c_int64), ("sentence", C.c_void_p)]
 
 
 class MiniGridHipError(RuntimeError):
@@ -39,7 +39,7 @@ _lib = None
 
 # every symbol include/minigrid_hip.h declares (tests/test_abi_cpu.py checks the built library exports all of them)
 SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
-           "mg_copy_slot", "mg_selftest_stream",
+           "mg_copy_slot", "mg_copy_sentence", "mg_selftest_stream",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
            "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles"]
@@ -73,6 +73,7 @@ def load():
     L.mg_rollout.argtypes = [vp, i, u64, i]
     L.mg_step_many.argtypes = [vp, vp, i, i]
     L.mg_copy_slot.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    L.mg_copy_sentence.argtypes = [vp, i, vp]
     L.mg_selftest_stream.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.mg_get_outputs.argtypes = [vp, C.POINTER(MgOutputs)]
     L.mg_copy_outputs.argtypes = [vp, vp, vp, vp, vp, vp, vp]

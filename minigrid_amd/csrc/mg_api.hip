@@ -55,6 +55,8 @@ struct mg_env {
   int max_fused = 1;          // steps per fused launch
   // device buffers
   uint8_t *grid = nullptr, *spare_grid = nullptr;
+  bool sentence = false;       // BabyAI levels with an instruction tree / object identity: instruction records + k_verify
+  uint64_t *instr = nullptr, *spare_instr = nullptr; uint32_t *gstate = nullptr, *gsnap = nullptr; size_t off_sentence = 0;
   uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *rng_tmp = nullptr, *seeds = nullptr;
   uint32_t *head = nullptr, *tail = nullptr, *claim = nullptr, *seg = nullptr, *seg_count = nullptr;
   uint8_t *mask = nullptr, *actions = nullptr;
@@ -116,6 +118,7 @@ static GenParams gen_params(const mg_env* e) {
   g.strip2_row = e->cfg.strip2_row;
   g.room_size = e->cfg.room_size;
   g.random_length = e->cfg.random_length;
+  g.max_steps = e->cfg.max_steps; g.instr_off = 0; g.scratch_off = 0;
   return g;
 }
 
@@ -131,6 +134,8 @@ static GenArgs gen_args(mg_env* e, int slot) {
   A.rng = e->rng;
   A.rng_snap = to_spare ? e->rng_snap + s * 5 * N : nullptr;
   A.dst_aux = (e->live_gen && !to_spare) ? e->aux : (e->goto_kind ? (to_spare ? e->spare_aux + s * N : e->aux) : nullptr);
+  A.dst_instr = e->sentence ? (to_spare ? e->spare_instr + s * N * INSTR_WORDS : e->instr) : nullptr;
+  A.gstate = e->sentence ? e->gstate : nullptr; A.gsnap = (e->sentence && to_spare) ? e->gsnap + s * N : nullptr;
   A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + e->nwaves;
@@ -146,7 +151,7 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
   A.mask = d_mask;
   const int wpb = GEN_THREADS / 64;
   const int blocks = std::min((e->N + wpb - 1) / wpb, 8192);
-  const size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words);
+  const size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
     hipLaunchKernelGGL(k_generate<WavePhilox>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
   else
@@ -166,7 +171,7 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
   A.wps = std::max(1, e->epw / 4);            // a GoToRedBall batch files ~EPW/7 requests per segment (Poisson: some segments twice that)
   if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
-  const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words);
+  const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
   if (e->cfg.rng_mode == MG_RNG_PHILOX)
     hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
   else
@@ -234,7 +239,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
   P.err = e->err; P.counters = e->counters;
-  P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->cfg.max_steps;
+  P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->sentence ? 65535 : e->cfg.max_steps;   // sentence levels: per-episode limit, applied by k_verify
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
@@ -296,6 +301,17 @@ static int launch_step(mg_env* e, StepParams& P) {
 #undef MG_TRY_LAUNCH
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
+  if (e->sentence) {
+    // RoomGridLevel.step's verifier half (per-episode max_steps, the instruction tree, object identity): see k_verify
+    VerifyParams V;
+    V.grid = e->grid; V.agent = e->agent; V.instr = e->instr; V.spare_instr = e->spare_instr;
+    V.head = e->head; V.ring_mask = (uint32_t)(e->R - 1);
+    V.rec = e->out + (size_t)P.slot0 * e->slot_bytes;
+    V.off_reward = e->off_reward; V.off_term = e->off_term; V.off_trunc = e->off_trunc; V.off_action = e->off_action; V.off_sentence = e->off_sentence;
+    V.err = e->err; V.N = e->N; V.W = e->W; V.H = e->H; V.CS = e->CS; V.phase = P.phase; V.autoreset_next_step = P.autoreset_next_step;
+    hipLaunchKernelGGL(k_verify, dim3((e->N + 127) / 128), dim3(128), 0, e->stream, V);
+    HIP_TRY(e, hipGetLastError());
+  }
   if (e->rgb) {
     hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
@@ -440,7 +456,21 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_OPENDOOR || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
+    const int st = cfg->room_size - 1, k = cfg->env_kind;
+    const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
+    if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || nc < 1 || nc > 3 || nr < 1 || nr > 3)
+      return fail(nullptr, MG_ERR_INVALID, "sentence levels: 1..3 x 1..3 rooms of room_size 4..8");
+    if ((k == MG_ENV_OPENTWODOORS || k == MG_ENV_OPENDOORSORDER) && (nc != 3 || nr != 3)) return fail(nullptr, MG_ERR_INVALID, "OpenTwoDoors / OpenDoorsOrder: 3 x 3 rooms");
+    if (k == MG_ENV_OPENTWODOORS && (cfg->agent_start_x < -1 || cfg->agent_start_x > 5 || cfg->agent_start_y < -1 || cfg->agent_start_y > 5))
+      return fail(nullptr, MG_ERR_INVALID, "OpenTwoDoors: agent_start_x / agent_start_y = first / second door colour (COLOR_NAMES index) or -1");
+    if (k == MG_ENV_OPENDOORSORDER && (cfg->num_dists < 2 || cfg->num_dists > 4)) return fail(nullptr, MG_ERR_INVALID, "OpenDoorsOrder: 2..4 doors");
+    if (k == MG_ENV_MOVETWOACROSS && (nc != 2 || nr != 1 || cfg->num_dists < 2 || cfg->num_dists > 9)) return fail(nullptr, MG_ERR_INVALID, "MoveTwoAcross: 1 x 2 rooms, 2..9 objects per room");
+    if (k == MG_ENV_LEVELGEN && (cfg->num_dists < 0 || cfg->num_dists > 24 || (cfg->num_crossings & 15) == 0 || ((cfg->num_crossings >> 4) & 7) == 0 ||
+        (unsigned)cfg->num_crossings > 1023u || cfg->strip2_row < 0 || cfg->strip2_row > 100))
+      return fail(nullptr, MG_ERR_INVALID, "LevelGen: num_crossings = action kinds | instr kinds << 4 | locations << 7 | unblocking << 8 | implicit_unlock << 9, strip2_row = locked_room_prob in percent, at most 24 distractors");
+  }
   if (cfg->env_kind >= MG_ENV_PUTNEXTLOCAL && cfg->env_kind <= MG_ENV_OPENDOOR) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;
     const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
@@ -569,6 +599,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
+  e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   {
@@ -597,7 +628,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (cfg->traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
     e->S = S;
     // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
-    e->max_fused = (rgb || e->live_gen) ? 1 : std::min(S, e->static_gen ? 32 : 2 * e->cb);
+    e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(S, e->static_gen ? 32 : 2 * e->cb);
     if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   }
   // GoToInstr levels: rule_div selects how the described object follows from the mission id (see k_step)
@@ -615,6 +646,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       cfg->env_kind == MG_ENV_UNBLOCKPICKUP || cfg->env_kind == MG_ENV_PICKUPABOVE) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_BABYAI_UNLOCK) { e->rule = RULE_OPENFRONT; e->rule_div = 6; }
   if (cfg->env_kind == MG_ENV_PUTNEAR) { e->rule = RULE_PUTNEAR; e->rule_div = 2; }        // target (colour, type) = mission id % 18, like GoToObj
+  if (e->sentence) e->rule = RULE_SENTENCE;
   if (cfg->env_kind == MG_ENV_PUTNEXTLOCAL || cfg->env_kind == MG_ENV_PUTNEXT) { e->rule = RULE_PUTNEXT; e->rule_div = cfg->env_kind == MG_ENV_PUTNEXT && cfg->num_crossings ? 1 : 0; }
   if (cfg->env_kind == MG_ENV_ACTIONOBJDOOR) { e->rule = RULE_GOTO_BIG; e->rule_div = 5; }        // verb = mission id / 48: go to | pick up | open
   if (cfg->env_kind == MG_ENV_OPENDOOR) { e->rule = RULE_OPENDOOR; e->rule_div = cfg->strip2_row ? 1 : 0; }   // strip2_row = strict (OpenDoorDebug)
@@ -637,7 +669,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   // k_step compiles each level rule only into the variant of its rule group
   e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
                 : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR) ? GG_ROOMGRID
-                : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE) ? GG_NONE : GG_LIGHT;
+                : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE || e->rule == RULE_SENTENCE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
 #define TRY_OR_FREE(call) do { hipError_t _e = (call); if (_e != hipSuccess) { int rc = fail(nullptr, MG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); mg_destroy(e); return rc; } } while (0)
@@ -680,6 +712,16 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   const size_t nseg = (size_t)(e->live_gen ? 1 : QSETS) * e->nwaves;
   TRY_OR_FREE(dalloc(&e->seg, nseg * e->seg_cap));
   TRY_OR_FREE(dalloc(&e->seg_count, nseg));
+  if (e->sentence) {
+    TRY_OR_FREE(dalloc(&e->instr, N * INSTR_WORDS));
+    TRY_OR_FREE(dalloc(&e->spare_instr, R * N * INSTR_WORDS));
+    TRY_OR_FREE(dalloc(&e->gstate, N));
+    TRY_OR_FREE(dalloc(&e->gsnap, R * N));
+    TRY_OR_FREE(hipMemsetAsync(e->instr, 0, N * INSTR_WORDS * sizeof(uint64_t), e->stream));
+    TRY_OR_FREE(hipMemsetAsync(e->spare_instr, 0, R * N * INSTR_WORDS * sizeof(uint64_t), e->stream));
+    TRY_OR_FREE(hipMemsetAsync(e->gstate, 0, N * sizeof(uint32_t), e->stream));
+    TRY_OR_FREE(hipMemsetAsync(e->gsnap, 0, R * N * sizeof(uint32_t), e->stream));
+  }
   TRY_OR_FREE(hipMemsetAsync(e->aux, 0, N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_aux, 0, R * N * sizeof(uint64_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->head, 0, N * sizeof(uint32_t), e->stream));
@@ -695,7 +737,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_dir = e->off_trunc + up(N);
     e->off_mission = e->off_dir + up(N);
     e->off_action = e->off_mission + up(2 * N);
-    e->record_bytes = up(e->off_action + N);
+    e->off_sentence = e->off_action + up(N);                 // sentence levels: the mission as data, two u64 per env
+    e->record_bytes = e->sentence ? up(e->off_sentence + 16 * N) : up(e->off_action + N);
     e->slot_bytes = e->record_bytes;
     if (e->slot_bytes >= ((size_t)1 << 32)) { mg_destroy(e); return fail(nullptr, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)"); }
     TRY_OR_FREE(dalloc(&e->out, e->slot_bytes * (size_t)e->S));
@@ -754,7 +797,7 @@ int mg_destroy(mg_env* e) {
   if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
   void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
                    e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->counters,
-                   e->tilemap, e->atlas, e->st_grid, e->st_agent };
+                   e->tilemap, e->atlas, e->st_grid, e->st_agent, e->instr, e->spare_instr, e->gstate, e->gsnap };
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (e->err_host) (void)hipHostFree((void*)e->err_host);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -774,7 +817,8 @@ static int refill_whole_ring(mg_env* e, const uint8_t* d_mask) {
   if (e->live_gen) return MG_OK;
   const int tb = 256, nb = (e->N + tb - 1) / tb;
   if (uses_ring(e)) {
-    hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, e->stream, e->head, e->tail, d_mask, (uint32_t)e->R, e->N);
+    hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, e->stream, e->head, e->tail, d_mask, (uint32_t)e->R, e->N,
+                       e->sentence ? e->gstate : nullptr, e->sentence ? e->gsnap : nullptr);
     HIP_TRY(e, hipGetLastError());
   }
   for (int s = 0; s < e->R; s++) { int rc = launch_generate(e, s, d_mask); if (rc) return rc; }
@@ -883,7 +927,16 @@ int mg_get_outputs(mg_env* e, mg_outputs* o) {
   o->obs_bytes_per_env = e->obs_bytes; o->num_envs = e->N;
   o->action = e->out + e->off_action; o->traj_slots = e->S; o->slot_bytes = (int64_t)e->slot_bytes; o->record_bytes = (int64_t)e->record_bytes;
   o->max_fused_steps = e->max_fused;
+  o->sentence = e->sentence ? (uint64_t*)(e->out + e->off_sentence) : nullptr;
   return MG_OK;
+}
+
+int mg_copy_sentence(mg_env* e, int slot, uint64_t* out) {
+  if (!e || !out || slot < 0 || slot >= e->S) return MG_ERR_INVALID;
+  if (!e->sentence) return fail(e, MG_ERR_INVALID, "mg_copy_sentence: not a sentence level (missions are mission_id table entries)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpyAsync(out, e->out + (size_t)slot * e->slot_bytes + e->off_sentence, (size_t)e->N * 16, hipMemcpyDeviceToHost, e->stream));
+  return check_device_errors(e);
 }
 
 int mg_copy_outputs(mg_env* e, uint8_t* obs, double* reward, uint8_t* term, uint8_t* trunc, uint8_t* dir, uint16_t* mission) {
@@ -941,6 +994,7 @@ int mg_get_state(mg_env* e, uint8_t* grid, int32_t* agent) {
 
 int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
   if (!e || !grid || !agent) return MG_ERR_INVALID;
+  if (e->sentence) return fail(e, MG_ERR_INVALID, "set_state: the exchanged state does not carry the instruction tree and object identities of a sentence level");
   HIP_TRY(e, hipSetDevice(e->device));
   { int rc = state_staging(e); if (rc) return rc; }
   const size_t N = (size_t)e->N, total = N * e->cells;

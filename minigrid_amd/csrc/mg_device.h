@@ -146,6 +146,7 @@ constexpr uint32_t FLAG_FRESH = 2u;           // regenerated just before this la
 constexpr uint32_t FLAG_NOT_CLEAR = 4u;       // DynamicObstacles: the front cell was occupied before the obstacles moved
 constexpr uint32_t FLAG_TARGETS_STALE = 8u;   // BabyAI GoTo levels: a described object moved since GoToInstr's positions were refreshed
 constexpr uint32_t FLAG_SHOW_TAKEN = 16u;     // PutNext(start_carrying): the episode's first observation shows the carried object where it was taken from
+constexpr uint32_t FLAG_NEW_EPISODE = 32u;    // sentence levels: k_step took a spare episode; k_verify installs its instruction record
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };
@@ -161,6 +162,37 @@ MG_HD uint64_t agent_pack(const Agent& a) {
          ((uint64_t)(a.carry & 0xFF) << 24) | ((uint64_t)(a.step & 0xFFFF) << 32) |
          ((uint64_t)(a.flags & 0xFF) << 48) | ((uint64_t)(a.mission & 0xFF) << 56);
 }
+
+// ---- the general BabyAI instruction as data (envs/babyai/core/verifier.py), INSTR_WORDS u64 per env ("sentence levels") ----
+// Up to four action instructions (leaves 0..3) under And / Before / After nodes (4..6): LevelGen's grammar (levelgen.py:157-211)
+// never nests deeper than Before/After(And(l, l), And(l, l)).  Objects are identified by an id (0..62) given at generation; the
+// record tracks where every object is (`pos`), which objects each description selected at reset (ObjDesc.obj_set), and -- for
+// GoToInstr / PutNextInstr, whose obj_poss are POSITIONS refreshed only at reset and by drop actions -- the cells a member left
+// since the last refresh (`stale`, see RULE_GOTO_BIG for the argument).
+//   word 0       header: [0:3) root | [3:27) 3 nodes x (kind 2: 1 Before 2 After 3 And | a 3 | b 3) | [27:39) 3 x (a_done 2 | b_done 2)
+//                | [39:55) this episode's max_steps | [55:62) id + 1 of the carried object (0 = none)
+//   words 1..4   leaf k: [0:20) leaf20 = verb 2 (go to, pick up, open, put next) | desc 9 | fixed desc 9 (PutNext) | [20] strict
+//                | [21:28) preCarrying id + 1;  desc 9 = type 2 (door key ball box) | colour 3 (0 any, COLOR_TO_IDX + 1) | loc 3
+//                (0 none, left right front behind) | article 1 (more than one object matched at reset)
+//   words 5..12  obj_set of leaf k's desc (5 + 2k) and fixed desc (6 + 2k), bit = id
+//   words 13..20 stale cells of the same descriptions: four u16 cell indices each (0xFFFF = free)
+//   words 21..36 pos: u16 cell index y * W + x per id; 0xFFFF carried, 0xFFFE gone (a toggled box)
+//   words 37, 38 the mission as data (what the host turns into the sentence, Instr.surface): [0:60) leaf20 of leaves 0..2 |
+//                [60:63) root;  [0:20) leaf20 of leaf 3 | [20:44) the three nodes
+constexpr int INSTR_WORDS = 40;
+constexpr int IW_LEAF = 1, IW_SET = 5, IW_STALE = 13, IW_POS = 21, IW_MISSION = 37;
+constexpr uint32_t POS_CARRIED = 0xFFFFu, POS_GONE = 0xFFFEu;
+enum : uint32_t { V_GOTO = 0, V_PICKUP = 1, V_OPEN = 2, V_PUTNEXT = 3 };
+enum : uint32_t { N_BEFORE = 1, N_AFTER = 2, N_AND = 3 };
+enum : uint32_t { R_CONTINUE = 0, R_SUCCESS = 1, R_FAILURE = 2 };
+MG_HD constexpr uint32_t desc9(uint32_t ref_type, uint32_t color_plus1, uint32_t loc, uint32_t article) {
+  return (ref_type - T_DOOR) | (color_plus1 << 2) | (loc << 5) | (article << 8);
+}
+MG_HD constexpr uint32_t desc9_type(uint32_t d) { return (d & 3u) + T_DOOR; }
+MG_HD constexpr uint32_t desc9_color(uint32_t d) { return (d >> 2) & 7u; }
+MG_HD constexpr uint32_t desc9_loc(uint32_t d) { return (d >> 5) & 7u; }
+MG_HD constexpr uint32_t leaf20(uint32_t verb, uint32_t d, uint32_t f) { return verb | (d << 2) | (f << 11); }
+MG_HD constexpr uint32_t node8(uint32_t kind, uint32_t a, uint32_t b) { return kind | (a << 2) | (b << 5); }
 
 // DIR_TO_VEC (core/constants.py:49-58) without a table: dir 0:(1,0) 1:(0,1) 2:(-1,0) 3:(0,-1)
 MG_HD int dir_dx(uint32_t d) { return (d & 1u) ? 0 : 1 - (int)(d & 2u); }

@@ -17,6 +17,8 @@ struct GenParams {
   int strip2_row;                    // DistShift
   int room_size;                     // RoomGrid levels
   int random_length;                 // Memory
+  int max_steps;                     // sentence levels with a fixed step limit
+  int instr_off;                     // sentence levels: byte offset from the wave's grid to INSTR_WORDS u64 of LDS for the instruction record
   int scratch_off;                   // byte offset from the wave's grid to GEN_SCRATCH_BYTES of LDS that outlive a checkpoint restart
 };
 
@@ -24,6 +26,7 @@ struct GenResult {
   uint32_t ax, ay, dir, mission;
   uint64_t aux;       // per-env auxiliary word: DynamicObstacles: byte i = cell index (y*W+x) of obstacle i, in list
                       // order; BabyAI GoTo levels: bitboard (bit y*W+x) of GoToInstr's tracked object positions
+  uint32_t gstate;    // LevelGen: locked_room as this episode leaves it (generator state carried from episode to episode)
   uint32_t carry;     // cell code the agent starts with in its hands (PutNext start_carrying), 0 = nothing
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
@@ -1679,6 +1682,344 @@ MG_D void gen_babyai_put_open(R& rng, GridRef& g, const GenParams& P, GenResult&
   out.failed = true;
 }
 
+// ======================================================================================================
+// Sentence levels: the BabyAI levels whose mission is an instruction TREE (verifier.py And / Before / After) and / or whose
+// descriptions need object identity (locations).  The generator leaves, next to the map, the instruction record of mg_device.h
+// (INSTR_WORDS u64 in LDS at `iw`); k_verify evaluates it after every step.
+// ======================================================================================================
+enum : int { KIND_OPENTWODOORS = 50, KIND_OPENDOORSORDER = 51, KIND_MOVETWOACROSS = 52, KIND_LEVELGEN = 53 };
+// lane l = object id l: where it is and what it is.  Ids are given in cell order to everything that is neither None nor a wall
+// (RoomGridLevel gives WorldObj identity to the same set; the order is internal).
+struct Objs { uint32_t pos, code; int x, y; uint32_t count; };
+MG_D Objs assign_ids(GridRef& g, uint64_t* iw) {
+  uint16_t* pos = (uint16_t*)(iw + IW_POS);
+  MG_WAVE_LDS_SYNC();
+  pos[g.lane] = (uint16_t)POS_GONE;
+  MG_WAVE_LDS_SYNC();
+  uint32_t count = 0;
+  const int cells = g.W * g.H;
+  for (int base = 0; base < cells; base += 64) {
+    const int c = base + g.lane;
+    const uint32_t code = c < cells ? (uint32_t)g.p[c] : 0u;
+    const bool isobj = c < cells && code != CELL_EMPTY && cell_type(code) != T_WALL;
+    const unsigned long long m = __ballot(isobj);
+    const uint32_t id = count + (uint32_t)__popcll(m & ((1ull << g.lane) - 1ull));
+    if (isobj && id < 63u) pos[id] = (uint16_t)c;
+    count += (uint32_t)__popcll(m);
+  }
+  MG_WAVE_LDS_SYNC();
+  Objs o;
+  o.pos = pos[g.lane]; o.count = count;
+  o.code = o.pos < POS_GONE ? (uint32_t)g.p[o.pos] : 0u;
+  o.y = o.pos < POS_GONE ? (int)o.pos / g.W : -9; o.x = o.pos < POS_GONE ? (int)o.pos - o.y * g.W : -9;
+  return o;
+}
+// ObjDesc.find_matching_objs(use_location=True) (verifier.py:105-171) as one ballot over the object ids
+MG_D uint64_t desc_set(const Objs& o, uint32_t type, uint32_t colp1, uint32_t loc, int ax, int ay, uint32_t dir, int rs) {
+  bool m = o.pos < POS_GONE && cell_ref_type(o.code) == type && (colp1 == 0u || cell_color(o.code) == colp1 - 1u);
+  if (loc) {
+    const int st = rs - 1, top_x = (ax / st) * st, top_y = (ay / st) * st;                       // room_from_pos(agent_pos).pos_inside
+    const bool inside = o.x >= top_x && o.x < top_x + rs && o.y >= top_y && o.y < top_y + rs;
+    const int vx = o.x - ax, vy = o.y - ay, d1x = dir_dx(dir), d1y = dir_dy(dir), d2x = -d1y, d2y = d1x;
+    const int side = vx * d2x + vy * d2y, ahead = vx * d1x + vy * d1y;
+    m = m && inside && (loc == 1u ? side < 0 : loc == 2u ? side > 0 : loc == 3u ? ahead > 0 : ahead < 0);
+  }
+  return __ballot(m);
+}
+// the record's constant parts once the tree is known: header, stale sets, mission words
+MG_D void sentence_finish(GridRef& g, uint64_t* iw, uint32_t root, const uint32_t node[3], uint32_t max_steps) {
+  if (g.lane == 0) {
+    uint64_t h = (uint64_t)root | ((uint64_t)max_steps << 39);
+    for (int n = 0; n < 3; n++) h |= (uint64_t)node[n] << (3 + 8 * n);
+    iw[0] = h;
+    for (int k = 0; k < 8; k++) iw[IW_STALE + k] = ~0ull;
+    uint64_t m0 = (uint64_t)root << 60, m1 = 0;
+    for (int k = 0; k < 3; k++) m0 |= (iw[IW_LEAF + k] & 0xFFFFFull) << (20 * k);
+    m1 = (iw[IW_LEAF + 3] & 0xFFFFFull) | ((uint64_t)node[0] << 20) | ((uint64_t)node[1] << 28) | ((uint64_t)node[2] << 36);
+    iw[IW_MISSION] = m0; iw[IW_MISSION + 1] = m1; iw[IW_MISSION + 2] = 0ull;
+  }
+  MG_WAVE_LDS_SYNC();
+}
+MG_D void sentence_leaf(GridRef& g, uint64_t* iw, int k, uint32_t verb, uint32_t d9, uint64_t dset, uint32_t f9, uint64_t fset, uint32_t strict) {
+  if (g.lane == 0) {
+    const uint32_t da = d9 | ((__popcll(dset) > 1 ? 1u : 0u) << 8), fa = f9 | ((__popcll(fset) > 1 ? 1u : 0u) << 8);
+    iw[IW_LEAF + k] = (uint64_t)leaf20(verb, da, fa) | ((uint64_t)strict << 20);
+    iw[IW_SET + 2 * k] = dset; iw[IW_SET + 2 * k + 1] = fset;
+  }
+}
+
+// sequences of two instructions: OpenTwoDoors (open.py:306-325; P.start_x / P.start_y = first / second colour as a COLOR_NAMES index
+// or -1, P.strip2_row = strict), OpenDoorsOrder (:399-425; P.num_dists = num_doors, P.strip2_row = debug), MoveTwoAcross
+// (other.py:404-428; P.num_dists = objs_per_room).  max_steps is the class's fixed value (P.max_steps).
+template <class R>
+MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out, uint64_t* iw) {
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    RG rg;
+    rg.gen_grid(rng, g, P.room_size);
+    int dx, dy;
+    out.aux = ~0ull; out.carry = 0; out.mission = 0;
+    uint32_t node[3] = { 0u, 0u, 0u }, root = 0;
+    if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull;
+    if (P.kind == KIND_OPENTWODOORS || P.kind == KIND_OPENDOORSORDER) {
+      const int nsub = P.kind == KIND_OPENTWODOORS ? 2 : P.num_dists;
+      uint32_t avail = 0x543210u;                             // _rand_subset(COLOR_NAMES, n)
+      int colors[4] = { 0, 0, 0, 0 };
+      for (int n = 0, na = 6; n < nsub; n++, na--) {
+        const int k = rand_int(rng, 0, na);
+        const int c = (int)((avail >> (4 * k)) & 15u);
+        if (n == 0) colors[0] = c; else if (n == 1) colors[1] = c; else if (n == 2) colors[2] = c; else colors[3] = c;
+        const uint32_t lowmask = (1u << (4 * k)) - 1u;
+        avail = (avail & lowmask) | ((avail >> 4) & ~lowmask);
+      }
+      int c1, c2;
+      uint32_t strict2 = 0;
+      if (P.kind == KIND_OPENTWODOORS) {
+        c1 = P.start_x >= 0 ? P.start_x : colors[0]; c2 = P.start_y >= 0 ? P.start_y : colors[1];
+        rg.add_door(rng, g, 1, 1, 2, c1, 0, dx, dy);
+        rg.add_door(rng, g, 1, 1, 0, c2, 0, dx, dy);
+        rg.place_agent_in(rng, g, 1, 1, out);
+        if (!rg.ok || rng.dead()) continue;
+        node[0] = node8(N_BEFORE, 0, 1); root = 4;
+      } else {
+        for (int d = 0; d < nsub && !rng.dead(); d++) {
+          const int c = d == 0 ? colors[0] : d == 1 ? colors[1] : d == 2 ? colors[2] : colors[3];
+          rg.add_door(rng, g, 1, 1, -1, c, 0, dx, dy);
+        }
+        rg.place_agent_in(rng, g, 1, 1, out);
+        if (!rg.ok || rng.dead()) continue;
+        const int a = rand_int(rng, 0, nsub);                 // _rand_subset(doors, 2)
+        int b = rand_int(rng, 0, nsub - 1); if (b >= a) b++;
+        const int mode = rand_int(rng, 0, 3);
+        c1 = a == 0 ? colors[0] : a == 1 ? colors[1] : a == 2 ? colors[2] : colors[3];
+        c2 = b == 0 ? colors[0] : b == 1 ? colors[1] : b == 2 ? colors[2] : colors[3];
+        strict2 = (uint32_t)P.strip2_row;
+        if (mode == 0) root = 0; else { node[0] = node8(mode == 1 ? N_BEFORE : N_AFTER, 0, 1); root = 4; }
+      }
+      if (rng.dead()) continue;
+      const Objs o = assign_ids(g, iw);
+      const uint32_t k1 = color_from_sorted((uint32_t)c1) + 1u, k2 = color_from_sorted((uint32_t)c2) + 1u;
+      const uint64_t s1 = desc_set(o, T_DOOR, k1, 0, rg.ax, rg.ay, out.dir, rg.rs), s2 = desc_set(o, T_DOOR, k2, 0, rg.ax, rg.ay, out.dir, rg.rs);
+      sentence_leaf(g, iw, 0, V_OPEN, desc9(T_DOOR, k1, 0, 0), s1, 0, 0, (uint32_t)P.strip2_row);
+      sentence_leaf(g, iw, 1, V_OPEN, desc9(T_DOOR, k2, 0, 0), s2, 0, 0, strict2);
+      sentence_finish(g, iw, root, node, (uint32_t)P.max_steps);
+      return;
+    }
+    // MoveTwoAcross
+    const int per = P.num_dists;
+    rg.place_agent_in(rng, g, 0, 0, out);
+    uint64_t opos[3] = { 0, 0, 0 }, okind[3] = { 0, 0, 0 };   // byte n & 7 of word n >> 3: x | y << 4; colour * 3 + type (up to 18 objects)
+    uint32_t used = 0;
+    int n = 0;
+    for (int room = 0; room < 2 && rg.ok && !rng.dead(); room++)
+      for (int k = 0; k < per && rg.ok && !rng.dead();) {
+        const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+        if ((used >> (c2 * 3 + t2)) & 1u) continue;
+        int x, y;
+        if (!place_obj(rng, g, make_cell((uint32_t)T_KEY + (uint32_t)t2, color_from_sorted((uint32_t)c2)), room * rg.st, 0, rg.rs, rg.rs, rg.ax, rg.ay, true, 1000, x, y)) { rg.ok = false; break; }
+        used |= 1u << (c2 * 3 + t2);
+        const int w = n >> 3, sh = 8 * (n & 7);
+        const uint64_t pv = (uint64_t)(x | (y << 4)) << sh, kv = (uint64_t)(c2 * 3 + t2) << sh;
+        if (w == 0) { opos[0] |= pv; okind[0] |= kv; } else if (w == 1) { opos[1] |= pv; okind[1] |= kv; } else { opos[2] |= pv; okind[2] |= kv; }
+        n++; k++;
+      }
+    if (!rg.ok || rng.dead()) continue;
+    MG_WAVE_LDS_SYNC();                                       // remove_wall(0, 0, 0)
+    if (g.lane >= 1 && g.lane < rg.rs - 1) g.p[g.lane * g.W + rg.st] = (uint8_t)CELL_EMPTY;
+    MG_WAVE_LDS_SYNC();
+    const int l0 = rand_int(rng, 0, per); int l1 = rand_int(rng, 0, per - 1); if (l1 >= l0) l1++;       // _rand_subset(objs_l, 2)
+    const int r0 = rand_int(rng, 0, per); int r1 = rand_int(rng, 0, per - 1); if (r1 >= r0) r1++;
+    if (rng.dead()) continue;
+    const int ia = l0, ib = per + r0, ic = per + r1, id = l1;
+    auto pos_of = [&](int i) -> int { const uint64_t w = (i >> 3) == 0 ? opos[0] : (i >> 3) == 1 ? opos[1] : opos[2]; return (int)(w >> (8 * (i & 7))) & 255; };
+    auto kind_of = [&](int i) -> uint32_t { const uint64_t w = (i >> 3) == 0 ? okind[0] : (i >> 3) == 1 ? okind[1] : okind[2]; return (uint32_t)(w >> (8 * (i & 7))) & 31u; };
+    auto adjacent = [&](int i, int j) -> bool { const int p = pos_of(i), q = pos_of(j); return abs((p & 15) - (q & 15)) + abs((p >> 4) - (q >> 4)) == 1; };
+    if (adjacent(ia, ib) || adjacent(ic, id)) continue;       // validate_instrs: "objs already next to each other" (the objects are unique)
+    const Objs o = assign_ids(g, iw);
+    auto d9_of = [&](int i) -> uint32_t { const uint32_t kd = kind_of(i); return desc9((uint32_t)T_KEY + kd % 3u, color_from_sorted(kd / 3u) + 1u, 0, 0); };
+    auto set_of = [&](int i) -> uint64_t { const uint32_t kd = kind_of(i); return desc_set(o, (uint32_t)T_KEY + kd % 3u, color_from_sorted(kd / 3u) + 1u, 0, rg.ax, rg.ay, out.dir, rg.rs); };
+    const uint64_t sa = set_of(ia), sb = set_of(ib), sc = set_of(ic), sd = set_of(id);
+    sentence_leaf(g, iw, 0, V_PUTNEXT, d9_of(ia), sa, d9_of(ib), sb, 0);
+    sentence_leaf(g, iw, 1, V_PUTNEXT, d9_of(ic), sc, d9_of(id), sd, 0);
+    node[0] = node8(N_BEFORE, 0, 1); root = 4;
+    sentence_finish(g, iw, root, node, (uint32_t)P.max_steps);
+    return;
+  }
+  out.failed = true;
+}
+
+// envs/babyai/core/levelgen.py: LevelGen (PickupLoc, GoToSeq, Synth*, MiniBossLevel, BossLevel*).  P.num_crossings = action kinds
+// (bit 0 goto, 1 pickup, 2 open, 3 putnext) | instr kinds (bit 4 action, 5 and, 6 seq) | bit 7 locations | bit 8 unblocking |
+// bit 9 implicit_unlock; P.strip2_row = locked_room_prob in percent; P.num_dists distractors.  LevelGen.locked_room survives from
+// episode to episode (only __init__ clears it), and rand_obj looks at it: `st[0]` = (i | j << 4 | 0x100 valid) as the env's previous
+// episode left it, st[1] = as of the current attempt's checkpoint; out.gstate = as this episode leaves it.
+template <class R>
+MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, uint64_t* iw, uint32_t* st) {
+  const int flags = P.num_crossings;
+  MG_WAVE_LDS_SYNC();
+  uint32_t locked = uni32(out.resume ? st[1] : st[0]);
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    rng.checkpoint();
+    if (g.lane == 0) st[1] = locked;
+    bool fresh = false;
+    RG rg;
+    rg.gen_grid(rng, g, P.room_size);
+    out.aux = ~0ull; out.carry = 0; out.mission = 0; out.gstate = locked;
+    if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull;
+    int dx, dy, ti, ci;
+    // _rand_float(0, 1) = Generator.uniform: next_double = (next_uint64 >> 11) / 2^53
+    const double u = (double)(rng.next64() >> 11) * (1.0 / 9007199254740992.0);
+    if (u < (double)P.strip2_row / 100.0) {                   // add_locked_room (levelgen.py:82-111)
+      int dc = 0;
+      while (!rng.dead()) {
+        const int i = rand_int(rng, 0, rg.nc), j = rand_int(rng, 0, rg.nr), k = rand_int(rng, 0, 4);
+        locked = (uint32_t)i | ((uint32_t)j << 4) | 0x100u; fresh = true;
+        if (!rg.has_nb(i, j, k)) continue;
+        dc = rg.add_door(rng, g, i, j, k, -1, 1, dx, dy);
+        break;
+      }
+      while (!rng.dead()) {
+        const int i = rand_int(rng, 0, rg.nc), j = rand_int(rng, 0, rg.nr);
+        if (i == (int)(locked & 15u) && j == (int)((locked >> 4) & 15u)) continue;
+        rg.add_object(rng, g, i, j, 0, dc, ti, ci);
+        break;
+      }
+    }
+    if (!rg.ok || rng.dead()) continue;
+    rg.connect_all(rng, g, -1);
+    if (!rg.ok || rng.dead()) continue;
+#pragma unroll 1
+    for (int n = 0; n < P.num_dists && rg.ok && !rng.dead(); n++) {     // add_distractors(all_unique=False) over random rooms
+      const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
+      const int ri = rand_int(rng, 0, rg.nc), rj = rand_int(rng, 0, rg.nr);
+      rg.add_object(rng, g, ri, rj, t2, c2, ti, ci);
+    }
+    if (!rg.ok || rng.dead()) continue;
+    while (!rng.dead()) {
+      const int ai = rand_int(rng, 0, rg.nc), aj = rand_int(rng, 0, rg.nr);
+      rg.place_agent_in(rng, g, ai, aj, out);
+      if (!rg.ok || rng.dead()) break;
+      if (fresh && rg.ax / rg.st == (int)(locked & 15u) && rg.ay / rg.st == (int)((locked >> 4) & 15u)) continue;
+      break;
+    }
+    if (!rg.ok || rng.dead()) continue;
+    if (!((flags >> 8) & 1) && !maze_objs_reachable(g, rg.ax, rg.ay)) continue;
+    const Objs o = assign_ids(g, iw);
+    if (o.count > 63u) { out.failed = true; return; }
+    // rand_instr (levelgen.py:157-211) without the recursion: root = action | And(action, action) | Before / After(sub, sub), sub =
+    // action | And(action, action).  rand_obj (:113-155) = draw (colour | None, type, location?) until something matches.
+    bool fail = false;
+    uint32_t nleaf = 0, nnode = 0, navs = 0;
+    uint32_t node[3] = { 0u, 0u, 0u };
+    uint64_t lastset = 0;
+    auto rand_obj = [&](int types) -> uint32_t {              // types: 0 OBJ_TYPES, 1 OBJ_TYPES_NOT_DOOR, 2 ["door"]; returns desc9, set in lastset
+      for (int tries = 0; !rng.dead(); ) {
+        if (tries > 100) { fail = true; return 0u; }          // RecursionError("failed to find suitable object")
+        tries++;
+        const int c = rand_int(rng, 0, 7);                    // _rand_elem([None, *COLOR_NAMES])
+        const int tk = types == 2 ? 3 : rand_int(rng, 0, types == 1 ? 3 : 4);       // OBJ_TYPES = [box, ball, key, door]
+        const uint32_t t = tk == 0 ? (uint32_t)T_BOX : tk == 1 ? (uint32_t)T_BALL : tk == 2 ? (uint32_t)T_KEY : (uint32_t)T_DOOR;
+        uint32_t loc = 0;
+        if ((flags >> 7) & 1) if (rand_int(rng, 0, 2) == 0) loc = 1u + (uint32_t)rand_int(rng, 0, 4);
+        const uint32_t colp1 = c ? color_from_sorted((uint32_t)(c - 1)) + 1u : 0u;
+        const uint64_t set = desc_set(o, t, colp1, loc, rg.ax, rg.ay, out.dir, rg.rs);
+        if (set == 0ull) continue;
+        if (!((flags >> 9) & 1) && (locked & 0x100u)) {       // isinstance(self.locked_room, Room): possibly last episode's
+          const int tx = (int)(locked & 15u) * rg.st, ty = (int)((locked >> 4) & 15u) * rg.st;
+          const bool outside = ((set >> g.lane) & 1ull) && !(o.x >= tx && o.x < tx + rg.rs && o.y >= ty && o.y < ty + rg.rs);
+          if (__ballot(outside) == 0ull) continue;
+        }
+        lastset = set;
+        return desc9(t, colp1, loc, 0);
+      }
+      fail = true; return 0u;
+    };
+    auto action = [&]() -> uint32_t {                         // "action": one of the enabled verbs about random description(s)
+      uint32_t acts = 0; int na = 0;
+      for (int k = 0; k < 4; k++) if ((flags >> k) & 1) { acts |= (uint32_t)k << (2 * na); na++; }
+      const uint32_t verb = (acts >> (2 * rand_int(rng, 0, na))) & 3u;
+      uint32_t d9 = 0, f9 = 0; uint64_t ds = 0, fs = 0;
+      if (verb == V_GOTO) { d9 = rand_obj(0); ds = lastset; }
+      else if (verb == V_PICKUP) { d9 = rand_obj(1); ds = lastset; }
+      else if (verb == V_OPEN) { d9 = rand_obj(2); ds = lastset; }
+      else { d9 = rand_obj(1); ds = lastset; if (!fail) { f9 = rand_obj(0); fs = lastset; } }
+      if (fail || nleaf >= 4u) { fail = true; return 0u; }
+      sentence_leaf(g, iw, (int)nleaf, verb, d9, ds, f9, fs, 0);
+      navs += verb == V_PUTNEXT ? 2u : 1u;
+      return nleaf++;
+    };
+    auto and_node = [&]() -> uint32_t {
+      const uint32_t a = action();
+      const uint32_t b = fail ? 0u : action();
+      if (fail || nnode >= 3u) { fail = true; return 0u; }
+      node[nnode] = node8(N_AND, a, b);
+      return 4u + nnode++;
+    };
+    auto pick = [&](int kinds) -> int {                       // _rand_elem of the enabled instruction kinds (0 action, 1 and, 2 seq)
+      uint32_t list = 0; int nk = 0;
+      for (int k = 0; k < 3; k++) if ((kinds >> k) & 1) { list |= (uint32_t)k << (2 * nk); nk++; }
+      return (int)((list >> (2 * rand_int(rng, 0, nk))) & 3u);
+    };
+    uint32_t root;
+    {
+      const int kind = pick((flags >> 4) & 7);
+      if (kind == 0) root = action();
+      else if (kind == 1) root = and_node();
+      else {
+        const uint32_t a = pick(3) == 0 ? action() : and_node();
+        uint32_t b = 0;
+        if (!fail) b = pick(3) == 0 ? action() : and_node();
+        if (fail || nnode >= 3u) { fail = true; root = 0; }
+        else {
+          node[nnode] = node8(rand_int(rng, 0, 2) == 0 ? N_BEFORE : N_AFTER, a, b);
+          root = 4u + nnode++;
+        }
+      }
+    }
+    if (fail || rng.dead()) continue;
+    // validate_instrs (roomgrid_level.py:146-203)
+    MG_WAVE_LDS_SYNC();
+    bool reject = false;
+    uint32_t locked_colors = 0;
+    if ((flags >> 8) & 1) {
+      for (int base = 0; base < g.W * g.H; base += 64) {
+        const int q = base + g.lane;
+        const uint32_t v = q < g.W * g.H ? (uint32_t)g.p[q] : 0u;
+        const bool lk = q < g.W * g.H && cell_type(v) == T_DOOR_LOCKED;
+        for (uint32_t c = 0; c < 6u; c++) if (__ballot(lk && cell_color(v) == c)) locked_colors |= 1u << c;
+      }
+    }
+    for (uint32_t k = 0; k < nleaf; k++) {
+      const uint32_t l20 = (uint32_t)uni64(iw[IW_LEAF + k]) & 0xFFFFFu, verb = l20 & 3u, d9 = (l20 >> 2) & 511u, f9 = (l20 >> 11) & 511u;
+      const uint64_t ds = uni64(iw[IW_SET + 2 * k]), fs = uni64(iw[IW_SET + 2 * k + 1]);
+      if (verb == V_PUTNEXT) {
+        if (ds & fs) reject = true;                           // "there are objects that match both lhs and rhs of PutNext"
+        bool next = false;                                    // objs_next(): some object to move already lies next to a fixed one
+        const bool mine = (ds >> g.lane) & 1ull;
+        for (int m = 0; m < 63; m++)
+          if ((fs >> m) & 1ull) {
+            const int fxm = (int)lane32((uint32_t)o.x, (uint32_t)m), fym = (int)lane32((uint32_t)o.y, (uint32_t)m);
+            next |= mine && abs(o.x - fxm) + abs(o.y - fym) == 1;
+          }
+        if (__ballot(next)) reject = true;
+      }
+      if ((flags >> 8) & 1) {                                 // unblocking: "cannot do anything with/to a locked door's key"
+        if (desc9_type(d9) == T_KEY && desc9_color(d9) && ((locked_colors >> (desc9_color(d9) - 1u)) & 1u)) reject = true;
+        if (verb == V_PUTNEXT && desc9_type(f9) == T_KEY && desc9_color(f9) && ((locked_colors >> (desc9_color(f9) - 1u)) & 1u)) reject = true;
+      }
+    }
+    if (reject) continue;
+    // RoomGridLevel.reset (roomgrid_level.py:71-85): max_steps = num_navs_needed * room_size**2 * num_rows * num_cols
+    sentence_finish(g, iw, root, node, navs * (uint32_t)(rg.rs * rg.rs * rg.nc * rg.nr));
+    out.gstate = locked;
+    return;
+  }
+  out.gstate = locked;
+  out.failed = true;
+}
+
 // Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
 // pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
 // under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
@@ -1687,7 +2028,7 @@ MG_D void gen_babyai_put_open(R& rng, GridRef& g, const GenParams& P, GenResult&
 //   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
 //            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
 enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 53) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -1734,6 +2075,8 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
       case 36: case 37: case 38: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
       case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
+      case 50: case 51: case 52: gen_babyai_seq(rng, g, P, out, (uint64_t*)(g.p + P.instr_off)); return;
+      case 53: gen_levelgen(rng, g, P, out, (uint64_t*)(g.p + P.instr_off), (uint32_t*)(g.p + P.scratch_off)); return;
       default: break;
     }
   }

@@ -35,7 +35,7 @@ enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
               RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
-              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13, RULE_PUTNEXT = 14, RULE_OPENDOOR = 15 };
+              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13, RULE_PUTNEXT = 14, RULE_OPENDOOR = 15, RULE_SENTENCE = 16 };
 
 struct StepParams {
   // ---- state ----
@@ -147,6 +147,8 @@ struct GenArgs {
   uint8_t* dst_grid; uint64_t* dst_agent;            // slot 0 of the destination (ring or live state)
   uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state of slot s there first
   uint64_t* dst_aux;                                 // auxiliary word of the generated episode (GenResult.aux) or null
+  uint64_t* dst_instr;                               // sentence levels: [slot][N][INSTR_WORDS] instruction records, or null
+  uint32_t* gstate; uint32_t* gsnap;                 // LevelGen: generator state carried across episodes [N]; as it was before slot s [R][N]
   const uint8_t* mask;                               // direct mode: optional per-env mask
   uint32_t* err; unsigned long long* counters;
   int N, CS;
@@ -176,7 +178,10 @@ MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k 
 
 constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
 constexpr int GEN_SCRATCH_BYTES = 64;   // generator state that must survive a restart from a checkpoint (MultiRoom's room lists), at the end
-MG_HD int gen_wave_lds_bytes(int CS, int cap_words) { return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4 + GEN_SCRATCH_BYTES; }
+constexpr int GEN_INSTR_BYTES = INSTR_WORDS * 8;   // sentence levels: the instruction record under construction, after the scratch words
+MG_HD int gen_wave_lds_bytes(int CS, int cap_words, bool sentence = false) {
+  return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4 + GEN_SCRATCH_BYTES + (sentence ? GEN_INSTR_BYTES : 0);
+}
 
 // wave-cooperative: all 64 lanes of one wave call this with the same `e` and ring slot; `lds` = gen_wave_lds_bytes() of LDS
 template <int GG, class RNG>
@@ -192,6 +197,14 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
   for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
   GenResult out;
+  const int scratch0 = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
+  if (A.gstate) {
+    // LevelGen's locked_room: the generator state this env's previous episode left (mg_gen.h gen_levelgen); the value before this
+    // slot's episode is kept, like rng_snap, for restarts of the ring
+    const uint32_t gs = uni32(A.gstate[e]);
+    if (lane == 0) { ((uint32_t*)(mygrid + scratch0))[0] = gs; if (A.gsnap) A.gsnap[se] = gs; }
+  }
+  out.gstate = 0;
   // draw-budget loop: buffer `budget` draws, run the generator.  A pass that ran out of draws restarts from its
   // last checkpoint (GoToRedBall: the start of the current whole-map attempt) with a fresh buffer, or -- no
   // checkpoint passed -- is replayed from the start (same draws, same path) with twice the budget.  One refill
@@ -211,6 +224,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70.
     GenParams gp = A.gp;
     gp.scratch_off = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
+    gp.instr_off = gp.scratch_off + GEN_SCRATCH_BYTES;
     asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
     asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length), "+s"(gp.scratch_off));
     g.W = gp.W; g.H = gp.H;
@@ -230,11 +244,13 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   MG_WAVE_LDS_SYNC();
   uint4* dst = (uint4*)(A.dst_grid + se * A.CS);
   for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
+  if (A.dst_instr && lane < (uint32_t)INSTR_WORDS) A.dst_instr[se * INSTR_WORDS + lane] = ((const uint64_t*)(mygrid + scratch0 + GEN_SCRATCH_BYTES))[lane];
   if (lane == 0) {
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = out.carry; ag.step = 0; ag.mission = out.mission;
     ag.flags = flags_out | (out.carry ? FLAG_SHOW_TAKEN : 0u);
     A.dst_agent[se] = agent_pack(ag);
     if (A.dst_aux) A.dst_aux[se] = out.aux;
+    if (A.gstate) A.gstate[e] = out.gstate;
     if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
@@ -255,7 +271,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   MG_STAMP(0);
   RNG rng;
   rng.prefetch(lane);
-  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words);
+  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words, A.dst_instr != nullptr);
   const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
   for (int e = (int)blockIdx.x * (GEN_THREADS / 64) + wave; e < A.N; e += nwaves) {
     if (A.mask && !uni32(A.mask[e])) continue;
@@ -317,9 +333,11 @@ __global__ void k_gather_rng(const uint64_t* rng_snap, const uint32_t* head, uin
 }
 
 // reset(seed=...): the ring of the selected envs restarts (head = 0; the host then draws all R slots, tail = R)
-__global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* mask, uint32_t R, int N) {
+__global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* mask, uint32_t R, int N, uint32_t* gstate, const uint32_t* gsnap) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N || (mask && !mask[e])) return;
+  // LevelGen's generator state goes back to what it was after the LIVE episode was drawn (= before the next spare, like mg_get_rng)
+  if (gstate) gstate[e] = gsnap[(size_t)(head[e] & (R - 1u)) * (size_t)N + (size_t)e];
   head[e] = 0u; tail[e] = R;
 }
 
@@ -736,6 +754,7 @@ k_step(const StepParams P) {
           shadow_valid = false;
         }
         a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
+        if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
         rec_dirty = true; wb_all = true;
         if (!P.static_gen) h++;
       } else if (a.flags & FLAG_FRESH) {
@@ -1078,6 +1097,169 @@ k_step(const StepParams P) {
   if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
 }
 
+
+// ======================================================================================================
+// k_verify: RoomGridLevel.step's second half for the sentence levels (roomgrid_level.py:87-104): update_objs_poss after a drop,
+// instrs.verify(action), and -- because max_steps is per episode there (:71-85) -- truncation and the reward.  Runs after every
+// k_step launch of such a level (one step per launch) on the state k_step left in HBM; one lane per env.  k_step itself applies
+// the action, encodes the observation and takes the spare episode at a reset; it reports reward 0 / terminated 0 / truncated 0.
+// ======================================================================================================
+struct VerifyParams {
+  const uint8_t* grid; uint64_t* agent; uint64_t* instr; const uint64_t* spare_instr;
+  const uint32_t* head; uint32_t ring_mask;
+  uint8_t* rec;                      // the step record k_step just wrote
+  size_t off_reward, off_term, off_trunc, off_action, off_sentence;
+  uint32_t* err;
+  int N, W, H, CS, phase, autoreset_next_step;
+};
+struct InstrRef {
+  uint64_t* I; const uint8_t* g; int W, H;
+  uint32_t act, carry_id;            // carry_id: id + 1 of what the agent holds after the action
+  int fidx; bool inb;                // the cell in front of the agent after the action
+  uint32_t errbits;
+  MG_D uint16_t* pos() const { return (uint16_t*)(I + IW_POS); }
+  MG_D int id_at(int cell) const { const uint16_t* p = pos(); for (int i = 0; i < 63; i++) if ((int)p[i] == cell) return i; return -1; }
+  MG_D bool in_stale(int j, int cell) const {
+    const uint64_t s = I[IW_STALE + j];
+    bool hit = false;
+    for (int k = 0; k < 4; k++) hit |= (int)((s >> (16 * k)) & 0xFFFFull) == cell;
+    return hit;
+  }
+  // an object left `cell` without a refresh of obj_poss (picked up, or a box toggled away): every description tracking it keeps the cell
+  MG_D void left(int id, int cell) {
+    for (int j = 0; j < 8; j++)
+      if ((I[IW_SET + j] >> id) & 1ull) {
+        uint64_t s = I[IW_STALE + j];
+        int slot = -1;
+        for (int k = 3; k >= 0; k--) if (((s >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
+        if (slot < 0) errbits |= ERR_TRACKED;
+        else I[IW_STALE + j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
+      }
+  }
+  // verifier.py: GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431
+  MG_D uint32_t leaf(int k) {
+    const uint64_t L = I[IW_LEAF + k];
+    const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
+    const uint64_t dset = I[IW_SET + 2 * k], fset = I[IW_SET + 2 * k + 1];
+    if (verb == V_GOTO) {
+      if (!inb) return R_CONTINUE;
+      const uint32_t c = g[fidx];
+      bool hit = in_stale(2 * k, fidx);
+      if (!hit && c != CELL_EMPTY && cell_type(c) != T_WALL) { const int id = id_at(fidx); hit = id >= 0 && ((dset >> id) & 1ull); }
+      return hit ? R_SUCCESS : R_CONTINUE;
+    }
+    if (verb == V_OPEN) {
+      if (act != A_TOGGLE || !inb) return R_CONTINUE;
+      const uint32_t c = g[fidx];
+      if (cell_ref_type(c) != T_DOOR || cell_type(c) == T_BOX_KEY) return R_CONTINUE;
+      const int id = id_at(fidx);
+      if (id >= 0 && ((dset >> id) & 1ull) && cell_type(c) == T_DOOR) return R_SUCCESS;
+      return strict ? R_FAILURE : R_CONTINUE;
+    }
+    const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying: updated only when this leaf is looked at
+    I[IW_LEAF + k] = (L & ~(127ull << 21)) | ((uint64_t)carry_id << 21);
+    if (verb == V_PICKUP) {
+      if (act != A_PICKUP) return R_CONTINUE;
+      if (pre == 0u && carry_id != 0u && ((dset >> (carry_id - 1u)) & 1ull)) return R_SUCCESS;
+      return (strict && carry_id != 0u) ? R_FAILURE : R_CONTINUE;
+    }
+    if (strict && act == A_PICKUP && carry_id != 0u) return R_FAILURE;
+    if (act != A_DROP) return R_CONTINUE;
+    if (pre == 0u || !((dset >> (pre - 1u)) & 1ull)) return R_CONTINUE;
+    const uint32_t cur = pos()[pre - 1u];                                 // obj_a.cur_pos: where it was just dropped, or (-1, -1)
+    if (cur >= POS_GONE) return R_CONTINUE;
+    const int cx = (int)cur % W, cy = (int)cur / W;
+    bool next = false;
+    for (int m = 0; m < 63; m++)
+      if ((fset >> m) & 1ull) { const uint32_t q = pos()[m]; if (q < POS_GONE) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
+    const uint64_t sf = I[IW_STALE + 2 * k + 1];
+    for (int j = 0; j < 4; j++) { const uint32_t q = (uint32_t)(sf >> (16 * j)) & 0xFFFFu; if (q != 0xFFFFu) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
+    return next ? R_SUCCESS : R_CONTINUE;
+  }
+};
+__global__ void k_verify(const VerifyParams V) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= V.N) return;
+  Agent a = agent_unpack(V.agent[e]);
+  uint64_t* I = V.instr + (size_t)e * INSTR_WORDS;
+  uint64_t* sent = (uint64_t*)(V.rec + V.off_sentence) + (size_t)e * 2;
+  if (a.flags & FLAG_NEW_EPISODE) {
+    // k_step took the env's next spare episode in this launch (reset, autoreset): its instruction record comes with it
+    const uint64_t* src = V.spare_instr + ((size_t)((V.head[e] - 1u) & V.ring_mask) * (size_t)V.N + (size_t)e) * INSTR_WORDS;
+    for (int k = 0; k < INSTR_WORDS; k++) I[k] = src[k];
+    a.flags &= ~FLAG_NEW_EPISODE;
+    V.agent[e] = agent_pack(a);
+    sent[0] = src[IW_MISSION]; sent[1] = src[IW_MISSION + 1];
+    return;
+  }
+  sent[0] = I[IW_MISSION]; sent[1] = I[IW_MISSION + 1];
+  if (V.phase != PHASE_STEP) return;
+  InstrRef R;
+  R.I = I; R.g = V.grid + (size_t)e * V.CS; R.W = V.W; R.H = V.H; R.errbits = 0;
+  R.act = V.rec[V.off_action + e];
+  const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+  R.inb = (unsigned)fx < (unsigned)V.W && (unsigned)fy < (unsigned)V.H;
+  R.fidx = R.inb ? fy * V.W + fx : 0;
+  uint64_t Hd = I[0];
+  uint32_t carry_id = (uint32_t)(Hd >> 55) & 127u;
+  // object identity through the action (minigrid_env.py:556-577): a pickup / drop shows as a change of `carrying`
+  if (a.carry != 0u && carry_id == 0u && R.inb) {
+    const int id = R.id_at(R.fidx);
+    if (id >= 0) { carry_id = (uint32_t)id + 1u; R.pos()[id] = (uint16_t)POS_CARRIED; R.left(id, R.fidx); }
+    else R.errbits |= ERR_TRACKED;
+  } else if (a.carry == 0u && carry_id != 0u && R.inb) {
+    R.pos()[carry_id - 1u] = (uint16_t)R.fidx; carry_id = 0u;
+  } else if (R.act == A_TOGGLE && R.inb && R.g[R.fidx] == CELL_EMPTY) {
+    const int id = R.id_at(R.fidx);                                       // a box was opened: Box.toggle replaces it by its (empty) content
+    if (id >= 0) { R.pos()[id] = (uint16_t)POS_GONE; R.left(id, R.fidx); }
+  }
+  R.carry_id = carry_id;
+  if (R.act == A_DROP) for (int j = 0; j < 8; j++) I[IW_STALE + j] = ~0ull;          // update_objs_poss (roomgrid_level.py:92-93, 106-117)
+  // instrs.verify(action): leaf | And (verifier.py:556-571) | Before / After (:464-486, :507-529) over leaves or And nodes
+  const uint32_t root = (uint32_t)Hd & 7u;
+  auto nodef = [&](uint32_t n) -> uint32_t { return (uint32_t)(Hd >> (3 + 8 * n)) & 255u; };
+  auto done_get = [&](uint32_t n, int which) -> uint32_t { return (uint32_t)(Hd >> (27 + 4 * n + 2 * which)) & 3u; };
+  auto done_set = [&](uint32_t n, int which, uint32_t v) { Hd = (Hd & ~(3ull << (27 + 4 * n + 2 * which))) | ((uint64_t)v << (27 + 4 * n + 2 * which)); };
+  auto and_verify = [&](uint32_t n) -> uint32_t {
+    const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
+    if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, R.leaf((int)ia));
+    if (done_get(n, 1) != R_SUCCESS) done_set(n, 1, R.leaf((int)ib));
+    return (done_get(n, 0) == R_SUCCESS && done_get(n, 1) == R_SUCCESS) ? (uint32_t)R_SUCCESS : (uint32_t)R_CONTINUE;
+  };
+  auto sub_verify = [&](uint32_t idx) -> uint32_t { return idx < 4u ? R.leaf((int)idx) : and_verify(idx - 4u); };
+  uint32_t status;
+  if (root < 4u) status = R.leaf((int)root);
+  else {
+    const uint32_t n = root - 4u, nd = nodef(n), kind = nd & 3u, ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
+    if (kind == N_AND) status = and_verify(n);
+    else {
+      const uint32_t first = kind == N_BEFORE ? ia : ib, second = kind == N_BEFORE ? ib : ia;
+      const int wf = kind == N_BEFORE ? 0 : 1, ws = 1 - wf;
+      status = R_CONTINUE;
+      bool look_at_second = done_get(n, wf) == R_SUCCESS;
+      if (!look_at_second) {
+        const uint32_t r = sub_verify(first);
+        done_set(n, wf, r);
+        if (r == R_FAILURE) status = R_FAILURE;
+        look_at_second = r == R_SUCCESS;                                  // "return self.verify(action)": the second one sees this action too
+      }
+      if (look_at_second) {
+        const uint32_t r = sub_verify(second);
+        done_set(n, ws, r);
+        if (r != R_CONTINUE) status = r;
+      }
+    }
+  }
+  Hd = (Hd & ~(127ull << 55)) | ((uint64_t)carry_id << 55);
+  I[0] = Hd;
+  const uint32_t max_steps = (uint32_t)(Hd >> 39) & 0xFFFFu;
+  const uint32_t term = status != R_CONTINUE, trunc = a.step >= max_steps;
+  *(double*)(V.rec + V.off_reward + (size_t)e * 8) = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
+  V.rec[V.off_term + e] = (uint8_t)term;
+  V.rec[V.off_trunc + e] = (uint8_t)trunc;
+  if ((term | trunc) && V.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; V.agent[e] = agent_pack(a); }
+  if (R.errbits) report_errors(V.err, R.errbits);
+}
 
 // DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
 // front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood

@@ -197,6 +197,7 @@ struct WavePcg64 {
   uint64_t* sbase;             // LDS: stream state after r refills (hi, lo), r < GEN_SBASE_ENTRIES
   u128 inc;                    // wave-uniform
   uint32_t off, limit, wpos, refills, cache_in, lane, ck;
+  uint32_t swap_at;            // next64() with a half cached: draws swap_at .. swap_at + 2 come from words swap_at + 1, + 2, + 0
   uint32_t reg_even, reg_odd;  // per lane: logical draws 2*lane and 2*lane+1 (the first 128 draws live in registers:
                                // v_readlane is ~10x quicker than the LDS round trip, and most episodes need < 128)
   u128 reg_st;                 // per lane: stream state after lane+1 outputs of the first refill
@@ -212,7 +213,7 @@ struct WavePcg64 {
     off = (uint32_t)(w_in[4] >> 32) & 1u; cache_in = (uint32_t)w_in[4];
     sbase[0] = w_in[0]; sbase[1] = w_in[1];
     buf[0] = cache_in;                       // overwritten by stream word 0 when nothing was carried in
-    refills = 0; limit = off; wpos = 0;
+    refills = 0; limit = off; wpos = 0; swap_at = 0x80000000u;
     MG_WAVE_LDS_SYNC();
   }
   MG_D void refill() {
@@ -236,20 +237,33 @@ struct WavePcg64 {
     refills++; limit = off + kRefillWords * refills;
     MG_WAVE_LDS_SYNC();
   }
-  MG_D void begin_pass() { wpos = 0; ck = 0; }
+  MG_D void begin_pass() { wpos = 0; ck = 0; swap_at = 0x80000000u; }
   MG_D bool dead() const { return wpos > limit; }
   MG_D void checkpoint() { ck = wpos; }     // a restart point of the generator: nothing before it is needed again
+  MG_D uint32_t word_of(uint32_t p) const { const uint32_t d = p - swap_at; return d < 3u ? swap_at + (d == 2u ? 0u : d + 1u) : p; }
   MG_D uint32_t next32() {
     uint32_t v;
-    if (__builtin_expect(wpos < 128u, 1)) v = (wpos & 1u) ? lane32(reg_odd, wpos >> 1) : lane32(reg_even, wpos >> 1);
-    else v = uni32(buf[wpos < limit ? wpos : 0u]);
+    const uint32_t q = word_of(wpos);
+    if (__builtin_expect(q < 128u, 1)) v = (q & 1u) ? lane32(reg_odd, q >> 1) : lane32(reg_even, q >> 1);
+    else v = uni32(buf[wpos < limit ? q : 0u]);
     wpos++;
     return v;
+  }
+  // numpy's next_uint64 (Generator.uniform / random): a whole raw output, low half first.  It does not look at the cached 32-bit
+  // half (pcg64_next64 leaves has_uint32 alone): with a half cached, the NEXT output is taken and the cached half stays for the
+  // 32-bit draw after it.  In the linear draw order kept here that is a rotation of three words.  The generator must make at least
+  // one more 32-bit draw before it ends or sets a checkpoint (LevelGen always does).
+  MG_D uint64_t next64() {
+    const bool cached = wpos < off || (((wpos - off) & 1u) != 0u);
+    if (cached) swap_at = wpos;
+    const uint32_t lo = next32(), hi = next32();
+    return (uint64_t)lo | ((uint64_t)hi << 32);
   }
   // lane-parallel look-ahead for speculative rejection sampling: logical draw p (a different p per lane) out of the
   // register window; only meaningful for p < window()
   MG_D uint32_t window() const { return limit < 128u ? limit : 128u; }
-  MG_D uint32_t peek_lane(uint32_t p) const {
+  MG_D uint32_t peek_lane(uint32_t p_) const {
+    const uint32_t p = word_of(p_);
     const uint32_t e = (uint32_t)__shfl((int)reg_even, (int)(p >> 1)), o = (uint32_t)__shfl((int)reg_odd, (int)(p >> 1));
     return (p & 1u) ? o : e;
   }
@@ -263,7 +277,7 @@ struct WavePcg64 {
     off = (uint32_t)(w[4] >> 32) & 1u; cache_in = (uint32_t)w[4];
     sbase[0] = w[0]; sbase[1] = w[1];
     buf[0] = cache_in;
-    refills = 0; limit = off; wpos = 0; ck = 0;
+    refills = 0; limit = off; wpos = 0; ck = 0; swap_at = 0x80000000u;
     MG_WAVE_LDS_SYNC();
   }
   MG_D void words_at(uint32_t pos, uint64_t w[5]) const {
@@ -337,6 +351,7 @@ struct WavePhilox {
     wpos++;
     return v;
   }
+  MG_D uint64_t next64() { const uint32_t lo = next32(), hi = next32(); return (uint64_t)lo | ((uint64_t)hi << 32); }
   MG_D uint32_t window() const { const uint32_t w = limit + skip < 256u ? limit + skip : 256u; return w - skip; }
   MG_D uint32_t peek_lane(uint32_t p) const {
     const uint32_t q = p + skip, l = q >> 2, k = q & 3u;

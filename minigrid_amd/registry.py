@@ -23,6 +23,7 @@ ENV_BABYAI_GOTO, ENV_BABYAI_PICKUP, ENV_BABYAI_OPEN = 33, 34, 35
 ENV_BABYAI_UNLOCKPICKUP, ENV_BABYAI_BLOCKEDUNLOCKPICKUP, ENV_UNLOCKTOUNLOCK, ENV_BABYAI_UNLOCK = 36, 37, 38, 40
 ENV_BABYAI_GOTODOOR, ENV_GOTOOBJDOOR, ENV_UNBLOCKPICKUP, ENV_PICKUPABOVE, ENV_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
 ENV_PUTNEXTLOCAL, ENV_PUTNEXT, ENV_ACTIONOBJDOOR, ENV_OPENDOOR = 46, 47, 48, 49
+ENV_OPENTWODOORS, ENV_OPENDOORSORDER, ENV_MOVETWOACROSS, ENV_LEVELGEN = 50, 51, 52, 53      # the sentence levels
 OBJ_WALL, OBJ_LAVA = 2, 9
 
 
@@ -328,6 +329,38 @@ _ROWS = [
               room_size=8, num_crossings=sel, strip2_row=int(dbg), entry_point="minigrid.envs.babyai:OpenDoor", kwargs=kw)
       for name, sel, dbg, kw in (("BabyAI-OpenDoor-v0", 0, False, {}), ("BabyAI-OpenDoorDebug-v0", 0, True, {"debug": True, "select_by": None}),
                                  ("BabyAI-OpenDoorColor-v0", 1, False, {"select_by": "color"}), ("BabyAI-OpenDoorLoc-v0", 2, False, {"select_by": "loc"}))],
+    # the sentence levels: the mission is an instruction tree, delivered as data and turned into the sentence on the host
+    # (minigrid_amd/sentence.py); no mission-id table.  envs/babyai/open.py:289-325 (OpenTwoDoors; first / second colour as COLOR_NAMES
+    # indices in agent_start), :383-425 (OpenDoorsOrder), other.py:388-428 (MoveTwoAcross): fixed max_steps
+    *[EnvSpec(name, ENV_OPENTWODOORS, 16, 16, 720, False, ("",), room_size=6, agent_start=(c1, c2, 0), strip2_row=int(strict),
+              entry_point="minigrid.envs.babyai:OpenTwoDoors", kwargs=kw)
+      for name, c1, c2, strict, kw in (("BabyAI-OpenTwoDoors-v0", -1, -1, False, {}),
+                                       ("BabyAI-OpenRedBlueDoors-v0", 4, 0, False, {"first_color": "red", "second_color": "blue"}),
+                                       ("BabyAI-OpenRedBlueDoorsDebug-v0", 4, 0, True, {"first_color": "red", "second_color": "blue", "strict": True}))],
+    *[EnvSpec(f"BabyAI-OpenDoorsOrderN{n}{'Debug' if dbg else ''}-v0", ENV_OPENDOORSORDER, 16, 16, 720, False, ("",), room_size=6, num_dists=n,
+              strip2_row=int(dbg), entry_point="minigrid.envs.babyai:OpenDoorsOrder", kwargs={"num_doors": n, **({"debug": True} if dbg else {})})
+      for n, dbg in ((2, False), (4, False), (2, True), (4, True))],
+    *[EnvSpec(f"BabyAI-MoveTwoAcrossS{rs}N{n}-v0", ENV_MOVETWOACROSS, 2 * (rs - 1) + 1, rs, 16 * rs * rs, False, ("",), room_size=rs, num_dists=n,
+              entry_point="minigrid.envs.babyai:MoveTwoAcross", kwargs={"room_size": rs, "objs_per_room": n})
+      for rs, n in ((5, 2), (8, 9))],
+    # LevelGen (envs/babyai/core/levelgen.py:24-80) configurations: pickup.py:198-213, goto.py:590-606, synth.py:83-97, :168-178, :274-281,
+    # :374-382, :476-480, :570-576.  max_steps is per episode (num_navs * room_size**2 * rooms, applied on the device); the value here is
+    # what the reference's env holds after gym.make + reset(seed=0) (tests/golden/reference_registry.json).  BabyAI-SynthS5R2-v0 is
+    # left out: the reference itself can spin for ever in place_agent there
+    *[EnvSpec(name, ENV_LEVELGEN, cols * (rs - 1) + 1, rows * (rs - 1) + 1, ms, False, ("",), room_size=rs, num_dists=nd, strip2_row=pct,
+              num_crossings=acts | kinds << 4 | int(loc) << 7 | int(unb) << 8 | int(imp) << 9,
+              entry_point="minigrid.envs.babyai:" + cls, kwargs=kw)
+      for name, cls, rs, rows, cols, nd, acts, kinds, loc, unb, imp, pct, ms, kw in (
+          ("BabyAI-PickupLoc-v0", "PickupLoc", 8, 1, 1, 8, 0b0010, 0b001, True, False, True, 0, 64, {}),
+          ("BabyAI-GoToSeq-v0", "GoToSeq", 8, 3, 3, 18, 0b0001, 0b111, False, False, True, 0, 2304, {}),
+          ("BabyAI-GoToSeqS5R2-v0", "GoToSeq", 5, 2, 2, 4, 0b0001, 0b111, False, False, True, 0, 100,
+           {"room_size": 5, "num_rows": 2, "num_cols": 2, "num_dists": 4}),
+          ("BabyAI-Synth-v0", "Synth", 8, 3, 3, 18, 0b1111, 0b001, False, True, False, 50, 1152, {}),
+          ("BabyAI-SynthLoc-v0", "SynthLoc", 8, 3, 3, 18, 0b1111, 0b001, True, True, False, 50, 1152, {}),
+          ("BabyAI-SynthSeq-v0", "SynthSeq", 8, 3, 3, 18, 0b1111, 0b111, True, True, False, 50, 2880, {}),
+          ("BabyAI-MiniBossLevel-v0", "MiniBossLevel", 5, 2, 2, 7, 0b1111, 0b111, True, True, True, 25, 100, {}),
+          ("BabyAI-BossLevel-v0", "BossLevel", 8, 3, 3, 18, 0b1111, 0b111, True, True, True, 50, 2880, {}),
+          ("BabyAI-BossLevelNoUnlock-v0", "BossLevelNoUnlock", 8, 3, 3, 18, 0b1111, 0b111, True, True, False, 0, 2880, {}))],
     _roomgrid_1x2("MiniGrid-Unlock-v0", ENV_UNLOCK, 6, 8 * 36, ("open the door",), "minigrid.envs:UnlockEnv"),
     _roomgrid_1x2("MiniGrid-UnlockPickup-v0", ENV_UNLOCKPICKUP, 6, 8 * 36,
                   tuple(f"pick up the {c} box" for c in _COLOR_NAMES), "minigrid.envs:UnlockPickupEnv"),

@@ -137,9 +137,16 @@ class MiniGridVecEnv(_VectorEnvBase):
                             "rgb_partial": (v * self.tile_size, v * self.tile_size, 3),
                             "rgb": (s.height * self.tile_size, s.width * self.tile_size, 3)}[obs_mode]
         self._missions = np.asarray(s.missions)
+        # sentence levels (instruction trees: GoToSeq, Synth*, BossLevel*, OpenTwoDoors, ...): the mission arrives as data
+        self.sentence = bool(outs.sentence)
+        if self.sentence:
+            from .sentence import SentenceDecoder
+            self._decode_sentences = SentenceDecoder()
+            self._h_sent = np.empty((self.num_envs, 2), np.uint64)
         # DictObservationSpaceWrapper (wrappers.py:429-554): mission string -> padded word-index vector, per mission id.  Its fixed
         # vocabulary lacks some BabyAI words ("next", "on", "left", ...): like the reference, wrapping such a level raises ValueError
-        self._mission_tokens = np.asarray([string_to_indices(m) for m in s.missions], np.int64) if self.dict_mission else None
+        self._mission_tokens = (np.asarray([string_to_indices(m) for m in s.missions], np.int64)
+                                if self.dict_mission and not self.sentence else None)
         self._seeded = False
         # spaces (minigrid_env.py:63, 72-84; FullyObsWrapper wrappers.py:404-417; ImgObsWrapper :211)
         # image spaces as the reference wrappers declare them (wrappers.py:263-267, 404-411, 655-662, 749-758)
@@ -197,14 +204,16 @@ class MiniGridVecEnv(_VectorEnvBase):
                 "action": _DeviceArray(o.action + off, (n,), "|u1", self),
                 # the whole step as ONE contiguous byte record (obs | reward | terminated | truncated | direction |
                 # mission | action): what a multi-GPU consumer all-gathers (minigrid_amd/sharded.py)
-                "record": _DeviceArray(o.obs + off, (int(o.record_bytes),), "|u1", self)}
+                "record": _DeviceArray(o.obs + off, (int(o.record_bytes),), "|u1", self),
+                # sentence levels: the mission as data (minigrid_amd/sentence.py decodes it), two u64 per env
+                **({"sentence": _DeviceArray(o.sentence + off, (n, 2), "<u8", self)} if o.sentence else {})}
 
     def record_layout(self) -> dict:
         """Byte offsets of the fields inside a step record (device_outputs()["record"])."""
         o = self._outs
         return {"image": 0, "reward": o.reward - o.obs, "terminated": o.terminated - o.obs, "truncated": o.truncated - o.obs,
                 "direction": o.direction - o.obs, "mission_id": o.mission_id - o.obs, "action": o.action - o.obs,
-                "record_bytes": int(o.record_bytes)}
+                "record_bytes": int(o.record_bytes), **({"sentence": o.sentence - o.obs} if o.sentence else {})}
 
     def torch_outputs(self, slot: int = 0) -> dict:
         """The same buffers as torch CUDA tensors (no copy)."""
@@ -246,8 +255,14 @@ class MiniGridVecEnv(_VectorEnvBase):
         if self.image_only:
             obs = image
         else:
-            obs = {"image": image, "direction": self._h_dir.astype(np.int64),
-                   "mission": self._mission_tokens[self._h_mis] if self.dict_mission else self._missions[self._h_mis]}
+            if self.sentence:
+                B.check(self._lib.mg_copy_sentence(self._h, 0, self._p(self._h_sent)), self._h)
+                mission = self._decode_sentences(self._h_sent)
+                if self.dict_mission:
+                    mission = np.asarray([string_to_indices(m) for m in mission], np.int64)
+            else:
+                mission = self._mission_tokens[self._h_mis] if self.dict_mission else self._missions[self._h_mis]
+            obs = {"image": image, "direction": self._h_dir.astype(np.int64), "mission": mission}
         return obs, self._h_rew.copy(), self._h_term.astype(bool), self._h_trunc.astype(bool)
 
     # ------------------------------------------------------------------ Gymnasium VectorEnv surface

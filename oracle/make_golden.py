@@ -951,18 +951,19 @@ WIDE2_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0"
              "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
              "BabyAI-PutNextS5N2Carrying-v0", "BabyAI-PutNextS6N3Carrying-v0", "BabyAI-PutNextS7N4Carrying-v0", "BabyAI-ActionObjDoor-v0",
              "BabyAI-OpenDoor-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-OpenDoorColor-v0", "BabyAI-OpenDoorLoc-v0"]
+# the sentence levels: instruction trees (Before / After / And), object identity, per-episode max_steps; missions are sentences
+SENTENCE_IDS = ["BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
+                "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0", "BabyAI-MoveTwoAcrossS5N2-v0",
+                "BabyAI-MoveTwoAcrossS8N9-v0", "BabyAI-PickupLoc-v0", "BabyAI-GoToSeq-v0", "BabyAI-GoToSeqS5R2-v0",
+                "BabyAI-Synth-v0", "BabyAI-SynthLoc-v0", "BabyAI-SynthSeq-v0", "BabyAI-MiniBossLevel-v0",
+                "BabyAI-BossLevel-v0", "BabyAI-BossLevelNoUnlock-v0"]
 
-# restated and pinned in the oracle, not yet built on the device (kept out of the GPU test lists)
-ORACLE_ONLY_IDS = ["BabyAI-KeyInBox-v0", "BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
-                   "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0",
-                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0",
-                   "BabyAI-PickupLoc-v0", "BabyAI-GoToSeq-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-Synth-v0",
-                   "BabyAI-SynthLoc-v0", "BabyAI-SynthSeq-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-BossLevel-v0",
-                   "BabyAI-BossLevelNoUnlock-v0"]
+# restated and pinned in the oracle, not built on the device (kept out of the GPU test lists)
+ORACLE_ONLY_IDS = ["BabyAI-KeyInBox-v0", ]
 
 
 def main_oracle_only():
-    for env_id in WIDE2_IDS + ORACLE_ONLY_IDS:
+    for env_id in WIDE2_IDS + SENTENCE_IDS + ORACLE_ONLY_IDS:
         np.savez_compressed(os.path.join(OUT, f"rollout_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 3, 1337], 400))
         np.savez_compressed(os.path.join(OUT, f"gen_{env_id}.npz"), **make_gen(env_id, 64))
         print("done", env_id, flush=True)

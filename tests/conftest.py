@@ -54,7 +54,13 @@ WIDE2_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0"
              "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
              "BabyAI-PutNextS5N2Carrying-v0", "BabyAI-PutNextS6N3Carrying-v0", "BabyAI-PutNextS7N4Carrying-v0", "BabyAI-ActionObjDoor-v0",
              "BabyAI-OpenDoor-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-OpenDoorColor-v0", "BabyAI-OpenDoorLoc-v0"]
-ALL_IDS = MAIN_IDS + EXTRA_IDS + WIDE_IDS + WIDE2_IDS
+# the sentence levels: instruction trees (Before / After / And), object identity, per-episode max_steps; missions are sentences
+SENTENCE_IDS = ["BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
+                "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0", "BabyAI-MoveTwoAcrossS5N2-v0",
+                "BabyAI-MoveTwoAcrossS8N9-v0", "BabyAI-PickupLoc-v0", "BabyAI-GoToSeq-v0", "BabyAI-GoToSeqS5R2-v0",
+                "BabyAI-Synth-v0", "BabyAI-SynthLoc-v0", "BabyAI-SynthSeq-v0", "BabyAI-MiniBossLevel-v0",
+                "BabyAI-BossLevel-v0", "BabyAI-BossLevelNoUnlock-v0"]
+ALL_IDS = MAIN_IDS + EXTRA_IDS + WIDE_IDS + WIDE2_IDS + SENTENCE_IDS
 
 
 # an abort inside the HIP / HSA runtime leaves no message: have the library print the native backtrace first (mg_api.hip)
@@ -71,12 +77,7 @@ def golden(name):
 
 
 # restated and pinned in the oracle only (oracle groundwork for the next widening step): not in the GPU lists
-ORACLE_ONLY_IDS = ["BabyAI-KeyInBox-v0", "BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-OpenRedBlueDoorsDebug-v0", "BabyAI-OpenDoorsOrderN2-v0",
-                   "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-OpenDoorsOrderN2Debug-v0", "BabyAI-OpenDoorsOrderN4Debug-v0",
-                   "BabyAI-MoveTwoAcrossS5N2-v0", "BabyAI-MoveTwoAcrossS8N9-v0",
-                   "BabyAI-PickupLoc-v0", "BabyAI-GoToSeq-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-Synth-v0",
-                   "BabyAI-SynthLoc-v0", "BabyAI-SynthSeq-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-BossLevel-v0",
-                   "BabyAI-BossLevelNoUnlock-v0"]
+ORACLE_ONLY_IDS = ["BabyAI-KeyInBox-v0", ]
 
 
 def full_obs_supported(env_id: str) -> bool:

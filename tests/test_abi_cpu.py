@@ -28,7 +28,7 @@ def test_config_struct_layout_matches_header():
     assert B.MgConfig.env_index_base.offset == 96
     assert B.MgConfig.tile_size.offset == 104 and B.MgConfig.rgb_highlight.offset == 108
     assert B.MgConfig.spare_ring.offset == 112 and B.MgConfig.traj_slots.offset == 116
-    assert C.sizeof(B.MgOutputs) == 104 and B.MgOutputs.action.offset == 64 and B.MgOutputs.max_fused_steps.offset == 96
+    assert C.sizeof(B.MgOutputs) == 112 and B.MgOutputs.action.offset == 64 and B.MgOutputs.max_fused_steps.offset == 96 and B.MgOutputs.sentence.offset == 104
 
 
 @pytest.mark.parametrize("obe", [147, 243, 27, 75, 363, 507, 675, 192, 980, 49, 64, 361 * 3, 5, 6, 7, 8, 9])
@@ -133,8 +133,12 @@ def test_registry_rows_match_oracle_table():
     from oracle import oracle as O
     for env_id, row in mg.registry.items():
         o = O.spec(env_id)
-        assert (row.env_kind, row.width, row.height, row.max_steps, int(row.see_through_walls)) == \
-               (o["kind"], o["width"], o["height"], o["max_steps"], o["see_through"]), env_id
+        if o["kind"] == O.K_LEVELGEN:      # per-episode max_steps: the oracle's row holds the 1-nav value, the registry the reference env's
+            assert row.max_steps % o["max_steps"] == 0, env_id
+        else:
+            assert row.max_steps == o["max_steps"], env_id
+        assert (row.env_kind, row.width, row.height, int(row.see_through_walls)) == (o["kind"], o["width"], o["height"], o["see_through"]), env_id
+        assert row.strip2_row == o.get("strip2_row", 0) or o["kind"] not in (O.K_LEVELGEN, O.K_OPENTWODOORS, O.K_OPENDOORSORDER), env_id
         assert list(row.missions) == o["missions"]
         assert row.num_crossings == o.get("num_crossings", 0) and row.num_dists == o.get("num_dists", 0)
 
@@ -227,7 +231,7 @@ def test_mg_create_valid_config_needs_a_device():
 
 def test_registry_rows_are_consistent():
     import minigrid_amd as mg
-    assert len(mg.registry) == 152
+    assert len(mg.registry) == 170
     for env_id, s in mg.registry.items():
         assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
         assert s.entry_point.startswith("minigrid.envs")
@@ -286,8 +290,8 @@ def test_golden_generator_id_lists_match_the_test_lists():
     for node in ast.parse(src).body:
         if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
             name = node.targets[0].id
-            if name in ("MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "ORACLE_ONLY_IDS"):
+            if name in ("MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "SENTENCE_IDS", "ORACLE_ONLY_IDS"):
                 lists[name] = ast.literal_eval(node.value)
     for name, ids in lists.items():
         assert ids == getattr(conftest, name), name
-    assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "ORACLE_ONLY_IDS"}
+    assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "SENTENCE_IDS", "ORACLE_ONLY_IDS"}
