@@ -138,7 +138,8 @@ static GenArgs gen_args(mg_env* e, int slot) {
   A.gstate = e->sentence ? e->gstate : nullptr; A.gsnap = (e->sentence && to_spare) ? e->gsnap + s * N : nullptr;
   A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
-  A.N = e->N; A.CS = e->CS; A.cap_words = 2048; A.stat_gen_off = STAT_EPISODES + e->nwaves;
+  A.N = e->N; A.CS = e->CS; A.stat_gen_off = STAT_EPISODES + e->nwaves;
+  A.cap_words = e->sentence ? 4864 : 2048;   // LevelGen: up to 100 tries per description (levelgen.py:113-155); 38 PCG refills (GEN_SBASE_ENTRIES)
   A.live = 0;
   A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
@@ -168,7 +169,7 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.seg = e->seg + (size_t)set * e->nwaves * e->seg_cap;
   A.seg_count = e->seg_count + (size_t)set * e->nwaves;
   A.epoch = epoch;
-  A.cap_words = 1024;                         // a pass that runs out of buffered draws restarts from its checkpoint / doubles
+  A.cap_words = e->sentence ? 4864 : 1024;    // a pass that runs out of buffered draws restarts from its checkpoint / doubles
   A.wps = std::max(1, e->epw / 4);            // a GoToRedBall batch files ~EPW/7 requests per segment (Poisson: some segments twice that)
   if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
@@ -777,6 +778,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       }
     }
   }
+  if (e->sentence) {
+    // 19 KB of buffered draws per generating wave: the direct generator launch (4 waves per workgroup) needs more than 64 KB of LDS
+    const int need = (GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, 4864, true);
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<WavePcg64>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<WavePhilox>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+  }
 #undef TRY_OR_FREE
   (void)env;
   // a usable state from the start: env i seeded with its global index (like reset(seed=env_index_base + i))
@@ -786,6 +793,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (rc != MG_OK) { g_create_error = e->last_error; mg_destroy(e); return rc; }
   rc = mg_sync(e);
   if (rc != MG_OK) { g_create_error = e->last_error; mg_destroy(e); return rc; }
+  if (e->sentence) {
+    // the episodes drawn above are a convenience, not part of the env's history: LevelGen's locked_room (generator state carried from
+    // episode to episode) starts out None for the caller's first reset(seed=...), as after gym.make
+    (void)hipMemsetAsync(e->gstate, 0, N * sizeof(uint32_t), e->stream);
+    (void)hipMemsetAsync(e->gsnap, 0, R * N * sizeof(uint32_t), e->stream);
+    (void)hipStreamSynchronize(e->stream);
+  }
   *out = e;
   return MG_OK;
 }
@@ -813,12 +827,12 @@ int mg_destroy(mg_env* e) {
 }
 
 // draw every ring slot of the selected envs from their current stream position (head = 0, tail = R)
-static int refill_whole_ring(mg_env* e, const uint8_t* d_mask) {
+static int refill_whole_ring(mg_env* e, const uint8_t* d_mask, bool restore_gstate = true) {
   if (e->live_gen) return MG_OK;
   const int tb = 256, nb = (e->N + tb - 1) / tb;
   if (uses_ring(e)) {
     hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, e->stream, e->head, e->tail, d_mask, (uint32_t)e->R, e->N,
-                       e->sentence ? e->gstate : nullptr, e->sentence ? e->gsnap : nullptr);
+                       (e->sentence && restore_gstate) ? e->gstate : nullptr, e->sentence ? e->gsnap : nullptr);
     HIP_TRY(e, hipGetLastError());
   }
   for (int s = 0; s < e->R; s++) { int rc = launch_generate(e, s, d_mask); if (rc) return rc; }
@@ -844,9 +858,14 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     else
       hipLaunchKernelGGL(k_seed<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->rng, e->seeds, d_mask, N);
     HIP_TRY(e, hipGetLastError());
+    if (e->sentence) {
+      // LevelGen's generator state (locked_room) continues from the LIVE episode, not from the spares drawn ahead of it
+      hipLaunchKernelGGL(k_gstate_restore, dim3(nb), dim3(tb), 0, e->stream, e->gstate, e->gsnap, e->head, d_mask, (uint32_t)e->R, N);
+      HIP_TRY(e, hipGetLastError());
+    }
     int rc = launch_generate(e, -1, d_mask);
     if (rc) return rc;
-    rc = refill_whole_ring(e, d_mask);
+    rc = refill_whole_ring(e, d_mask, false);
     if (rc) return rc;
   } else if (e->live_gen) {
     // reset(): continue each env's stream from where its last step left it

@@ -211,7 +211,8 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   // covers every DoorKey/Crossing episode; GoToRedBall (about 60 draws per attempt, 15.6 % of attempts rejected)
   // starts with three.
   const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
-  const uint32_t budget0 = A.gp.kind == 3 ? ((384u + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords : RNG::kRefillWords;
+  const uint32_t want0 = A.gp.kind == 3 ? 384u : A.gp.kind == 53 ? 512u : 1u;        // GoToRedBall; LevelGen (an attempt draws 150-500 words)
+  const uint32_t budget0 = ((want0 + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords;
   uint32_t budget = budget0, retries_before = 0;
   out.resume = 0;
   for (;;) {
@@ -333,6 +334,11 @@ __global__ void k_gather_rng(const uint64_t* rng_snap, const uint32_t* head, uin
 }
 
 // reset(seed=...): the ring of the selected envs restarts (head = 0; the host then draws all R slots, tail = R)
+__global__ void k_gstate_restore(uint32_t* gstate, const uint32_t* gsnap, const uint32_t* head, const uint8_t* mask, uint32_t R, int N) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N || (mask && !mask[e])) return;
+  gstate[e] = gsnap[(size_t)(head[e] & (R - 1u)) * (size_t)N + (size_t)e];
+}
 __global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* mask, uint32_t R, int N, uint32_t* gstate, const uint32_t* gsnap) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N || (mask && !mask[e])) return;
