@@ -92,6 +92,7 @@ typedef enum mg_env_kind {
   MG_ENV_BABYAI_UNLOCKPICKUP = 36,        /* envs/babyai/unlock.py:307-319 (1 x 2 rooms; num_dists = 0 | 4 = UnlockPickupDist)               */
   MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP = 37, /* unlock.py:380-393 (1 x 2 rooms)                                                             */
   MG_ENV_UNLOCKTOUNLOCK = 38,             /* unlock.py:452-474 (1 x 3 rooms)                                                             */
+  MG_ENV_KEYINBOX = 39,                   /* unlock.py:232-242 (3 x 3 rooms; the locked door's key lies in a box of a random colour)     */
   MG_ENV_BABYAI_UNLOCK = 40,              /* unlock.py:67-112 (3 x 3 rooms, OpenInstr about a door colour; id = article * 6 + colour)    */
   MG_ENV_BABYAI_GOTODOOR = 41,            /* goto.py:730-740 (GoToInstr about a door colour; id = article * 6 + colour)                  */
   MG_ENV_GOTOOBJDOOR = 42,                /* goto.py:800-813 (id = article * 24 + colour * 4 + (key, ball, box, door))                   */

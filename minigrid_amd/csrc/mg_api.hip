@@ -457,7 +457,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
   if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
-  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN || cfg->env_kind == 39) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
+  if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;
     const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
@@ -485,7 +485,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind >= MG_ENV_BABYAI_UNLOCKPICKUP && cfg->env_kind <= MG_ENV_GOTOIMPUNLOCK) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;
     const int nc = st > 0 ? (cfg->width - 1) / st : 0, nr = st > 0 ? (cfg->height - 1) / st : 0;
-    const int want_c = (k == MG_ENV_BABYAI_UNLOCKPICKUP || k == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP) ? 2 : 3;
+    const int want_c = (k == MG_ENV_BABYAI_UNLOCKPICKUP || k == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP) ? 2 : 3;      // (KeyInBox, 39: 3 x 3)
     const int want_r = (k == MG_ENV_BABYAI_UNLOCKPICKUP || k == MG_ENV_BABYAI_BLOCKEDUNLOCKPICKUP || k == MG_ENV_UNLOCKTOUNLOCK) ? 1 : 3;
     if (cfg->room_size < 4 || cfg->room_size > 8 || (cfg->width - 1) % st || (cfg->height - 1) % st || nc != want_c || nr != want_r ||
         cfg->num_dists < 0 || cfg->num_dists > 8)
@@ -655,7 +655,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_PICKUPDIST || cfg->env_kind == MG_ENV_ONEROOM || cfg->env_kind == MG_ENV_FINDOBJ ||
       cfg->env_kind == MG_ENV_BABYAI_KEYCORRIDOR) { e->rule = RULE_PICKUPDESC; e->rule_div = 1; }
   if (cfg->env_kind == MG_ENV_PICKUPDIST_DEBUG) { e->rule = RULE_PICKUPDESC; e->rule_div = 2; }      // strict
-  if (cfg->env_kind == MG_ENV_OPENREDDOOR || cfg->env_kind == MG_ENV_UNLOCKLOCAL) e->rule = RULE_OPENFRONT;
+  if (cfg->env_kind == MG_ENV_OPENREDDOOR || cfg->env_kind == MG_ENV_UNLOCKLOCAL || cfg->env_kind == MG_ENV_KEYINBOX) e->rule = RULE_OPENFRONT;
   if (cfg->env_kind == MG_ENV_FETCH) e->rule = RULE_FETCH;
   if (cfg->env_kind == MG_ENV_GOTODOOR) e->rule = RULE_GOTODOOR;
   if (cfg->env_kind == MG_ENV_DYNOBS) e->rule = RULE_DYNOBS;

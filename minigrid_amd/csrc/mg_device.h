@@ -28,8 +28,11 @@ enum : uint32_t { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP =
 //   type 14 (internal) is a GREY box whose `contains` is a key (Box.contains, world_object.py:272-293; ObstructedMaze hides
 //           every key in a box of colour COLOR_NAMES[2] = grey, obstructedmaze.py:120,161-164): colour field = the KEY's colour.
 //           It encodes, renders and is picked up as the grey box; toggling it leaves the key in its place.
+//   type 15 (internal) is a box of colour c holding the key of the level's ONLY door (BabyAI KeyInBox, unlock.py:232-242): the
+//           key's colour is the door's, found on the grid when the box is opened (k_step).
 constexpr uint32_t T_AGENT_MARK = 13;
 constexpr uint32_t T_BOX_KEY = 14;
+constexpr uint32_t T_BOX_DOORKEY = 15;
 constexpr uint32_t OPAQUE_TYPES = (1u << T_WALL) | (1u << 11) | (1u << 12);
 constexpr uint32_t OPAQUE_BIT = 0x80u;
 
@@ -60,6 +63,7 @@ MG_HD uint32_t cell_triple(uint32_t code) {
   uint32_t t = code & 15u, c = (code >> 4) & 7u;
   if (t == T_AGENT_MARK) return (uint32_t)T_AGENT | ((uint32_t)C_RED << 8) | (c << 16);   // wrappers.py:422-424
   if (t == T_BOX_KEY) return (uint32_t)T_BOX | ((uint32_t)C_GREY << 8);
+  if (t == T_BOX_DOORKEY) return (uint32_t)T_BOX | (c << 8);
   uint32_t st = t >= T_DOOR_CLOSED ? t - 10u : 0u;
   t = t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t;
   return t | (c << 8) | (st << 16);
@@ -69,7 +73,7 @@ MG_HD uint32_t cell_triple(uint32_t code) {
 // can_overlap (world_object.py:113,128,141,177-179): goal, floor, lava, OPEN door; None (empty) is walkable too
 constexpr uint32_t WALKABLE_MASK = (1u << T_EMPTY) | (1u << T_FLOOR) | (1u << T_DOOR) | (1u << T_GOAL) | (1u << T_LAVA);
 // can_pickup (world_object.py:243,265,277)
-constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX) | (1u << T_BOX_KEY);
+constexpr uint32_t PICKUP_MASK = (1u << T_KEY) | (1u << T_BALL) | (1u << T_BOX) | (1u << T_BOX_KEY) | (1u << T_BOX_DOORKEY);
 
 MG_HD bool cell_walkable(uint32_t code) { return (WALKABLE_MASK >> (code & 15u)) & 1u; }
 MG_HD bool cell_pickable(uint32_t code) { return (PICKUP_MASK >> (code & 15u)) & 1u; }
@@ -134,7 +138,7 @@ MG_HD uint32_t color_from_sorted(uint32_t i) {
 }
 
 // reference OBJECT_TO_IDX of a cell code (the internal closed/locked door types are doors)
-MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return t == T_BOX_KEY ? (uint32_t)T_BOX : (t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t); }
+MG_HD uint32_t cell_ref_type(uint32_t code) { const uint32_t t = code & 15u; return (t == T_BOX_KEY || t == T_BOX_DOORKEY) ? (uint32_t)T_BOX : (t >= T_DOOR_CLOSED ? (uint32_t)T_DOOR : t); }
 
 // agent record: one u64 per env
 //   byte 0 x, 1 y, 2 dir (bits 0-1) | mission id bits 8-13 (bits 2-7), 3 carrying (cell code, 0 = nothing), 4-5 step_count (u16),

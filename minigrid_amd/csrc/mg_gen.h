@@ -1398,7 +1398,7 @@ MG_D uint32_t count_cells(GridRef& g, bool doors_of_color, uint32_t c) {
   return n;
 }
 
-enum : int { KIND_BABYAI_UNLOCKPICKUP = 36, KIND_BABYAI_BLOCKEDUNLOCKPICKUP = 37, KIND_UNLOCKTOUNLOCK = 38, KIND_BABYAI_UNLOCK = 40,
+enum : int { KIND_BABYAI_UNLOCKPICKUP = 36, KIND_BABYAI_BLOCKEDUNLOCKPICKUP = 37, KIND_UNLOCKTOUNLOCK = 38, KIND_KEYINBOX = 39, KIND_BABYAI_UNLOCK = 40,
              KIND_BABYAI_GOTODOOR = 41, KIND_GOTOOBJDOOR = 42, KIND_UNBLOCKPICKUP = 43, KIND_PICKUPABOVE = 44, KIND_GOTOIMPUNLOCK = 45 };
 // envs/babyai/unlock.py: UnlockPickup (:307-319; P.num_dists = 0 | 4 distractors = UnlockPickupDist), BlockedUnlockPickup (:380-393),
 // UnlockToUnlock (:452-474), Unlock (:67-112); goto.py: GoToDoor (:730-740), GoToObjDoor (:800-813), GoToImpUnlock (:486-531);
@@ -1462,6 +1462,18 @@ MG_D void gen_babyai_levels(R& rng, GridRef& g, const GenParams& P, GenResult& o
       rg.place_agent_in(rng, g, 1, 0, out);
       if (!rg.ok || rng.dead()) continue;
       out.mission = 2u;                                                       // "pick up the ball"
+      return;
+    }
+    if (P.kind == KIND_KEYINBOX) {
+      // KeyInBox (unlock.py:232-242): a locked door, its key inside a box of a random colour (Box(colour, contains=Key(door colour)):
+      // cell type T_BOX_DOORKEY, the key's colour is read off the door when the box is opened)
+      rg.add_door(rng, g, 1, 1, -1, -1, 1, dx, dy);
+      const int bc = rand_int(rng, 0, 6);
+      int x, y;
+      if (!place_obj(rng, g, make_cell(T_BOX_DOORKEY, color_from_sorted((uint32_t)bc)), rg.st, rg.st, rg.rs, rg.rs, rg.ax, rg.ay, true, 1000, x, y)) continue;
+      rg.place_agent_in(rng, g, 1, 1, out);
+      if (!rg.ok || rng.dead()) continue;
+      out.mission = 0;
       return;
     }
     if (P.kind == KIND_BABYAI_GOTODOOR || P.kind == KIND_GOTOOBJDOOR) {
@@ -2073,7 +2085,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 31: gen_obstructedmaze(rng, g, P, out); return;
       case 32: gen_putnear(rng, g, P, out); return;
       case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
-      case 36: case 37: case 38: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
+      case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
       case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
       case 50: case 51: case 52: gen_babyai_seq(rng, g, P, out, (uint64_t*)(g.p + P.instr_off)); return;
       case 53: gen_levelgen(rng, g, P, out, (uint64_t*)(g.p + P.instr_off), (uint32_t*)(g.p + P.scratch_off)); return;

@@ -791,6 +791,12 @@ k_step(const StepParams P) {
           if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
         } else if (act == A_TOGGLE) {
           newF = cell_toggle(F, a.carry);
+          if constexpr (GG == GG_ROOMS) if (ftype == T_BOX_DOORKEY) {
+            // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
+            uint32_t dc = 0;
+            for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
+            newF = make_cell(T_KEY, dc);
+          }
         } else if (act != A_DONE) {
           errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
         }

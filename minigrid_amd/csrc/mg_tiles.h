@@ -31,6 +31,7 @@ MG_HD uint32_t cell_tile_key(uint32_t code) {
     case T_BALL: return 19u + c;
     case T_BOX: return 25u + c;
     case T_BOX_KEY: return 25u + (uint32_t)C_GREY;            // a box shows its own colour, not its content's
+    case T_BOX_DOORKEY: return 25u + c;
     case T_DOOR: return 31u + 3u * c;
     case T_DOOR_CLOSED: return 32u + 3u * c;
     case T_DOOR_LOCKED: return 33u + 3u * c;

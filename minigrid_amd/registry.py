@@ -21,6 +21,7 @@ ENV_PICKUPDIST, ENV_ONEROOM, ENV_OPENREDDOOR, ENV_PICKUPDIST_DEBUG, ENV_FINDOBJ 
 ENV_UNLOCKLOCAL, ENV_BABYAI_KEYCORRIDOR, ENV_OBSTRUCTEDMAZE, ENV_PUTNEAR = 29, 30, 31, 32
 ENV_BABYAI_GOTO, ENV_BABYAI_PICKUP, ENV_BABYAI_OPEN = 33, 34, 35
 ENV_BABYAI_UNLOCKPICKUP, ENV_BABYAI_BLOCKEDUNLOCKPICKUP, ENV_UNLOCKTOUNLOCK, ENV_BABYAI_UNLOCK = 36, 37, 38, 40
+ENV_KEYINBOX = 39
 ENV_BABYAI_GOTODOOR, ENV_GOTOOBJDOOR, ENV_UNBLOCKPICKUP, ENV_PICKUPABOVE, ENV_GOTOIMPUNLOCK = 41, 42, 43, 44, 45
 ENV_PUTNEXTLOCAL, ENV_PUTNEXT, ENV_ACTIONOBJDOOR, ENV_OPENDOOR = 46, 47, 48, 49
 ENV_OPENTWODOORS, ENV_OPENDOORSORDER, ENV_MOVETWOACROSS, ENV_LEVELGEN = 50, 51, 52, 53      # the sentence levels
@@ -300,6 +301,7 @@ _ROWS = [
           ("BabyAI-UnlockPickupDist-v0", ENV_BABYAI_UNLOCKPICKUP, "UnlockPickup", 6, 1, 2, 72, 4, _PICKUP_MISSIONS, {"distractors": True}),
           ("BabyAI-BlockedUnlockPickup-v0", ENV_BABYAI_BLOCKEDUNLOCKPICKUP, "BlockedUnlockPickup", 6, 1, 2, 576, 0, _PICKUP_MISSIONS, {}),
           ("BabyAI-UnlockToUnlock-v0", ENV_UNLOCKTOUNLOCK, "UnlockToUnlock", 6, 1, 3, 1080, 0, _PICKUP_MISSIONS, {}),
+          ("BabyAI-KeyInBox-v0", ENV_KEYINBOX, "KeyInBox", 8, 3, 3, 576, 0, ("open the door",), {}),
           ("BabyAI-Unlock-v0", ENV_BABYAI_UNLOCK, "Unlock", 8, 3, 3, 576, 0,
            tuple(f"open {art} {c} door" for art in ("the", "a") for c in _COLOR_NAMES), {}),
           ("BabyAI-GoToDoor-v0", ENV_BABYAI_GOTODOOR, "GoToDoor", 7, 3, 3, 441, 0,

@@ -945,7 +945,7 @@ WIDE2_IDS = ["MiniGrid-ObstructedMaze-1Dl-v0", "MiniGrid-ObstructedMaze-1Dlh-v0"
              "BabyAI-GoTo-v0", "BabyAI-GoToOpen-v0", "BabyAI-GoToObjMaze-v0", "BabyAI-GoToObjMazeOpen-v0",
              "BabyAI-GoToObjMazeS4R2-v0", "BabyAI-GoToObjMazeS4-v0", "BabyAI-GoToObjMazeS5-v0", "BabyAI-GoToObjMazeS6-v0",
              "BabyAI-GoToObjMazeS7-v0", "BabyAI-Pickup-v0", "BabyAI-Open-v0",
-             "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0", "BabyAI-Unlock-v0",
+             "BabyAI-UnlockPickup-v0", "BabyAI-UnlockPickupDist-v0", "BabyAI-BlockedUnlockPickup-v0", "BabyAI-UnlockToUnlock-v0", "BabyAI-Unlock-v0", "BabyAI-KeyInBox-v0",
              "BabyAI-GoToDoor-v0", "BabyAI-GoToObjDoor-v0", "BabyAI-GoToImpUnlock-v0", "BabyAI-UnblockPickup-v0", "BabyAI-PickupAbove-v0",
              "BabyAI-PutNextLocal-v0", "BabyAI-PutNextLocalS5N3-v0", "BabyAI-PutNextLocalS6N4-v0", "BabyAI-PutNextS4N1-v0",
              "BabyAI-PutNextS5N2-v0", "BabyAI-PutNextS5N1-v0", "BabyAI-PutNextS6N3-v0", "BabyAI-PutNextS7N4-v0",
@@ -959,7 +959,7 @@ SENTENCE_IDS = ["BabyAI-OpenTwoDoors-v0", "BabyAI-OpenRedBlueDoors-v0", "BabyAI-
                 "BabyAI-BossLevel-v0", "BabyAI-BossLevelNoUnlock-v0"]
 
 # restated and pinned in the oracle, not built on the device (kept out of the GPU test lists)
-ORACLE_ONLY_IDS = ["BabyAI-KeyInBox-v0", ]
+ORACLE_ONLY_IDS = []
 
 
 def main_oracle_only():

@@ -231,7 +231,7 @@ def test_mg_create_valid_config_needs_a_device():
 
 def test_registry_rows_are_consistent():
     import minigrid_amd as mg
-    assert len(mg.registry) == 170
+    assert len(mg.registry) == 171
     for env_id, s in mg.registry.items():
         assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
         assert s.entry_point.startswith("minigrid.envs")
