@@ -84,6 +84,9 @@ class ShardedVecEnv:
             from .vector_env import make_vec as make
             kwargs.setdefault("output", "torch")
         self.local = make(env_id, self.local_num_envs, env_index_base=self.lo, **kwargs)
+        if getattr(self.local, "sentence", False):
+            # their missions travel as two u64 per env (mg_outputs.sentence), which the gathered record below does not carry yet
+            raise NotImplementedError(f"{env_id}: the sentence levels are not wired into the gathered step record; use make_vec per rank")
         self._missions = np.asarray(getattr(self.local, "_missions", ()))
         self._mission_index = {m: i for i, m in enumerate(self._missions.tolist())}
         self._zero_copy = hasattr(self.local, "torch_outputs") and getattr(self.local, "output", "") == "torch"
