@@ -37,6 +37,8 @@ WORKLOADS = {
     # SURVEY.md §8(f) rank 4 -- what the stock benchmark.py times: RGBImgObsWrapper / RGBImgPartialObsWrapper frames
     "empty8x8_rgb": ("MiniGrid-Empty-8x8-v0", 65536, "rgb"),            # 64x64x3 frame per env-step (805 MB per step)
     "doorkey8x8_rgb_partial": ("MiniGrid-DoorKey-8x8-v0", 65536, "rgb_partial"),   # 56x56x3 agent-POV frame
+    # step() itself draws (the obstacles move on the env's stream): live generation + k_move_obstacles + k_step per step
+    "dynobs16x16": ("MiniGrid-Dynamic-Obstacles-16x16-v0", 65536, "partial"),
 }
 
 

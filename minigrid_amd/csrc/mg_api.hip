@@ -268,12 +268,13 @@ static int launch_step(mg_env* e, StepParams& P) {
       if (rc) return rc;
     }
     if (P.phase == PHASE_STEP) {
-      const int tb = 256, nb = (e->N + tb - 1) / tb;
+      const int nb = (e->N + 63) / 64;
+      const size_t mlds = (size_t)64 * (size_t)(e->CS + 4);           // 64 staged grids (DynamicObstacles: at most 16 x 16)
       if (e->cfg.rng_mode == MG_RNG_PHILOX)
-        hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->aux,
+        hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(64), mlds, e->stream, e->grid, e->agent, e->rng, e->aux,
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists);
       else
-        hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(tb), 0, e->stream, e->grid, e->agent, e->rng, e->aux,
+        hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(64), mlds, e->stream, e->grid, e->agent, e->rng, e->aux,
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists);
       HIP_TRY(e, hipGetLastError());
     }

@@ -1275,45 +1275,74 @@ __global__ void k_verify(const VerifyParams V) {
 
 // DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
 // front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood
-// (place_obj with max_tries=100 on the ENV's stream; an obstacle that finds no place stays).  One lane per env,
-// straight on the HBM state: this level's step consumes the stream, so it is kept out of k_step's register budget.
+// (place_obj with max_tries=100 on the ENV's stream; an obstacle that finds no place stays).  This level's step consumes the
+// stream, so it is kept out of k_step's register budget.  One wavefront per 64 envs, like k_step: the 64 grids are staged
+// into LDS with 16 B/lane coalesced loads (env stride CS + 4: an odd dword stride), lane l works on env l's copy -- the
+// rejection-sampling chain (draw, look at the cell, draw again) runs at LDS latency instead of one HBM round trip per try --
+// and the grids go back with coalesced 16 B stores.
 template <class RNG>
-__global__ void k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
-                                 int n_obst) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N) return;
-  Agent a = agent_unpack(agent[e]);
-  if (a.flags & (FLAG_RESET_PENDING | FLAG_FRESH)) return;          // no step for this env in the coming launch
-  uint8_t* g = grid + (size_t)e * CS;
-  const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-  const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)g[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
-  const bool not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
-  RNG r;
-  r.load(rng, (size_t)N, (size_t)e);
-  uint64_t o = obst[e];
-  for (int i = 0; i < n_obst; i++) {
-    const int idx = (int)((o >> (8 * i)) & 0xFF), ox = idx % W, oy = idx / W;
-    const int topx = max(ox - 1, 0), topy = max(oy - 1, 0), hx = min(topx + 3, W), hy = min(topy + 3, H);
-    int tries = 0, nx = -1, ny = -1;
-    for (;;) {
-      if (tries > 100) break;                                       // RecursionError, swallowed by `except Exception`
-      tries++;
-      const int x = rand_int(r, topx, hx), y = rand_int(r, topy, hy);
-      if (g[y * W + x] != CELL_EMPTY) continue;
-      if (x == (int)a.x && y == (int)a.y) continue;
-      nx = x; ny = y;
-      break;
-    }
-    if (nx >= 0) {
-      g[ny * W + nx] = (uint8_t)CELL_BALL_BLUE;
-      g[idx] = (uint8_t)CELL_EMPTY;
-      o = (o & ~(0xFFull << (8 * i))) | ((uint64_t)(ny * W + nx) << (8 * i));
+__global__ void __launch_bounds__(64) k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
+                                                       int n_obst) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * 64, nvalid = min(64, N - env0);
+  const int GS = CS + 4, cpe = CS >> 4, nchunks = nvalid * cpe;
+  uint4* live = (uint4*)(grid + (size_t)env0 * CS);
+  for (int c = lane; c < nchunks; c += 64) {
+    const int ce = c / cpe, part = c - ce * cpe;
+    const uint4 v = live[c];
+    uint32_t* d = (uint32_t*)(smem + ce * GS + part * 16);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int e = env0 + lane;
+  bool moved = false;
+  if (lane < nvalid) {
+    Agent a = agent_unpack(agent[e]);
+    if (!(a.flags & (FLAG_RESET_PENDING | FLAG_FRESH))) {            // (otherwise: no step for this env in the coming launch)
+      uint8_t* g = smem + lane * GS;
+      const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+      const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)g[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
+      const bool not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
+      RNG r;
+      r.load(rng, (size_t)N, (size_t)e);
+      uint64_t o = obst[e];
+      for (int i = 0; i < n_obst; i++) {
+        const int idx = (int)((o >> (8 * i)) & 0xFF), oy = idx / W, ox = idx - oy * W;
+        const int topx = max(ox - 1, 0), topy = max(oy - 1, 0), hx = min(topx + 3, W), hy = min(topy + 3, H);
+        int tries = 0, nx = -1, ny = -1;
+        for (;;) {
+          if (tries > 100) break;                                       // RecursionError, swallowed by `except Exception`
+          tries++;
+          const int x = rand_int(r, topx, hx), y = rand_int(r, topy, hy);
+          if (g[y * W + x] != CELL_EMPTY) continue;
+          if (x == (int)a.x && y == (int)a.y) continue;
+          nx = x; ny = y;
+          break;
+        }
+        if (nx >= 0) {
+          g[ny * W + nx] = (uint8_t)CELL_BALL_BLUE;
+          g[idx] = (uint8_t)CELL_EMPTY;
+          o = (o & ~(0xFFull << (8 * i))) | ((uint64_t)(ny * W + nx) << (8 * i));
+          moved = true;
+        }
+      }
+      r.store(rng, (size_t)N, (size_t)e);
+      obst[e] = o;
+      a.flags = (a.flags & ~FLAG_NOT_CLEAR) | (not_clear ? FLAG_NOT_CLEAR : 0u);
+      agent[e] = agent_pack(a);
     }
   }
-  r.store(rng, (size_t)N, (size_t)e);
-  obst[e] = o;
-  a.flags = (a.flags & ~FLAG_NOT_CLEAR) | (not_clear ? FLAG_NOT_CLEAR : 0u);
-  agent[e] = agent_pack(a);
+  const unsigned long long wb = __ballot(moved);
+  __syncthreads();
+  if (wb)
+    for (int c = lane; c < nchunks; c += 64) {
+      const int ce = c / cpe, part = c - ce * cpe;
+      if ((wb >> ce) & 1ull) {
+        const uint32_t* sp = (const uint32_t*)(smem + ce * GS + part * 16);
+        uint4 v; v.x = sp[0]; v.y = sp[1]; v.z = sp[2]; v.w = sp[3];
+        live[c] = v;
+      }
+    }
 }
 
 // gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)
