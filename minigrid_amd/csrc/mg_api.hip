@@ -153,10 +153,16 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
   const int wpb = GEN_THREADS / 64;
   const int blocks = std::min((e->N + wpb - 1) / wpb, 8192);
   const size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
-  if (e->cfg.rng_mode == MG_RNG_PHILOX)
-    hipLaunchKernelGGL(k_generate<WavePhilox>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
-  else
-    hipLaunchKernelGGL(k_generate<WavePcg64>, dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);
+  // one instantiation per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
+  const int gg = gen_group_of_kind(e->cfg.env_kind);
+  const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
+#define MG_GEN_LAUNCH(GGEN)                                                                                              \
+  if (gg == GGEN) {                                                                                                      \
+    if (philox) hipLaunchKernelGGL((k_generate<GGEN, WavePhilox>), dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A); \
+    else hipLaunchKernelGGL((k_generate<GGEN, WavePcg64>), dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);         \
+  }
+  MG_GEN_LAUNCH(GG_LIGHT) MG_GEN_LAUNCH(GG_ROOMGRID) MG_GEN_LAUNCH(GG_ROOMS) MG_GEN_LAUNCH(GG_SENTENCE)
+#undef MG_GEN_LAUNCH
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
 }
@@ -173,10 +179,15 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.wps = std::max(1, e->epw / 4);            // a GoToRedBall batch files ~EPW/7 requests per segment (Poisson: some segments twice that)
   if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
-  if (e->cfg.rng_mode == MG_RNG_PHILOX)
-    hipLaunchKernelGGL(k_refill<WavePhilox>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
-  else
-    hipLaunchKernelGGL(k_refill<WavePcg64>, dim3(e->nwaves * A.wps), dim3(64), lds, st, A);
+  const int gg = gen_group_of_kind(e->cfg.env_kind);
+  const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
+#define MG_REFILL_LAUNCH(GGEN)                                                                                          \
+  if (gg == GGEN) {                                                                                                     \
+    if (philox) hipLaunchKernelGGL((k_refill<GGEN, WavePhilox>), dim3(e->nwaves * A.wps), dim3(64), lds, st, A);        \
+    else hipLaunchKernelGGL((k_refill<GGEN, WavePcg64>), dim3(e->nwaves * A.wps), dim3(64), lds, st, A);                \
+  }
+  MG_REFILL_LAUNCH(GG_LIGHT) MG_REFILL_LAUNCH(GG_ROOMGRID) MG_REFILL_LAUNCH(GG_ROOMS) MG_REFILL_LAUNCH(GG_SENTENCE)
+#undef MG_REFILL_LAUNCH
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemsetAsync(A.seg_count, 0, (size_t)e->nwaves * sizeof(uint32_t), st));
   return MG_OK;
@@ -669,8 +680,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->env_kind == MG_ENV_BLOCKEDUNLOCKPICKUP) { e->rule = RULE_PICKUP; e->rule_cell = (int)T_BOX; e->rule_div = 2; }
 
   // k_step compiles each level rule only into the variant of its rule group
-  e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT) ? GG_ROOMS
-                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR) ? GG_ROOMGRID
+  e->rule_group = (e->rule == RULE_PICKUPDESC || e->rule == RULE_OPENFRONT || e->rule == RULE_GOTO_BIG || e->rule == RULE_PUTNEXT || e->rule == RULE_OPENDOOR) ? GG_ROOMS
+                : (e->rule == RULE_GOTO || e->rule == RULE_GOTOOBJ || e->rule == RULE_UNLOCK || e->rule == RULE_PICKUP || e->rule == RULE_PUTNEAR) ? GG_ROOMGRID
                 : (e->rule == RULE_DYNOBS || e->rule == RULE_NONE || e->rule == RULE_SENTENCE) ? GG_NONE : GG_LIGHT;
 
   mg_env* env = e;   // for HIP_TRY
@@ -782,8 +793,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->sentence) {
     // 19 KB of buffered draws per generating wave: the direct generator launch (4 waves per workgroup) needs more than 64 KB of LDS
     const int need = (GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, 4864, true);
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<WavePcg64>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<WavePhilox>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<GG_SENTENCE, WavePcg64>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<GG_SENTENCE, WavePhilox>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
   }
 #undef TRY_OR_FREE
   (void)env;

@@ -2032,15 +2032,14 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
   out.failed = true;
 }
 
-// Generator groups: the generator role inside k_step is compiled per group, so that a launch only carries (and only
-// pays registers / scratch for) the generators its env kind can need.  All kinds inlined together need ~166 VGPRs;
-// under k_step's 64-VGPR budget that meant 256 B/lane of scratch on EVERY wave of the launch (+12 % launch time).
-//   GG_ALL   stand-alone k_generate (explicit resets, flushes): every kind
-//   GG_LIGHT single-room levels        GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject (needs the aux word)
-//   GG_ROOMS everything added after the BASELINE kernels were tuned, so that those stay byte-identical: the multi-room
-//            maps without a step rule (LockedRoom, Playground, MultiRoom) and BabyAI PickupDist / OneRoom / OpenRedDoor
-enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_ALL = 7 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 21 && kind <= 53) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+// Groups.  The generator kernels (k_generate / k_refill) are instantiated per generator group, so that a level's generator
+// launch only carries -- and only pays registers for -- the generators its env kind can need: with every kind inlined into one
+// kernel the register count is that of the largest one (LevelGen), which costs the BASELINE levels occupancy (GoToRedBall's
+// refill: +14 %).  k_step is instantiated per RULE group with the same constants (mg_api.hip rule_group).
+//   GG_LIGHT single-room levels (+ DynamicObstacles)   GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject
+//   GG_ROOMS the multi-room MiniGrid and BabyAI levels with one instruction (kinds 21..49)   GG_SENTENCE kinds 50..53
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15 };
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 50 && kind <= 53) ? GG_SENTENCE : (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
@@ -2057,7 +2056,7 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 8: gen_gotodoor(rng, g, P, out); return;
       case 12: gen_redbluedoors(rng, g, P, out); return;
       case 13: gen_memory(rng, g, P, out); return;
-      case 15: if constexpr (GG == GG_ALL) { gen_dynobs(rng, g, P, out); return; } break;   // only ever drawn by k_generate
+      case 15: gen_dynobs(rng, g, P, out); return;
       default: break;
     }
   }
@@ -2087,6 +2086,11 @@ MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
       case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
       case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
+      default: break;
+    }
+  }
+  if constexpr (GG == GG_SENTENCE || GG == GG_ALL) {
+    switch (P.kind) {
       case 50: case 51: case 52: gen_babyai_seq(rng, g, P, out, (uint64_t*)(g.p + P.instr_off)); return;
       case 53: gen_levelgen(rng, g, P, out, (uint64_t*)(g.p + P.instr_off), (uint32_t*)(g.p + P.scratch_off)); return;
       default: break;

@@ -264,7 +264,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
 // Direct launch over all envs (optionally masked): explicit reset(seed=...), mg_set_rng.  4 generating waves per workgroup.
 // The destination pointers are pre-offset to the ring slot by the host.
 constexpr int GEN_THREADS = 256;
-template <class RNG>
+template <int GGEN, class RNG>
 __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
   const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
   for (int e = (int)blockIdx.x * (GEN_THREADS / 64) + wave; e < A.N; e += nwaves) {
     if (A.mask && !uni32(A.mask[e])) continue;
-    generate_one<GG_ALL, RNG>(A, rng, e, 0u, 0u, lane, lds);
+    generate_one<GGEN, RNG>(A, rng, e, 0u, 0u, lane, lds);
   }
 }
 
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
 // b % wps, b % wps + wps, ... of segment b / wps).  Single-wave workgroups keep the LDS footprint at one draw buffer (5 KB), so
 // a CU holds 32 generating waves; multi-wave workgroups held their whole allocation until the slowest wave finished and
 // capped the chip at ~1000 concurrent generations (LavaCrossing refill: 210 us -> measured in profiles/r2).
-template <class RNG>
+template <int GGEN, class RNG>
 __global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t lane = threadIdx.x;
@@ -310,14 +310,14 @@ __global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
     if (A.live) {
       const uint32_t fl = (uint32_t)(uni64(A.dst_agent[e]) >> 48) & 0xFFu;
       if (!(fl & FLAG_RESET_PENDING)) continue;                // an explicit reset() has drawn this env in the meantime
-      generate_one<GG_ALL, RNG>(A, rng, e, 0u, FLAG_FRESH, lane, lds);
+      generate_one<GGEN, RNG>(A, rng, e, 0u, FLAG_FRESH, lane, lds);
       continue;
     }
     const uint32_t h = uni32(A.head[e]) + A.ring_mask + 1u;    // every slot below head + R is free to fill
     uint32_t t = uni32(A.tail[e]);
     if (h - t > A.ring_mask + 1u) { if (lane == 0) report_errors(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
     while (t != h) {
-      generate_one<GG_ALL, RNG>(A, rng, e, t & A.ring_mask, 0u, lane, lds);
+      generate_one<GGEN, RNG>(A, rng, e, t & A.ring_mask, 0u, lane, lds);
       t++;
     }
     if (lane == 0) A.tail[e] = t;
@@ -629,7 +629,10 @@ k_step(const StepParams P) {
   uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
   uint8_t* sT = smem + P.off_T;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR || P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR);   // levels with an auxiliary word
+  // levels with an auxiliary word.  The single-room rules share the variant of the BASELINE GoToRedBall config; the heavier multi-room
+  // ones live in the GG_ROOMS variants so that they do not cost it registers (202 VGPRs with everything in one variant)
+  const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
+                         (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
@@ -816,7 +819,7 @@ k_step(const StepParams P) {
           const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
           if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
         }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO_BIG) {
+        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_GOTO_BIG) {
           // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
           // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
           // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
@@ -847,7 +850,7 @@ k_step(const StepParams P) {
             else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
           }
         }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
+        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
           // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
           // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
           // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
@@ -867,7 +870,7 @@ k_step(const StepParams P) {
             if (next) { term = 1; success = true; }
           }
         }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
+        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
           // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
           // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
           if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
@@ -1024,7 +1027,7 @@ k_step(const StepParams P) {
     const int obe = P.OBE;
     Agent av = a;
     bool show_taken = false;
-    if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
+    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
       // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER MiniGridEnv.reset made the
       // observation: the episode's first core observation (and what OneHotPartialObsWrapper makes of it) shows it where it was, and
       // empty hands.  The wrappers that look at the env when they are called (FullyObs, Symbolic, RGBImg*) see the state after.
@@ -1034,7 +1037,7 @@ k_step(const StepParams P) {
       }
       a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
     }
-    if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
+    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
     if constexpr (FAST7) {
       obs_view7<LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
@@ -1044,7 +1047,7 @@ k_step(const StepParams P) {
       obs_full<MODE, LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     }
     MG_LDS_SYNC();
-    if constexpr (GG == GG_ROOMGRID) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
+    if constexpr (GG == GG_ROOMS) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
 
     // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
     {
