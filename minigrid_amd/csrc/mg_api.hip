@@ -279,8 +279,8 @@ static int launch_step(mg_env* e, StepParams& P) {
       if (rc) return rc;
     }
     if (P.phase == PHASE_STEP) {
-      const int nb = (e->N + 63) / 64;
-      const size_t mlds = (size_t)64 * (size_t)(e->CS + 4);           // 64 staged grids (DynamicObstacles: at most 16 x 16)
+      const int nb = (e->N + MOVE_EPB - 1) / MOVE_EPB;
+      const size_t mlds = (size_t)MOVE_EPB * (size_t)(e->CS + 4);     // the wave's staged grids (DynamicObstacles: at most 16 x 16)
       if (e->cfg.rng_mode == MG_RNG_PHILOX)
         hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(64), mlds, e->stream, e->grid, e->agent, e->rng, e->aux,
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists);

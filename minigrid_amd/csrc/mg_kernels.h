@@ -1279,15 +1279,18 @@ __global__ void k_verify(const VerifyParams V) {
 // DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
 // front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood
 // (place_obj with max_tries=100 on the ENV's stream; an obstacle that finds no place stays).  This level's step consumes the
-// stream, so it is kept out of k_step's register budget.  One wavefront per 64 envs, like k_step: the 64 grids are staged
+// stream, so it is kept out of k_step's register budget.  One wavefront per MOVE_EPB envs: their grids are staged
 // into LDS with 16 B/lane coalesced loads (env stride CS + 4: an odd dword stride), lane l works on env l's copy -- the
 // rejection-sampling chain (draw, look at the cell, draw again) runs at LDS latency instead of one HBM round trip per try --
 // and the grids go back with coalesced 16 B stores.
+constexpr int MOVE_EPB = 16;
 template <class RNG>
 __global__ void __launch_bounds__(64) k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
                                                        int n_obst) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * 64, nvalid = min(64, N - env0);
+  // The per-env chain (PCG64 draw -> cell test -> next draw) is latency-bound and sequential: MOVE_EPB = 16 envs per wavefront
+  // (the other lanes only help with the staging) puts four wavefronts on every SIMD at 65 536 envs instead of one.
+  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * MOVE_EPB, nvalid = min(MOVE_EPB, N - env0);
   const int GS = CS + 4, cpe = CS >> 4, nchunks = nvalid * cpe;
   uint4* live = (uint4*)(grid + (size_t)env0 * CS);
   for (int c = lane; c < nchunks; c += 64) {
