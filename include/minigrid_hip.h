@@ -172,8 +172,8 @@ typedef struct mg_config {
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
   int32_t tile_size;          /* RGB modes: pixels per cell, 4 | 8 | 12 | 16 (wrappers.py:305, 355: default 8); else ignored */
   int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
-  int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..64); 0 = default (16)                */
-  int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (16, fewer when a slot is large)     */
+  int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default (128 / 64 / 16)      */
+  int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (32, fewer when a slot is large)     */
 } mg_config;
 
 /* Borrowed device pointers to the outputs of the last step/reset = slot 0 of the trajectory ring.  The ring has

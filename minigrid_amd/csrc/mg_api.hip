@@ -617,24 +617,28 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   {
     // spare ring depth R (power of two).  Levels that draw nothing keep ONE constant spare; DynamicObstacles draws in
-    // place (no ring).  Default 32: with cb = R/4 = 8 a fused launch runs 16 steps, and the generator may lag three
-    // batches (48 steps) behind before a step launch has to wait for it.  A refill's duration is set by its longest chain
-    // of whole-map retries (GoToRedBall: 70-100 us), not by its size, so longer batches amortise it: measured 11.1 us per
-    // step with R = 16, 7.4 with R = 32 (profiles/r2).  Sized for 288 GB of HBM: 32 spare maps of 64 B are 2 KB per env;
-    // very large maps x batches are capped at 8 GB of ring.
+    // place (no ring).  cb = R/4 spares per env and batch; a batch is up to 2 cb steps, its refill runs behind it on the generator
+    // stream and may lag three batches before a step launch has to wait.  A refill's duration is set by its longest chain of
+    // whole-map retries (GoToRedBall: 70-100 us), not by its size, so deeper rings -- fewer, larger refills -- pay for every
+    // level.  Measured per step with every consumed episode regenerated inside the timed region (mg_sync closes the open batch;
+    // profiles/r2/sweep_ring_sync.txt): GoToRedBall x 32 768: 11.1 us (R = 16), 7.4 (32), 6.4 (64), 7.7 (128);
+    // DoorKey-8x8 x 262 144: 19.0 (32), 17.9 (64), 16.8 (128); LavaCrossing FullyObs x 131 072: 18.1 (32), 15.2 (64), 13.5 (128).
+    // Default: 128, and 64 for the BabyAI single-room generators (whole-map rejection sampling: their long refill chains do
+    // worse with twice the work per refill).  Sized for 288 GB of HBM: 128 spare maps of 64 B are 8 KB per env (2 GB at 262 144
+    // envs); capped at 8 GB of ring.  The sentence levels step once per launch and carry a 320 B instruction record per spare: 16.
     int R = 1;
     if (!e->static_gen && !e->live_gen) {
-      R = cfg->spare_ring > 0 ? cfg->spare_ring : 32;
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : (e->sentence ? 16 : gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID ? 64 : 128);
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
-      if (R < 4 || R > 64 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..64"); }
+      if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
     e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each
-    // trajectory slots S: default 16, 32 for levels without a generator (fused launches write every step of the launch to its own slot), fewer when one
+    // trajectory slots S: default 32 (fused launches write every step of the launch to its own slot), fewer when one
     // slot is large (RGB frames: a single slot)
     const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
-    int S = cfg->traj_slots > 0 ? cfg->traj_slots : (e->static_gen ? 32 : 16);
+    int S = cfg->traj_slots > 0 ? cfg->traj_slots : 32;
     if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
     if (S > 4096) { delete e; return fail(nullptr, MG_ERR_INVALID, "traj_slots must be <= 4096"); }
     if (rgb) S = 1;
@@ -993,8 +997,10 @@ int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* ter
 int mg_sync(mg_env* e) {
   if (!e) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
-  // the generator stream runs ahead-of-need work for the episodes to come: a sync covers it too, so that a timed
-  // region bracketed by mg_sync pays for every episode drawn inside it
+  // the generator stream runs ahead-of-need work for the episodes to come: a sync closes the open batch (its refill is launched now)
+  // and covers the generator stream too, so that a timed region bracketed by mg_sync pays for every episode consumed inside it --
+  // the rings are full again when it returns, whatever their depth
+  { int rc = close_batch(e); if (rc) return rc; }
   if (e->gen_stream) HIP_TRY(e, hipStreamSynchronize(e->gen_stream));
   return check_device_errors(e);
 }
