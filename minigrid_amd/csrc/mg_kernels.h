@@ -393,16 +393,51 @@ MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, 
   const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
   uint32_t code[NC + 1];                                      // this lane's cells (+ cell 48, used by the last lane only)
   const int vx0 = LPE == 1 ? 0 : (k0 * 37) >> 8, vy0 = LPE == 1 ? 0 : k0 - 7 * vx0;
-  {
+  if constexpr (LPE == 1) {
+    // One lane holds the whole view: seven LINES of seven cells that are contiguous along world x -- the view's columns when the
+    // agent faces +-x (line t = vx, byte = vy), its rows when it faces +-y (line t = vy, byte = vx) -- as seven unaligned 8-byte
+    // LDS reads instead of 49 byte reads at scattered banks.  A line is byte-reversed when the view index runs against x, masked
+    // to walls outside the grid as a whole (7 validity bits -> 7 byte masks), and cell (vx, vy) is byte vy of line vx or byte vx
+    // of line vy.  The out-of-grid parts of a line lie in a neighbour's grid or a guard band, like the single cells before.
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    const uint32_t d = a.dir;
+    const bool rev = d < 2u;                                  // east, south: the view index runs against world x
+    const int row_base = (int)a.y + (d == 0u ? -HV : d == 2u ? HV : d == 1u ? V - 1 : -(V - 1));
+    const int lstep = (d == 0u || d == 3u) ? W : -W;
+    const uint8_t* lp = mygrid + row_base * W + (int)a.x - (d == 0u ? 0 : d == 2u ? V - 1 : HV);
+    const uint32_t linemask = horiz ? colmask : rowmask, bytemask = horiz ? rowmask : colmask;
+    uint32_t bm_lo = 0, bm_hi = 0;                            // validity bit j -> byte j = 0xFF
+#pragma unroll
+    for (int j = 0; j < 4; j++) bm_lo |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * j));
+#pragma unroll
+    for (int j = 4; j < V; j++) bm_hi |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * (j - 4)));
+    const uint32_t WALL4 = CELL_WALL_GREY * 0x01010101u;
+    uint32_t qlo[V], qhi[V];
+#pragma unroll
+    for (int t = 0; t < V; t++) {
+      const uint64_t q = *(const u64u*)(lp + t * lstep);
+      const uint64_t r = __builtin_bswap64(q) >> 8;
+      const uint32_t lo = rev ? (uint32_t)r : (uint32_t)q, hi = rev ? (uint32_t)(r >> 32) : (uint32_t)(q >> 32);
+      const uint32_t on = 0u - ((linemask >> t) & 1u);
+      const uint32_t ml = bm_lo & on, mh = bm_hi & on;
+      qlo[t] = (lo & ml) | (WALL4 & ~ml);
+      qhi[t] = (hi & mh) | (WALL4 & ~mh);
+    }
+    auto byte_of = [&](int t, int j) -> uint32_t { return j < 4 ? ((qlo[t] >> (8 * j)) & 0xFFu) : ((qhi[t] >> (8 * (j - 4))) & 0xFFu); };
+#pragma unroll
+    for (int i = 0; i <= NC; i++) {
+      const int vx = i / V, vy = i % V;
+      code[i] = vx == vy ? byte_of(vx, vy) : (horiz ? byte_of(vx, vy) : byte_of(vy, vx));
+    }
+  } else {
     int vx = vx0, vy = vy0;
 #pragma unroll
     for (int i = 0; i <= NC; i++) {
-      if (LPE == 1) { vx = i / V; vy = i % V; }
       const uint32_t raw = vbase[vy * SU + vx * SR];
       const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
       const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
       code[i] = c;
-      if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
+      if (++vy == V) { vy = 0; vx++; }
     }
   }
   // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6 (every lane of the env)
