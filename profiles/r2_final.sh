@@ -3,8 +3,8 @@
 # driver-sized runs, the single-step path, the RGB workloads, DynamicObstacles with its per-kernel breakdown.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-bash profiles/collect.sh r2ad empty8x8 doorkey8x8 lavacrossing_full gotoredball
-cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r2ad
+bash profiles/collect.sh r2ag empty8x8 doorkey8x8 lavacrossing_full gotoredball
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r2ag
 show() { python -c "
 import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], '%.3f G steps/s %.2f us/step frac %.3f' % (d['value']/1e9, d['ms_per_step']*1e3, d['roofline']['frac']))" $1 "$2" | tee -a $O/summary.txt; }
 for i in 1 2 3; do timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver$i.json 2> $O/bench_driver.err; show $O/bench_driver$i.json "driver-sized"; done
