@@ -25,6 +25,9 @@ def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
               dict_mission=env.dict_mission, tile_size=env.tile_size, highlight=env.highlight,
               device=env.device, stream=env._stream_arg, spare_ring=env.spare_ring, traj_slots=env.traj_slots_arg)
     kw.update(changes)
+    if env._seeded and getattr(env, "sentence", False):
+        # their live state includes the instruction tree and the object identities, which get_state / set_state do not carry
+        raise NotImplementedError(f"{env.env_id}: wrap a sentence level before its first reset(); a live episode cannot be carried over")
     new = MiniGridVecEnv(env.env_id, env.num_envs, **kw)
     if env._seeded:
         new.set_rng_state(env.get_rng_state())     # also re-draws the spare episodes from that position
