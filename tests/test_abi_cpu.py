@@ -205,7 +205,19 @@ def _cfg(**kw):
                                  dict(env_kind=26, width=9, height=6, room_size=5),      # OpenRedDoor: height = room_size
                                  dict(env_kind=24, width=7, height=8),                   # PickupDist: one square room
                                  dict(env_kind=29, width=22, height=22, room_size=8, num_dists=9),      # UnlockLocal: <= 8 distractors
-                                 dict(env_kind=20, width=8, height=8, num_dists=0)])     # GoToObject: numObjs >= 1
+                                 dict(env_kind=20, width=8, height=8, num_dists=0),      # GoToObject: numObjs >= 1
+                                 dict(env_kind=33, width=22, height=22, room_size=8, num_dists=22),     # BabyAI GoTo: <= 21 distractors
+                                 dict(env_kind=36, width=16, height=6, room_size=6),     # UnlockPickup: 1 x 2 rooms
+                                 dict(env_kind=39, width=11, height=6, room_size=6),     # KeyInBox: 3 x 3 rooms
+                                 dict(env_kind=46, width=8, height=8, room_size=8, num_dists=1),        # PutNextLocal: >= 2 objects
+                                 dict(env_kind=47, width=13, height=7, room_size=7, num_dists=5),       # PutNext: <= 4 objects per room
+                                 dict(env_kind=49, width=22, height=22, room_size=8, num_crossings=3),  # OpenDoor: select_by 0..2
+                                 dict(env_kind=51, width=16, height=16, room_size=6, num_dists=5),      # OpenDoorsOrder: 2..4 doors
+                                 dict(env_kind=52, width=15, height=15, room_size=8, num_dists=9),      # MoveTwoAcross: 1 x 2 rooms
+                                 dict(env_kind=53, width=22, height=22, room_size=8, num_dists=18, num_crossings=0),   # LevelGen: some action kind
+                                 dict(env_kind=53, width=22, height=22, room_size=8, num_dists=18, num_crossings=0x1F, strip2_row=101),  # probability in percent
+                                 dict(env_kind=31, width=16, height=16, room_size=5, num_dists=1),      # ObstructedMaze: room_size 6
+                                 dict(env_kind=32, width=9, height=9, num_dists=2)])     # PutNear: size 5..8
 def test_mg_create_rejects_bad_configs_before_touching_a_device(bad):
     """Validation comes first (MG_ERR_INVALID with a message); only a valid config gets as far as the device check,
     which on this GPU-less box answers MG_ERR_NO_DEVICE -- there is no CPU fallback to fall into."""
