@@ -37,6 +37,63 @@ def decode(w0: int, w1: int) -> str:
     return surf((w0 >> 60) & 7)
 
 
+def _parse_desc(text: str) -> int:
+    art, rest = text.split(" ", 1)
+    loc = 0
+    for k in range(1, 5):
+        if rest.endswith(_LOC[k]):
+            loc, rest = k, rest[: -len(_LOC[k])]
+            break
+    words = rest.split(" ")
+    typ = _TYPE.index(words[-1])
+    col = _COLOR.index(words[0] + " ") if len(words) == 2 else 0
+    return typ | (col << 2) | (loc << 5) | ((1 if art == "a" else 0) << 8)
+
+
+def _parse_leaf(text: str) -> int:
+    for verb, prefix in enumerate(_VERB):
+        if text.startswith(prefix):
+            body = text[len(prefix):]
+            if verb == 3:
+                d, f = body.split(" next to ")
+                return verb | (_parse_desc(d) << 2) | (_parse_desc(f) << 11)
+            return verb | (_parse_desc(body) << 2)
+    raise ValueError(f"not an instruction: {text!r}")
+
+
+def encode(sentence: str):
+    """The inverse of decode (the tree shape LevelGen can produce: leaf | And | Before / After over leaves or Ands): used by the
+    CPU stand-in of the multi-GPU tests and to check decode; the device builds the words from the instruction itself."""
+    leaves, nodes = [], []
+
+    def sub(text: str) -> int:
+        if " and " in text:
+            a, b = text.split(" and ")
+            ia = len(leaves); leaves.append(_parse_leaf(a))
+            ib = len(leaves); leaves.append(_parse_leaf(b))
+            nodes.append(3 | (ia << 2) | (ib << 5))
+            return 3 + len(nodes)
+        leaves.append(_parse_leaf(text))
+        return len(leaves) - 1
+    for kind, sep in ((1, ", then "), (2, " after you ")):
+        if sep in sentence:
+            a, b = sentence.split(sep)
+            ia = sub(a)
+            ib = sub(b)
+            nodes.append(kind | (ia << 2) | (ib << 5))
+            root = 3 + len(nodes)
+            break
+    else:
+        root = sub(sentence)
+    if len(leaves) > 4 or len(nodes) > 3:
+        raise ValueError(f"more than four instructions: {sentence!r}")
+    leaves += [0] * (4 - len(leaves))
+    nodes += [0] * (3 - len(nodes))
+    w0 = leaves[0] | (leaves[1] << 20) | (leaves[2] << 40) | (root << 60)
+    w1 = leaves[3] | (nodes[0] << 20) | (nodes[1] << 28) | (nodes[2] << 36)
+    return w0, w1
+
+
 class SentenceDecoder:
     """(N, 2) u64 mission words -> numpy array of N strings; the distinct sentences of a batch are decoded once and kept."""
 

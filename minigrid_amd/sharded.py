@@ -38,7 +38,7 @@ def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def record_layout(n: int, obs_bytes: int) -> dict:
+def record_layout(n: int, obs_bytes: int, sentence: bool = False) -> dict:
     """Byte offsets of the fields of one step record for a shard of n envs -- the layout mg_create gives a trajectory slot
     (minigrid_amd/csrc/mg_api.hip: every field starts on a 256-byte boundary; tests check it against mg_get_outputs)."""
     up = lambda v: (v + 255) & ~255
@@ -50,6 +50,9 @@ def record_layout(n: int, obs_bytes: int) -> dict:
     off["mission_id"] = off["direction"] + up(n)
     off["action"] = off["mission_id"] + up(2 * n)
     off["record_bytes"] = up(off["action"] + n)
+    if sentence:                      # the sentence levels: the mission as data, two u64 per env (mg_outputs.sentence)
+        off["sentence"] = off["action"] + up(n)
+        off["record_bytes"] = up(off["sentence"] + 16 * n)
     return off
 
 
@@ -84,9 +87,11 @@ class ShardedVecEnv:
             from .vector_env import make_vec as make
             kwargs.setdefault("output", "torch")
         self.local = make(env_id, self.local_num_envs, env_index_base=self.lo, **kwargs)
-        if getattr(self.local, "sentence", False):
-            # their missions travel as two u64 per env (mg_outputs.sentence), which the gathered record below does not carry yet
-            raise NotImplementedError(f"{env_id}: the sentence levels are not wired into the gathered step record; use make_vec per rank")
+        # the sentence levels' missions travel as two u64 per env inside the record and become strings again on every rank
+        self._sentence = bool(getattr(self.local, "sentence", False))
+        if self._sentence:
+            from .sentence import SentenceDecoder
+            self._decode_sentences = SentenceDecoder()
         self._missions = np.asarray(getattr(self.local, "_missions", ()))
         self._mission_index = {m: i for i, m in enumerate(self._missions.tolist())}
         self._zero_copy = hasattr(self.local, "torch_outputs") and getattr(self.local, "output", "") == "torch"
@@ -131,7 +136,7 @@ class ShardedVecEnv:
                 self.local.sync()          # private non-blocking stream: nothing orders it with the collective's stream
             return self.local.torch_outputs()["record"], obs_bytes
         n = self.local_num_envs
-        lay = record_layout(n, obs_bytes)
+        lay = record_layout(n, obs_bytes, self._sentence)
         rec = torch.zeros(lay["record_bytes"], dtype=torch.uint8)
 
         def put(name, t):
@@ -143,10 +148,15 @@ class ShardedVecEnv:
         put("truncated", _to_tensor(np.asarray(trunc, np.uint8)))
         if isinstance(obs, dict):
             put("direction", _to_tensor(np.asarray(obs["direction"], np.uint8)))
-            mis = obs.get("mission_id")
-            if mis is None:
-                mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint16, n)
-            put("mission_id", _to_tensor(np.asarray(mis, np.uint16).view(np.uint8)))
+            if self._sentence:
+                from .sentence import encode
+                words = np.asarray([encode(str(m)) for m in np.asarray(obs["mission"]).tolist()], np.uint64).reshape(n, 2)
+                put("sentence", _to_tensor(words.view(np.uint8).reshape(-1)))
+            else:
+                mis = obs.get("mission_id")
+                if mis is None:
+                    mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint16, n)
+                put("mission_id", _to_tensor(np.asarray(mis, np.uint16).view(np.uint8)))
         return rec, obs_bytes
 
     def gather_record(self, rec=None, obs_bytes=None):
@@ -156,7 +166,7 @@ class ShardedVecEnv:
             rec = self.local.torch_outputs()["record"]
             obs_bytes = int(np.prod(self.local.image_shape))
         W = self.world_size
-        max_bytes = record_layout(self._max_local, obs_bytes)["record_bytes"]
+        max_bytes = record_layout(self._max_local, obs_bytes, self._sentence)["record_bytes"]
         if W == 1:
             return rec.reshape(1, -1)
         self.collectives += 1
@@ -182,7 +192,7 @@ class ShardedVecEnv:
             for r in range(W):
                 lo, hi = shard_range(self.num_envs, r, W)
                 n = hi - lo
-                lay = record_layout(n, obs_bytes)
+                lay = record_layout(n, obs_bytes, self._sentence)
                 raw = buf[r, lay[name]: lay[name] + n * esz]
                 parts.append(raw.view(dtype).reshape((n,) + tuple(tail)))
             return parts[0] if W == 1 else torch.cat(parts, 0)
@@ -190,6 +200,14 @@ class ShardedVecEnv:
         rew_g = field("reward", torch.float64)
         term_g = field("terminated", torch.uint8).bool()
         trunc_g = field("truncated", torch.uint8).bool()
+        if isinstance(obs, dict) and self._sentence:
+            words = field("sentence", torch.int64, (2,))
+            out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}
+            if "mission_id" in obs:          # device outputs: the words stay a tensor (minigrid_amd.sentence.decode turns a row into text)
+                out["sentence"] = words
+            else:
+                out["mission"] = self._decode_sentences(words.cpu().numpy().view(np.uint64))
+            return out, rew_g, term_g, trunc_g
         if isinstance(obs, dict):
             ids = field("mission_id", torch.int16)
             out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}

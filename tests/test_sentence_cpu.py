@@ -58,3 +58,23 @@ def test_batch_decoder_keeps_order_and_caches():
     assert list(out) == ["go to the green box", "pick up a ball", "go to the green box", "go to the green box", "pick up a ball"]
     assert len(dec._cache) == 2
     assert list(dec(arr[::-1])) == list(out[::-1])
+
+
+def test_encode_is_the_inverse_of_decode_on_every_golden_mission():
+    """Every mission string the reference produced for the BabyAI goldens (sentence levels and one-instruction levels alike) survives
+    string -> words -> string; the words are what the multi-GPU record carries for the sentence levels (minigrid_amd/sharded.py)."""
+    import glob
+    import os
+
+    from conftest import GOLDEN
+    from minigrid_amd.sentence import encode
+    n = 0
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "gen_BabyAI-*.npz"))):
+        g = np.load(f)
+        if "mission_str" not in g.files:
+            continue
+        for s in np.unique(g["mission_str"]):
+            s = str(s)
+            assert decode(*encode(s)) == s, (os.path.basename(f), s)
+            n += 1
+    assert n > 500

@@ -25,9 +25,12 @@ class OracleShard:
         self.o = O.OracleVec(env_id, num_envs, full_obs=(obs_mode == "full"))
         self.num_envs, self.env_index_base = num_envs, env_index_base
         self._missions = np.asarray(self.o.missions)
+        # the levels whose mission is an instruction tree: sentences (OracleVec.mission_strings), no mission-id table
+        self.sentence = O.spec(env_id)["kind"] in (O.K_OPENTWODOORS, O.K_OPENDOORSORDER, O.K_MOVETWOACROSS, O.K_LEVELGEN)
 
     def _obs(self, img, d, m):
-        return {"image": img, "direction": d.astype(np.int64), "mission": self._missions[m]}
+        mission = np.asarray(self.o.mission_strings()) if self.sentence else self._missions[m]
+        return {"image": img, "direction": d.astype(np.int64), "mission": mission}
 
     def reset(self, *, seed=None, options=None):
         if isinstance(seed, (int, np.integer)):
@@ -68,7 +71,7 @@ def _worker(rank, world, port, env_id, n, full, out_dir):
             a = rng.integers(0, 7, n, dtype=np.uint8)           # every rank draws the same global action vector
             obs, rew, term, trunc, _ = env.step(a if t % 2 == 0 else a[env.lo:env.hi])   # global or local slice
             log += [obs["image"].numpy().copy(), rew.numpy().copy(), term.numpy().copy(), trunc.numpy().copy(),
-                    np.asarray(obs["mission"] == env._missions[0])]
+                    np.asarray(obs["mission"]).astype(str)]
         # bench.py's timing reduction: MAX over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -80,7 +83,8 @@ def _worker(rank, world, port, env_id, n, full, out_dir):
 
 @pytest.mark.parametrize("env_id,n,full", [("MiniGrid-DoorKey-8x8-v0", 64, False),
                                             ("MiniGrid-LavaCrossingS9N1-v0", 37, True),     # ragged: 19 + 18
-                                            ("BabyAI-GoToRedBall-v0", 50, False)])
+                                            ("BabyAI-GoToRedBall-v0", 50, False),
+                                            ("BabyAI-BossLevel-v0", 21, False)])              # sentences travel as data; ragged: 11 + 10
 def test_two_rank_batch_equals_single_process_batch(tmp_path, env_id, n, full):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), env_id, n, full, str(tmp_path)), nprocs=world, join=True)
@@ -92,7 +96,7 @@ def test_two_rank_batch_equals_single_process_batch(tmp_path, env_id, n, full):
     for t in range(40):
         a = rng.integers(0, 7, n, dtype=np.uint8)
         obs, rew, term, trunc, _ = ref.step(a)
-        want += [obs["image"], rew, term, trunc, obs["mission"] == ref._missions[0]]
+        want += [obs["image"], rew, term, trunc, np.asarray(obs["mission"]).astype(str)]
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         arrs = [got[k] for k in got.files]
