@@ -567,3 +567,23 @@ def test_rgb_65536_envs_sampled_against_oracle():
         seen |= set(np.unique(fold(blk)).tolist())
     assert len(seen) >= 8 and seen <= known
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["MiniGrid-DoorKey-8x8-v0", "BabyAI-BossLevel-v0"])
+def test_step_record_layout_matches_the_host_side_formula(env_id):
+    """minigrid_amd/sharded.py computes the record layout on the host (it has to size the gather buffer for other ranks' shards):
+    offsets and size must be the library's, incl. the mission words of the sentence levels."""
+    from minigrid_amd.sharded import record_layout
+    n = 1000
+    env = _mk(env_id, n)
+    lay = env.record_layout()
+    want = record_layout(n, int(np.prod(env.image_shape)), sentence=env.sentence)
+    assert {k: int(v) for k, v in lay.items()} == {k: int(v) for k, v in want.items()}, (lay, want)
+    if env.sentence:
+        from minigrid_amd.sentence import decode
+        obs, _ = env.reset(seed=3)
+        words = np.asarray(env.device_outputs()["sentence"].__cuda_array_interface__["shape"])
+        assert tuple(words) == (n, 2)
+        env.sync()
+        assert obs["mission"][0] == decode(*(int(x) for x in env._h_sent[0]))
+    env.close()
