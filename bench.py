@@ -59,29 +59,58 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, v
     return b
 
 
-def pmc_traffic_bytes(workload: str, n_per_gpu: int):
+def _profile_dirs(workload: str, n_per_gpu: int, spl: int):
+    """profiles/r*/ directories whose committed rocprofv3 passes of `workload` were taken at THIS batch size and THIS steps-per-
+    launch (profiles/collect.sh writes the run's parameters to meta_<workload>.json next to the counters)."""
+    import glob
+    out = []
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+        try:
+            meta = json.load(open(os.path.join(d, f"meta_{workload}.json")))
+        except Exception:
+            continue
+        if int(meta.get("envs_per_gpu", -1)) == n_per_gpu and int(meta.get("steps_per_launch", -1)) == spl:
+            out.append(d)
+    return out
+
+
+def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
     """HBM bytes per k_step launch from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload>.txt, separate --pmc runs, written by profiles/collect.sh).
     Units and gfx950 correction as MI355X_MICROARCH.md prescribes: the counters are in KiB (x1024); FETCH_SIZE reads
     exactly half of a wide (16 B/lane) coalesced read stream on gfx950, so it is doubled; WRITE_SIZE is taken as is.
-    Counters cannot be read from inside the timed process, so this is the committed measurement, or None."""
-    import glob
+    Counters cannot be read from inside the timed process, so this is the committed measurement -- of a run with the same
+    batch size and steps per launch (the per-call maximum = the full launches) -- or None."""
     import re
-    if n_per_gpu != WORKLOADS[workload][1]:
-        return None
     best = None
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+    for d in _profile_dirs(workload, n_per_gpu, spl):
         vals = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(d, f"pmc_{c}_{workload}.txt")
             if not os.path.exists(f):
                 break
             for line in open(f):
-                m = re.match(rf"{c},(?:void )?mg::(k_step<[^>]*>|k_render),calls=\d+,mean=([0-9.]+)", line)
-                if m:                            # RGB workloads: k_step + k_render make one step
-                    vals[c] = vals.get(c, 0.0) + float(m.group(2))
+                m = re.match(rf"{c},(?:void )?mg::(k_\w+<[^>]*>|k_render),calls=\d+,mean=([0-9.]+)(?:,total=[0-9.]+)?(?:,max=([0-9.]+))?", line)
+                if m and (m.group(1).startswith("k_step") or m.group(1).startswith("k_roll") or m.group(1) == "k_render"):
+                    # RGB workloads: k_step + k_render make one step.  A run mixes full launches with one-step reset observations:
+                    # the per-call maximum is the full launch when the summary has it
+                    vals[c] = vals.get(c, 0.0) + float(m.group(3) or m.group(2))
         if len(vals) == 2:
             best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return best
+
+
+def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int):
+    """Average duration of a FULL step launch / steps per launch from the committed `rocprofv3 --kernel-trace --stats` summary of
+    this command (profiles/<round>/kernel_stats_<workload>.csv; meta_<workload>.json holds the full-launch average computed
+    from the trace by profiles/collect.sh), or None."""
+    best = None
+    for d in _profile_dirs(workload, n_per_gpu, spl):
+        try:
+            meta = json.load(open(os.path.join(d, f"meta_{workload}.json")))
+            best = float(meta["full_launch_avg_us"]) / spl
+        except Exception:
+            pass
     return best
 
 
@@ -105,10 +134,9 @@ def reference_python_baseline(workload: str):
     return best
 
 
-def pmc_traffic_source(workload: str):
-    import glob
+def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int):
     src = None
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+    for d in _profile_dirs(workload, n_per_gpu, spl):
         if all(os.path.exists(os.path.join(d, f"pmc_{c}_{workload}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
             src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}.txt"
     return src
@@ -247,7 +275,7 @@ def main():
         senv = None
         env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
     fused = bool(args.fused) and not gather
-    spl = env.max_fused_steps if fused else 1          # steps per k_step launch
+    spl = min(env.max_fused_steps, args.steps) if fused else 1          # steps per k_step launch in the timed region
     env.reset(seed=0)
     env.sync()
 
@@ -267,13 +295,13 @@ def main():
     run(args.warmup, 1)
     env.sync()
     barrier()
-    env.timer_start()
-    t0 = time.perf_counter()
+    env.timer_start()                    # HIP event on the step stream ...
+    t0 = time.perf_counter()             # ... and the host clock, both opened before the first launch is enqueued
     run(args.steps, 2)
-    env.sync()
+    ev_ms = env.timer_stop()             # event after the last launch on the same stream (waits for it): the launches' own time
+    env.sync()                           # + the generator stream: every episode consumed in the region is drawn again
     barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = env.timer_stop()
+    dt = time.perf_counter() - t0        # whole-job clock (>= the event time): what `value` is computed from
 
     per_rank_us = [dt / args.steps * 1e6]
     if world > 1:
@@ -293,7 +321,8 @@ def main():
         n_launch = -(-args.steps // spl)
         launch_s = (ev_ms / 1e3) / n_launch             # average k_step launch period on its stream (HIP events)
         step_s = (ev_ms / 1e3) / args.steps
-        achieved = n_per_gpu * bpe / step_s / 1e9       # = algorithmic bytes per launch / launch period
+        bytes_per_launch = bpe * n_per_gpu * args.steps / n_launch      # (the last launch of the region may be shorter)
+        achieved = bytes_per_launch / launch_s / 1e9    # algorithmic bytes per launch / average launch duration
         obe = int(np_prod(env.image_shape))
         # what a fused launch has to move per env-step: the outputs (obs + reward 8 + 5 flag/id bytes); the grid and the
         # agent record are read and written once per launch, not per step
@@ -301,6 +330,7 @@ def main():
         out = {
             "metric": "env-steps/s (random policy)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "host_ms": dt * 1e3, "event_ms": ev_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
@@ -314,11 +344,13 @@ def main():
                                        "per_rank_us_per_step": per_rank_us,
                                        "collective": ("one all_gather_into_tensor of the step record per step" if gather else "none on the data path")}},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(args.workload, n_per_gpu) if not args.obs_mode and args.view == 7 else None,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic_bytes(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,
                          "traffic_unit": "bytes per k_step launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
-                         "traffic_source": pmc_traffic_source(args.workload),
-                         "algorithmic_bytes_per_launch": bpe * n_per_gpu * spl,
+                         "traffic_source": pmc_traffic_source(args.workload, n_per_gpu, spl),
+                         "launches": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
+                         "kernel_us_per_step": rocprof_kernel_us_per_step(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,
                          "hbm_bytes_per_env_step_this_kernel": hbm_min,
                          "frac_of_peak_on_actual_bytes": n_per_gpu * hbm_min / step_s / 1e9 / HBM_PEAK_GBPS,
                          "note": "achieved/frac price the SURVEY 8(d) algorithmic bytes (the reference's 3 B/cell grid re-read "

@@ -5,31 +5,58 @@
 hipcc cross-compiles without a GPU.  The library is linked against whatever `libamdhip64.so` the process already
 has (PyTorch-ROCm ships its own copy; importing torch first makes both share ONE HIP runtime) and falls back to
 /opt/rocm/lib through RUNPATH.
+
+The kernels are spread over several translation units (one per k_step rule group, one per generator group and stream
+kind: csrc/mg_launch.h) that compile in parallel; an object is rebuilt only when the hash of its own sources changes.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminigrid_hip.so")
-SOURCES = ["mg_api.hip"]
-HEADERS = ["mg_device.h", "mg_rng.h", "mg_gen.h", "mg_kernels.h", "mg_tiles.h", os.path.join("..", "..", "include", "minigrid_hip.h")]
+OBJDIR = os.path.join(CSRC, ".obj")
+ABI_HEADER = os.path.join("..", "..", "include", "minigrid_hip.h")
 
+_COMMON = ["mg_device.h", "mg_rng.h", "mg_tiles.h", "mg_launch.h"]
+_STEP = _COMMON + ["mg_step.h", "mg_step_tu.inc"]
+_GEN = _COMMON + ["mg_step.h", "mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
+# translation unit -> the headers it is built from (its own file included)
+UNITS = {
+    "mg_api.hip": _COMMON + ["mg_step.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", ABI_HEADER],
+    "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
+}
+for _g in ("rooms", "sentence", "roomgrid", "light"):
+    for _r in ("pcg", "philox"):
+        for _k in ("refill", "generate"):
+            UNITS[f"mg_gen_{_g}_{_r}_{_k}.hip"] = _GEN
+# the slowest units (minutes) first, so that the pool does not end on one of them
+SOURCES = sorted(UNITS, key=lambda n: (not n.startswith("mg_gen_rooms"), not n.startswith("mg_gen_sentence")))
+HEADERS = sorted({h for deps in UNITS.values() for h in deps})
 
 STAMP = LIB + ".srchash"      # sha256 of the sources the library was built from (travels with the .so; mtimes do not)
+CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+          "-fvisibility=hidden"]
+
+
+def _hash_files(names, extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def _source_hash() -> str:
-    import hashlib
-    h = hashlib.sha256()
-    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]:
-        with open(d, "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()
+    with open(os.path.abspath(__file__), "rb") as f:
+        me = hashlib.sha256(f.read()).hexdigest()
+    return _hash_files(SOURCES + HEADERS, me)
 
 
 def _stale() -> bool:
@@ -39,13 +66,16 @@ def _stale() -> bool:
         return f.read().strip() != _source_hash()
 
 
-def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = False, lib: str = LIB, extra_flags=(), extra_link=(),
+          tag: str = "", arch: str = "gfx950") -> str:
+    """`lib` / `extra_flags` / `extra_link` / `tag`: an alternative build of the same sources next to the product library (the
+    sanitizer build, profiles/asan_build.py) -- selected at run time with MINIGRID_AMD_LIB."""
+    if lib == LIB and not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        if missing_hipcc_ok and os.path.exists(LIB):
-            return LIB                      # a deployed tree: use the library it was shipped with
+        if missing_hipcc_ok and os.path.exists(lib):
+            return lib                      # a deployed tree: use the library it was shipped with
         raise RuntimeError("hipcc not found: cannot build libminigrid_hip.so (no CPU fallback exists)")
     rocm_lib = os.environ.get("ROCM_PATH", "/opt/rocm") + "/lib"
     # DT_NEEDED must read "libamdhip64.so" (no version suffix): that is the name PyTorch-ROCm's bundled runtime is
@@ -55,18 +85,37 @@ def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = F
     os.makedirs(stub_dir, exist_ok=True)
     stub = os.path.join(stub_dir, "libamdhip64.so")
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-x", "c", "/dev/null", "-o", stub])
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function", "-fvisibility=hidden",
-           "-no-hip-rt", "-L" + stub_dir, "-Wl,--no-as-needed", "-lamdhip64", "-Wl,--as-needed",
-           "-Wl,-rpath," + rocm_lib, "-Wl,--enable-new-dtags"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB]
+    cflags = ["--offload-arch=" + arch] + CFLAGS + list(extra_flags)
+    os.makedirs(OBJDIR, exist_ok=True)
+
+    def compile_one(src):
+        base = os.path.splitext(src)[0] + tag
+        obj, stamp = os.path.join(OBJDIR, base + ".o"), os.path.join(OBJDIR, base + ".hash")
+        want = _hash_files([src] + UNITS[src], " ".join(cflags))
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return obj
+        cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        t0 = time.time()
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(want)
+        if verbose:
+            print(f"[build] {src}{' ' + tag if tag else ''}: {time.time() - t0:.0f}s", flush=True)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = int(os.environ.get("MINIGRID_AMD_BUILD_JOBS", "0")) or min(len(SOURCES), os.cpu_count() or 1)
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=" + arch, "-shared", "-fPIC", "-no-hip-rt", "-L" + stub_dir, "-Wl,--no-as-needed", "-lamdhip64",
+           "-Wl,--as-needed", "-Wl,-rpath," + rocm_lib, "-Wl,--enable-new-dtags"] + list(extra_link) + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
-        f.write(_source_hash())
-    return LIB
+    if lib == LIB:
+        with open(STAMP, "w") as f:
+            f.write(_source_hash())
+    return lib
 
 
 if __name__ == "__main__":

@@ -17,6 +17,8 @@
 
 #include "../../include/minigrid_hip.h"
 #include "mg_kernels.h"
+#include "mg_kernels_aux.h"
+#include "mg_launch.h"
 
 using namespace mg;
 
@@ -153,16 +155,10 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
   const int wpb = GEN_THREADS / 64;
   const int blocks = std::min((e->N + wpb - 1) / wpb, 8192);
   const size_t lds = (size_t)wpb * gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
-  // one instantiation per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
+  // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-#define MG_GEN_LAUNCH(GGEN)                                                                                              \
-  if (gg == GGEN) {                                                                                                      \
-    if (philox) hipLaunchKernelGGL((k_generate<GGEN, WavePhilox>), dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A); \
-    else hipLaunchKernelGGL((k_generate<GGEN, WavePcg64>), dim3(blocks), dim3(GEN_THREADS), lds, e->stream, A);         \
-  }
-  MG_GEN_LAUNCH(GG_LIGHT) MG_GEN_LAUNCH(GG_ROOMGRID) MG_GEN_LAUNCH(GG_ROOMS) MG_GEN_LAUNCH(GG_SENTENCE)
-#undef MG_GEN_LAUNCH
+  MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, e->stream, A);
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
 }
@@ -181,13 +177,8 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-#define MG_REFILL_LAUNCH(GGEN)                                                                                          \
-  if (gg == GGEN) {                                                                                                     \
-    if (philox) hipLaunchKernelGGL((k_refill<GGEN, WavePhilox>), dim3(e->nwaves * A.wps), dim3(64), lds, st, A);        \
-    else hipLaunchKernelGGL((k_refill<GGEN, WavePcg64>), dim3(e->nwaves * A.wps), dim3(64), lds, st, A);                \
-  }
-  MG_REFILL_LAUNCH(GG_LIGHT) MG_REFILL_LAUNCH(GG_ROOMGRID) MG_REFILL_LAUNCH(GG_ROOMS) MG_REFILL_LAUNCH(GG_SENTENCE)
-#undef MG_REFILL_LAUNCH
+  const dim3 rgrid(e->nwaves * A.wps);
+  MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemsetAsync(A.seg_count, 0, (size_t)e->nwaves * sizeof(uint32_t), st));
   return MG_OK;
@@ -264,11 +255,6 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.env_base = e->cfg.env_index_base;
 }
 
-// every k_step instantiation the library launches: (MODE, FAST7) x rule group
-#define MG_FOR_STEP_VARIANTS(X, GG) X(0, true, GG, 1) X(0, true, GG, 4) X(0, false, GG, 1) X(1, false, GG, 1) X(1, false, GG, 4) \
-  X(2, false, GG, 1) X(3, false, GG, 1) X(3, false, GG, 4) X(4, false, GG, 1)
-#define MG_FOR_STEP_GROUPS(X) MG_FOR_STEP_VARIANTS(X, GG_NONE) MG_FOR_STEP_VARIANTS(X, GG_LIGHT) MG_FOR_STEP_VARIANTS(X, GG_ROOMGRID) MG_FOR_STEP_VARIANTS(X, GG_ROOMS)
-
 static int launch_step(mg_env* e, StepParams& P) {
   // grid = one 64-lane workgroup (one autonomous wavefront) per 64 consecutive envs; P.T steps per launch
   if (e->live_gen) {
@@ -299,19 +285,16 @@ static int launch_step(mg_env* e, StepParams& P) {
   // fused launches stage every env's next spare episode in its LDS shadow slot at launch start
   P.use_shadow = P.T > 1 ? 1 : 0;
   const size_t lds = (size_t)(P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP ? e->lds_bytes : e->off_act);
-  dim3 grid(e->nwaves), block(64);
+  dim3 grid(e->nwaves);
   const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && e->cfg.agent_view_size == 7;
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
                  : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
   const int gg = e->rule_group;
-  bool launched = false;
-#define MG_TRY_LAUNCH(MODE, FAST, GG, LPE)                                                         \
-  if (!launched && mode == MODE && fast7 == FAST && gg == GG && e->lpe == LPE) {                   \
-    hipLaunchKernelGGL((k_step<MODE, FAST, GG, LPE>), grid, block, lds, e->stream, P);             \
-    launched = true;                                                                               \
-  }
-  MG_FOR_STEP_GROUPS(MG_TRY_LAUNCH)
-#undef MG_TRY_LAUNCH
+  // one translation unit per rule group (mg_step_*.hip): (MODE, FAST7, LPE) picks the instantiation inside it
+  const bool launched = gg == GG_NONE ? launch_step_none(mode, fast7, e->lpe, grid, lds, e->stream, P)
+                      : gg == GG_LIGHT ? launch_step_light(mode, fast7, e->lpe, grid, lds, e->stream, P)
+                      : gg == GG_ROOMGRID ? launch_step_roomgrid(mode, fast7, e->lpe, grid, lds, e->stream, P)
+                                          : launch_step_rooms(mode, fast7, e->lpe, grid, lds, e->stream, P);
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
   if (e->sentence) {
@@ -608,7 +591,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
     e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
     e->off_act = e->off_spr + e->epw * 16;
-    e->lds_bytes = e->off_act + 32 * e->epw;                // the actions (at most 32 steps per launch) only when the caller supplies them
+    e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -645,7 +628,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (cfg->traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
     e->S = S;
     // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
-    e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(S, e->static_gen ? 32 : 2 * e->cb);
+    // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
+    e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS : 2 * e->cb);
     if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   }
   // GoToInstr levels: rule_div selects how the described object follows from the mission id (see k_step)
@@ -778,18 +762,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   {
     const int need = e->lds_bytes;
     if (need > 64 * 1024) {
-      const void* fns[] = {
-#define MG_FN(MODE, FAST, GG, LPE) (const void*)k_step<MODE, FAST, GG, LPE>,
-        MG_FOR_STEP_GROUPS(MG_FN)
-#undef MG_FN
-      };
       // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
       // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
       static std::mutex lds_mu;
       static int lds_max[64] = { 0 };
       std::lock_guard<std::mutex> lk(lds_mu);
       if (need > lds_max[device & 63]) {
-        for (const void* f : fns) TRY_OR_FREE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+        TRY_OR_FREE(step_max_lds_none(need)); TRY_OR_FREE(step_max_lds_light(need)); TRY_OR_FREE(step_max_lds_roomgrid(need)); TRY_OR_FREE(step_max_lds_rooms(need));
         lds_max[device & 63] = need;
       }
     }
@@ -797,8 +776,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->sentence) {
     // 19 KB of buffered draws per generating wave: the direct generator launch (4 waves per workgroup) needs more than 64 KB of LDS
     const int need = (GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, 4864, true);
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<GG_SENTENCE, WavePcg64>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
-    TRY_OR_FREE(hipFuncSetAttribute((const void*)k_generate<GG_SENTENCE, WavePhilox>, hipFuncAttributeMaxDynamicSharedMemorySize, need));
+    TRY_OR_FREE(gen_max_lds_sentence_pcg(need)); TRY_OR_FREE(gen_max_lds_sentence_philox(need));
   }
 #undef TRY_OR_FREE
   (void)env;

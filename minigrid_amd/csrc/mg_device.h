@@ -211,4 +211,13 @@ __device__ __forceinline__ void report_errors(uint32_t* err, uint32_t bits) {
   for (int k = 0; k < 4; k++) if ((bits >> k) & 1u) err[k] = 1u;
 }
 
+// generator / rule groups (see mg_gen.h "Groups")
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15 };
+MG_HD int gen_group_of_kind(int kind) { return (kind >= 50 && kind <= 53) ? GG_SENTENCE : (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+
+// `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env wave |
+// STAT_GEN_SLOTS x {maps generated, whole-map retries}; mg_get_counters sums them on the host
+constexpr int STAT_EPISODES = 16;
+constexpr uint32_t STAT_GEN_SLOTS = 4096;
+
 }  // namespace mg

@@ -2038,8 +2038,7 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
 // refill: +14 %).  k_step is instantiated per RULE group with the same constants (mg_api.hip rule_group).
 //   GG_LIGHT single-room levels (+ DynamicObstacles)   GG_ROOMGRID RoomGrid-based levels (incl. GoToRedBall) + GoToObject
 //   GG_ROOMS the multi-room MiniGrid and BabyAI levels with one instruction (kinds 21..49)   GG_SENTENCE kinds 50..53
-enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15 };
-MG_HD int gen_group_of_kind(int kind) { return (kind >= 50 && kind <= 53) ? GG_SENTENCE : (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
+// (the GG_* constants and gen_group_of_kind live in mg_device.h: the step kernels use them without the generators)
 
 template <int GG, class R>
 MG_D void generate_episode(R& rng, GridRef& g, const GenParams& P, GenResult& out) {

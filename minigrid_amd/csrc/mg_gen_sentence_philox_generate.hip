@@ -1,0 +1,6 @@
+// generate kernel of generator group GG_SENTENCE, WavePhilox streams (see mg_gen_tu.inc)
+#define MG_TU_GG GG_SENTENCE
+#define MG_TU_RNG WavePhilox
+#define MG_TU_REFILL 0
+#define MG_TU_NAME sentence_philox
+#include "mg_gen_tu.inc"

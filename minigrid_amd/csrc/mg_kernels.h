@@ -1,1581 +1,4 @@
-// mg_kernels.h — HIP kernels for gfx950 (MI355X): the lockstep MiniGridEnv.step()/gen_obs()/FullyObs hot path as a
-// T-step fused rollout kernel, the asynchronous episode generator that keeps a ring of spare episodes per env full,
-// and seeding.  One wavefront lane per environment; one wavefront = 64 consecutive envs = one workgroup.
-//
-// HBM layout (all per mg_env handle; N envs, env-major):
-//   grid        u8  [N][CS]      one byte per cell (mg_device.h), row-major y*W+x, CS = W*H rounded up to 16
-//   spare_grid  u8  [R][N][CS]   ring of R pre-generated NEXT episodes per env (R = 1 for levels that draw nothing)
-//   agent       u64 [N]          packed agent record (x, y, dir, carrying, step_count, flags, mission)
-//   spare_agent u64 [R][N], spare_aux u64 [R][N]
-//   head / tail u32 [N]          spares consumed / generated so far; slot = count & (R-1); after a flush tail = head + R
-//   rng u64 [5][N]               generator state after the last generated spare; rng_snap u64 [R][5][N] = as it was
-//                                before slot s was drawn (what the reference env's np_random would hold at that point)
-//   out         [S] slots of { obs u8 [N][obe] | reward f64 [N] | terminated, truncated, direction, mission, action u8 [N] }:
-//               the trajectory ring; slot 0 is always the most recent step (mg_get_outputs), slot k the step k calls ago
-//
-// Why spare episodes: in the reference an env's np_random stream is consumed ONLY by reset() on this path, so the
-// maps of episodes k+1, k+2, ... can be drawn any time after episode k's map without changing the stream.  The step
-// kernel therefore never runs a generator: on (auto)reset it takes the next spare out of the ring and files a refill
-// request; a generator kernel on a SECOND stream (one wavefront per request, mg_gen.h) refills the ring while later
-// step launches run.  The host orders the two streams with events so that a slot is never consumed before its refill
-// completed (mg_api.hip: batches); the sequential PCG64 + rejection-sampling code is off the step critical path.
+// mg_kernels.h — everything: the step kernel (mg_step.h) and the generator kernels (mg_genk.h).
 #pragma once
-#include "mg_device.h"
-#include "mg_gen.h"
-#include "mg_tiles.h"
-#include "mg_rng.h"
-
-namespace mg {
-
-constexpr int VIEW = 7;
-constexpr int VIEW_CELLS = VIEW * VIEW;        // 49
-constexpr int PARTIAL_OBS_BYTES = VIEW_CELLS * 3;  // 147
-
-enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
-enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
-enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
-              RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
-              RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13, RULE_PUTNEXT = 14, RULE_OPENDOOR = 15, RULE_SENTENCE = 16 };
-
-struct StepParams {
-  // ---- state ----
-  uint8_t* grid; uint64_t* agent;
-  uint64_t* aux;                                  // BabyAI GoTo levels: bitboard of the tracked target positions
-  const uint8_t* spare_grid; const uint64_t* spare_agent; const uint64_t* spare_aux;   // rings [R][N]...
-  uint32_t* head; uint32_t ring_mask;             // spares consumed per env; slot = head & ring_mask
-  uint32_t* seg; uint32_t* seg_count; int seg_cap;   // this batch's refill requests: one segment of seg_cap env ids per wave
-  // ---- inputs ----
-  const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t0;   // buffer: [T][N] of act_dtype
-  const uint8_t* obs_mask;                        // PHASE_OBSERVE of a masked reset(): only these envs take a new episode
-  // ---- outputs: slot s of the trajectory ring starts at out + s * slot_bytes; step j of this launch -> slot slot0 - j (mod S) ----
-  uint8_t* out; unsigned long long slot_bytes, off_reward, off_term, off_trunc, off_dir, off_mission, off_action;
-  uint8_t* obs; unsigned long long obs_stride;    // observation stream of slot s at obs + s * obs_stride (= out / slot_bytes, or the RGB tile map)
-  int T, slot0, S;
-  // ---- tables / bookkeeping ----
-  uint32_t* err; unsigned long long* counters;
-  // ---- config ----
-  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen;
-  int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
-  int use_shadow;         // the next spare of every env is staged in LDS (its shadow slot) at launch start (fused launches)
-  int off_grid, off_shadow, off_spr, off_act, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
-  int view;               // agent view size V (odd, 3..15)
-  int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
-  uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
-  int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
-  long long env_base;
-};
-
-// _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).
-// Normally read from the host-built LUT; this exact device form covers step_count > max_steps (autoreset disabled).
-MG_D double reward_exact(uint32_t step, int max_steps) {
-  double q = __ddiv_rn((double)step, (double)max_steps);
-  double p = __dmul_rn(0.9, q);
-  return __dsub_rn(1.0, p);
-}
-
-// Uniform-random policy on the device: Philox4x32-10 keyed by action_seed, counter = (global env index, t / 4); the
-// four output words are the actions of steps 4*(t/4) .. 4*(t/4)+3, each mapped to Discrete(7) (minigrid_env.py:63).
-MG_D void philox_action_block(const StepParams& P, int e, uint32_t tblk, uint32_t w[4]) {
-  const uint64_t gi = (uint64_t)(P.env_base + e);
-  w[0] = (uint32_t)gi; w[1] = (uint32_t)(gi >> 32); w[2] = tblk; w[3] = 0x41435431u;
-  philox4x32_10(w, (uint32_t)P.action_seed, (uint32_t)(P.action_seed >> 32));
-}
-MG_D uint32_t load_action(const StepParams& P, int e, int j) {      // prologue only: the loop reads the staged copy from LDS
-  const size_t i = (size_t)j * (size_t)P.N + (size_t)e;
-  if (P.act_dtype == 0) return ((const uint8_t*)P.actions)[i];
-  if (P.act_dtype == 1) { const int32_t v = ((const int32_t*)P.actions)[i]; return (v < 0 || v > 255) ? 255u : (uint32_t)v; }
-  const long long v = ((const long long*)P.actions)[i];
-  return (v < 0 || v > 255) ? 255u : (uint32_t)v;
-}
-
-// bits k in [0,V-1] with 0 <= c0 + s*k < L (s = +1 or -1): the in-bounds run of a view row/column
-MG_D uint32_t inb_mask_v(int c0, int s, int L, int V) {
-  const int lo = s > 0 ? max(0, -c0) : max(0, c0 - (L - 1));
-  const int hi = s > 0 ? min(V - 1, L - 1 - c0) : min(V - 1, c0);
-  const uint32_t m = ((2u << (hi & 31)) - 1u) & ~((1u << (lo & 31)) - 1u);
-  return hi >= lo ? m : 0u;
-}
-
-// ======================================================================================================
-// Observation byte stream.  The 64 envs of a wave produce ONE contiguous byte stream (env-major, obe bytes per env) that
-// is staged in LDS and copied out with 16 B per lane.  obe is odd (147, 243, ...), so an env's bytes do not start on a
-// dword of the stream; byte stores at a 147-byte lane stride were the LDS-conflict hot spot of the previous kernel.
-// Here every lane packs its env's bytes into dwords IN REGISTERS (D[0], D[1], ...: little-endian, stream order) and
-// hands them to StreamEmit, which shifts them by the env's phase and writes only whole, aligned stream dwords:
-//   B                               first stream byte of the lane's byte range (l * obe with one lane per env)
-//   q = (-B) & 3                    leading bytes that belong to the last dword STARTING in env l-1
-//   lane l writes the dwords starting inside its env: indices ceil(B/4) .. ceil((B+obe)/4) - 1
-//   E[i] = bytes [q+4i, q+4i+4) of the env's stream continued by the next env's = funnel(D[i+1] : D[i], q)
-// The one dword a lane cannot complete alone is its last: it ends with the first bytes of the next env, fetched from
-// lane l+1's D[0] by the caller.  Host-callable so that the CPU suite can check it for every obe (mg_selftest_stream).
-// ======================================================================================================
-MG_HD uint32_t funnel_bytes(uint32_t hi, uint32_t lo, uint32_t q) {      // ({hi:lo} >> 8q), q in 0..3
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __funnelshift_r(lo, hi, 8u * q);
-#else
-  return q ? (lo >> (8u * q)) | (hi << (32u - 8u * q)) : lo;
-#endif
-}
-struct StreamEmit {
-  uint32_t* p;        // next aligned dword of the group's stream this lane writes
-  uint32_t prev;      // last dword handed in, not yet written out
-  uint32_t q;
-  uint32_t tb;        // valid bytes of the env's last dword D[ND-1] (1..4)
-  // this lane's bytes are [B, B + len) of the stream (one env, or with several lanes per env its share of the env's cells)
-  MG_HD void setup(uint32_t* stream, uint32_t B, uint32_t len) {
-    q = (0u - B) & 3u;
-    p = stream + ((B + q) >> 2);
-    const uint32_t nd = (len + 3u) >> 2;
-    tb = len - 4u * (nd - 1u);
-  }
-  MG_HD void first(uint32_t d0) { prev = d0; }
-  MG_HD void put(uint32_t d) { *p++ = funnel_bytes(d, prev, q); prev = d; }
-  // the env's last dword (tb valid bytes), completed with the first bytes of the next env's stream (next0 = its D[0])
-  MG_HD void put_last(uint32_t d, uint32_t next0) {
-    const uint32_t xl = tb < 4u ? ((d & ((1u << (8u * tb)) - 1u)) | (next0 << (8u * tb))) : d;
-    const uint32_t xa = tb < 4u ? (next0 >> (32u - 8u * tb)) : next0;
-    put(xl);
-    if (q < tb) *p = funnel_bytes(xa, prev, q);          // one more dword starts inside this env
-  }
-};
-
-// ======================================================================================================
-// Episode generation (the reference's _gen_grid, see mg_gen.h): one wavefront draws one episode.
-// ======================================================================================================
-struct GenArgs {
-  GenParams gp;
-  uint8_t* dst_grid; uint64_t* dst_agent;            // slot 0 of the destination (ring or live state)
-  uint64_t* rng; uint64_t* rng_snap;                 // rng_snap != null: save the pre-draw state of slot s there first
-  uint64_t* dst_aux;                                 // auxiliary word of the generated episode (GenResult.aux) or null
-  uint64_t* dst_instr;                               // sentence levels: [slot][N][INSTR_WORDS] instruction records, or null
-  uint32_t* gstate; uint32_t* gsnap;                 // LevelGen: generator state carried across episodes [N]; as it was before slot s [R][N]
-  const uint8_t* mask;                               // direct mode: optional per-env mask
-  uint32_t* err; unsigned long long* counters;
-  int N, CS;
-  int cap_words;                                     // draw-buffer capacity per generating wave (LDS), in words
-  int stat_gen_off;                                  // first generator statistics slot in `counters`
-  int live;                                          // 1: requests are regenerated IN PLACE (dst = live state): only
-                                                     //    envs still flagged RESET_PENDING are drawn, and come out FRESH
-  // refill mode (k_refill): request segments of one batch, ring bookkeeping
-  const uint32_t* seg; uint32_t* seg_count; int seg_cap;
-  int wps;                                           // generating workgroups (one wavefront each) per request segment
-  const uint32_t* head; uint32_t* tail; uint32_t* claim; uint32_t epoch; uint32_t ring_mask;
-};
-
-// `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env wave |
-// STAT_GEN_SLOTS x {maps generated, whole-map retries}; mg_get_counters sums them on the host
-constexpr int STAT_EPISODES = 16;
-constexpr uint32_t STAT_GEN_SLOTS = 4096;
-
-#ifdef MG_DEBUG_TIMING
-// tuning aid (never built into the product library): cycle stamps of the first wave of block 0 -> counters[4..]
-#define MG_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) A.counters[4 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define MG_STAMP(k) do { } while (0)
-#endif
-
-MG_D uint64_t pick5(const uint64_t w[5], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4]; }
-
-constexpr int GEN_SBASE_BYTES = (int)GEN_SBASE_ENTRIES * 16;
-constexpr int GEN_SCRATCH_BYTES = 64;   // generator state that must survive a restart from a checkpoint (MultiRoom's room lists), at the end
-constexpr int GEN_INSTR_BYTES = INSTR_WORDS * 8;   // sentence levels: the instruction record under construction, after the scratch words
-MG_HD int gen_wave_lds_bytes(int CS, int cap_words, bool sentence = false) {
-  return CS + GEN_SBASE_BYTES + (cap_words + 4) * 4 + GEN_SCRATCH_BYTES + (sentence ? GEN_INSTR_BYTES : 0);
-}
-
-// wave-cooperative: all 64 lanes of one wave call this with the same `e` and ring slot; `lds` = gen_wave_lds_bytes() of LDS
-template <int GG, class RNG>
-MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_t flags_out, uint32_t lane, uint8_t* lds) {
-  const size_t N = (size_t)A.N;
-  const size_t se = (size_t)slot * N + (size_t)e;      // index of (slot, env) in the [R][N] arrays
-
-  uint8_t* mygrid = lds;
-  MG_STAMP(1);
-  rng.load(A.rng, N, (size_t)e, lds + A.CS);
-  MG_STAMP(2);
-  if (A.rng_snap && lane < 5u) A.rng_snap[(size_t)slot * 5u * N + lane * N + (size_t)e] = pick5(rng.w_in, lane);
-  GridRef g{ mygrid, A.gp.W, A.gp.H, (int)lane };
-  for (int k = A.gp.W * A.gp.H + (int)lane; k < A.CS; k += 64) mygrid[k] = 0;
-  GenResult out;
-  const int scratch0 = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
-  if (A.gstate) {
-    // LevelGen's locked_room: the generator state this env's previous episode left (mg_gen.h gen_levelgen); the value before this
-    // slot's episode is kept, like rng_snap, for restarts of the ring
-    const uint32_t gs = uni32(A.gstate[e]);
-    if (lane == 0) { ((uint32_t*)(mygrid + scratch0))[0] = gs; if (A.gsnap) A.gsnap[se] = gs; }
-  }
-  out.gstate = 0;
-  // draw-budget loop: buffer `budget` draws, run the generator.  A pass that ran out of draws restarts from its
-  // last checkpoint (GoToRedBall: the start of the current whole-map attempt) with a fresh buffer, or -- no
-  // checkpoint passed -- is replayed from the start (same draws, same path) with twice the budget.  One refill
-  // covers every DoorKey/Crossing episode; GoToRedBall (about 60 draws per attempt, 15.6 % of attempts rejected)
-  // starts with three.
-  const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
-  const uint32_t want0 = A.gp.kind == 3 ? 384u : A.gp.kind == 53 ? 512u : 1u;        // GoToRedBall; LevelGen (an attempt draws 150-500 words)
-  const uint32_t budget0 = ((want0 + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords;
-  uint32_t budget = budget0, retries_before = 0;
-  out.resume = 0;
-  for (;;) {
-    out.carry = 0;
-    budget = min(budget, cap);
-    while (rng.limit < rng.off + budget) rng.refill();
-    MG_STAMP(3);
-    rng.begin_pass();
-    // The generator parameters are made opaque per pass: otherwise every switch case's loop-invariant set-up is
-    // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70.
-    GenParams gp = A.gp;
-    gp.scratch_off = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
-    gp.instr_off = gp.scratch_off + GEN_SCRATCH_BYTES;
-    asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
-    asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length), "+s"(gp.scratch_off));
-    g.W = gp.W; g.H = gp.H;
-    asm volatile("" : "+v"(g.p), "+v"(g.lane));
-    generate_episode<GG>(rng, g, gp, out);
-    MG_STAMP(4);
-    out.retries += retries_before;
-    if (!rng.dead()) break;
-    if (rng.ck != 0) { retries_before = out.retries; rng.rebase_to_checkpoint(); budget = budget0; out.resume = 1; continue; }
-    if (budget >= cap) { out.failed = true; break; }
-    budget *= 2u;
-  }
-  uint64_t w[5];
-  rng.final_words(w);
-  MG_STAMP(5);
-  if (lane < 5u) A.rng[lane * N + (size_t)e] = pick5(w, lane);
-  MG_WAVE_LDS_SYNC();
-  uint4* dst = (uint4*)(A.dst_grid + se * A.CS);
-  for (int k = (int)lane; k < (A.CS >> 4); k += 64) dst[k] = ((const uint4*)mygrid)[k];
-  if (A.dst_instr && lane < (uint32_t)INSTR_WORDS) A.dst_instr[se * INSTR_WORDS + lane] = ((const uint64_t*)(mygrid + scratch0 + GEN_SCRATCH_BYTES))[lane];
-  if (lane == 0) {
-    Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = out.carry; ag.step = 0; ag.mission = out.mission;
-    ag.flags = flags_out | (out.carry ? FLAG_SHOW_TAKEN : 0u);
-    A.dst_agent[se] = agent_pack(ag);
-    if (A.dst_aux) A.dst_aux[se] = out.aux;
-    if (A.gstate) A.gstate[e] = out.gstate;
-    if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
-    unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
-    atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
-    if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
-  }
-  MG_STAMP(6);
-  MG_WAVE_LDS_SYNC();
-}
-
-// Direct launch over all envs (optionally masked): explicit reset(seed=...), mg_set_rng.  4 generating waves per workgroup.
-// The destination pointers are pre-offset to the ring slot by the host.
-constexpr int GEN_THREADS = 256;
-template <int GGEN, class RNG>
-__global__ void __launch_bounds__(GEN_THREADS) k_generate(const GenArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const int wave = (int)(threadIdx.x >> 6);
-  MG_STAMP(0);
-  RNG rng;
-  rng.prefetch(lane);
-  uint8_t* lds = smem + wave * gen_wave_lds_bytes(A.CS, A.cap_words, A.dst_instr != nullptr);
-  const int nwaves = (int)gridDim.x * (GEN_THREADS / 64);
-  for (int e = (int)blockIdx.x * (GEN_THREADS / 64) + wave; e < A.N; e += nwaves) {
-    if (A.mask && !uni32(A.mask[e])) continue;
-    generate_one<GGEN, RNG>(A, rng, e, 0u, 0u, lane, lds);
-  }
-}
-
-// Refill launch (second stream): workgroup b serves the request segment of step-wave b -- the envs of that 64-env group
-// that took a spare out of their ring during the batch.  A request is an env id; an env may be listed more than once
-// (several launches of one batch), the first wave to raise claim[e] to this batch's epoch serves it: it draws episodes
-// into the consumed slots tail .. head-1 in stream order.  head[] may already be ahead of what the batch consumed
-// (later step launches run concurrently): those slots are free as well, and drawing them early is harmless.
-// live = 1 (DynamicObstacles, same stream, right before the step launch): requests are the envs whose episode ended;
-// they are redrawn IN PLACE if they are still waiting for a reset, and come out FRESH (observed, not stepped).
-// Launch geometry: ONE generating wavefront per workgroup, A.wps workgroups per request segment (workgroup b serves requests
-// b % wps, b % wps + wps, ... of segment b / wps).  Single-wave workgroups keep the LDS footprint at one draw buffer (5 KB), so
-// a CU holds 32 generating waves; multi-wave workgroups held their whole allocation until the slowest wave finished and
-// capped the chip at ~1000 concurrent generations (LavaCrossing refill: 210 us -> measured in profiles/r2).
-template <int GGEN, class RNG>
-__global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t lane = threadIdx.x;
-  const int sidx = (int)(blockIdx.x / (uint32_t)A.wps), wave = (int)(blockIdx.x % (uint32_t)A.wps);
-  const int cnt = (int)uni32(A.seg_count[sidx]);
-  if (wave >= cnt) return;
-  RNG rng;
-  rng.prefetch(lane);
-  uint8_t* lds = smem;
-  const uint32_t* seg = A.seg + (size_t)sidx * A.seg_cap;
-  for (int k = wave; k < cnt; k += A.wps) {
-    const int e = (int)uni32(seg[k]);
-    uint32_t old = 0;
-    if (lane == 0) old = atomicMax(&A.claim[e], A.epoch);
-    if (uni32(old) >= A.epoch) continue;                       // another request of this batch already covers the env
-    if (A.live) {
-      const uint32_t fl = (uint32_t)(uni64(A.dst_agent[e]) >> 48) & 0xFFu;
-      if (!(fl & FLAG_RESET_PENDING)) continue;                // an explicit reset() has drawn this env in the meantime
-      generate_one<GGEN, RNG>(A, rng, e, 0u, FLAG_FRESH, lane, lds);
-      continue;
-    }
-    const uint32_t h = uni32(A.head[e]) + A.ring_mask + 1u;    // every slot below head + R is free to fill
-    uint32_t t = uni32(A.tail[e]);
-    if (h - t > A.ring_mask + 1u) { if (lane == 0) report_errors(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
-    while (t != h) {
-      generate_one<GGEN, RNG>(A, rng, e, t & A.ring_mask, 0u, lane, lds);
-      t++;
-    }
-    if (lane == 0) A.tail[e] = t;
-  }
-  // (the host clears the segment counters on the same stream after this launch; the set is reused QSETS batches later)
-}
-
-// mg_get_rng: the reference env's stream position "now" = the state before its next unconsumed spare was drawn
-__global__ void k_gather_rng(const uint64_t* rng_snap, const uint32_t* head, uint32_t ring_mask, uint64_t* out, int N) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N) return;
-  const size_t s = head ? (size_t)(head[e] & ring_mask) : 0;
-  for (int k = 0; k < 5; k++) out[(size_t)k * N + e] = rng_snap[(s * 5 + k) * (size_t)N + e];
-}
-
-// reset(seed=...): the ring of the selected envs restarts (head = 0; the host then draws all R slots, tail = R)
-__global__ void k_gstate_restore(uint32_t* gstate, const uint32_t* gsnap, const uint32_t* head, const uint8_t* mask, uint32_t R, int N) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N || (mask && !mask[e])) return;
-  gstate[e] = gsnap[(size_t)(head[e] & (R - 1u)) * (size_t)N + (size_t)e];
-}
-__global__ void k_ring_restart(uint32_t* head, uint32_t* tail, const uint8_t* mask, uint32_t R, int N, uint32_t* gstate, const uint32_t* gsnap) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N || (mask && !mask[e])) return;
-  // LevelGen's generator state goes back to what it was after the LIVE episode was drawn (= before the next spare, like mg_get_rng)
-  if (gstate) gstate[e] = gsnap[(size_t)(head[e] & (R - 1u)) * (size_t)N + (size_t)e];
-  head[e] = 0u; tail[e] = R;
-}
-
-// ======================================================================================================
-// k_step: T lockstep steps of MiniGridEnv.step (minigrid_env.py:525-595) + RoomGridLevel.step/GoToInstr
-// (roomgrid_level.py:87-104, verifier.py:309-316) + gen_obs (597-650: get_view_exts/slice/rotate_left/process_vis/
-// encode) or FullyObsWrapper.observation (wrappers.py:419-426), with Gymnasium NEXT_STEP autoreset -- the loop of
-// minigrid/benchmark.py:36-43 for 64 envs per wavefront.  T = 1 is Env.step(); T > 1 is the fused rollout.
-// MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3,
-// 4 = tile map for k_render (RGBImgPartialObsWrapper: VxV bytes; RGBImgObsWrapper: WxH bytes), byte = tile key * 2 + highlight.
-// FAST7: MODE 0 with the reference's default 7x7 view, fully unrolled.  GG = rule group compiled in (mg_gen.h).
-//
-// A wavefront is autonomous: lane l = env env0 + l, no workgroup barrier anywhere.  Launch start: the 64 grids are staged
-// into LDS with 16 B/lane coalesced loads (and, for fused launches, each env's next spare episode into a shadow copy).
-// Per step, all in registers + LDS: Philox action, dynamics (the one modified cell is written in place), view gather
-// through a guard-banded layout (out-of-grid cells need no address clamp, only a mask), process_vis as bit-parallel rows,
-// encode through a 256-entry LDS table, the wave's observations packed into aligned stream dwords (StreamEmit) and
-// copied out with 16 B/lane stores, scalars with one coalesced store each.  HBM traffic per env-step in the loop: the
-// outputs only (obe + 13 bytes written); the grid is read once and written back once per launch.
-// ======================================================================================================
-// LDS hand-off inside one wave for the step loop.  MG_WAVE_LDS_SYNC's release fence also waits for vmcnt(0) on gfx950 -- i.e.
-// for every global store still in flight: inside the T-step loop that would serialise each step behind the previous step's
-// observation stores (measured: 4.2 us per step instead of the store stream's own pace).  DS operations of one wave
-// execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
-#define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-template <int LPE>
-MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
-                    int lane, int nlanes) {
-  // LPE lanes per env: the 49 cells in output order k = vx * 7 + vy are dealt out as 12 units of 4 cells (12 bytes = 3 stream
-  // dwords each) -- 12 / LPE consecutive units per lane -- plus cell 48, which goes to the env's last lane.  A lane's bytes are
-  // one contiguous range of the stream, so StreamEmit works per lane exactly as it does per env.
-  const int W = P.W, H = P.H;
-  constexpr int V = 7, HV = 3, UPL = 12 / LPE, NC = UPL * 4;
-  const bool SEE_THROUGH = P.see_through != 0;
-  const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
-  const bool last_sub = sub == LPE - 1;
-  const int k0 = sub * NC;
-  const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
-  const int rx = -fyv, ry = fxv;
-  const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
-  const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
-  const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
-  const int SR = ry * W + rx;                                 // linear index step per vx
-  const int SU = -(fyv * W + fxv);                            // linear index step per vy
-  // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
-  const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
-  uint32_t code[NC + 1];                                      // this lane's cells (+ cell 48, used by the last lane only)
-  const int vx0 = LPE == 1 ? 0 : (k0 * 37) >> 8, vy0 = LPE == 1 ? 0 : k0 - 7 * vx0;
-  if constexpr (LPE == 1) {
-    // One lane holds the whole view: seven LINES of seven cells that are contiguous along world x -- the view's columns when the
-    // agent faces +-x (line t = vx, byte = vy), its rows when it faces +-y (line t = vy, byte = vx) -- as seven unaligned 8-byte
-    // LDS reads instead of 49 byte reads at scattered banks.  A line is byte-reversed when the view index runs against x, masked
-    // to walls outside the grid as a whole (7 validity bits -> 7 byte masks), and cell (vx, vy) is byte vy of line vx or byte vx
-    // of line vy.  The out-of-grid parts of a line lie in a neighbour's grid or a guard band, like the single cells before.
-    typedef uint64_t u64u __attribute__((aligned(1)));
-    const uint32_t d = a.dir;
-    const bool rev = d < 2u;                                  // east, south: the view index runs against world x
-    const int row_base = (int)a.y + (d == 0u ? -HV : d == 2u ? HV : d == 1u ? V - 1 : -(V - 1));
-    const int lstep = (d == 0u || d == 3u) ? W : -W;
-    const uint8_t* lp = mygrid + row_base * W + (int)a.x - (d == 0u ? 0 : d == 2u ? V - 1 : HV);
-    const uint32_t linemask = horiz ? colmask : rowmask, bytemask = horiz ? rowmask : colmask;
-    uint32_t bm_lo = 0, bm_hi = 0;                            // validity bit j -> byte j = 0xFF
-#pragma unroll
-    for (int j = 0; j < 4; j++) bm_lo |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * j));
-#pragma unroll
-    for (int j = 4; j < V; j++) bm_hi |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * (j - 4)));
-    const uint32_t WALL4 = CELL_WALL_GREY * 0x01010101u;
-    uint32_t qlo[V], qhi[V];
-#pragma unroll
-    for (int t = 0; t < V; t++) {
-      const uint64_t q = *(const u64u*)(lp + t * lstep);
-      const uint64_t r = __builtin_bswap64(q) >> 8;
-      const uint32_t lo = rev ? (uint32_t)r : (uint32_t)q, hi = rev ? (uint32_t)(r >> 32) : (uint32_t)(q >> 32);
-      const uint32_t on = 0u - ((linemask >> t) & 1u);
-      const uint32_t ml = bm_lo & on, mh = bm_hi & on;
-      qlo[t] = (lo & ml) | (WALL4 & ~ml);
-      qhi[t] = (hi & mh) | (WALL4 & ~mh);
-    }
-    auto byte_of = [&](int t, int j) -> uint32_t { return j < 4 ? ((qlo[t] >> (8 * j)) & 0xFFu) : ((qhi[t] >> (8 * (j - 4))) & 0xFFu); };
-#pragma unroll
-    for (int i = 0; i <= NC; i++) {
-      const int vx = i / V, vy = i % V;
-      code[i] = vx == vy ? byte_of(vx, vy) : (horiz ? byte_of(vx, vy) : byte_of(vy, vx));
-    }
-  } else {
-    int vx = vx0, vy = vy0;
-#pragma unroll
-    for (int i = 0; i <= NC; i++) {
-      const uint32_t raw = vbase[vy * SU + vx * SR];
-      const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
-      const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-      code[i] = c;
-      if (++vy == V) { vy = 0; vx++; }
-    }
-  }
-  // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6 (every lane of the env)
-  unsigned long long vis = ~0ull;
-  if (!SEE_THROUGH) {
-    unsigned long long opq49 = 0;                             // opacity bits of this lane's cells, bit 7 * vy + vx
-    {
-      int vx = vx0, vy = vy0;
-#pragma unroll
-      for (int i = 0; i <= NC; i++) {                         // (the extra cell's bit is its owner's bit too)
-        if (LPE == 1) { vx = i / V; vy = i % V; }
-        opq49 |= (unsigned long long)(code[i] >> 7) << (7 * vy + vx);
-        if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
-      }
-    }
-    if (LPE > 1) {
-      uint32_t lo = (uint32_t)opq49, hi = (uint32_t)(opq49 >> 32);
-#pragma unroll
-      for (int d = 1; d < LPE; d <<= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d); hi |= (uint32_t)__shfl_xor((int)hi, d); }
-      opq49 = ((unsigned long long)hi << 32) | lo;
-    }
-    uint32_t m = 1u << HV;
-    vis = 0;
-#pragma unroll
-    for (int j = V - 1; j >= 0; j--) {
-      uint32_t vr, up;
-      vis_row(m, ~(uint32_t)(opq49 >> (7 * j)) & 0x7Fu, &vr, &up);
-      vis |= (unsigned long long)vr << (7 * j);
-      m = up;
-    }
-  }
-  // Grid.encode(vis_mask) (grid.py:244-268) in image[vx][vy][c] order; invisible -> (0,0,0); the agent's own cell shows
-  // what it carries (minigrid_env.py:623-630).  4 cells = 12 bytes = 3 stream dwords.
-  int evx = vx0, evy = vy0;
-  auto tri_of = [&](int i) -> uint32_t {
-    int vx = evx, vy = evy;
-    if (LPE == 1) { vx = i / V; vy = i % V; if (i == NC) { vx = 6; vy = 6; } }
-    uint32_t c = code[i];
-    if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-    if (LPE != 1) { if (++evy == V) { evy = 0; evx++; } }
-    return slut[c & (0u - ((uint32_t)(vis >> (7 * vy + vx)) & 1u))];
-  };
-  StreamEmit em;
-  em.setup(stream, (uint32_t)(el * PARTIAL_OBS_BYTES + k0 * 3), (uint32_t)(NC * 3 + (last_sub ? 3 : 0)));
-  uint32_t next0 = 0, dlast = 0;
-#pragma unroll
-  for (int g = 0; g < UPL; g++) {
-    const uint32_t t0 = tri_of(4 * g), t1 = tri_of(4 * g + 1), t2 = tri_of(4 * g + 2), t3 = tri_of(4 * g + 3);
-    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
-    if (g == 0) {
-      em.first(d0);
-      next0 = (uint32_t)__shfl_down((int)d0, 1);
-      if (lane >= nlanes - 1) next0 = 0u;
-    } else em.put(d0);
-    em.put(d1);
-    if (g < UPL - 1) em.put(d2); else dlast = d2;
-  }
-  const uint32_t t48 = tri_of(NC);
-  if (LPE == 1) { em.put(dlast); em.put_last(t48, next0); }
-  else if (last_sub) { em.put(dlast); em.put_last(t48, next0); }
-  else em.put_last(dlast, next0);
-}
-
-// The same for any odd view size V <= 15 (ViewSizeWrapper), the one-hot encode (MODE 2) and the RGB tile map (MODE 4):
-// run-time loops, visibility rows kept in LDS (16 x u16 per env), bytes stored straight at their stream position.
-template <int MODE>
-MG_D void obs_view_generic(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint16_t* rows,
-                           uint8_t* myT, bool active) {
-  const int W = P.W, H = P.H;
-  const int V = P.view, HV = V >> 1;
-  const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
-  const int rx = -fyv, ry = fxv;
-  const bool horiz = fyv == 0;
-  const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
-  const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
-  const int SR = ry * W + rx, SU = -(fyv * W + fxv);
-  const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
-  const uint32_t full = (1u << V) - 1u;
-  auto cell_at = [&](int vx, int vy) -> uint32_t {
-    const uint32_t raw = vbase[vy * SU + vx * SR];
-    const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
-    return ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-  };
-  if (!P.see_through) {
-#pragma unroll 1
-    for (int vy = 0; vy < V; vy++) {
-      uint32_t opq = 0;
-      for (int vx = 0; vx < V; vx++) opq |= (cell_at(vx, vy) >> 7) << vx;
-      rows[vy] = (uint16_t)(~opq & full);
-    }
-    uint32_t m = 1u << HV;
-#pragma unroll 1
-    for (int j = V - 1; j >= 0; j--) {
-      uint32_t vr, up;
-      vis_row_n(m, rows[j], V, &vr, &up);
-      rows[j] = (uint16_t)vr;
-      m = up;
-    }
-  }
-#pragma unroll 1
-  for (int vy = 0; vy < V; vy++) {
-    const uint32_t vrow = P.see_through ? full : (uint32_t)rows[vy];
-    for (int vx = 0; vx < V; vx++) {
-      uint32_t c = cell_at(vx, vy);
-      if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-      const uint32_t bit = (vrow >> vx) & 1u;
-      if (MODE == 4) {
-        // get_pov_render (minigrid_env.py:652-666): process_vis has blanked the invisible cells (grid.py:324-327),
-        // so they are empty un-highlighted tiles (byte 0); visible ones are highlighted.  Image order [vy][vx].
-        if (!P.rgb_full) myT[vy * V + vx] = (uint8_t)(slut[c] & (0u - bit));
-        continue;
-      }
-      const uint32_t tri = slut[c & (0u - bit)];
-      if (MODE == 0) {
-        uint8_t* o = myT + (vx * V + vy) * 3;
-        o[0] = (uint8_t)tri; o[1] = (uint8_t)(tri >> 8); o[2] = (uint8_t)(tri >> 16);
-      } else if (active) {
-        // OneHotPartialObsWrapper (wrappers.py:267-284): 20 bytes per cell, one 1 in each of the type / colour / state
-        // groups.  Lanes past the batch end hold stale LDS "cells": their codes could index past the 20 bytes.
-        uint8_t* o = myT + (vx * V + vy) * 20;
-        uint32_t* o4 = (uint32_t*)o;
-        o4[0] = 0; o4[1] = 0; o4[2] = 0; o4[3] = 0; o4[4] = 0;
-        o[tri & 0xFF] = 1; o[11 + ((tri >> 8) & 0xFF)] = 1; o[17 + (tri >> 16)] = 1;
-      }
-    }
-  }
-  if (MODE == 4 && P.rgb_full) {
-    // get_full_render (minigrid_env.py:668-714): every grid cell, highlighted where the agent's view sees it.
-    // World cell (x, y) is view cell (HV + d.r, V-1 - d.f) with d = (x, y) - agent: the inverse of the gather above.
-    const uint32_t hl_on = P.rgb_highlight ? 1u : 0u;
-#pragma unroll 1
-    for (int y = 0; y < H; y++) {
-      const int dy = y - (int)a.y;
-      for (int x = 0; x < W; x++) {
-        const int idx = y * W + x, dx = x - (int)a.x;
-        const uint32_t c = mygrid[idx];
-        const int fwd = dx * fxv + dy * fyv, side = dx * rx + dy * ry + HV;
-        const bool inside = (unsigned)fwd < (unsigned)V && (unsigned)side < (unsigned)V;
-        const uint32_t vrow = P.see_through ? full : (uint32_t)rows[inside ? V - 1 - fwd : 0];
-        const uint32_t bit = inside ? ((vrow >> side) & hl_on) : 0u;
-        myT[idx] = (uint8_t)(slut[c] - 1u + bit);
-      }
-    }
-  }
-}
-
-// MODE 1: FullyObsWrapper.observation (wrappers.py:419-426): grid.encode() in image[x][y] order, agent cell = (10, 0, dir).
-// MODE 3: SymbolicObsWrapper.observation (wrappers.py:763-782): (x, y, type or -1), agent cell type = 10.
-// Three bytes per cell in x-major order: 4 cells = 3 stream dwords, like the partial view.  LPE lanes per env: the
-// cells / 4 units are dealt out in LPE consecutive runs (upl units each), the env's last lane also takes what is left over.
-template <int MODE, int LPE>
-MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
-                   int lane, int nlanes) {
-  const int W = P.W, H = P.H, cells = P.cells;
-  const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
-  const bool last_sub = sub == LPE - 1;
-  const int units = cells >> 2, upl = units / LPE;               // host guarantees upl >= 1
-  const int kc0 = sub * upl * 4;                                  // this lane's first cell (output order k = x * H + y)
-  const int nunits = last_sub ? units - (LPE - 1) * upl : upl;
-  const int rem = last_sub ? (cells & 3) : 0;
-  const int aidx = (int)a.y * W + (int)a.x;
-  int x = LPE == 1 ? 0 : kc0 / H, y = LPE == 1 ? 0 : kc0 - x * H;
-  auto next_tri = [&]() -> uint32_t {
-    const int idx = y * W + x;
-    uint32_t c = mygrid[idx], r;
-    if (MODE == 1) {
-      if (idx == aidx) c = T_AGENT_MARK | (a.dir << 4);
-      r = slut[c];
-    } else {
-      const uint32_t t = idx == aidx ? (uint32_t)T_AGENT : (c == CELL_EMPTY ? 0xFFu : cell_ref_type(c));
-      r = (uint32_t)x | ((uint32_t)y << 8) | (t << 16);
-    }
-    if (++y == H) { y = 0; x++; }
-    return r;
-  };
-  StreamEmit em;
-  em.setup(stream, (uint32_t)(el * cells * 3 + kc0 * 3), (uint32_t)(nunits * 12 + rem * 3));
-  uint32_t next0;
-  {
-    const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
-    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
-    em.first(d0);
-    next0 = (uint32_t)__shfl_down((int)d0, 1);
-    if (lane >= nlanes - 1) next0 = 0u;
-    em.put(d1);
-    if (nunits == 1 && rem == 0) em.put_last(d2, next0); else em.put(d2);
-  }
-#pragma unroll 1
-  for (int u = 1; u < nunits; u++) {
-    const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(), t3 = next_tri();
-    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
-    em.put(d0); em.put(d1);
-    if (u == nunits - 1 && rem == 0) em.put_last(d2, next0); else em.put(d2);
-  }
-  if (rem == 1) { em.put_last(next_tri(), next0); }
-  else if (rem == 2) { const uint32_t t0 = next_tri(), t1 = next_tri(); em.put(t0 | (t1 << 24)); em.put_last(t1 >> 8, next0); }
-  else if (rem == 3) { const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(); em.put(t0 | (t1 << 24)); em.put((t1 >> 8) | (t2 << 16)); em.put_last(t2 >> 16, next0); }
-}
-
-template <int MODE, bool FAST7, int GG, int LPE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))    // one autonomous wave per workgroup; LDS, not registers, bounds the occupancy
-k_step(const StepParams P) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // LPE lanes per env (1 or 4): lane = el * LPE + sub.  The LPE lanes of an env hold the same agent state and compute the
-  // same dynamics (free in SIMD terms); they share the observation work (cells dealt out in stream order) and sub-lane 0
-  // does the env's stores.  Fewer envs per wave = more waves for the same batch: latency hiding without any barrier.
-  constexpr int EPW = 64 / LPE;
-  const int lane = threadIdx.x;
-  const int el = LPE == 1 ? lane : lane / LPE, sub = LPE == 1 ? 0 : (lane & (LPE - 1));
-  const bool lead = sub == 0;
-  const int wg = blockIdx.x;
-  const int env0 = wg * EPW;
-  const int e = env0 + el;
-  const bool active = e < P.N;
-  const int nvalid = min(EPW, P.N - env0);
-  const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
-  const size_t N = (size_t)P.N;
-  uint32_t* slut = (uint32_t*)smem;                              // 256-entry cell code -> (type, colour, state) / tile key table
-  uint8_t* sgrid = smem + P.off_grid;
-  uint8_t* sshadow = smem + P.off_shadow;
-  uint16_t* srows = (uint16_t*)(smem + P.off_trow) + el * 16;
-  uint8_t* sslot = smem + P.off_trow;                            // staging only: ring slot of each env's next spare
-  uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + el * 2;       // shadow slot: the spare's agent record and auxiliary word
-  uint8_t* sact = smem + P.off_act;                              // caller-supplied actions of the launch's steps: [T][EPW]
-  uint8_t* sT = smem + P.off_T;
-  const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  // levels with an auxiliary word.  The single-room rules share the variant of the BASELINE GoToRedBall config; the heavier multi-room
-  // ones live in the GG_ROOMS variants so that they do not cost it registers (202 VGPRs with everything in one variant)
-  const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
-                         (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
-
-  // ---- every independent load is issued up front ----
-  const uint64_t rec = active ? P.agent[e] : 0ull;
-  uint64_t targets = (goto_rule && active) ? P.aux[e] : 0ull;   // BabyAI GoTo levels: tracked positions
-  uint32_t h = (P.head && active) ? P.head[e] : 0u;
-  const uint32_t h_in = h;
-  uint32_t qn = P.seg_count ? uni32(P.seg_count[wg]) : 0u;
-  const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
-  // No global LOAD may sit in the step loop or feed a value that is live across it: on gfx950 loads and stores share vmcnt,
-  // so the s_waitcnt a (even conditional, even never-taken) load needs at its join point waits for every observation store
-  // still in flight -- one HBM round trip per step.  Everything the loop may read is staged in LDS here: the grids, the
-  // next spare episode (shadow slot), the caller's actions; the success reward is computed, not looked up.
-  bool shadow_valid = P.use_shadow != 0;
-  if (shadow_valid && active && lead) {
-    const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
-    sspr[0] = P.spare_agent[se];
-    sspr[1] = goto_rule ? P.spare_aux[se] : 0ull;
-  }
-  if (P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER && active && lead)
-    for (int j = 0; j < P.T; j++) sact[j * EPW + el] = (uint8_t)load_action(P, e, j);
-#pragma unroll
-  for (int k = lane; k < 256; k += 64) slut[k] = MODE == 4 ? cell_tile_key((uint32_t)k) * 2u + 1u : cell_triple((uint32_t)k);
-  const int cpe = CS >> 4;
-  const int nchunks = nvalid * cpe;
-  if (P.use_shadow) { if (lead) sslot[el] = (uint8_t)(h & P.ring_mask); MG_LDS_SYNC(); }
-  {
-    // stage the 64 grids: 16 B per lane, fully coalesced (and the next spare episode of every env next to it)
-    const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
-    for (int c = lane; c < nchunks; c += 64) {
-      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20;
-      const uint32_t part = (uint32_t)c - ce * (uint32_t)cpe;
-      const uint4 v = live[c];
-      uint32_t* dst = (uint32_t*)(sgrid + ce * GS + part * 16);
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-      if (P.use_shadow) {
-        const uint32_t slot = sslot[ce];         // (not a __shfl: lanes past the last chunk are off here, and read as 0)
-        const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
-        uint32_t* d2 = (uint32_t*)(sshadow + ce * GS + part * 16);
-        d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
-      }
-    }
-  }
-  MG_LDS_SYNC();
-
-  Agent a = agent_unpack(rec);
-  uint8_t* mygrid = sgrid + el * GS;
-  // BabyAI GoTo levels (RoomGridLevel.step + GoToInstr): `targets` = the TRACKED positions of the described objects, which the
-  // reference refreshes from the grid on every drop ACTION (update_objs_poss, roomgrid_level.py:92-93) and never otherwise;
-  // `cur` = where the described objects are on the grid right now, kept up to date cell change by cell change, so that the
-  // refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
-  // differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
-  auto goto_desc = [&](uint32_t mission) -> uint32_t {
-    // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
-    // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
-    // is returned as the OPEN door's code and matches the door in any state (desc_match).  5 = ActionObjDoor: as 4; id / 48 = the verb.
-    const uint32_t m18 = mission % 18u, m24 = mission % 24u;
-    return P.rule_div == 0 ? (uint32_t)P.rule_cell
-         : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-         : P.rule_div == 2 ? make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u))
-         : P.rule_div == 3 ? make_cell(T_DOOR, color_from_sorted(mission % 6u))
-                           : make_cell((m24 & 3u) == 3u ? (uint32_t)T_DOOR : (uint32_t)T_KEY + (m24 & 3u), color_from_sorted(m24 >> 2));
-  };
-  auto desc_match = [&](uint32_t c, uint32_t desc) -> bool {
-    return c == desc || (cell_type(desc) == T_DOOR && cell_ref_type(c) == T_DOOR && cell_color(c) == cell_color(desc));
-  };
-  uint64_t cur = targets;
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
-    const uint32_t desc = goto_desc(a.mission);
-    cur = 0;
-    for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
-  }
-  // per-lane byte offsets of this env's scalars inside a trajectory slot (slot_bytes < 4 GB): vector registers, so that
-  // the loop does not carry six 64-bit field offsets in scalar registers (the kernel is at the SGPR limit)
-  const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
-                 o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
-                 o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
-  bool rec_dirty = false, aux_dirty = false, wb_all = false;
-  uint32_t errbits = 0, fin_total = 0;
-  uint32_t pw[4] = { 0, 0, 0, 0 };
-
-  for (int j = 0; j < P.T; j++) {
-    int slot_out = P.slot0 - j;
-    while (slot_out < 0) slot_out += P.S;
-    uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
-    // ---- action ----
-    uint32_t act = A_DONE;
-    if (P.phase == PHASE_STEP) {
-      if (P.act_src == ACT_SRC_PHILOX) {
-        const uint32_t t = P.t0 + (uint32_t)j;
-        if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
-        const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
-        act = (uint32_t)(((uint64_t)w * 7u) >> 32);
-      } else act = sact[j * EPW + el];
-    }
-    const uint32_t act_in = act;
-    if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
-    if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
-    double reward = 0.0;
-    uint32_t term = 0, trunc = 0;
-    // The one cell an action can change: it can only change under pickup/drop/toggle, which leave the pose alone, so it
-    // is always the cell straight ahead.  The level rules below see the grid as it was BEFORE the action plus this patch
-    // (RedBlueDoors compares both states); it is written into the LDS grid after them.
-    int dirty_idx = -1;              // linear index of the modified cell, -1 = none
-    uint32_t dirty_code = 0;
-
-    if (active) {
-      if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
-        // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
-        if (!shadow_valid) {
-          // not staged (single-step launch, or the env's second reset within a fused launch): fetch the spare into the
-          // shadow slot first -- the loads and their wait stay inside this branch
-          const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
-          const uint4* src = (const uint4*)(P.spare_grid + se * CS);
-          for (int c = sub; c < cpe; c += LPE) {
-            const uint4 v = src[c];
-            uint32_t* d = (uint32_t*)(sshadow + el * GS + c * 16);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-          }
-          if (lead) { sspr[0] = P.spare_agent[se]; sspr[1] = goto_rule ? P.spare_aux[se] : 0ull; }
-          MG_LDS_SYNC();
-        }
-        {
-          const uint32_t* s = (const uint32_t*)(sshadow + el * GS);
-          uint32_t* d = (uint32_t*)mygrid;
-          for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
-          a = agent_unpack(sspr[0]);
-          if (goto_rule) { targets = sspr[1]; cur = targets; aux_dirty = true; }
-          shadow_valid = false;
-        }
-        a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
-        if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
-        rec_dirty = true; wb_all = true;
-        if (!P.static_gen) h++;
-      } else if (a.flags & FLAG_FRESH) {
-        a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
-        rec_dirty = true;
-      } else if (P.phase == PHASE_STEP) {
-        // ---- MiniGridEnv.step ----
-        rec_dirty = true;
-        const uint32_t pre_carry = a.carry;
-        a.step = min(a.step + 1u, 0xFFFFu);
-        const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-        const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
-        if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
-        const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
-        const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
-        uint32_t newF = F;
-        const uint32_t ftype = cell_type(F);
-        bool success = false;
-        if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
-        else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
-        else if (act == A_FORWARD) {
-          if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
-          if (ftype == T_GOAL) { term = 1; success = true; }
-          if (ftype == T_LAVA) term = 1;
-        } else if (act == A_PICKUP) {
-          if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
-        } else if (act == A_DROP) {
-          if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
-        } else if (act == A_TOGGLE) {
-          newF = cell_toggle(F, a.carry);
-          if constexpr (GG == GG_ROOMS) if (ftype == T_BOX_DOORKEY) {
-            // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
-            uint32_t dc = 0;
-            for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
-            newF = make_cell(T_KEY, dc);
-          }
-        } else if (act != A_DONE) {
-          errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
-        }
-        if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
-        trunc = a.step >= (uint32_t)P.max_steps;
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
-          // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
-          // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
-          // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
-          // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
-          if (dirty_idx >= 0) {
-            const uint32_t desc = goto_desc(a.mission);
-            if (F == desc) cur &= ~(1ull << dirty_idx);
-            if (newF == desc) cur |= 1ull << dirty_idx;
-          }
-          if (act == A_DROP && targets != cur) { targets = cur; aux_dirty = true; }
-          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_GOTO_BIG) {
-          // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
-          // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
-          // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
-          // or a box toggled away): at most one pickup plus the toggled boxes.  `targets` = S as four 16-bit cell indices
-          // (0xFFFF = free); a fifth is reported as ERR_TRACKED instead of being dropped silently.
-          const uint32_t desc = goto_desc(a.mission);
-          if (dirty_idx >= 0 && desc_match(F, desc) && !desc_match(newF, desc)) {
-            int slot = -1;
-#pragma unroll
-            for (int k = 3; k >= 0; k--) if (((targets >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
-            if (slot < 0) errbits |= ERR_TRACKED;
-            else targets = (targets & ~(0xFFFFull << (16 * slot))) | ((uint64_t)dirty_idx << (16 * slot));
-            aux_dirty = true;
-          }
-          if (act == A_DROP && targets != ~0ull) { targets = ~0ull; aux_dirty = true; }           // update_objs_poss
-          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
-            const int gi = gy * W + gx;
-            const uint32_t c = gi == dirty_idx ? dirty_code : (uint32_t)mygrid[gi];
-            bool hit = desc_match(c, desc);
-#pragma unroll
-            for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
-            if (hit && (P.rule_div != 5 || a.mission < 48u)) { term = 1; success = true; }
-          }
-          if (P.rule_div == 5 && a.mission >= 48u) {
-            // ActionObjDoor (other.py:86-106): PickupInstr / OpenInstr about the same description (verifier.py:343-363, 270-287)
-            if (a.mission < 96u) { if (act == A_PICKUP && pre_carry == 0 && a.carry == desc) { term = 1; success = true; } }
-            else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
-          }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
-          // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
-          // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
-          // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
-          // that fails leaves cur_pos at (-1, -1) or -- start_carrying -- at the initial cell, which validate_instrs made non-adjacent
-          // to the fixed object, and that object cannot have moved while the hands were full.
-          // start_carrying (rule_div == 1): the verifier was reset before the object was handed over, so at the episode's first
-          // step its preCarrying is still None
-          const uint32_t mv = a.mission / 18u, fo = a.mission % 18u;
-          if (!(P.rule_div == 1 && a.step == 1u) && pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
-            const uint32_t fixed = make_cell((uint32_t)T_KEY + fo % 3u, color_from_sorted(fo / 3u));
-            bool next = false;
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) {
-              const int nx = fx + dir_dx((uint32_t)d), ny = fy + dir_dy((uint32_t)d);
-              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) next |= (uint32_t)mygrid[ny * W + nx] == fixed;
-            }
-            if (next) { term = 1; success = true; }
-          }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
-          // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
-          // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
-          if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
-          else if (P.rule_div == 1 && cell_ref_type(newF) == T_DOOR) term = 1;
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
-          // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
-          // stands next to target_pos (the one-bit board drawn at reset)
-          if (act == A_TOGGLE) term = 1;
-          if (act == A_DONE) {
-            const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
-            const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
-            term = 1; success = (targets & ring) != 0;
-          }
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEAR) {
-          // PutNearEnv.step (putnear.py:177-199).  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type
-          // (COLOR_NAMES / [key, ball, box] indices); target_pos is a POSITION fixed at reset: the one-bit board `targets`.
-          const uint32_t mv = a.mission / 18u;
-          const uint32_t move = make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u));
-          if (act == A_PICKUP && a.carry != 0 && a.carry != move) term = 1;           // picked up the wrong object
-          if (act == A_DROP && pre_carry != 0) {
-            if (newF != F && inb && targets) {                                        // `grid.get(ox, oy) is preCarrying`: the drop happened
-              const int tidx = __ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
-              if (abs(fx - tx) <= 1 && abs(fy - ty) <= 1) success = true;
-            }
-            term = 1;
-          }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
-          // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
-          // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
-          const uint32_t m12 = a.mission % 12u;
-          const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
-          term = 1; success = a.carry == target;
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
-          // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
-          // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
-          bool open = false;
-          for (int y = 1; y < H - 1; y++) {
-            const int idx = y * W + P.rule_cell;
-            const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
-            open |= cell_type(c) == T_DOOR;
-          }
-          if (open) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
-          // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
-          // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
-          const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
-          if (a.carry == target) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
-          // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
-          // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
-          // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
-          // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
-          const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
-          const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
-                             (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
-          if (newF != F && match) { term = 1; success = true; }
-          else if (P.rule_div == 2) term = 1;
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
-          // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
-          // and it is open after the toggle
-          // (rule_div == 6: the description names a colour -- mission id % 6 -- and any door of that colour counts)
-          if (inb && cell_type(newF) == T_DOOR && (P.rule_div != 6 || cell_color(newF) == color_from_sorted(a.mission % 6u))) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
-          // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
-          // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
-          bool red_before = false, red_after = false, blue_before = false, blue_after = false;
-          const int xr = H / 2, xb = H / 2 + H - 1;
-#pragma unroll 1
-          for (int y = 1; y < H - 1; y++) {
-            const int ir = y * W + xr, ib = y * W + xb;
-            const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
-            const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
-            red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
-            blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
-          }
-          if (blue_after) { term = 1; success = red_before; }
-          else if (red_after && blue_before) { term = 1; success = false; }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
-          // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
-          // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
-          // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
-          // the start-room object at (1, H/2 - 1)
-          const int mid = H / 2;
-          const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
-          if (oy >= 0) {
-            const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
-            if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
-          }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
-          // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
-          // door = the door whose colour the mission names (door colours are distinct and doors never move)
-          if (act == A_TOGGLE) term = 1;
-          if (act == A_DONE) {
-            const uint32_t tc = color_from_sorted(a.mission);
-            bool next_to = false;
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) {
-              const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
-              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
-                const uint32_t c = mygrid[ny * W + nx];
-                next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
-              }
-            }
-            term = 1; success = next_to;
-          }
-        }
-        if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
-        if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
-          // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
-          // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
-          if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
-          a.flags &= ~FLAG_NOT_CLEAR;
-        }
-        if (P.no_death_mask && term) {
-          // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
-          // cell does not terminate; death_cost is added to the reward instead
-          const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
-          const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
-          const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
-          if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
-        }
-        if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
-        if (dirty_idx >= 0) {
-          if (lead) mygrid[dirty_idx] = (uint8_t)dirty_code;
-          if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
-          else wb_all = true;
-        }
-      }
-    }
-    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && lead && (term | trunc)));   // episodes finished in this wave
-    MG_LDS_SYNC();
-
-    // ---- per-env scalar outputs: one coalesced store each ----
-    if (active && lead) {
-      *(double*)(ob + o_rew) = reward;
-      ob[o_term] = (uint8_t)term;
-      ob[o_trunc] = (uint8_t)trunc;
-      ob[o_dir] = (uint8_t)a.dir;
-      *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
-      ob[o_act] = (uint8_t)act_in;
-    }
-
-    // ---- observation -> the wave's byte stream in LDS ----
-    const int obe = P.OBE;
-    Agent av = a;
-    bool show_taken = false;
-    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
-      // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER MiniGridEnv.reset made the
-      // observation: the episode's first core observation (and what OneHotPartialObsWrapper makes of it) shows it where it was, and
-      // empty hands.  The wrappers that look at the env when they are called (FullyObs, Symbolic, RGBImg*) see the state after.
-      if constexpr (MODE == 0 || MODE == 2) {
-        show_taken = true; av.carry = 0;
-        if (lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)a.carry;
-      }
-      a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
-    }
-    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
-    if constexpr (FAST7) {
-      obs_view7<LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
-    } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
-      static_assert(FAST7 || MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
-      obs_view_generic<MODE>(P, av, mygrid, slut, srows, sT + el * obe, active);
-    } else {
-      obs_full<MODE, LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
-    }
-    MG_LDS_SYNC();
-    if constexpr (GG == GG_ROOMS) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
-
-    // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
-    {
-      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)obe;    // 64*obe is a multiple of 16
-      const int nbytes = nvalid * obe;
-      const int nvec = nbytes >> 4;
-      if (FAST7 && nvalid == EPW) {
-        // EPW * 147 / 16 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
-        constexpr int NCH = EPW * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;
-        uint4 v[NIT];                       // (unconditional, clamped reads: a conditionally written array goes to scratch)
-#pragma unroll
-        for (int i = 0; i < NIT; i++) v[i] = ((const uint4*)sT)[min(lane + 64 * i, NCH - 1)];
-#pragma unroll
-        for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) ((uint4*)obase)[c] = v[i]; }
-      } else {
-#pragma unroll 4
-        for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
-        for (int b = (nvec << 4) + lane; b < nbytes; b += 64) obase[b] = sT[b];   // ragged last group only
-      }
-    }
-    MG_LDS_SYNC();
-  }
-
-  // ---- launch end: state back to HBM, refill requests, statistics ----
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
-    const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (cur != targets ? FLAG_TARGETS_STALE : 0u);
-    if (fl != a.flags) { a.flags = fl; rec_dirty = true; }
-  }
-  if (active && lead) {
-    if (rec_dirty) P.agent[e] = agent_pack(a);
-    if (goto_rule && aux_dirty) P.aux[e] = targets;
-    if (h != h_in) P.head[e] = h;
-    if (errbits) report_errors(P.err, errbits);
-  }
-  {
-    const unsigned long long wb = __ballot(active && lead && wb_all);      // envs whose whole live grid changed (new episode, fused launch)
-    if (wb) {
-      uint4* live = (uint4*)(P.grid + (size_t)env0 * CS);
-      for (int c = lane; c < nchunks; c += 64) {
-        const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20;
-        const uint32_t part = (uint32_t)c - ce * (uint32_t)cpe;
-        if ((wb >> (ce * LPE)) & 1ull) {
-          const uint32_t* s = (const uint32_t*)(sgrid + ce * GS + part * 16);
-          uint4 v; v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
-          live[c] = v;
-        }
-      }
-    }
-  }
-  if (P.seg_count) {
-    // one refill request per env that took a spare (however many): the generator draws head - tail episodes for it.
-    // live_gen (DynamicObstacles): the request is "this env's episode ended", served in place before the next step.
-    const bool want = active && lead && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (h != h_in));
-    const unsigned long long m = __ballot(want);
-    if (m) {
-      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (want && qn + rank < (uint32_t)P.seg_cap) P.seg[(size_t)wg * P.seg_cap + qn + rank] = (uint32_t)e;
-      qn = min(qn + (uint32_t)__popcll(m), (uint32_t)P.seg_cap);
-      if (lane == 0) P.seg_count[wg] = qn;
-    }
-  }
-  if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
-}
-
-
-// ======================================================================================================
-// k_verify: RoomGridLevel.step's second half for the sentence levels (roomgrid_level.py:87-104): update_objs_poss after a drop,
-// instrs.verify(action), and -- because max_steps is per episode there (:71-85) -- truncation and the reward.  Runs after every
-// k_step launch of such a level (one step per launch) on the state k_step left in HBM; one lane per env.  k_step itself applies
-// the action, encodes the observation and takes the spare episode at a reset; it reports reward 0 / terminated 0 / truncated 0.
-// ======================================================================================================
-struct VerifyParams {
-  const uint8_t* grid; uint64_t* agent; uint64_t* instr; const uint64_t* spare_instr;
-  const uint32_t* head; uint32_t ring_mask;
-  uint8_t* rec;                      // the step record k_step just wrote
-  size_t off_reward, off_term, off_trunc, off_action, off_sentence;
-  uint32_t* err;
-  int N, W, H, CS, phase, autoreset_next_step;
-};
-struct InstrRef {
-  uint64_t* I; const uint8_t* g; int W, H;
-  uint32_t act, carry_id;            // carry_id: id + 1 of what the agent holds after the action
-  int fidx; bool inb;                // the cell in front of the agent after the action
-  uint32_t errbits;
-  MG_D uint16_t* pos() const { return (uint16_t*)(I + IW_POS); }
-  MG_D int id_at(int cell) const { const uint16_t* p = pos(); for (int i = 0; i < 63; i++) if ((int)p[i] == cell) return i; return -1; }
-  MG_D bool in_stale(int j, int cell) const {
-    const uint64_t s = I[IW_STALE + j];
-    bool hit = false;
-    for (int k = 0; k < 4; k++) hit |= (int)((s >> (16 * k)) & 0xFFFFull) == cell;
-    return hit;
-  }
-  // an object left `cell` without a refresh of obj_poss (picked up, or a box toggled away): every description tracking it keeps the cell
-  MG_D void left(int id, int cell) {
-    for (int j = 0; j < 8; j++)
-      if ((I[IW_SET + j] >> id) & 1ull) {
-        uint64_t s = I[IW_STALE + j];
-        int slot = -1;
-        for (int k = 3; k >= 0; k--) if (((s >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
-        if (slot < 0) errbits |= ERR_TRACKED;
-        else I[IW_STALE + j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
-      }
-  }
-  // verifier.py: GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431
-  MG_D uint32_t leaf(int k) {
-    const uint64_t L = I[IW_LEAF + k];
-    const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
-    const uint64_t dset = I[IW_SET + 2 * k], fset = I[IW_SET + 2 * k + 1];
-    if (verb == V_GOTO) {
-      if (!inb) return R_CONTINUE;
-      const uint32_t c = g[fidx];
-      bool hit = in_stale(2 * k, fidx);
-      if (!hit && c != CELL_EMPTY && cell_type(c) != T_WALL) { const int id = id_at(fidx); hit = id >= 0 && ((dset >> id) & 1ull); }
-      return hit ? R_SUCCESS : R_CONTINUE;
-    }
-    if (verb == V_OPEN) {
-      if (act != A_TOGGLE || !inb) return R_CONTINUE;
-      const uint32_t c = g[fidx];
-      if (cell_ref_type(c) != T_DOOR || cell_type(c) == T_BOX_KEY) return R_CONTINUE;
-      const int id = id_at(fidx);
-      if (id >= 0 && ((dset >> id) & 1ull) && cell_type(c) == T_DOOR) return R_SUCCESS;
-      return strict ? R_FAILURE : R_CONTINUE;
-    }
-    const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying: updated only when this leaf is looked at
-    I[IW_LEAF + k] = (L & ~(127ull << 21)) | ((uint64_t)carry_id << 21);
-    if (verb == V_PICKUP) {
-      if (act != A_PICKUP) return R_CONTINUE;
-      if (pre == 0u && carry_id != 0u && ((dset >> (carry_id - 1u)) & 1ull)) return R_SUCCESS;
-      return (strict && carry_id != 0u) ? R_FAILURE : R_CONTINUE;
-    }
-    if (strict && act == A_PICKUP && carry_id != 0u) return R_FAILURE;
-    if (act != A_DROP) return R_CONTINUE;
-    if (pre == 0u || !((dset >> (pre - 1u)) & 1ull)) return R_CONTINUE;
-    const uint32_t cur = pos()[pre - 1u];                                 // obj_a.cur_pos: where it was just dropped, or (-1, -1)
-    if (cur >= POS_GONE) return R_CONTINUE;
-    const int cx = (int)cur % W, cy = (int)cur / W;
-    bool next = false;
-    for (int m = 0; m < 63; m++)
-      if ((fset >> m) & 1ull) { const uint32_t q = pos()[m]; if (q < POS_GONE) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
-    const uint64_t sf = I[IW_STALE + 2 * k + 1];
-    for (int j = 0; j < 4; j++) { const uint32_t q = (uint32_t)(sf >> (16 * j)) & 0xFFFFu; if (q != 0xFFFFu) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
-    return next ? R_SUCCESS : R_CONTINUE;
-  }
-};
-__global__ void k_verify(const VerifyParams V) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= V.N) return;
-  Agent a = agent_unpack(V.agent[e]);
-  uint64_t* I = V.instr + (size_t)e * INSTR_WORDS;
-  uint64_t* sent = (uint64_t*)(V.rec + V.off_sentence) + (size_t)e * 2;
-  if (a.flags & FLAG_NEW_EPISODE) {
-    // k_step took the env's next spare episode in this launch (reset, autoreset): its instruction record comes with it
-    const uint64_t* src = V.spare_instr + ((size_t)((V.head[e] - 1u) & V.ring_mask) * (size_t)V.N + (size_t)e) * INSTR_WORDS;
-    for (int k = 0; k < INSTR_WORDS; k++) I[k] = src[k];
-    a.flags &= ~FLAG_NEW_EPISODE;
-    V.agent[e] = agent_pack(a);
-    sent[0] = src[IW_MISSION]; sent[1] = src[IW_MISSION + 1];
-    return;
-  }
-  sent[0] = I[IW_MISSION]; sent[1] = I[IW_MISSION + 1];
-  if (V.phase != PHASE_STEP) return;
-  InstrRef R;
-  R.I = I; R.g = V.grid + (size_t)e * V.CS; R.W = V.W; R.H = V.H; R.errbits = 0;
-  R.act = V.rec[V.off_action + e];
-  const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-  R.inb = (unsigned)fx < (unsigned)V.W && (unsigned)fy < (unsigned)V.H;
-  R.fidx = R.inb ? fy * V.W + fx : 0;
-  uint64_t Hd = I[0];
-  uint32_t carry_id = (uint32_t)(Hd >> 55) & 127u;
-  // object identity through the action (minigrid_env.py:556-577): a pickup / drop shows as a change of `carrying`
-  if (a.carry != 0u && carry_id == 0u && R.inb) {
-    const int id = R.id_at(R.fidx);
-    if (id >= 0) { carry_id = (uint32_t)id + 1u; R.pos()[id] = (uint16_t)POS_CARRIED; R.left(id, R.fidx); }
-    else R.errbits |= ERR_TRACKED;
-  } else if (a.carry == 0u && carry_id != 0u && R.inb) {
-    R.pos()[carry_id - 1u] = (uint16_t)R.fidx; carry_id = 0u;
-  } else if (R.act == A_TOGGLE && R.inb && R.g[R.fidx] == CELL_EMPTY) {
-    const int id = R.id_at(R.fidx);                                       // a box was opened: Box.toggle replaces it by its (empty) content
-    if (id >= 0) { R.pos()[id] = (uint16_t)POS_GONE; R.left(id, R.fidx); }
-  }
-  R.carry_id = carry_id;
-  if (R.act == A_DROP) for (int j = 0; j < 8; j++) I[IW_STALE + j] = ~0ull;          // update_objs_poss (roomgrid_level.py:92-93, 106-117)
-  // instrs.verify(action): leaf | And (verifier.py:556-571) | Before / After (:464-486, :507-529) over leaves or And nodes
-  const uint32_t root = (uint32_t)Hd & 7u;
-  auto nodef = [&](uint32_t n) -> uint32_t { return (uint32_t)(Hd >> (3 + 8 * n)) & 255u; };
-  auto done_get = [&](uint32_t n, int which) -> uint32_t { return (uint32_t)(Hd >> (27 + 4 * n + 2 * which)) & 3u; };
-  auto done_set = [&](uint32_t n, int which, uint32_t v) { Hd = (Hd & ~(3ull << (27 + 4 * n + 2 * which))) | ((uint64_t)v << (27 + 4 * n + 2 * which)); };
-  auto and_verify = [&](uint32_t n) -> uint32_t {
-    const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
-    if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, R.leaf((int)ia));
-    if (done_get(n, 1) != R_SUCCESS) done_set(n, 1, R.leaf((int)ib));
-    return (done_get(n, 0) == R_SUCCESS && done_get(n, 1) == R_SUCCESS) ? (uint32_t)R_SUCCESS : (uint32_t)R_CONTINUE;
-  };
-  auto sub_verify = [&](uint32_t idx) -> uint32_t { return idx < 4u ? R.leaf((int)idx) : and_verify(idx - 4u); };
-  uint32_t status;
-  if (root < 4u) status = R.leaf((int)root);
-  else {
-    const uint32_t n = root - 4u, nd = nodef(n), kind = nd & 3u, ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
-    if (kind == N_AND) status = and_verify(n);
-    else {
-      const uint32_t first = kind == N_BEFORE ? ia : ib, second = kind == N_BEFORE ? ib : ia;
-      const int wf = kind == N_BEFORE ? 0 : 1, ws = 1 - wf;
-      status = R_CONTINUE;
-      bool look_at_second = done_get(n, wf) == R_SUCCESS;
-      if (!look_at_second) {
-        const uint32_t r = sub_verify(first);
-        done_set(n, wf, r);
-        if (r == R_FAILURE) status = R_FAILURE;
-        look_at_second = r == R_SUCCESS;                                  // "return self.verify(action)": the second one sees this action too
-      }
-      if (look_at_second) {
-        const uint32_t r = sub_verify(second);
-        done_set(n, ws, r);
-        if (r != R_CONTINUE) status = r;
-      }
-    }
-  }
-  Hd = (Hd & ~(127ull << 55)) | ((uint64_t)carry_id << 55);
-  I[0] = Hd;
-  const uint32_t max_steps = (uint32_t)(Hd >> 39) & 0xFFFFu;
-  const uint32_t term = status != R_CONTINUE, trunc = a.step >= max_steps;
-  *(double*)(V.rec + V.off_reward + (size_t)e * 8) = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
-  V.rec[V.off_term + e] = (uint8_t)term;
-  V.rec[V.off_trunc + e] = (uint8_t)trunc;
-  if ((term | trunc) && V.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; V.agent[e] = agent_pack(a); }
-  if (R.errbits) report_errors(V.err, R.errbits);
-}
-
-// DynamicObstaclesEnv.step, the part before MiniGridEnv.step (dynamicobstacles.py:141-157): remember whether the
-// front cell is occupied, then move every obstacle, in list order, to a random free cell of its 3x3 neighbourhood
-// (place_obj with max_tries=100 on the ENV's stream; an obstacle that finds no place stays).  This level's step consumes the
-// stream, so it is kept out of k_step's register budget.  One wavefront per MOVE_EPB envs: their grids are staged
-// into LDS with 16 B/lane coalesced loads (env stride CS + 4: an odd dword stride), lane l works on env l's copy -- the
-// rejection-sampling chain (draw, look at the cell, draw again) runs at LDS latency instead of one HBM round trip per try --
-// and the grids go back with coalesced 16 B stores.
-constexpr int MOVE_EPB = 16;
-template <class RNG>
-__global__ void __launch_bounds__(64) k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
-                                                       int n_obst) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // The per-env chain (PCG64 draw -> cell test -> next draw) is latency-bound and sequential: MOVE_EPB = 16 envs per wavefront
-  // (the other lanes only help with the staging) puts four wavefronts on every SIMD at 65 536 envs instead of one.
-  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * MOVE_EPB, nvalid = min(MOVE_EPB, N - env0);
-  const int GS = CS + 4, cpe = CS >> 4, nchunks = nvalid * cpe;
-  uint4* live = (uint4*)(grid + (size_t)env0 * CS);
-  for (int c = lane; c < nchunks; c += 64) {
-    const int ce = c / cpe, part = c - ce * cpe;
-    const uint4 v = live[c];
-    uint32_t* d = (uint32_t*)(smem + ce * GS + part * 16);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-  __syncthreads();
-  const int e = env0 + lane;
-  bool moved = false;
-  if (lane < nvalid) {
-    Agent a = agent_unpack(agent[e]);
-    if (!(a.flags & (FLAG_RESET_PENDING | FLAG_FRESH))) {            // (otherwise: no step for this env in the coming launch)
-      uint8_t* g = smem + lane * GS;
-      const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-      const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)g[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
-      const bool not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
-      RNG r;
-      r.load(rng, (size_t)N, (size_t)e);
-      uint64_t o = obst[e];
-      for (int i = 0; i < n_obst; i++) {
-        const int idx = (int)((o >> (8 * i)) & 0xFF), oy = idx / W, ox = idx - oy * W;
-        const int topx = max(ox - 1, 0), topy = max(oy - 1, 0), hx = min(topx + 3, W), hy = min(topy + 3, H);
-        int tries = 0, nx = -1, ny = -1;
-        for (;;) {
-          if (tries > 100) break;                                       // RecursionError, swallowed by `except Exception`
-          tries++;
-          const int x = rand_int(r, topx, hx), y = rand_int(r, topy, hy);
-          if (g[y * W + x] != CELL_EMPTY) continue;
-          if (x == (int)a.x && y == (int)a.y) continue;
-          nx = x; ny = y;
-          break;
-        }
-        if (nx >= 0) {
-          g[ny * W + nx] = (uint8_t)CELL_BALL_BLUE;
-          g[idx] = (uint8_t)CELL_EMPTY;
-          o = (o & ~(0xFFull << (8 * i))) | ((uint64_t)(ny * W + nx) << (8 * i));
-          moved = true;
-        }
-      }
-      r.store(rng, (size_t)N, (size_t)e);
-      obst[e] = o;
-      a.flags = (a.flags & ~FLAG_NOT_CLEAR) | (not_clear ? FLAG_NOT_CLEAR : 0u);
-      agent[e] = agent_pack(a);
-    }
-  }
-  const unsigned long long wb = __ballot(moved);
-  __syncthreads();
-  if (wb)
-    for (int c = lane; c < nchunks; c += 64) {
-      const int ce = c / cpe, part = c - ce * cpe;
-      if ((wb >> ce) & 1ull) {
-        const uint32_t* sp = (const uint32_t*)(smem + ce * GS + part * 16);
-        uint4 v; v.x = sp[0]; v.y = sp[1]; v.z = sp[2]; v.w = sp[3];
-        live[c] = v;
-      }
-    }
-}
-
-// gymnasium.Env.reset(seed=s): np_random = Generator(PCG64(SeedSequence(s)))  (minigrid_env.py:125)
-template <class RNG>
-__global__ void k_seed(uint64_t* rng, const uint64_t* seeds, const uint8_t* mask, int N) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N || (mask && !mask[e])) return;
-  RNG r;
-  r.seed(seeds[e]);
-  r.store(rng, (size_t)N, (size_t)e);
-}
-
-// mark envs for an explicit reset() that continues their stream (consumes the spare)
-__global__ void k_mark_pending(uint64_t* agent, const uint8_t* mask, int N) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N || (mask && !mask[e])) return;
-  Agent a = agent_unpack(agent[e]);
-  a.flags |= FLAG_RESET_PENDING;
-  agent[e] = agent_pack(a);
-}
-
-// ======================================================================================================
-// k_render: RGBImgObsWrapper / RGBImgPartialObsWrapper (wrappers.py:287-380) = Grid.render (grid.py:200-242): the
-// frame is a mosaic of pre-rendered tiles (mg_tiles.h).  Input: k_step's tile map (one byte per cell = tile key * 2 +
-// highlight) and, for the full render, the agent record; output: [N][Ht*ts][Wt*ts][3] bytes.
-//
-// HBM-write bound (9-12 KB written per env against ~60 B read), so the kernel is organised around the store stream:
-//  * A workgroup's EPW consecutive frames are ONE contiguous byte range, dealt out as 16 B chunks, thread t taking
-//    chunks t, t + T, t + 2T, ... with T a multiple of the chunks per "period" (R pixel rows, R the smallest count
-//    whose dwords divide by 4).  A thread's position inside its period -- which tile columns and which dword of the
-//    tile row its four dwords come from -- is therefore loop-invariant; per chunk only the period index is
-//    decomposed into env / tile row / pixel row, incrementally and with 24-bit multiplies.
-//  * Tiles are read from LDS: the 102 agent-free tiles are staged once per workgroup (which then loops over groups
-//    of EPW envs), the one agent tile of each env (cell kind x direction x highlight) once per env.
-// Measured (profiles/r1_final/render_*.txt): the kernel runs at the speed of its own bare store loop; the write order
-// (contiguous per workgroup vs. all workgroups sweeping adjacent frames) made no difference on MI355X.
-// ======================================================================================================
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int RENDER_MAX_THREADS = 1024;          // 256 per workgroup while the LDS footprint lets >= 4 workgroups share a CU, else 1024
-constexpr int STATIC_TILES = 2 * TILE_KEYS;          // [key][highlight]
-
-struct RenderParams {
-  const uint8_t* tilemap; const uint64_t* agent;
-  const uint32_t* atlas_static;    // [key][hl][ts][ts*3/4] dwords
-  const uint32_t* atlas_agent;     // [key][dir][hl][...]
-  uint4* out;
-  int N, Wt, Ht, cells, ts, full, epw, ngroups;
-  int tile_dw, tdw_row, rowdw, R, cpp, ppe, t_active, pp;      // see above; ppe = periods per env, pp = periods per sweep
-  int log2R; uint32_t magic_ts, magic_tdw;                     // R = 1 << log2R; magic_x = ceil(2^16 / x)
-  int off_map;                                                 // LDS: [atlas dwords | u16 tile offsets per cell]
-};
-
-__global__ void __launch_bounds__(RENDER_MAX_THREADS) k_render(const RenderParams R) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* satlas = (uint32_t*)smem;
-  uint16_t* smap = (uint16_t*)(smem + R.off_map);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = (int)blockDim.x;
-  for (int i = tid; i < STATIC_TILES * R.tile_dw; i += nthreads) satlas[i] = R.atlas_static[i];
-
-  // loop-invariant position of this thread's four dwords inside a period
-  const bool worker = tid < R.t_active;
-  const int cidx = tid % R.cpp, p0 = tid / R.cpp;
-  int txj[4], srcj[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int dw = cidx * 4 + j, dr = dw / R.rowdw, col = dw - dr * R.rowdw;
-    txj[j] = col / R.tdw_row;
-    srcj[j] = dr * R.tdw_row + (col - txj[j] * R.tdw_row);
-  }
-  const int img_chunks = R.ppe * R.cpp;
-
-  for (int g = blockIdx.x; g < R.ngroups; g += gridDim.x) {
-    const int env0 = g * R.epw, nv = min(R.epw, R.N - env0);
-    __syncthreads();                                                 // the previous group's blit is done with smap / the agent tiles
-    for (int el = wave; el < nv; el += nthreads >> 6) {
-      const int env = env0 + el;
-      // the agent's cell: POV = bottom centre facing up (minigrid_env.py:659-663); full = its position and direction
-      int cell = (R.Ht - 1) * R.Wt + (R.Wt >> 1), dir = 3;
-      if (R.full) {
-        const Agent a = agent_unpack(R.agent[env]);
-        cell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
-      }
-      const uint8_t* tm = R.tilemap + (size_t)env * R.cells;
-      uint16_t* m = smap + el * R.cells;
-      for (int k = lane; k < R.cells; k += 64) m[k] = (uint16_t)__umul24((uint32_t)tm[k], (uint32_t)R.tile_dw);
-      MG_WAVE_LDS_SYNC();
-      const uint32_t tb = (__umul24((uint32_t)m[cell], R.magic_tdw) >> 16);          // the tile byte under the agent
-      const uint32_t* src = R.atlas_agent + (size_t)(((tb >> 1) * 4u + (uint32_t)dir) * 2u + (tb & 1u)) * R.tile_dw;
-      uint32_t* dst = satlas + (STATIC_TILES + el) * R.tile_dw;
-      for (int k = lane; k < R.tile_dw; k += 64) dst[k] = src[k];
-      MG_WAVE_LDS_SYNC();
-      if (lane == 0) m[cell] = (uint16_t)((STATIC_TILES + el) * R.tile_dw);
-    }
-    __syncthreads();
-    if (worker) {
-      // period p = p0, p0 + pp, ...: (env, period inside the env) advance by constant steps with one conditional
-      // wrap; the rest is 24-bit multiplies of small numbers (full rate), no division
-      u32x4* out = (u32x4*)R.out + (size_t)env0 * img_chunks + (uint32_t)(p0 * R.cpp + cidx);
-      const uint32_t ostep = (uint32_t)(R.pp * R.cpp);
-      const int total = nv * R.ppe, d_el = R.pp / R.ppe, d_pr = R.pp - d_el * R.ppe;
-      int el = p0 / R.ppe, pr = p0 - el * R.ppe;
-      int mb = el * R.cells;
-      const int d_mb = d_el * R.cells;
-#pragma unroll 2
-      for (int p = p0; p < total; p += R.pp) {
-        const uint32_t row0 = (uint32_t)pr << R.log2R;
-        const uint32_t ty = __umul24(row0, R.magic_ts) >> 16;
-        const uint32_t rowoff = __umul24(row0 - __umul24(ty, (uint32_t)R.ts), (uint32_t)R.tdw_row);
-        const uint16_t* m = smap + mb + __umul24(ty, (uint32_t)R.Wt);
-        u32x4 v;
-        v.x = satlas[(uint32_t)m[txj[0]] + rowoff + srcj[0]];
-        v.y = satlas[(uint32_t)m[txj[1]] + rowoff + srcj[1]];
-        v.z = satlas[(uint32_t)m[txj[2]] + rowoff + srcj[2]];
-        v.w = satlas[(uint32_t)m[txj[3]] + rowoff + srcj[3]];
-        *out = v;
-        out += ostep;
-        pr += d_pr; mb += d_mb;
-        if (pr >= R.ppe) { pr -= R.ppe; mb += R.cells; }
-      }
-    }
-  }
-}
-
-// ======================================================================================================
-// State exchange on the device (mg_get_state / mg_set_state): Grid.encode() layout (N, W, H, 3) <-> the one-byte-per-cell
-// row-major grids, and the (N, 8) i32 agent records <-> the packed u64 records.  One thread per (env, cell) / per env.
-// ======================================================================================================
-__global__ void k_state_encode(const uint8_t* grid, const uint64_t* agent, uint8_t* out_grid, int32_t* out_agent, int N, int W, int H, int CS) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t cells = (size_t)W * H;
-  if (i >= (size_t)N * cells) return;
-  const size_t n = i / cells;
-  const int k = (int)(i - n * cells), x = k / H, y = k - x * H;             // output order image[x][y]
-  const uint32_t tri = cell_triple(grid[n * CS + (size_t)y * W + x]);
-  uint8_t* p = out_grid + i * 3;
-  p[0] = (uint8_t)tri; p[1] = (uint8_t)(tri >> 8); p[2] = (uint8_t)(tri >> 16);
-  if (k == 0) {
-    const Agent ag = agent_unpack(agent[n]);
-    int32_t* o = out_agent + n * 8;
-    o[0] = (int32_t)ag.x; o[1] = (int32_t)ag.y; o[2] = (int32_t)ag.dir;
-    o[3] = ag.carry ? (int32_t)(cell_triple(ag.carry) & 0xFF) : 0;
-    o[4] = ag.carry ? (int32_t)((cell_triple(ag.carry) >> 8) & 0xFF) : 0;
-    o[5] = (int32_t)ag.step; o[6] = (int32_t)(ag.flags & FLAG_RESET_PENDING); o[7] = (int32_t)ag.mission;
-  }
-}
-__global__ void k_state_decode(const uint8_t* in_grid, const int32_t* in_agent, uint8_t* grid, uint64_t* agent, uint32_t* bad, int N, int W, int H, int CS) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t cells = (size_t)W * H;
-  if (i >= (size_t)N * cells) return;
-  const size_t n = i / cells;
-  const int k = (int)(i - n * cells), x = k / H, y = k - x * H;
-  const uint8_t* p = in_grid + i * 3;
-  grid[n * CS + (size_t)y * W + x] = (uint8_t)cell_from_triple(p[0], p[1], p[2]);
-  if (k == 0) {
-    const int32_t* o = in_agent + n * 8;
-    if (o[0] < 0 || o[0] >= W || o[1] < 0 || o[1] >= H || (unsigned)o[2] > 3u || o[5] < 0 || o[5] > 65535 || (unsigned)o[7] > 16383u) { *bad = 1u; return; }
-    Agent ag;
-    ag.x = (uint32_t)o[0]; ag.y = (uint32_t)o[1]; ag.dir = (uint32_t)o[2];
-    ag.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
-    if (ag.carry == CELL_EMPTY) ag.carry = 0;
-    ag.step = (uint32_t)o[5]; ag.flags = o[6] ? FLAG_RESET_PENDING : 0u; ag.mission = (uint32_t)o[7];
-    agent[n] = agent_pack(ag);
-    for (int c = (int)cells; c < CS; c++) grid[n * CS + c] = 0;
-  }
-}
-// the auxiliary word is not part of the exchanged state: it is re-derived from the injected grid.  mode 1: GoToInstr's tracked
-// positions / target_pos = the cells holding the described object (desc from the mission id, see k_step); mode 2:
-// DynamicObstacles' obstacle list, rebuilt in cell-index order
-__global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64_t* aux, int N, int cells, int CS, int mode, int rule_div, int rule_cell) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  const uint8_t* g = grid + (size_t)n * CS;
-  uint64_t w = 0;
-  if (mode == 1) {
-    const uint32_t mis = agent_unpack(agent[n]).mission, m18 = mis % 18u;
-    const uint32_t desc = rule_div == 0 ? (uint32_t)rule_cell
-                        : rule_div == 1 ? make_cell(T_BALL, mis ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-                                        : make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u));
-    for (int c = 0; c < cells && c < 64; c++) if (g[c] == desc) w |= 1ull << c;
-  } else if (mode == 3) {
-    w = ~0ull;                                       // RULE_GOTO_BIG: no stale tracked position; PutNext: not used once an episode runs
-  } else if (mode == 4) {
-    // OpenDoor: the described doors.  A colour description follows from the mission id; a location description ("the door on
-    // your left") was resolved against the agent's pose at reset and is not part of the exchanged state: the env's set is kept.
-    const uint32_t mis = agent_unpack(agent[n]).mission;
-    if (mis >= 6u) return;
-    w = 1ull << color_from_sorted(mis);
-  } else {
-    int k = 0;
-    for (int c = 0; c < cells && k < 8; c++) if (cell_type(g[c]) == T_BALL) w |= (uint64_t)c << (8 * k++);
-  }
-  aux[n] = w;
-}
-
-}  // namespace mg
+#include "mg_step.h"
+#include "mg_genk.h"

@@ -1,0 +1,40 @@
+// mg_launch.h — host-side launch entry points of the kernel translation units.  The k_step instantiations of one rule group and
+// the generator kernels of one generator group each live in their own .hip file (mg_step_g*.hip, mg_gen_g*.hip, bodies in
+// mg_step_tu.inc / mg_gen_tu.inc) so that the library builds in parallel (minigrid_amd/build.py); mg_api.hip only sees these.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mg_step.h"
+#ifndef MG_STEP_TU_ONLY
+#include "mg_genk.h"
+#endif
+
+namespace mg {
+
+// Launch the k_step<mode, fast7, GG, lpe> instantiation of rule group GG; false if the group's TU has no such variant.
+#define MG_DECL_STEP_TU(NAME)                                                                                              \
+  bool launch_step_##NAME(int mode, bool fast7, int lpe, dim3 grid, size_t lds, hipStream_t st, const StepParams& P);      \
+  hipError_t step_max_lds_##NAME(int bytes);
+MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_STEP_TU(rooms)
+#undef MG_DECL_STEP_TU
+
+#ifndef MG_STEP_TU_ONLY
+// k_generate / k_refill of one generator group and stream kind (numpy PCG64 | Philox): one translation unit per kernel
+#define MG_DECL_GEN_TU(NAME)                                                                       \
+  void launch_generate_##NAME(dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);            \
+  void launch_refill_##NAME(dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);              \
+  hipError_t gen_max_lds_##NAME(int bytes);
+MG_DECL_GEN_TU(light_pcg) MG_DECL_GEN_TU(roomgrid_pcg) MG_DECL_GEN_TU(rooms_pcg) MG_DECL_GEN_TU(sentence_pcg)
+MG_DECL_GEN_TU(light_philox) MG_DECL_GEN_TU(roomgrid_philox) MG_DECL_GEN_TU(rooms_philox) MG_DECL_GEN_TU(sentence_philox)
+#undef MG_DECL_GEN_TU
+// dispatch on (generator group, stream kind)
+#define MG_GEN_DISPATCH(FN, gg, philox, ...)                                                       \
+  do {                                                                                             \
+    if (philox) { if (gg == GG_LIGHT) FN##light_philox(__VA_ARGS__); else if (gg == GG_ROOMGRID) FN##roomgrid_philox(__VA_ARGS__);   \
+                  else if (gg == GG_ROOMS) FN##rooms_philox(__VA_ARGS__); else FN##sentence_philox(__VA_ARGS__); }                   \
+    else { if (gg == GG_LIGHT) FN##light_pcg(__VA_ARGS__); else if (gg == GG_ROOMGRID) FN##roomgrid_pcg(__VA_ARGS__);               \
+           else if (gg == GG_ROOMS) FN##rooms_pcg(__VA_ARGS__); else FN##sentence_pcg(__VA_ARGS__); }                                \
+  } while (0)
+#endif
+
+}  // namespace mg

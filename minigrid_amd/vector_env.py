@@ -225,13 +225,14 @@ class MiniGridVecEnv(_VectorEnvBase):
             self._torch_views[slot] = {k: torch.as_tensor(v, device=dev) for k, v in self.device_outputs(slot).items()}
         return self._torch_views[slot]
 
-    def trajectory(self, slot: int):
-        """Host copy of trajectory slot `slot`: (image, reward, terminated, truncated, direction, mission_id, action)."""
+    def trajectory(self, slot: int, image: bool = True):
+        """Host copy of trajectory slot `slot`: (image, reward, terminated, truncated, direction, mission_id, action).
+        image=False skips the (large) observation copy and returns None in its place."""
         n = self.num_envs
-        img = np.empty((n,) + self.image_shape, np.int8 if self.obs_mode == "symbolic" else np.uint8)
+        img = np.empty((n,) + self.image_shape, np.int8 if self.obs_mode == "symbolic" else np.uint8) if image else None
         rew = np.empty(n, np.float64)
         u8 = [np.empty(n, np.uint16 if k == 3 else np.uint8) for k in range(5)]      # mission ids are 16 bits wide
-        rc = self._lib.mg_copy_slot(self._h, int(slot), self._p(img), self._p(rew), *[self._p(a) for a in u8])
+        rc = self._lib.mg_copy_slot(self._h, int(slot), None if img is None else self._p(img), self._p(rew), *[self._p(a) for a in u8])
         B.check(rc, self._h)
         return img, rew, u8[0].astype(bool), u8[1].astype(bool), u8[2], u8[3], u8[4]
 

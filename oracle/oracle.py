@@ -356,6 +356,8 @@ def lib():
         L.oracle_rng_kat.argtypes = [C.c_uint64, vp, vp, C.c_int, vp, C.c_int, C.c_int64]
         L.oracle_shuffle_kat.argtypes = [C.c_uint64, vp, C.c_int]
         L.oracle_reward_lut.argtypes = [C.c_int, vp]
+        L.oracle_philox_actions.argtypes = [C.c_uint64, C.c_uint32, C.c_int64, C.c_int, vp]
+        L.oracle_philox4x32_10.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.oracle_rollout.restype = C.c_uint64
         L.oracle_rollout.argtypes = [vp, C.c_int, C.c_uint64, vp]
         _LIB = L
@@ -437,6 +439,20 @@ class OracleVec:
         lib().oracle_reset(self.h, _p(sd), _p(mk), _p(obs), _p(d), _p(m))
         return self._frame(obs), d, self._missions(m)
 
+    def step_quiet(self, actions, autoreset: int = 1):
+        """step() without producing the observation (replaying a long rollout whose observations are compared on a sample of
+        steps only): returns (reward, terminated, truncated)."""
+        a = np.ascontiguousarray(actions, dtype=np.uint8)
+        rew = np.zeros(self.n, np.float64)
+        term = np.zeros(self.n, np.uint8)
+        trunc = np.zeros(self.n, np.uint8)
+        rc = lib().oracle_step(self.h, _p(a), autoreset, None, _p(rew), _p(term), _p(trunc), None, None)
+        if rc == -1:
+            raise ValueError("Unknown action")
+        if rc:
+            raise AssertionError("front cell out of bounds")
+        return rew, term.astype(bool), trunc.astype(bool)
+
     def step(self, actions, autoreset: int = 1):
         obs, d, m = self._outs()
         a = np.ascontiguousarray(actions, dtype=np.uint8)
@@ -474,6 +490,19 @@ class OracleVec:
     def rollout(self, T: int, action_seed: int = 0) -> int:
         scratch = np.zeros(int(np.prod(self.obs_shape)), np.uint8)
         return int(lib().oracle_rollout(self.h, T, action_seed, _p(scratch)))
+
+
+def philox_actions(action_seed: int, t: int, n: int, env_base: int = 0):
+    """Actions of step counter `t` of the product's device policy (mg_rollout) for envs env_base .. env_base + n - 1."""
+    out = np.zeros(n, np.uint8)
+    lib().oracle_philox_actions(int(action_seed), int(t), int(env_base), int(n), _p(out))
+    return out
+
+
+def philox4x32_10(counter, key):
+    c = np.asarray(counter, np.uint32).copy()
+    lib().oracle_philox4x32_10(_p(c), int(key[0]), int(key[1]))
+    return c
 
 
 def rng_kat(seed: int, n32: int = 16, nb: int = 16, bound_hi: int = 7):

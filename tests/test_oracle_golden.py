@@ -227,3 +227,18 @@ def test_oracle_stepping_past_termination_matches_reference(env_id):
         assert rew.tobytes() == g["reward"][:, t].tobytes() and (term == g["term"][:, t]).all() and (trunc == g["trunc"][:, t]).all(), (env_id, t)
         repeats += int(term.sum())
     assert repeats > 8              # successes re-fire after the first one
+
+
+def test_philox4x32_10_known_answers():
+    """The device policy's generator, restated in the oracle, against Random123's published known-answer vectors
+    (kat_vectors: `philox4x32 10 <counter x4> <key x2> <output x4>`)."""
+    from oracle import oracle as O
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(v) for v in O.philox4x32_10(ctr, key)) == want
+    # the action mapping: word t & 3 of block t >> 2, multiply-shift to Discrete(7); env index in the counter
+    a = np.stack([O.philox_actions(9, t, 4096, env_base=100) for t in range(8)])
+    assert a.max() == 6 and a.min() == 0 and abs(np.bincount(a.ravel(), minlength=7) / a.size - 1 / 7).max() < 0.01
+    assert (O.philox_actions(9, 5, 10, env_base=103) == a[5, 3:13]).all()
