@@ -26,7 +26,7 @@ ABI_HEADER = os.path.join("..", "..", "include", "minigrid_hip.h")
 
 _COMMON = ["mg_device.h", "mg_rng.h", "mg_tiles.h", "mg_launch.h"]
 _STEP = _COMMON + ["mg_step.h", "mg_step_tu.inc"]
-_GEN = _COMMON + ["mg_step.h", "mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
+_GEN = _COMMON + ["mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
 # translation unit -> the headers it is built from (its own file included)
 UNITS = {
     "mg_api.hip": _COMMON + ["mg_step.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", ABI_HEADER],

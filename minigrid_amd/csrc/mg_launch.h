@@ -4,19 +4,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef MG_GEN_TU_ONLY
 #include "mg_step.h"
+#endif
 #ifndef MG_STEP_TU_ONLY
 #include "mg_genk.h"
 #endif
 
 namespace mg {
 
+#ifndef MG_GEN_TU_ONLY
 // Launch the k_step<mode, fast7, GG, lpe> instantiation of rule group GG; false if the group's TU has no such variant.
 #define MG_DECL_STEP_TU(NAME)                                                                                              \
   bool launch_step_##NAME(int mode, bool fast7, int lpe, dim3 grid, size_t lds, hipStream_t st, const StepParams& P);      \
   hipError_t step_max_lds_##NAME(int bytes);
 MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_STEP_TU(rooms)
 #undef MG_DECL_STEP_TU
+#endif
 
 #ifndef MG_STEP_TU_ONLY
 // k_generate / k_refill of one generator group and stream kind (numpy PCG64 | Philox): one translation unit per kernel

@@ -429,6 +429,333 @@ MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, c
   else if (rem == 3) { const uint32_t t0 = next_tri(), t1 = next_tri(), t2 = next_tri(); em.put(t0 | (t1 << 24)); em.put((t1 >> 8) | (t2 << 16)); em.put_last(t2 >> 16, next0); }
 }
 
+// ======================================================================================================
+// One env transition: MiniGridEnv.reset (take the next spare episode) | observe-only | MiniGridEnv.step + the level rule,
+// on the lane's registers (EnvRegs) and the env's LDS grid.  Shared by k_step and k_roll7 (mg_roll.h).
+// ======================================================================================================
+struct EnvRegs {          // what lives in registers across the steps of a launch
+  Agent a;
+  uint64_t targets, cur;  // GoTo levels: tracked positions / where the described objects are now (see below)
+  uint32_t h;             // spares consumed so far (ring head)
+  bool shadow_valid;      // the env's next spare episode is staged in its LDS shadow slot
+  bool rec_dirty, aux_dirty, wb_all;
+  uint32_t errbits;
+};
+struct LaneCtx {          // the lane's view of its env: loop-invariant
+  int e, el, sub;
+  bool active, lead, reset_enabled, maskok, goto_rule;
+  uint8_t* mygrid; const uint8_t* myshadow; const uint64_t* sspr;
+};
+
+// BabyAI GoTo levels (RoomGridLevel.step + GoToInstr): `targets` = the TRACKED positions of the described objects, which the
+// reference refreshes from the grid on every drop ACTION (update_objs_poss, roomgrid_level.py:92-93) and never otherwise;
+// `cur` = where the described objects are on the grid right now, kept up to date cell change by cell change, so that the
+// refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
+// differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
+MG_D uint32_t goto_desc(const StepParams& P, uint32_t mission) {
+  // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
+  // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
+  // is returned as the OPEN door's code and matches the door in any state (desc_match).  5 = ActionObjDoor: as 4; id / 48 = the verb.
+  const uint32_t m18 = mission % 18u, m24 = mission % 24u;
+  return P.rule_div == 0 ? (uint32_t)P.rule_cell
+       : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
+       : P.rule_div == 2 ? make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u))
+       : P.rule_div == 3 ? make_cell(T_DOOR, color_from_sorted(mission % 6u))
+                         : make_cell((m24 & 3u) == 3u ? (uint32_t)T_DOOR : (uint32_t)T_KEY + (m24 & 3u), color_from_sorted(m24 >> 2));
+}
+MG_D bool desc_match(uint32_t c, uint32_t desc) {
+  return c == desc || (cell_type(desc) == T_DOOR && cell_ref_type(c) == T_DOOR && cell_color(c) == cell_color(desc));
+}
+
+template <int GG, int LPE>
+MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc) {
+  const int W = P.W, H = P.H, CS = P.CS, cpe = P.CS >> 4;
+  const size_t N = (size_t)P.N;
+  const int e = C.e, sub = C.sub;
+  const bool active = C.active, lead = C.lead, reset_enabled = C.reset_enabled, maskok = C.maskok, goto_rule = C.goto_rule;
+  uint8_t* mygrid = C.mygrid;
+  Agent& a = S.a;
+  uint64_t& targets = S.targets; uint64_t& cur = S.cur;
+  uint32_t& h = S.h; uint32_t& errbits = S.errbits;
+  bool& shadow_valid = S.shadow_valid; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
+  // The one cell an action can change: it can only change under pickup/drop/toggle, which leave the pose alone, so it
+  // is always the cell straight ahead.  The level rules below see the grid as it was BEFORE the action plus this patch
+  // (RedBlueDoors compares both states); it is written into the LDS grid after them.
+  int dirty_idx = -1;              // linear index of the modified cell, -1 = none
+  uint32_t dirty_code = 0;
+  if (active) {
+    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
+      // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
+      if (!shadow_valid) {
+        // not staged (single-step launch, or the env's second reset within a fused launch): straight from the ring in HBM into the
+        // live LDS grid -- the loads and their wait stay inside this branch
+        const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
+        const uint4* src = (const uint4*)(P.spare_grid + se * CS);
+        for (int c = sub; c < cpe; c += LPE) {
+          const uint4 v = src[c];
+          uint32_t* d = (uint32_t*)(mygrid + c * 16);
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        a = agent_unpack(P.spare_agent[se]);
+        if (goto_rule) { targets = P.spare_aux[se]; cur = targets; aux_dirty = true; }
+      } else {
+        const uint32_t* s = (const uint32_t*)C.myshadow;
+        uint32_t* d = (uint32_t*)mygrid;
+        for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
+        a = agent_unpack(C.sspr[0]);
+        if (goto_rule) { targets = C.sspr[1]; cur = targets; aux_dirty = true; }
+        shadow_valid = false;
+      }
+      a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
+      if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
+      rec_dirty = true; wb_all = true;
+      if (!P.static_gen) h++;
+    } else if (a.flags & FLAG_FRESH) {
+      a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
+      rec_dirty = true;
+    } else if (P.phase == PHASE_STEP) {
+      // ---- MiniGridEnv.step ----
+      rec_dirty = true;
+      const uint32_t pre_carry = a.carry;
+      a.step = min(a.step + 1u, 0xFFFFu);
+      const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+      const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
+      if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
+      const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
+      const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
+      uint32_t newF = F;
+      const uint32_t ftype = cell_type(F);
+      bool success = false;
+      if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
+      else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
+      else if (act == A_FORWARD) {
+        if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
+        if (ftype == T_GOAL) { term = 1; success = true; }
+        if (ftype == T_LAVA) term = 1;
+      } else if (act == A_PICKUP) {
+        if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
+      } else if (act == A_DROP) {
+        if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
+      } else if (act == A_TOGGLE) {
+        newF = cell_toggle(F, a.carry);
+        if constexpr (GG == GG_ROOMS) if (ftype == T_BOX_DOORKEY) {
+          // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
+          uint32_t dc = 0;
+          for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
+          newF = make_cell(T_KEY, dc);
+        }
+      } else if (act != A_DONE) {
+        errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
+      }
+      if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
+      trunc = a.step >= (uint32_t)P.max_steps;
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+        // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
+        // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
+        // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
+        // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
+        if (dirty_idx >= 0) {
+          const uint32_t desc = goto_desc(P, a.mission);
+          if (F == desc) cur &= ~(1ull << dirty_idx);
+          if (newF == desc) cur |= 1ull << dirty_idx;
+        }
+        if (act == A_DROP && targets != cur) { targets = cur; aux_dirty = true; }
+        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_GOTO_BIG) {
+        // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
+        // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
+        // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
+        // or a box toggled away): at most one pickup plus the toggled boxes.  `targets` = S as four 16-bit cell indices
+        // (0xFFFF = free); a fifth is reported as ERR_TRACKED instead of being dropped silently.
+        const uint32_t desc = goto_desc(P, a.mission);
+        if (dirty_idx >= 0 && desc_match(F, desc) && !desc_match(newF, desc)) {
+          int slot = -1;
+#pragma unroll
+          for (int k = 3; k >= 0; k--) if (((targets >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
+          if (slot < 0) errbits |= ERR_TRACKED;
+          else targets = (targets & ~(0xFFFFull << (16 * slot))) | ((uint64_t)dirty_idx << (16 * slot));
+          aux_dirty = true;
+        }
+        if (act == A_DROP && targets != ~0ull) { targets = ~0ull; aux_dirty = true; }           // update_objs_poss
+        const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
+        if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
+          const int gi = gy * W + gx;
+          const uint32_t c = gi == dirty_idx ? dirty_code : (uint32_t)mygrid[gi];
+          bool hit = desc_match(c, desc);
+#pragma unroll
+          for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
+          if (hit && (P.rule_div != 5 || a.mission < 48u)) { term = 1; success = true; }
+        }
+        if (P.rule_div == 5 && a.mission >= 48u) {
+          // ActionObjDoor (other.py:86-106): PickupInstr / OpenInstr about the same description (verifier.py:343-363, 270-287)
+          if (a.mission < 96u) { if (act == A_PICKUP && pre_carry == 0 && a.carry == desc) { term = 1; success = true; } }
+          else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
+        }
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
+        // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
+        // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
+        // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
+        // that fails leaves cur_pos at (-1, -1) or -- start_carrying -- at the initial cell, which validate_instrs made non-adjacent
+        // to the fixed object, and that object cannot have moved while the hands were full.
+        // start_carrying (rule_div == 1): the verifier was reset before the object was handed over, so at the episode's first
+        // step its preCarrying is still None
+        const uint32_t mv = a.mission / 18u, fo = a.mission % 18u;
+        if (!(P.rule_div == 1 && a.step == 1u) && pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
+          const uint32_t fixed = make_cell((uint32_t)T_KEY + fo % 3u, color_from_sorted(fo / 3u));
+          bool next = false;
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) {
+            const int nx = fx + dir_dx((uint32_t)d), ny = fy + dir_dy((uint32_t)d);
+            if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) next |= (uint32_t)mygrid[ny * W + nx] == fixed;
+          }
+          if (next) { term = 1; success = true; }
+        }
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
+        // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
+        // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
+        if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
+        else if (P.rule_div == 1 && cell_ref_type(newF) == T_DOOR) term = 1;
+      }
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
+        // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
+        // stands next to target_pos (the one-bit board drawn at reset)
+        if (act == A_TOGGLE) term = 1;
+        if (act == A_DONE) {
+          const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
+          const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
+          term = 1; success = (targets & ring) != 0;
+        }
+      }
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEAR) {
+        // PutNearEnv.step (putnear.py:177-199).  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type
+        // (COLOR_NAMES / [key, ball, box] indices); target_pos is a POSITION fixed at reset: the one-bit board `targets`.
+        const uint32_t mv = a.mission / 18u;
+        const uint32_t move = make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u));
+        if (act == A_PICKUP && a.carry != 0 && a.carry != move) term = 1;           // picked up the wrong object
+        if (act == A_DROP && pre_carry != 0) {
+          if (newF != F && inb && targets) {                                        // `grid.get(ox, oy) is preCarrying`: the drop happened
+            const int tidx = __ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
+            if (abs(fx - tx) <= 1 && abs(fy - ty) <= 1) success = true;
+          }
+          term = 1;
+        }
+      }
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
+        // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
+        // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
+        const uint32_t m12 = a.mission % 12u;
+        const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
+        term = 1; success = a.carry == target;
+      }
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
+        // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
+        // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
+        bool open = false;
+        for (int y = 1; y < H - 1; y++) {
+          const int idx = y * W + P.rule_cell;
+          const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
+          open |= cell_type(c) == T_DOOR;
+        }
+        if (open) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
+        // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
+        // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
+        const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
+        if (a.carry == target) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
+        // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
+        // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
+        // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
+        // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
+        const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
+        const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
+                           (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
+        if (newF != F && match) { term = 1; success = true; }
+        else if (P.rule_div == 2) term = 1;
+      }
+      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
+        // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
+        // and it is open after the toggle
+        // (rule_div == 6: the description names a colour -- mission id % 6 -- and any door of that colour counts)
+        if (inb && cell_type(newF) == T_DOOR && (P.rule_div != 6 || cell_color(newF) == color_from_sorted(a.mission % 6u))) { term = 1; success = true; }
+      }
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
+        // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
+        // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
+        bool red_before = false, red_after = false, blue_before = false, blue_after = false;
+        const int xr = H / 2, xb = H / 2 + H - 1;
+#pragma unroll 1
+        for (int y = 1; y < H - 1; y++) {
+          const int ir = y * W + xr, ib = y * W + xb;
+          const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
+          const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
+          red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
+          blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
+        }
+        if (blue_after) { term = 1; success = red_before; }
+        else if (red_after && blue_before) { term = 1; success = false; }
+      }
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
+        // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
+        // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
+        // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
+        // the start-room object at (1, H/2 - 1)
+        const int mid = H / 2;
+        const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
+        if (oy >= 0) {
+          const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
+          if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
+        }
+      }
+      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
+        // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
+        // door = the door whose colour the mission names (door colours are distinct and doors never move)
+        if (act == A_TOGGLE) term = 1;
+        if (act == A_DONE) {
+          const uint32_t tc = color_from_sorted(a.mission);
+          bool next_to = false;
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) {
+            const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
+            if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
+              const uint32_t c = mygrid[ny * W + nx];
+              next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
+            }
+          }
+          term = 1; success = next_to;
+        }
+      }
+      if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
+      if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
+        // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
+        // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
+        if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
+        a.flags &= ~FLAG_NOT_CLEAR;
+      }
+      if (P.no_death_mask && term) {
+        // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
+        // cell does not terminate; death_cost is added to the reward instead
+        const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
+        const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
+        const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
+        if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
+      }
+      if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
+      if (dirty_idx >= 0) {
+        if (lead) mygrid[dirty_idx] = (uint8_t)dirty_code;
+        if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
+        else wb_all = true;
+      }
+    }
+  }
+}
+
 template <int MODE, bool FAST7, int GG, int LPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))    // one autonomous wave per workgroup; LDS, not registers, bounds the occupancy
 k_step(const StepParams P) {
@@ -445,7 +772,7 @@ k_step(const StepParams P) {
   const int e = env0 + el;
   const bool active = e < P.N;
   const int nvalid = min(EPW, P.N - env0);
-  const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
+  const int CS = P.CS, GS = P.GS;
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;                              // 256-entry cell code -> (type, colour, state) / tile key table
   uint8_t* sgrid = smem + P.off_grid;
@@ -463,8 +790,12 @@ k_step(const StepParams P) {
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
-  uint64_t targets = (goto_rule && active) ? P.aux[e] : 0ull;   // BabyAI GoTo levels: tracked positions
-  uint32_t h = (P.head && active) ? P.head[e] : 0u;
+  EnvRegs S;
+  uint64_t& targets = S.targets; uint64_t& cur = S.cur; uint32_t& h = S.h; uint32_t& errbits = S.errbits;
+  bool& shadow_valid = S.shadow_valid; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
+  Agent& a = S.a;
+  targets = (goto_rule && active) ? P.aux[e] : 0ull;   // BabyAI GoTo levels: tracked positions
+  h = (P.head && active) ? P.head[e] : 0u;
   const uint32_t h_in = h;
   uint32_t qn = P.seg_count ? uni32(P.seg_count[wg]) : 0u;
   const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
@@ -472,7 +803,7 @@ k_step(const StepParams P) {
   // so the s_waitcnt a (even conditional, even never-taken) load needs at its join point waits for every observation store
   // still in flight -- one HBM round trip per step.  Everything the loop may read is staged in LDS here: the grids, the
   // next spare episode (shadow slot), the caller's actions; the success reward is computed, not looked up.
-  bool shadow_valid = P.use_shadow != 0;
+  shadow_valid = P.use_shadow != 0;
   if (shadow_valid && active && lead) {
     const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
     sspr[0] = P.spare_agent[se];
@@ -504,30 +835,11 @@ k_step(const StepParams P) {
   }
   MG_LDS_SYNC();
 
-  Agent a = agent_unpack(rec);
+  a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + el * GS;
-  // BabyAI GoTo levels (RoomGridLevel.step + GoToInstr): `targets` = the TRACKED positions of the described objects, which the
-  // reference refreshes from the grid on every drop ACTION (update_objs_poss, roomgrid_level.py:92-93) and never otherwise;
-  // `cur` = where the described objects are on the grid right now, kept up to date cell change by cell change, so that the
-  // refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
-  // differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
-  auto goto_desc = [&](uint32_t mission) -> uint32_t {
-    // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
-    // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
-    // is returned as the OPEN door's code and matches the door in any state (desc_match).  5 = ActionObjDoor: as 4; id / 48 = the verb.
-    const uint32_t m18 = mission % 18u, m24 = mission % 24u;
-    return P.rule_div == 0 ? (uint32_t)P.rule_cell
-         : P.rule_div == 1 ? make_cell(T_BALL, mission ? (uint32_t)C_BLUE : (uint32_t)C_RED)
-         : P.rule_div == 2 ? make_cell(T_KEY + m18 % 3u, color_from_sorted(m18 / 3u))
-         : P.rule_div == 3 ? make_cell(T_DOOR, color_from_sorted(mission % 6u))
-                           : make_cell((m24 & 3u) == 3u ? (uint32_t)T_DOOR : (uint32_t)T_KEY + (m24 & 3u), color_from_sorted(m24 >> 2));
-  };
-  auto desc_match = [&](uint32_t c, uint32_t desc) -> bool {
-    return c == desc || (cell_type(desc) == T_DOOR && cell_ref_type(c) == T_DOOR && cell_color(c) == cell_color(desc));
-  };
-  uint64_t cur = targets;
+  cur = targets;
   if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
-    const uint32_t desc = goto_desc(a.mission);
+    const uint32_t desc = goto_desc(P, a.mission);
     cur = 0;
     for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
   }
@@ -536,8 +848,11 @@ k_step(const StepParams P) {
   const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
                  o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
                  o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
-  bool rec_dirty = false, aux_dirty = false, wb_all = false;
-  uint32_t errbits = 0, fin_total = 0;
+  rec_dirty = false; aux_dirty = false; wb_all = false; errbits = 0;
+  uint32_t fin_total = 0;
+  LaneCtx C;
+  C.e = e; C.el = el; C.sub = sub; C.active = active; C.lead = lead; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
+  C.mygrid = mygrid; C.myshadow = sshadow + el * GS; C.sspr = sspr;
   uint32_t pw[4] = { 0, 0, 0, 0 };
 
   for (int j = 0; j < P.T; j++) {
@@ -559,284 +874,7 @@ k_step(const StepParams P) {
     if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
     double reward = 0.0;
     uint32_t term = 0, trunc = 0;
-    // The one cell an action can change: it can only change under pickup/drop/toggle, which leave the pose alone, so it
-    // is always the cell straight ahead.  The level rules below see the grid as it was BEFORE the action plus this patch
-    // (RedBlueDoors compares both states); it is written into the LDS grid after them.
-    int dirty_idx = -1;              // linear index of the modified cell, -1 = none
-    uint32_t dirty_code = 0;
-
-    if (active) {
-      if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
-        // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
-        if (!shadow_valid) {
-          // not staged (single-step launch, or the env's second reset within a fused launch): fetch the spare into the
-          // shadow slot first -- the loads and their wait stay inside this branch
-          const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
-          const uint4* src = (const uint4*)(P.spare_grid + se * CS);
-          for (int c = sub; c < cpe; c += LPE) {
-            const uint4 v = src[c];
-            uint32_t* d = (uint32_t*)(sshadow + el * GS + c * 16);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-          }
-          if (lead) { sspr[0] = P.spare_agent[se]; sspr[1] = goto_rule ? P.spare_aux[se] : 0ull; }
-          MG_LDS_SYNC();
-        }
-        {
-          const uint32_t* s = (const uint32_t*)(sshadow + el * GS);
-          uint32_t* d = (uint32_t*)mygrid;
-          for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
-          a = agent_unpack(sspr[0]);
-          if (goto_rule) { targets = sspr[1]; cur = targets; aux_dirty = true; }
-          shadow_valid = false;
-        }
-        a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
-        if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
-        rec_dirty = true; wb_all = true;
-        if (!P.static_gen) h++;
-      } else if (a.flags & FLAG_FRESH) {
-        a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
-        rec_dirty = true;
-      } else if (P.phase == PHASE_STEP) {
-        // ---- MiniGridEnv.step ----
-        rec_dirty = true;
-        const uint32_t pre_carry = a.carry;
-        a.step = min(a.step + 1u, 0xFFFFu);
-        const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
-        const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
-        if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
-        const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
-        const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
-        uint32_t newF = F;
-        const uint32_t ftype = cell_type(F);
-        bool success = false;
-        if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
-        else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
-        else if (act == A_FORWARD) {
-          if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
-          if (ftype == T_GOAL) { term = 1; success = true; }
-          if (ftype == T_LAVA) term = 1;
-        } else if (act == A_PICKUP) {
-          if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
-        } else if (act == A_DROP) {
-          if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
-        } else if (act == A_TOGGLE) {
-          newF = cell_toggle(F, a.carry);
-          if constexpr (GG == GG_ROOMS) if (ftype == T_BOX_DOORKEY) {
-            // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
-            uint32_t dc = 0;
-            for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
-            newF = make_cell(T_KEY, dc);
-          }
-        } else if (act != A_DONE) {
-          errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
-        }
-        if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
-        trunc = a.step >= (uint32_t)P.max_steps;
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
-          // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
-          // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
-          // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
-          // carried -- which only matters when a finished episode keeps being stepped (autoreset disabled).
-          if (dirty_idx >= 0) {
-            const uint32_t desc = goto_desc(a.mission);
-            if (F == desc) cur &= ~(1ull << dirty_idx);
-            if (newF == desc) cur |= 1ull << dirty_idx;
-          }
-          if (act == A_DROP && targets != cur) { targets = cur; aux_dirty = true; }
-          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_GOTO_BIG) {
-          // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
-          // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
-          // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
-          // or a box toggled away): at most one pickup plus the toggled boxes.  `targets` = S as four 16-bit cell indices
-          // (0xFFFF = free); a fifth is reported as ERR_TRACKED instead of being dropped silently.
-          const uint32_t desc = goto_desc(a.mission);
-          if (dirty_idx >= 0 && desc_match(F, desc) && !desc_match(newF, desc)) {
-            int slot = -1;
-#pragma unroll
-            for (int k = 3; k >= 0; k--) if (((targets >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
-            if (slot < 0) errbits |= ERR_TRACKED;
-            else targets = (targets & ~(0xFFFFull << (16 * slot))) | ((uint64_t)dirty_idx << (16 * slot));
-            aux_dirty = true;
-          }
-          if (act == A_DROP && targets != ~0ull) { targets = ~0ull; aux_dirty = true; }           // update_objs_poss
-          const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
-          if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H) {
-            const int gi = gy * W + gx;
-            const uint32_t c = gi == dirty_idx ? dirty_code : (uint32_t)mygrid[gi];
-            bool hit = desc_match(c, desc);
-#pragma unroll
-            for (int k = 0; k < 4; k++) hit |= ((targets >> (16 * k)) & 0xFFFFull) == (uint64_t)gi;
-            if (hit && (P.rule_div != 5 || a.mission < 48u)) { term = 1; success = true; }
-          }
-          if (P.rule_div == 5 && a.mission >= 48u) {
-            // ActionObjDoor (other.py:86-106): PickupInstr / OpenInstr about the same description (verifier.py:343-363, 270-287)
-            if (a.mission < 96u) { if (act == A_PICKUP && pre_carry == 0 && a.carry == desc) { term = 1; success = true; } }
-            else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
-          }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
-          // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
-          // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
-          // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
-          // that fails leaves cur_pos at (-1, -1) or -- start_carrying -- at the initial cell, which validate_instrs made non-adjacent
-          // to the fixed object, and that object cannot have moved while the hands were full.
-          // start_carrying (rule_div == 1): the verifier was reset before the object was handed over, so at the episode's first
-          // step its preCarrying is still None
-          const uint32_t mv = a.mission / 18u, fo = a.mission % 18u;
-          if (!(P.rule_div == 1 && a.step == 1u) && pre_carry == make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u))) {
-            const uint32_t fixed = make_cell((uint32_t)T_KEY + fo % 3u, color_from_sorted(fo / 3u));
-            bool next = false;
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) {
-              const int nx = fx + dir_dx((uint32_t)d), ny = fy + dir_dy((uint32_t)d);
-              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) next |= (uint32_t)mygrid[ny * W + nx] == fixed;
-            }
-            if (next) { term = 1; success = true; }
-          }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
-          // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
-          // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
-          if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
-          else if (P.rule_div == 1 && cell_ref_type(newF) == T_DOOR) term = 1;
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
-          // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
-          // stands next to target_pos (the one-bit board drawn at reset)
-          if (act == A_TOGGLE) term = 1;
-          if (act == A_DONE) {
-            const int ax = (int)a.x, ay = (int)a.y;          // interior cell: the four neighbours are inside the grid
-            const uint64_t ring = (1ull << (ay * W + ax - 1)) | (1ull << (ay * W + ax + 1)) | (1ull << ((ay - 1) * W + ax)) | (1ull << ((ay + 1) * W + ax));
-            term = 1; success = (targets & ring) != 0;
-          }
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEAR) {
-          // PutNearEnv.step (putnear.py:177-199).  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type
-          // (COLOR_NAMES / [key, ball, box] indices); target_pos is a POSITION fixed at reset: the one-bit board `targets`.
-          const uint32_t mv = a.mission / 18u;
-          const uint32_t move = make_cell((uint32_t)T_KEY + mv % 3u, color_from_sorted(mv / 3u));
-          if (act == A_PICKUP && a.carry != 0 && a.carry != move) term = 1;           // picked up the wrong object
-          if (act == A_DROP && pre_carry != 0) {
-            if (newF != F && inb && targets) {                                        // `grid.get(ox, oy) is preCarrying`: the drop happened
-              const int tidx = __ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
-              if (abs(fx - tx) <= 1 && abs(fy - ty) <= 1) success = true;
-            }
-            term = 1;
-          }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
-          // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
-          // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
-          const uint32_t m12 = a.mission % 12u;
-          const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
-          term = 1; success = a.carry == target;
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
-          // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
-          // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
-          bool open = false;
-          for (int y = 1; y < H - 1; y++) {
-            const int idx = y * W + P.rule_cell;
-            const uint32_t c = idx == dirty_idx ? dirty_code : (uint32_t)mygrid[idx];
-            open |= cell_type(c) == T_DOOR;
-          }
-          if (open) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
-          // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
-          // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
-          const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
-          if (a.carry == target) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
-          // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
-          // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
-          // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
-          // strict (PickupDistDebug, rule_div == 2): any other pickup action with something in hand fails the episode
-          const uint32_t m = a.mission % 28u, ci = m >> 2, ti = m & 3u;
-          const bool match = (ti == 0u || cell_type(a.carry) == (uint32_t)T_KEY + ti - 1u) &&
-                             (ci == 0u || cell_color(a.carry) == color_from_sorted(ci - 1u));
-          if (newF != F && match) { term = 1; success = true; }
-          else if (P.rule_div == 2) term = 1;
-        }
-        if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
-          // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
-          // and it is open after the toggle
-          // (rule_div == 6: the description names a colour -- mission id % 6 -- and any door of that colour counts)
-          if (inb && cell_type(newF) == T_DOOR && (P.rule_div != 6 || cell_color(newF) == color_from_sorted(a.mission % 6u))) { term = 1; success = true; }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
-          // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
-          // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
-          bool red_before = false, red_after = false, blue_before = false, blue_after = false;
-          const int xr = H / 2, xb = H / 2 + H - 1;
-#pragma unroll 1
-          for (int y = 1; y < H - 1; y++) {
-            const int ir = y * W + xr, ib = y * W + xb;
-            const uint32_t r0 = mygrid[ir], b0 = mygrid[ib];
-            const uint32_t r1 = ir == dirty_idx ? dirty_code : r0, b1 = ib == dirty_idx ? dirty_code : b0;
-            red_before |= cell_type(r0) == T_DOOR; red_after |= cell_type(r1) == T_DOOR;
-            blue_before |= cell_type(b0) == T_DOOR; blue_after |= cell_type(b1) == T_DOOR;
-          }
-          if (blue_after) { term = 1; success = red_before; }
-          else if (red_after && blue_before) { term = 1; success = false; }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
-          // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
-          // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
-          // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
-          // the start-room object at (1, H/2 - 1)
-          const int mid = H / 2;
-          const int oy = (int)a.y == mid - 1 ? mid - 2 : ((int)a.y == mid + 1 ? mid + 2 : -1);
-          if (oy >= 0) {
-            const uint32_t o = mygrid[oy * W + (int)a.x], st = mygrid[(mid - 1) * W + 1];
-            if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
-          }
-        }
-        if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
-          // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
-          // door = the door whose colour the mission names (door colours are distinct and doors never move)
-          if (act == A_TOGGLE) term = 1;
-          if (act == A_DONE) {
-            const uint32_t tc = color_from_sorted(a.mission);
-            bool next_to = false;
-#pragma unroll 1
-            for (int d = 0; d < 4; d++) {
-              const int nx = (int)a.x + dir_dx((uint32_t)d), ny = (int)a.y + dir_dy((uint32_t)d);
-              if ((unsigned)nx < (unsigned)W && (unsigned)ny < (unsigned)H) {
-                const uint32_t c = mygrid[ny * W + nx];
-                next_to |= cell_ref_type(c) == T_DOOR && cell_color(c) == tc;
-              }
-            }
-            term = 1; success = next_to;
-          }
-        }
-        if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
-        if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
-          // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
-          // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
-          if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
-          a.flags &= ~FLAG_NOT_CLEAR;
-        }
-        if (P.no_death_mask && term) {
-          // NoDeath.step (wrappers.py:860-882): walking into (or ending the episode while standing in) a no-death
-          // cell does not terminate; death_cost is added to the reward instead
-          const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
-          const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
-          const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
-          if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
-        }
-        if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
-        if (dirty_idx >= 0) {
-          if (lead) mygrid[dirty_idx] = (uint8_t)dirty_code;
-          if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
-          else wb_all = true;
-        }
-      }
-    }
+    env_transition<GG, LPE>(P, C, S, act, reward, term, trunc);
     if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && lead && (term | trunc)));   // episodes finished in this wave
     MG_LDS_SYNC();
 
