@@ -276,6 +276,15 @@ MG_API int mg_selftest_stream(int32_t obe, int32_t nenv, int32_t lanes_per_env, 
  * empty 0 | wall 1+c | floor 7+c | key 13+c | ball 19+c | box 25+c | door 31+3c+state | goal 49 | lava 50. */
 MG_API int mg_render_tiles(int32_t tile_size, uint8_t* out);
 MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uint32_t* code, uint32_t* triple);
+/* k_roll7's observation pipeline (minigrid_amd/csrc/mg_roll.h) -- gen_obs_grid / process_vis / Grid.encode of the default 7x7 view
+ * (minigrid_env.py:597-650, core/grid.py:244-328) as line gathers, byte transposes, carry-propagation visibility rows and the
+ * output-space encode -- run on the host over states in mg_set_state's exchange format: grid (n, W, H, 3) u8, agent (n, 8) i32;
+ * out (n, 7, 7, 3) u8.  mg_selftest_vis_row_carry is its process_vis row; mg_selftest_prims evaluates its VALU primitives
+ * (perm / dot4 / bit reverse / bit-to-byte expand / visibility row) on the host or, on_device = 1, on the GPU: out[5][n]. */
+MG_API int mg_selftest_obs7(int32_t width, int32_t height, int32_t n, const uint8_t* grid, const int32_t* agent, int32_t see_through,
+                            uint8_t* out);
+MG_API int mg_selftest_vis_row_carry(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
+MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@
 #include "../../include/minigrid_hip.h"
 #include "mg_kernels.h"
 #include "mg_kernels_aux.h"
+#include "mg_roll.h"
 #include "mg_launch.h"
 
 using namespace mg;
@@ -45,6 +46,9 @@ struct mg_env {
   int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
   int off_grid = 0, off_shadow = 0, off_spr = 0, off_act = 0, off_trow = 0, off_T = 0, lds_bytes = 0;
   int lpe = 1, epw = 64;      // lanes per env in k_step (1 or 4), envs per wavefront = 64 / lpe
+  bool fast7 = false;         // the default 7x7 partial view: k_roll7 (mg_roll.h) instead of k_step
+  int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
+  int roll_guard = 0;
   int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
   bool static_gen = false;
   bool live_gen = false;      // DynamicObstacles: step() consumes the stream => resets are drawn right before the step launch
@@ -226,6 +230,21 @@ static int flush_refills(mg_env* e) {
   return MG_OK;
 }
 
+// LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
+// stagings | shadow grids | shadow agent / aux words | caller-supplied actions
+struct RollLayout { int off_grid, off_codes, off_shadow, off_spr, off_act, total; };
+static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions) {
+  RollLayout L;
+  L.off_grid = 1024 + e->roll_guard;
+  L.off_codes = (L.off_grid + nw * 64 * e->GS + e->roll_guard + 15) & ~15;
+  L.off_shadow = L.off_codes + nw * ROLL_CODES_BYTES;
+  L.off_spr = L.off_shadow + ((64 * e->GS + 15) & ~15);
+  L.off_act = L.off_spr + 64 * 16;
+  L.total = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
+  return L;
+}
+static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions) { return roll_layout(e, nw, with_actions).total; }
+
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.grid = e->grid; P.agent = e->agent; P.aux = e->aux;
   P.spare_grid = e->spare_grid; P.spare_agent = e->spare_agent; P.spare_aux = e->spare_aux;
@@ -286,12 +305,34 @@ static int launch_step(mg_env* e, StepParams& P) {
   P.use_shadow = P.T > 1 ? 1 : 0;
   const size_t lds = (size_t)(P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP ? e->lds_bytes : e->off_act);
   dim3 grid(e->nwaves);
-  const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && e->cfg.agent_view_size == 7;
+  const bool fast7 = false;             // (the 7x7 view is launched below: k_roll7)
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
                  : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
   const int gg = e->rule_group;
+  bool launched = false;
+  if (e->fast7) {
+    // wave w of a workgroup produces steps [split[w], split[w + 1]) after replaying the steps before them silently: the split that
+    // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
+    int nw = std::min(e->roll_nw, std::max(1, P.T));
+    static const double ratio = [] { const char* s = getenv("MG_ROLL_RATIO"); const double v = s ? atof(s) : 0.0; return v > 0.0 && v < 1.0 ? v : 0.12; }();
+    double geo = 0.0, pw = 1.0;
+    for (int w = 0; w < nw; w++) { geo += pw; pw *= 1.0 - ratio; }
+    const double x1 = (double)P.T / geo;
+    double x = 0.0;
+    P.split[0] = 0;
+    for (int w = 1; w < nw; w++) { x = x * (1.0 - ratio) + x1; P.split[w] = std::min(P.T - (nw - w), std::max(P.split[w - 1] + 1, (int)std::lround(x))); }
+    for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
+    const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
+    const RollLayout L = roll_layout(e, nw, acts);
+    P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
+    if (gg == GG_NONE) launch_roll_none(grid, nw, (size_t)L.total, e->stream, P);
+    else if (gg == GG_LIGHT) launch_roll_light(grid, nw, (size_t)L.total, e->stream, P);
+    else if (gg == GG_ROOMGRID) launch_roll_roomgrid(grid, nw, (size_t)L.total, e->stream, P);
+    else launch_roll_rooms(grid, nw, (size_t)L.total, e->stream, P);
+    launched = true;
+  }
   // one translation unit per rule group (mg_step_*.hip): (MODE, FAST7, LPE) picks the instantiation inside it
-  const bool launched = gg == GG_NONE ? launch_step_none(mode, fast7, e->lpe, grid, lds, e->stream, P)
+  if (!launched) launched = gg == GG_NONE ? launch_step_none(mode, fast7, e->lpe, grid, lds, e->stream, P)
                       : gg == GG_LIGHT ? launch_step_light(mode, fast7, e->lpe, grid, lds, e->stream, P)
                       : gg == GG_ROOMGRID ? launch_step_roomgrid(mode, fast7, e->lpe, grid, lds, e->stream, P)
                                           : launch_step_rooms(mode, fast7, e->lpe, grid, lds, e->stream, P);
@@ -572,8 +613,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     const bool fullish = (cfg->obs_mode == MG_OBS_FULL || cfg->obs_mode == MG_OBS_SYMBOLIC) && e->cells >= 32;
     // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
     // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
-    e->lpe = (fullish || (fast7 && cfg->num_envs <= 40000)) ? 4 : 1;
-    if (fast7 && getenv("MG_LPE") && atoi(getenv("MG_LPE")) == 4) e->lpe = 4;
+    // (the 7x7 view runs k_roll7: one lane per env, more wavefronts through its time split)
+    e->fast7 = fast7;
+    e->lpe = fullish ? 4 : 1;
     if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
   }
@@ -592,6 +634,16 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
     e->off_act = e->off_spr + e->epw * 16;
     e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
+  }
+  if (e->fast7) {
+    // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
+    // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
+    e->roll_guard = (6 * e->W + 8 + 15) & ~15;
+    int nw = 4;
+    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw >>= 1;
+    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) nw = v; }
+    e->roll_nw = nw;
+    e->lds_bytes = roll_lds_bytes(e, nw, true);
   }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
@@ -769,6 +821,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       std::lock_guard<std::mutex> lk(lds_mu);
       if (need > lds_max[device & 63]) {
         TRY_OR_FREE(step_max_lds_none(need)); TRY_OR_FREE(step_max_lds_light(need)); TRY_OR_FREE(step_max_lds_roomgrid(need)); TRY_OR_FREE(step_max_lds_rooms(need));
+        TRY_OR_FREE(roll_max_lds_none(need)); TRY_OR_FREE(roll_max_lds_light(need)); TRY_OR_FREE(roll_max_lds_roomgrid(need)); TRY_OR_FREE(roll_max_lds_rooms(need));
         lds_max[device & 63] = need;
       }
     }
@@ -1148,6 +1201,73 @@ int mg_selftest_stream(int32_t obe, int32_t nenv, int32_t lpe, const uint8_t* in
   }
   memcpy(out, stream.data(), (size_t)nenv * obe);
   return MG_OK;
+}
+int mg_selftest_vis_row_carry(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
+  if (!m_out || !up_out) return MG_ERR_INVALID;
+  vis_row_carry(m & 0x7F, t & 0x7F, m_out, up_out);
+  return MG_OK;
+}
+// The observation pipeline of k_roll7 (mg_roll.h: obs7_codes per env, obs7_chunk per 16 output bytes) run on the HOST over states in
+// the exchange format of mg_set_state -- a check of the kernel's arithmetic for the CPU test-suite, laid out exactly like a wave's LDS.
+int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const int32_t* agent, int32_t see_through, uint8_t* out) {
+  if (!grid || !agent || !out || W < 3 || H < 3 || W > 25 || H > 25 || n < 1) return MG_ERR_INVALID;
+  const int cells = W * H, CS = (cells + 15) & ~15, GS = CS + 4, guard = (6 * W + 8 + 15) & ~15;
+  std::vector<uint32_t> slut(256);
+  for (uint32_t k = 0; k < 256; k++) slut[k] = cell_triple(k);
+  std::vector<uint8_t> lds((size_t)guard * 2 + 64 * (size_t)GS), codes(ROLL_CODES_BYTES);
+  for (int g0 = 0; g0 < n; g0 += 64) {
+    const int nv = std::min(64, n - g0);
+    std::fill(lds.begin(), lds.end(), (uint8_t)0xA5);                 // whatever lies around an env's grid must not matter
+    std::fill(codes.begin(), codes.end(), (uint8_t)0x5A);
+    for (int l = 0; l < nv; l++) {
+      const uint8_t* g = grid + (size_t)(g0 + l) * cells * 3;
+      uint8_t* mygrid = lds.data() + guard + (size_t)l * GS;
+      for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {
+        const uint8_t* t = g + ((size_t)x * H + y) * 3;
+        mygrid[y * W + x] = (uint8_t)cell_from_triple(t[0], t[1], t[2]);
+      }
+    }
+    for (int l = 0; l < 64; l++) {                                    // (lanes past the batch end run too, like on the device)
+      Agent a = agent_unpack(0ull);
+      if (l < nv) {
+        const int32_t* o = agent + (size_t)(g0 + l) * 8;
+        a.x = (uint32_t)o[0]; a.y = (uint32_t)o[1]; a.dir = (uint32_t)o[2] & 3u;
+        a.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
+        if (a.carry == CELL_EMPTY) a.carry = 0;
+      }
+      obs7_codes(a, lds.data() + guard + (size_t)l * GS, W, H, see_through != 0, codes.data() + l * VIEW_CELLS);
+    }
+    const int nbytes = nv * PARTIAL_OBS_BYTES;
+    uint8_t* ob = out + (size_t)g0 * PARTIAL_OBS_BYTES;
+    for (int c = 0; c * 16 < nbytes; c++) {
+      uint32_t o4[4];
+      obs7_chunk((uint32_t)c, codes.data(), slut.data(), o4);
+      for (int b = 0; b < 16 && c * 16 + b < nbytes; b++) ob[c * 16 + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
+    }
+  }
+  return MG_OK;
+}
+// out = [perm_b32 | udot4 | brev32 | expand4 | vis_row_carry (m | up << 8)] x n of (a, b, c); on_device: by k_selftest_prims
+int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device) {
+  if (n < 1 || !a || !b || !c || !out) return MG_ERR_INVALID;
+  if (!on_device) {
+    for (int i = 0; i < n; i++) {
+      out[i] = perm_b32(a[i], b[i], c[i]); out[n + i] = udot4(a[i], b[i], c[i]); out[2 * n + i] = brev32(a[i]); out[3 * n + i] = expand4(a[i]);
+      uint32_t m, up;
+      vis_row_carry(a[i] & 0x7Fu, b[i] & 0x7Fu, &m, &up);
+      out[4 * n + i] = m | (up << 8);
+    }
+    return MG_OK;
+  }
+  if (mg_device_count() < 1) return MG_ERR_NO_DEVICE;
+  uint32_t* d = nullptr;
+  const size_t bytes = (size_t)n * sizeof(uint32_t);
+  if (hipMalloc((void**)&d, 8 * bytes) != hipSuccess) return MG_ERR_HIP;
+  (void)hipMemcpy(d, a, bytes, hipMemcpyHostToDevice); (void)hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice); (void)hipMemcpy(d + 2 * n, c, bytes, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_selftest_prims, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, d, d + n, d + 2 * n, d + 3 * n);
+  const hipError_t rc = hipMemcpy(out, d + 3 * n, 5 * bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return rc == hipSuccess ? MG_OK : MG_ERR_HIP;
 }
 int mg_render_tiles(int32_t tile_size, uint8_t* out) {
   if (!out || tile_size < 1 || tile_size > 64) return MG_ERR_INVALID;

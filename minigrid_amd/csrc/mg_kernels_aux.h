@@ -3,6 +3,7 @@
 // __global__ functions here must be compiled into exactly one translation unit).
 #pragma once
 #include "mg_kernels.h"
+#include "mg_roll.h"
 
 namespace mg {
 
@@ -462,6 +463,19 @@ __global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64
     for (int c = 0; c < cells && k < 8; c++) if (cell_type(g[c]) == T_BALL) w |= (uint64_t)c << (8 * k++);
   }
   aux[n] = w;
+}
+
+// the VALU primitives of mg_roll.h on the device, for the GPU test that compares them with their host forms
+__global__ void k_selftest_prims(int n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = perm_b32(a[i], b[i], c[i]);
+  out[n + i] = udot4(a[i], b[i], c[i]);
+  out[2 * n + i] = brev32(a[i]);
+  out[3 * n + i] = expand4(a[i]);
+  uint32_t m, up;
+  vis_row_carry(a[i] & 0x7Fu, b[i] & 0x7Fu, &m, &up);
+  out[4 * n + i] = m | (up << 8);
 }
 
 }  // namespace mg

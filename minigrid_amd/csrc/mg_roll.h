@@ -1,0 +1,426 @@
+// mg_roll.h — k_roll7: the step / fused-rollout kernel for the reference's default observation, the 7x7x3 egocentric view
+// (MiniGridEnv.step + gen_obs, minigrid_env.py:525-650), round 3.  It replaces k_step<0, true, ...> for every level.
+//
+// What changed against k_step's 7x7 path (mg_step.h) and why -- measured there: one wave per SIMD at 65 536 envs, 824 VALU per
+// wave-step, 179 VGPRs and 20 KB of LDS per wave (occupancy 2), the wave parked on LDS round trips 43 % of its cycles:
+//  * TIME SPLIT.  A workgroup is still 64 consecutive envs, but NW (1, 2 or 4) wavefronts share them: wave w produces the outputs
+//    of steps [split[w], split[w+1]) of the launch.  Dynamics are a few dozen instructions per step, the observation several
+//    hundred, so wave w first replays steps 0 .. split[w]-1 SILENTLY (actions, dynamics, resets on its private copy of the 64 grids;
+//    no observation, no stores) and then runs its own steps in full.  No barrier after the prologue, no inter-wave traffic: the
+//    waves are independent instruction streams on (normally) four different SIMDs, i.e. four times the wavefronts for the same
+//    batch without four lanes per env replicating every step's work.  The last wave owns the final state and writes it back.
+//  * The observation leaves the lane-per-env domain as CELL CODES, not as bytes: each lane stages its env's 49 one-byte codes
+//    (already masked by process_vis, in output order) in LDS (3.1 KB per wave instead of the 9.4 KB byte stream), and the encode
+//    runs in OUTPUT space: lane c of an iteration produces the 16 bytes [16 c, 16 c + 16) of the wave's contiguous observation
+//    stream -- six code -> (type, colour, state) lookups, five packs, four byte-aligns -- and stores them with one 16 B store.
+//    Nothing is assembled per env in registers (k_step held 37 packed dwords + 10 copy-out quads per lane).
+//  * The view is handled as seven LINES of seven codes (2 VGPRs each) end to end: orientation by v_perm_b32 (byte reversal, the
+//    8 x 8 byte transpose between "line = view column" and "line = view row"), opacity rows by v_dot4_u32_u8, process_vis rows
+//    by carry propagation (an occluded fill to the right is (((t + g) ^ t) & t) | g; to the left the same on bit-reversed
+//    words), visibility applied as byte masks.  No per-cell select, no per-cell bit insert.
+// Every function of the observation pipeline is host-callable: mg_selftest_obs7 runs it on the CPU for the test-suite
+// (tests/test_abi_cpu.py compares it with the oracle over rollouts); the primitives' device forms are checked on the GPU.
+#pragma once
+#include "mg_step.h"
+
+// analysis aid: -DMG_ISA_MARKS puts section comments into the device ISA (profiles/isa_stats.py --marks); never in the product build
+#if defined(MG_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define MG_MARK(name) asm volatile("; ##MARK " name ::: "memory")
+#else
+#define MG_MARK(name) do { } while (0)
+#endif
+
+namespace mg {
+
+// ---- VALU primitives with host equivalents ----
+// v_perm_b32: byte i of the result = byte sel.byte[i] (0..7) of {hi:lo}; selector 0x0c gives 0x00, 0x0d and above 0xff
+MG_HD uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t v = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t s = (sel >> (8 * i)) & 0xFFu;
+    const uint32_t b = s < 8u ? (uint32_t)(v >> (8u * s)) & 0xFFu : (s == 0x0Cu ? 0u : 0xFFu);
+    r |= b << (8 * i);
+  }
+  return r;
+#endif
+}
+// v_dot4_u32_u8: sum of the four byte products + c
+MG_HD uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+  return c;
+#endif
+}
+MG_HD uint32_t brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x);
+#else
+  uint32_t r = 0;
+  for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i);
+  return r;
+#endif
+}
+MG_HD uint32_t mul24(uint32_t a, uint32_t b) {          // both < 2^24: the full-rate 24-bit multiply
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+// four bits -> four bytes of 0x00 / 0xff (bit i -> byte i)
+MG_HD uint32_t expand4(uint32_t bits) {
+  return perm_b32(0u, 0u, 0x0C0C0C0Cu | (mul24(bits & 15u, 0x00204081u) & 0x01010101u));
+}
+
+// One row of Grid.process_vis (core/grid.py:291-328) like vis_row (mg_device.h), with the two occluded fills done by carry
+// propagation instead of Kogge-Stone steps: adding the seeds g (a subset of the transparent cells t) to t ripples a carry from
+// every seed through the run of 1s above it, so (t + g) ^ t marks each seed's run up to and including the first opaque cell,
+// "& t" drops that cell, "| g" restores seeds that sat inside another seed's ripple.  The fill toward lower indices is the
+// same on bit-reversed words.  tests/test_abi_cpu.py checks all 2^14 (m, t) pairs against vis_row and the literal loops.
+MG_HD void vis_row_carry(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t* up_out) {
+  const uint32_t g = m & t;
+  const uint32_t fr = (((t + g) ^ t) & t) | g;
+  const uint32_t tr = brev32(t), gr = brev32(g);
+  const uint32_t fl = brev32((((tr + gr) ^ tr) & tr) | gr);
+  const uint32_t s1 = fr & 0x3Fu;                 // sweep-1 sources i = 0..5: light i+1 here, i and i+1 above
+  const uint32_t s2 = (fr | fl) & 0x7Eu;          // sweep-2 sources i = 6..1: light i-1 here, i and i-1 above
+  const uint32_t s1s = s1 << 1, s2s = s2 >> 1;
+  *m_out = m | s1s | s2s;
+  *up_out = s1 | s1s | s2 | s2s;
+}
+
+// Seven lines of seven cell codes: line t, byte j; lo = bytes 0..3, hi = bytes 4..6 (top byte 0).
+struct View7 { uint32_t lo[7], hi[7]; };
+
+// 4 x 4 byte transpose: c_j.byte[t] = r_t.byte[j]
+MG_HD void transpose4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3) {
+  const uint32_t p0 = perm_b32(r1, r0, 0x05010400u), p1 = perm_b32(r1, r0, 0x07030602u);   // bytes of r0 / r1 interleaved
+  const uint32_t p2 = perm_b32(r3, r2, 0x05010400u), p3 = perm_b32(r3, r2, 0x07030602u);
+  c0 = perm_b32(p2, p0, 0x05040100u); c1 = perm_b32(p2, p0, 0x07060302u);
+  c2 = perm_b32(p3, p1, 0x05040100u); c3 = perm_b32(p3, p1, 0x07060302u);
+}
+// B.line[j].byte[t] = A.line[t].byte[j] (the eighth line / byte is zero)
+MG_HD void view7_transpose(const View7& A, View7& B) {
+  uint32_t x;
+  transpose4(A.lo[0], A.lo[1], A.lo[2], A.lo[3], B.lo[0], B.lo[1], B.lo[2], B.lo[3]);
+  transpose4(A.lo[4], A.lo[5], A.lo[6], 0u, B.hi[0], B.hi[1], B.hi[2], B.hi[3]);
+  transpose4(A.hi[0], A.hi[1], A.hi[2], A.hi[3], B.lo[4], B.lo[5], B.lo[6], x);
+  transpose4(A.hi[4], A.hi[5], A.hi[6], 0u, B.hi[4], B.hi[5], B.hi[6], x);
+  (void)x;
+}
+
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint16_t u16_unaligned __attribute__((aligned(1)));
+
+// gen_obs up to the encode (minigrid_env.py:597-632, core/grid.py:110-143, 291-328): the agent's 7x7 view as 49 cell codes in
+// image order k = vx * 7 + vy, invisible cells already 0 (= the code of "unseen"), the agent's own cell showing what it carries
+// (:623-630) -- written to `codes` (49 bytes, any alignment; the 50th byte is left alone).
+// View cell (vx, vy) is world cell agent + f (6 - vy) + r (vx - 3), f = DIR_TO_VEC[dir], r = (-f.y, f.x).  World x is the
+// contiguous direction of the grid, so the seven LINES read are world rows: the view's columns when the agent faces +-x
+// (line t = vx, byte = vy), its rows when it faces +-y (line t = vy, byte = vx); bytes reversed when the view index runs
+// against world x (east, south).  Cells outside the grid read a neighbour env's cells or a guard band and are replaced by walls.
+MG_HD void obs7_codes(const Agent& a, const uint8_t* mygrid, int W, int H, bool see_through, uint8_t* codes) {
+  const uint32_t d = a.dir;
+  const int ax = (int)a.x, ay = (int)a.y;
+  const bool horiz = (d & 1u) == 0u, rev = d < 2u;
+  const int row_base = ay + (d == 0u ? -3 : d == 2u ? 3 : d == 1u ? 6 : -6);   // world row of line 0 ...
+  const int sy = (d == 0u || d == 3u) ? 1 : -1;                                 // ... and the step to the next line
+  const int x0 = ax - (d == 0u ? 0 : d == 2u ? 6 : 3);                          // world x of a line's first byte in memory
+  // validity, in memory order: byte m is world x0 + m, line t is world row row_base + sy t (neither range is ever empty)
+  const int mlo = max(0, -x0), mhi = min(6, W - 1 - x0);
+  const uint32_t mm = ((2u << mhi) - 1u) & ~((1u << mlo) - 1u);
+  const int tlo = sy > 0 ? max(0, -row_base) : max(0, row_base - (H - 1));
+  const int thi = sy > 0 ? min(6, H - 1 - row_base) : min(6, row_base);
+  const uint32_t lm = ((2u << thi) - 1u) & ~((1u << tlo) - 1u);
+  const uint32_t bm_lo = expand4(mm), bm_hi = expand4(mm >> 4) & 0x00FFFFFFu;
+  const uint32_t sel_lo = rev ? 0x03040506u : 0x03020100u, sel_hi = rev ? 0x0C000102u : 0x0C060504u;
+  const uint32_t WALL4 = CELL_WALL_GREY * 0x01010101u;
+  const uint8_t* lp = mygrid + row_base * W + x0;
+  const int lstep = sy * W;
+  View7 N;                                                     // natural orientation
+#pragma unroll
+  for (int t = 0; t < 7; t++) {
+    const uint64_t q = *(const u64_unaligned*)(lp + t * lstep);
+    const uint32_t on = 0u - ((lm >> t) & 1u);
+    const uint32_t ml = bm_lo & on, mh = bm_hi & on;
+    const uint32_t qlo = ((uint32_t)q & ml) | (WALL4 & ~ml), qhi = ((uint32_t)(q >> 32) & mh) | (WALL4 & ~mh);
+    N.lo[t] = perm_b32(qhi, qlo, sel_lo);
+    N.hi[t] = perm_b32(qhi, qlo, sel_hi);
+  }
+  // rows of the view for everyone: line = vy, byte = vx
+  View7 R, X;
+  view7_transpose(N, X);
+#pragma unroll
+  for (int t = 0; t < 7; t++) { R.lo[t] = horiz ? X.lo[t] : N.lo[t]; R.hi[t] = horiz ? X.hi[t] : N.hi[t]; }
+  // the agent's own cell (vx 3, vy 6) shows what it carries, or nothing
+  R.lo[6] = (R.lo[6] & 0x00FFFFFFu) | ((a.carry ? a.carry : (uint32_t)CELL_EMPTY) << 24);
+  if (!see_through) {
+    // process_vis, rows bottom-up; the visibility of row vy as a byte mask over its codes
+    uint32_t m = 1u << 3;
+#pragma unroll
+    for (int j = 6; j >= 0; j--) {
+      // transparency bits of the row: bit vx = !(code & OPAQUE_BIT)
+      const uint32_t tl = (~R.lo[j] & 0x80808080u) >> 7, th = (~R.hi[j] & 0x00808080u) >> 7;
+      const uint32_t tb = udot4(th, 0x00402010u, udot4(tl, 0x08040201u, 0u));
+      uint32_t vr, up;
+      vis_row_carry(m, tb, &vr, &up);
+      R.lo[j] &= expand4(vr);
+      R.hi[j] &= expand4(vr >> 4);
+      m = up;
+    }
+  }
+  // image order: line = vx, byte = vy
+  View7 O;
+  view7_transpose(R, O);
+#pragma unroll
+  for (int t = 0; t < 6; t++) *(u64_unaligned*)(codes + 7 * t) = ((uint64_t)O.hi[t] << 32) | O.lo[t];   // (the 8th byte is the next line's first)
+  *(u32_unaligned*)(codes + 42) = O.lo[6];
+  *(u16_unaligned*)(codes + 46) = (uint16_t)O.hi[6];
+  codes[48] = (uint8_t)(O.hi[6] >> 16);
+}
+
+// Grid.encode(vis_mask) (core/grid.py:244-268) in OUTPUT space: the 16 bytes [16 c, 16 c + 16) of a contiguous observation stream
+// whose cell g (= env * 49 + k) has its code at codes[g] and its three bytes at 3 g.  16 c = 3 q + ph with ph = c mod 3, so the
+// chunk is bytes ph .. ph + 15 of the 18 bytes of cells q .. q + 5.  `slut` = cell code -> type | colour << 8 | state << 16.
+// (Reads codes[q .. q + 7]: the staging buffer carries 8 bytes of slack.)
+MG_HD void obs7_chunk(uint32_t c, const uint8_t* codes, const uint32_t* slut, uint32_t out[4]) {
+  const uint32_t q = mul24(c * 16u, 0xAAABu) >> 17;            // 16 c / 3 (exact below 2^16; the full-rate 24-bit multiply)
+  const uint32_t ph8 = (16u * c - 3u * q) * 8u;
+  const uint64_t w = *(const u64_unaligned*)(codes + q);
+  const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+  const uint32_t t0 = slut[wl & 0xFFu], t1 = slut[(wl >> 8) & 0xFFu], t2 = slut[(wl >> 16) & 0xFFu], t3 = slut[wl >> 24];
+  const uint32_t t4 = slut[wh & 0xFFu], t5 = slut[(wh >> 8) & 0xFFu];
+  const uint32_t p0 = t0 | (t1 << 24), p1 = (t1 >> 8) | (t2 << 16), p2 = (t2 >> 16) | (t3 << 8), p3 = t4 | (t5 << 24), p4 = t5 >> 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+  out[0] = __funnelshift_r(p0, p1, ph8); out[1] = __funnelshift_r(p1, p2, ph8);
+  out[2] = __funnelshift_r(p2, p3, ph8); out[3] = __funnelshift_r(p3, p4, ph8);
+#else
+  const uint32_t p[5] = { p0, p1, p2, p3, p4 };
+  for (int i = 0; i < 4; i++) out[i] = ph8 ? (p[i] >> ph8) | (p[i + 1] << (32u - ph8)) : p[i];
+#endif
+}
+
+constexpr int ROLL_CODES_BYTES = 64 * VIEW_CELLS + 16;        // one wave's code staging (+ slack for the 8-byte accesses)
+constexpr int ROLL_MAX_WAVES = 4;
+
+// LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
+//   [0, 1024) code -> triple table | guard | NW private copies of the 64 grids (GS bytes per env) | guard | NW code stagings |
+//   shadow grids (every env's next spare episode) | shadow agent / aux words | the caller's actions [T][64]
+// StepParams: off_grid = first private grid copy, off_T = first code staging, off_shadow / off_spr / off_act as in k_step;
+// split[w] = first step wave w produces (split[NW] = T).
+
+template <int GG>
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(GG == GG_NONE ? 4 : 3, 8))) k_roll7(const StepParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int NW = nthreads >> 6;
+  const int wg = blockIdx.x, env0 = wg * 64, e = env0 + lane;
+  const bool active = e < P.N;
+  const int nvalid = min(64, P.N - env0);
+  const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
+  const size_t N = (size_t)P.N;
+  uint32_t* slut = (uint32_t*)smem;
+  uint8_t* sgrid = smem + P.off_grid + wave * (64 * GS);             // this wave's private copy of the 64 grids
+  uint8_t* scodes = smem + P.off_T + wave * ROLL_CODES_BYTES;
+  uint8_t* sshadow = smem + P.off_shadow;
+  uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
+  uint8_t* sact = smem + P.off_act;
+  const bool last_wave = wave == NW - 1;
+  const int j_begin = P.split[wave], j_end = P.split[wave + 1];
+  const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
+  const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
+                         (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
+
+  // ---- prologue: every load up front (see k_step: no global load may sit in the step loop) ----
+  const uint64_t rec = active ? P.agent[e] : 0ull;
+  EnvRegs S;
+  Agent& a = S.a;
+  S.targets = (goto_rule && active) ? P.aux[e] : 0ull;
+  S.h = (P.head && active) ? P.head[e] : 0u;
+  const uint32_t h_in = S.h;
+  uint32_t qn = (P.seg_count && last_wave) ? uni32(P.seg_count[wg]) : 0u;
+  const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
+  S.shadow_valid = P.use_shadow != 0;
+  const int cpe = CS >> 4, nchunks = nvalid * cpe;
+  {
+    // private grids: each wave stages its own copy (the redundant reads hit L2); 16 B per lane, coalesced
+    const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
+    for (int c = lane; c < nchunks; c += 64) {
+      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
+      const uint4 v = live[c];
+      uint32_t* dst = (uint32_t*)(sgrid + ce * GS + part * 16);
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  }
+  // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
+  for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
+  if (P.use_shadow) {
+    if (wave == 0 && active) {
+      const size_t se = (size_t)(S.h & P.ring_mask) * N + (size_t)e;
+      sspr[0] = P.spare_agent[se];
+      sspr[1] = goto_rule ? P.spare_aux[se] : 0ull;
+    }
+    for (int c = tid; c < nchunks; c += nthreads) {
+      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
+      const uint32_t slot = P.head ? (P.head[env0 + ce] & P.ring_mask) : 0u;
+      const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
+      uint32_t* d2 = (uint32_t*)(sshadow + ce * GS + part * 16);
+      d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
+    }
+  }
+  if (P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER)
+    for (int k = tid; k < P.T * 64; k += nthreads) {
+      const int j = k >> 6, l = k & 63;
+      if (env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
+    }
+  __syncthreads();
+
+  a = agent_unpack(rec);
+  uint8_t* mygrid = sgrid + lane * GS;
+  S.cur = S.targets;
+  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
+    const uint32_t desc = goto_desc(P, a.mission);
+    S.cur = 0;
+    for (int k = 0; k < P.cells; k++) S.cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
+  }
+  const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
+                 o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
+                 o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
+  S.rec_dirty = false; S.aux_dirty = false; S.wb_all = false; S.errbits = 0;
+  uint32_t fin_total = 0, errs_mine = 0;
+  uint32_t pw[4] = { 0, 0, 0, 0 };
+  LaneCtx C;
+  C.e = e; C.el = lane; C.sub = 0; C.active = active; C.lead = true; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
+  C.mygrid = mygrid; C.myshadow = sshadow + lane * GS; C.sspr = sspr;
+  const bool see_through = P.see_through != 0;
+
+  for (int j = 0; j < j_end; j++) {
+    const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
+    // ---- action ----
+    MG_MARK("action");
+    uint32_t act = A_DONE;
+    if (P.phase == PHASE_STEP) {
+      if (P.act_src == ACT_SRC_PHILOX) {
+        const uint32_t t = P.t0 + (uint32_t)j;
+        if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
+        const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
+        act = (uint32_t)(((uint64_t)w * 7u) >> 32);
+      } else act = sact[j * 64 + lane];
+    }
+    const uint32_t act_in = act;
+    if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
+    if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+    double reward = 0.0;
+    uint32_t term = 0, trunc = 0;
+    S.errbits = 0;
+    MG_MARK("transition");
+    env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
+    MG_MARK("after_transition");
+    bool show_taken = false;
+    Agent av = a;
+    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
+      // PutNext(start_carrying): the episode's first core observation shows the object where it was and empty hands (see k_step)
+      show_taken = true; av.carry = 0;
+      a.flags &= ~FLAG_SHOW_TAKEN; S.rec_dirty = true;
+    }
+    if (!emit) continue;
+    MG_MARK("scalars");
+    errs_mine |= S.errbits;
+    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));
+
+    int slot_out = P.slot0 - j;
+    while (slot_out < 0) slot_out += P.S;
+    uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
+    if (active) {
+      *(double*)(ob + o_rew) = reward;
+      ob[o_term] = (uint8_t)term;
+      ob[o_trunc] = (uint8_t)trunc;
+      ob[o_dir] = (uint8_t)a.dir;
+      *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
+      ob[o_act] = (uint8_t)act_in;
+    }
+    // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
+    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
+    MG_MARK("codes");
+    obs7_codes(av, mygrid, W, H, see_through, scodes + lane * VIEW_CELLS);
+    MG_MARK("codes_end");
+    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
+    MG_LDS_SYNC();
+    MG_MARK("chunks");
+    {
+      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;   // 64 * 147 is a multiple of 16
+      const int nbytes = nvalid * PARTIAL_OBS_BYTES;
+      const int nvec = nbytes >> 4;
+      constexpr int NCH = 64 * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;   // 588 chunks: ten rounds, the last one 12 lanes wide
+      if (nvalid == 64) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int c = lane + 64 * it;
+          uint32_t o4[4];
+          obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), scodes, slut, o4);
+          uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
+          if (it < NIT - 1 || c < NCH) ((uint4*)obase)[c] = v;
+        }
+      } else {
+        // the ragged last workgroup of a batch: whole chunks, then the stream's last bytes one by one
+#pragma unroll 1
+        for (int c = lane; c <= nvec; c += 64) {
+          uint32_t o4[4];
+          obs7_chunk((uint32_t)c, scodes, slut, o4);
+          if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; ((uint4*)obase)[c] = v; }
+          else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
+        }
+      }
+    }
+    MG_MARK("step_end");
+    // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
+  }
+
+  // ---- launch end.  Device errors and finished episodes: every wave for the steps it produced; state: the last wave ----
+  if (errs_mine && active) report_errors(P.err, errs_mine);
+  if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
+  if (!last_wave) return;
+  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+    const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (S.cur != S.targets ? FLAG_TARGETS_STALE : 0u);
+    if (fl != a.flags) { a.flags = fl; S.rec_dirty = true; }
+  }
+  if (active) {
+    if (S.rec_dirty) P.agent[e] = agent_pack(a);
+    if (goto_rule && S.aux_dirty) P.aux[e] = S.targets;
+    // (sentence levels: k_verify publishes head, after it copied the consumed slot's instruction record)
+    if (S.h != h_in && !(GG == GG_NONE && P.rule == RULE_SENTENCE)) P.head[e] = S.h;
+  }
+  {
+    const unsigned long long wb = __ballot(active && S.wb_all);        // envs whose whole live grid changed (new episode, fused launch)
+    if (wb) {
+      uint4* live = (uint4*)(P.grid + (size_t)env0 * CS);
+      for (int c = lane; c < nchunks; c += 64) {
+        const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
+        if ((wb >> ce) & 1ull) {
+          const uint32_t* s = (const uint32_t*)(sgrid + ce * GS + part * 16);
+          uint4 v; v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
+          live[c] = v;
+        }
+      }
+    }
+  }
+  if (P.seg_count) {
+    const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (S.h != h_in));
+    const unsigned long long m = __ballot(want);
+    if (m) {
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (want && qn + rank < (uint32_t)P.seg_cap) P.seg[(size_t)wg * P.seg_cap + qn + rank] = (uint32_t)e;
+      qn = min(qn + (uint32_t)__popcll(m), (uint32_t)P.seg_cap);
+      if (lane == 0) P.seg_count[wg] = qn;
+    }
+  }
+}
+
+}  // namespace mg

@@ -63,6 +63,7 @@ struct StepParams {
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
   int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
   long long env_base;
+  int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
 };
 
 // _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).

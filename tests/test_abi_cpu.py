@@ -307,3 +307,70 @@ def test_golden_generator_id_lists_match_the_test_lists():
     for name, ids in lists.items():
         assert ids == getattr(conftest, name), name
     assert set(lists) == {"MAIN_IDS", "EXTRA_IDS", "WIDE_IDS", "WIDE2_IDS", "SENTENCE_IDS", "ORACLE_ONLY_IDS"}
+
+
+# ---- k_roll7's observation pipeline (minigrid_amd/csrc/mg_roll.h) on the host ----------------------------------------------
+
+def test_vis_row_carry_equals_vis_row_exhaustively():
+    """process_vis rows by carry propagation == the Kogge-Stone form (itself checked against the literal loops above)."""
+    import ctypes as C
+    L = B.load()
+    m1, u1, m2, u2 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    for m in range(128):
+        for t in range(128):
+            L.mg_selftest_vis_row(m, t, C.byref(m1), C.byref(u1))
+            L.mg_selftest_vis_row_carry(m, t, C.byref(m2), C.byref(u2))
+            assert (m1.value, u1.value) == (m2.value, u2.value), (m, t)
+
+
+def test_valu_primitives_host_forms():
+    """perm_b32 / udot4 / brev32 / expand4 as the host evaluates them, against plain Python (the GPU suite compares the
+    device instructions with these host forms)."""
+    L = B.load()
+    rng = np.random.default_rng(0)
+    n = 4096
+    a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    sel = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0C, 0x0D], size=(n, 4)).astype(np.uint32)
+    c = (sel[:, 0] | (sel[:, 1] << 8) | (sel[:, 2] << 16) | (sel[:, 3] << 24)).astype(np.uint32)
+    out = np.zeros((5, n), np.uint32)
+    p = lambda x: x.ctypes.data_as(__import__("ctypes").c_void_p)
+    assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(out), 0) == 0
+    for i in range(0, n, 37):
+        v = (int(a[i]) << 32) | int(b[i])
+        want = 0
+        for k in range(4):
+            s = int(sel[i, k])
+            byte = (v >> (8 * s)) & 0xFF if s < 8 else (0 if s == 0x0C else 0xFF)
+            want |= byte << (8 * k)
+        assert int(out[0, i]) == want
+        dot = sum(((int(a[i]) >> (8 * k)) & 0xFF) * ((int(b[i]) >> (8 * k)) & 0xFF) for k in range(4)) + int(c[i])
+        assert int(out[1, i]) == dot & 0xFFFFFFFF
+        assert int(out[2, i]) == int(format(int(a[i]), "032b")[::-1], 2)
+        assert int(out[3, i]) == sum(0xFF << (8 * k) for k in range(4) if (int(a[i]) >> k) & 1)
+
+
+@pytest.mark.parametrize("env_id,n,T", [("MiniGrid-DoorKey-8x8-v0", 200, 80), ("MiniGrid-Empty-5x5-v0", 64, 40),
+                                        ("MiniGrid-LavaCrossingS9N1-v0", 130, 60), ("BabyAI-GoToRedBall-v0", 100, 60),
+                                        ("MiniGrid-FourRooms-v0", 70, 80), ("MiniGrid-MultiRoom-N6-v0", 40, 60),
+                                        ("MiniGrid-DistShift1-v0", 64, 40), ("MiniGrid-ObstructedMaze-1Dlhb-v0", 65, 80),
+                                        ("MiniGrid-KeyCorridorS3R3-v0", 64, 80), ("MiniGrid-Unlock-v0", 64, 80)])
+def test_roll7_observation_pipeline_on_the_host_equals_the_oracle(env_id, n, T):
+    """mg_selftest_obs7 = the device code of k_roll7's observation (line gather, byte transposes, carry visibility rows, output-space
+    encode) compiled for the host: every observation of random rollouts (doors opened, objects carried, every pose at the borders)."""
+    import ctypes as C
+    from oracle import oracle as O
+    L = B.load()
+    orc = O.OracleVec(env_id, n)
+    obs, _, _ = orc.reset(seeds=np.arange(n, dtype=np.uint64))
+    rng = np.random.default_rng(1)
+    out = np.zeros((n, 7, 7, 3), np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    see = int(O.spec(env_id)["see_through"])
+    for t in range(T):
+        grid, agent = orc.get_state()
+        assert L.mg_selftest_obs7(orc.W, orc.H, n, p(np.ascontiguousarray(grid)), p(np.ascontiguousarray(agent)), see, p(out)) == 0
+        bad = np.argwhere((out != obs).reshape(n, -1).any(1)).ravel()
+        assert bad.size == 0, (env_id, t, bad[:5], agent[bad[:1]], out[bad[0]].reshape(49, 3)[:, 0].reshape(7, 7), obs[bad[0]].reshape(49, 3)[:, 0].reshape(7, 7))
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs = orc.step(a)[0]

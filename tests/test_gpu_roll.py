@@ -1,0 +1,61 @@
+"""GPU tests of k_roll7 (minigrid_amd/csrc/mg_roll.h), the step / fused-rollout kernel of the default 7x7 view: its VALU primitives
+as the device executes them against their host forms (which the CPU suite pins to the oracle), and every time-split width
+(1, 2, 4 wavefronts per 64-env workgroup; MG_ROLL_NW) against the oracle under short episodes -- several resets per launch, i.e. the
+silent replay has to take the same spares, including the second reset of a launch that is fetched straight from the ring."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_valu_primitives_device_equals_host():
+    from minigrid_amd import _binding as B
+    L = B.load()
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    a = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    sel = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0C, 0x0D], size=(n, 4)).astype(np.uint32)
+    c = (sel[:, 0] | (sel[:, 1] << 8) | (sel[:, 2] << 16) | (sel[:, 3] << 24)).astype(np.uint32)
+    a[:128] = np.arange(128); b[:128 * 128:128] = 0                      # all (m, t) pairs of a visibility row appear below
+    mt = np.arange(128 * 128, dtype=np.uint32)
+    a[:128 * 128], b[:128 * 128] = mt >> 7, mt & 127
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    host, dev = np.zeros((5, n), np.uint32), np.zeros((5, n), np.uint32)
+    assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(host), 0) == 0
+    assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(dev), 1) == 0
+    for k, name in enumerate(("perm_b32", "udot4", "brev32", "expand4", "vis_row_carry")):
+        assert (host[k] == dev[k]).all(), name
+
+
+@pytest.mark.parametrize("nw", [1, 2, 4])
+@pytest.mark.parametrize("env_id,max_steps,full_T", [("MiniGrid-DoorKey-8x8-v0", 3, 128), ("BabyAI-GoToRedBall-v0", 2, 96),
+                                                      ("BabyAI-PutNextS5N2Carrying-v0", 4, 96), ("MiniGrid-MemoryS7-v0", 5, 96),
+                                                      ("MiniGrid-LavaCrossingS9N1-v0", 40, 160)])
+def test_time_split_widths_equal_the_oracle(nw, env_id, max_steps, full_T, monkeypatch):
+    from test_gpu_fused import _fused_vs_oracle
+    monkeypatch.setenv("MG_ROLL_NW", str(nw))
+    nterm, ntrunc = _fused_vs_oracle(env_id, 1000 + nw, full_T, False, chunk=32, max_steps=max_steps)
+    assert nterm + ntrunc > 1000
+
+
+def test_time_split_default_rings_caller_actions():
+    """step_many (caller-supplied actions staged in LDS, shared by the workgroup's waves) == step by step."""
+    import minigrid_amd as mg
+    n, T = 3000, 96
+    a_env, b_env = mg.make_vec("MiniGrid-DoorKey-8x8-v0", n, max_steps=9), mg.make_vec("MiniGrid-DoorKey-8x8-v0", n, max_steps=9)
+    a_env.reset(seed=21); b_env.reset(seed=21)
+    rng = np.random.default_rng(1)
+    for rnd in range(T // 32):
+        acts = rng.choice(7, size=(32, n), p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        a_env.step_many(acts)
+        for j in range(32):
+            obs, rew, term, trunc, _ = b_env.step(acts[j])
+            img, r2, t2, u2, d2, m2, act = a_env.trajectory(31 - j)
+            assert (img == obs["image"]).all(), (rnd, j)
+            assert r2.tobytes() == rew.tobytes() and (t2 == term).all() and (u2 == trunc).all() and (act == acts[j]).all()
+    assert (a_env.get_rng_state() == b_env.get_rng_state()).all()
+    a_env.close(); b_env.close()
