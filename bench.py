@@ -274,7 +274,7 @@ def main():
     else:
         senv = None
         env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
-    fused = bool(args.fused) and not gather
+    fused = bool(args.fused)
     spl = min(env.max_fused_steps, args.steps) if fused else 1          # steps per k_step launch in the timed region
     env.reset(seed=0)
     env.sync()
@@ -282,10 +282,15 @@ def main():
     def run(k, seed):
         if not gather:
             env.rollout(k, action_seed=seed, fused=fused)
+        elif fused:
+            # ONE all_gather_into_tensor per fused launch (its max_fused_steps step records = one contiguous block of the trajectory
+            # ring), on a communication stream ordered by events: launch k + 1 runs under the gather of launch k
+            senv.rollout_gather(k, action_seed=seed)
         else:
-            for _ in range(k):
-                env.rollout(1, action_seed=seed)
-                senv.gather_record()             # ONE all_gather_into_tensor of the step record, stream-ordered (no host sync)
+            with senv._on_step_stream():
+                for _ in range(k):
+                    env.rollout(1, action_seed=seed)
+                    senv.gather_record()         # ONE all_gather_into_tensor of the step record, stream-ordered (no host sync)
 
     def barrier():
         if world > 1:
@@ -300,6 +305,8 @@ def main():
     run(args.steps, 2)
     ev_ms = env.timer_stop()             # event after the last launch on the same stream (waits for it): the launches' own time
     env.sync()                           # + the generator stream: every episode consumed in the region is drawn again
+    if gather:
+        senv.finish()                    # + the communication stream: every collective issued in the region has completed
     barrier()
     dt = time.perf_counter() - t0        # whole-job clock (>= the event time): what `value` is computed from
 
@@ -342,7 +349,10 @@ def main():
                        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
                                        "backend": (dist.get_backend() if world > 1 else None),
                                        "per_rank_us_per_step": per_rank_us,
-                                       "collective": ("one all_gather_into_tensor of the step record per step" if gather else "none on the data path")}},
+                                       "collective": (("one all_gather_into_tensor per fused launch (its %d step records, one contiguous block), on a "
+                                                       "communication stream overlapped with the next launch" % spl) if gather and fused else
+                                                      "one all_gather_into_tensor of the step record per step" if gather else "none on the data path"),
+                                       "collectives_rank0": (senv.collectives if senv is not None else 0)}},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic_bytes(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,

@@ -227,6 +227,11 @@ MG_API int mg_step(mg_env* env, const void* actions, int dtype, int on_device);
 MG_API int mg_rollout(mg_env* env, int T, uint64_t action_seed, int fused);
 /* The same fused loop for actions the caller supplies: u8 [T][N], host or device.  Identical results to T mg_step calls. */
 MG_API int mg_step_many(mg_env* env, const uint8_t* actions, int T, int on_device);
+/* ONE fused launch of T <= max_fused_steps steps of the device policy (mg_rollout's, same action counter) whose step j lands in
+ * trajectory slot slot0 - j: the T step records are the contiguous byte range [slot0 - T + 1, slot0] x slot_bytes.  The unit a
+ * multi-GPU consumer gathers with one collective per launch while the next launch runs (minigrid_amd/sharded.py rollout_gather);
+ * the reference's counterpart is the body of the benchmark loop, minigrid/benchmark.py:36-43. */
+MG_API int mg_rollout_block(mg_env* env, int T, uint64_t action_seed, int slot0);
 
 MG_API int mg_get_outputs(mg_env* env, mg_outputs* out);
 /* Synchronises the stream, then copies whichever destinations are non-NULL to host memory.

@@ -38,7 +38,7 @@ class MiniGridHipError(RuntimeError):
 _lib = None
 
 # every symbol include/minigrid_hip.h declares (tests/test_abi_cpu.py checks the built library exports all of them)
-SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
+SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_rollout_block", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
            "mg_copy_slot", "mg_copy_sentence", "mg_selftest_stream",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
@@ -73,6 +73,7 @@ def load():
     L.mg_step.argtypes = [vp, vp, i, i]
     L.mg_rollout.argtypes = [vp, i, u64, i]
     L.mg_step_many.argtypes = [vp, vp, i, i]
+    L.mg_rollout_block.argtypes = [vp, i, u64, i]
     L.mg_copy_slot.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     L.mg_copy_sentence.argtypes = [vp, i, vp]
     L.mg_selftest_stream.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp]

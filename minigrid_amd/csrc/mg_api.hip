@@ -25,6 +25,23 @@ using namespace mg;
 
 static thread_local std::string g_create_error;
 
+// Host waits poll the stream / event for a while before they block: a blocking hipStreamSynchronize sleeps on an interrupt and
+// wakes up tens of microseconds late, which is most of a driver-sized run (one 20-step launch = 60 us) and of every Env.step().
+static hipError_t wait_stream(hipStream_t st) {
+  for (int i = 0; i < 20000; i++) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q != hipErrorNotReady) return q;
+  }
+  return hipStreamSynchronize(st);
+}
+static hipError_t wait_event(hipEvent_t ev) {
+  for (int i = 0; i < 20000; i++) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipErrorNotReady) return q;
+  }
+  return hipEventSynchronize(ev);
+}
+
 // Spare-episode ring and refill batches (see mg_kernels.h).  A BATCH is a run of consecutive step launches whose
 // refill requests are served by ONE k_refill launch on the generator stream.  With R ring slots per env and at most
 // cb = R/4 spares consumed per env and batch (a reset call consumes one; among n consecutive step calls at most
@@ -41,6 +58,8 @@ struct mg_env {
   bool own_stream = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_step[QSETS] = {}, ev_gen[QSETS] = {};
+  hipEvent_t ev_live = nullptr, ev_fill = nullptr;   // reset(seed=...): the ring is redrawn on the generator stream
+  bool fill_pending = false, fill_no_wait = false;
   // geometry
   int N = 0, W = 0, H = 0, cells = 0, CS = 0, GS = 0, obs_bytes = 0;
   int map_bytes = 0;          // bytes per env k_step writes: obs_bytes, or the tile map k_render expands (RGB modes)
@@ -153,7 +172,8 @@ static GenArgs gen_args(mg_env* e, int slot) {
 }
 
 // Direct generator launch over all envs (optionally masked), on the main stream.
-static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
+static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask, hipStream_t st = nullptr) {
+  if (!st) st = e->stream;
   GenArgs A = gen_args(e, slot);
   A.mask = d_mask;
   const int wpb = GEN_THREADS / 64;
@@ -162,7 +182,7 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask) {
   // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-  MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, e->stream, A);
+  MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, st, A);
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
 }
@@ -188,6 +208,14 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   return MG_OK;
 }
 
+// the ring redraw a seeded reset left running on the generator stream: whatever consumes spares or reads stream positions waits for it
+static int await_ring_fill(mg_env* e) {
+  if (!e->fill_pending) return MG_OK;
+  HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_fill, 0));
+  e->fill_pending = false;
+  return MG_OK;
+}
+
 static bool uses_ring(const mg_env* e) { return !e->static_gen && !e->live_gen; }
 
 // close the open batch: its refill runs on the generator stream as soon as the batch's last step launch has finished
@@ -206,6 +234,8 @@ static int close_batch(mg_env* e) {
 // account a launch (an OBSERVE launch, or T step calls) to the open batch, closing / opening batches as needed
 static int batch_admit(mg_env* e, int phase, int T) {
   if (!uses_ring(e)) return MG_OK;
+  // (a seeded reset's own OBSERVE launch takes no spare -- the live episode was drawn in place -- and does not wait: fill_no_wait)
+  if (!e->fill_no_wait) { int rc = await_ring_fill(e); if (rc) return rc; }
   const int add_obs = phase == PHASE_OBSERVE ? 1 : 0, add_steps = phase == PHASE_STEP ? T : 0;
   if (e->batch_open && (e->batch_obs + add_obs) + (e->batch_steps + add_steps + 1) / 2 > e->cb) {
     int rc = close_batch(e);
@@ -223,6 +253,7 @@ static int batch_admit(mg_env* e, int phase, int T) {
 // Entry points that read or overwrite spares / stream positions first bring every ring up to date: all requests
 // served (tail = head + R for every env), and the main stream ordered after the generator stream.
 static int flush_refills(mg_env* e) {
+  { int rc = await_ring_fill(e); if (rc) return rc; }
   if (!uses_ring(e)) return MG_OK;
   int rc = close_batch(e);
   if (rc) return rc;
@@ -272,6 +303,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
   P.env_base = e->cfg.env_index_base;
+  { static const int exp = [] { const char* s = getenv("MG_EXP"); return s ? atoi(s) : 0; }(); P.exp = exp; }
 }
 
 static int launch_step(mg_env* e, StepParams& P) {
@@ -305,7 +337,6 @@ static int launch_step(mg_env* e, StepParams& P) {
   P.use_shadow = P.T > 1 ? 1 : 0;
   const size_t lds = (size_t)(P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP ? e->lds_bytes : e->off_act);
   dim3 grid(e->nwaves);
-  const bool fast7 = false;             // (the 7x7 view is launched below: k_roll7)
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
                  : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
   const int gg = e->rule_group;
@@ -331,11 +362,11 @@ static int launch_step(mg_env* e, StepParams& P) {
     else launch_roll_rooms(grid, nw, (size_t)L.total, e->stream, P);
     launched = true;
   }
-  // one translation unit per rule group (mg_step_*.hip): (MODE, FAST7, LPE) picks the instantiation inside it
-  if (!launched) launched = gg == GG_NONE ? launch_step_none(mode, fast7, e->lpe, grid, lds, e->stream, P)
-                      : gg == GG_LIGHT ? launch_step_light(mode, fast7, e->lpe, grid, lds, e->stream, P)
-                      : gg == GG_ROOMGRID ? launch_step_roomgrid(mode, fast7, e->lpe, grid, lds, e->stream, P)
-                                          : launch_step_rooms(mode, fast7, e->lpe, grid, lds, e->stream, P);
+  // one translation unit per rule group (mg_step_*.hip): (MODE, LPE) picks the instantiation inside it
+  if (!launched) launched = gg == GG_NONE ? launch_step_none(mode, e->lpe, grid, lds, e->stream, P)
+                      : gg == GG_LIGHT ? launch_step_light(mode, e->lpe, grid, lds, e->stream, P)
+                      : gg == GG_ROOMGRID ? launch_step_roomgrid(mode, e->lpe, grid, lds, e->stream, P)
+                                          : launch_step_rooms(mode, e->lpe, grid, lds, e->stream, P);
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
   if (e->sentence) {
@@ -360,7 +391,7 @@ static int launch_step(mg_env* e, StepParams& P) {
 
 static int check_device_errors(mg_env* e) {
   uint32_t bits = 0;
-  HIP_TRY(e, hipStreamSynchronize(e->stream));
+  HIP_TRY(e, wait_stream(e->stream));
   for (int k = 0; k < 4; k++) if (e->err_host[k]) { bits |= 1u << k; e->err_host[k] = 0u; }
   if (!bits) return MG_OK;
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
@@ -742,6 +773,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   }
   TRY_OR_FREE(hipEventCreate(&e->ev0));
   TRY_OR_FREE(hipEventCreate(&e->ev1));
+  TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_live, hipEventDisableTiming));
+  TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_fill, hipEventDisableTiming));
   for (int i = 0; i < QSETS; i++) {
     TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_step[i], hipEventDisableTiming));
     TRY_OR_FREE(hipEventCreateWithFlags(&e->ev_gen[i], hipEventDisableTiming));
@@ -863,6 +896,8 @@ int mg_destroy(mg_env* e) {
   if (e->err_host) (void)hipHostFree((void*)e->err_host);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->ev_live) (void)hipEventDestroy(e->ev_live);
+  if (e->ev_fill) (void)hipEventDestroy(e->ev_fill);
   for (int i = 0; i < QSETS; i++) {
     if (e->ev_step[i]) (void)hipEventDestroy(e->ev_step[i]);
     if (e->ev_gen[i]) (void)hipEventDestroy(e->ev_gen[i]);
@@ -874,15 +909,16 @@ int mg_destroy(mg_env* e) {
 }
 
 // draw every ring slot of the selected envs from their current stream position (head = 0, tail = R)
-static int refill_whole_ring(mg_env* e, const uint8_t* d_mask, bool restore_gstate = true) {
+static int refill_whole_ring(mg_env* e, const uint8_t* d_mask, bool restore_gstate = true, hipStream_t st = nullptr) {
   if (e->live_gen) return MG_OK;
+  if (!st) st = e->stream;
   const int tb = 256, nb = (e->N + tb - 1) / tb;
   if (uses_ring(e)) {
-    hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, e->stream, e->head, e->tail, d_mask, (uint32_t)e->R, e->N,
+    hipLaunchKernelGGL(k_ring_restart, dim3(nb), dim3(tb), 0, st, e->head, e->tail, d_mask, (uint32_t)e->R, e->N,
                        (e->sentence && restore_gstate) ? e->gstate : nullptr, e->sentence ? e->gsnap : nullptr);
     HIP_TRY(e, hipGetLastError());
   }
-  for (int s = 0; s < e->R; s++) { int rc = launch_generate(e, s, d_mask); if (rc) return rc; }
+  for (int s = 0; s < e->R; s++) { int rc = launch_generate(e, s, d_mask, st); if (rc) return rc; }
   return MG_OK;
 }
 
@@ -891,6 +927,7 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
   HIP_TRY(e, hipSetDevice(e->device));
   const int N = e->N;
   const uint8_t* d_mask = nullptr;
+  { int rc = await_ring_fill(e); if (rc) return rc; }     // (a ring redraw still running reads e->mask and e->rng)
   if (mask) {
     HIP_TRY(e, hipMemcpyAsync(e->mask, mask, (size_t)N, hipMemcpyHostToDevice, e->stream));
     d_mask = e->mask;
@@ -912,8 +949,20 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     }
     int rc = launch_generate(e, -1, d_mask);
     if (rc) return rc;
-    rc = refill_whole_ring(e, d_mask, false);
-    if (rc) return rc;
+    if (uses_ring(e) && e->R > 1) {
+      // The observation of a seeded reset needs the live episode only.  The R spare episodes behind it (episodes 2, 3, ... of the
+      // same streams: 128 generator launches, tens of milliseconds at 262 144 envs) are drawn on the generator stream while the caller
+      // looks at the observation; the next launch that could take a spare waits for them (await_ring_fill).
+      HIP_TRY(e, hipEventRecord(e->ev_live, e->stream));
+      HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_live, 0));
+      rc = refill_whole_ring(e, d_mask, false, e->gen_stream);
+      if (rc) return rc;
+      HIP_TRY(e, hipEventRecord(e->ev_fill, e->gen_stream));
+      e->fill_pending = true;
+    } else {
+      rc = refill_whole_ring(e, d_mask, false);
+      if (rc) return rc;
+    }
   } else if (e->live_gen) {
     // reset(): continue each env's stream from where its last step left it
     int rc = launch_generate(e, -1, d_mask);
@@ -926,7 +975,10 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
   StepParams P;
   fill_step_params(e, P, PHASE_OBSERVE);
   P.obs_mask = d_mask;       // a masked reset() leaves the other envs alone, autoreset-pending ones included
-  return launch_step(e, P);
+  e->fill_no_wait = e->fill_pending;
+  const int rc = launch_step(e, P);
+  e->fill_no_wait = false;
+  return rc;
 }
 
 int mg_step(mg_env* e, const void* actions, int dtype, int on_device) {
@@ -963,6 +1015,18 @@ int mg_rollout(mg_env* e, int T, uint64_t action_seed, int fused) {
     j += tc;
   }
   return MG_OK;
+}
+
+int mg_rollout_block(mg_env* e, int T, uint64_t action_seed, int slot0) {
+  if (!e) return MG_ERR_INVALID;
+  if (T < 1 || T > e->max_fused || slot0 < T - 1 || slot0 >= e->S)
+    return fail(e, MG_ERR_INVALID, "rollout_block: 1 <= T <= max_fused_steps (%d) and T - 1 <= slot0 < traj_slots (%d)", e->max_fused, e->S);
+  HIP_TRY(e, hipSetDevice(e->device));
+  StepParams P;
+  fill_step_params(e, P, PHASE_STEP);
+  P.act_src = ACT_SRC_PHILOX; P.action_seed = action_seed; P.t0 = e->t; P.T = T; P.slot0 = slot0;
+  e->t += (uint32_t)T;
+  return launch_step(e, P);
 }
 
 int mg_step_many(mg_env* e, const uint8_t* actions, int T, int on_device) {
@@ -1032,7 +1096,7 @@ int mg_sync(mg_env* e) {
   // and covers the generator stream too, so that a timed region bracketed by mg_sync pays for every episode consumed inside it --
   // the rings are full again when it returns, whatever their depth
   { int rc = close_batch(e); if (rc) return rc; }
-  if (e->gen_stream) HIP_TRY(e, hipStreamSynchronize(e->gen_stream));
+  if (e->gen_stream) HIP_TRY(e, wait_stream(e->gen_stream));
   return check_device_errors(e);
 }
 
@@ -1127,7 +1191,7 @@ int mg_timer_start(mg_env* e) {
 int mg_timer_stop(mg_env* e, float* ms) {
   if (!e || !ms) return MG_ERR_INVALID;
   HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
-  HIP_TRY(e, hipEventSynchronize(e->ev1));
+  HIP_TRY(e, wait_event(e->ev1));
   HIP_TRY(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
   return MG_OK;
 }

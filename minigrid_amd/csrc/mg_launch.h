@@ -14,9 +14,9 @@
 namespace mg {
 
 #ifndef MG_GEN_TU_ONLY
-// Launch the k_step<mode, fast7, GG, lpe> instantiation of rule group GG; false if the group's TU has no such variant.
+// Launch the k_step<mode, GG, lpe> instantiation of rule group GG; false if the group's TU has no such variant.
 #define MG_DECL_STEP_TU(NAME)                                                                                              \
-  bool launch_step_##NAME(int mode, bool fast7, int lpe, dim3 grid, size_t lds, hipStream_t st, const StepParams& P);      \
+  bool launch_step_##NAME(int mode, int lpe, dim3 grid, size_t lds, hipStream_t st, const StepParams& P);      \
   hipError_t step_max_lds_##NAME(int bytes);                                                                               \
   void launch_roll_##NAME(dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);                             \
   hipError_t roll_max_lds_##NAME(int bytes);

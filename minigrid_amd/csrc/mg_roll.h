@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   LaneCtx C;
   C.e = e; C.el = lane; C.sub = 0; C.active = active; C.lead = true; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
   C.mygrid = mygrid; C.myshadow = sshadow + lane * GS; C.sspr = sspr;
-  const bool see_through = P.see_through != 0;
+  const bool see_through = P.see_through != 0 || (P.exp & 1);
 
   for (int j = 0; j < j_end; j++) {
     const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     uint32_t term = 0, trunc = 0;
     S.errbits = 0;
     MG_MARK("transition");
-    env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
+    if (!(P.exp & 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
     MG_MARK("after_transition");
     bool show_taken = false;
     Agent av = a;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     int slot_out = P.slot0 - j;
     while (slot_out < 0) slot_out += P.S;
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
-    if (active) {
+    if (active && !(P.exp & 8)) {
       *(double*)(ob + o_rew) = reward;
       ob[o_term] = (uint8_t)term;
       ob[o_trunc] = (uint8_t)trunc;
@@ -349,12 +349,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
     MG_MARK("codes");
-    obs7_codes(av, mygrid, W, H, see_through, scodes + lane * VIEW_CELLS);
+    if (!(P.exp & 4)) obs7_codes(av, mygrid, W, H, see_through, scodes + lane * VIEW_CELLS);
     MG_MARK("codes_end");
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
-    {
+    if (!(P.exp & 2)) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;   // 64 * 147 is a multiple of 16
       const int nbytes = nvalid * PARTIAL_OBS_BYTES;
       const int nvec = nbytes >> 4;

@@ -63,6 +63,7 @@ struct StepParams {
   uint32_t cpe_magic;     // ceil(2^20 / (CS/16))
   int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
   long long env_base;
+  int exp;                // tuning aid (MG_EXP, never set in normal use): k_roll7 skips parts of a step so that their cost can be timed
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
 };
 
@@ -147,7 +148,7 @@ struct StreamEmit {
 // minigrid/benchmark.py:36-43 for 64 envs per wavefront.  T = 1 is Env.step(); T > 1 is the fused rollout.
 // MODE 0 = partial VxVx3 view, 1 = FullyObs WxHx3, 2 = one-hot partial view VxVx20, 3 = symbolic WxHx3,
 // 4 = tile map for k_render (RGBImgPartialObsWrapper: VxV bytes; RGBImgObsWrapper: WxH bytes), byte = tile key * 2 + highlight.
-// FAST7: MODE 0 with the reference's default 7x7 view, fully unrolled.  GG = rule group compiled in (mg_gen.h).
+// (The default 7x7x3 view is k_roll7, mg_roll.h; MODE 0 here is the run-time view size of ViewSizeWrapper.)  GG = rule group compiled in (mg_gen.h).
 //
 // A wavefront is autonomous: lane l = env env0 + l, no workgroup barrier anywhere.  Launch start: the 64 grids are staged
 // into LDS with 16 B/lane coalesced loads (and, for fused launches, each env's next spare episode into a shadow copy).
@@ -163,138 +164,8 @@ struct StreamEmit {
 // execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
 #define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int LPE>
-MG_D void obs_view7(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint32_t* stream,
-                    int lane, int nlanes) {
-  // LPE lanes per env: the 49 cells in output order k = vx * 7 + vy are dealt out as 12 units of 4 cells (12 bytes = 3 stream
-  // dwords each) -- 12 / LPE consecutive units per lane -- plus cell 48, which goes to the env's last lane.  A lane's bytes are
-  // one contiguous range of the stream, so StreamEmit works per lane exactly as it does per env.
-  const int W = P.W, H = P.H;
-  constexpr int V = 7, HV = 3, UPL = 12 / LPE, NC = UPL * 4;
-  const bool SEE_THROUGH = P.see_through != 0;
-  const int sub = LPE == 1 ? 0 : (lane & (LPE - 1)), el = LPE == 1 ? lane : lane / LPE;
-  const bool last_sub = sub == LPE - 1;
-  const int k0 = sub * NC;
-  const int fxv = dir_dx(a.dir), fyv = dir_dy(a.dir);
-  const int rx = -fyv, ry = fxv;
-  const bool horiz = fyv == 0;                                // facing +-x: wx moves with vy, wy with vx
-  const uint32_t colmask = horiz ? inb_mask_v((int)a.y - HV * ry, ry, H, V) : inb_mask_v((int)a.x - HV * rx, rx, W, V);
-  const uint32_t rowmask = horiz ? inb_mask_v((int)a.x + (V - 1) * fxv, -fxv, W, V) : inb_mask_v((int)a.y + (V - 1) * fyv, -fyv, H, V);
-  const int SR = ry * W + rx;                                 // linear index step per vx
-  const int SU = -(fyv * W + fxv);                            // linear index step per vy
-  // may point outside this env's grid (into a neighbour's or a guard band): such cells are masked below
-  const uint8_t* vbase = mygrid + ((int)a.y + (V - 1) * fyv - HV * ry) * W + ((int)a.x + (V - 1) * fxv - HV * rx);
-  uint32_t code[NC + 1];                                      // this lane's cells (+ cell 48, used by the last lane only)
-  const int vx0 = LPE == 1 ? 0 : (k0 * 37) >> 8, vy0 = LPE == 1 ? 0 : k0 - 7 * vx0;
-  if constexpr (LPE == 1) {
-    // One lane holds the whole view: seven LINES of seven cells that are contiguous along world x -- the view's columns when the
-    // agent faces +-x (line t = vx, byte = vy), its rows when it faces +-y (line t = vy, byte = vx) -- as seven unaligned 8-byte
-    // LDS reads instead of 49 byte reads at scattered banks.  A line is byte-reversed when the view index runs against x, masked
-    // to walls outside the grid as a whole (7 validity bits -> 7 byte masks), and cell (vx, vy) is byte vy of line vx or byte vx
-    // of line vy.  The out-of-grid parts of a line lie in a neighbour's grid or a guard band, like the single cells before.
-    typedef uint64_t u64u __attribute__((aligned(1)));
-    const uint32_t d = a.dir;
-    const bool rev = d < 2u;                                  // east, south: the view index runs against world x
-    const int row_base = (int)a.y + (d == 0u ? -HV : d == 2u ? HV : d == 1u ? V - 1 : -(V - 1));
-    const int lstep = (d == 0u || d == 3u) ? W : -W;
-    const uint8_t* lp = mygrid + row_base * W + (int)a.x - (d == 0u ? 0 : d == 2u ? V - 1 : HV);
-    const uint32_t linemask = horiz ? colmask : rowmask, bytemask = horiz ? rowmask : colmask;
-    uint32_t bm_lo = 0, bm_hi = 0;                            // validity bit j -> byte j = 0xFF
-#pragma unroll
-    for (int j = 0; j < 4; j++) bm_lo |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * j));
-#pragma unroll
-    for (int j = 4; j < V; j++) bm_hi |= (0u - ((bytemask >> j) & 1u)) & (0xFFu << (8 * (j - 4)));
-    const uint32_t WALL4 = CELL_WALL_GREY * 0x01010101u;
-    uint32_t qlo[V], qhi[V];
-#pragma unroll
-    for (int t = 0; t < V; t++) {
-      const uint64_t q = *(const u64u*)(lp + t * lstep);
-      const uint64_t r = __builtin_bswap64(q) >> 8;
-      const uint32_t lo = rev ? (uint32_t)r : (uint32_t)q, hi = rev ? (uint32_t)(r >> 32) : (uint32_t)(q >> 32);
-      const uint32_t on = 0u - ((linemask >> t) & 1u);
-      const uint32_t ml = bm_lo & on, mh = bm_hi & on;
-      qlo[t] = (lo & ml) | (WALL4 & ~ml);
-      qhi[t] = (hi & mh) | (WALL4 & ~mh);
-    }
-    auto byte_of = [&](int t, int j) -> uint32_t { return j < 4 ? ((qlo[t] >> (8 * j)) & 0xFFu) : ((qhi[t] >> (8 * (j - 4))) & 0xFFu); };
-#pragma unroll
-    for (int i = 0; i <= NC; i++) {
-      const int vx = i / V, vy = i % V;
-      code[i] = vx == vy ? byte_of(vx, vy) : (horiz ? byte_of(vx, vy) : byte_of(vy, vx));
-    }
-  } else {
-    int vx = vx0, vy = vy0;
-#pragma unroll
-    for (int i = 0; i <= NC; i++) {
-      const uint32_t raw = vbase[vy * SU + vx * SR];
-      const uint32_t valid = 0u - (((rowmask >> vy) & (colmask >> vx)) & 1u);
-      const uint32_t c = ((raw ^ CELL_WALL_GREY) & valid) ^ CELL_WALL_GREY;
-      code[i] = c;
-      if (++vy == V) { vy = 0; vx++; }
-    }
-  }
-  // process_vis (grid.py:291-328), bit-parallel rows bottom-up: 49 bits, row j at bits 7j..7j+6 (every lane of the env)
-  unsigned long long vis = ~0ull;
-  if (!SEE_THROUGH) {
-    unsigned long long opq49 = 0;                             // opacity bits of this lane's cells, bit 7 * vy + vx
-    {
-      int vx = vx0, vy = vy0;
-#pragma unroll
-      for (int i = 0; i <= NC; i++) {                         // (the extra cell's bit is its owner's bit too)
-        if (LPE == 1) { vx = i / V; vy = i % V; }
-        opq49 |= (unsigned long long)(code[i] >> 7) << (7 * vy + vx);
-        if (LPE != 1) { if (++vy == V) { vy = 0; vx++; } }
-      }
-    }
-    if (LPE > 1) {
-      uint32_t lo = (uint32_t)opq49, hi = (uint32_t)(opq49 >> 32);
-#pragma unroll
-      for (int d = 1; d < LPE; d <<= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d); hi |= (uint32_t)__shfl_xor((int)hi, d); }
-      opq49 = ((unsigned long long)hi << 32) | lo;
-    }
-    uint32_t m = 1u << HV;
-    vis = 0;
-#pragma unroll
-    for (int j = V - 1; j >= 0; j--) {
-      uint32_t vr, up;
-      vis_row(m, ~(uint32_t)(opq49 >> (7 * j)) & 0x7Fu, &vr, &up);
-      vis |= (unsigned long long)vr << (7 * j);
-      m = up;
-    }
-  }
-  // Grid.encode(vis_mask) (grid.py:244-268) in image[vx][vy][c] order; invisible -> (0,0,0); the agent's own cell shows
-  // what it carries (minigrid_env.py:623-630).  4 cells = 12 bytes = 3 stream dwords.
-  int evx = vx0, evy = vy0;
-  auto tri_of = [&](int i) -> uint32_t {
-    int vx = evx, vy = evy;
-    if (LPE == 1) { vx = i / V; vy = i % V; if (i == NC) { vx = 6; vy = 6; } }
-    uint32_t c = code[i];
-    if (vx == HV && vy == V - 1) c = a.carry ? a.carry : (uint32_t)CELL_EMPTY;
-    if (LPE != 1) { if (++evy == V) { evy = 0; evx++; } }
-    return slut[c & (0u - ((uint32_t)(vis >> (7 * vy + vx)) & 1u))];
-  };
-  StreamEmit em;
-  em.setup(stream, (uint32_t)(el * PARTIAL_OBS_BYTES + k0 * 3), (uint32_t)(NC * 3 + (last_sub ? 3 : 0)));
-  uint32_t next0 = 0, dlast = 0;
-#pragma unroll
-  for (int g = 0; g < UPL; g++) {
-    const uint32_t t0 = tri_of(4 * g), t1 = tri_of(4 * g + 1), t2 = tri_of(4 * g + 2), t3 = tri_of(4 * g + 3);
-    const uint32_t d0 = t0 | (t1 << 24), d1 = (t1 >> 8) | (t2 << 16), d2 = (t2 >> 16) | (t3 << 8);
-    if (g == 0) {
-      em.first(d0);
-      next0 = (uint32_t)__shfl_down((int)d0, 1);
-      if (lane >= nlanes - 1) next0 = 0u;
-    } else em.put(d0);
-    em.put(d1);
-    if (g < UPL - 1) em.put(d2); else dlast = d2;
-  }
-  const uint32_t t48 = tri_of(NC);
-  if (LPE == 1) { em.put(dlast); em.put_last(t48, next0); }
-  else if (last_sub) { em.put(dlast); em.put_last(t48, next0); }
-  else em.put_last(dlast, next0);
-}
-
-// The same for any odd view size V <= 15 (ViewSizeWrapper), the one-hot encode (MODE 2) and the RGB tile map (MODE 4):
+// The agent's view for any odd view size V <= 15 (ViewSizeWrapper; the default 7x7x3 view runs k_roll7, mg_roll.h), the one-hot
+// encode (MODE 2) and the RGB tile map (MODE 4):
 // run-time loops, visibility rows kept in LDS (16 x u16 per env), bytes stored straight at their stream position.
 template <int MODE>
 MG_D void obs_view_generic(const StepParams& P, const Agent& a, const uint8_t* mygrid, const uint32_t* slut, uint16_t* rows,
@@ -757,7 +628,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
   }
 }
 
-template <int MODE, bool FAST7, int GG, int LPE>
+template <int MODE, int GG, int LPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))    // one autonomous wave per workgroup; LDS, not registers, bounds the occupancy
 k_step(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -904,10 +775,8 @@ k_step(const StepParams P) {
       a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
     }
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
-    if constexpr (FAST7) {
-      obs_view7<LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
-    } else if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
-      static_assert(FAST7 || MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
+    if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
+      static_assert(MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
       obs_view_generic<MODE>(P, av, mygrid, slut, srows, sT + el * obe, active);
     } else {
       obs_full<MODE, LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
@@ -920,15 +789,7 @@ k_step(const StepParams P) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)obe;    // 64*obe is a multiple of 16
       const int nbytes = nvalid * obe;
       const int nvec = nbytes >> 4;
-      if (FAST7 && nvalid == EPW) {
-        // EPW * 147 / 16 chunks: all LDS reads first, then the stores (the loop form exposes one LDS round trip per iteration)
-        constexpr int NCH = EPW * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;
-        uint4 v[NIT];                       // (unconditional, clamped reads: a conditionally written array goes to scratch)
-#pragma unroll
-        for (int i = 0; i < NIT; i++) v[i] = ((const uint4*)sT)[min(lane + 64 * i, NCH - 1)];
-#pragma unroll
-        for (int i = 0; i < NIT; i++) { const int c = lane + 64 * i; if (c < NCH) ((uint4*)obase)[c] = v[i]; }
-      } else {
+      {
 #pragma unroll 4
         for (int c = lane; c < nvec; c += 64) ((uint4*)obase)[c] = ((const uint4*)sT)[c];
         for (int b = (nvec << 4) + lane; b < nbytes; b += 64) obase[b] = sT[b];   // ragged last group only

@@ -83,9 +83,20 @@ class ShardedVecEnv:
         self.lo, self.hi = shard_range(self.num_envs, self.rank, self.world_size)
         self.local_num_envs = self.hi - self.lo
         self._max_local = -(-self.num_envs // self.world_size)
+        self._step_stream = self._comm_stream = None
         if make is None:
             from .vector_env import make_vec as make
             kwargs.setdefault("output", "torch")
+            if self.gather and kwargs["output"] == "torch" and kwargs.get("stream") is None:
+                # The shard steps on its OWN (non-blocking) stream and the collectives run on a second one, ordered by events
+                # (rollout_gather): launch k + 1 runs under the gather of launch k.  Two blocks of max_fused_steps trajectory slots
+                # rotate, hence 64 slots.
+                import torch
+                dev = kwargs.get("device")
+                self._step_stream = torch.cuda.Stream(device=dev)
+                self._comm_stream = torch.cuda.Stream(device=dev)
+                kwargs["stream"] = self._step_stream.cuda_stream
+                kwargs.setdefault("traj_slots", 64)
         self.local = make(env_id, self.local_num_envs, env_index_base=self.lo, **kwargs)
         # the sentence levels' missions travel as two u64 per env inside the record and become strings again on every rank
         self._sentence = bool(getattr(self.local, "sentence", False))
@@ -132,7 +143,7 @@ class ShardedVecEnv:
         self._image_shape, self._image_dtype = tuple(image.shape[1:]), image.dtype
         obs_bytes = int(np.prod(self._image_shape)) * image.element_size()
         if self._zero_copy:
-            if getattr(self.local._cfg, "null_stream_sync", 0) != 1 and not getattr(self.local, "_stream_arg", None):
+            if getattr(self.local._cfg, "null_stream_sync", 0) != 1 and not getattr(self.local, "_stream_arg", None):   # (own step stream: it IS torch's current stream here)
                 self.local.sync()          # private non-blocking stream: nothing orders it with the collective's stream
             return self.local.torch_outputs()["record"], obs_bytes
         n = self.local_num_envs
@@ -218,6 +229,100 @@ class ShardedVecEnv:
             return out, rew_g, term_g, trunc_g
         return image, rew_g, term_g, trunc_g
 
+    def _on_step_stream(self):
+        """torch's current stream = the shard's stream, so that torch.distributed orders its collectives against the step kernels."""
+        import contextlib
+        if self._step_stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self._step_stream)
+
+    # ---- the fused rollout: ONE collective per launch, overlapped with the next launch --------------------------------
+    def rollout_gather(self, steps: int, action_seed: int = 0, consumer=None) -> int:
+        """`steps` lockstep steps of the device policy in fused launches of F = max_fused_steps steps.  After every launch ONE
+        all_gather_into_tensor moves the launch's F step records -- a contiguous block of the trajectory ring, zero-copy -- to
+        every rank: (world_size, F, record bytes) uint8.  The collective is issued on a dedicated communication stream and ordered
+        with events, two ring blocks in rotation, so launch k + 1 runs under the gather of launch k and nothing synchronises the
+        host.  `consumer(block, T)` is called per launch with the gathered tensor (on the communication stream when there is one;
+        the buffer is reused two launches later; `unpack_block` turns one of its steps into per-field tensors).  Returns the
+        number of collectives issued (= launches)."""
+        import torch
+        loc = self.local
+        F = max(1, min(int(loc.max_fused_steps), int(loc.traj_slots) // 2))
+        W = self.world_size
+        rec_bytes = record_layout(self._max_local, int(np.prod(loc.image_shape)), self._sentence)["record_bytes"]
+        n_coll, done = 0, 0
+        if getattr(self, "_blk", None) is None:
+            self._blk = {"gbuf": [None, None], "stepped": [None, None], "gathered": [None, None]}
+        st = self._blk
+        k = getattr(self, "_blk_next", 0)
+        while done < steps:
+            T = min(F, steps - done)
+            b = k & 1
+            slot0 = (b + 1) * F - 1                                   # block b = slots [b F, b F + T) counted from its top
+            lo = slot0 - T + 1
+            if self._step_stream is not None:
+                if st["gathered"][b] is not None:
+                    self._step_stream.wait_event(st["gathered"][b])   # the block's previous gather has read it
+                with torch.cuda.stream(self._step_stream):
+                    loc.rollout_block(T, action_seed, slot0)
+                    st["stepped"][b] = self._step_stream.record_event(st["stepped"][b])
+                self._comm_stream.wait_event(st["stepped"][b])
+            else:
+                loc.rollout_block(T, action_seed, slot0)
+            view = loc.block_view(lo, T)                               # (T, this shard's slot bytes) u8
+            with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else self._on_step_stream()):
+                if W > 1 and view.shape[1] != rec_bytes:                # ragged shard: pad the records to the largest shard's
+                    pad = torch.zeros((T, rec_bytes), dtype=torch.uint8, device=view.device)
+                    pad[:, : view.shape[1]] = view
+                    view = pad
+                g = st["gbuf"][b]
+                if g is None or g.shape != (W, F, view.shape[1]) or g.device != view.device:
+                    g = st["gbuf"][b] = torch.empty((W, F, view.shape[1]), dtype=torch.uint8, device=view.device)
+                out = g if T == F else torch.empty((W, T, view.shape[1]), dtype=torch.uint8, device=view.device)
+                if W > 1:
+                    self.collectives += 1
+                    self._dist.all_gather_into_tensor(out.reshape(-1), view.reshape(-1), group=self.group)
+                else:
+                    out = view.reshape(1, T, -1)
+                n_coll += 1
+                if consumer is not None:
+                    consumer(out, T)
+                if self._comm_stream is not None:
+                    st["gathered"][b] = self._comm_stream.record_event(st["gathered"][b])
+            done += T
+            k += 1
+        self._blk_next = k
+        return n_coll
+
+    def finish(self):
+        """Wait (host) until every launch and collective issued by rollout_gather has completed."""
+        if self._comm_stream is not None:
+            self._comm_stream.synchronize()
+            self._step_stream.synchronize()
+
+    def unpack_block(self, block, j: int) -> dict:
+        """Per-field GLOBAL tensors of step record j of a gathered block ((world, T, bytes) uint8; record j = the launch's step
+        T - 1 - j, like trajectory slots): image, reward, terminated, truncated, direction, mission_id, action."""
+        import torch
+        loc = self.local
+        obs_bytes = int(np.prod(loc.image_shape))
+        img_dtype = torch.int8 if getattr(loc, "obs_mode", "") == "symbolic" else torch.uint8
+        fields = {"image": (img_dtype, tuple(loc.image_shape)), "reward": (torch.float64, ()), "terminated": (torch.uint8, ()),
+                  "truncated": (torch.uint8, ()), "direction": (torch.uint8, ()), "mission_id": (torch.int16, ()), "action": (torch.uint8, ())}
+        out = {}
+        for name, (dt, tail) in fields.items():
+            esz = torch.empty(0, dtype=dt).element_size() * (int(np.prod(tail)) if tail else 1)
+            parts = []
+            for r in range(self.world_size):
+                lo, hi = shard_range(self.num_envs, r, self.world_size)
+                n = hi - lo
+                lay = record_layout(n, obs_bytes, self._sentence)
+                raw = block[r, j, lay[name]: lay[name] + n * esz]
+                parts.append(raw.view(dt).reshape((n,) + tail))
+            out[name] = parts[0] if self.world_size == 1 else torch.cat(parts, 0)
+        return out
+
     # ---- Gymnasium VectorEnv surface ----------------------------------------------------------------------
     def _local_slice(self, seq, what):
         n = len(seq)
@@ -232,20 +337,22 @@ class ShardedVecEnv:
             seed = list(self._local_slice(list(seed), "seed"))
         if options and options.get("reset_mask") is not None:
             options = dict(options, reset_mask=np.asarray(self._local_slice(np.asarray(options["reset_mask"]), "reset_mask")))
-        obs, info = self.local.reset(seed=seed, options=options)     # int seed: the shard adds its env_index_base
-        if not self.gather:
-            return obs, info
-        n = self.local_num_envs
-        z = np.zeros(n, np.uint8)
-        return self._gather_step(obs, np.zeros(n, np.float64), z, z)[0], info
+        with self._on_step_stream():
+            obs, info = self.local.reset(seed=seed, options=options)     # int seed: the shard adds its env_index_base
+            if not self.gather:
+                return obs, info
+            n = self.local_num_envs
+            z = np.zeros(n, np.uint8)
+            return self._gather_step(obs, np.zeros(n, np.float64), z, z)[0], info
 
     def step(self, actions):
         a = self._local_slice(actions, "actions")
-        obs, rew, term, trunc, info = self.local.step(a)
-        if not self.gather:
+        with self._on_step_stream():
+            obs, rew, term, trunc, info = self.local.step(a)
+            if not self.gather:
+                return obs, rew, term, trunc, info
+            obs, rew, term, trunc = self._gather_step(obs, rew, term, trunc)
             return obs, rew, term, trunc, info
-        obs, rew, term, trunc = self._gather_step(obs, rew, term, trunc)
-        return obs, rew, term, trunc, info
 
     def close(self):
         self.local.close()

@@ -334,6 +334,20 @@ class MiniGridVecEnv(_VectorEnvBase):
         LDS; step j writes trajectory slot (steps-1-j) % traj_slots, so slot 0 is the last step."""
         B.check(self._lib.mg_rollout(self._h, int(steps), int(action_seed), int(fused)), self._h)
 
+    def rollout_block(self, steps: int, action_seed: int = 0, slot0: Optional[int] = None):
+        """ONE fused launch of `steps` <= max_fused_steps steps of the device policy; step j lands in trajectory slot slot0 - j
+        (default slot0 = steps - 1), so the launch's step records are the contiguous slots [slot0 - steps + 1, slot0]."""
+        B.check(self._lib.mg_rollout_block(self._h, int(steps), int(action_seed), int(steps - 1 if slot0 is None else slot0)), self._h)
+
+    def block_view(self, slot_lo: int, nslots: int):
+        """Zero-copy torch view of `nslots` consecutive trajectory slots starting at slot_lo: (nslots, slot_bytes) uint8."""
+        import torch
+        if not (0 <= slot_lo and slot_lo + nslots <= self.traj_slots):
+            raise ValueError("block outside the trajectory ring")
+        sb = int(self._outs.slot_bytes)
+        arr = _DeviceArray(self._outs.obs + slot_lo * sb, (nslots, sb), "|u1", self)
+        return torch.as_tensor(arr, device=torch.device("cuda", self.device))
+
     def step_many(self, actions):
         """The fused loop for caller-supplied actions: uint8 (T, num_envs), numpy or a CUDA tensor.  Identical to T
         step() calls; outputs of the step k calls before the last are in trajectory slot k (trajectory() /
@@ -406,6 +420,9 @@ class MiniGridVecEnv(_VectorEnvBase):
 
 
 try:
+    import os as _os
+    if _os.environ.get("MINIGRID_AMD_NO_TORCH", "0") == "1":       # a torch-free process (numpy outputs only): see _binding.load
+        raise ImportError
     import torch as _torch
     _TORCH_ACT = {_torch.uint8: B.ACT_U8, _torch.int32: B.ACT_I32, _torch.int64: B.ACT_I64}
 except Exception:  # pragma: no cover

@@ -61,3 +61,83 @@ def test_sharded_env_over_rccl_matches_the_oracle(env_id, n, full):
     if world < 2:
         pytest.skip("needs >= 2 visible GPUs (RCCL all-gather of the step record)")
     mp.spawn(_worker, args=(world, _free_port(), env_id, n, full), nprocs=world, join=True)
+
+
+def _worker_blocks(rank, world, port, env_id, n, steps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from minigrid_amd.sharded import ShardedVecEnv
+        from par_oracle import ParOracle
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == world           # RCCL, one rank per GPU
+        env = ShardedVecEnv(env_id, n, gather=True, device=rank)
+        assert env.local.device == rank and env.local.traj_slots == 64 and env.local.max_fused_steps == 32
+        orc = ParOracle(env_id, n, threads=8)                                            # every rank checks the WHOLE gathered batch
+        env.reset(seed=5); orc.reset(5)
+        got = []
+
+        def consumer(block, T):                           # stream-ordered on the communication stream: clone, look later
+            got.append((block[:, :T].clone(), T))
+        c0 = env.collectives
+        launches = env.rollout_gather(steps, action_seed=6, consumer=consumer)
+        env.finish()
+        assert launches == -(-steps // 32) and env.collectives - c0 == launches          # exactly one collective per fused launch
+        t = 0
+        for block, T in got:
+            for j in reversed(range(T)):
+                f = env.unpack_block(block, j)
+                oo, orew, oterm, otrunc, od, om, oact = orc.philox_step(6, t, quiet=False); t += 1
+                assert (f["image"].cpu().numpy() == oo).all(), (rank, t)
+                assert f["reward"].cpu().numpy().tobytes() == orew.tobytes() and (f["terminated"].cpu().numpy().astype(bool) == oterm).all()
+                assert (f["action"].cpu().numpy() == oact).all() and (f["direction"].cpu().numpy() == od).all()
+        env.close(); orc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env_id,n,steps", [("MiniGrid-DoorKey-8x8-v0", 8192, 96), ("BabyAI-GoToRedBall-v0", 3001, 80)])
+def test_fused_block_gather_over_rccl(env_id, n, steps):
+    """rollout_gather over RCCL: fused 32-step launches, ONE all-gather per launch on the communication stream while the next launch
+    runs; every rank holds every rank's step records, equal to the oracle under the device policy."""
+    import torch
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("needs >= 2 visible GPUs (RCCL all-gather of the fused trajectory block)")
+    mp.spawn(_worker_blocks, args=(world, _free_port(), env_id, n, steps), nprocs=world, join=True)
+
+
+def test_fused_block_gather_single_process_streams():
+    """The same path with world_size 1 on one GPU: the shard's own step stream + the communication stream + the event rotation of
+    two ring blocks (no collective to issue): blocks arrive complete and in order."""
+    import torch
+    import torch.distributed as dist
+    from minigrid_amd.sharded import ShardedVecEnv
+    from oracle import oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        n, steps = 5000, 200
+        env = ShardedVecEnv("MiniGrid-DoorKey-8x8-v0", n, gather=True, max_steps=12)
+        orc = O.OracleVec("MiniGrid-DoorKey-8x8-v0", n, max_steps=12)
+        env.reset(seed=2); orc.reset(seeds=np.arange(2, 2 + n, dtype=np.uint64))
+        got = []
+        assert env.rollout_gather(steps, action_seed=3, consumer=lambda blk, T: got.append((blk[:, :T].clone(), T))) == 7
+        env.finish()
+        t = 0
+        for block, T in got:
+            for j in reversed(range(T)):
+                f = env.unpack_block(block, j)
+                act = O.philox_actions(3, t, n); t += 1
+                oo, orew, oterm, otrunc, od, om = orc.step(act)
+                assert (f["image"].cpu().numpy() == oo).all() and (f["action"].cpu().numpy() == act).all(), t
+                assert f["reward"].cpu().numpy().tobytes() == orew.tobytes() and (f["truncated"].cpu().numpy().astype(bool) == otrunc).all()
+        assert t == steps
+        env.close()
+    finally:
+        dist.destroy_process_group()
