@@ -106,6 +106,9 @@ struct mg_env {
   uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
   uint32_t launches = 0;      // k_step launches so far
   uint32_t t = 0;             // rollout step counter (Philox action counter)
+  // every device buffer of the handle: freed in mg_destroy; with MG_GUARD=1 each one sits between two pattern-filled red zones
+  struct Alloc { void* user; void* base; size_t bytes; const char* name; };
+  std::vector<Alloc> allocs;
   std::string last_error;
 };
 
@@ -400,6 +403,47 @@ static int check_device_errors(mg_env* e) {
   return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound");
 }
 
+// Debug aid for the crash hunt (MG_GUARD=1; profiles/crash_hunt.md): every device buffer gets a 4 KB red zone on both sides, filled
+// with a pattern; mg_sync and mg_destroy verify that no kernel wrote into one and name the buffer otherwise.
+constexpr size_t GUARD_ZONE = 4096;
+constexpr uint8_t GUARD_BYTE = 0xC7;
+static bool guard_on() { static const bool on = [] { const char* s = getenv("MG_GUARD"); return s && atoi(s) == 1; }(); return on; }
+static hipError_t env_alloc(mg_env* e, void** p, size_t bytes, const char* name) {
+  const size_t z = guard_on() ? GUARD_ZONE : 0;
+  void* base = nullptr;
+  hipError_t rc = hipMalloc(&base, bytes + 2 * z + 16);
+  if (rc != hipSuccess) return rc;
+  if (z) {
+    rc = hipMemset(base, GUARD_BYTE, z);
+    if (rc == hipSuccess) rc = hipMemset((uint8_t*)base + z + bytes, GUARD_BYTE, z + 16);
+    if (rc != hipSuccess) { (void)hipFree(base); return rc; }
+  }
+  *p = (uint8_t*)base + z;
+  e->allocs.push_back({ *p, base, bytes, name });
+  return hipSuccess;
+}
+template <class T>
+static hipError_t dalloc_named(mg_env* e, T** p, size_t n, const char* name) { return env_alloc(e, (void**)p, n * sizeof(T), name); }
+#define dalloc(p, n) dalloc_named(e, p, n, #p)
+static int check_guards(mg_env* e) {
+  if (!guard_on()) return MG_OK;
+  std::vector<uint8_t> h(GUARD_ZONE + 16);
+  for (const auto& a : e->allocs) {
+    for (int side = 0; side < 2; side++) {
+      const size_t len = side ? GUARD_ZONE + 16 : GUARD_ZONE;
+      const uint8_t* src = side ? (const uint8_t*)a.user + a.bytes : (const uint8_t*)a.base;
+      if (hipMemcpy(h.data(), src, len, hipMemcpyDeviceToHost) != hipSuccess) return fail(e, MG_ERR_HIP, "guard check: copy failed");
+      for (size_t i = 0; i < len; i++)
+        if (h[i] != GUARD_BYTE) {
+          const long long off = side ? (long long)(a.bytes + i) : (long long)i - (long long)GUARD_ZONE;
+          fprintf(stderr, "[libminigrid_hip] MG_GUARD: out-of-bounds write at %s%+lld (buffer of %zu bytes, value 0x%02x)\n", a.name, off, a.bytes, h[i]);
+          return fail(e, MG_ERR_HIP, "MG_GUARD: out-of-bounds device write at %s%+lld (buffer of %zu bytes)", a.name, off, a.bytes);
+        }
+    }
+  }
+  return MG_OK;
+}
+
 // ---- RGB modes: the tile atlas and k_render's launch geometry ------------------------------------------------
 static int setup_render(mg_env* e) {
   const int ts = e->cfg.tile_size, V = e->cfg.agent_view_size;
@@ -450,9 +494,9 @@ static int setup_render(mg_env* e) {
         const size_t di = ad == 0 ? (size_t)k * 2 + hl : (size_t)STATIC_TILES + ((size_t)k * 4 + (ad - 1)) * 2 + hl;
         memcpy(dev.data() + di * tb, src, tb);
       }
-  HIP_TRY(e, hipMalloc((void**)&e->atlas, dev.size()));
+  HIP_TRY(e, env_alloc(e, (void**)&e->atlas, dev.size(), "atlas"));
   HIP_TRY(e, hipMemcpy(e->atlas, dev.data(), dev.size(), hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMalloc((void**)&e->tilemap, (size_t)e->N * e->map_bytes + 16));
+  HIP_TRY(e, env_alloc(e, (void**)&e->tilemap, (size_t)e->N * e->map_bytes + 16, "tilemap"));
   HIP_TRY(e, hipMemsetAsync(e->tilemap, 0, (size_t)e->N * e->map_bytes + 16, e->stream));
   R.tilemap = e->tilemap; R.agent = e->agent;
   R.atlas_static = e->atlas; R.atlas_agent = e->atlas + (size_t)STATIC_TILES * R.tile_dw;
@@ -460,9 +504,6 @@ static int setup_render(mg_env* e) {
   if (e->render_lds > 64 * 1024) HIP_TRY(e, hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, e->render_lds));
   return MG_OK;
 }
-
-template <class T>
-static hipError_t dalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -669,7 +710,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (e->fast7) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
-    e->roll_guard = (6 * e->W + 8 + 15) & ~15;
+    e->roll_guard = (6 * e->W + 12 + 15) & ~15;
     int nw = 4;
     while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw >>= 1;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) nw = v; }
@@ -889,10 +930,9 @@ int mg_destroy(mg_env* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->gen_stream) (void)hipStreamSynchronize(e->gen_stream);
-  void* bufs[] = { e->grid, e->spare_grid, e->agent, e->spare_agent, e->rng, e->rng_snap, e->rng_tmp, e->seeds, e->mask, e->actions, e->aux,
-                   e->spare_aux, e->head, e->tail, e->claim, e->seg, e->seg_count, e->out, e->counters,
-                   e->tilemap, e->atlas, e->st_grid, e->st_agent, e->instr, e->spare_instr, e->gstate, e->gsnap };
-  for (void* b : bufs) if (b) (void)hipFree(b);
+  (void)check_guards(e);
+  for (const auto& a : e->allocs) (void)hipFree(a.base);
+  e->allocs.clear();
   if (e->err_host) (void)hipHostFree((void*)e->err_host);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1097,15 +1137,16 @@ int mg_sync(mg_env* e) {
   // the rings are full again when it returns, whatever their depth
   { int rc = close_batch(e); if (rc) return rc; }
   if (e->gen_stream) HIP_TRY(e, wait_stream(e->gen_stream));
-  return check_device_errors(e);
+  { int rc = check_device_errors(e); if (rc) return rc; }
+  return check_guards(e);
 }
 
 // staging buffers of the state exchange, allocated on first use: (N, W, H, 3) u8 + (N, 8) i32
 static int state_staging(mg_env* e) {
   if (e->st_grid) return MG_OK;
   const size_t N = (size_t)e->N;
-  HIP_TRY(e, hipMalloc((void**)&e->st_grid, N * e->cells * 3));
-  HIP_TRY(e, hipMalloc((void**)&e->st_agent, N * 8 * sizeof(int32_t)));
+  HIP_TRY(e, env_alloc(e, (void**)&e->st_grid, N * e->cells * 3, "st_grid"));
+  HIP_TRY(e, env_alloc(e, (void**)&e->st_agent, N * 8 * sizeof(int32_t), "st_agent"));
   return MG_OK;
 }
 
@@ -1275,10 +1316,13 @@ int mg_selftest_vis_row_carry(uint32_t m, uint32_t t, uint32_t* m_out, uint32_t*
 // the exchange format of mg_set_state -- a check of the kernel's arithmetic for the CPU test-suite, laid out exactly like a wave's LDS.
 int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const int32_t* agent, int32_t see_through, uint8_t* out) {
   if (!grid || !agent || !out || W < 3 || H < 3 || W > 25 || H > 25 || n < 1) return MG_ERR_INVALID;
-  const int cells = W * H, CS = (cells + 15) & ~15, GS = CS + 4, guard = (6 * W + 8 + 15) & ~15;
+  const int cells = W * H, CS = (cells + 15) & ~15, GS = CS + 4, guard = (6 * W + 12 + 15) & ~15;
   std::vector<uint32_t> slut(256);
   for (uint32_t k = 0; k < 256; k++) slut[k] = cell_triple(k);
-  std::vector<uint8_t> lds((size_t)guard * 2 + 64 * (size_t)GS), codes(ROLL_CODES_BYTES);
+  std::vector<uint32_t> lds_w(((size_t)guard * 2 + 64 * (size_t)GS) / 4 + 4), codes_w(ROLL_CODES_BYTES / 4 + 4);    // (dword-aligned, like LDS)
+  struct Bytes { uint8_t* p; size_t n; uint8_t* data() { return p; } uint8_t* begin() { return p; } uint8_t* end() { return p + n; } };
+  Bytes lds{ (uint8_t*)lds_w.data(), lds_w.size() * 4 }, codes{ (uint8_t*)codes_w.data(), codes_w.size() * 4 };
+  uint32_t D[64][13];
   for (int g0 = 0; g0 < n; g0 += 64) {
     const int nv = std::min(64, n - g0);
     std::fill(lds.begin(), lds.end(), (uint8_t)0xA5);                 // whatever lies around an env's grid must not matter
@@ -1299,8 +1343,11 @@ int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const
         a.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
         if (a.carry == CELL_EMPTY) a.carry = 0;
       }
-      obs7_codes(a, lds.data() + guard + (size_t)l * GS, W, H, see_through != 0, codes.data() + l * VIEW_CELLS);
+      View7 O;
+      obs7_view(a, lds.data() + guard + (size_t)l * GS, W, H, see_through != 0, O);
+      view7_pack(O, D[l]);
     }
+    for (int l = 0; l < 64; l++) obs7_stage(D[l], l < 63 ? D[l + 1][0] : 0u, l, (uint32_t*)codes.data());
     const int nbytes = nv * PARTIAL_OBS_BYTES;
     uint8_t* ob = out + (size_t)g0 * PARTIAL_OBS_BYTES;
     for (int c = 0; c * 16 < nbytes; c++) {

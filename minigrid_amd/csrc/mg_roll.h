@@ -126,7 +126,7 @@ typedef uint16_t u16_unaligned __attribute__((aligned(1)));
 // contiguous direction of the grid, so the seven LINES read are world rows: the view's columns when the agent faces +-x
 // (line t = vx, byte = vy), its rows when it faces +-y (line t = vy, byte = vx); bytes reversed when the view index runs
 // against world x (east, south).  Cells outside the grid read a neighbour env's cells or a guard band and are replaced by walls.
-MG_HD void obs7_codes(const Agent& a, const uint8_t* mygrid, int W, int H, bool see_through, uint8_t* codes) {
+MG_HD void obs7_view(const Agent& a, const uint8_t* mygrid, int W, int H, bool see_through, View7& O) {
   const uint32_t d = a.dir;
   const int ax = (int)a.x, ay = (int)a.y;
   const bool horiz = (d & 1u) == 0u, rev = d < 2u;
@@ -142,15 +142,21 @@ MG_HD void obs7_codes(const Agent& a, const uint8_t* mygrid, int W, int H, bool 
   const uint32_t bm_lo = expand4(mm), bm_hi = expand4(mm >> 4) & 0x00FFFFFFu;
   const uint32_t sel_lo = rev ? 0x03040506u : 0x03020100u, sel_hi = rev ? 0x0C000102u : 0x0C060504u;
   const uint32_t WALL4 = CELL_WALL_GREY * 0x01010101u;
-  const uint8_t* lp = mygrid + row_base * W + x0;
-  const int lstep = sy * W;
+  // A line is read as the three ALIGNED dwords that hold its seven bytes and shifted into place: one unaligned 8-byte LDS access
+  // takes ~70 cycles of the CU's LDS pipe on gfx950 (the lanes are served one by one; measured, profiles/r3/lds_notes.md), three
+  // aligned dword reads take ~6.  (mygrid is 4-byte aligned: LDS carve-up and GS are multiples of 4.)
+  const int off0 = row_base * W + x0, lstep = sy * W;
   View7 N;                                                     // natural orientation
 #pragma unroll
   for (int t = 0; t < 7; t++) {
-    const uint64_t q = *(const u64_unaligned*)(lp + t * lstep);
+    const int off = off0 + t * lstep;
+    const uint32_t* ap = (const uint32_t*)(mygrid + (off & ~3));
+    const uint32_t sh = (uint32_t)off & 3u;
+    const uint32_t d0 = ap[0], d1 = ap[1], d2 = ap[2];
+    const uint32_t rlo = funnel_bytes(d1, d0, sh), rhi = funnel_bytes(d2, d1, sh);
     const uint32_t on = 0u - ((lm >> t) & 1u);
     const uint32_t ml = bm_lo & on, mh = bm_hi & on;
-    const uint32_t qlo = ((uint32_t)q & ml) | (WALL4 & ~ml), qhi = ((uint32_t)(q >> 32) & mh) | (WALL4 & ~mh);
+    const uint32_t qlo = (rlo & ml) | (WALL4 & ~ml), qhi = (rhi & mh) | (WALL4 & ~mh);
     N.lo[t] = perm_b32(qhi, qlo, sel_lo);
     N.hi[t] = perm_b32(qhi, qlo, sel_hi);
   }
@@ -177,24 +183,54 @@ MG_HD void obs7_codes(const Agent& a, const uint8_t* mygrid, int W, int H, bool 
     }
   }
   // image order: line = vx, byte = vy
-  View7 O;
   view7_transpose(R, O);
+}
+
+// The 49 codes of an env (seven lines of seven bytes, image order) as the 13 dwords D[i] = bytes [4 i, 4 i + 4) of its code string
+// (D[12]: one byte).  Every D[i] takes its bytes from at most two neighbouring line registers: one v_perm_b32 each.
+MG_HD void view7_pack(const View7& O, uint32_t D[13]) {
+  // the code string is lo0 (4 bytes) hi0 (3) lo1 hi1 ... : byte 7 t + j is line t byte j
+#define MG_B(k) ((k) % 7 < 4 ? O.lo[(k) / 7] : O.hi[(k) / 7])                 /* register holding code byte k */
+#define MG_I(k) ((uint32_t)((k) % 7 < 4 ? (k) % 7 : (k) % 7 - 4))             /* its byte index inside that register */
 #pragma unroll
-  for (int t = 0; t < 6; t++) *(u64_unaligned*)(codes + 7 * t) = ((uint64_t)O.hi[t] << 32) | O.lo[t];   // (the 8th byte is the next line's first)
-  *(u32_unaligned*)(codes + 42) = O.lo[6];
-  *(u16_unaligned*)(codes + 46) = (uint16_t)O.hi[6];
-  codes[48] = (uint8_t)(O.hi[6] >> 16);
+  for (int i = 0; i < 12; i++) {
+    const int k = 4 * i;
+    // bytes k .. k+3: the register of byte k is "lo" of the perm, the register of byte k+3 is "hi" (the same one when they coincide)
+    const uint32_t rl = MG_B(k), rh = MG_B(k + 3);
+    uint32_t sel = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const bool in_lo = ((k + b) / 7 == k / 7) && (((k + b) % 7 < 4) == (k % 7 < 4));
+      sel |= (in_lo ? MG_I(k + b) : 4u + MG_I(k + b)) << (8 * b);
+    }
+    D[i] = perm_b32(rh, rl, sel);
+  }
+  D[12] = (O.hi[6] >> 16) & 0xFFu;
+#undef MG_B
+#undef MG_I
+}
+
+// Lane `lane` stages its env's code string at byte 49 * lane of the wave's code stream with ALIGNED dword stores (StreamEmit: the
+// string shifted by the env's byte phase; the last, partial dword completed with the first bytes of the next lane's string, next0).
+MG_HD void obs7_stage(const uint32_t D[13], uint32_t next0, int lane, uint32_t* stream) {
+  StreamEmit em;
+  em.setup(stream, (uint32_t)(lane * VIEW_CELLS), (uint32_t)VIEW_CELLS);
+  em.first(D[0]);
+#pragma unroll
+  for (int i = 1; i < 12; i++) em.put(D[i]);
+  em.put_last(D[12], next0);
 }
 
 // Grid.encode(vis_mask) (core/grid.py:244-268) in OUTPUT space: the 16 bytes [16 c, 16 c + 16) of a contiguous observation stream
 // whose cell g (= env * 49 + k) has its code at codes[g] and its three bytes at 3 g.  16 c = 3 q + ph with ph = c mod 3, so the
 // chunk is bytes ph .. ph + 15 of the 18 bytes of cells q .. q + 5.  `slut` = cell code -> type | colour << 8 | state << 16.
-// (Reads codes[q .. q + 7]: the staging buffer carries 8 bytes of slack.)
+// (Reads the three aligned dwords from codes[q & ~3] on: the staging buffer carries 16 bytes of slack.)
 MG_HD void obs7_chunk(uint32_t c, const uint8_t* codes, const uint32_t* slut, uint32_t out[4]) {
   const uint32_t q = mul24(c * 16u, 0xAAABu) >> 17;            // 16 c / 3 (exact below 2^16; the full-rate 24-bit multiply)
   const uint32_t ph8 = (16u * c - 3u * q) * 8u;
-  const uint64_t w = *(const u64_unaligned*)(codes + q);
-  const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+  const uint32_t* cw = (const uint32_t*)codes + (q >> 2);      // three aligned dwords, shifted: see obs7_view on unaligned LDS accesses
+  const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], qs = q & 3u;
+  const uint32_t wl = funnel_bytes(w1, w0, qs), wh = funnel_bytes(w2, w1, qs);
   const uint32_t t0 = slut[wl & 0xFFu], t1 = slut[(wl >> 8) & 0xFFu], t2 = slut[(wl >> 16) & 0xFFu], t3 = slut[wl >> 24];
   const uint32_t t4 = slut[wh & 0xFFu], t5 = slut[(wh >> 8) & 0xFFu];
   const uint32_t p0 = t0 | (t1 << 24), p1 = (t1 >> 8) | (t2 << 16), p2 = (t2 >> 16) | (t3 << 8), p3 = t4 | (t5 << 24), p4 = t5 >> 8;
@@ -349,7 +385,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
     MG_MARK("codes");
-    if (!(P.exp & 4)) obs7_codes(av, mygrid, W, H, see_through, scodes + lane * VIEW_CELLS);
+    if (!(P.exp & 4)) {
+      View7 O;
+      obs7_view(av, mygrid, W, H, see_through, O);
+      uint32_t D[13];
+      view7_pack(O, D);
+      const uint32_t next0 = lane < 63 ? (uint32_t)__shfl_down((int)D[0], 1) : 0u;
+      obs7_stage(D, next0, lane, (uint32_t*)scodes);
+    }
     MG_MARK("codes_end");
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
@@ -360,7 +403,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const int nvec = nbytes >> 4;
       constexpr int NCH = 64 * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;   // 588 chunks: ten rounds, the last one 12 lanes wide
       if (nvalid == 64) {
-#pragma unroll
+#pragma unroll 2
         for (int it = 0; it < NIT; it++) {
           const int c = lane + 64 * it;
           uint32_t o4[4];
