@@ -208,6 +208,13 @@ typedef struct mg_env mg_env;
  * stream: a hipStream_t to run on (borrowed), or NULL to let the library create its own non-blocking stream. */
 MG_API int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out);
 MG_API int mg_destroy(mg_env* env);                                   /* Env.close() */
+/* Change the OBSERVATION part of a live handle's configuration -- obs_mode, agent_view_size, tile_size, rgb_highlight,
+ * no_death_mask / death_cost, traj_slots; every other field of `cfg` must equal what mg_create was given -- without touching the
+ * environments: grids, agent records, missions, instruction trees, hidden box contents and every env's generator position stay as
+ * they are, only the output buffers are re-made (mg_get_outputs must be called again; their contents start zeroed).  This is what
+ * composing the reference's observation wrappers does to ONE env object (minigrid/wrappers.py:187-214, 217-426, 629-882: they
+ * wrap the same env, mid-episode or not).  Synchronises. */
+MG_API int mg_set_obs_config(mg_env* env, const mg_config* cfg);
 
 /* Env.reset(seed=...) for the selected envs (minigrid_env.py:119-157).
  *   seeds: host array [N] of per-env seeds (env i is seeded exactly like `reset(seed=seeds[i])`), or NULL to

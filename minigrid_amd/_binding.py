@@ -38,7 +38,7 @@ class MiniGridHipError(RuntimeError):
 _lib = None
 
 # every symbol include/minigrid_hip.h declares (tests/test_abi_cpu.py checks the built library exports all of them)
-SYMBOLS = ["mg_create", "mg_destroy", "mg_reset", "mg_step", "mg_rollout", "mg_rollout_block", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
+SYMBOLS = ["mg_create", "mg_destroy", "mg_set_obs_config", "mg_reset", "mg_step", "mg_rollout", "mg_rollout_block", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
            "mg_copy_slot", "mg_copy_sentence", "mg_selftest_stream",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
@@ -69,6 +69,7 @@ def load():
     vp, i, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.mg_create.argtypes = [C.POINTER(MgConfig), i, vp, C.POINTER(vp)]
     L.mg_destroy.argtypes = [vp]
+    L.mg_set_obs_config.argtypes = [vp, C.POINTER(MgConfig)]
     L.mg_reset.argtypes = [vp, vp, vp]
     L.mg_step.argtypes = [vp, vp, i, i]
     L.mg_rollout.argtypes = [vp, i, u64, i]

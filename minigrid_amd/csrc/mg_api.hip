@@ -104,6 +104,7 @@ struct mg_env {
   unsigned long long* counters = nullptr;
   size_t ncounters = 0;
   uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
+  uint64_t stat_base[3] = { 0, 0, 0 };   // episodes / maps / retries counted before the last mg_set_obs_config (its statistics slots are re-made)
   uint32_t launches = 0;      // k_step launches so far
   uint32_t t = 0;             // rollout step counter (Philox action counter)
   // every device buffer of the handle: freed in mg_destroy; with MG_GUARD=1 each one sits between two pattern-filled red zones
@@ -505,6 +506,143 @@ static int setup_render(mg_env* e) {
   return MG_OK;
 }
 
+// What follows from the OBSERVATION part of the configuration (obs_mode, agent_view_size, tile_size, traj_slots): output sizes,
+// lanes per env, the kernels' LDS carve-ups, trajectory slots, steps per fused launch.  Used by mg_create and mg_set_obs_config;
+// needs the level flags (static_gen / live_gen / sentence) and the ring depth (cb) in place.  Returns an error text or null.
+static const char* configure_obs(mg_env* e) {
+  const int V = e->cfg.agent_view_size;
+  switch (e->cfg.obs_mode) {
+    case MG_OBS_FULL: case MG_OBS_SYMBOLIC: e->obs_bytes = e->cells * 3; break;
+    case MG_OBS_ONEHOT: e->obs_bytes = V * V * 20; break;
+    case MG_OBS_RGB_PARTIAL: e->obs_bytes = V * V * e->cfg.tile_size * e->cfg.tile_size * 3; break;
+    case MG_OBS_RGB: e->obs_bytes = e->cells * e->cfg.tile_size * e->cfg.tile_size * 3; break;
+    default: e->obs_bytes = V * V * 3; break;
+  }
+  const bool rgb = e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL;
+  e->rgb = rgb;
+  e->map_bytes = !rgb ? e->obs_bytes : (e->cfg.obs_mode == MG_OBS_RGB ? e->cells : V * V);
+  {
+    // lanes per env: 4 wherever the encode supports it (default 7x7 partial view, FullyObs) -- four times the wavefronts for
+    // the same batch (16 envs each), each a quarter of the LDS: the step loop is latency-bound per wave, not issue-bound
+    const bool fast7 = e->cfg.obs_mode == MG_OBS_PARTIAL && V == 7;
+    const bool fullish = (e->cfg.obs_mode == MG_OBS_FULL || e->cfg.obs_mode == MG_OBS_SYMBOLIC) && e->cells >= 32;
+    // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
+    // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
+    // (the 7x7 view runs k_roll7: one lane per env, more wavefronts through its time split)
+    e->fast7 = fast7;
+    e->lpe = fullish ? 4 : 1;
+    if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
+    e->epw = 64 / e->lpe;
+  }
+  e->nwaves = (e->N + e->epw - 1) / e->epw;
+  {
+    // LDS carve-up of k_step (bytes), per wavefront of epw envs: decode table | guard | staged grids | guard | visibility
+    // rows | observation byte stream in output order | shadow slots: every env's next spare episode (grid, agent record,
+    // auxiliary word) | the caller's actions for the launch's steps.  The guard bands cover the furthest a view cell can
+    // lie outside an env's own grid (V-1 rows + V-1 cells): such reads are masked, they only have to stay inside the allocation.
+    const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
+    e->off_grid = 1024 + guard;
+    e->off_trow = (e->off_grid + e->epw * e->GS + guard + 15) & ~15;
+    const bool generic_view = !(e->cfg.obs_mode == MG_OBS_PARTIAL && V == 7) && e->cfg.obs_mode != MG_OBS_FULL && e->cfg.obs_mode != MG_OBS_SYMBOLIC;
+    e->off_T = e->off_trow + (generic_view ? e->epw * 32 : 64);   // one u16 per view row and env (generic view encode); staging scratch
+    e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
+    e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
+    e->off_act = e->off_spr + e->epw * 16;
+    e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
+  }
+  if (e->fast7) {
+    // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
+    // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
+    e->roll_guard = (6 * e->W + 12 + 15) & ~15;
+    int nw = 4;
+    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw >>= 1;
+    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) nw = v; }
+    e->roll_nw = nw;
+    e->lds_bytes = roll_lds_bytes(e, nw, true);
+  }
+  if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";
+  e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each
+  // trajectory slots S: default 32 (fused launches write every step of the launch to its own slot), fewer when one
+  // slot is large (RGB frames: a single slot)
+  const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
+  int S = e->cfg.traj_slots > 0 ? e->cfg.traj_slots : 32;
+  if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
+  if (S > 4096) return "traj_slots must be <= 4096";
+  if (rgb) S = 1;
+  if (e->cfg.traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
+  e->S = S;
+  // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
+  // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
+  e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS : 2 * e->cb);
+  if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
+  return nullptr;
+}
+
+static const char* validate_obs_cfg(const mg_config* cfg) {
+  if (cfg->agent_view_size < 3 || cfg->agent_view_size > 15 || (cfg->agent_view_size & 1) == 0)
+    return "agent_view_size must be odd and in 3..15 (wrappers.py:650-651 asserts odd, >= 3)";
+  if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_RGB) return "unknown obs_mode";
+  const bool rgb = cfg->obs_mode == MG_OBS_RGB || cfg->obs_mode == MG_OBS_RGB_PARTIAL;
+  if (rgb && (cfg->tile_size < 4 || cfg->tile_size > 16 || cfg->tile_size % 4 != 0)) return "RGB observations: tile_size must be 4, 8, 12 or 16";
+  if (rgb && cfg->agent_view_size != 7) return "RGB observations are built for the default agent_view_size 7";
+  if (cfg->no_death_mask & (1 << T_GOAL)) return "goal cannot be a death cell (wrappers.py:854)";
+  return nullptr;
+}
+
+// The buffers whose size follows from the observation configuration (configure_obs): refill request segments (one per step
+// workgroup), the trajectory ring, the RGB atlas / tile map, the per-workgroup statistics.  alloc_obs / free_obs bracket them so that
+// mg_set_obs_config can swap the observation mode of a live handle without touching its state.
+static int alloc_obs(mg_env* e) {
+  const size_t N = (size_t)e->N;
+  const size_t nseg = (size_t)(e->live_gen ? 1 : QSETS) * e->nwaves;
+  HIP_TRY(e, dalloc(&e->seg, nseg * e->seg_cap));
+  HIP_TRY(e, dalloc(&e->seg_count, nseg));
+  HIP_TRY(e, hipMemsetAsync(e->seg_count, 0, nseg * sizeof(uint32_t), e->stream));
+  {
+    // one trajectory slot = one contiguous record: obs | reward | terminated | truncated | direction | mission | action
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    e->off_reward = up(N * e->obs_bytes + 16);
+    e->off_term = e->off_reward + up(N * 8);
+    e->off_trunc = e->off_term + up(N);
+    e->off_dir = e->off_trunc + up(N);
+    e->off_mission = e->off_dir + up(N);
+    e->off_action = e->off_mission + up(2 * N);
+    e->off_sentence = e->off_action + up(N);                 // sentence levels: the mission as data, two u64 per env
+    e->record_bytes = e->sentence ? up(e->off_sentence + 16 * N) : up(e->off_action + N);
+    e->slot_bytes = e->record_bytes;
+    if (e->slot_bytes >= ((size_t)1 << 32)) return fail(e, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)");
+    HIP_TRY(e, dalloc(&e->out, e->slot_bytes * (size_t)e->S));
+    HIP_TRY(e, hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
+  }
+  if (e->rgb) { int rc = setup_render(e); if (rc) return rc; }
+  e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
+  HIP_TRY(e, dalloc(&e->counters, e->ncounters));
+  HIP_TRY(e, hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
+  const int need = e->lds_bytes;
+  if (need > 64 * 1024) {
+    // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
+    // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
+    static std::mutex lds_mu;
+    static int lds_max[64] = { 0 };
+    std::lock_guard<std::mutex> lk(lds_mu);
+    if (need > lds_max[e->device & 63]) {
+      HIP_TRY(e, step_max_lds_none(need)); HIP_TRY(e, step_max_lds_light(need)); HIP_TRY(e, step_max_lds_roomgrid(need)); HIP_TRY(e, step_max_lds_rooms(need));
+      HIP_TRY(e, roll_max_lds_none(need)); HIP_TRY(e, roll_max_lds_light(need)); HIP_TRY(e, roll_max_lds_roomgrid(need)); HIP_TRY(e, roll_max_lds_rooms(need));
+      lds_max[e->device & 63] = need;
+    }
+  }
+  return MG_OK;
+}
+static void free_obs(mg_env* e) {
+  void** ptrs[] = { (void**)&e->seg, (void**)&e->seg_count, (void**)&e->out, (void**)&e->counters, (void**)&e->tilemap, (void**)&e->atlas };
+  for (void** pp : ptrs) {
+    if (!*pp) continue;
+    for (size_t k = 0; k < e->allocs.size(); k++)
+      if (e->allocs[k].user == *pp) { (void)hipFree(e->allocs[k].base); e->allocs.erase(e->allocs.begin() + (long)k); break; }
+    *pp = nullptr;
+  }
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -555,15 +693,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (cfg->num_envs < 1) return fail(nullptr, MG_ERR_INVALID, "num_envs must be >= 1");
   if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25)
     return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
-  if (cfg->agent_view_size < 3 || cfg->agent_view_size > 15 || (cfg->agent_view_size & 1) == 0)
-    return fail(nullptr, MG_ERR_INVALID, "agent_view_size must be odd and in 3..15 (wrappers.py:650-651 asserts odd, >= 3)");
-  if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_RGB) return fail(nullptr, MG_ERR_INVALID, "unknown obs_mode");
-  const bool rgb = cfg->obs_mode == MG_OBS_RGB || cfg->obs_mode == MG_OBS_RGB_PARTIAL;
-  if (rgb && (cfg->tile_size < 4 || cfg->tile_size > 16 || cfg->tile_size % 4 != 0))
-    return fail(nullptr, MG_ERR_INVALID, "RGB observations: tile_size must be 4, 8, 12 or 16");
-  if (rgb && cfg->agent_view_size != 7)
-    return fail(nullptr, MG_ERR_INVALID, "RGB observations are built for the default agent_view_size 7");
-  if (cfg->no_death_mask & (1 << T_GOAL)) return fail(nullptr, MG_ERR_INVALID, "goal cannot be a death cell (wrappers.py:854)");
+  if (const char* bad = validate_obs_cfg(cfg)) return fail(nullptr, MG_ERR_INVALID, "%s", bad);
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
@@ -668,60 +798,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->N = cfg->num_envs; e->W = cfg->width; e->H = cfg->height; e->cells = e->W * e->H;
   e->CS = (e->cells + 15) & ~15;
   e->GS = e->CS + 4;                                     // odd dword stride: conflict-free same-cell LDS reads
-  const int V = cfg->agent_view_size;
-  switch (cfg->obs_mode) {
-    case MG_OBS_FULL: case MG_OBS_SYMBOLIC: e->obs_bytes = e->cells * 3; break;
-    case MG_OBS_ONEHOT: e->obs_bytes = V * V * 20; break;
-    case MG_OBS_RGB_PARTIAL: e->obs_bytes = V * V * cfg->tile_size * cfg->tile_size * 3; break;
-    case MG_OBS_RGB: e->obs_bytes = e->cells * cfg->tile_size * cfg->tile_size * 3; break;
-    default: e->obs_bytes = V * V * 3; break;
-  }
-  e->rgb = rgb;
-  e->map_bytes = !rgb ? e->obs_bytes : (cfg->obs_mode == MG_OBS_RGB ? e->cells : V * V);
-  {
-    // lanes per env: 4 wherever the encode supports it (default 7x7 partial view, FullyObs) -- four times the wavefronts for
-    // the same batch (16 envs each), each a quarter of the LDS: the step loop is latency-bound per wave, not issue-bound
-    const bool fast7 = cfg->obs_mode == MG_OBS_PARTIAL && V == 7;
-    const bool fullish = (cfg->obs_mode == MG_OBS_FULL || cfg->obs_mode == MG_OBS_SYMBOLIC) && e->cells >= 32;
-    // measured (profiles/r2/sweep_lpe_*.txt): 4 wins for FullyObs; for the 7x7 view 1 wins once the batch fills the chip with
-    // one wave per SIMD (65 536 envs = 1024 waves), below that the extra waves of 4 lanes per env win
-    // (the 7x7 view runs k_roll7: one lane per env, more wavefronts through its time split)
-    e->fast7 = fast7;
-    e->lpe = fullish ? 4 : 1;
-    if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
-    e->epw = 64 / e->lpe;
-  }
-  e->nwaves = (e->N + e->epw - 1) / e->epw;
-  {
-    // LDS carve-up of k_step (bytes), per wavefront of epw envs: decode table | guard | staged grids | guard | visibility
-    // rows | observation byte stream in output order | shadow slots: every env's next spare episode (grid, agent record,
-    // auxiliary word) | the caller's actions for the launch's steps.  The guard bands cover the furthest a view cell can
-    // lie outside an env's own grid (V-1 rows + V-1 cells): such reads are masked, they only have to stay inside the allocation.
-    const int guard = ((V - 1) * e->W + (V - 1) + 15) & ~15;
-    e->off_grid = 1024 + guard;
-    e->off_trow = (e->off_grid + e->epw * e->GS + guard + 15) & ~15;
-    const bool generic_view = !(cfg->obs_mode == MG_OBS_PARTIAL && V == 7) && cfg->obs_mode != MG_OBS_FULL && cfg->obs_mode != MG_OBS_SYMBOLIC;
-    e->off_T = e->off_trow + (generic_view ? e->epw * 32 : 64);   // one u16 per view row and env (generic view encode); staging scratch
-    e->off_shadow = e->off_T + ((e->epw * e->map_bytes + 15) & ~15) + 16;
-    e->off_spr = e->off_shadow + ((e->epw * e->GS + 15) & ~15);
-    e->off_act = e->off_spr + e->epw * 16;
-    e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
-  }
-  if (e->fast7) {
-    // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
-    // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
-    e->roll_guard = (6 * e->W + 12 + 15) & ~15;
-    int nw = 4;
-    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw >>= 1;
-    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) nw = v; }
-    e->roll_nw = nw;
-    e->lds_bytes = roll_lds_bytes(e, nw, true);
-  }
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
-  if (e->lds_bytes > 160 * 1024) { delete e; return fail(nullptr, MG_ERR_INVALID, "grid too large for the LDS staging"); }
   {
     // spare ring depth R (power of two).  Levels that draw nothing keep ONE constant spare; DynamicObstacles draws in
     // place (no ring).  cb = R/4 spares per env and batch; a batch is up to 2 cb steps, its refill runs behind it on the generator
@@ -741,21 +821,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
-    e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each
-    // trajectory slots S: default 32 (fused launches write every step of the launch to its own slot), fewer when one
-    // slot is large (RGB frames: a single slot)
-    const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
-    int S = cfg->traj_slots > 0 ? cfg->traj_slots : 32;
-    if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
-    if (S > 4096) { delete e; return fail(nullptr, MG_ERR_INVALID, "traj_slots must be <= 4096"); }
-    if (rgb) S = 1;
-    if (cfg->traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
-    e->S = S;
-    // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
-    // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
-    e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS : 2 * e->cb);
-    if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   }
+  if (const char* bad = configure_obs(e)) { const std::string msg = bad; delete e; return fail(nullptr, MG_ERR_INVALID, "%s", msg.c_str()); }
   // GoToInstr levels: rule_div selects how the described object follows from the mission id (see k_step)
   if (cfg->env_kind == MG_ENV_GOTO_REDBALL || cfg->env_kind == MG_ENV_GOTO_REDBALLGREY) { e->rule = RULE_GOTO; e->rule_cell = (int)CELL_BALL_RED; e->rule_div = 0; }
   if (cfg->env_kind == MG_ENV_GOTO_REDBLUEBALL) { e->rule = RULE_GOTO; e->rule_div = 1; }
@@ -836,9 +903,6 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(dalloc(&e->head, N));
   TRY_OR_FREE(dalloc(&e->tail, N));
   TRY_OR_FREE(dalloc(&e->claim, N));
-  const size_t nseg = (size_t)(e->live_gen ? 1 : QSETS) * e->nwaves;
-  TRY_OR_FREE(dalloc(&e->seg, nseg * e->seg_cap));
-  TRY_OR_FREE(dalloc(&e->seg_count, nseg));
   if (e->sentence) {
     TRY_OR_FREE(dalloc(&e->instr, N * INSTR_WORDS));
     TRY_OR_FREE(dalloc(&e->spare_instr, R * N * INSTR_WORDS));
@@ -854,24 +918,6 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   TRY_OR_FREE(hipMemsetAsync(e->head, 0, N * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->tail, 0, N * sizeof(uint32_t), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->claim, 0, N * sizeof(uint32_t), e->stream));
-  TRY_OR_FREE(hipMemsetAsync(e->seg_count, 0, nseg * sizeof(uint32_t), e->stream));
-  {
-    // one trajectory slot = one contiguous record: obs | reward | terminated | truncated | direction | mission | action
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    e->off_reward = up(N * e->obs_bytes + 16);
-    e->off_term = e->off_reward + up(N * 8);
-    e->off_trunc = e->off_term + up(N);
-    e->off_dir = e->off_trunc + up(N);
-    e->off_mission = e->off_dir + up(N);
-    e->off_action = e->off_mission + up(2 * N);
-    e->off_sentence = e->off_action + up(N);                 // sentence levels: the mission as data, two u64 per env
-    e->record_bytes = e->sentence ? up(e->off_sentence + 16 * N) : up(e->off_action + N);
-    e->slot_bytes = e->record_bytes;
-    if (e->slot_bytes >= ((size_t)1 << 32)) { mg_destroy(e); return fail(nullptr, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)"); }
-    TRY_OR_FREE(dalloc(&e->out, e->slot_bytes * (size_t)e->S));
-    TRY_OR_FREE(hipMemsetAsync(e->out, 0, e->slot_bytes * (size_t)e->S, e->stream));
-  }
-  if (e->rgb) { int rc = setup_render(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
   {
     void* h = nullptr;
     TRY_OR_FREE(hipHostMalloc(&h, ERR_WORDS * sizeof(uint32_t), hipHostMallocMapped));
@@ -879,27 +925,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     for (int k = 0; k < ERR_WORDS; k++) e->err_host[k] = 0u;
     TRY_OR_FREE(hipHostGetDevicePointer((void**)&e->err, h, 0));
   }
-  e->ncounters = (size_t)STAT_EPISODES + (size_t)e->nwaves + 2 * (size_t)STAT_GEN_SLOTS;
-  TRY_OR_FREE(dalloc(&e->counters, e->ncounters));
-  TRY_OR_FREE(hipMemsetAsync(e->counters, 0, e->ncounters * sizeof(unsigned long long), e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->grid, 0, N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->spare_grid, 0, R * N * e->CS, e->stream));
   TRY_OR_FREE(hipMemsetAsync(e->agent, 0, N * sizeof(uint64_t), e->stream));
-  {
-    const int need = e->lds_bytes;
-    if (need > 64 * 1024) {
-      // the attribute is per function, not per handle: only ever raise it, so that a handle with a smaller LDS need
-      // created later cannot make the launches of an earlier, larger one fail (per device; guarded for concurrent creates)
-      static std::mutex lds_mu;
-      static int lds_max[64] = { 0 };
-      std::lock_guard<std::mutex> lk(lds_mu);
-      if (need > lds_max[device & 63]) {
-        TRY_OR_FREE(step_max_lds_none(need)); TRY_OR_FREE(step_max_lds_light(need)); TRY_OR_FREE(step_max_lds_roomgrid(need)); TRY_OR_FREE(step_max_lds_rooms(need));
-        TRY_OR_FREE(roll_max_lds_none(need)); TRY_OR_FREE(roll_max_lds_light(need)); TRY_OR_FREE(roll_max_lds_roomgrid(need)); TRY_OR_FREE(roll_max_lds_rooms(need));
-        lds_max[device & 63] = need;
-      }
-    }
-  }
+  { int rc = alloc_obs(e); if (rc) { g_create_error = e->last_error; mg_destroy(e); return rc; } }
   if (e->sentence) {
     // 19 KB of buffered draws per generating wave: the direct generator launch (4 waves per workgroup) needs more than 64 KB of LDS
     const int need = (GEN_THREADS / 64) * gen_wave_lds_bytes(e->CS, 4864, true);
@@ -922,6 +951,44 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     (void)hipStreamSynchronize(e->stream);
   }
   *out = e;
+  return MG_OK;
+}
+
+int mg_set_obs_config(mg_env* e, const mg_config* cfg) {
+  if (!e || !cfg) return MG_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  // everything but the observation part must be what the handle was created with
+  mg_config want = e->cfg;
+  want.obs_mode = cfg->obs_mode; want.agent_view_size = cfg->agent_view_size; want.tile_size = cfg->tile_size; want.rgb_highlight = cfg->rgb_highlight;
+  want.no_death_mask = cfg->no_death_mask; want.death_cost = cfg->death_cost; want.traj_slots = cfg->traj_slots;
+  {
+    mg_config given = *cfg;
+    given.null_stream_sync = want.null_stream_sync;              // (decided by the binding at create time)
+    if (memcmp(&given, &want, sizeof(mg_config)) != 0)
+      return fail(e, MG_ERR_INVALID, "set_obs_config: only obs_mode, agent_view_size, tile_size, rgb_highlight, no_death_mask, death_cost and traj_slots may change");
+  }
+  if (const char* bad = validate_obs_cfg(&want)) return fail(e, MG_ERR_INVALID, "%s", bad);
+  // quiesce: every refill request served, both streams idle, device errors surfaced
+  { int rc = flush_refills(e); if (rc) return rc; }
+  { int rc = mg_sync(e); if (rc) return rc; }
+  uint64_t c[4];
+  { int rc = mg_get_counters(e, c); if (rc) return rc; }
+  const mg_config old_cfg = e->cfg;
+  e->stat_base[0] = c[1]; e->stat_base[1] = c[2]; e->stat_base[2] = c[3];
+  free_obs(e);
+  e->cfg = want;
+  const char* bad = configure_obs(e);
+  int rc = bad ? fail(e, MG_ERR_INVALID, "%s", bad) : alloc_obs(e);
+  if (rc != MG_OK) {
+    // back to the configuration that worked (its buffers are re-made; the env state was never touched)
+    const std::string msg = e->last_error;
+    free_obs(e);
+    e->cfg = old_cfg;
+    if (configure_obs(e) || alloc_obs(e) != MG_OK) return fail(e, MG_ERR_HIP, "set_obs_config failed (%s) and the previous configuration could not be restored", msg.c_str());
+    e->last_error = msg;
+    return rc;
+  }
+  HIP_TRY(e, hipStreamSynchronize(e->stream));
   return MG_OK;
 }
 
@@ -1246,6 +1313,7 @@ int mg_get_counters(mg_env* e, uint64_t out[4]) {
   out[0] = e->env_steps; out[1] = out[2] = out[3] = 0;
   for (size_t k = 0; k < groups; k++) out[1] += c[STAT_EPISODES + k];
   for (size_t k = 0; k < STAT_GEN_SLOTS; k++) { out[2] += c[g0 + 2 * k]; out[3] += c[g0 + 2 * k + 1]; }
+  out[1] += e->stat_base[0]; out[2] += e->stat_base[1]; out[3] += e->stat_base[2];
   return MG_OK;
 }
 

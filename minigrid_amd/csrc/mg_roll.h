@@ -390,7 +390,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       obs7_view(av, mygrid, W, H, see_through, O);
       uint32_t D[13];
       view7_pack(O, D);
-      const uint32_t next0 = lane < 63 ? (uint32_t)__shfl_down((int)D[0], 1) : 0u;
+      // (every lane takes part in the shuffle: a lane that is masked off reads back as 0 -- lane 62 would lose env 63's first bytes)
+      const uint32_t next0 = (uint32_t)__shfl_down((int)D[0], 1);
       obs7_stage(D, next0, lane, (uint32_t*)scodes);
     }
     MG_MARK("codes_end");

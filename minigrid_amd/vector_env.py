@@ -125,18 +125,26 @@ class MiniGridVecEnv(_VectorEnvBase):
             except Exception:
                 device = 0
         self.device = int(device)
+        self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
+        self._missions = np.asarray(s.missions)
+        self._seeded = False
+        self._bind_outputs()
+
+    def _bind_outputs(self):
+        """Everything that follows from the observation configuration of the handle: output pointers, shapes, spaces, host staging.
+        Called at construction and again after `_reconfigure` (an observation wrapper applied to this env)."""
+        s = self.spec_row
+        obs_mode, image_only = self.obs_mode, self.image_only
         outs = B.MgOutputs()
         B.check(self._lib.mg_get_outputs(self._h, C.byref(outs)), self._h)
         self._outs = outs
         self.traj_slots, self.max_fused_steps = int(outs.traj_slots), int(outs.max_fused_steps)
-        self.width, self.height, self.max_steps = s.width, s.height, s.max_steps
         v = self.agent_view_size
         self.image_shape = {"partial": (v, v, 3), "full": (s.width, s.height, 3), "onehot": (v, v, 20),
                             "symbolic": (s.width, s.height, 3),
                             # RGBImgPartialObsWrapper / RGBImgObsWrapper spaces (wrappers.py:357-368, 307-323): rows x columns x 3
                             "rgb_partial": (v * self.tile_size, v * self.tile_size, 3),
                             "rgb": (s.height * self.tile_size, s.width * self.tile_size, 3)}[obs_mode]
-        self._missions = np.asarray(s.missions)
         # sentence levels (instruction trees: GoToSeq, Synth*, BossLevel*, OpenTwoDoors, ...): the mission arrives as data
         self.sentence = bool(outs.sentence)
         if self.sentence:
@@ -147,7 +155,6 @@ class MiniGridVecEnv(_VectorEnvBase):
         # vocabulary lacks some BabyAI words ("next", "on", "left", ...): like the reference, wrapping such a level raises ValueError
         self._mission_tokens = (np.asarray([string_to_indices(m) for m in s.missions], np.int64)
                                 if self.dict_mission and not self.sentence else None)
-        self._seeded = False
         # spaces (minigrid_env.py:63, 72-84; FullyObsWrapper wrappers.py:404-417; ImgObsWrapper :211)
         # image spaces as the reference wrappers declare them (wrappers.py:263-267, 404-411, 655-662, 749-758)
         img_high = 10 if obs_mode == "symbolic" else 255
@@ -369,6 +376,43 @@ class MiniGridVecEnv(_VectorEnvBase):
             self.sync()                    # the staged host buffer is reused chunk by chunk
             return
         B.check(rc, self._h)
+
+    def _reconfigure(self, **changes):
+        """Apply an observation wrapper to THIS env, the way the reference's wrappers wrap the same env object (wrappers.py:187-214):
+        the handle's observation configuration changes in place (mg_set_obs_config) -- grids, agent records, instruction trees,
+        hidden box contents and every env's np_random position are untouched, nothing is re-created."""
+        py_only = {"image_only", "dict_mission"}
+        cfg_map = {"obs_mode": ("obs_mode", lambda v: _OBS_MODES[v]), "agent_view_size": ("agent_view_size", int),
+                   "tile_size": ("tile_size", int), "highlight": ("rgb_highlight", lambda v: int(bool(v))),
+                   "death_cost": ("death_cost", float)}
+        cfg = B.MgConfig.from_buffer_copy(self._cfg)
+        for k, v in changes.items():
+            if k in py_only:
+                continue
+            if k == "no_death_types":
+                assert "goal" not in v, "goal cannot be a death cell"          # NoDeath.__init__ (wrappers.py:854)
+                m = 0
+                for t in v:
+                    m |= 1 << OBJECT_TO_IDX[t]
+                cfg.no_death_mask = m
+            elif k in cfg_map:
+                name, conv = cfg_map[k]
+                setattr(cfg, name, conv(v))
+            else:
+                raise TypeError(f"cannot change {k!r} on a live env")
+        if "agent_view_size" in changes:
+            v = int(changes["agent_view_size"])
+            assert v % 2 == 1 and v >= 3                                          # ViewSizeWrapper.__init__ (wrappers.py:650-651)
+            if v > 15:
+                raise ValueError("agent_view_size up to 15 is supported on the accelerated path")
+        B.check(self._lib.mg_set_obs_config(self._h, C.byref(cfg)), self._h)
+        self._cfg = cfg
+        for k, v in changes.items():
+            setattr(self, {"no_death_types": "no_death_types"}.get(k, k), tuple(v) if k == "no_death_types" else v)
+        self.image_only, self.dict_mission = bool(self.image_only), bool(self.dict_mission)
+        self._torch_views = None
+        self._bind_outputs()
+        return self
 
     def close(self, **kwargs):
         if getattr(self, "_h", None):

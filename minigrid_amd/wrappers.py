@@ -4,9 +4,9 @@
   FullyObsWrapper (minigrid/wrappers.py:383-426): obs["image"] = grid.encode() with the agent cell set to
                    (OBJECT_TO_IDX["agent"], COLOR_TO_IDX["red"], agent_dir); other keys unchanged.
 
-The encodes run inside the HIP step kernel (no extra pass): wrapping re-creates the underlying MiniGridVecEnv with
-the matching `obs_mode` / `image_only` option, exactly like composing the reference wrappers changes what
-`step()` returns.
+The encodes run inside the HIP step kernel (no extra pass): wrapping switches the observation configuration of the
+SAME env (obs_mode / view size / ... : `mg_set_obs_config`; `image_only` and the mission vocabulary are host-side),
+exactly like composing the reference wrappers changes what `step()` of the one wrapped env returns.
 """
 from __future__ import annotations
 
@@ -14,27 +14,16 @@ from .vector_env import MiniGridVecEnv
 
 
 def _rebuild(env: MiniGridVecEnv, **changes) -> MiniGridVecEnv:
-    """The reference's wrappers wrap the SAME env object (wrappers.py:187-214): whatever state it is in -- mid-episode,
-    its np_random position -- is what the wrapped env continues from.  Here an observation wrapper is a different
-    encode inside the step kernel, i.e. a handle with another obs_mode; the live state (grids, agent records, step
-    counts, missions) and every env's generator position are carried across, on the same device and stream."""
-    kw = dict(obs_mode=env.obs_mode, autoreset_mode=env.metadata["autoreset_mode"],
-              rng=env.rng_kind, env_index_base=env.env_index_base,
-              max_steps=env.max_steps, output=env.output, image_only=env.image_only,
-              agent_view_size=env.agent_view_size, no_death_types=env.no_death_types, death_cost=env.death_cost,
-              dict_mission=env.dict_mission, tile_size=env.tile_size, highlight=env.highlight,
-              device=env.device, stream=env._stream_arg, spare_ring=env.spare_ring, traj_slots=env.traj_slots_arg)
-    kw.update(changes)
-    if env._seeded and getattr(env, "sentence", False):
-        # their live state includes the instruction tree and the object identities, which get_state / set_state do not carry
-        raise NotImplementedError(f"{env.env_id}: wrap a sentence level before its first reset(); a live episode cannot be carried over")
-    new = MiniGridVecEnv(env.env_id, env.num_envs, **kw)
-    if env._seeded:
-        new.set_rng_state(env.get_rng_state())     # also re-draws the spare episodes from that position
-        new.set_state(*env.get_state())
-        new._seeded = True
-    env.close()
-    return new
+    """The reference's wrappers wrap the SAME env object (wrappers.py:187-214): whatever state it is in -- mid-episode, its np_random
+    position -- is what the wrapped env continues from.  Here an observation wrapper is a different encode inside the step kernel:
+    the handle's observation configuration is switched in place (`mg_set_obs_config`); the live state -- grids, agent records,
+    step counts, missions, the sentence levels' instruction trees, keys hidden in boxes -- and every env's generator position are
+    not touched, nothing is allocated besides the new output buffers, and the returned object IS `env`."""
+    if changes.get("dict_mission") and not getattr(env, "sentence", False):
+        from .mission_vocab import string_to_indices
+        for m in env.spec_row.missions:                 # DictObservationSpaceWrapper raises for words outside its vocabulary
+            string_to_indices(m)
+    return env._reconfigure(**changes)
 
 
 def ImgObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
