@@ -257,6 +257,15 @@ MG_API int mg_sync(mg_env* env);        /* synchronises the handle's streams (st
  *   agent: (N, 8) i32 = {x, y, dir, carry_type, carry_color, step_count, reset_pending, mission_id}      */
 MG_API int mg_get_state(mg_env* env, uint8_t* grid, int32_t* agent);
 MG_API int mg_set_state(mg_env* env, const uint8_t* grid, const int32_t* agent);
+/* Lossless checkpoint of a live handle -- what pickling a reference env carries (tests/test_envs.py:185-196 test_pickle_env): the
+ * grids as the library holds them (hidden box contents included), agent records, level words (tracked positions, obstacle lists),
+ * every env's np_random position, the sentence levels' instruction trees and object identities, the device policy's step counter.
+ * mg_state_size bytes; mg_load_state needs a handle created with the same level / grid / batch size (any observation mode) and
+ * re-draws the spare episodes from the restored stream positions.  Both synchronise. */
+MG_API int mg_state_size(mg_env* env, int64_t* bytes);
+MG_API int mg_save_state(mg_env* env, void* buf, int64_t bytes);
+MG_API int mg_load_state(mg_env* env, const void* buf, int64_t bytes);
+
 /* Per-env generator state (N, 5) u64 = {state_hi, state_lo, inc_hi, inc_lo, (has_uint32 << 32) | uinteger}:
  * numpy's PCG64 state as the reference env would hold it at this point of the episode sequence. */
 MG_API int mg_get_rng(mg_env* env, uint64_t* out);
@@ -292,7 +301,7 @@ MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uin
  * (minigrid_env.py:597-650, core/grid.py:244-328) as line gathers, byte transposes, carry-propagation visibility rows and the
  * output-space encode -- run on the host over states in mg_set_state's exchange format: grid (n, W, H, 3) u8, agent (n, 8) i32;
  * out (n, 7, 7, 3) u8.  mg_selftest_vis_row_carry is its process_vis row; mg_selftest_prims evaluates its VALU primitives
- * (perm / dot4 / bit reverse / bit-to-byte expand / visibility row) on the host or, on_device = 1, on the GPU: out[5][n]. */
+ * (perm / dot4 / bit reverse / bit-to-byte expand / visibility row / SDWA byte index) on the host or, on_device = 1, on the GPU: out[6][n]. */
 MG_API int mg_selftest_obs7(int32_t width, int32_t height, int32_t n, const uint8_t* grid, const int32_t* agent, int32_t see_through,
                             uint8_t* out);
 MG_API int mg_selftest_vis_row_carry(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);

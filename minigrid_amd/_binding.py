@@ -40,7 +40,7 @@ _lib = None
 # every symbol include/minigrid_hip.h declares (tests/test_abi_cpu.py checks the built library exports all of them)
 SYMBOLS = ["mg_create", "mg_destroy", "mg_set_obs_config", "mg_reset", "mg_step", "mg_rollout", "mg_rollout_block", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
            "mg_copy_slot", "mg_copy_sentence", "mg_selftest_stream",
-           "mg_sync", "mg_get_state", "mg_set_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
+           "mg_sync", "mg_get_state", "mg_set_state", "mg_state_size", "mg_save_state", "mg_load_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_device_count", "mg_selftest_vis_row",
            "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles",
            "mg_selftest_obs7", "mg_selftest_vis_row_carry", "mg_selftest_prims"]
@@ -84,6 +84,9 @@ def load():
     L.mg_get_state.argtypes = [vp, vp, vp]
     L.mg_set_state.argtypes = [vp, vp, vp]
     L.mg_get_rng.argtypes = [vp, vp]
+    L.mg_state_size.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.mg_save_state.argtypes = [vp, vp, C.c_int64]
+    L.mg_load_state.argtypes = [vp, vp, C.c_int64]
     L.mg_set_rng.argtypes = [vp, vp]
     L.mg_timer_start.argtypes = [vp]
     L.mg_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]

@@ -818,7 +818,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       R = cfg->spare_ring > 0 ? cfg->spare_ring : (e->sentence ? 16 : gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID ? 64 : 128);
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
-      while (R > 4 && (size_t)R * e->N * e->CS > ((size_t)8 << 30)) R >>= 1;
+      // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
+      // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 8 GB cap
+      const size_t per_slot_env = (size_t)e->CS + 16 + 40 + (e->sentence ? 4 + INSTR_WORDS * 8 : 0);
+      while (R > 4 && (size_t)R * e->N * per_slot_env > ((size_t)8 << 30)) R >>= 1;
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
   }
@@ -1034,6 +1037,7 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
   HIP_TRY(e, hipSetDevice(e->device));
   const int N = e->N;
   const uint8_t* d_mask = nullptr;
+  bool async_fill = false;
   { int rc = await_ring_fill(e); if (rc) return rc; }     // (a ring redraw still running reads e->mask and e->rng)
   if (mask) {
     HIP_TRY(e, hipMemcpyAsync(e->mask, mask, (size_t)N, hipMemcpyHostToDevice, e->stream));
@@ -1056,17 +1060,8 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
     }
     int rc = launch_generate(e, -1, d_mask);
     if (rc) return rc;
-    if (uses_ring(e) && e->R > 1) {
-      // The observation of a seeded reset needs the live episode only.  The R spare episodes behind it (episodes 2, 3, ... of the
-      // same streams: 128 generator launches, tens of milliseconds at 262 144 envs) are drawn on the generator stream while the caller
-      // looks at the observation; the next launch that could take a spare waits for them (await_ring_fill).
-      HIP_TRY(e, hipEventRecord(e->ev_live, e->stream));
-      HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_live, 0));
-      rc = refill_whole_ring(e, d_mask, false, e->gen_stream);
-      if (rc) return rc;
-      HIP_TRY(e, hipEventRecord(e->ev_fill, e->gen_stream));
-      e->fill_pending = true;
-    } else {
+    if (uses_ring(e) && e->R > 1) async_fill = true;       // the R spare episodes behind it: after the observation (below)
+    else {
       rc = refill_whole_ring(e, d_mask, false);
       if (rc) return rc;
     }
@@ -1082,10 +1077,19 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
   StepParams P;
   fill_step_params(e, P, PHASE_OBSERVE);
   P.obs_mask = d_mask;       // a masked reset() leaves the other envs alone, autoreset-pending ones included
-  e->fill_no_wait = e->fill_pending;
-  const int rc = launch_step(e, P);
-  e->fill_no_wait = false;
-  return rc;
+  int rc = launch_step(e, P);
+  if (rc != MG_OK || !async_fill) return rc;
+  // The observation of a seeded reset needs the live episode only.  The R spare episodes behind it (episodes 2, 3, ... of the same
+  // streams: 128 generator launches, tens of milliseconds at 262 144 envs) are drawn on the generator stream AFTER the observation
+  // launch -- so that they do not compete with it -- while the caller looks at the observation; the next launch that could take a
+  // spare waits for them (await_ring_fill).
+  HIP_TRY(e, hipEventRecord(e->ev_live, e->stream));
+  HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_live, 0));
+  rc = refill_whole_ring(e, d_mask, false, e->gen_stream);
+  if (rc) return rc;
+  HIP_TRY(e, hipEventRecord(e->ev_fill, e->gen_stream));
+  e->fill_pending = true;
+  return MG_OK;
 }
 
 int mg_step(mg_env* e, const void* actions, int dtype, int on_device) {
@@ -1257,6 +1261,82 @@ int mg_set_state(mg_env* e, const uint8_t* grid, const int32_t* agent) {
   return MG_OK;
 }
 
+// ---- lossless checkpoint: everything a live handle's future depends on ------------------------------------------------
+// (mg_get_state / mg_set_state exchange the REFERENCE encoding -- Grid.encode() + the agent tuple -- which, like Grid.decode in the
+// reference, cannot carry what a box hides or an instruction tree; this pair carries the library's own state verbatim.)
+struct StateHeader { uint32_t magic, version; int32_t N, CS, W, H, env_kind, sentence; uint32_t t; uint32_t pad; uint64_t env_steps; };
+constexpr uint32_t STATE_MAGIC = 0x5453474Du;   // "MGST"
+static size_t state_bytes(const mg_env* e) {
+  const size_t N = (size_t)e->N;
+  return sizeof(StateHeader) + N * e->CS + N * 8 + N * 8 + 5 * N * 8 + (e->sentence ? N * INSTR_WORDS * 8 + N * 4 : 0);
+}
+int mg_state_size(mg_env* e, int64_t* bytes) {
+  if (!e || !bytes) return MG_ERR_INVALID;
+  *bytes = (int64_t)state_bytes(e);
+  return MG_OK;
+}
+int mg_save_state(mg_env* e, void* buf, int64_t bytes) {
+  if (!e || !buf) return MG_ERR_INVALID;
+  if (bytes != (int64_t)state_bytes(e)) return fail(e, MG_ERR_INVALID, "save_state: buffer of %lld bytes, mg_state_size says %zu", (long long)bytes, state_bytes(e));
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  { int rc = flush_refills(e); if (rc) return rc; }
+  { int rc = mg_sync(e); if (rc) return rc; }
+  uint8_t* p = (uint8_t*)buf;
+  StateHeader h{ STATE_MAGIC, 1u, e->N, e->CS, e->W, e->H, e->cfg.env_kind, e->sentence ? 1 : 0, e->t, 0u, e->env_steps };
+  memcpy(p, &h, sizeof h); p += sizeof h;
+  HIP_TRY(e, hipMemcpy(p, e->grid, N * e->CS, hipMemcpyDeviceToHost)); p += N * e->CS;
+  HIP_TRY(e, hipMemcpy(p, e->agent, N * 8, hipMemcpyDeviceToHost)); p += N * 8;
+  HIP_TRY(e, hipMemcpy(p, e->aux, N * 8, hipMemcpyDeviceToHost)); p += N * 8;
+  // every env's stream position "now" = the state before its next unconsumed spare was drawn (as mg_get_rng), SoA [5][N]
+  const uint64_t* src = e->rng;
+  if (uses_ring(e)) {
+    const int tb = 256, nb = (e->N + tb - 1) / tb;
+    hipLaunchKernelGGL(k_gather_rng, dim3(nb), dim3(tb), 0, e->stream, e->rng_snap, e->head, (uint32_t)(e->R - 1), e->rng_tmp, e->N);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    src = e->rng_tmp;
+  }
+  HIP_TRY(e, hipMemcpy(p, src, 5 * N * 8, hipMemcpyDeviceToHost)); p += 5 * N * 8;
+  if (e->sentence) {
+    HIP_TRY(e, hipMemcpy(p, e->instr, N * INSTR_WORDS * 8, hipMemcpyDeviceToHost)); p += N * INSTR_WORDS * 8;
+    // LevelGen's generator state as it was before the next unconsumed spare (like the stream position)
+    std::vector<uint32_t> head(N), snap((size_t)e->R * N);
+    HIP_TRY(e, hipMemcpy(head.data(), e->head, N * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(snap.data(), e->gsnap, (size_t)e->R * N * 4, hipMemcpyDeviceToHost));
+    uint32_t* g = (uint32_t*)p;
+    for (size_t n = 0; n < N; n++) g[n] = snap[(size_t)(head[n] & (uint32_t)(e->R - 1)) * N + n];
+    p += N * 4;
+  }
+  return MG_OK;
+}
+int mg_load_state(mg_env* e, const void* buf, int64_t bytes) {
+  if (!e || !buf) return MG_ERR_INVALID;
+  if (bytes != (int64_t)state_bytes(e)) return fail(e, MG_ERR_INVALID, "load_state: %lld bytes for a handle whose state is %zu bytes", (long long)bytes, state_bytes(e));
+  const uint8_t* p = (const uint8_t*)buf;
+  StateHeader h;
+  memcpy(&h, p, sizeof h); p += sizeof h;
+  if (h.magic != STATE_MAGIC || h.version != 1u || h.N != e->N || h.CS != e->CS || h.W != e->W || h.H != e->H || h.env_kind != e->cfg.env_kind ||
+      h.sentence != (e->sentence ? 1 : 0))
+    return fail(e, MG_ERR_INVALID, "load_state: the checkpoint was taken from a different configuration (level, grid or batch size)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->N;
+  { int rc = flush_refills(e); if (rc) return rc; }
+  { int rc = mg_sync(e); if (rc) return rc; }
+  HIP_TRY(e, hipMemcpy(e->grid, p, N * e->CS, hipMemcpyHostToDevice)); p += N * e->CS;
+  HIP_TRY(e, hipMemcpy(e->agent, p, N * 8, hipMemcpyHostToDevice)); p += N * 8;
+  HIP_TRY(e, hipMemcpy(e->aux, p, N * 8, hipMemcpyHostToDevice)); p += N * 8;
+  HIP_TRY(e, hipMemcpy(e->rng, p, 5 * N * 8, hipMemcpyHostToDevice)); p += 5 * N * 8;
+  if (e->sentence) {
+    HIP_TRY(e, hipMemcpy(e->instr, p, N * INSTR_WORDS * 8, hipMemcpyHostToDevice)); p += N * INSTR_WORDS * 8;
+    HIP_TRY(e, hipMemcpy(e->gstate, p, N * 4, hipMemcpyHostToDevice)); p += N * 4;
+  }
+  e->t = h.t; e->env_steps = h.env_steps;
+  // the spare episodes are not part of a checkpoint: they are re-drawn from the restored stream positions (as mg_set_rng does)
+  { int rc = refill_whole_ring(e, nullptr, false); if (rc) return rc; }
+  return mg_sync(e);
+}
+
 int mg_get_rng(mg_env* e, uint64_t* out) {
   if (!e || !out) return MG_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -1426,7 +1506,7 @@ int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const
   }
   return MG_OK;
 }
-// out = [perm_b32 | udot4 | brev32 | expand4 | vis_row_carry (m | up << 8)] x n of (a, b, c); on_device: by k_selftest_prims
+// out = [perm_b32 | udot4 | brev32 | expand4 | vis_row_carry (m | up << 8) | MG_BYTE_X4 of the four bytes] x n of (a, b, c); on_device: by k_selftest_prims
 int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device) {
   if (n < 1 || !a || !b || !c || !out) return MG_ERR_INVALID;
   if (!on_device) {
@@ -1435,16 +1515,18 @@ int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uin
       uint32_t m, up;
       vis_row_carry(a[i] & 0x7Fu, b[i] & 0x7Fu, &m, &up);
       out[4 * n + i] = m | (up << 8);
+      const uint32_t two = 2u;
+      out[5 * n + i] = MG_BYTE_X4(a[i], 0, two) ^ (MG_BYTE_X4(a[i], 1, two) << 10) ^ (MG_BYTE_X4(a[i], 2, two) << 20) ^ (MG_BYTE_X4(a[i], 3, two) << 22);
     }
     return MG_OK;
   }
   if (mg_device_count() < 1) return MG_ERR_NO_DEVICE;
   uint32_t* d = nullptr;
   const size_t bytes = (size_t)n * sizeof(uint32_t);
-  if (hipMalloc((void**)&d, 8 * bytes) != hipSuccess) return MG_ERR_HIP;
+  if (hipMalloc((void**)&d, 9 * bytes) != hipSuccess) return MG_ERR_HIP;
   (void)hipMemcpy(d, a, bytes, hipMemcpyHostToDevice); (void)hipMemcpy(d + n, b, bytes, hipMemcpyHostToDevice); (void)hipMemcpy(d + 2 * n, c, bytes, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(k_selftest_prims, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, d, d + n, d + 2 * n, d + 3 * n);
-  const hipError_t rc = hipMemcpy(out, d + 3 * n, 5 * bytes, hipMemcpyDeviceToHost);
+  const hipError_t rc = hipMemcpy(out, d + 3 * n, 6 * bytes, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   return rc == hipSuccess ? MG_OK : MG_ERR_HIP;
 }

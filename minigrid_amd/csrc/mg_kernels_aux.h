@@ -476,6 +476,8 @@ __global__ void k_selftest_prims(int n, const uint32_t* a, const uint32_t* b, co
   uint32_t m, up;
   vis_row_carry(a[i] & 0x7Fu, b[i] & 0x7Fu, &m, &up);
   out[4 * n + i] = m | (up << 8);
+  const uint32_t two = 2u;
+  out[5 * n + i] = MG_BYTE_X4(a[i], 0, two) ^ (MG_BYTE_X4(a[i], 1, two) << 10) ^ (MG_BYTE_X4(a[i], 2, two) << 20) ^ (MG_BYTE_X4(a[i], 3, two) << 22);
 }
 
 }  // namespace mg

@@ -73,6 +73,13 @@ MG_HD uint32_t mul24(uint32_t a, uint32_t b) {          // both < 2^24: the full
   return a * b;
 #endif
 }
+// ((w >> 8 n) & 0xff) << 2 -- the byte offset of entry `byte n of w` in a table of dwords -- as ONE instruction: an SDWA shift that
+// reads its operand through a byte select (the compiler emits an extract and a shift-add).  `two` = a register holding 2.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MG_BYTE_X4(w, n, two) ({ uint32_t _r; asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #n : "=v"(_r) : "v"(two), "v"(w)); _r; })
+#else
+#define MG_BYTE_X4(w, n, two) ((((w) >> (8 * (n))) & 0xFFu) << (two))
+#endif
 // four bits -> four bytes of 0x00 / 0xff (bit i -> byte i)
 MG_HD uint32_t expand4(uint32_t bits) {
   return perm_b32(0u, 0u, 0x0C0C0C0Cu | (mul24(bits & 15u, 0x00204081u) & 0x01010101u));
@@ -226,14 +233,27 @@ MG_HD void obs7_stage(const uint32_t D[13], uint32_t next0, int lane, uint32_t* 
 // chunk is bytes ph .. ph + 15 of the 18 bytes of cells q .. q + 5.  `slut` = cell code -> type | colour << 8 | state << 16.
 // (Reads the three aligned dwords from codes[q & ~3] on: the staging buffer carries 16 bytes of slack.)
 MG_HD void obs7_chunk(uint32_t c, const uint8_t* codes, const uint32_t* slut, uint32_t out[4]) {
-  const uint32_t q = mul24(c * 16u, 0xAAABu) >> 17;            // 16 c / 3 (exact below 2^16; the full-rate 24-bit multiply)
-  const uint32_t ph8 = (16u * c - 3u * q) * 8u;
+  const uint32_t q = mul24(c, 0xAAAB0u) >> 17;                 // 16 c / 3 (exact for 16 c < 2^16; the full-rate 24-bit multiply)
+  const uint32_t ph8 = (16u * c - mul24(q, 3u)) * 8u;
   const uint32_t* cw = (const uint32_t*)codes + (q >> 2);      // three aligned dwords, shifted: see obs7_view on unaligned LDS accesses
   const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], qs = q & 3u;
   const uint32_t wl = funnel_bytes(w1, w0, qs), wh = funnel_bytes(w2, w1, qs);
-  const uint32_t t0 = slut[wl & 0xFFu], t1 = slut[(wl >> 8) & 0xFFu], t2 = slut[(wl >> 16) & 0xFFu], t3 = slut[wl >> 24];
-  const uint32_t t4 = slut[wh & 0xFFu], t5 = slut[(wh >> 8) & 0xFFu];
-  const uint32_t p0 = t0 | (t1 << 24), p1 = (t1 >> 8) | (t2 << 16), p2 = (t2 >> 16) | (t3 << 8), p3 = t4 | (t5 << 24), p4 = t5 >> 8;
+  const uint32_t two = 2u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the table as an LDS byte address (an integer): the SDWA result IS the ds_read address, no pointer arithmetic in between
+  typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+  // (k_roll7 keeps the table at LDS address 0 -- the start of its dynamic LDS, it has no static LDS -- and checks that at launch)
+#define MG_LUT(off) (*(lds_u32*)(uintptr_t)(off))
+#else
+  const uint8_t* lut = (const uint8_t*)slut;
+#define MG_LUT(off) (*(const uint32_t*)(lut + (off)))
+#endif
+  const uint32_t t0 = MG_LUT(MG_BYTE_X4(wl, 0, two)), t1 = MG_LUT(MG_BYTE_X4(wl, 1, two)), t2 = MG_LUT(MG_BYTE_X4(wl, 2, two));
+  const uint32_t t3 = MG_LUT(MG_BYTE_X4(wl, 3, two)), t4 = MG_LUT(MG_BYTE_X4(wh, 0, two)), t5 = MG_LUT(MG_BYTE_X4(wh, 1, two));
+#undef MG_LUT
+  // the 18 bytes of the six triples as dwords p0..p4, one byte permute each
+  const uint32_t p0 = perm_b32(t1, t0, 0x04020100u), p1 = perm_b32(t2, t1, 0x05040201u), p2 = perm_b32(t3, t2, 0x06050402u),
+                 p3 = perm_b32(t5, t4, 0x04020100u), p4 = t5 >> 8;
 #if defined(__HIP_DEVICE_COMPILE__)
   out[0] = __funnelshift_r(p0, p1, ph8); out[1] = __funnelshift_r(p1, p2, ph8);
   out[2] = __funnelshift_r(p2, p3, ph8); out[3] = __funnelshift_r(p3, p4, ph8);
@@ -263,6 +283,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;
+  // obs7_chunk addresses the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
   uint8_t* sgrid = smem + P.off_grid + wave * (64 * GS);             // this wave's private copy of the 64 grids
   uint8_t* scodes = smem + P.off_T + wave * ROLL_CODES_BYTES;
   uint8_t* sshadow = smem + P.off_shadow;

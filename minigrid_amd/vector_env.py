@@ -66,6 +66,9 @@ class MiniGridVecEnv(_VectorEnvBase):
         assert "goal" not in no_death_types, "goal cannot be a death cell"      # NoDeath.__init__ (wrappers.py:854)
         if output not in ("numpy", "torch"):
             raise ValueError("output must be 'numpy' or 'torch'")
+        # what pickling needs to build the same env again (__getstate__)
+        self._ctor = dict(env_id=env_id, num_envs=int(num_envs), autoreset_mode=autoreset_mode, rng=rng, env_index_base=int(env_index_base),
+                          max_steps=max_steps, output=output, spare_ring=int(spare_ring), traj_slots=int(traj_slots))
         s: EnvSpec = _spec(env_id)
         if max_steps is not None:
             if not isinstance(max_steps, int):
@@ -439,6 +442,34 @@ class MiniGridVecEnv(_VectorEnvBase):
         if grid.shape != (self.num_envs, self.width, self.height, 3) or agent.shape != (self.num_envs, 8):
             raise ValueError("bad state shapes")
         B.check(self._lib.mg_set_state(self._h, self._p(grid), self._p(agent)), self._h)
+
+    def save_state(self) -> bytes:
+        """Lossless checkpoint of the live batch (mg_save_state): grids incl. what boxes hide, agent records, level words, every env's
+        np_random position, the sentence levels' instruction trees -- what pickling a reference env carries."""
+        nb = C.c_int64()
+        B.check(self._lib.mg_state_size(self._h, C.byref(nb)), self._h)
+        buf = np.empty(int(nb.value), np.uint8)
+        B.check(self._lib.mg_save_state(self._h, self._p(buf), nb), self._h)
+        return buf.tobytes()
+
+    def load_state(self, blob: bytes):
+        """Continue from a checkpoint taken from an env of the same level, grid and batch size (any observation configuration)."""
+        buf = np.frombuffer(blob, np.uint8).copy()
+        B.check(self._lib.mg_load_state(self._h, self._p(buf), C.c_int64(buf.size)), self._h)
+        self._seeded = True
+
+    def __getstate__(self):
+        # pickling = the constructor arguments as they are now (observation wrappers included) + the checkpoint
+        kw = dict(self._ctor, obs_mode=self.obs_mode, image_only=self.image_only, agent_view_size=self.agent_view_size,
+                  no_death_types=tuple(self.no_death_types), death_cost=self.death_cost, dict_mission=self.dict_mission,
+                  tile_size=self.tile_size, highlight=self.highlight, device=self.device)
+        return {"ctor": kw, "seeded": self._seeded, "state": self.save_state()}
+
+    def __setstate__(self, st):
+        kw = dict(st["ctor"])
+        self.__init__(kw.pop("env_id"), kw.pop("num_envs"), **kw)
+        self.load_state(st["state"])
+        self._seeded = st["seeded"]
 
     def get_rng_state(self):
         r = np.empty((self.num_envs, 5), np.uint64)

@@ -333,7 +333,7 @@ def test_valu_primitives_host_forms():
     b = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
     sel = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 0x0C, 0x0D], size=(n, 4)).astype(np.uint32)
     c = (sel[:, 0] | (sel[:, 1] << 8) | (sel[:, 2] << 16) | (sel[:, 3] << 24)).astype(np.uint32)
-    out = np.zeros((5, n), np.uint32)
+    out = np.zeros((6, n), np.uint32)
     p = lambda x: x.ctypes.data_as(__import__("ctypes").c_void_p)
     assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(out), 0) == 0
     for i in range(0, n, 37):

@@ -253,3 +253,34 @@ def test_wrapping_a_live_env_in_place_keeps_everything(env_id):
             assert (obs["mission"] == orc_f.mission_strings()).all(), (env_id, t)
     assert (env.get_rng_state() == orc_f.get_rng()).all()
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-ObstructedMaze-2Dlhb-v0", "BabyAI-BossLevel-v0",
+                                    "MiniGrid-Dynamic-Obstacles-6x6-v0", "BabyAI-GoToLocalS8N7-v0", "MiniGrid-Empty-8x8-v0"])
+def test_pickling_a_live_env_continues_identically(env_id):
+    """The reference's test_pickle_env (tests/test_envs.py:185-196) for a live batch: a pickled copy -- mid-episode, boxes closed,
+    instructions half done, objects in hand -- steps exactly like the original, through later episodes too (stream positions)."""
+    import pickle
+    import minigrid_amd as mg
+    from conftest import SENTENCE_IDS
+    n = 600
+    env = mg.make_vec(env_id, n)
+    env.reset(seed=11)
+    rng = np.random.default_rng(2)
+    probs = [0.15, 0.15, 0.35, 0.12, 0.05, 0.13, 0.05]
+    nact = 3 if "Dynamic" in env_id else 7
+    draw = lambda: (rng.integers(0, 3, n).astype(np.uint8) if nact == 3 else rng.choice(7, size=n, p=probs).astype(np.uint8))
+    for _ in range(50):
+        env.step(draw())
+    twin = pickle.loads(pickle.dumps(env))
+    assert twin.handle.value != env.handle.value
+    for t in range(150):
+        a = draw()
+        o1, r1, te1, tr1, _ = env.step(a)
+        o2, r2, te2, tr2, _ = twin.step(a)
+        assert (o1["image"] == o2["image"]).all() and r1.tobytes() == r2.tobytes() and (te1 == te2).all() and (tr1 == tr2).all(), (env_id, t)
+        assert (o1["direction"] == o2["direction"]).all() and (np.asarray(o1["mission"]) == np.asarray(o2["mission"])).all(), (env_id, t)
+    assert (env.get_rng_state() == twin.get_rng_state()).all()
+    g1, a1 = env.get_state(); g2, a2 = twin.get_state()
+    assert (g1 == g2).all() and (a1 == a2).all()
+    env.close(); twin.close()

@@ -24,10 +24,10 @@ def test_valu_primitives_device_equals_host():
     mt = np.arange(128 * 128, dtype=np.uint32)
     a[:128 * 128], b[:128 * 128] = mt >> 7, mt & 127
     p = lambda x: x.ctypes.data_as(C.c_void_p)
-    host, dev = np.zeros((5, n), np.uint32), np.zeros((5, n), np.uint32)
+    host, dev = np.zeros((6, n), np.uint32), np.zeros((6, n), np.uint32)
     assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(host), 0) == 0
     assert L.mg_selftest_prims(n, p(a), p(b), p(c), p(dev), 1) == 0
-    for k, name in enumerate(("perm_b32", "udot4", "brev32", "expand4", "vis_row_carry")):
+    for k, name in enumerate(("perm_b32", "udot4", "brev32", "expand4", "vis_row_carry", "byte_x4")):
         assert (host[k] == dev[k]).all(), name
 
 
