@@ -554,9 +554,12 @@ static const char* configure_obs(mg_env* e) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
     e->roll_guard = (6 * e->W + 12 + 15) & ~15;
-    int nw = 4;
-    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw >>= 1;
-    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) nw = v; }
+    // Measured (profiles/r3/sweep_nw_ratio.txt): 4 waves per workgroup while the batch alone cannot fill the SIMDs (Empty-8x8 x
+    // 65 536: 2.85 us per step with 4, 2.93 with 3, 3.01 with 2); 3 once there are thousands of workgroups anyway and the silent
+    // replays are pure overhead (DoorKey-8x8 x 262 144: 11.5 us with 3, 11.6 with 2, 12.1 with 4).
+    int nw = (e->N + 63) / 64 > 1536 ? 3 : 4;
+    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw--;
+    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
     e->lds_bytes = roll_lds_bytes(e, nw, true);
   }
@@ -641,6 +644,29 @@ static void free_obs(mg_env* e) {
       if (e->allocs[k].user == *pp) { (void)hipFree(e->allocs[k].base); e->allocs.erase(e->allocs.begin() + (long)k); break; }
     *pp = nullptr;
   }
+}
+
+// DynamicObstacles draws a finished env's next episode in place right before the next step launch, from a request the step that
+// ended it filed (one segment per step workgroup).  The requests follow from the agent records (RESET_PENDING): this re-files them
+// after the segments were re-made (mg_set_obs_config) or the records replaced (mg_load_state).  host_rec: the N agent records, or
+// null to read them from the device.
+static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
+  const size_t N = (size_t)e->N;
+  std::vector<uint64_t> tmp;
+  if (!host_rec) {
+    tmp.resize(N);
+    HIP_TRY(e, hipMemcpy(tmp.data(), e->agent, N * 8, hipMemcpyDeviceToHost));
+    host_rec = tmp.data();
+  }
+  std::vector<uint32_t> seg((size_t)e->nwaves * e->seg_cap, 0u), cnt((size_t)e->nwaves, 0u);
+  for (size_t n = 0; n < N; n++)
+    if ((host_rec[n] >> 48) & FLAG_RESET_PENDING) {
+      const size_t wg = n / (size_t)e->epw;
+      if (cnt[wg] < (uint32_t)e->seg_cap) seg[wg * e->seg_cap + cnt[wg]++] = (uint32_t)n;
+    }
+  HIP_TRY(e, hipMemcpy(e->seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->seg_count, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice));
+  return MG_OK;
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
@@ -992,6 +1018,7 @@ int mg_set_obs_config(mg_env* e, const mg_config* cfg) {
     return rc;
   }
   HIP_TRY(e, hipStreamSynchronize(e->stream));
+  if (e->live_gen) { int rc2 = rebuild_live_requests(e, nullptr); if (rc2) return rc2; }
   return MG_OK;
 }
 
@@ -1332,6 +1359,11 @@ int mg_load_state(mg_env* e, const void* buf, int64_t bytes) {
     HIP_TRY(e, hipMemcpy(e->gstate, p, N * 4, hipMemcpyHostToDevice)); p += N * 4;
   }
   e->t = h.t; e->env_steps = h.env_steps;
+  if (e->live_gen) {
+    const uint64_t* rec = (const uint64_t*)((const uint8_t*)buf + sizeof(StateHeader) + N * e->CS);
+    int rc = rebuild_live_requests(e, rec);
+    if (rc) return rc;
+  }
   // the spare episodes are not part of a checkpoint: they are re-drawn from the restored stream positions (as mg_set_rng does)
   { int rc = refill_whole_ring(e, nullptr, false); if (rc) return rc; }
   return mg_sync(e);

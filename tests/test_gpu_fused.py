@@ -218,7 +218,7 @@ def test_int32_actions_outside_a_byte_raise_like_the_reference():
 
 
 @pytest.mark.parametrize("env_id", ["MiniGrid-ObstructedMaze-1Dlhb-v0", "BabyAI-KeyInBox-v0", "BabyAI-BossLevel-v0", "BabyAI-OpenDoorLoc-v0",
-                                    "BabyAI-GoToRedBall-v0"])
+                                    "BabyAI-GoToRedBall-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0"])
 def test_wrapping_a_live_env_in_place_keeps_everything(env_id):
     """ADVICE r2 / VERDICT r2 #4: an observation wrapper applied to a LIVE env switches the encode of the same handle
     (mg_set_obs_config): keys hidden in boxes, the sentence levels' instruction trees and object identities, location-resolved door

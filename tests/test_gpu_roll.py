@@ -31,7 +31,7 @@ def test_valu_primitives_device_equals_host():
         assert (host[k] == dev[k]).all(), name
 
 
-@pytest.mark.parametrize("nw", [1, 2, 4])
+@pytest.mark.parametrize("nw", [1, 2, 3, 4])
 @pytest.mark.parametrize("env_id,max_steps,full_T", [("MiniGrid-DoorKey-8x8-v0", 3, 128), ("BabyAI-GoToRedBall-v0", 2, 96),
                                                       ("BabyAI-PutNextS5N2Carrying-v0", 4, 96), ("MiniGrid-MemoryS7-v0", 5, 96),
                                                       ("MiniGrid-LavaCrossingS9N1-v0", 40, 160)])
