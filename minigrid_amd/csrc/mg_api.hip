@@ -299,6 +299,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->sentence ? 65535 : e->cfg.max_steps;   // sentence levels: per-episode limit, applied by k_verify
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
+  P.share = 0;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
   P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
   P.off_T = e->off_T; P.OBE = e->map_bytes;
@@ -349,6 +350,10 @@ static int launch_step(mg_env* e, StepParams& P) {
     // wave w of a workgroup produces steps [split[w], split[w + 1]) after replaying the steps before them silently: the split that
     // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
     int nw = std::min(e->roll_nw, std::max(1, P.T));
+    // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
+    static const bool share_ok = [] { const char* s = getenv("MG_ROLL_SHARE"); return !s || atoi(s) != 0; }();
+    const bool share = P.T == 1 && share_ok && P.phase == PHASE_STEP;
+    P.share = share ? 1 : 0;
     static const double ratio = [] { const char* s = getenv("MG_ROLL_RATIO"); const double v = s ? atof(s) : 0.0; return v > 0.0 && v < 1.0 ? v : 0.12; }();
     double geo = 0.0, pw = 1.0;
     for (int w = 0; w < nw; w++) { geo += pw; pw *= 1.0 - ratio; }
@@ -359,6 +364,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
     const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
     const RollLayout L = roll_layout(e, nw, acts);
+    if (share) nw = ROLL_MAX_WAVES;          // (layout of one private copy, four waves' worth of threads)
     P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
     if (gg == GG_NONE) launch_roll_none(grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(grid, nw, (size_t)L.total, e->stream, P);

@@ -290,8 +290,11 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
-  const bool last_wave = wave == NW - 1;
-  const int j_begin = P.split[wave], j_end = P.split[wave + 1];
+  // share (one-step launches, Env.step): there is nothing to split in time, so wave 0 runs the step up to the staged codes and ALL waves
+  // of the workgroup share the output-space encode behind one barrier (a quarter of the ten rounds each); wave 0 owns the state.
+  const bool share = P.share != 0;
+  const bool last_wave = share ? wave == 0 : wave == NW - 1;
+  const int j_begin = P.split[wave], j_end = (share && wave > 0) ? 0 : P.split[wave + 1];
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
                          (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
   S.shadow_valid = P.use_shadow != 0;
   const int cpe = CS >> 4, nchunks = nvalid * cpe;
-  {
+  if (j_end > 0) {
     // private grids: each wave stages its own copy (the redundant reads hit L2); 16 B per lane, coalesced
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
     for (int c = lane; c < nchunks; c += 64) {
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
-    if (!(P.exp & 2)) {
+    if (!(P.exp & 2) && !share) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;   // 64 * 147 is a multiple of 16
       const int nbytes = nvalid * PARTIAL_OBS_BYTES;
       const int nvec = nbytes >> 4;
@@ -447,6 +450,21 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
+  }
+
+  if (share) {
+    // the one step's observation, encoded by every wave of the workgroup from wave 0's code stream
+    __syncthreads();
+    const uint8_t* codes0 = smem + P.off_T;
+    uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;
+    const int nbytes = nvalid * PARTIAL_OBS_BYTES, nvec = nbytes >> 4;
+    if (!(P.exp & 2))
+      for (int c = tid; c <= nvec; c += nthreads) {
+        uint32_t o4[4];
+        obs7_chunk((uint32_t)c, codes0, slut, o4);
+        if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; ((uint4*)obase)[c] = v; }
+        else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
+      }
   }
 
   // ---- launch end.  Device errors and finished episodes: every wave for the steps it produced; state: the last wave ----
