@@ -299,7 +299,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    env.timer_start()                    # (the warm-up also warms the event pair the timed region uses)
     run(args.warmup, 1)
+    env.timer_stop()
     env.sync()
     barrier()
     env.timer_start()                    # HIP event on the step stream ...

@@ -66,6 +66,7 @@ struct mg_env {
   int off_grid = 0, off_shadow = 0, off_spr = 0, off_act = 0, off_trow = 0, off_T = 0, lds_bytes = 0;
   int lpe = 1, epw = 64;      // lanes per env in k_step (1 or 4), envs per wavefront = 64 / lpe
   bool fast7 = false;         // the default 7x7 partial view: k_roll7 (mg_roll.h) instead of k_step
+  bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
   int roll_guard = 0;
   int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
@@ -267,13 +268,16 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
-struct RollLayout { int off_grid, off_codes, off_shadow, off_spr, off_act, total; };
+struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, off_shadow_gt, off_spr, off_act, total; };
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions) {
   RollLayout L;
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + nw * 64 * e->GS + e->roll_guard + 15) & ~15;
-  L.off_shadow = L.off_codes + nw * ROLL_CODES_BYTES;
-  L.off_spr = L.off_shadow + ((64 * e->GS + 15) & ~15);
+  // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
+  L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
+  L.off_shadow = L.off_codes + nw * L.codes_stride;
+  L.off_shadow_gt = L.off_shadow + ((64 * e->GS + 15) & ~15);
+  L.off_spr = L.off_shadow_gt + (e->fast_full ? L.codes_stride : 0);
   L.off_act = L.off_spr + 64 * 16;
   L.total = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
   return L;
@@ -299,7 +303,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->sentence ? 65535 : e->cfg.max_steps;   // sentence levels: per-episode limit, applied by k_verify
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.share = 0;
+  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
   P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
   P.off_T = e->off_T; P.OBE = e->map_bytes;
@@ -346,13 +350,15 @@ static int launch_step(mg_env* e, StepParams& P) {
                  : (e->cfg.obs_mode == MG_OBS_RGB || e->cfg.obs_mode == MG_OBS_RGB_PARTIAL) ? 4 : 0;
   const int gg = e->rule_group;
   bool launched = false;
-  if (e->fast7) {
+  if (e->fast7 || e->fast_full) {
     // wave w of a workgroup produces steps [split[w], split[w + 1]) after replaying the steps before them silently: the split that
     // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
     int nw = std::min(e->roll_nw, std::max(1, P.T));
     // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
     static const bool share_ok = [] { const char* s = getenv("MG_ROLL_SHARE"); return !s || atoi(s) != 0; }();
-    const bool share = P.T == 1 && share_ok && P.phase == PHASE_STEP;
+    // (only while the batch leaves wave slots free: at 4 096 workgroups the three waiting waves per workgroup cost more than the shared
+    // encode saves -- Empty-8x8 x 65 536: 9.4 us per step against 10.1; DoorKey-8x8 x 262 144: 33.0 against 23.8, profiles/r3/unfused_share.txt)
+    const bool share = P.T == 1 && share_ok && P.phase == PHASE_STEP && e->nwaves <= 2048;
     P.share = share ? 1 : 0;
     static const double ratio = [] { const char* s = getenv("MG_ROLL_RATIO"); const double v = s ? atof(s) : 0.0; return v > 0.0 && v < 1.0 ? v : 0.12; }();
     double geo = 0.0, pw = 1.0;
@@ -366,10 +372,13 @@ static int launch_step(mg_env* e, StepParams& P) {
     const RollLayout L = roll_layout(e, nw, acts);
     if (share) nw = ROLL_MAX_WAVES;          // (layout of one private copy, four waves' worth of threads)
     P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
-    if (gg == GG_NONE) launch_roll_none(grid, nw, (size_t)L.total, e->stream, P);
-    else if (gg == GG_LIGHT) launch_roll_light(grid, nw, (size_t)L.total, e->stream, P);
-    else if (gg == GG_ROOMGRID) launch_roll_roomgrid(grid, nw, (size_t)L.total, e->stream, P);
-    else launch_roll_rooms(grid, nw, (size_t)L.total, e->stream, P);
+    P.codes_stride = L.codes_stride; P.off_shadow_gt = L.off_shadow_gt;
+    P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W;
+    const bool full = e->fast_full;
+    if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
+    else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
+    else if (gg == GG_ROOMGRID) launch_roll_roomgrid(full, grid, nw, (size_t)L.total, e->stream, P);
+    else launch_roll_rooms(full, grid, nw, (size_t)L.total, e->stream, P);
     launched = true;
   }
   // one translation unit per rule group (mg_step_*.hip): (MODE, LPE) picks the instantiation inside it
@@ -556,10 +565,19 @@ static const char* configure_obs(mg_env* e) {
     e->off_act = e->off_spr + e->epw * 16;
     e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
   }
-  if (e->fast7) {
+  e->fast_full = false;
+  if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341 && !getenv("MG_NO_ROLL_FULL")) {
+    // FullyObs through k_roll7<., true>: the row-major grids + their image-order streams, private per wave, and the shadow pair.  Only
+    // while one wave's worth fits comfortably (grids up to 16 x 16); larger grids keep k_step with four lanes per env.
+    e->fast_full = true;
+    e->roll_guard = 16;
+    if (roll_lds_bytes(e, 1, true) > 72 * 1024) e->fast_full = false;
+    else { e->lpe = 1; e->epw = 64; e->nwaves = (e->N + 63) / 64; }
+  }
+  if (e->fast7 || e->fast_full) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
-    e->roll_guard = (6 * e->W + 12 + 15) & ~15;
+    if (e->fast7) e->roll_guard = (6 * e->W + 12 + 15) & ~15;
     // Measured (profiles/r3/sweep_nw_ratio.txt): 4 waves per workgroup while the batch alone cannot fill the SIMDs (Empty-8x8 x
     // 65 536: 2.85 us per step with 4, 2.93 with 3, 3.01 with 2); 3 once there are thousands of workgroups anyway and the silent
     // replays are pure overhead (DoorKey-8x8 x 262 144: 11.5 us with 3, 11.6 with 2, 12.1 with 4).

@@ -18,7 +18,7 @@ namespace mg {
 #define MG_DECL_STEP_TU(NAME)                                                                                              \
   bool launch_step_##NAME(int mode, int lpe, dim3 grid, size_t lds, hipStream_t st, const StepParams& P);      \
   hipError_t step_max_lds_##NAME(int bytes);                                                                               \
-  void launch_roll_##NAME(dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);                             \
+  void launch_roll_##NAME(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);                             \
   hipError_t roll_max_lds_##NAME(int bytes);
 MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_STEP_TU(rooms)
 #undef MG_DECL_STEP_TU

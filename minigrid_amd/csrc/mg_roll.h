@@ -272,8 +272,28 @@ constexpr int ROLL_MAX_WAVES = 4;
 // StepParams: off_grid = first private grid copy, off_T = first code staging, off_shadow / off_spr / off_act as in k_step;
 // split[w] = first step wave w produces (split[NW] = T).
 
-template <int GG>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(GG == GG_NONE ? 4 : 3, 8))) k_roll7(const StepParams P) {
+// FullyObsWrapper.observation (wrappers.py:419-426) in the same kernel (FULL): the observation is the WHOLE grid, image[x][y] =
+// encode(grid[y][x]) with the agent's cell = (10, 0, dir).  There is nothing to gather or to mask, so the per-env work of a step is the
+// dynamics alone, provided the encode finds its input ready: every wave keeps, next to its row-major copy of the 64 grids (what the
+// dynamics index), a second image of them in IMAGE order -- one contiguous code stream, W*H bytes per env, k = x*H + y -- that follows
+// the grids cell by cell (the one dirty cell of a step; a reset copies the shadow spare's image stream).  A step patches the agent's
+// cell into the stream, runs the same output-space encode as the 7x7 view over it (obs7_chunk: lane c = bytes [16 c, 16 c + 16) of the
+// wave's observations) and restores the cell.  Round 2 ran FullyObs with four lanes per env replicating the dynamics (k_step<1,.,4>).
+MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {          // gt[x*H + y] = g[y*W + x]
+  for (int x = 0; x < W; x++)
+    for (int y = 0; y < H; y++) gt[x * H + y] = g[y * W + x];
+}
+// copy the string [B, B + len) of one stream to the same bytes of another: aligned dwords inside, single bytes at the two ends (the
+// dwords at the ends are shared with the neighbouring lanes' strings: no read-modify-write)
+MG_D void stream_copy(uint8_t* dst, const uint8_t* src, int B, int len) {
+  const int a0 = (B + 3) & ~3, a1 = (B + len) & ~3;
+  for (int b = B; b < a0; b++) dst[b] = src[b];
+  for (int b = a0; b < a1; b += 4) *(uint32_t*)(dst + b) = *(const uint32_t*)(src + b);
+  for (int b = a1; b < B + len; b++) dst[b] = src[b];
+}
+
+template <int GG, bool FULL>
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
@@ -286,7 +306,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // obs7_chunk addresses the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
   uint8_t* sgrid = smem + P.off_grid + wave * (64 * GS);             // this wave's private copy of the 64 grids
-  uint8_t* scodes = smem + P.off_T + wave * ROLL_CODES_BYTES;
+  uint8_t* scodes = smem + P.off_T + wave * P.codes_stride;          // the wave's code stream (FULL: its image-order stream of the 64 grids)
+  const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
@@ -341,7 +362,15 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const int j = k >> 6, l = k & 63;
       if (env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
     }
+  if constexpr (FULL) {
+    // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
+    if (P.use_shadow) {
+      __syncthreads();
+      if (wave == 0 && active) image_stream_build(sshadow + lane * GS, smem + P.off_shadow_gt + lane * cells, W, H);
+    }
+  }
   __syncthreads();
+  if constexpr (FULL) { if (j_end > 0 && active) image_stream_build(sgrid + lane * GS, scodes + lane * cells, W, H); MG_LDS_SYNC(); }
 
   a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + lane * GS;
@@ -384,6 +413,15 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_MARK("transition");
     if (!(P.exp & 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
     MG_MARK("after_transition");
+    if constexpr (FULL) if (active) {
+      uint8_t* mygt = scodes + lane * cells;
+      if (S.ev_reset == 1) stream_copy(scodes, smem + P.off_shadow_gt, lane * cells, cells);
+      else if (S.ev_reset == 2) image_stream_build(mygrid, mygt, W, H);
+      if (S.ev_dirty_idx >= 0) {
+        const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
+        mygt[x * H + y] = (uint8_t)S.ev_dirty_code;
+      }
+    }
     bool show_taken = false;
     Agent av = a;
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
@@ -410,7 +448,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
     MG_MARK("codes");
-    if (!(P.exp & 4)) {
+    uint32_t gt_pos = 0, gt_old = 0;
+    if constexpr (FULL) {
+      // the agent's own cell reads (10, 0, dir) in the observation: patched into the stream for the encode, restored after it
+      gt_pos = (uint32_t)(lane * cells) + a.x * (uint32_t)H + a.y;
+      if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (a.dir << 4)); }
+    } else if (!(P.exp & 4)) {
       View7 O;
       obs7_view(av, mygrid, W, H, see_through, O);
       uint32_t D[13];
@@ -424,11 +467,11 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_LDS_SYNC();
     MG_MARK("chunks");
     if (!(P.exp & 2) && !share) {
-      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;   // 64 * 147 is a multiple of 16
-      const int nbytes = nvalid * PARTIAL_OBS_BYTES;
+      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)OBE;   // 64 * OBE is a multiple of 16
+      const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
-      constexpr int NCH = 64 * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;   // 588 chunks: ten rounds, the last one 12 lanes wide
-      if (nvalid == 64) {
+      if (!FULL && nvalid == 64) {
+        constexpr int NCH = 64 * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;   // 588 chunks: ten rounds, the last one 12 lanes wide
 #pragma unroll 2
         for (int it = 0; it < NIT; it++) {
           const int c = lane + 64 * it;
@@ -436,6 +479,15 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), scodes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
           if (it < NIT - 1 || c < NCH) ((uint4*)obase)[c] = v;
+        }
+      } else if (FULL && nvalid == 64) {
+        const int nch = 12 * cells;                                               // 64 * 3 * cells / 16 chunks
+#pragma unroll 2
+        for (int c = lane; c < nch; c += 64) {
+          uint32_t o4[4];
+          obs7_chunk((uint32_t)c, scodes, slut, o4);
+          uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
+          ((uint4*)obase)[c] = v;
         }
       } else {
         // the ragged last workgroup of a batch: whole chunks, then the stream's last bytes one by one
@@ -448,6 +500,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
     }
+    if constexpr (FULL) if (active && !share) scodes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
   }
@@ -456,8 +509,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the one step's observation, encoded by every wave of the workgroup from wave 0's code stream
     __syncthreads();
     const uint8_t* codes0 = smem + P.off_T;
-    uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)PARTIAL_OBS_BYTES;
-    const int nbytes = nvalid * PARTIAL_OBS_BYTES, nvec = nbytes >> 4;
+    uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;
+    const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
     if (!(P.exp & 2))
       for (int c = tid; c <= nvec; c += nthreads) {
         uint32_t o4[4];

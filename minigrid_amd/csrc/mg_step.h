@@ -64,6 +64,7 @@ struct StepParams {
   int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
   long long env_base;
   int exp;                // tuning aid (MG_EXP, never set in normal use): k_roll7 skips parts of a step so that their cost can be timed
+  int codes_stride, off_shadow_gt; uint32_t w_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W)
   int share;              // k_roll7, one-step launches: the workgroup's waves share the output-space encode of wave 0's step
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
 };
@@ -313,6 +314,10 @@ struct EnvRegs {          // what lives in registers across the steps of a launc
   bool shadow_valid;      // the env's next spare episode is staged in its LDS shadow slot
   bool rec_dirty, aux_dirty, wb_all;
   uint32_t errbits;
+  // what the last env_transition did to the env's grid (for kernels that keep a second image of it: k_roll7's FullyObs stream)
+  int ev_dirty_idx;       // the one cell a step changed (row-major index), -1 = none
+  uint32_t ev_dirty_code;
+  uint32_t ev_reset;      // 0 = no reset, 1 = the staged shadow spare was taken, 2 = a spare was fetched from the ring in HBM
 };
 struct LaneCtx {          // the lane's view of its env: loop-invariant
   int e, el, sub;
@@ -356,6 +361,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
   // (RedBlueDoors compares both states); it is written into the LDS grid after them.
   int dirty_idx = -1;              // linear index of the modified cell, -1 = none
   uint32_t dirty_code = 0;
+  S.ev_dirty_idx = -1; S.ev_dirty_code = 0; S.ev_reset = 0;
   if (active) {
     if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
       // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
@@ -371,6 +377,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         }
         a = agent_unpack(P.spare_agent[se]);
         if (goto_rule) { targets = P.spare_aux[se]; cur = targets; aux_dirty = true; }
+        S.ev_reset = 2;
       } else {
         const uint32_t* s = (const uint32_t*)C.myshadow;
         uint32_t* d = (uint32_t*)mygrid;
@@ -378,6 +385,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         a = agent_unpack(C.sspr[0]);
         if (goto_rule) { targets = C.sspr[1]; cur = targets; aux_dirty = true; }
         shadow_valid = false;
+        S.ev_reset = 1;
       }
       a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
       if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
@@ -621,6 +629,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       }
       if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
       if (dirty_idx >= 0) {
+        S.ev_dirty_idx = dirty_idx; S.ev_dirty_code = dirty_code;
         if (lead) mygrid[dirty_idx] = (uint8_t)dirty_code;
         if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
         else wb_all = true;
