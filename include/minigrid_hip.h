@@ -170,7 +170,7 @@ typedef struct mg_config {
   int32_t room_size;          /* RoomGrid levels (core/roomgrid.py:75)                                                  */
   int32_t random_length;      /* Memory (memory.py:70)                                                                  */
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
-  int32_t tile_size;          /* RGB modes: pixels per cell, 4 | 8 | 12 | 16 (wrappers.py:305, 355: default 8); else ignored */
+  int32_t tile_size;          /* RGB modes: pixels per cell, 1..64 (wrappers.py:305, 355: default 8; 4 | 8 | 12 | 16 take the fast blit); else ignored */
   int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
   int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default (128 / 64 / 16)      */
   int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (32, fewer when a slot is large)     */

@@ -95,6 +95,7 @@ struct mg_env {
                                                            // them (only when something is wrong), the host reads them after a stream sync
                                                            // without a device-to-host copy (a 4-byte copy costs ~10 us per mg_sync)
   RenderParams render;        // ... and k_render's launch geometry
+  bool render_generic = false; RenderGenericParams render_g;   // any other tile size: k_render_generic
   int render_lds = 0, render_blocks = 0, render_threads = 256;
   bool rgb = false;
   // trajectory ring: S slots of { obs | reward | terminated | truncated | direction | mission | action }
@@ -303,7 +304,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->sentence ? 65535 : e->cfg.max_steps;   // sentence levels: per-episode limit, applied by k_verify
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0;
+  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0; P.h_magic = 0;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
   P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
   P.off_T = e->off_T; P.OBE = e->map_bytes;
@@ -373,7 +374,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     if (share) nw = ROLL_MAX_WAVES;          // (layout of one private copy, four waves' worth of threads)
     P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
     P.codes_stride = L.codes_stride; P.off_shadow_gt = L.off_shadow_gt;
-    P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W;
+    P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W; P.h_magic = (65536u + (uint32_t)e->H - 1u) / (uint32_t)e->H;
     const bool full = e->fast_full;
     if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
@@ -400,7 +401,11 @@ static int launch_step(mg_env* e, StepParams& P) {
     HIP_TRY(e, hipGetLastError());
   }
   if (e->rgb) {
-    hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
+    if (e->render_generic) {
+      const size_t px = (size_t)e->N * e->render_g.Ht * e->render_g.ts * e->render_g.Wt * e->render_g.ts;
+      hipLaunchKernelGGL(k_render_generic, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, e->stream, e->render_g);
+    } else
+      hipLaunchKernelGGL(k_render, dim3(e->render_blocks), dim3(e->render_threads), (size_t)e->render_lds, e->stream, e->render);
     HIP_TRY(e, hipGetLastError());
   }
   e->launches++;
@@ -467,6 +472,28 @@ static int setup_render(mg_env* e) {
   RenderParams& R = e->render;
   R.N = e->N; R.ts = ts; R.full = full ? 1 : 0;
   R.Wt = full ? e->W : V; R.Ht = full ? e->H : V; R.cells = R.Wt * R.Ht;
+  e->render_generic = !(ts % 4 == 0 && ts >= 4 && ts <= 16);
+  if (e->render_generic) {
+    // any other tile size: the per-pixel kernel, atlas in global memory (the tile bytes need not be whole dwords)
+    const size_t tb = (size_t)ts * ts * 3;
+    std::vector<uint8_t> all((size_t)TILE_KEYS * 10 * tb), dev((size_t)TILE_KEYS * 10 * tb);
+    tiles::render_all(ts, all.data());
+    for (int k = 0; k < TILE_KEYS; k++)
+      for (int ad = 0; ad < 5; ad++)
+        for (int hl = 0; hl < 2; hl++) {
+          const uint8_t* src = all.data() + (((size_t)k * 5 + ad) * 2 + hl) * tb;
+          const size_t di = ad == 0 ? (size_t)k * 2 + hl : (size_t)STATIC_TILES + ((size_t)k * 4 + (ad - 1)) * 2 + hl;
+          memcpy(dev.data() + di * tb, src, tb);
+        }
+    HIP_TRY(e, env_alloc(e, (void**)&e->atlas, dev.size() + 16, "atlas"));
+    HIP_TRY(e, hipMemcpy(e->atlas, dev.data(), dev.size(), hipMemcpyHostToDevice));
+    HIP_TRY(e, env_alloc(e, (void**)&e->tilemap, (size_t)e->N * e->map_bytes + 16, "tilemap"));
+    HIP_TRY(e, hipMemsetAsync(e->tilemap, 0, (size_t)e->N * e->map_bytes + 16, e->stream));
+    RenderGenericParams& G = e->render_g;
+    G.tilemap = e->tilemap; G.agent = e->agent; G.atlas = (const uint8_t*)e->atlas; G.out = e->out;
+    G.N = e->N; G.Wt = R.Wt; G.Ht = R.Ht; G.cells = R.cells; G.ts = ts; G.full = R.full;
+    return MG_OK;
+  }
   R.tdw_row = ts * 3 / 4; R.tile_dw = ts * R.tdw_row;
   R.rowdw = R.Wt * R.tdw_row;
   R.R = R.rowdw % 4 == 0 ? 1 : (R.rowdw % 2 == 0 ? 2 : 4);            // ts % 4 == 0, so R divides ts: a period stays inside one tile row
@@ -610,8 +637,7 @@ static const char* validate_obs_cfg(const mg_config* cfg) {
     return "agent_view_size must be odd and in 3..15 (wrappers.py:650-651 asserts odd, >= 3)";
   if (cfg->obs_mode < MG_OBS_PARTIAL || cfg->obs_mode > MG_OBS_RGB) return "unknown obs_mode";
   const bool rgb = cfg->obs_mode == MG_OBS_RGB || cfg->obs_mode == MG_OBS_RGB_PARTIAL;
-  if (rgb && (cfg->tile_size < 4 || cfg->tile_size > 16 || cfg->tile_size % 4 != 0)) return "RGB observations: tile_size must be 4, 8, 12 or 16";
-  if (rgb && cfg->agent_view_size != 7) return "RGB observations are built for the default agent_view_size 7";
+  if (rgb && (cfg->tile_size < 1 || cfg->tile_size > 64)) return "RGB observations: tile_size must be in 1..64";
   if (cfg->no_death_mask & (1 << T_GOAL)) return "goal cannot be a death cell (wrappers.py:854)";
   return nullptr;
 }

@@ -394,6 +394,33 @@ __global__ void __launch_bounds__(RENDER_MAX_THREADS) k_render(const RenderParam
   }
 }
 
+// The same mosaic for ANY tile size (the reference's wrappers take tile_size as an argument, wrappers.py:299, 346): one thread per
+// pixel, tiles read from the atlas in global memory.  The general fallback -- tile sizes 4 / 8 / 12 / 16 run k_render above.
+struct RenderGenericParams {
+  const uint8_t* tilemap; const uint64_t* agent; const uint8_t* atlas; uint8_t* out;
+  int N, Wt, Ht, cells, ts, full;
+};
+__global__ void k_render_generic(const RenderGenericParams R) {
+  const size_t ppe = (size_t)R.Ht * R.ts * R.Wt * R.ts;                  // pixels per env
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R.N * ppe) return;
+  const size_t env = i / ppe;
+  const uint32_t p = (uint32_t)(i - env * ppe), roww = (uint32_t)(R.Wt * R.ts);
+  const uint32_t py = p / roww, px = p - py * roww, ty = py / (uint32_t)R.ts, tx = px / (uint32_t)R.ts;
+  const int cell = (int)(ty * (uint32_t)R.Wt + tx);
+  int acell = (R.Ht - 1) * R.Wt + (R.Wt >> 1), dir = 3;              // POV: bottom centre, facing up (minigrid_env.py:659-663)
+  if (R.full) {
+    const Agent a = agent_unpack(R.agent[env]);
+    acell = (int)a.y * R.Wt + (int)a.x; dir = (int)a.dir;
+  }
+  const uint32_t tm = R.tilemap[env * (size_t)R.cells + cell];
+  const uint32_t tile = cell == acell ? (uint32_t)STATIC_TILES + (((tm >> 1) * 4u + (uint32_t)dir) * 2u + (tm & 1u)) : tm;
+  const size_t tb = (size_t)R.ts * R.ts * 3;
+  const uint8_t* src = R.atlas + tile * tb + ((size_t)(py - ty * (uint32_t)R.ts) * R.ts + (px - tx * (uint32_t)R.ts)) * 3;
+  uint8_t* dst = R.out + i * 3;
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
 // ======================================================================================================
 // State exchange on the device (mg_get_state / mg_set_state): Grid.encode() layout (N, W, H, 3) <-> the one-byte-per-cell
 // row-major grids, and the (N, 8) i32 agent records <-> the packed u64 records.  One thread per (env, cell) / per env.

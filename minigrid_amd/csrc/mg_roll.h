@@ -283,15 +283,6 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
   for (int x = 0; x < W; x++)
     for (int y = 0; y < H; y++) gt[x * H + y] = g[y * W + x];
 }
-// copy the string [B, B + len) of one stream to the same bytes of another: aligned dwords inside, single bytes at the two ends (the
-// dwords at the ends are shared with the neighbouring lanes' strings: no read-modify-write)
-MG_D void stream_copy(uint8_t* dst, const uint8_t* src, int B, int len) {
-  const int a0 = (B + 3) & ~3, a1 = (B + len) & ~3;
-  for (int b = B; b < a0; b++) dst[b] = src[b];
-  for (int b = a0; b < a1; b += 4) *(uint32_t*)(dst + b) = *(const uint32_t*)(src + b);
-  for (int b = a1; b < B + len; b++) dst[b] = src[b];
-}
-
 template <int GG, bool FULL>
 __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -413,13 +404,31 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_MARK("transition");
     if (!(P.exp & 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
     MG_MARK("after_transition");
-    if constexpr (FULL) if (active) {
-      uint8_t* mygt = scodes + lane * cells;
-      if (S.ev_reset == 1) stream_copy(scodes, smem + P.off_shadow_gt, lane * cells, cells);
-      else if (S.ev_reset == 2) image_stream_build(mygrid, mygt, W, H);
-      if (S.ev_dirty_idx >= 0) {
+    if constexpr (FULL) {
+      // The image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
+      // env at a time, lane k doing cell k (a lane re-imaging its own env cell by cell would make the whole wave walk W*H cells in
+      // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
+      unsigned long long rm = __ballot(active && S.ev_reset != 0u);
+      if (rm) {
+        const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u);
+        MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
+        while (rm) {
+          const int b = __ffsll((long long)rm) - 1;
+          rm &= rm - 1ull;
+          const uint8_t* sgt = smem + P.off_shadow_gt + b * cells;
+          const uint8_t* gb = sgrid + b * GS;
+          uint8_t* gt = scodes + b * cells;
+          if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }
+          else for (int k = lane; k < cells; k += 64) {
+            const uint32_t x = ((uint32_t)k * P.h_magic) >> 16, y = (uint32_t)k - x * (uint32_t)H;      // k = x * H + y
+            gt[k] = gb[y * (uint32_t)W + x];
+          }
+        }
+        MG_LDS_SYNC();
+      }
+      if (active && S.ev_dirty_idx >= 0) {
         const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
-        mygt[x * H + y] = (uint8_t)S.ev_dirty_code;
+        scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
       }
     }
     bool show_taken = false;
@@ -482,7 +491,6 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       } else if (FULL && nvalid == 64) {
         const int nch = 12 * cells;                                               // 64 * 3 * cells / 16 chunks
-#pragma unroll 2
         for (int c = lane; c < nch; c += 64) {
           uint32_t o4[4];
           obs7_chunk((uint32_t)c, scodes, slut, o4);

@@ -64,7 +64,7 @@ struct StepParams {
   int rgb_full, rgb_highlight;   // MODE 4 (tile map for k_render): whole grid + highlight mask instead of the agent's view
   long long env_base;
   int exp;                // tuning aid (MG_EXP, never set in normal use): k_roll7 skips parts of a step so that their cost can be timed
-  int codes_stride, off_shadow_gt; uint32_t w_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W)
+  int codes_stride, off_shadow_gt; uint32_t w_magic, h_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W), ceil(2^16 / H)
   int share;              // k_roll7, one-step launches: the workgroup's waves share the output-space encode of wave 0's step
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
 };

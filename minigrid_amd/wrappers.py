@@ -34,7 +34,7 @@ def ImgObsWrapper(env: MiniGridVecEnv) -> MiniGridVecEnv:
 def RGBImgObsWrapper(env: MiniGridVecEnv, tile_size: int = 8) -> MiniGridVecEnv:
     """Fully observable RGB image as observation (wrappers.py:287-331): get_frame(highlight=env.highlight, tile_size),
     (height*tile_size, width*tile_size, 3) uint8, blitted on the device from the pre-rendered tile atlas."""
-    return _rebuild(env, obs_mode="rgb", agent_view_size=7, tile_size=tile_size)
+    return _rebuild(env, obs_mode="rgb", tile_size=tile_size)
 
 
 def RGBImgPartialObsWrapper(env: MiniGridVecEnv, tile_size: int = 8) -> MiniGridVecEnv:

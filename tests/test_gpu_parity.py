@@ -522,6 +522,32 @@ def test_rgb_vs_oracle_2048_envs(env_id, what, ts):
     env.close()
 
 
+@pytest.mark.parametrize("env_id,what,ts,view", [("MiniGrid-DoorKey-8x8-v0", "partial", 8, 5), ("MiniGrid-DoorKey-8x8-v0", "partial", 12, 9),
+                                                 ("MiniGrid-KeyCorridorS3R3-v0", "full", 8, 9), ("MiniGrid-LavaCrossingS9N1-v0", "full", 4, 3),
+                                                 ("MiniGrid-DoorKey-8x8-v0", "partial", 6, 7), ("MiniGrid-DoorKey-8x8-v0", "full", 10, 7),
+                                                 ("BabyAI-GoToLocalS8N7-v0", "partial", 7, 5), ("MiniGrid-Empty-8x8-v0", "full", 32, 7),
+                                                 ("MiniGrid-FourRooms-v0", "full", 3, 11)])
+def test_rgb_any_view_size_and_tile_size_vs_oracle(env_id, what, ts, view):
+    """the reference composes ViewSizeWrapper with the RGB wrappers and takes any tile_size (wrappers.py:357-381,
+    629-673).  Tile sizes 4 / 8 / 12 / 16 take the LDS-atlas blit with any view size, the others the per-pixel kernel."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 300 if ts >= 16 else 1000
+    env = mg.ViewSizeWrapper(_mk(env_id, n), agent_view_size=view)
+    env = (mg.RGBImgObsWrapper if what == "full" else mg.RGBImgPartialObsWrapper)(env, tile_size=ts)
+    assert env.agent_view_size == view and env.tile_size == ts
+    orc = O.OracleVec(env_id, n, obs="rgb" if what == "full" else "rgb_partial", tile_size=ts, view_size=view)
+    obs, _ = env.reset(seed=2)
+    o_obs, _, _ = orc.reset(seeds=np.arange(2, 2 + n, dtype=np.uint64))
+    assert obs["image"].shape == o_obs.shape and (obs["image"] == o_obs).all()
+    rng = np.random.default_rng(6)
+    for t in range(50):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs = env.step(a)[0]
+        assert (obs["image"] == orc.step(a)[0]).all(), (env_id, what, ts, view, t)
+    env.close()
+
+
 @pytest.mark.parametrize("n", [1, 31, 33, 65, 200])
 def test_rgb_ragged_batch_sizes_and_no_highlight(n):
     from oracle import oracle as O
