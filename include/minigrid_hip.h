@@ -133,7 +133,9 @@ typedef enum mg_obs_mode {
 
 typedef enum mg_autoreset_mode {
   MG_AUTORESET_NEXT_STEP = 0, /* Gymnasium >= 1.0 default: the step after a done resets, ignores its action, reward 0 */
-  MG_AUTORESET_DISABLED = 1   /* never reset implicitly; the caller uses mg_reset with a mask                         */
+  MG_AUTORESET_DISABLED = 1,  /* never reset implicitly; the caller uses mg_reset with a mask                         */
+  MG_AUTORESET_SAME_STEP = 2  /* gymnasium 0.28 / 0.29 vector semantics (the reference pins gymnasium >= 0.28.1): the step that ends an
+                               * episode also resets the env -- obs = the new episode's first, reward / flags = the ended one's */
 } mg_autoreset_mode;
 
 typedef enum mg_rng_mode {

@@ -10,7 +10,7 @@ from . import build as _build
 MG_ABI_VERSION = 2
 MG_OK, MG_ERR_INVALID, MG_ERR_HIP, MG_ERR_BAD_ACTION, MG_ERR_GENERATOR, MG_ERR_NO_DEVICE, MG_ERR_OOB, MG_ERR_TRACKED = 0, -1, -2, -3, -4, -5, -6, -7
 OBS_PARTIAL, OBS_FULL, OBS_ONEHOT, OBS_SYMBOLIC, OBS_RGB_PARTIAL, OBS_RGB = 0, 1, 2, 3, 4, 5
-AUTORESET_NEXT_STEP, AUTORESET_DISABLED = 0, 1
+AUTORESET_NEXT_STEP, AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1, 2
 RNG_PCG64, RNG_PHILOX = 0, 1
 ACT_U8, ACT_I32, ACT_I64 = 0, 1, 2
 

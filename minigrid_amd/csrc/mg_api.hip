@@ -68,6 +68,7 @@ struct mg_env {
   bool fast7 = false;         // the default 7x7 partial view: k_roll7 (mg_roll.h) instead of k_step
   bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
+  int roll_shadows = 1;       // spare episodes per env staged in LDS by a fused k_roll7 launch (2 unless the level draws nothing)
   int roll_guard = 0;
   int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
   bool static_gen = false;
@@ -243,7 +244,9 @@ static int batch_admit(mg_env* e, int phase, int T) {
   // (a seeded reset's own OBSERVE launch takes no spare -- the live episode was drawn in place -- and does not wait: fill_no_wait)
   if (!e->fill_no_wait) { int rc = await_ring_fill(e); if (rc) return rc; }
   const int add_obs = phase == PHASE_OBSERVE ? 1 : 0, add_steps = phase == PHASE_STEP ? T : 0;
-  if (e->batch_open && (e->batch_obs + add_obs) + (e->batch_steps + add_steps + 1) / 2 > e->cb) {
+  // (SAME_STEP autoreset: every step can take a spare, not every other one)
+  const int div = e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP ? 1 : 2;
+  if (e->batch_open && (e->batch_obs + add_obs) + (e->batch_steps + add_steps + div - 1) / div > e->cb) {
     int rc = close_batch(e);
     if (rc) return rc;
   }
@@ -269,17 +272,20 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
-struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, off_shadow_gt, off_spr, off_act, total; };
+struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, total; };
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions) {
   RollLayout L;
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + nw * 64 * e->GS + e->roll_guard + 15) & ~15;
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
+  // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
+  const int K = e->roll_shadows;
+  L.shadow_stride = (64 * e->GS + 15) & ~15;
   L.off_shadow = L.off_codes + nw * L.codes_stride;
-  L.off_shadow_gt = L.off_shadow + ((64 * e->GS + 15) & ~15);
-  L.off_spr = L.off_shadow_gt + (e->fast_full ? L.codes_stride : 0);
-  L.off_act = L.off_spr + 64 * 16;
+  L.off_shadow_gt = L.off_shadow + K * L.shadow_stride;
+  L.off_spr = L.off_shadow_gt + (e->fast_full ? K * L.codes_stride : 0);
+  L.off_act = L.off_spr + K * 64 * 16;
   L.total = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
   return L;
 }
@@ -304,7 +310,8 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.N = e->N; P.W = e->W; P.H = e->H; P.CS = e->CS; P.GS = e->GS; P.cells = e->cells; P.max_steps = e->sentence ? 65535 : e->cfg.max_steps;   // sentence levels: per-episode limit, applied by k_verify
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
-  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0; P.h_magic = 0;
+  P.autoreset_same_step = e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP;
+  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0; P.h_magic = 0; P.shadow_stride = 0; P.spr_stride = 0;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
   P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
   P.off_T = e->off_T; P.OBE = e->map_bytes;
@@ -374,6 +381,8 @@ static int launch_step(mg_env* e, StepParams& P) {
     if (share) nw = ROLL_MAX_WAVES;          // (layout of one private copy, four waves' worth of threads)
     P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
     P.codes_stride = L.codes_stride; P.off_shadow_gt = L.off_shadow_gt;
+    P.shadow_stride = L.shadow_stride; P.spr_stride = 64 * 16;
+    if (P.use_shadow) P.use_shadow = e->roll_shadows;
     P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W; P.h_magic = (65536u + (uint32_t)e->H - 1u) / (uint32_t)e->H;
     const bool full = e->fast_full;
     if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
@@ -592,6 +601,11 @@ static const char* configure_obs(mg_env* e) {
     e->off_act = e->off_spr + e->epw * 16;
     e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
   }
+  // Fused k_roll7 launches stage the next TWO spare episodes of every env in LDS: under a random policy on a level with short episodes
+  // (LavaCrossing: ~17 steps) most envs reset twice within a 32-step launch, and a spare fetched from the ring in HBM inside the
+  // step loop stalls its whole wave for a memory round trip.  (Needs cb >= 2: a batch may take that many spares per env.)
+  e->roll_shadows = (!e->static_gen && !e->live_gen && e->cb >= 2) ? 2 : 1;
+  if (const char* s = getenv("MG_ROLL_SHADOWS")) { int v = atoi(s); if (v == 1) e->roll_shadows = 1; }
   e->fast_full = false;
   if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341 && !getenv("MG_NO_ROLL_FULL")) {
     // FullyObs through k_roll7<., true>: the row-major grids + their image-order streams, private per wave, and the shadow pair.  Only
@@ -627,7 +641,8 @@ static const char* configure_obs(mg_env* e) {
   e->S = S;
   // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
   // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
-  e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS : 2 * e->cb);
+  e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS :
+                                                                        (e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP ? 1 : 2) * e->cb);
   if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   return nullptr;
 }
@@ -771,6 +786,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     return fail(nullptr, MG_ERR_INVALID, "width/height must be in 3..25 (core/grid.py:29-30 asserts >= 3)");
   if (const char* bad = validate_obs_cfg(cfg)) return fail(nullptr, MG_ERR_INVALID, "%s", bad);
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
+  if (cfg->autoreset_mode < MG_AUTORESET_NEXT_STEP || cfg->autoreset_mode > MG_AUTORESET_SAME_STEP) return fail(nullptr, MG_ERR_INVALID, "unknown autoreset_mode");
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && (cfg->env_kind == MG_ENV_DYNOBS || (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)))
+    return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset is not built for DynamicObstacles (its reset draws on the stream its steps consume) and the sentence levels (k_verify ends their episodes after the step kernel)");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;

@@ -284,7 +284,7 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
     for (int y = 0; y < H; y++) gt[x * H + y] = g[y * W + x];
 }
 template <int GG, bool FULL>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(((GG == GG_NONE || GG == GG_ROOMGRID) && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint32_t h_in = S.h;
   uint32_t qn = (P.seg_count && last_wave) ? uni32(P.seg_count[wg]) : 0u;
   const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
-  S.shadow_valid = P.use_shadow != 0;
+  S.shadow_left = (uint32_t)P.use_shadow;
   const int cpe = CS >> 4, nchunks = nvalid * cpe;
   if (j_end > 0) {
     // private grids: each wave stages its own copy (the redundant reads hit L2); 16 B per lane, coalesced
@@ -334,17 +334,19 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   }
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
-  if (P.use_shadow) {
+  // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
+  for (int set = 0; set < P.use_shadow; set++) {
     if (wave == 0 && active) {
-      const size_t se = (size_t)(S.h & P.ring_mask) * N + (size_t)e;
-      sspr[0] = P.spare_agent[se];
-      sspr[1] = goto_rule ? P.spare_aux[se] : 0ull;
+      const size_t se = (size_t)((S.h + (uint32_t)set) & P.ring_mask) * N + (size_t)e;
+      uint64_t* sp = (uint64_t*)((uint8_t*)sspr + set * P.spr_stride);
+      sp[0] = P.spare_agent[se];
+      sp[1] = goto_rule ? P.spare_aux[se] : 0ull;
     }
     for (int c = tid; c < nchunks; c += nthreads) {
       const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
-      const uint32_t slot = P.head ? (P.head[env0 + ce] & P.ring_mask) : 0u;
+      const uint32_t slot = P.head ? ((P.head[env0 + ce] + (uint32_t)set) & P.ring_mask) : 0u;
       const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
-      uint32_t* d2 = (uint32_t*)(sshadow + ce * GS + part * 16);
+      uint32_t* d2 = (uint32_t*)(sshadow + set * P.shadow_stride + ce * GS + part * 16);
       d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
     }
   }
@@ -357,7 +359,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
     if (P.use_shadow) {
       __syncthreads();
-      if (wave == 0 && active) image_stream_build(sshadow + lane * GS, smem + P.off_shadow_gt + lane * cells, W, H);
+      for (int set = wave; set < P.use_shadow; set += NW)
+        if (active) image_stream_build(sshadow + set * P.shadow_stride + lane * GS, smem + P.off_shadow_gt + set * P.codes_stride + lane * cells, W, H);
     }
   }
   __syncthreads();
@@ -410,12 +413,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
       unsigned long long rm = __ballot(active && S.ev_reset != 0u);
       if (rm) {
-        const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u);
+        const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u), from_set1 = __ballot(active && S.ev_reset == 1u && S.ev_shadow == 1u);
         MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
         while (rm) {
           const int b = __ffsll((long long)rm) - 1;
           rm &= rm - 1ull;
-          const uint8_t* sgt = smem + P.off_shadow_gt + b * cells;
+          const uint8_t* sgt = smem + P.off_shadow_gt + (int)((from_set1 >> b) & 1ull) * P.codes_stride + b * cells;
           const uint8_t* gb = sgrid + b * GS;
           uint8_t* gt = scodes + b * cells;
           if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }

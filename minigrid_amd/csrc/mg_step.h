@@ -54,9 +54,10 @@ struct StepParams {
   // ---- tables / bookkeeping ----
   uint32_t* err; unsigned long long* counters;
   // ---- config ----
-  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, phase, static_gen;
+  int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, autoreset_same_step, phase, static_gen;
   int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
-  int use_shadow;         // the next spare of every env is staged in LDS (its shadow slot) at launch start (fused launches)
+  int use_shadow;         // spare episodes of every env staged in LDS (its shadow slots) at launch start: 0 (one-step launches), 1, or 2 (k_roll7)
+  int shadow_stride, spr_stride;   // bytes between the shadow sets of the staged grids / of the staged (agent record, aux word) pairs
   int off_grid, off_shadow, off_spr, off_act, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env
   int view;               // agent view size V (odd, 3..15)
   int no_death_mask; double death_cost;   // NoDeath wrapper (wrappers.py:845-882)
@@ -311,7 +312,8 @@ struct EnvRegs {          // what lives in registers across the steps of a launc
   Agent a;
   uint64_t targets, cur;  // GoTo levels: tracked positions / where the described objects are now (see below)
   uint32_t h;             // spares consumed so far (ring head)
-  bool shadow_valid;      // the env's next spare episode is staged in its LDS shadow slot
+  uint32_t shadow_left;   // staged spare episodes (LDS shadow slots) the env has not taken yet
+  uint32_t ev_shadow;     // which shadow set the last reset took (ev_reset == 1)
   bool rec_dirty, aux_dirty, wb_all;
   uint32_t errbits;
   // what the last env_transition did to the env's grid (for kernels that keep a second image of it: k_roll7's FullyObs stream)
@@ -355,18 +357,17 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
   Agent& a = S.a;
   uint64_t& targets = S.targets; uint64_t& cur = S.cur;
   uint32_t& h = S.h; uint32_t& errbits = S.errbits;
-  bool& shadow_valid = S.shadow_valid; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
+  uint32_t& shadow_left = S.shadow_left; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
   // The one cell an action can change: it can only change under pickup/drop/toggle, which leave the pose alone, so it
   // is always the cell straight ahead.  The level rules below see the grid as it was BEFORE the action plus this patch
   // (RedBlueDoors compares both states); it is written into the LDS grid after them.
   int dirty_idx = -1;              // linear index of the modified cell, -1 = none
   uint32_t dirty_code = 0;
   S.ev_dirty_idx = -1; S.ev_dirty_code = 0; S.ev_reset = 0;
-  if (active) {
-    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
-      // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
-      if (!shadow_valid) {
-        // not staged (single-step launch, or the env's second reset within a fused launch): straight from the ring in HBM into the
+  // ---- MiniGridEnv.reset (minigrid_env.py:119-157): take the next spare episode out of the ring ----
+  auto take_spare = [&]() {
+      if (shadow_left == 0u) {
+        // not staged (single-step launch, or the env took every staged spare of this fused launch already): straight from the ring in HBM into the
         // live LDS grid -- the loads and their wait stay inside this branch
         const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
         const uint4* src = (const uint4*)(P.spare_grid + se * CS);
@@ -379,18 +380,25 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         if (goto_rule) { targets = P.spare_aux[se]; cur = targets; aux_dirty = true; }
         S.ev_reset = 2;
       } else {
-        const uint32_t* s = (const uint32_t*)C.myshadow;
+        // shadow set 0 first, then set 1 (a level that draws nothing has ONE constant spare and takes it again and again)
+        const uint32_t set = P.static_gen ? 0u : (uint32_t)P.use_shadow - shadow_left;
+        const uint32_t* s = (const uint32_t*)(C.myshadow + set * (uint32_t)P.shadow_stride);
+        const uint64_t* sp = (const uint64_t*)((const uint8_t*)C.sspr + set * (uint32_t)P.spr_stride);
         uint32_t* d = (uint32_t*)mygrid;
         for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
-        a = agent_unpack(C.sspr[0]);
-        if (goto_rule) { targets = C.sspr[1]; cur = targets; aux_dirty = true; }
-        shadow_valid = false;
-        S.ev_reset = 1;
+        a = agent_unpack(sp[0]);
+        if (goto_rule) { targets = sp[1]; cur = targets; aux_dirty = true; }
+        if (!P.static_gen) shadow_left--;
+        S.ev_reset = 1; S.ev_shadow = set;
       }
       a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
       if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
       rec_dirty = true; wb_all = true;
       if (!P.static_gen) h++;
+  };
+  if (active) {
+    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
+      take_spare();
     } else if (a.flags & FLAG_FRESH) {
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
       rec_dirty = true;
@@ -634,6 +642,10 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         if (P.T == 1) { if (lead) P.grid[(size_t)e * CS + dirty_idx] = (uint8_t)dirty_code; }
         else wb_all = true;
       }
+      // Gymnasium's SAME_STEP autoreset (the vector semantics of gymnasium 0.28 / 0.29, which the reference pins as its minimum): the step
+      // that ends an episode also resets the env; the observation returned is the new episode's first, reward / terminated / truncated
+      // are the ended episode's
+      if ((term | trunc) && P.autoreset_same_step) { S.ev_dirty_idx = -1; take_spare(); }
     }
   }
 }
@@ -674,7 +686,7 @@ k_step(const StepParams P) {
   const uint64_t rec = active ? P.agent[e] : 0ull;
   EnvRegs S;
   uint64_t& targets = S.targets; uint64_t& cur = S.cur; uint32_t& h = S.h; uint32_t& errbits = S.errbits;
-  bool& shadow_valid = S.shadow_valid; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
+  uint32_t& shadow_left = S.shadow_left; bool& rec_dirty = S.rec_dirty; bool& aux_dirty = S.aux_dirty; bool& wb_all = S.wb_all;
   Agent& a = S.a;
   targets = (goto_rule && active) ? P.aux[e] : 0ull;   // BabyAI GoTo levels: tracked positions
   h = (P.head && active) ? P.head[e] : 0u;
@@ -685,8 +697,8 @@ k_step(const StepParams P) {
   // so the s_waitcnt a (even conditional, even never-taken) load needs at its join point waits for every observation store
   // still in flight -- one HBM round trip per step.  Everything the loop may read is staged in LDS here: the grids, the
   // next spare episode (shadow slot), the caller's actions; the success reward is computed, not looked up.
-  shadow_valid = P.use_shadow != 0;
-  if (shadow_valid && active && lead) {
+  shadow_left = P.use_shadow != 0 ? 1u : 0u;
+  if (shadow_left && active && lead) {
     const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
     sspr[0] = P.spare_agent[se];
     sspr[1] = goto_rule ? P.spare_aux[se] : 0ull;

@@ -29,7 +29,7 @@ except Exception:
     class _VectorEnvBase:  # type: ignore
         pass
 
-_AUTORESET = {"next_step": B.AUTORESET_NEXT_STEP, "disabled": B.AUTORESET_DISABLED}
+_AUTORESET = {"next_step": B.AUTORESET_NEXT_STEP, "disabled": B.AUTORESET_DISABLED, "same_step": B.AUTORESET_SAME_STEP}
 _OBS_MODES = {"partial": B.OBS_PARTIAL, "full": B.OBS_FULL, "onehot": B.OBS_ONEHOT, "symbolic": B.OBS_SYMBOLIC,
               "rgb_partial": B.OBS_RGB_PARTIAL, "rgb": B.OBS_RGB}
 # minigrid/core/constants.py:25-37

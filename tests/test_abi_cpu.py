@@ -197,8 +197,8 @@ def _cfg(**kw):
                                  dict(env_kind=12, width=8, height=8),                   # RedBlueDoors: width = 2 * height
                                  dict(env_kind=9, width=11, height=6, room_size=5),      # Unlock: inconsistent room size
                                  dict(env_kind=19, width=9, height=9, num_dists=3),      # GoToLocal: room_size <= 8
-                                 dict(obs_mode=5, tile_size=6),                          # RGB: tile_size in 4, 8, 12, 16
-                                 dict(obs_mode=4, tile_size=8, agent_view_size=5),       # RGB: default view only
+                                 dict(obs_mode=5, tile_size=0), dict(obs_mode=4, tile_size=65),     # RGB: tile_size in 1..64
+                                 dict(autoreset_mode=3), dict(autoreset_mode=2, env_kind=15),          # SAME_STEP: not for DynamicObstacles
                                  dict(env_kind=23, width=25, height=25, room_size=10, num_crossings=2, num_dists=7),   # MultiRoom: <= 6 rooms
                                  dict(env_kind=23, width=25, height=25, room_size=3, num_crossings=2, num_dists=2),    # maxRoomSize >= 4
                                  dict(env_kind=28, width=13, height=13, room_size=6),    # FindObj: 3*(room_size-1)+1

@@ -59,3 +59,47 @@ def test_time_split_default_rings_caller_actions():
             assert r2.tobytes() == rew.tobytes() and (t2 == term).all() and (u2 == trunc).all() and (act == acts[j]).all()
     assert (a_env.get_rng_state() == b_env.get_rng_state()).all()
     a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("env_id,full,max_steps", [("MiniGrid-DoorKey-8x8-v0", False, 4), ("MiniGrid-LavaCrossingS9N1-v0", True, 30),
+                                                   ("BabyAI-GoToRedBall-v0", False, 6), ("MiniGrid-Fetch-8x8-N3-v0", False, 9),
+                                                   ("MiniGrid-Empty-8x8-v0", False, 5), ("MiniGrid-FourRooms-v0", True, 7)])
+def test_same_step_autoreset_equals_the_oracle(env_id, full, max_steps):
+    """Gymnasium's SAME_STEP autoreset (0.28 / 0.29 vector semantics): the step that ends an episode returns the next
+    episode's first observation with the ended episode's reward and flags.  One launch per step, then fused launches."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 1500
+    env = mg.make_vec(env_id, n, obs_mode="full" if full else "partial", autoreset_mode="same_step", max_steps=max_steps, traj_slots=16)
+    orc = O.OracleVec(env_id, n, full_obs=full, max_steps=max_steps)
+    obs, _ = env.reset(seed=8)
+    assert (obs["image"] == orc.reset(seeds=np.arange(8, 8 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(4)
+    ended = 0
+    for t in range(50):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=2)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (obs["direction"] == od).all()
+        ended += int((term | trunc).sum())
+    assert ended > n
+    assert env.max_fused_steps <= 16
+    for c in range(4):
+        env.rollout(16, action_seed=5, fused=True)
+        for k in reversed(range(16)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act, autoreset=2)
+            assert (img == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, c, k)
+            assert (d == od).all() and (m == om).all()
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all() and (a1[:, 6] == 0).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+
+
+def test_same_step_autoreset_is_refused_where_it_is_not_built():
+    import minigrid_amd as mg
+    for env_id in ("MiniGrid-Dynamic-Obstacles-6x6-v0", "BabyAI-BossLevel-v0"):
+        with pytest.raises(ValueError):
+            mg.make_vec(env_id, 64, autoreset_mode="same_step")
