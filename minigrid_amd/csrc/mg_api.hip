@@ -301,6 +301,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.seg_cap = e->seg_cap;
   P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0;
   P.obs_mask = nullptr;
+  P.instr = e->instr; P.spare_instr = e->spare_instr; P.off_sentence = e->off_sentence;
   P.out = e->out; P.slot_bytes = e->slot_bytes;
   P.obs = e->rgb ? e->tilemap : e->out; P.obs_stride = e->rgb ? 0ull : (unsigned long long)e->slot_bytes;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
@@ -362,6 +363,8 @@ static int launch_step(mg_env* e, StepParams& P) {
     // wave w of a workgroup produces steps [split[w], split[w + 1]) after replaying the steps before them silently: the split that
     // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
     int nw = std::min(e->roll_nw, std::max(1, P.T));
+    const bool in_loop_verify = e->sentence && e->fast7;       // k_roll7<GG_SENTENCE>: one wave per workgroup (the record is shared state)
+    if (in_loop_verify) nw = 1;
     // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
     static const bool share_ok = [] { const char* s = getenv("MG_ROLL_SHARE"); return !s || atoi(s) != 0; }();
     // (only while the batch leaves wave slots free: at 4 096 workgroups the three waiting waves per workgroup cost more than the shared
@@ -385,7 +388,8 @@ static int launch_step(mg_env* e, StepParams& P) {
     if (P.use_shadow) P.use_shadow = e->roll_shadows;
     P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W; P.h_magic = (65536u + (uint32_t)e->H - 1u) / (uint32_t)e->H;
     const bool full = e->fast_full;
-    if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
+    if (in_loop_verify) launch_roll_sentence(full, grid, nw, (size_t)L.total, e->stream, P);
+    else if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_ROOMGRID) launch_roll_roomgrid(full, grid, nw, (size_t)L.total, e->stream, P);
     else launch_roll_rooms(full, grid, nw, (size_t)L.total, e->stream, P);
@@ -398,8 +402,9 @@ static int launch_step(mg_env* e, StepParams& P) {
                                           : launch_step_rooms(mode, e->lpe, grid, lds, e->stream, P);
   if (!launched) return fail(e, MG_ERR_INVALID, "internal: no k_step variant for mode %d / group %d", mode, gg);
   HIP_TRY(e, hipGetLastError());
-  if (e->sentence) {
+  if (e->sentence && !e->fast7) {
     // RoomGridLevel.step's verifier half (per-episode max_steps, the instruction tree, object identity): see k_verify
+    // (the default 7x7 view runs it inside k_roll7<GG_SENTENCE>'s step loop instead)
     VerifyParams V;
     V.grid = e->grid; V.agent = e->agent; V.instr = e->instr; V.spare_instr = e->spare_instr;
     V.head = e->head; V.ring_mask = (uint32_t)(e->R - 1);
@@ -601,11 +606,12 @@ static const char* configure_obs(mg_env* e) {
     e->off_act = e->off_spr + e->epw * 16;
     e->lds_bytes = e->off_act + MAX_FUSED_STEPS * e->epw;   // the actions (at most MAX_FUSED_STEPS steps per launch) only when the caller supplies them
   }
-  // Fused k_roll7 launches stage the next TWO spare episodes of every env in LDS: under a random policy on a level with short episodes
-  // (LavaCrossing: ~17 steps) most envs reset twice within a 32-step launch, and a spare fetched from the ring in HBM inside the
-  // step loop stalls its whole wave for a memory round trip.  (Needs cb >= 2: a batch may take that many spares per env.)
-  e->roll_shadows = (!e->static_gen && !e->live_gen && e->cb >= 2) ? 2 : 1;
-  if (const char* s = getenv("MG_ROLL_SHADOWS")) { int v = atoi(s); if (v == 1) e->roll_shadows = 1; }
+  // Spare episodes per env a fused k_roll7 launch stages in LDS: ONE.  Two were measured (MG_ROLL_SHADOWS=2; profiles/r3/shadows.txt):
+  // a second reset of an env within a launch then finds its spare in LDS instead of fetching it from the ring in HBM inside the step
+  // loop, but the doubled staging costs more than that saves on every level tried (DoorKey-8x8 x 262 144: 12.3 -> 13.8 us per step,
+  // LavaCrossing FullyObs: 13.0 -> 14.0, GoToRedBall: equal).  (Two need cb >= 2: a batch may take that many spares per env.)
+  e->roll_shadows = 1;
+  if (const char* s = getenv("MG_ROLL_SHADOWS")) { if (atoi(s) == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2; }
   e->fast_full = false;
   if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341 && !getenv("MG_NO_ROLL_FULL")) {
     // FullyObs through k_roll7<., true>: the row-major grids + their image-order streams, private per wave, and the shadow pair.  Only
@@ -641,7 +647,8 @@ static const char* configure_obs(mg_env* e) {
   e->S = S;
   // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
   // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
-  e->max_fused = (rgb || e->live_gen || e->sentence) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS :
+  // (the sentence levels fuse only where their verifier runs inside the step loop: the default 7x7 view)
+  e->max_fused = (rgb || e->live_gen || (e->sentence && !e->fast7)) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS :
                                                                         (e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP ? 1 : 2) * e->cb);
   if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   return nullptr;
@@ -696,6 +703,7 @@ static int alloc_obs(mg_env* e) {
     if (need > lds_max[e->device & 63]) {
       HIP_TRY(e, step_max_lds_none(need)); HIP_TRY(e, step_max_lds_light(need)); HIP_TRY(e, step_max_lds_roomgrid(need)); HIP_TRY(e, step_max_lds_rooms(need));
       HIP_TRY(e, roll_max_lds_none(need)); HIP_TRY(e, roll_max_lds_light(need)); HIP_TRY(e, roll_max_lds_roomgrid(need)); HIP_TRY(e, roll_max_lds_rooms(need));
+      HIP_TRY(e, roll_max_lds_sentence(need));
       lds_max[e->device & 63] = need;
     }
   }

@@ -22,6 +22,9 @@ namespace mg {
   hipError_t roll_max_lds_##NAME(int bytes);
 MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_STEP_TU(rooms)
 #undef MG_DECL_STEP_TU
+// (the sentence levels' k_roll7: the verifier inside the step loop; mg_step_sentence.hip)
+void launch_roll_sentence(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
+hipError_t roll_max_lds_sentence(int bytes);
 #endif
 
 #ifndef MG_STEP_TU_ONLY

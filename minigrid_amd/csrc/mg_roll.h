@@ -22,6 +22,7 @@
 // (tests/test_abi_cpu.py compares it with the oracle over rollouts); the primitives' device forms are checked on the GPU.
 #pragma once
 #include "mg_step.h"
+#include "mg_verify.h"
 
 // analysis aid: -DMG_ISA_MARKS puts section comments into the device ISA (profiles/isa_stats.py --marks); never in the product build
 #if defined(MG_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
@@ -434,6 +435,28 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
       }
     }
+    uint64_t sent0 = 0, sent1 = 0;
+    if constexpr (GG == GG_SENTENCE) if (active) {
+      // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): the env's
+      // instruction record stays in global memory -- one lane per env, a few dependent loads per step, no other wave touches it (one
+      // wave per workgroup: the time split would replay it) -- the grid it looks at is the LDS copy.
+      uint64_t* I = P.instr + (size_t)e * INSTR_WORDS;
+      if (a.flags & FLAG_NEW_EPISODE) {
+        // the spare taken in this step brings its instruction record (its ring slot = the head before the take); head itself is
+        // published at launch end, so no refill can have touched the slot
+        const uint64_t* src = P.spare_instr + ((size_t)((S.h - 1u) & P.ring_mask) * N + (size_t)e) * INSTR_WORDS;
+        for (int k = 0; k < INSTR_WORDS; k++) I[k] = src[k];
+        a.flags &= ~FLAG_NEW_EPISODE;
+      } else if (P.phase == PHASE_STEP) {
+        uint32_t max_steps = 0, verr = 0;
+        const uint32_t status = verify_action(I, mygrid, W, H, a, act_in, max_steps, verr);
+        S.errbits |= verr;
+        term = status != R_CONTINUE; trunc = a.step >= max_steps;
+        reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
+        if ((term | trunc) && P.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; S.rec_dirty = true; }
+      }
+      sent0 = I[IW_MISSION]; sent1 = I[IW_MISSION + 1];
+    }
     bool show_taken = false;
     Agent av = a;
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
@@ -456,6 +479,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       ob[o_dir] = (uint8_t)a.dir;
       *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
       ob[o_act] = (uint8_t)act_in;
+      if constexpr (GG == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = sent0; sp[1] = sent1; }
     }
     // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;

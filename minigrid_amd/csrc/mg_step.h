@@ -47,6 +47,7 @@ struct StepParams {
   // ---- inputs ----
   const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t0;   // buffer: [T][N] of act_dtype
   const uint8_t* obs_mask;                        // PHASE_OBSERVE of a masked reset(): only these envs take a new episode
+  uint64_t* instr; const uint64_t* spare_instr; unsigned long long off_sentence;   // sentence levels through k_roll7<GG_SENTENCE>: the verifier runs inside the step loop
   // ---- outputs: slot s of the trajectory ring starts at out + s * slot_bytes; step j of this launch -> slot slot0 - j (mod S) ----
   uint8_t* out; unsigned long long slot_bytes, off_reward, off_term, off_trunc, off_dir, off_mission, off_action;
   uint8_t* obs; unsigned long long obs_stride;    // observation stream of slot s at obs + s * obs_stride (= out / slot_bytes, or the RGB tile map)
@@ -392,7 +393,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         S.ev_reset = 1; S.ev_shadow = set;
       }
       a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
-      if constexpr (GG == GG_NONE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify installs the instruction record
+      if constexpr (GG == GG_NONE || GG == GG_SENTENCE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify / k_roll7<GG_SENTENCE> installs the instruction record
       rec_dirty = true; wb_all = true;
       if (!P.static_gen) h++;
   };

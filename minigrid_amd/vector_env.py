@@ -246,6 +246,14 @@ class MiniGridVecEnv(_VectorEnvBase):
         B.check(rc, self._h)
         return img, rew, u8[0].astype(bool), u8[1].astype(bool), u8[2], u8[3], u8[4]
 
+    def trajectory_missions(self, slot: int):
+        """The mission strings of trajectory slot `slot` (sentence levels: decoded from the slot's mission words; else by mission id)."""
+        if self.sentence:
+            buf = np.empty((self.num_envs, 2), np.uint64)
+            B.check(self._lib.mg_copy_sentence(self._h, int(slot), self._p(buf)), self._h)
+            return self._decode_sentences(buf)
+        return self._missions[self.trajectory(slot, image=False)[5]]
+
     def sync(self):
         B.check(self._lib.mg_sync(self._h), self._h)
 

@@ -103,3 +103,42 @@ def test_same_step_autoreset_is_refused_where_it_is_not_built():
     for env_id in ("MiniGrid-Dynamic-Obstacles-6x6-v0", "BabyAI-BossLevel-v0"):
         with pytest.raises(ValueError):
             mg.make_vec(env_id, 64, autoreset_mode="same_step")
+
+
+@pytest.mark.parametrize("env_id", ["BabyAI-BossLevel-v0", "BabyAI-GoToSeq-v0", "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-MoveTwoAcrossS8N9-v0",
+                                    "BabyAI-SynthLoc-v0", "BabyAI-OpenTwoDoors-v0", "BabyAI-PickupLoc-v0"])
+def test_sentence_levels_fused_with_the_verifier_in_the_step_loop(env_id):
+    """Round 3: the sentence levels' verifier (instruction trees, object identity, per-episode max_steps) runs inside k_roll7's step
+    loop, so these levels fuse like every other one (8 steps per launch with their ring of 16): fused rollouts, then single steps,
+    against the oracle -- observations, rewards, flags, mission sentences, final state and stream positions."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n, T, F = 777, 160, 8
+    env = mg.make_vec(env_id, n, traj_slots=F)
+    assert env.max_fused_steps == F and env.sentence
+    orc = O.OracleVec(env_id, n)
+    obs, _ = env.reset(seed=31)
+    assert (obs["image"] == orc.reset(seeds=np.arange(31, 31 + n, dtype=np.uint64))[0]).all()
+    assert (obs["mission"] == orc.mission_strings()).all()
+    ended = 0
+    for c in range(T // F):
+        env.rollout(F, action_seed=12, fused=True)
+        for k in reversed(range(F)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act)
+            assert (img == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, c, k)
+            assert (d == od).all()
+            if k % 3 == 0:
+                assert (env.trajectory_missions(k) == orc.mission_strings()).all(), (env_id, c, k)
+            ended += int((term | trunc).sum())
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.35, 0.12, 0.05, 0.13, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (obs["mission"] == orc.mission_strings()).all()
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
