@@ -629,6 +629,7 @@ static const char* configure_obs(mg_env* e) {
     // 65 536: 2.85 us per step with 4, 2.93 with 3, 3.01 with 2); 3 once there are thousands of workgroups anyway and the silent
     // replays are pure overhead (DoorKey-8x8 x 262 144: 11.5 us with 3, 11.6 with 2, 12.1 with 4).
     int nw = (e->N + 63) / 64 > 1536 ? 3 : 4;
+    if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
     while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw--;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
@@ -914,10 +915,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // DoorKey-8x8 x 262 144: 19.0 (32), 17.9 (64), 16.8 (128); LavaCrossing FullyObs x 131 072: 18.1 (32), 15.2 (64), 13.5 (128).
     // Default: 128, and 64 for the BabyAI single-room generators (whole-map rejection sampling: their long refill chains do
     // worse with twice the work per refill).  Sized for 288 GB of HBM: 128 spare maps of 64 B are 8 KB per env (2 GB at 262 144
-    // envs); capped at 8 GB of ring.  The sentence levels step once per launch and carry a 320 B instruction record per spare: 16.
+    // envs); capped at 8 GB of ring (the sentence levels carry a 320 B instruction record per spare: the cap halves their ring at large batches).
     int R = 1;
     if (!e->static_gen && !e->live_gen) {
-      R = cfg->spare_ring > 0 ? cfg->spare_ring : (e->sentence ? 16 : gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID ? 64 : 128);
+      // (the sentence levels: 64 since their verifier runs inside the fused step loop -- with 16 a refill of ~0.6 ms, the length of its
+      // longest LevelGen chain, was due every 8 steps and bounded BossLevel at 76 us per step; 64: 38 us, profiles/r3/bosslevel_ring.txt)
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : (gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID || e->sentence) ? 64 : 128;
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
