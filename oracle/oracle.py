@@ -351,7 +351,7 @@ def lib():
         L.oracle_step.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
         for f in (L.oracle_get_state, L.oracle_set_state):
             f.argtypes = [vp, vp, vp]
-        for f in (L.oracle_get_rng, L.oracle_set_rng, L.oracle_get_missions, L.oracle_get_mission_strs):
+        for f in (L.oracle_get_rng, L.oracle_set_rng, L.oracle_get_missions, L.oracle_get_mission_strs, L.oracle_get_stuck):
             f.argtypes = [vp, vp]
         L.oracle_rng_kat.argtypes = [C.c_uint64, vp, vp, C.c_int, vp, C.c_int, C.c_int64]
         L.oracle_shuffle_kat.argtypes = [C.c_uint64, vp, C.c_int]
@@ -477,6 +477,12 @@ class OracleVec:
         agent = np.ascontiguousarray(agent, np.int32)
         assert grid.shape == (self.n, self.W, self.H, 3) and agent.shape == (self.n, 8)
         lib().oracle_set_state(self.h, _p(grid), _p(agent))
+
+    def stuck(self):
+        """Per env: the current episode's generation met RoomGrid.place_agent's endless loop (the reference would hang)."""
+        r = np.zeros(self.n, np.uint8)
+        lib().oracle_get_stuck(self.h, _p(r))
+        return r.astype(bool)
 
     def get_rng(self):
         r = np.zeros((self.n, 5), np.uint64)
