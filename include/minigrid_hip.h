@@ -40,7 +40,12 @@ typedef enum mg_status {
   MG_ERR_HIP = -2,         /* a HIP runtime call failed                                                       */
   MG_ERR_BAD_ACTION = -3,  /* an action outside 0..6 was seen (reference: ValueError, minigrid_env.py:584-585) */
   MG_ERR_GENERATOR = -4,   /* map generation exhausted its retry bound (reference: RecursionError,
-                              minigrid_env.py:342-343; roomgrid_level.py:131-134 retries instead)            */
+                              minigrid_env.py:342-343; roomgrid_level.py:131-134 retries instead), or the episode an env
+                              has just started is one whose drawing met RoomGrid.place_agent's unbounded loop
+                              (roomgrid.py:327-332: every free cell of the agent's room faces an object; the reference
+                              never returns from that reset() -- BabyAI-SynthS5R2-v0, about 0.4 % of the episodes).
+                              Episodes are drawn ahead, so the error is held back until the env takes that episode.
+                              LevelGen's redraw_stuck bit accepts the redrawn map instead (not a reference behaviour) */
   MG_ERR_NO_DEVICE = -5,   /* no usable HIP device                                                            */
   MG_ERR_OOB = -6,         /* front cell outside the grid (reference: AssertionError, core/grid.py:74-78)     */
   MG_ERR_TRACKED = -7      /* multi-room GoTo: more than four described objects were removed from the grid between two drop actions
@@ -110,7 +115,8 @@ typedef enum mg_env_kind {
   MG_ENV_MOVETWOACROSS = 52,              /* other.py:404-428 (1 x 2 rooms, num_dists = objs_per_room)                                   */
   MG_ENV_LEVELGEN = 53,                   /* envs/babyai/core/levelgen.py:24-211 (PickupLoc, GoToSeq, Synth*, MiniBossLevel, BossLevel*):
                                              num_crossings = action kinds (bit 0 goto, 1 pickup, 2 open, 3 putnext) | instr kinds (bit 4
-                                             action, 5 and, 6 seq) | bit 7 locations | bit 8 unblocking | bit 9 implicit_unlock;
+                                             action, 5 and, 6 seq) | bit 7 locations | bit 8 unblocking | bit 9 implicit_unlock | bit 10
+                                             redraw_stuck (see MG_ERR_GENERATOR);
                                              strip2_row = locked_room_prob in percent; num_dists distractors.  50..53 are the "sentence
                                              levels": the mission is an instruction tree (mg_outputs.sentence), max_steps is per episode */
   MG_ENV_PUTNEAR = 32,      /* envs/putnear.py:101-199 (size 5..8, num_dists = numObjs 2..8); mission id (324 of them, hence 16-bit ids) =

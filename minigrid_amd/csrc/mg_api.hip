@@ -173,6 +173,8 @@ static GenArgs gen_args(mg_env* e, int slot) {
   A.N = e->N; A.CS = e->CS; A.stat_gen_off = STAT_EPISODES + e->nwaves;
   A.cap_words = e->sentence ? 4864 : 2048;   // LevelGen: up to 100 tries per description (levelgen.py:113-155); 38 PCG refills (GEN_SBASE_ENTRIES)
   A.live = 0;
+  // LevelGen, num_crossings bit 10: an episode whose drawing met RoomGrid.place_agent's endless loop is redrawn and accepted
+  A.stuck_mode = (e->cfg.env_kind == MG_ENV_LEVELGEN && ((e->cfg.num_crossings >> 10) & 1)) ? 2 : (to_spare ? 0 : 1);
   A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
@@ -435,7 +437,8 @@ static int check_device_errors(mg_env* e) {
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
   if (bits & ERR_OOB) return fail(e, MG_ERR_OOB, "front cell outside the grid (core/grid.py:74-78 assert)");
   if (bits & ERR_TRACKED) return fail(e, MG_ERR_TRACKED, "GoToInstr: more than four stale tracked positions between two drop actions");
-  return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound");
+  return fail(e, MG_ERR_GENERATOR, "map generator exhausted its retry bound, or RoomGrid.place_agent cannot terminate (every free cell of the "
+                                   "agent's room faces an object: the reference spins for ever in roomgrid.py:327-332)");
 }
 
 // Debug aid for the crash hunt (MG_GUARD=1; profiles/crash_hunt.md): every device buffer gets a 4 KB red zone on both sides, filled
@@ -810,8 +813,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (k == MG_ENV_OPENDOORSORDER && (cfg->num_dists < 2 || cfg->num_dists > 4)) return fail(nullptr, MG_ERR_INVALID, "OpenDoorsOrder: 2..4 doors");
     if (k == MG_ENV_MOVETWOACROSS && (nc != 2 || nr != 1 || cfg->num_dists < 2 || cfg->num_dists > 9)) return fail(nullptr, MG_ERR_INVALID, "MoveTwoAcross: 1 x 2 rooms, 2..9 objects per room");
     if (k == MG_ENV_LEVELGEN && (cfg->num_dists < 0 || cfg->num_dists > 24 || (cfg->num_crossings & 15) == 0 || ((cfg->num_crossings >> 4) & 7) == 0 ||
-        (unsigned)cfg->num_crossings > 1023u || cfg->strip2_row < 0 || cfg->strip2_row > 100))
-      return fail(nullptr, MG_ERR_INVALID, "LevelGen: num_crossings = action kinds | instr kinds << 4 | locations << 7 | unblocking << 8 | implicit_unlock << 9, strip2_row = locked_room_prob in percent, at most 24 distractors");
+        (unsigned)cfg->num_crossings > 2047u || cfg->strip2_row < 0 || cfg->strip2_row > 100))
+      return fail(nullptr, MG_ERR_INVALID, "LevelGen: num_crossings = action kinds | instr kinds << 4 | locations << 7 | unblocking << 8 | implicit_unlock << 9 | redraw_stuck << 10, strip2_row = locked_room_prob in percent, at most 24 distractors");
   }
   if (cfg->env_kind >= MG_ENV_PUTNEXTLOCAL && cfg->env_kind <= MG_ENV_OPENDOOR) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;

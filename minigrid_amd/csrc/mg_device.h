@@ -151,6 +151,9 @@ constexpr uint32_t FLAG_NOT_CLEAR = 4u;       // DynamicObstacles: the front cel
 constexpr uint32_t FLAG_TARGETS_STALE = 8u;   // BabyAI GoTo levels: a described object moved since GoToInstr's positions were refreshed
 constexpr uint32_t FLAG_SHOW_TAKEN = 16u;     // PutNext(start_carrying): the episode's first observation shows the carried object where it was taken from
 constexpr uint32_t FLAG_NEW_EPISODE = 32u;    // sentence levels: k_step took a spare episode; k_verify installs its instruction record
+// spare episodes only: drawing this episode met RoomGrid.place_agent's endless loop (mg_gen.h room_stuck) -- the reference would never
+// return from the reset() that reaches it.  Taking the episode out of the ring reports ERR_GENERATOR (take_spare, mg_step.h).
+constexpr uint32_t FLAG_STUCK = 64u;
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };

@@ -30,6 +30,7 @@ struct GenResult {
   uint32_t carry;     // cell code the agent starts with in its hands (PutNext start_carrying), 0 = nothing
   uint32_t retries;   // whole-map regenerations (RejectSampling / RecursionError in the reference)
   bool failed;        // retry bound exhausted
+  uint32_t stuck;     // RoomGrid.place_agent's endless loop was met (room_stuck); set by generate_one to 0 before the first pass
   uint32_t resume;    // set by generate_one: this pass restarts from the generator's last checkpoint (state in the wave's scratch words)
 };
 
@@ -479,9 +480,32 @@ MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 }
 
 // ---- core/roomgrid.py pieces for the 1 x 2 RoomGrid levels (Unlock, UnlockPickup, BlockedUnlockPickup) ----
+// RoomGrid.place_agent's `while True` (roomgrid.py:327-332) has no bound: when the room holds a free cell but every free cell faces a
+// non-wall object in all four directions, the reference never returns (BabyAI-SynthS5R2: 18 objects in six 3 x 3 rooms, about 0.4 % of
+// the episodes).  Decided exactly, one lane per cell of the room's rs x rs rectangle, before anything is drawn.  (A room without any free
+// cell is not this case: place_obj's 1000 tries run out -- RecursionError, which the callers' retry loops handle.)
+MG_D bool room_stuck(GridRef& g, int topx, int topy, int rs) {
+  if (rs > 8) return false;
+  MG_WAVE_LDS_SYNC();
+  const int ly = g.lane / rs, lx = g.lane - ly * rs, x = topx + lx, y = topy + ly;
+  const bool in = ly < rs && x < g.W && y < g.H;
+  const bool is_free = in && (uint32_t)g.p[y * g.W + x] == CELL_EMPTY;
+  bool ok = false;
+  if (is_free) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int fx = x + dir_dx(d), fy = y + dir_dy(d);
+      if (fx < 0 || fy < 0 || fx >= g.W || fy >= g.H) continue;
+      const uint32_t f = (uint32_t)g.p[fy * g.W + fx];
+      ok = ok || f == CELL_EMPTY || cell_type(f) == T_WALL;
+    }
+  }
+  return __ballot(is_free) != 0ull && __ballot(ok) == 0ull;
+}
 // RoomGrid.place_agent (roomgrid.py:313-334): place_agent in the room until the front cell is None or a wall
 template <class R>
 MG_D bool rg_place_agent(R& rng, GridRef& g, int topx, int topy, int rs, GenResult& out) {
+  if (room_stuck(g, topx, topy, rs)) { out.stuck = 1u; return false; }     // ends the attempt like a RecursionError; the episode is marked
   for (;;) {
     if (!place_agent(rng, g, topx, topy, rs, rs, 1000, out)) return false;
     const uint32_t f = g.get((int)out.ax + dir_dx(out.dir), (int)out.ay + dir_dy(out.dir));

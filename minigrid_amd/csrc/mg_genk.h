@@ -25,6 +25,9 @@ struct GenArgs {
   int stat_gen_off;                                  // first generator statistics slot in `counters`
   int live;                                          // 1: requests are regenerated IN PLACE (dst = live state): only
                                                      //    envs still flagged RESET_PENDING are drawn, and come out FRESH
+  int stuck_mode;                                    // an episode whose drawing met RoomGrid.place_agent's endless loop (GenResult.stuck):
+                                                     //    0 = mark the record FLAG_STUCK (ring slots: the error is due when the episode is
+                                                     //    taken), 1 = report ERR_GENERATOR now (the live state), 2 = neither (redrawn, accepted)
   // refill mode (k_refill): request segments of one batch, ring bookkeeping
   const uint32_t* seg; uint32_t* seg_count; int seg_cap;
   int wps;                                           // generating workgroups (one wavefront each) per request segment
@@ -69,7 +72,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     const uint32_t gs = uni32(A.gstate[e]);
     if (lane == 0) { ((uint32_t*)(mygrid + scratch0))[0] = gs; if (A.gsnap) A.gsnap[se] = gs; }
   }
-  out.gstate = 0;
+  out.gstate = 0; out.stuck = 0;
   // draw-budget loop: buffer `budget` draws, run the generator.  A pass that ran out of draws restarts from its
   // last checkpoint (GoToRedBall: the start of the current whole-map attempt) with a fresh buffer, or -- no
   // checkpoint passed -- is replayed from the start (same draws, same path) with twice the budget.  One refill
@@ -113,11 +116,11 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   if (A.dst_instr && lane < (uint32_t)INSTR_WORDS) A.dst_instr[se * INSTR_WORDS + lane] = ((const uint64_t*)(mygrid + scratch0 + GEN_SCRATCH_BYTES))[lane];
   if (lane == 0) {
     Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = out.carry; ag.step = 0; ag.mission = out.mission;
-    ag.flags = flags_out | (out.carry ? FLAG_SHOW_TAKEN : 0u);
+    ag.flags = flags_out | (out.carry ? FLAG_SHOW_TAKEN : 0u) | ((out.stuck && A.stuck_mode == 0) ? FLAG_STUCK : 0u);
     A.dst_agent[se] = agent_pack(ag);
     if (A.dst_aux) A.dst_aux[se] = out.aux;
     if (A.gstate) A.gstate[e] = out.gstate;
-    if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
+    if (out.failed || (out.stuck && A.stuck_mode == 1)) report_errors(A.err, (uint32_t)ERR_GENERATOR);
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
     if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);

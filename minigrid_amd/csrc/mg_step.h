@@ -392,6 +392,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         if (!P.static_gen) shadow_left--;
         S.ev_reset = 1; S.ev_shadow = set;
       }
+      if (a.flags & FLAG_STUCK) errbits |= ERR_GENERATOR;   // the reference would never return from this reset() (mg_gen.h room_stuck)
       a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
       if constexpr (GG == GG_NONE || GG == GG_SENTENCE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify / k_roll7<GG_SENTENCE> installs the instruction record
       rec_dirty = true; wb_all = true;

@@ -14,6 +14,7 @@ All compute happens in libminigrid_hip.so (HIP, gfx950).  There is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+from dataclasses import replace
 from typing import Any, Optional, Sequence
 
 import numpy as np
@@ -21,7 +22,7 @@ import numpy as np
 from . import _binding as B
 from . import spaces
 from .mission_vocab import string_to_indices
-from .registry import EnvSpec, spec as _spec
+from .registry import ENV_LEVELGEN, EnvSpec, spec as _spec
 
 try:  # subclass the real thing when it exists so isinstance checks pass
     from gymnasium.vector import VectorEnv as _VectorEnvBase  # type: ignore
@@ -55,7 +56,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                  max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
                  image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
                  death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True,
-                 spare_ring: int = 0, traj_slots: int = 0):
+                 spare_ring: int = 0, traj_slots: int = 0, stuck_place_agent: str = "raise"):
         if obs_mode not in _OBS_MODES:
             raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
         # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
@@ -66,10 +67,21 @@ class MiniGridVecEnv(_VectorEnvBase):
         assert "goal" not in no_death_types, "goal cannot be a death cell"      # NoDeath.__init__ (wrappers.py:854)
         if output not in ("numpy", "torch"):
             raise ValueError("output must be 'numpy' or 'torch'")
+        # RoomGrid.place_agent loops without a bound (roomgrid.py:327-332): when every free cell of the agent's room faces an object the
+        # reference never returns from reset() (BabyAI-SynthS5R2-v0: about 0.4 % of the episodes).  "raise": RecursionError when an env
+        # reaches such an episode; "redraw" (LevelGen levels only): the attempt ends like the RecursionError the level's retry loop catches
+        # and the redrawn map is accepted -- usable at batch sizes where some env always meets the case, but not a reference behaviour.
+        if stuck_place_agent not in ("raise", "redraw"):
+            raise ValueError("stuck_place_agent must be 'raise' or 'redraw'")
         # what pickling needs to build the same env again (__getstate__)
         self._ctor = dict(env_id=env_id, num_envs=int(num_envs), autoreset_mode=autoreset_mode, rng=rng, env_index_base=int(env_index_base),
-                          max_steps=max_steps, output=output, spare_ring=int(spare_ring), traj_slots=int(traj_slots))
+                          max_steps=max_steps, output=output, spare_ring=int(spare_ring), traj_slots=int(traj_slots),
+                          stuck_place_agent=stuck_place_agent)
         s: EnvSpec = _spec(env_id)
+        if stuck_place_agent == "redraw":
+            if s.env_kind != ENV_LEVELGEN:
+                raise ValueError("stuck_place_agent='redraw' applies to the LevelGen levels (PickupLoc, GoToSeq*, Synth*, *BossLevel*)")
+            s = replace(s, num_crossings=s.num_crossings | 1 << 10)
         if max_steps is not None:
             if not isinstance(max_steps, int):
                 raise AssertionError(f"The argument max_steps must be an integer, got: {type(max_steps)}")  # minigrid_env.py:102-104

@@ -656,9 +656,9 @@ def make_rollouts(env_id, seeds, T):
     return out
 
 
-def make_gen(env_id, nseeds, episodes=3):
+def make_gen(env_id, nseeds, episodes=3, seeds=None):
     grids, agents, missions, strs = [], [], [], []
-    for s in range(nseeds):
+    for s in (range(nseeds) if seeds is None else seeds):
         env = gym.make(env_id)          # one env per seed, like one slot of the vector env (LevelGen keeps state across resets)
         g, a, m, ms = [], [], [], []
         for ep in range(episodes):
@@ -675,6 +675,8 @@ def make_gen(env_id, nseeds, episodes=3):
                mission=np.array(missions, np.uint8 if max(map(max, missions)) < 256 else np.uint16))
     if env_id.startswith(STRING_MISSION_PREFIXES):
         out["mission_str"] = np.array(strs)
+    if seeds is not None:
+        out["seeds"] = np.array(list(seeds), np.uint64)
     return out
 
 
@@ -969,6 +971,57 @@ def main_oracle_only():
         print("done", env_id, flush=True)
 
 
+class _Hang(Exception):
+    pass
+
+
+def _finishes(fn, secs=5):
+    """fn() under an alarm: None when it does not come back (RoomGrid.place_agent's `while True`, roomgrid.py:327-332)."""
+    import signal
+
+    def on_alarm(*_):
+        raise _Hang()
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(secs)
+    try:
+        return fn()
+    except _Hang:
+        return None
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+
+
+SYNTH_S5R2 = "BabyAI-SynthS5R2-v0"
+
+
+def main_synths5r2():
+    """BabyAI-SynthS5R2-v0: 18 objects in six 3 x 3 rooms.  The reference never comes back from reset() when the agent's room has a
+    free cell but every free cell faces an object on all four sides (about 0.4 % of the episodes).  Goldens = the seeds where it does
+    come back, plus the (seed, episode) pairs where it does not -- what the oracle's / the device's exact test is pinned to."""
+    hang_seed, hang_ep, good = [], [], []
+    for s in range(200):
+        env = gym.make(SYNTH_S5R2)
+        for ep in range(4):
+            if _finishes(lambda: env.reset(seed=s) if ep == 0 else env.reset()) is None:
+                hang_seed.append(s)
+                hang_ep.append(ep)
+                break
+        else:
+            good.append(s)
+    gen = make_gen(SYNTH_S5R2, 0, episodes=4, seeds=good[:64])
+    gen["hang_seed"], gen["hang_episode"] = np.array(hang_seed, np.uint64), np.array(hang_ep, np.int32)
+    np.savez_compressed(os.path.join(OUT, f"gen_{SYNTH_S5R2}.npz"), **gen)
+    seeds = []
+    for s in good:                       # rollouts reset many times: keep the seeds whose 400 steps come back in both modes
+        if all(_finishes(lambda: rollout(SYNTH_S5R2, s, 400, mode), 60) is not None for mode in ("random", "solver")):
+            seeds.append(s)
+        if len(seeds) == 5:
+            break
+    np.savez_compressed(os.path.join(OUT, f"rollout_{SYNTH_S5R2}.npz"), **make_rollouts(SYNTH_S5R2, seeds, 400))
+    print("done", SYNTH_S5R2, "hangs at", list(zip(hang_seed, hang_ep)), "rollout seeds", seeds, flush=True)
+
+
 def main_registry():
     """tests/golden/reference_registry.json: every registered id with its entry point, kwargs and the geometry of an
     instantiated env -- what minigrid_amd/registry.py and oracle.spec() are checked against."""
@@ -976,8 +1029,8 @@ def main_registry():
     from gymnasium.envs.registration import registry
     rows = {}
     for env_id, spec in sorted(registry.items()):
-        if not env_id.startswith(("MiniGrid-", "BabyAI-")) or "WFC" in env_id or env_id == "BabyAI-SynthS5R2-v0":
-            # WFC needs the absent imageio package (out of scope); SynthS5R2: the reference can hang
+        if not env_id.startswith(("MiniGrid-", "BabyAI-")) or "WFC" in env_id:
+            # WFC needs the absent imageio package (out of scope)
             continue
         u = gym.make(env_id).unwrapped
         dynamic = hasattr(u, "fixed_max_steps") and not u.fixed_max_steps      # RoomGridLevel.reset recomputes it from the instruction
@@ -1015,6 +1068,8 @@ def main():
         return main_registry()
     if len(sys.argv) > 1 and sys.argv[1] == "oracle_only":
         return main_oracle_only()
+    if len(sys.argv) > 1 and sys.argv[1] == "synths5r2":
+        return main_synths5r2()
     np.savez_compressed(os.path.join(OUT, "rng_kat.npz"), **make_rng_kat())
     main_seeds = list(range(12)) + [100, 243, 500, 1337]
     for env_id in MAIN_IDS:
@@ -1030,6 +1085,7 @@ def main():
     main_wrappers()
     main_rgb()
     main_oracle_only()
+    main_synths5r2()
     main_registry()
 
 

@@ -243,7 +243,7 @@ def test_mg_create_valid_config_needs_a_device():
 
 def test_registry_rows_are_consistent():
     import minigrid_amd as mg
-    assert len(mg.registry) == 171
+    assert len(mg.registry) == 172
     for env_id, s in mg.registry.items():
         assert s.id == env_id and 3 <= s.width <= 25 and 3 <= s.height <= 25 and 1 <= s.max_steps <= 65535 and len(s.missions) >= 1
         assert s.entry_point.startswith("minigrid.envs")
@@ -258,7 +258,7 @@ def test_registry_and_oracle_tables_match_the_reference_registry():
     import minigrid_amd as mg
     from oracle import oracle as O
     ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_registry.json")))
-    assert len(ref) == 171
+    assert len(ref) == 172
     for env_id, s in mg.registry.items():
         r = ref[env_id]
         assert s.entry_point == r["entry_point"], env_id

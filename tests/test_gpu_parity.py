@@ -5,7 +5,7 @@ Everything is bit-exact (u8 obs, f64 reward compared by bytes, flags)."""
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, SENTENCE_IDS, WIDE_IDS, WIDE2_IDS, full_obs_supported, golden
+from conftest import ALL_IDS, MAIN_IDS, SENTENCE_IDS, STUCK_IDS, WIDE_IDS, WIDE2_IDS, full_obs_supported, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -20,26 +20,27 @@ def _assert_native_loaded():
     assert "libminigrid_hip.so" in maps, "HIP extension not loaded"
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS)
+@pytest.mark.parametrize("env_id", ALL_IDS + STUCK_IDS)
 def test_generators_match_reference_goldens(env_id):
     g = golden(f"gen_{env_id}.npz")
     n, episodes = g["grid"].shape[:2]
     env = _mk(env_id, n)
     _assert_native_loaded()
+    seeds = [int(s) for s in g["seeds"]] if "seeds" in g else list(range(n))     # (STUCK_IDS: the seeds where the reference comes back)
     for ep in range(episodes):
-        obs, info = env.reset(seed=list(range(n))) if ep == 0 else env.reset()
+        obs, info = env.reset(seed=seeds) if ep == 0 else env.reset()
         assert info == {}
         grid, agent = env.get_state()
         assert (grid == g["grid"][:, ep]).all(), (env_id, ep)
         assert (agent[:, :6] == g["agent"][:, ep, :6]).all(), (env_id, ep)
-        if env_id in SENTENCE_IDS:                    # the mission is a sentence built from the drawn instruction tree
+        if env_id in SENTENCE_IDS + STUCK_IDS:        # the mission is a sentence built from the drawn instruction tree
             assert (obs["mission"] == g["mission_str"][:, ep]).all(), (env_id, ep, obs["mission"][:3], g["mission_str"][:3, ep])
         else:
             assert (env._missions[g["mission"][:, ep]] == obs["mission"]).all()
     env.close()
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS)
+@pytest.mark.parametrize("env_id", ALL_IDS + STUCK_IDS)
 @pytest.mark.parametrize("mode", ["random", "solver"])
 @pytest.mark.parametrize("full", [False, True])
 def test_rollouts_match_reference_goldens(env_id, mode, full):
@@ -51,7 +52,7 @@ def test_rollouts_match_reference_goldens(env_id, mode, full):
     if f"{mode}_max_steps" not in g:              # LevelGen levels recompute max_steps per episode from the instruction
         assert env.max_steps == int(g["max_steps"])
     obs, _ = env.reset(seed=[int(s) for s in g["seeds"]])
-    if env_id in SENTENCE_IDS:
+    if env_id in SENTENCE_IDS + STUCK_IDS:
         assert (obs["mission"] == g[f"{mode}_mission_str"][:, 0]).all(), (env_id, obs["mission"], g[f"{mode}_mission_str"][:, 0])
     assert obs["image"].dtype == np.uint8 and (obs["image"] == want_obs[:, 0]).all()
     assert (obs["direction"] == g[f"{mode}_dir"][:, 0]).all()
@@ -62,7 +63,7 @@ def test_rollouts_match_reference_goldens(env_id, mode, full):
         assert term.dtype == bool and (term == g[f"{mode}_term"][:, t]).all(), (env_id, t)
         assert (trunc == g[f"{mode}_trunc"][:, t]).all(), (env_id, t)
         assert obs["direction"].dtype == np.int64 and (obs["direction"] == g[f"{mode}_dir"][:, t + 1]).all()
-        if env_id in SENTENCE_IDS:
+        if env_id in SENTENCE_IDS + STUCK_IDS:
             assert (obs["mission"] == g[f"{mode}_mission_str"][:, t + 1]).all(), (env_id, t)
         else:
             assert (obs["mission"] == env._missions[g[f"{mode}_mission"][:, t + 1]]).all()
@@ -73,9 +74,9 @@ def test_rollouts_match_reference_goldens(env_id, mode, full):
     env.close()
 
 
-def _compare_with_oracle(env_id, n, T, full, seed0=0, action_seed=0, probs=None, autoreset="next_step"):
+def _compare_with_oracle(env_id, n, T, full, seed0=0, action_seed=0, probs=None, autoreset="next_step", **mk_kw):
     from oracle import oracle as O
-    env = _mk(env_id, n, obs_mode="full" if full else "partial", autoreset_mode=autoreset)
+    env = _mk(env_id, n, obs_mode="full" if full else "partial", autoreset_mode=autoreset, **mk_kw)
     orc = O.OracleVec(env_id, n, full_obs=full)
     seeds = np.arange(seed0, seed0 + n, dtype=np.uint64)
     obs, _ = env.reset(seed=int(seed0))
@@ -91,7 +92,7 @@ def _compare_with_oracle(env_id, n, T, full, seed0=0, action_seed=0, probs=None,
         assert rew.tobytes() == orew.tobytes(), (env_id, t)
         assert (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
         assert (obs["direction"] == od).all(), (env_id, t)
-        assert (obs["mission"] == (orc.mission_strings() if env_id in SENTENCE_IDS else env._missions[om])).all(), (env_id, t)
+        assert (obs["mission"] == (orc.mission_strings() if env_id in SENTENCE_IDS + STUCK_IDS else env._missions[om])).all(), (env_id, t)
         nterm += int(term.sum()); ntrunc += int(trunc.sum())
     g1, a1 = env.get_state()
     g2, a2 = orc.get_state()

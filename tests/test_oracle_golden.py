@@ -6,7 +6,7 @@ These tests run on CPU (no GPU marker): if they fail, no GPU parity claim means 
 import numpy as np
 import pytest
 
-from conftest import ALL_IDS, MAIN_IDS, golden, ORACLE_ONLY_IDS
+from conftest import ALL_IDS, MAIN_IDS, golden, ORACLE_ONLY_IDS, STUCK_IDS
 from oracle import oracle as O
 
 
@@ -62,13 +62,15 @@ def test_reference_doctest_first_obs_column():
     assert (obs[0, 0] == np.array([2, 5, 0], np.uint8)).all()
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS)
+@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS + STUCK_IDS)
 def test_generators_match_reference(env_id):
     g = golden(f"gen_{env_id}.npz")
     n, episodes = g["grid"].shape[:2]
     v = O.OracleVec(env_id, n)
+    seeds = g["seeds"] if "seeds" in g else np.arange(n)
     for ep in range(episodes):
-        _, _, mission = v.reset(seeds=np.arange(n) if ep == 0 else None)
+        _, _, mission = v.reset(seeds=seeds if ep == 0 else None)
+        assert not v.stuck().any()
         grid, agent = v.get_state()
         assert (grid == g["grid"][:, ep]).all(), (env_id, ep)
         assert (agent[:, :6] == g["agent"][:, ep, :6]).all(), (env_id, ep)
@@ -77,7 +79,25 @@ def test_generators_match_reference(env_id):
             assert (v.mission_strings() == g["mission_str"][:, ep]).all(), (env_id, ep)
 
 
-@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS)
+@pytest.mark.parametrize("env_id", STUCK_IDS)
+def test_oracle_decides_place_agents_endless_loop_where_the_reference_hangs(env_id):
+    """RoomGrid.place_agent (roomgrid.py:327-332) loops without a bound.  The golden file lists the (seed, episode) pairs among seeds
+    0..199 x 4 episodes where the unmodified reference did not come back from reset() (make_golden.py main_synths5r2); the oracle's
+    exact test (rg_room_stuck) must flag exactly those episodes -- and none of the 64 x 4 recorded ones (test above)."""
+    g = golden(f"gen_{env_id}.npz")
+    hs, he = g["hang_seed"], g["hang_episode"]
+    assert len(hs) >= 3
+    v = O.OracleVec(env_id, 200)
+    first = np.full(200, -1)
+    for ep in range(4):
+        v.reset(seeds=np.arange(200) if ep == 0 else None)
+        st = v.stuck()
+        first[(first < 0) & st] = ep
+    assert sorted(np.flatnonzero(first >= 0)) == sorted(int(s) for s in hs)
+    assert (first[hs.astype(int)] == he).all()
+
+
+@pytest.mark.parametrize("env_id", ALL_IDS + ORACLE_ONLY_IDS + STUCK_IDS)
 @pytest.mark.parametrize("mode", ["random", "solver"])
 @pytest.mark.parametrize("full", [False, True])
 def test_rollouts_match_reference(env_id, mode, full):
