@@ -368,11 +368,13 @@ static int launch_step(mg_env* e, StepParams& P) {
     const bool in_loop_verify = e->sentence && e->fast7;       // k_roll7<GG_SENTENCE>: one wave per workgroup (the record is shared state)
     if (in_loop_verify) nw = 1;
     // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
-    static const bool share_ok = [] { const char* s = getenv("MG_ROLL_SHARE"); return !s || atoi(s) != 0; }();
+    // MG_ROLL_SHARE: 0 = off, 1..15 = the stepping wave is (workgroup >> (value - 1)) & 3, 16 = always wave 0
+    static const int share_mode = [] { const char* s = getenv("MG_ROLL_SHARE"); const int v = s ? atoi(s) : 16; return v < 0 || v > 16 ? 16 : v; }();
+    const bool share_ok = share_mode != 0;
     // (only while the batch leaves wave slots free: at 4 096 workgroups the three waiting waves per workgroup cost more than the shared
     // encode saves -- Empty-8x8 x 65 536: 9.4 us per step against 10.1; DoorKey-8x8 x 262 144: 33.0 against 23.8, profiles/r3/unfused_share.txt)
     const bool share = P.T == 1 && share_ok && P.phase == PHASE_STEP && e->nwaves <= 2048;
-    P.share = share ? 1 : 0;
+    P.share = share ? share_mode : 0;
     static const double ratio = [] { const char* s = getenv("MG_ROLL_RATIO"); const double v = s ? atof(s) : 0.0; return v > 0.0 && v < 1.0 ? v : 0.12; }();
     double geo = 0.0, pw = 1.0;
     for (int w = 0; w < nw; w++) { geo += pw; pw *= 1.0 - ratio; }

@@ -297,17 +297,21 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   uint32_t* slut = (uint32_t*)smem;
   // obs7_chunk addresses the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
-  uint8_t* sgrid = smem + P.off_grid + wave * (64 * GS);             // this wave's private copy of the 64 grids
-  uint8_t* scodes = smem + P.off_T + wave * P.codes_stride;          // the wave's code stream (FULL: its image-order stream of the 64 grids)
+  // share (one-step launches, Env.step): there is nothing to split in time, so ONE wave runs the step up to the staged codes and ALL waves
+  // of the workgroup share the output-space encode behind one barrier (a quarter of the ten rounds each); the stepping wave owns the state.
+  // Which wave steps rotates with the workgroup index (P.share - 1 = the shift): the workgroups resident on one CU then step on different
+  // SIMDs instead of all on the one that holds every workgroup's wave 0.
+  const bool share = P.share != 0;
+  const int sw = (share && P.share < 16) ? (int)(((uint32_t)wg >> (P.share - 1)) & (uint32_t)(NW - 1)) : 0;
+  const int mycopy = share ? 0 : wave;
+  uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
+  uint8_t* scodes = smem + P.off_T + mycopy * P.codes_stride;        // the wave's code stream (FULL: its image-order stream of the 64 grids)
   const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
-  // share (one-step launches, Env.step): there is nothing to split in time, so wave 0 runs the step up to the staged codes and ALL waves
-  // of the workgroup share the output-space encode behind one barrier (a quarter of the ten rounds each); wave 0 owns the state.
-  const bool share = P.share != 0;
-  const bool last_wave = share ? wave == 0 : wave == NW - 1;
-  const int j_begin = P.split[wave], j_end = (share && wave > 0) ? 0 : P.split[wave + 1];
+  const bool last_wave = share ? wave == sw : wave == NW - 1;
+  const int j_begin = share ? 0 : P.split[wave], j_end = share ? (wave == sw ? P.T : 0) : P.split[wave + 1];
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
                          (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
@@ -541,7 +545,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   }
 
   if (share) {
-    // the one step's observation, encoded by every wave of the workgroup from wave 0's code stream
+    // the one step's observation, encoded by every wave of the workgroup from the stepping wave's code stream
     __syncthreads();
     const uint8_t* codes0 = smem + P.off_T;
     uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;

@@ -70,11 +70,14 @@ def test_autoreset_raises_at_the_step_that_reaches_a_stuck_episode(fused):
     import minigrid_amd as mg
     from oracle import oracle as O
     n = 256
+    probe = O.OracleVec(ID, 2 * n)                     # seeds whose FIRST episode the reference comes back from
+    probe.reset(seeds=np.arange(5000, 5000 + 2 * n, dtype=np.uint64))
+    seeds = (5000 + np.flatnonzero(~probe.stuck())[:n]).astype(np.uint64)
     env = mg.make_vec(ID, n, traj_slots=16)
     orc = O.OracleVec(ID, n)
-    env.reset(seed=5000)
-    orc.reset(seeds=np.arange(5000, 5000 + n, dtype=np.uint64))
-    assert not orc.stuck().any()
+    obs, _ = env.reset(seed=[int(s) for s in seeds])
+    o_obs, _, _ = orc.reset(seeds=seeds)
+    assert not orc.stuck().any() and (obs["image"] == o_obs).all()
     rng = np.random.default_rng(1)
     probs = [0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]
     T, chunk = 4000, 16
