@@ -260,9 +260,14 @@ MG_API int mg_copy_slot(mg_env* env, int slot, uint8_t* obs, double* reward, uin
                  uint8_t* direction, uint16_t* mission_id, uint8_t* action);
 MG_API int mg_sync(mg_env* env);        /* synchronises the handle's streams (steps AND episode generation) + error-flag check */
 
-/* State exchange (checkpoint/resume and parity-harness state injection).
+/* State exchange in the reference's own encoding (parity-harness state injection; for checkpoints use mg_save_state below).
  *   grid : (N, W, H, 3) u8 in Grid.encode() layout (core/grid.py:244-268), decoded like Grid.decode (270-289)
- *   agent: (N, 8) i32 = {x, y, dir, carry_type, carry_color, step_count, reset_pending, mission_id}      */
+ *   agent: (N, 8) i32 = {x, y, dir, carry_type, carry_color, step_count, reset_pending, mission_id}
+ * Grid.encode() is lossy where the reference's objects hold more than (type, colour, state), and so is this pair: a key hidden in a box
+ * reads back as a plain box (Box.encode, world_object.py:65-67, knows nothing of Box.contains), the sentence levels are refused
+ * (instruction trees and object identities are not in the encoding), and the level words are re-derived from grid + mission id where
+ * that is possible (tracked GoTo / PutNext positions, obstacle lists) and KEPT as the handle has them where it is not (OpenDoor with a
+ * location description: which doors "the door on your left" meant at reset time). */
 MG_API int mg_get_state(mg_env* env, uint8_t* grid, int32_t* agent);
 MG_API int mg_set_state(mg_env* env, const uint8_t* grid, const int32_t* agent);
 /* Lossless checkpoint of a live handle -- what pickling a reference env carries (tests/test_envs.py:185-196 test_pickle_env): the

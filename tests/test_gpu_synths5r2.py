@@ -123,10 +123,13 @@ def test_redraw_mode_equals_the_oracle_over_many_episodes(full):
     nterm, ntrunc = _compare_with_oracle(ID, 2048, 400, full, seed0=77, probs=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05],
                                          stuck_place_agent="redraw")
     assert nterm + ntrunc > 2048
-    # the case was met: the oracle flags some of the first episodes of these very seeds
+    # the case was met on the way: these envs draw about 2 048 x 7 episodes, the oracle flags some of the first 3 x 2 048 alone
     orc = O.OracleVec(ID, 2048)
-    orc.reset(seeds=np.arange(77, 77 + 2048, dtype=np.uint64))
-    assert orc.stuck().sum() >= 2
+    met = 0
+    for ep in range(3):
+        orc.reset(seeds=np.arange(77, 77 + 2048, dtype=np.uint64) if ep == 0 else None)
+        met += int(orc.stuck().sum())
+    assert met >= 2
 
 
 def test_redraw_mode_fused_rollout_equals_the_oracle():
