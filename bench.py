@@ -311,8 +311,12 @@ def main():
     env.sync()                           # + the generator stream: every episode consumed in the region is drawn again
     if gather:
         senv.finish()                    # + the communication stream: every collective issued in the region has completed
-    barrier()
-    dt = time.perf_counter() - t0        # whole-job clock (>= the event time): what `value` is computed from
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0        # THIS rank's clock (>= the event time): its K steps are complete on the device
+    if world > 1:
+        dist.barrier()                   # the closing barrier of the bracket; the job's time is the MAX over the ranks' clocks (below) --
+                                         # the ranks started together, so that is when the slowest one finished; the latency of the
+                                         # barrier collective itself (tens of us over 8 GPUs) is not part of the K steps
 
     per_rank_us = [dt / args.steps * 1e6]
     if world > 1:
