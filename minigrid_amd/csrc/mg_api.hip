@@ -1614,6 +1614,14 @@ int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const
     for (int l = 0; l < 64; l++) obs7_stage(D[l], l < 63 ? D[l + 1][0] : 0u, l, (uint32_t*)codes.data());
     const int nbytes = nv * PARTIAL_OBS_BYTES;
     uint8_t* ob = out + (size_t)g0 * PARTIAL_OBS_BYTES;
+    if (MG_ENCODE_QUADS && nv == 64) {                                // a full workgroup: the quad encode, like the kernel
+      for (int u = 0; u < 16 * VIEW_CELLS; u++) {
+        uint32_t o3[3];
+        obs7_quad((uint32_t)u, codes.data(), slut.data(), o3);
+        for (int b = 0; b < 12; b++) ob[u * 12 + b] = (uint8_t)(o3[b >> 2] >> (8 * (b & 3)));
+      }
+      continue;
+    }
     for (int c = 0; c * 16 < nbytes; c++) {
       uint32_t o4[4];
       obs7_chunk((uint32_t)c, codes.data(), slut.data(), o4);

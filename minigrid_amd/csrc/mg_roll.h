@@ -264,6 +264,29 @@ MG_HD void obs7_chunk(uint32_t c, const uint8_t* codes, const uint32_t* slut, ui
 #endif
 }
 
+// The same encode per QUAD of cells: the 12 bytes [12 u, 12 u + 12) of the stream are the triples of the four codes in dword u of the
+// code stream -- one aligned code dword, four lookups, three byte permutes, no phase: 4 u cells never straddle anything.  A round of 64
+// lanes writes 768 contiguous bytes with one 12-byte store per lane.  Needs a stream of 4 k cells (a full workgroup: 64 envs).
+MG_HD void obs7_quad(uint32_t u, const uint8_t* codes, const uint32_t* slut, uint32_t out[3]) {
+  const uint32_t w = ((const uint32_t*)codes)[u];
+  const uint32_t two = 2u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+#define MG_LUT(off) (*(lds_u32*)(uintptr_t)(off))
+#else
+  const uint8_t* lut = (const uint8_t*)slut;
+#define MG_LUT(off) (*(const uint32_t*)(lut + (off)))
+#endif
+  const uint32_t t0 = MG_LUT(MG_BYTE_X4(w, 0, two)), t1 = MG_LUT(MG_BYTE_X4(w, 1, two)), t2 = MG_LUT(MG_BYTE_X4(w, 2, two)), t3 = MG_LUT(MG_BYTE_X4(w, 3, two));
+#undef MG_LUT
+  out[0] = perm_b32(t1, t0, 0x04020100u); out[1] = perm_b32(t2, t1, 0x05040201u); out[2] = perm_b32(t3, t2, 0x06050402u);
+}
+// compile-time choice of the encode of full workgroups (the chunk form stays for ragged ones): 0 builds the round-3 chunk encode for A/B runs
+#ifndef MG_ENCODE_QUADS
+#define MG_ENCODE_QUADS 1
+#endif
+struct Out12 { uint32_t x, y, z; };                    // 4-byte aligned: one global_store_dwordx3
+
 constexpr int ROLL_CODES_BYTES = 64 * VIEW_CELLS + 16;        // one wave's code staging (+ slack for the 8-byte accesses)
 constexpr int ROLL_MAX_WAVES = 4;
 
@@ -510,6 +533,28 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)OBE;   // 64 * OBE is a multiple of 16
       const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
+#if MG_ENCODE_QUADS
+      if (!FULL && nvalid == 64) {
+        constexpr int NQ = 64 * VIEW_CELLS / 4, NIT = (NQ + 63) / 64;             // 784 cell quads: thirteen rounds, the last one 16 lanes wide
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int u = lane + 64 * it;
+          uint32_t o3[3];
+          obs7_quad((uint32_t)(it == NIT - 1 ? min(u, NQ - 1) : u), scodes, slut, o3);
+          Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
+          if (it < NIT - 1 || u < NQ) ((Out12*)obase)[u] = v;
+        }
+      } else if (FULL && nvalid == 64) {
+        const int nq = 16 * cells;                                                // 64 * cells / 4 quads
+#pragma unroll 4
+        for (int u = lane; u < nq; u += 64) {
+          uint32_t o3[3];
+          obs7_quad((uint32_t)u, scodes, slut, o3);
+          Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
+          ((Out12*)obase)[u] = v;
+        }
+      } else {
+#else
       if (!FULL && nvalid == 64) {
         constexpr int NCH = 64 * PARTIAL_OBS_BYTES / 16, NIT = (NCH + 63) / 64;   // 588 chunks: ten rounds, the last one 12 lanes wide
 #pragma unroll 2
@@ -529,6 +574,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           ((uint4*)obase)[c] = v;
         }
       } else {
+#endif
         // the ragged last workgroup of a batch: whole chunks, then the stream's last bytes one by one
 #pragma unroll 1
         for (int c = lane; c <= nvec; c += 64) {
@@ -550,7 +596,16 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const uint8_t* codes0 = smem + P.off_T;
     uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
-    if (!(P.exp & 2))
+    if (MG_ENCODE_QUADS && nvalid == 64) {
+      const int nq = 16 * (FULL ? cells : VIEW_CELLS);
+      if (!(P.exp & 2))
+        for (int u = tid; u < nq; u += nthreads) {
+          uint32_t o3[3];
+          obs7_quad((uint32_t)u, codes0, slut, o3);
+          Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
+          ((Out12*)obase)[u] = v;
+        }
+    } else if (!(P.exp & 2))
       for (int c = tid; c <= nvec; c += nthreads) {
         uint32_t o4[4];
         obs7_chunk((uint32_t)c, codes0, slut, o4);
