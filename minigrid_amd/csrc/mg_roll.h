@@ -267,8 +267,8 @@ MG_HD void obs7_chunk(uint32_t c, const uint8_t* codes, const uint32_t* slut, ui
 // The same encode per QUAD of cells: the 12 bytes [12 u, 12 u + 12) of the stream are the triples of the four codes in dword u of the
 // code stream -- one aligned code dword, four lookups, three byte permutes, no phase: 4 u cells never straddle anything.  A round of 64
 // lanes writes 768 contiguous bytes with one 12-byte store per lane.  Needs a stream of 4 k cells (a full workgroup: 64 envs).
-MG_HD void obs7_quad(uint32_t u, const uint8_t* codes, const uint32_t* slut, uint32_t out[3]) {
-  const uint32_t w = ((const uint32_t*)codes)[u];
+// (in two halves, so that a loop can have the lookups of the next quad in flight while it packs this one)
+MG_HD void obs7_quad_lookup(uint32_t w, const uint32_t* slut, uint32_t t[4]) {
   const uint32_t two = 2u;
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((address_space(3))) const uint32_t lds_u32;
@@ -277,15 +277,42 @@ MG_HD void obs7_quad(uint32_t u, const uint8_t* codes, const uint32_t* slut, uin
   const uint8_t* lut = (const uint8_t*)slut;
 #define MG_LUT(off) (*(const uint32_t*)(lut + (off)))
 #endif
-  const uint32_t t0 = MG_LUT(MG_BYTE_X4(w, 0, two)), t1 = MG_LUT(MG_BYTE_X4(w, 1, two)), t2 = MG_LUT(MG_BYTE_X4(w, 2, two)), t3 = MG_LUT(MG_BYTE_X4(w, 3, two));
+  t[0] = MG_LUT(MG_BYTE_X4(w, 0, two)); t[1] = MG_LUT(MG_BYTE_X4(w, 1, two)); t[2] = MG_LUT(MG_BYTE_X4(w, 2, two)); t[3] = MG_LUT(MG_BYTE_X4(w, 3, two));
 #undef MG_LUT
-  out[0] = perm_b32(t1, t0, 0x04020100u); out[1] = perm_b32(t2, t1, 0x05040201u); out[2] = perm_b32(t3, t2, 0x06050402u);
+}
+MG_HD void obs7_quad_pack(const uint32_t t[4], uint32_t out[3]) {
+  out[0] = perm_b32(t[1], t[0], 0x04020100u); out[1] = perm_b32(t[2], t[1], 0x05040201u); out[2] = perm_b32(t[3], t[2], 0x06050402u);
+}
+MG_HD void obs7_quad(uint32_t u, const uint8_t* codes, const uint32_t* slut, uint32_t out[3]) {
+  uint32_t t[4];
+  obs7_quad_lookup(((const uint32_t*)codes)[u], slut, t);
+  obs7_quad_pack(t, out);
 }
 // compile-time choice of the encode of full workgroups (the chunk form stays for ragged ones): 0 builds the round-3 chunk encode for A/B runs
 #ifndef MG_ENCODE_QUADS
 #define MG_ENCODE_QUADS 1
 #endif
+
 struct Out12 { uint32_t x, y, z; };                    // 4-byte aligned: one global_store_dwordx3
+// NQ quads by threads l0, l0 + STRIDE, ...: software-pipelined -- every code dword first, then the lookups of quad it + 1 are issued before
+// quad it is packed and stored
+template <int STRIDE, int NQ>
+MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase) {
+  constexpr int NIT = (NQ + STRIDE - 1) / STRIDE;
+  uint32_t cw[NIT], tq[2][4];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) cw[it] = ((const uint32_t*)codes)[(it + 1) * STRIDE > NQ ? min(l0 + STRIDE * it, NQ - 1) : l0 + STRIDE * it];
+  obs7_quad_lookup(cw[0], slut, tq[0]);
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int u = l0 + STRIDE * it;
+    if (it + 1 < NIT) obs7_quad_lookup(cw[it + 1], slut, tq[(it + 1) & 1]);
+    uint32_t o3[3];
+    obs7_quad_pack(tq[it & 1], o3);
+    Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
+    if ((it + 1) * STRIDE <= NQ || u < NQ) ((Out12*)obase)[u] = v;
+  }
+}
 
 constexpr int ROLL_CODES_BYTES = 64 * VIEW_CELLS + 16;        // one wave's code staging (+ slack for the 8-byte accesses)
 constexpr int ROLL_MAX_WAVES = 4;
@@ -334,35 +361,66 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
   const bool last_wave = share ? wave == sw : wave == NW - 1;
-  const int j_begin = share ? 0 : P.split[wave], j_end = share ? (wave == sw ? P.T : 0) : P.split[wave + 1];
+  // (split[] is read with compile-time indices: a register-indexed read of a kernel argument is a load from the argument segment)
+  const int sp_lo = wave == 0 ? P.split[0] : wave == 1 ? P.split[1] : wave == 2 ? P.split[2] : P.split[3];
+  const int sp_hi = wave == 0 ? P.split[1] : wave == 1 ? P.split[2] : wave == 2 ? P.split[3] : P.split[4];
+  const int j_begin = share ? 0 : sp_lo, j_end = share ? (wave == sw ? P.T : 0) : sp_hi;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
                          (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
 
-  // ---- prologue: every load up front (see k_step: no global load may sit in the step loop) ----
-  const uint64_t rec = active ? P.agent[e] : 0ull;
+  // ---- prologue: every load up front (see k_step: no global load may sit in the step loop), and every INDEPENDENT load issued before
+  // the first one is waited for: a one-step launch (Env.step) is a chain of memory round trips and little else
+  // (profiles/r3/unfused_anatomy.txt: 5.0 of 9.8 us were a launch without any step work; a kernel that only loads 4 MB into LDS takes 3.55)
+  // (lane-level conditions are kept OUT of the loads -- clamped indices instead: a load under a divergent branch is waited for at the
+  // branch's end, which made the prologue a chain of eight round trips)
+  const int ec = min(e, P.N - 1);
+  const uint64_t rec_ld = P.agent[ec];
   EnvRegs S;
   Agent& a = S.a;
-  S.targets = (goto_rule && active) ? P.aux[e] : 0ull;
-  S.h = (P.head && active) ? P.head[e] : 0u;
-  const uint32_t h_in = S.h;
-  uint32_t qn = (P.seg_count && last_wave) ? uni32(P.seg_count[wg]) : 0u;
-  const bool maskok = !P.obs_mask || (active && P.obs_mask[e]);
+  const uint64_t tg_ld = goto_rule ? P.aux[ec] : 0ull;
+  const uint32_t h_ld = P.head ? P.head[ec] : 0u;
+  const uint32_t mask_ld = P.obs_mask ? (uint32_t)P.obs_mask[ec] : 1u;
+  const bool stage_acts = P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER;
+  const bool act_mine = tid < P.T * 64 && env0 + (tid & 63) < P.N;    // one-step launches: this lane's share of the caller's actions
+  const uint32_t act_ld = stage_acts ? load_action(P, min(env0 + (tid & 63), P.N - 1), min(tid >> 6, P.T - 1)) : 0u;
   S.shadow_left = (uint32_t)P.use_shadow;
   const int cpe = CS >> 4, nchunks = nvalid * cpe;
-  if (j_end > 0) {
-    // private grids: each wave stages its own copy (the redundant reads hit L2); 16 B per lane, coalesced
+  {
+    // the 64 grids, 16 B per lane, coalesced.  Time split: each wave stages its own private copy (the redundant reads hit L2); share: ONE
+    // copy, staged by all the threads of the workgroup.  Four loads in flight per lane, then the four LDS writes.
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
-    for (int c = lane; c < nchunks; c += 64) {
-      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
-      const uint4 v = live[c];
-      uint32_t* dst = (uint32_t*)(sgrid + ce * GS + part * 16);
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    const bool loads = share || j_end > 0;                           // wave-uniform
+    const int l0 = share ? tid : lane, lstride = share ? nthreads : 64;
+    auto stage4 = [&](int base) {
+      uint4 gv[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) gv[k] = live[min(base + l0 + k * lstride, nchunks - 1)];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c = base + l0 + k * lstride;
+        if (c < nchunks) {
+          const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
+          uint32_t* dst = (uint32_t*)(sgrid + ce * GS + part * 16);
+          dst[0] = gv[k].x; dst[1] = gv[k].y; dst[2] = gv[k].z; dst[3] = gv[k].w;
+        }
+      }
+    };
+    // (the first group outside the loop: a loop header waits for every load in flight, the lane's agent record and ring position included)
+    if (loads) {
+      stage4(0);
+      for (int base = 4 * lstride; base < nchunks; base += 4 * lstride) stage4(base);
     }
   }
+  const uint64_t rec = active ? rec_ld : 0ull;
+  S.targets = active ? tg_ld : 0ull;
+  S.h = active ? h_ld : 0u;
+  const uint32_t mask_byte = active ? mask_ld : 0u;
+  const uint32_t act0 = act_ld;
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
   // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
+  // (an env's ring position is lane ce's S.h: every wave has loaded its own copy of the 64 heads)
   for (int set = 0; set < P.use_shadow; set++) {
     if (wave == 0 && active) {
       const size_t se = (size_t)((S.h + (uint32_t)set) & P.ring_mask) * N + (size_t)e;
@@ -370,19 +428,26 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       sp[0] = P.spare_agent[se];
       sp[1] = goto_rule ? P.spare_aux[se] : 0ull;
     }
-    for (int c = tid; c < nchunks; c += nthreads) {
-      const uint32_t ce = ((uint32_t)c * P.cpe_magic) >> 20, part = (uint32_t)c - ce * (uint32_t)cpe;
-      const uint32_t slot = P.head ? ((P.head[env0 + ce] + (uint32_t)set) & P.ring_mask) : 0u;
-      const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
-      uint32_t* d2 = (uint32_t*)(sshadow + set * P.shadow_stride + ce * GS + part * 16);
-      d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
+    for (int c0 = 0; c0 < nchunks; c0 += nthreads) {                 // (uniform trip count: every lane takes part in the shuffle)
+      const int c = c0 + tid;
+      const bool in = c < nchunks;
+      const uint32_t ce = in ? ((uint32_t)c * P.cpe_magic) >> 20 : 0u, part = (uint32_t)c - ce * (uint32_t)cpe;
+      const uint32_t hce = (uint32_t)__shfl((int)S.h, (int)ce);
+      if (in) {
+        const uint32_t slot = P.head ? ((hce + (uint32_t)set) & P.ring_mask) : 0u;
+        const uint4 s = ((const uint4*)(P.spare_grid + ((size_t)slot * N + (size_t)env0 + ce) * CS))[part];
+        uint32_t* d2 = (uint32_t*)(sshadow + set * P.shadow_stride + ce * GS + part * 16);
+        d2[0] = s.x; d2[1] = s.y; d2[2] = s.z; d2[3] = s.w;
+      }
     }
   }
-  if (P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER)
-    for (int k = tid; k < P.T * 64; k += nthreads) {
+  if (stage_acts) {
+    if (act_mine) sact[tid] = (uint8_t)act0;
+    for (int k = tid + nthreads; k < P.T * 64; k += nthreads) {       // (fused launches with caller actions: the rest of the T x 64 block)
       const int j = k >> 6, l = k & 63;
       if (env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
     }
+  }
   if constexpr (FULL) {
     // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
     if (P.use_shadow) {
@@ -395,6 +460,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if constexpr (FULL) { if (j_end > 0 && active) image_stream_build(sgrid + lane * GS, scodes + lane * cells, W, H); MG_LDS_SYNC(); }
 
   a = agent_unpack(rec);
+  const uint32_t h_in = S.h;
+  const bool maskok = mask_byte != 0u;
   uint8_t* mygrid = sgrid + lane * GS;
   S.cur = S.targets;
   if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
@@ -535,18 +602,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const int nvec = nbytes >> 4;
 #if MG_ENCODE_QUADS
       if (!FULL && nvalid == 64) {
-        constexpr int NQ = 64 * VIEW_CELLS / 4, NIT = (NQ + 63) / 64;             // 784 cell quads: thirteen rounds, the last one 16 lanes wide
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-          const int u = lane + 64 * it;
-          uint32_t o3[3];
-          obs7_quad((uint32_t)(it == NIT - 1 ? min(u, NQ - 1) : u), scodes, slut, o3);
-          Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          if (it < NIT - 1 || u < NQ) ((Out12*)obase)[u] = v;
-        }
+        // 784 cell quads: thirteen rounds, the last one 16 lanes wide
+        encode_quads<64, 64 * VIEW_CELLS / 4>(lane, scodes, slut, obase);
       } else if (FULL && nvalid == 64) {
         const int nq = 16 * cells;                                                // 64 * cells / 4 quads
-#pragma unroll 4
         for (int u = lane; u < nq; u += 64) {
           uint32_t o3[3];
           obs7_quad((uint32_t)u, scodes, slut, o3);
@@ -596,7 +655,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const uint8_t* codes0 = smem + P.off_T;
     uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
-    if (MG_ENCODE_QUADS && nvalid == 64) {
+    if (MG_ENCODE_QUADS && !FULL && nvalid == 64 && nthreads == 64 * ROLL_MAX_WAVES) {
+      if (!(P.exp & 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
+    } else if (MG_ENCODE_QUADS && nvalid == 64) {
       const int nq = 16 * (FULL ? cells : VIEW_CELLS);
       if (!(P.exp & 2))
         for (int u = tid; u < nq; u += nthreads) {
@@ -646,6 +707,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (S.h != h_in));
     const unsigned long long m = __ballot(want);
     if (m) {
+      // (the segment's fill count is read here, where a request is filed -- in the prologue it was one more round trip before the grids)
+      uint32_t qn = uni32(P.seg_count[wg]);
       const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (want && qn + rank < (uint32_t)P.seg_cap) P.seg[(size_t)wg * P.seg_cap + qn + rank] = (uint32_t)e;
       qn = min(qn + (uint32_t)__popcll(m), (uint32_t)P.seg_cap);
