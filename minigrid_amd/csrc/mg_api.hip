@@ -630,10 +630,10 @@ static const char* configure_obs(mg_env* e) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
     if (e->fast7) e->roll_guard = (6 * e->W + 12 + 15) & ~15;
-    // Measured (profiles/r3/sweep_nw_ratio.txt): 4 waves per workgroup while the batch alone cannot fill the SIMDs (Empty-8x8 x
-    // 65 536: 2.85 us per step with 4, 2.93 with 3, 3.01 with 2); 3 once there are thousands of workgroups anyway and the silent
-    // replays are pure overhead (DoorKey-8x8 x 262 144: 11.5 us with 3, 11.6 with 2, 12.1 with 4).
-    int nw = (e->N + 63) / 64 > 1536 ? 3 : 4;
+    // Measured with the quad encode (profiles/r3/sweep_nw_ratio_quads.txt): 4 waves per workgroup at every batch size (Empty-8x8 x
+    // 65 536: 2.64 us per step with 4, 2.71 with 3; DoorKey-8x8 x 262 144: 11.3 with 4, 11.8 with 3, 12.1 with 2).  (With the chunk
+    // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
+    int nw = 4;
     if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
     while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw--;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
