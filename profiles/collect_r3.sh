@@ -2,6 +2,7 @@
 # Round-3 evidence on the GPU box: bench lines of the BASELINE workloads, rocprofv3 kernel stats and (separate passes, as
 # MI355X_MICROARCH.md prescribes) the FETCH_SIZE / WRITE_SIZE PMC counters, each with the run's parameters in meta_<workload>.json so
 # that bench.py only quotes counters taken at ITS batch size and steps per launch.
+# Order: the profiler passes first, then the bench lines (which quote them).
 # usage (via gpurun): bash profiles/collect_r3.sh <tag> [workloads for rocprof...]
 TAG=${1:-r3}; shift
 PROF_WL=${@:-empty8x8 doorkey8x8 lavacrossing_full gotoredball}
@@ -9,16 +10,6 @@ export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-for w in empty8x8 doorkey8x8 lavacrossing_full gotoredball; do
-  extra="--no-cpu-baseline"; [ $w = empty8x8 ] && extra=""
-  timeout 300 python bench.py --workload $w --steps 2048 --warmup 256 $extra > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-  python - $OUT/bench_$w.json <<'PY'
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["config"]["env_id"], "%.3f G steps/s"%(d["value"]/1e9), "%.2f us/step"%(d["ms_per_step"]*1e3), "frac %.3f"%d["roofline"]["frac"])
-PY
-done
-for i in 1 2 3; do timeout 100 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver$i.json 2> $OUT/bench_driver$i.err; done
 cd /tmp
 for w in $PROF_WL; do
   CMD="python $ROOT/bench.py --workload $w --steps 512 --warmup 128 --no-cpu-baseline"   # whole fused launches only
@@ -42,5 +33,18 @@ PY
     grep -E "k_roll7|k_step" $OUT/pmc_${c}_$w.txt
   done
   rm -rf $OUT/prof_$w $OUT/pmc_*_$w
+  # the bench lines below quote kernel time / HBM traffic from profiles/r3: give them THIS build's (the box's copy of the tree is scratch)
+  cp $OUT/kernel_stats_$w.csv $OUT/meta_$w.json $OUT/pmc_FETCH_SIZE_$w.txt $OUT/pmc_WRITE_SIZE_$w.txt $ROOT/profiles/r3/
   head -3 $OUT/kernel_stats_$w.csv | cut -c1-160
 done
+cd $ROOT
+for w in empty8x8 doorkey8x8 lavacrossing_full gotoredball; do
+  extra="--no-cpu-baseline"; [ $w = empty8x8 ] && extra=""
+  timeout 300 python bench.py --workload $w --steps 2048 --warmup 256 $extra > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+  python - $OUT/bench_$w.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(d["config"]["env_id"], "%.3f G steps/s"%(d["value"]/1e9), "%.2f us/step"%(d["ms_per_step"]*1e3), "frac %.3f"%d["roofline"]["frac"])
+PY
+done
+for i in 1 2 3; do timeout 100 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver$i.json 2> $OUT/bench_driver$i.err; done
