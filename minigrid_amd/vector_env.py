@@ -56,7 +56,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                  max_steps: Optional[int] = None, stream: Optional[int] = None, output: str = "numpy",
                  image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
                  death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True,
-                 spare_ring: int = 0, traj_slots: int = 0, stuck_place_agent: str = "raise"):
+                 spare_ring: int = 0, traj_slots: int = 0, stuck_place_agent: str = "raise", final_obs: bool = False):
         if obs_mode not in _OBS_MODES:
             raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
         # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
@@ -73,10 +73,19 @@ class MiniGridVecEnv(_VectorEnvBase):
         # and the redrawn map is accepted -- usable at batch sizes where some env always meets the case, but not a reference behaviour.
         if stuck_place_agent not in ("raise", "redraw"):
             raise ValueError("stuck_place_agent must be 'raise' or 'redraw'")
+        # autoreset_mode="same_step" resets inside the step kernel: the returned observation is the new episode's first one and the
+        # terminal observation is gone (what Gymnasium 0.28/0.29 users saw as info["final_observation"]).  final_obs=True keeps it, the
+        # way Gymnasium 1.x's SAME_STEP vector envs report it -- info["final_obs"] (object array of observation dicts) and
+        # info["_final_obs"] (mask) -- by composition instead: the step kernel runs with NEXT_STEP semantics (the terminal observation
+        # is its output), and the envs that finished are reset and observed by a second, masked launch before step() returns.
+        # One launch per step(): the fused entry points refuse this mode.
+        if final_obs and autoreset_mode != "same_step":
+            raise ValueError("final_obs=True belongs to autoreset_mode='same_step'")
+        self._final_obs = bool(final_obs)
         # what pickling needs to build the same env again (__getstate__)
         self._ctor = dict(env_id=env_id, num_envs=int(num_envs), autoreset_mode=autoreset_mode, rng=rng, env_index_base=int(env_index_base),
                           max_steps=max_steps, output=output, spare_ring=int(spare_ring), traj_slots=int(traj_slots),
-                          stuck_place_agent=stuck_place_agent)
+                          stuck_place_agent=stuck_place_agent, final_obs=bool(final_obs))
         s: EnvSpec = _spec(env_id)
         if stuck_place_agent == "redraw":
             if s.env_kind != ENV_LEVELGEN:
@@ -108,7 +117,7 @@ class MiniGridVecEnv(_VectorEnvBase):
             abi_version=B.MG_ABI_VERSION, env_kind=s.env_kind, width=s.width, height=s.height, max_steps=s.max_steps,
             see_through_walls=int(s.see_through_walls), agent_view_size=self.agent_view_size,
             no_death_mask=no_death_mask, death_cost=self.death_cost,
-            obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET[autoreset_mode],
+            obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET["next_step" if final_obs else autoreset_mode],
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
@@ -356,17 +365,55 @@ class MiniGridVecEnv(_VectorEnvBase):
             rc = self._lib.mg_step(self._h, self._p(a), dt, 0)
         B.check(rc, self._h)
         obs, rew, term, trunc = self._collect()
+        if self._final_obs:
+            return self._same_step_with_final_obs(obs, rew, term, trunc)
         return obs, rew, term, trunc, {}
+
+    def _same_step_with_final_obs(self, obs, rew, term, trunc):
+        """SAME_STEP by composition (see __init__): `obs` is the step kernel's NEXT_STEP output, i.e. the terminal observation for the envs
+        that just finished.  Those envs take their next episode now (masked reset, each continuing its own stream) and the returned
+        observation shows it; the terminal one goes to info["final_obs"]."""
+        n = self.num_envs
+        if self.output == "torch":
+            import torch
+            done = term | trunc
+            if not bool(done.any()):
+                return obs, rew, term, trunc, {}
+            # the outputs are views of trajectory slot 0, which the reset launch rewrites: keep what this step reported
+            rew, term, trunc = rew.clone(), term.clone(), trunc.clone()
+            idx = torch.nonzero(done).flatten()
+            final = obs[idx].clone() if self.image_only else {k: v[idx].clone() for k, v in obs.items()}
+            mask = done.to(torch.uint8).cpu().numpy()
+            B.check(self._lib.mg_reset(self._h, None, self._p(np.ascontiguousarray(mask))), self._h)
+            new_obs, _, _, _ = self._collect()
+            return new_obs, rew, term, trunc, {"final_obs": final, "final_obs_indices": idx, "_final_obs": done}
+        done = term | trunc
+        if not done.any():
+            return obs, rew, term, trunc, {}
+        idx = np.flatnonzero(done)
+        fo = np.full(n, None, dtype=object)
+        for i in idx:
+            fo[i] = obs[i] if self.image_only else {"image": obs["image"][i], "direction": obs["direction"][i], "mission": obs["mission"][i]}
+        B.check(self._lib.mg_reset(self._h, None, self._p(np.ascontiguousarray(done.astype(np.uint8)))), self._h)
+        new_obs, _, _, _ = self._collect()
+        return new_obs, rew, term, trunc, {"final_obs": fo, "_final_obs": done, "final_info": np.full(n, None, dtype=object), "_final_info": done}
+
+    def _no_fused_with_final_obs(self):
+        if self._final_obs:
+            raise ValueError("final_obs=True reports terminal observations from step(), one launch at a time; "
+                             "the fused entry points need autoreset_mode='same_step' without it (or 'next_step')")
 
     def rollout(self, steps: int, action_seed: int = 0, fused: bool = False):
         """`steps` lockstep steps under a uniform-random policy generated on the device (the loop of
         minigrid/benchmark.py:36-43).  fused: up to `max_fused_steps` steps per kernel launch, the grids resident in
         LDS; step j writes trajectory slot (steps-1-j) % traj_slots, so slot 0 is the last step."""
+        self._no_fused_with_final_obs()
         B.check(self._lib.mg_rollout(self._h, int(steps), int(action_seed), int(fused)), self._h)
 
     def rollout_block(self, steps: int, action_seed: int = 0, slot0: Optional[int] = None):
         """ONE fused launch of `steps` <= max_fused_steps steps of the device policy; step j lands in trajectory slot slot0 - j
         (default slot0 = steps - 1), so the launch's step records are the contiguous slots [slot0 - steps + 1, slot0]."""
+        self._no_fused_with_final_obs()
         B.check(self._lib.mg_rollout_block(self._h, int(steps), int(action_seed), int(steps - 1 if slot0 is None else slot0)), self._h)
 
     def block_view(self, slot_lo: int, nslots: int):
@@ -382,6 +429,7 @@ class MiniGridVecEnv(_VectorEnvBase):
         """The fused loop for caller-supplied actions: uint8 (T, num_envs), numpy or a CUDA tensor.  Identical to T
         step() calls; outputs of the step k calls before the last are in trajectory slot k (trajectory() /
         torch_outputs(k))."""
+        self._no_fused_with_final_obs()
         if hasattr(actions, "data_ptr"):
             import torch
             a = actions

@@ -98,6 +98,64 @@ def test_same_step_autoreset_equals_the_oracle(env_id, full, max_steps):
     env.close()
 
 
+@pytest.mark.parametrize("env_id,full,max_steps", [("MiniGrid-DoorKey-8x8-v0", False, 6), ("MiniGrid-LavaCrossingS9N1-v0", True, 30),
+                                                   ("BabyAI-PickupLoc-v0", False, None), ("MiniGrid-Dynamic-Obstacles-6x6-v0", False, None),
+                                                   ("MiniGrid-Empty-8x8-v0", False, 5)])
+@pytest.mark.parametrize("output", ["numpy", "torch"])
+def test_same_step_with_final_obs_equals_the_oracle(env_id, full, max_steps, output):
+    """Gymnasium 1.x's SAME_STEP report: the step that ends an episode returns the next episode's first observation AND the ended
+    episode's last one in info["final_obs"] / info["_final_obs"].  Built by composition (vector_env._same_step_with_final_obs), so it
+    also covers the levels the in-kernel SAME_STEP refuses (sentence levels, DynamicObstacles).  Oracle: a step without autoreset (its
+    observation IS the terminal one), then a masked reset of the envs that finished, each continuing its own stream."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 700
+    kw = {} if max_steps is None else {"max_steps": max_steps}
+    env = mg.make_vec(env_id, n, obs_mode="full" if full else "partial", autoreset_mode="same_step", final_obs=True, output=output, **kw)
+    orc = O.OracleVec(env_id, n, full_obs=full, **kw)
+    obs, _ = env.reset(seed=8)
+    arr = (lambda x: x.cpu().numpy()) if output == "torch" else (lambda x: np.asarray(x))
+    assert (arr(obs["image"]) == orc.reset(seeds=np.arange(8, 8 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(4)
+    nact = 3 if "Dynamic" in env_id else 7
+    ended = 0
+    for t in range(90 if max_steps is not None else 260):
+        a = rng.integers(0, nact, n).astype(np.uint8) if nact == 3 else rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs, rew, term, trunc, info = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=0)
+        done = oterm | otrunc
+        assert arr(rew).tobytes() == orew.tobytes() and (arr(term) == oterm).all() and (arr(trunc) == otrunc).all(), (env_id, t)
+        want, want_dir = oo.copy(), od.copy()
+        if done.any():
+            assert (arr(info["_final_obs"]) == done).all(), (env_id, t)
+            idx = np.flatnonzero(done)
+            if output == "torch":
+                assert (arr(info["final_obs_indices"]) == idx).all()
+                assert (arr(info["final_obs"]["image"]) == oo[idx]).all() and (arr(info["final_obs"]["direction"]) == od[idx]).all(), (env_id, t)
+            else:
+                for i in idx:
+                    assert (info["final_obs"][i]["image"] == oo[i]).all() and info["final_obs"][i]["direction"] == od[i], (env_id, t, i)
+                assert all(info["final_obs"][i] is None for i in np.flatnonzero(~done)[:5])
+            if env.sentence and output == "numpy":
+                ms = orc.mission_strings()
+                assert all(info["final_obs"][i]["mission"] == ms[i] for i in idx), (env_id, t)
+            o2, d2, _ = orc.reset(seeds=None, mask=done)
+            want[done], want_dir[done] = o2[done], d2[done]
+            ended += int(done.sum())
+        else:
+            assert info == {}
+        assert (arr(obs["image"]) == want).all() and (arr(obs["direction"]) == want_dir).all(), (env_id, t)
+        if env.sentence and output == "numpy":
+            assert (obs["mission"] == orc.mission_strings()).all(), (env_id, t)
+    assert ended > (n if max_steps is not None else 20)
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :6] == a2[:, :6]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    with pytest.raises(ValueError):
+        env.rollout(8, fused=True)
+    env.close()
+
+
 def test_same_step_autoreset_is_refused_where_it_is_not_built():
     import minigrid_amd as mg
     for env_id in ("MiniGrid-Dynamic-Obstacles-6x6-v0", "BabyAI-BossLevel-v0"):
