@@ -141,7 +141,10 @@ typedef enum mg_autoreset_mode {
   MG_AUTORESET_NEXT_STEP = 0, /* Gymnasium >= 1.0 default: the step after a done resets, ignores its action, reward 0 */
   MG_AUTORESET_DISABLED = 1,  /* never reset implicitly; the caller uses mg_reset with a mask                         */
   MG_AUTORESET_SAME_STEP = 2  /* gymnasium 0.28 / 0.29 vector semantics (the reference pins gymnasium >= 0.28.1): the step that ends an
-                               * episode also resets the env -- obs = the new episode's first, reward / flags = the ended one's */
+                               * episode also resets the env -- obs = the new episode's first, reward / flags = the ended one's.
+                               * (The ended episode's last observation is not produced in this mode: a caller that wants it -- Gymnasium
+                               * 1.x's info["final_obs"] -- steps with NEXT_STEP and resets the finished envs with a masked mg_reset
+                               * before the next step; minigrid_amd/vector_env.py does that for final_obs=True.) */
 } mg_autoreset_mode;
 
 typedef enum mg_rng_mode {
