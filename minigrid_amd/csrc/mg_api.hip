@@ -331,21 +331,36 @@ static int launch_step(mg_env* e, StepParams& P) {
   if (e->live_gen) {
     // (1) draw, in place, the episodes of the envs the previous launch left RESET_PENDING (they come out FRESH and
     //     are only observed by this launch); (2) before a real step, move the obstacles of everyone else
+    // (1) and (2) touch disjoint envs -- (1) the ones flagged RESET_PENDING, (2) everyone else (an env whose flag turns FRESH under (2)'s
+    // eyes is skipped either way; (2) writes back only the grids it moved) -- so before a real step they CAN run side by side: the redraw
+    // on the generator stream, the moves on the step stream, the step launch behind both (MG_LIVE_OVERLAP=1).  Measured
+    // (profiles/r3/dynobs_overlap.txt, 16x16 x 65 536): 72.5 us per step side by side, 71.5 one after the other -- both kernels are
+    // bound by the SIMDs' issue rate, not by latency, so sharing the machine buys nothing.  Off by default.
+    static const bool overlap_ok = [] { const char* s = getenv("MG_LIVE_OVERLAP"); return s && atoi(s) != 0; }();
+    bool live_on_gen = false;
     if (e->launches > 0) {
-      int rc = launch_refill(e, 0, e->launches + 1u, true, e->stream);
+      live_on_gen = overlap_ok && P.phase == PHASE_STEP;
+      if (live_on_gen) {
+        HIP_TRY(e, hipEventRecord(e->ev_step[0], e->stream));
+        HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_step[0], 0));
+      }
+      int rc = launch_refill(e, 0, e->launches + 1u, true, live_on_gen ? e->gen_stream : e->stream);
       if (rc) return rc;
+      if (live_on_gen) HIP_TRY(e, hipEventRecord(e->ev_gen[0], e->gen_stream));
     }
     if (P.phase == PHASE_STEP) {
-      const int nb = (e->N + MOVE_EPB - 1) / MOVE_EPB;
-      const size_t mlds = (size_t)MOVE_EPB * (size_t)(e->CS + 4);     // the wave's staged grids (DynamicObstacles: at most 16 x 16)
+      static const int epb = [] { const char* s = getenv("MG_MOVE_EPB"); const int v = s ? atoi(s) : 0; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : MOVE_EPB; }();
+      const int nb = (e->N + epb - 1) / epb;
+      const size_t mlds = (size_t)epb * (size_t)(e->CS + 4);          // the wave's staged grids (DynamicObstacles: at most 16 x 16)
       if (e->cfg.rng_mode == MG_RNG_PHILOX)
         hipLaunchKernelGGL(k_move_obstacles<PhiloxStream>, dim3(nb), dim3(64), mlds, e->stream, e->grid, e->agent, e->rng, e->aux,
-                           e->N, e->W, e->H, e->CS, e->cfg.num_dists);
+                           e->N, e->W, e->H, e->CS, e->cfg.num_dists, epb);
       else
         hipLaunchKernelGGL(k_move_obstacles<Pcg64Stream>, dim3(nb), dim3(64), mlds, e->stream, e->grid, e->agent, e->rng, e->aux,
-                           e->N, e->W, e->H, e->CS, e->cfg.num_dists);
+                           e->N, e->W, e->H, e->CS, e->cfg.num_dists, epb);
       HIP_TRY(e, hipGetLastError());
     }
+    if (live_on_gen) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gen[0], 0));
   }
   { int rc = batch_admit(e, P.phase, P.T); if (rc) return rc; }
   {

@@ -87,11 +87,11 @@ __global__ void k_verify(const VerifyParams V) {
 constexpr int MOVE_EPB = 16;
 template <class RNG>
 __global__ void __launch_bounds__(64) k_move_obstacles(uint8_t* grid, uint64_t* agent, uint64_t* rng, uint64_t* obst, int N, int W, int H, int CS,
-                                                       int n_obst) {
+                                                       int n_obst, int epb) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The per-env chain (PCG64 draw -> cell test -> next draw) is latency-bound and sequential: MOVE_EPB = 16 envs per wavefront
   // (the other lanes only help with the staging) puts four wavefronts on every SIMD at 65 536 envs instead of one.
-  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * MOVE_EPB, nvalid = min(MOVE_EPB, N - env0);
+  const int lane = (int)threadIdx.x, env0 = (int)blockIdx.x * epb, nvalid = min(epb, N - env0);
   const int GS = CS + 4, cpe = CS >> 4, nchunks = nvalid * cpe;
   uint4* live = (uint4*)(grid + (size_t)env0 * CS);
   for (int c = lane; c < nchunks; c += 64) {
