@@ -11,8 +11,9 @@
 //    batch without four lanes per env replicating every step's work.  The last wave owns the final state and writes it back.
 //  * The observation leaves the lane-per-env domain as CELL CODES, not as bytes: each lane stages its env's 49 one-byte codes
 //    (already masked by process_vis, in output order) in LDS (3.1 KB per wave instead of the 9.4 KB byte stream), and the encode
-//    runs in OUTPUT space: lane c of an iteration produces the 16 bytes [16 c, 16 c + 16) of the wave's contiguous observation
-//    stream -- six code -> (type, colour, state) lookups, five packs, four byte-aligns -- and stores them with one 16 B store.
+//    runs in OUTPUT space: lane u of a round takes dword u of the code stream (four cells), does four code -> (type, colour, state)
+//    lookups and three byte permutes and stores the 12 bytes [12 u, 12 u + 12) of the wave's contiguous observation stream with one
+//    store (obs7_quad; obs7_chunk, 16 bytes per lane with a phase, for a ragged last workgroup).
 //    Nothing is assembled per env in registers (k_step held 37 packed dwords + 10 copy-out quads per lane).
 //  * The view is handled as seven LINES of seven codes (2 VGPRs each) end to end: orientation by v_perm_b32 (byte reversal, the
 //    8 x 8 byte transpose between "line = view column" and "line = view row"), opacity rows by v_dot4_u32_u8, process_vis rows
@@ -328,7 +329,7 @@ constexpr int ROLL_MAX_WAVES = 4;
 // dynamics alone, provided the encode finds its input ready: every wave keeps, next to its row-major copy of the 64 grids (what the
 // dynamics index), a second image of them in IMAGE order -- one contiguous code stream, W*H bytes per env, k = x*H + y -- that follows
 // the grids cell by cell (the one dirty cell of a step; a reset copies the shadow spare's image stream).  A step patches the agent's
-// cell into the stream, runs the same output-space encode as the 7x7 view over it (obs7_chunk: lane c = bytes [16 c, 16 c + 16) of the
+// cell into the stream, runs the same output-space encode as the 7x7 view over it (obs7_quad: lane u = bytes [12 u, 12 u + 12) of the
 // wave's observations) and restores the cell.  Round 2 ran FullyObs with four lanes per env replicating the dynamics (k_step<1,.,4>).
 MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {          // gt[x*H + y] = g[y*W + x]
   for (int x = 0; x < W; x++)
@@ -345,10 +346,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;
-  // obs7_chunk addresses the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
+  // obs7_quad / obs7_chunk address the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
   // share (one-step launches, Env.step): there is nothing to split in time, so ONE wave runs the step up to the staged codes and ALL waves
-  // of the workgroup share the output-space encode behind one barrier (a quarter of the ten rounds each); the stepping wave owns the state.
+  // of the workgroup share the output-space encode behind one barrier (a quarter of the 784 cell quads each); the stepping wave owns the state.
   // Which wave steps rotates with the workgroup index (P.share - 1 = the shift): the workgroups resident on one CU then step on different
   // SIMDs instead of all on the one that holds every workgroup's wave 0.
   const bool share = P.share != 0;
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       ob[o_act] = (uint8_t)act_in;
       if constexpr (GG == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = sent0; sp[1] = sent1; }
     }
-    // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = 16-byte chunk) ----
+    // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = four cells = 12 bytes) ----
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
     MG_MARK("codes");
     uint32_t gt_pos = 0, gt_old = 0;
