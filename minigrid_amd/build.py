@@ -73,6 +73,18 @@ def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = F
     sanitizer build, profiles/asan_build.py) -- selected at run time with MINIGRID_AMD_LIB."""
     if lib == LIB and not force and not _stale():
         return LIB
+    # one builder at a time per tree (N ranks of a multi-GPU job importing the package at once must not compile into the same
+    # object directory): the others wait here and find the library up to date when they get the lock
+    import fcntl
+    os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(OBJDIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if lib == LIB and not force and not _stale():
+            return LIB
+        return _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch)
+
+
+def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if missing_hipcc_ok and os.path.exists(lib):
