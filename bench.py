@@ -11,7 +11,7 @@ step writing its full outputs (obs u8 (N,7,7,3), reward f64, terminated, truncat
 NEXT_STEP autoreset inside the timed region.  Env state and all buffers are resident in HBM before timing starts.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (k_step): ALGORITHMIC bytes per launch (324 B/env-step partial obs,
+  roofline     — dominant kernel (k_roll7; k_step for the other observation modes): ALGORITHMIC bytes per launch (324 B/env-step partial obs,
                  W*H*3*2+30 for FullyObs) / average launch period measured with HIP events on the launch stream.
   cpu_baseline — the oracle's C port (oracle/minigrid_oracle.c) timed on this host's cores on a bounded sample.
 """
