@@ -328,6 +328,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # ... and the job's: the slowest rank
         dt = float(t.item())
     counters = env.counters()
+    # the step kernel this configuration runs (mg_api.hip: k_roll7 for the default 7x7 view and for FullyObs of grids up to 341 cells)
+    kname = ("k_roll7" if (obs_mode == "partial" and args.view == 7) else
+             "k_roll7<., FullyObs>" if (obs_mode == "full" and env.width * env.height <= 341) else "k_step")
 
     if rank == 0:
         total_envs = n_per_gpu * world
@@ -350,8 +353,8 @@ def main():
             "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
                        "env_id": env_id, "envs_per_gpu": n_per_gpu, "obs_mode": obs_mode,
-                       "launch": (f"fused: {spl} steps per k_step launch, state resident in LDS, each step's outputs to its own trajectory slot"
-                                  if spl > 1 else "one k_step launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
+                       "launch": (f"fused: {spl} steps per {kname} launch, state resident in LDS, each step's outputs to its own trajectory slot"
+                                  if spl > 1 else f"one {kname} launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "steps_per_launch": spl,
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"],
                        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
@@ -361,10 +364,10 @@ def main():
                                                        "communication stream overlapped with the next launch" % spl) if gather and fused else
                                                       "one all_gather_into_tensor of the step record per step" if gather else "none on the data path"),
                                        "collectives_rank0": (senv.collectives if senv is not None else 0)}},
-            "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else "k_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic_bytes(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,
-                         "traffic_unit": "bytes per k_step launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
+                         "traffic_unit": "bytes per step-kernel launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
                          "traffic_source": pmc_traffic_source(args.workload, n_per_gpu, spl),
                          "launches": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
