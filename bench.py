@@ -2,8 +2,9 @@
 """bench.py — env-steps/s of the MI355X-native MiniGrid hot path under a uniform-random policy.
 
     python bench.py --gpus 1 --steps 1000 --warmup 100
+    python bench.py --gpus 8 --steps 1000 --warmup 100          # no RANK/WORLD_SIZE in the environment: spawns the 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                  # the driver's form: one rank per GPU, RCCL (backend "nccl")
 
 One "step" = one lockstep pass of MiniGridEnv.step()+gen_obs() over the whole batch (BASELINE.json configs[1]:
 MiniGrid-Empty-8x8-v0, 65 536 envs per GPU, 7x7x3 partial obs), actions drawn on the device (Philox4x32-10), every
@@ -11,8 +12,12 @@ step writing its full outputs (obs u8 (N,7,7,3), reward f64, terminated, truncat
 NEXT_STEP autoreset inside the timed region.  Env state and all buffers are resident in HBM before timing starts.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (k_roll7; k_step for the other observation modes): ALGORITHMIC bytes per launch (324 B/env-step partial obs,
-                 W*H*3*2+30 for FullyObs) / average launch period measured with HIP events on the launch stream.
+  roofline     — dominant kernel (k_roll7; k_step for the other observation modes).  achieved = the HBM bytes a launch REALLY moves
+                 (rocprofv3 FETCH_SIZE / WRITE_SIZE counters of a committed pass of this same launch shape; without one, the analytic
+                 floor: every output byte + the state once per launch) / the average launch duration measured live with HIP events on
+                 the launch stream; frac = achieved / 8 TB/s, <= 1 by construction.  SURVEY.md section 8(d)'s bytes (324 B/env-step:
+                 they price a grid re-read per step that a fused launch, with the grids resident in LDS, does not make) are reported
+                 next to it as roofline.survey_8d -- a fraction on those can exceed 1 and is not the headline.
   cpu_baseline — the oracle's C port (oracle/minigrid_oracle.c) timed on this host's cores on a bounded sample.
 """
 from __future__ import annotations
@@ -61,34 +66,41 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, v
     return b
 
 
-def _profile_dirs(workload: str, n_per_gpu: int, spl: int):
-    """profiles/r*/ directories whose committed rocprofv3 passes of `workload` were taken at THIS batch size and THIS steps-per-
-    launch (profiles/collect.sh writes the run's parameters to meta_<workload>.json next to the counters)."""
+def _profile_metas(workload: str, n_per_gpu: int, spl: int):
+    """Committed rocprofv3 passes of `workload` taken at THIS batch size and THIS steps-per-launch: (directory, meta, suffix) for every
+    profiles/r*/meta_<workload><suffix>.json that matches (suffix "" = the 32-step launches of a long run, "_spl20" = the driver-sized
+    run; the collection scripts write the run's parameters into the meta file next to the counters), oldest round first."""
     import glob
     out = []
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"meta_{workload}*.json"))):
+        suffix = os.path.basename(f)[len(f"meta_{workload}"):-len(".json")]
+        if suffix and not suffix.startswith("_spl"):
+            continue                                   # meta_<workload>_<other workload suffix>.json of a longer name
         try:
-            meta = json.load(open(os.path.join(d, f"meta_{workload}.json")))
+            meta = json.load(open(f))
         except Exception:
             continue
         if int(meta.get("envs_per_gpu", -1)) == n_per_gpu and int(meta.get("steps_per_launch", -1)) == spl:
-            out.append(d)
+            out.append((os.path.dirname(f), meta, suffix))
     return out
 
 
+def _pmc_files(d: str, workload: str, suffix: str):
+    return [os.path.join(d, f"pmc_{c}_{workload}{suffix}.txt") for c in ("FETCH_SIZE", "WRITE_SIZE")]
+
+
 def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
-    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload>.txt, separate --pmc runs, written by profiles/collect.sh).
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload><suffix>.txt, separate --pmc runs, written by profiles/collect*.sh).
     Units and gfx950 correction as MI355X_MICROARCH.md prescribes: the counters are in KiB (x1024); FETCH_SIZE reads
     exactly half of a wide (16 B/lane) coalesced read stream on gfx950, so it is doubled; WRITE_SIZE is taken as is.
     Counters cannot be read from inside the timed process, so this is the committed measurement -- of a run with the same
     batch size and steps per launch (the per-call maximum = the full launches) -- or None."""
     import re
     best = None
-    for d in _profile_dirs(workload, n_per_gpu, spl):
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl):
         vals = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            f = os.path.join(d, f"pmc_{c}_{workload}.txt")
+        for c, f in zip(("FETCH_SIZE", "WRITE_SIZE"), _pmc_files(d, workload, suffix)):
             if not os.path.exists(f):
                 break
             for line in open(f):
@@ -104,16 +116,23 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
 
 def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int):
     """Average duration of a FULL step launch / steps per launch from the committed `rocprofv3 --kernel-trace --stats` summary of
-    this command (profiles/<round>/kernel_stats_<workload>.csv; meta_<workload>.json holds the full-launch average computed
-    from the trace by profiles/collect.sh), or None."""
+    this command (profiles/<round>/kernel_stats_<workload><suffix>.csv; meta_<workload><suffix>.json holds the full-launch average
+    computed from the trace by the collection script), or None."""
     best = None
-    for d in _profile_dirs(workload, n_per_gpu, spl):
+    for _d, meta, _suffix in _profile_metas(workload, n_per_gpu, spl):
         try:
-            meta = json.load(open(os.path.join(d, f"meta_{workload}.json")))
             best = float(meta["full_launch_avg_us"]) / spl
         except Exception:
             pass
     return best
+
+
+def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int):
+    src = None
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl):
+        if all(os.path.exists(f) for f in _pmc_files(d, workload, suffix)):
+            src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}{suffix}.txt"
+    return src
 
 
 def reference_python_baseline(workload: str):
@@ -134,14 +153,6 @@ def reference_python_baseline(workload: str):
         except Exception:
             pass
     return best
-
-
-def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int):
-    src = None
-    for d in _profile_dirs(workload, n_per_gpu, spl):
-        if all(os.path.exists(os.path.join(d, f"pmc_{c}_{workload}.txt")) for c in ("FETCH_SIZE", "WRITE_SIZE")):
-            src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}.txt"
-    return src
 
 
 def cpu_baseline_rgb(env_id: str, obs_mode: str, budget_s: float = 10.0):
@@ -222,7 +233,97 @@ def np_prod(shape):
     return p
 
 
-def main():
+def _ref_live_worker(a):
+    env_id, obs_mode, seconds, seed = a
+    import gymnasium as gym
+    import minigrid  # noqa: F401  (registers the ids)
+    import numpy as np
+    from minigrid.wrappers import FullyObsWrapper, ImgObsWrapper
+    env = gym.make(env_id)
+    env = FullyObsWrapper(env) if obs_mode == "full" else ImgObsWrapper(env)
+    env.reset(seed=seed)
+    acts = np.random.default_rng(seed).integers(0, 7, 4096)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for a_ in acts:
+            _, _, term, trunc, _ = env.step(int(a_))
+            if term or trunc:
+                env.reset()
+        n += len(acts)
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            return n / dt
+
+
+def reference_python_live(workload: str, seconds: float = 3.0):
+    """The reference's own loop (minigrid/benchmark.py:32-43 plumbing, random actions), timed HERE when the reference package and a
+    real gymnasium are importable on this node (they are not in the build image or on the round's GPU boxes: then the committed
+    build-container measurement is quoted instead, see reference_python_baseline).  Stand-alone copy of profiles/ref_python_baseline.py's
+    loop; never reads /root/reference or the oracle's gymnasium stand-in."""
+    try:
+        import gymnasium as gym
+        import minigrid  # noqa: F401
+        if "gym_shim" in (getattr(gym, "__file__", "") or ""):
+            return None
+    except Exception:
+        return None
+    import multiprocessing as mp
+    env_id, _n, obs_mode = WORKLOADS[workload]
+    if obs_mode not in ("partial", "full"):
+        return None
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    one = _ref_live_worker((env_id, obs_mode, seconds, 0))
+    with mp.get_context("fork").Pool(cores) as pool:
+        allc = sum(pool.map(_ref_live_worker, [(env_id, obs_mode, seconds, s) for s in range(cores)]))
+    return {"one_core": one, "all_cores": allc, "cores": cores, "unit": "env-steps/s", "kind": "reference",
+            "how": "the installed minigrid package on this node's host cores, benchmark.py:32-43 loop with random actions, "
+                   f"{seconds:.0f} s per sample"}
+
+
+def mg_environment():
+    """Every tuning / debugging switch this process runs under: the MG_* and MINIGRID_AMD_* environment variables (the library reads
+    ~15 MG_* knobs at create time) -- printed into the JSON line so that a number produced under a stray knob says so."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(("MG_", "MINIGRID_AMD_"))}
+
+
+class _StubEnv:
+    """--stub: a stand-in for the vector env that touches no GPU, so that the launcher, the rendezvous, the barriers, the max-over-ranks
+    clock and the JSON line can be exercised on a CPU-only host (tests/test_bench_cpu.py, backend gloo).  Its `value` is meaningless and
+    the line says so (config.stub = true)."""
+    max_fused_steps, width, height, image_shape = 32, 8, 8, (7, 7, 3)
+
+    def __init__(self, n, base):
+        self.num_envs, self.env_index_base = n, base
+
+    def reset(self, seed=0): pass
+    def sync(self): pass
+    def timer_start(self): self._t = time.perf_counter()
+    def timer_stop(self): return (time.perf_counter() - self._t) * 1e3
+    def rollout(self, k, action_seed=0, fused=True): time.sleep(1e-5 * k)
+    def counters(self): return {"episodes": 0}
+    def close(self): pass
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks here -- one process per GPU under
+    torch.distributed.run (127.0.0.1 rendezvous on a free port), the same command line the driver uses -- and pass rank 0's line through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -238,34 +339,43 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets the multi-process path be exercised "
                          "on a box with fewer GPUs than ranks: ranks then share devices round-robin)")
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help="no GPU: a stub env; exercises the launcher / barriers / JSON line only")
+    args = ap.parse_args(argv)
 
+    have_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_launcher:
+        raise SystemExit(spawn_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (one rank per GPU)")
 
     import torch
     import torch.distributed as dist
-    if args.backend == "gloo":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+    use_gpu = not args.stub
+    if use_gpu:
+        if args.backend == "gloo":
+            local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-
-    import minigrid_amd as mg
+        assert dist.get_world_size() == args.gpus
 
     env_id, n_per_gpu, obs_mode = WORKLOADS[args.workload]
     if args.envs_per_gpu:
         n_per_gpu = args.envs_per_gpu
     if args.obs_mode:
         obs_mode = args.obs_mode
-    gather = bool(args.gather_obs and world > 1)
-    if world > 1:
+    gather = bool(args.gather_obs and world > 1 and use_gpu)
+    senv = None
+    build_info = "stub"
+    if not use_gpu:
+        env = _StubEnv(n_per_gpu, rank * n_per_gpu)
+    elif world > 1:
         # weak scaling: the global batch is world x n_per_gpu envs; rank g owns the contiguous block g (seed = global
         # env index), no data-path collective unless --gather-obs asks for the optional all-gather of the obs tensor
         from minigrid_amd.sharded import ShardedVecEnv
@@ -274,8 +384,11 @@ def main():
         env = senv.local
         assert env.env_index_base == rank * n_per_gpu and env.num_envs == n_per_gpu
     else:
-        senv = None
+        import minigrid_amd as mg
         env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
+    if use_gpu:
+        from minigrid_amd import _binding
+        build_info = _binding.load().mg_build_info().decode()
     fused = bool(args.fused)
     spl = min(env.max_fused_steps, args.steps) if fused else 1          # steps per k_step launch in the timed region
     env.reset(seed=0)
@@ -297,22 +410,26 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
     env.timer_start()                    # (the warm-up also warms the event pair the timed region uses)
     run(args.warmup, 1)
     env.timer_stop()
     env.sync()
-    barrier()
-    env.timer_start()                    # HIP event on the step stream ...
-    t0 = time.perf_counter()             # ... and the host clock, both opened before the first launch is enqueued
+    barrier()                            # opening side of the bracket: barrier + torch.cuda.synchronize()
+    env.timer_start()                    # HIP event on the step stream (an enqueue; measurement apparatus, not step work) ...
+    t0 = time.perf_counter()             # ... and the host clock, opened before the first launch is enqueued
     run(args.steps, 2)
     ev_ms = env.timer_stop()             # event after the last launch on the same stream (waits for it): the launches' own time
-    env.sync()                           # + the generator stream: every episode consumed in the region is drawn again
+    env.sync()                           # + the generator stream: every episode consumed in the region is drawn again; device error words
     if gather:
         senv.finish()                    # + the communication stream: every collective issued in the region has completed
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0        # THIS rank's clock (>= the event time): its K steps are complete on the device
+    dt = time.perf_counter() - t0        # THIS rank's K steps are complete on the device: every stream that carried their work (step,
+                                         # generator, communication) has been waited for, one wait each (VERDICT r3 "next" #8)
+    if use_gpu:
+        torch.cuda.synchronize()         # closing side of the bracket, device-wide: nothing is outstanding, so this only costs host time;
+    dt_dev_sync = time.perf_counter() - t0   # the clock INCLUDING it is printed too (host_ms_incl_device_sync)
     if world > 1:
         dist.barrier()                   # the closing barrier of the bracket; the job's time is the MAX over the ranks' clocks (below) --
                                          # the ranks started together, so that is when the slowest one finished; the latency of the
@@ -320,13 +437,13 @@ def main():
 
     per_rank_us = [dt / args.steps * 1e6]
     if world > 1:
-        dev = "cuda" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        allt = torch.zeros(world, dtype=torch.float64, device=dev)
+        dev = "cuda" if (args.backend == "nccl" and use_gpu) else "cpu"
+        t = torch.tensor([dt, dt_dev_sync], dtype=torch.float64, device=dev)
+        allt = torch.zeros(2 * world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allt, t)                       # every rank's own clock ...
-        per_rank_us = [float(x) / args.steps * 1e6 for x in allt.cpu()]
+        per_rank_us = [float(x) / args.steps * 1e6 for x in allt.cpu()[0::2]]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # ... and the job's: the slowest rank
-        dt = float(t.item())
+        dt, dt_dev_sync = float(t[0].item()), float(t[1].item())
     counters = env.counters()
     # the step kernel this configuration runs (mg_api.hip: k_roll7 for the default 7x7 view and for FullyObs of grids up to 341 cells)
     kname = ("k_roll7" if (obs_mode == "partial" and args.view == 7) else
@@ -339,16 +456,22 @@ def main():
         n_launch = -(-args.steps // spl)
         launch_s = (ev_ms / 1e3) / n_launch             # average k_step launch period on its stream (HIP events)
         step_s = (ev_ms / 1e3) / args.steps
-        bytes_per_launch = bpe * n_per_gpu * args.steps / n_launch      # (the last launch of the region may be shorter)
-        achieved = bytes_per_launch / launch_s / 1e9    # algorithmic bytes per launch / average launch duration
+        steps_per_launch_avg = args.steps / n_launch    # (the last launch of the region may be shorter)
+        survey_bytes_per_launch = bpe * n_per_gpu * steps_per_launch_avg
         obe = int(np_prod(env.image_shape))
         # what a fused launch has to move per env-step: the outputs (obs + reward 8 + 5 flag/id bytes); the grid and the
         # agent record are read and written once per launch, not per step
         hbm_min = obe + 13 + (2 * (env.width * env.height) + 16) / spl
+        floor_bytes_per_launch = hbm_min * n_per_gpu * steps_per_launch_avg
+        quotable = not args.obs_mode and args.view == 7 and use_gpu
+        traffic = pmc_traffic_bytes(args.workload, n_per_gpu, spl) if quotable else None
+        # the counters are per FULL launch (spl steps); a region whose last launch is shorter moves proportionally less on average
+        real_bytes_per_launch = traffic * steps_per_launch_avg / spl if traffic else floor_bytes_per_launch
+        achieved = real_bytes_per_launch / launch_s / 1e9
         out = {
             "metric": "env-steps/s (random policy)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "host_ms": dt * 1e3, "event_ms": ev_ms,
+            "host_ms": dt * 1e3, "event_ms": ev_ms, "host_ms_incl_device_sync": dt_dev_sync * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{env_id}, {n_per_gpu} envs/GPU x {world} GPU, {obs_mode} obs "
                                    f"{'x'.join(map(str, env.image_shape))}, device Philox random actions, NEXT_STEP autoreset",
@@ -357,6 +480,10 @@ def main():
                                   if spl > 1 else f"one {kname} launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "steps_per_launch": spl,
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"],
+                       "library_build": build_info, "environment": mg_environment(), "stub": not use_gpu,
+                       "clock": "host_ms: perf_counter from just before the first launch is enqueued until the stop event on the step stream, the "
+                                "generator stream and (gather) the communication stream have each been waited for; "
+                                "host_ms_incl_device_sync adds the closing torch.cuda.synchronize()",
                        "distributed": {"world_size": (dist.get_world_size() if world > 1 else 1),
                                        "backend": (dist.get_backend() if world > 1 else None),
                                        "per_rank_us_per_step": per_rank_us,
@@ -364,26 +491,39 @@ def main():
                                                        "communication stream overlapped with the next launch" % spl) if gather and fused else
                                                       "one all_gather_into_tensor of the step record per step" if gather else "none on the data path"),
                                        "collectives_rank0": (senv.collectives if senv is not None else 0)}},
-            "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic_bytes(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,
-                         "traffic_unit": "bytes per step-kernel launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
-                         "traffic_source": pmc_traffic_source(args.workload, n_per_gpu, spl),
-                         "launches": n_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "algorithmic_bytes_per_env_step": bpe, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
-                         "kernel_us_per_step": rocprof_kernel_us_per_step(args.workload, n_per_gpu, spl) if not args.obs_mode and args.view == 7 else None,
+            "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else kname,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "bytes_per_launch": real_bytes_per_launch,
+                         "bytes_source": ("rocprofv3 PMC counters (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) of a committed pass of this launch shape"
+                                          if traffic else "analytic floor: outputs of every step + grids / agent records once per launch (no committed "
+                                                          "PMC pass has this batch size and steps per launch)"),
+                         "traffic": traffic,
+                         "traffic_unit": "bytes per full step-kernel launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
+                         "traffic_source": pmc_traffic_source(args.workload, n_per_gpu, spl) if quotable else None,
+                         "traffic_vs_floor": (traffic / (hbm_min * n_per_gpu * spl)) if traffic else None,
+                         "launches": n_launch, "avg_launch_us": launch_s * 1e6, "avg_step_us": step_s * 1e6,
+                         "kernel_us_per_step": rocprof_kernel_us_per_step(args.workload, n_per_gpu, spl) if quotable else None,
                          "hbm_bytes_per_env_step_this_kernel": hbm_min,
-                         "frac_of_peak_on_actual_bytes": n_per_gpu * hbm_min / step_s / 1e9 / HBM_PEAK_GBPS,
-                         "note": "achieved/frac price the SURVEY 8(d) algorithmic bytes (the reference's 3 B/cell grid re-read "
-                                 "every step); the fused kernel keeps the grid in LDS, so its real HBM traffic per env-step is "
-                                 "hbm_bytes_per_env_step_this_kernel and the bound it actually runs against is the HBM WRITE stream"},
+                         "survey_8d": {"bytes_per_env_step": bpe, "bytes_per_launch": survey_bytes_per_launch,
+                                       "achieved": survey_bytes_per_launch / launch_s / 1e9,
+                                       "frac": survey_bytes_per_launch / launch_s / 1e9 / HBM_PEAK_GBPS,
+                                       "note": "SURVEY.md 8(d) prices the reference's 3 B/cell grid re-read and the agent record r/w in every step; "
+                                               "a fused launch keeps them in LDS, so these bytes never reach HBM and this fraction can exceed 1 -- "
+                                               "it is the secondary figure, not the roofline"},
+                         "note": "achieved = HBM bytes the launch really moves / its duration (HIP events, this run); the bound this kernel "
+                                 "runs against is the HBM WRITE stream"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and use_gpu:
             if obs_mode.startswith("rgb"):
                 out["cpu_baseline"] = cpu_baseline_rgb(env_id, obs_mode)
             else:
                 out["cpu_baseline"] = cpu_baseline(env_id, obs_mode if obs_mode in ("partial", "full") else "partial")
-            out["cpu_baseline"]["reference_python"] = reference_python_baseline(args.workload)
+            live = None
+            try:
+                live = reference_python_live(args.workload)
+            except Exception:
+                live = None
+            out["cpu_baseline"]["reference_python"] = live or reference_python_baseline(args.workload)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

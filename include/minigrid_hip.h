@@ -297,6 +297,9 @@ MG_API int mg_get_counters(mg_env* env, uint64_t out[4]);
 
 MG_API const char* mg_last_error(mg_env* env);   /* env may be NULL for creation errors */
 MG_API int mg_abi_version(void);
+/* compile-time switches of this build as "key=value;..." ("attribution=0" in the product library: the MG_EXP step-skipping aid of
+ * the attribution build is compiled out; bench.py prints the string into its JSON line next to every MG_* environment variable) */
+MG_API const char* mg_build_info(void);
 MG_API int mg_device_count(void);
 
 /* Host-side self-test hooks (no GPU needed): run the library's own inline helpers on the CPU so that the

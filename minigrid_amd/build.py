@@ -68,9 +68,10 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = False, lib: str = LIB, extra_flags=(), extra_link=(),
-          tag: str = "", arch: str = "gfx950") -> str:
+          tag: str = "", arch: str = "gfx950", flag_units=None) -> str:
     """`lib` / `extra_flags` / `extra_link` / `tag`: an alternative build of the same sources next to the product library (the
-    sanitizer build, profiles/asan_build.py) -- selected at run time with MINIGRID_AMD_LIB."""
+    sanitizer build, profiles/asan_build.py; the attribution / A-B variants, profiles/variant_build.py) -- selected at run time with
+    MINIGRID_AMD_LIB.  `flag_units`: the translation units the extra flags apply to (the others are shared with the product build)."""
     if lib == LIB and not force and not _stale():
         return LIB
     # one builder at a time per tree (N ranks of a multi-GPU job importing the package at once must not compile into the same
@@ -81,10 +82,10 @@ def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = F
         fcntl.flock(lock, fcntl.LOCK_EX)
         if lib == LIB and not force and not _stale():
             return LIB
-        return _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch)
+        return _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch, flag_units)
 
 
-def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch) -> str:
+def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch, flag_units=None) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if missing_hipcc_ok and os.path.exists(lib):
@@ -98,11 +99,13 @@ def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link
     os.makedirs(stub_dir, exist_ok=True)
     stub = os.path.join(stub_dir, "libamdhip64.so")
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-x", "c", "/dev/null", "-o", stub])
-    cflags = ["--offload-arch=" + arch] + CFLAGS + list(extra_flags)
+    base_cflags = ["--offload-arch=" + arch] + CFLAGS
     os.makedirs(OBJDIR, exist_ok=True)
 
     def compile_one(src):
-        base = os.path.splitext(src)[0] + tag
+        mine = flag_units is None or src in flag_units
+        cflags = base_cflags + (list(extra_flags) if mine else [])
+        base = os.path.splitext(src)[0] + (tag if mine else "")
         obj, stamp = os.path.join(OBJDIR, base + ".o"), os.path.join(OBJDIR, base + ".hash")
         want = _hash_files([src] + UNITS[src], " ".join(cflags))
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:

@@ -323,7 +323,11 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   const uint32_t cpe = (uint32_t)(e->CS >> 4);
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
   P.env_base = e->cfg.env_index_base;
-  { static const int exp = [] { const char* s = getenv("MG_EXP"); return s ? atoi(s) : 0; }(); P.exp = exp; }
+#if defined(MG_ATTRIBUTION)
+  { static const int exp = [] { const char* s = getenv("MG_EXP"); return s ? atoi(s) : 0; }(); P.exp = exp; }   // attribution builds only (mg_roll.h MG_EXPBIT)
+#else
+  P.exp = 0;
+#endif
 }
 
 static int launch_step(mg_env* e, StepParams& P) {
@@ -767,6 +771,17 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
+
+const char* mg_build_info(void) {
+#if defined(MG_ATTRIBUTION)
+#define MG_BI_ATTR "1"
+#else
+#define MG_BI_ATTR "0"
+#endif
+#define MG_BI_STR2(x) #x
+#define MG_BI_STR(x) MG_BI_STR2(x)
+  return "attribution=" MG_BI_ATTR ";encode_quads=" MG_BI_STR(MG_ENCODE_QUADS) ";arch=gfx950";
+}
 
 int mg_device_count(void) {
   int n = 0;

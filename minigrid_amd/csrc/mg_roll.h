@@ -31,6 +31,14 @@
 #else
 #define MG_MARK(name) do { } while (0)
 #endif
+// attribution aid: -DMG_ATTRIBUTION builds (profiles/attr_build.py, a SEPARATE library selected with MINIGRID_AMD_LIB) read MG_EXP and
+// skip parts of a step so that their cost can be timed.  The product library is built without it: the switch folds to 0 and a stray
+// MG_EXP in somebody's environment cannot make it produce garbage.
+#if defined(MG_ATTRIBUTION)
+#define MG_EXPBIT(P, b) (((P).exp & (b)) != 0)
+#else
+#define MG_EXPBIT(P, b) false
+#endif
 
 namespace mg {
 
@@ -479,7 +487,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   LaneCtx C;
   C.e = e; C.el = lane; C.sub = 0; C.active = active; C.lead = true; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
   C.mygrid = mygrid; C.myshadow = sshadow + lane * GS; C.sspr = sspr;
-  const bool see_through = P.see_through != 0 || (P.exp & 1);
+  const bool see_through = P.see_through != 0 || MG_EXPBIT(P, 1);
 
   for (int j = 0; j < j_end; j++) {
     const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
@@ -501,7 +509,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     uint32_t term = 0, trunc = 0;
     S.errbits = 0;
     MG_MARK("transition");
-    if (!(P.exp & 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
+    if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
     MG_MARK("after_transition");
     if constexpr (FULL) {
       // The image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
@@ -567,7 +575,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     int slot_out = P.slot0 - j;
     while (slot_out < 0) slot_out += P.S;
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
-    if (active && !(P.exp & 8)) {
+    if (active && !MG_EXPBIT(P, 8)) {
       *(double*)(ob + o_rew) = reward;
       ob[o_term] = (uint8_t)term;
       ob[o_trunc] = (uint8_t)trunc;
@@ -584,7 +592,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       // the agent's own cell reads (10, 0, dir) in the observation: patched into the stream for the encode, restored after it
       gt_pos = (uint32_t)(lane * cells) + a.x * (uint32_t)H + a.y;
       if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (a.dir << 4)); }
-    } else if (!(P.exp & 4)) {
+    } else if (!MG_EXPBIT(P, 4)) {
       View7 O;
       obs7_view(av, mygrid, W, H, see_through, O);
       uint32_t D[13];
@@ -597,7 +605,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
-    if (!(P.exp & 2) && !share) {
+    if (!MG_EXPBIT(P, 2) && !share) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)OBE;   // 64 * OBE is a multiple of 16
       const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
@@ -657,17 +665,17 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
     if (MG_ENCODE_QUADS && !FULL && nvalid == 64 && nthreads == 64 * ROLL_MAX_WAVES) {
-      if (!(P.exp & 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
+      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
     } else if (MG_ENCODE_QUADS && nvalid == 64) {
       const int nq = 16 * (FULL ? cells : VIEW_CELLS);
-      if (!(P.exp & 2))
+      if (!MG_EXPBIT(P, 2))
         for (int u = tid; u < nq; u += nthreads) {
           uint32_t o3[3];
           obs7_quad((uint32_t)u, codes0, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
           ((Out12*)obase)[u] = v;
         }
-    } else if (!(P.exp & 2))
+    } else if (!MG_EXPBIT(P, 2))
       for (int c = tid; c <= nvec; c += nthreads) {
         uint32_t o4[4];
         obs7_chunk((uint32_t)c, codes0, slut, o4);
