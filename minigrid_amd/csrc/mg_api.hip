@@ -664,7 +664,9 @@ static const char* configure_obs(mg_env* e) {
   // trajectory slots S: default 32 (fused launches write every step of the launch to its own slot), fewer when one
   // slot is large (RGB frames: a single slot)
   const size_t per_slot = (size_t)e->N * ((size_t)e->obs_bytes + 16);
-  int S = e->cfg.traj_slots > 0 ? e->cfg.traj_slots : 32;
+  // traj_slots > 0: exactly that many; 0: the default; < 0: -traj_slots PREFERRED, halved like the default while the ring would exceed 2 GB
+  // (ShardedVecEnv asks for two blocks of max_fused_steps slots this way: ADVICE r3)
+  int S = e->cfg.traj_slots > 0 ? e->cfg.traj_slots : e->cfg.traj_slots < 0 ? -e->cfg.traj_slots : 32;
   if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
   if (S > 4096) return "traj_slots must be <= 4096";
   if (rgb) S = 1;
@@ -1105,9 +1107,19 @@ int mg_set_obs_config(mg_env* e, const mg_config* cfg) {
   want.obs_mode = cfg->obs_mode; want.agent_view_size = cfg->agent_view_size; want.tile_size = cfg->tile_size; want.rgb_highlight = cfg->rgb_highlight;
   want.no_death_mask = cfg->no_death_mask; want.death_cost = cfg->death_cost; want.traj_slots = cfg->traj_slots;
   {
-    mg_config given = *cfg;
-    given.null_stream_sync = want.null_stream_sync;              // (decided by the binding at create time)
-    if (memcmp(&given, &want, sizeof(mg_config)) != 0)
+    // field by field: a C caller that fills a stack struct member by member leaves the padding bytes undefined, so the
+    // comparison must not look at them
+    const mg_config& g = *cfg; const mg_config& w = want;
+    const bool same = g.abi_version == w.abi_version && g.env_kind == w.env_kind && g.width == w.width && g.height == w.height &&
+                      g.max_steps == w.max_steps && g.see_through_walls == w.see_through_walls && g.agent_view_size == w.agent_view_size &&
+                      g.obs_mode == w.obs_mode && g.autoreset_mode == w.autoreset_mode && g.rng_mode == w.rng_mode && g.num_envs == w.num_envs &&
+                      g.agent_start_x == w.agent_start_x && g.agent_start_y == w.agent_start_y && g.agent_start_dir == w.agent_start_dir &&
+                      g.num_crossings == w.num_crossings && g.obstacle_type == w.obstacle_type && g.num_dists == w.num_dists &&
+                      /* null_stream_sync: decided by the binding at create time */
+                      g.strip2_row == w.strip2_row && g.no_death_mask == w.no_death_mask && g.death_cost == w.death_cost &&
+                      g.room_size == w.room_size && g.random_length == w.random_length && g.env_index_base == w.env_index_base &&
+                      g.tile_size == w.tile_size && g.rgb_highlight == w.rgb_highlight && g.spare_ring == w.spare_ring && g.traj_slots == w.traj_slots;
+    if (!same)
       return fail(e, MG_ERR_INVALID, "set_obs_config: only obs_mode, agent_view_size, tile_size, rgb_highlight, no_death_mask, death_cost and traj_slots may change");
   }
   if (const char* bad = validate_obs_cfg(&want)) return fail(e, MG_ERR_INVALID, "%s", bad);

@@ -306,7 +306,7 @@ struct Out12 { uint32_t x, y, z; };                    // 4-byte aligned: one gl
 // NQ quads by threads l0, l0 + STRIDE, ...: software-pipelined -- every code dword first, then the lookups of quad it + 1 are issued before
 // quad it is packed and stored
 template <int STRIDE, int NQ>
-MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase) {
+MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase, bool do_store = true) {
   constexpr int NIT = (NQ + STRIDE - 1) / STRIDE;
   uint32_t cw[NIT], tq[2][4];
 #pragma unroll
@@ -319,7 +319,7 @@ MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8
     uint32_t o3[3];
     obs7_quad_pack(tq[it & 1], o3);
     Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-    if ((it + 1) * STRIDE <= NQ || u < NQ) ((Out12*)obase)[u] = v;
+    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) ((Out12*)obase)[u] = v;
   }
 }
 
@@ -348,7 +348,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
-  const int wg = blockIdx.x, env0 = wg * 64, e = env0 + lane;
+  const int wg = blockIdx.x;      // (an XCD-contiguous remap of the workgroups and a wait after every store were measured: no gain, profiles/r4/ab_store_variants.txt)
+  const int env0 = wg * 64, e = env0 + lane;
   const bool active = e < P.N;
   const int nvalid = min(64, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
@@ -572,8 +573,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     errs_mine |= S.errbits;
     if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));
 
-    int slot_out = P.slot0 - j;
-    while (slot_out < 0) slot_out += P.S;
+    int slot_out = P.slot0 - j;                                      // (T <= S and slot0 < S: at most one wrap; a loop here compiled to a scalar division)
+    slot_out += slot_out < 0 ? P.S : 0;
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
     if (active && !MG_EXPBIT(P, 8)) {
       *(double*)(ob + o_rew) = reward;
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
 #if MG_ENCODE_QUADS
       if (!FULL && nvalid == 64) {
         // 784 cell quads: thirteen rounds, the last one 16 lanes wide
-        encode_quads<64, 64 * VIEW_CELLS / 4>(lane, scodes, slut, obase);
+        encode_quads<64, 64 * VIEW_CELLS / 4>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));
       } else if (FULL && nvalid == 64) {
         const int nq = 16 * cells;                                                // 64 * cells / 4 quads
         for (int u = lane; u < nq; u += 64) {

@@ -405,7 +405,11 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
       rec_dirty = true;
     } else if (P.phase == PHASE_STEP) {
-      // ---- MiniGridEnv.step ----
+      // ---- MiniGridEnv.step (minigrid_env.py:525-595) ----
+      // STRAIGHT-LINE: under a random policy every action occurs among a wave's 64 envs in every step, so an if / else chain over the
+      // action makes the wave walk all seven bodies one after the other (exec-mask save / restore + branch around each: the round-3
+      // transition cost 1.1 of the 2.7 us of a 65 536-env step, profiles/r4/attribution.txt, more than the observation).  Every effect
+      // is computed for every lane and selected by the action instead; the only memory access is the front cell.
       rec_dirty = true;
       const uint32_t pre_carry = a.carry;
       a.step = min(a.step + 1u, 0xFFFFu);
@@ -413,30 +417,38 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
       if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
       const uint32_t fidx = inb ? (uint32_t)(fy * W + fx) : 0u;
-      const uint32_t F = inb ? (uint32_t)mygrid[fidx] : (uint32_t)CELL_WALL_GREY;
-      uint32_t newF = F;
-      const uint32_t ftype = cell_type(F);
-      bool success = false;
-      if (act == A_LEFT) a.dir = (a.dir + 3u) & 3u;
-      else if (act == A_RIGHT) a.dir = (a.dir + 1u) & 3u;
-      else if (act == A_FORWARD) {
-        if (cell_walkable(F)) { a.x = (uint32_t)fx; a.y = (uint32_t)fy; }
-        if (ftype == T_GOAL) { term = 1; success = true; }
-        if (ftype == T_LAVA) term = 1;
-      } else if (act == A_PICKUP) {
-        if (cell_pickable(F) && a.carry == 0) { a.carry = F; newF = CELL_EMPTY; }
-      } else if (act == A_DROP) {
-        if (F == CELL_EMPTY && a.carry != 0) { newF = a.carry; a.carry = 0; }
-      } else if (act == A_TOGGLE) {
-        newF = cell_toggle(F, a.carry);
-        if constexpr (GG == GG_ROOMS) if (ftype == T_BOX_DOORKEY) {
-          // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
-          uint32_t dc = 0;
-          for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
-          newF = make_cell(T_KEY, dc);
-        }
-      } else if (act != A_DONE) {
-        errbits |= ERR_BAD_ACTION;                                   // reference raises ValueError (584-585)
+      const uint32_t Fraw = (uint32_t)mygrid[fidx];
+      const uint32_t F = inb ? Fraw : (uint32_t)CELL_WALL_GREY;
+      const uint32_t ftype = cell_type(F), fcol = F & 0x70u;
+      const bool is_fwd = act == A_FORWARD, is_pick = act == A_PICKUP, is_drop = act == A_DROP, is_tog = act == A_TOGGLE;
+      if (act > A_DONE) errbits |= ERR_BAD_ACTION;                   // reference raises ValueError (584-585)
+      // left / right (:552-560)
+      a.dir = (a.dir + (act == A_LEFT ? 3u : act == A_RIGHT ? 1u : 0u)) & 3u;
+      // forward (:563-571)
+      const bool walk = is_fwd && cell_walkable(F);
+      a.x = walk ? (uint32_t)fx : a.x; a.y = walk ? (uint32_t)fy : a.y;
+      bool success = is_fwd && ftype == T_GOAL;
+      if (is_fwd && (ftype == T_GOAL || ftype == T_LAVA)) term = 1;
+      // pickup (:574-579) / drop (:582-587)
+      const bool picks = is_pick && cell_pickable(F) && pre_carry == 0u;
+      const bool drops = is_drop && F == CELL_EMPTY && pre_carry != 0u;
+      // toggle (:590-592): Door.toggle / Box.toggle (world_object.py:184-194, 290-293) as a table over the type nibble --
+      // open door (4) -> closed (11), closed -> open, locked (12) -> open with the key of its colour in hand, box (7) -> gone,
+      // box-with-key (14) -> the key (5) -- everything else toggles to itself
+      constexpr uint64_t TOG = 0xF5D44A98165B3210ull;   // nibble t = the type after a toggle
+      static_assert(((TOG >> (4 * T_DOOR)) & 15) == T_DOOR_CLOSED && ((TOG >> (4 * T_DOOR_CLOSED)) & 15) == T_DOOR && ((TOG >> (4 * T_BOX)) & 15) == T_EMPTY &&
+                    ((TOG >> (4 * T_BOX_KEY)) & 15) == T_KEY && ((TOG >> (4 * T_DOOR_LOCKED)) & 15) == T_DOOR && ((TOG >> (4 * T_WALL)) & 15) == T_WALL &&
+                    ((TOG >> (4 * T_BOX_DOORKEY)) & 15) == T_BOX_DOORKEY && ((TOG >> (4 * T_KEY)) & 15) == T_KEY, "toggle table");
+      const bool no_key = ftype == T_DOOR_LOCKED && pre_carry != ((uint32_t)T_KEY | fcol);
+      const uint32_t tt = no_key ? (uint32_t)T_DOOR_LOCKED : (uint32_t)(TOG >> (4u * ftype)) & 15u;
+      const uint32_t toggled = tt | (tt == T_EMPTY ? 0u : fcol) | (((OPAQUE_TYPES >> tt) & 1u) << 7);
+      uint32_t newF = is_tog ? toggled : picks ? (uint32_t)CELL_EMPTY : drops ? pre_carry : F;
+      a.carry = picks ? F : drops ? 0u : pre_carry;
+      if constexpr (GG == GG_ROOMS) if (is_tog && ftype == T_BOX_DOORKEY) {
+        // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
+        uint32_t dc = 0;
+        for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
+        newF = make_cell(T_KEY, dc);
       }
       if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
       trunc = a.step >= (uint32_t)P.max_steps;
@@ -753,7 +765,7 @@ k_step(const StepParams P) {
 
   for (int j = 0; j < P.T; j++) {
     int slot_out = P.slot0 - j;
-    while (slot_out < 0) slot_out += P.S;
+    slot_out += slot_out < 0 ? P.S : 0;                              // (T <= S, slot0 < S: at most one wrap)
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
     // ---- action ----
     uint32_t act = A_DONE;

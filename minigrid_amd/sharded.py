@@ -96,7 +96,7 @@ class ShardedVecEnv:
                 self._step_stream = torch.cuda.Stream(device=dev)
                 self._comm_stream = torch.cuda.Stream(device=dev)
                 kwargs["stream"] = self._step_stream.cuda_stream
-                kwargs.setdefault("traj_slots", 64)
+                kwargs.setdefault("traj_slots", -64)      # 64 preferred; the library halves it while the ring would exceed 2 GB
         self.local = make(env_id, self.local_num_envs, env_index_base=self.lo, **kwargs)
         # the sentence levels' missions travel as two u64 per env inside the record and become strings again on every rank
         self._sentence = bool(getattr(self.local, "sentence", False))
@@ -230,12 +230,26 @@ class ShardedVecEnv:
         return image, rew_g, term_g, trunc_g
 
     def _on_step_stream(self):
-        """torch's current stream = the shard's stream, so that torch.distributed orders its collectives against the step kernels."""
+        """torch's current stream = the shard's stream, so that torch.distributed orders its collectives against the step kernels.
+        The shard's stream is non-blocking, so it is ordered with the CALLER's stream explicitly, both ways: on entry it
+        waits for the caller's stream (device action tensors produced there are complete before mg_step reads them), on exit the
+        caller's stream waits for it (the tensors handed back -- views of slot 0, the gathered buffer -- are complete for any consumer
+        on the caller's stream).  Device-side waits only; the host is not synchronised."""
         import contextlib
         if self._step_stream is None:
             return contextlib.nullcontext()
         import torch
-        return torch.cuda.stream(self._step_stream)
+
+        @contextlib.contextmanager
+        def ordered():
+            caller = torch.cuda.current_stream(self._step_stream.device)
+            self._step_stream.wait_stream(caller)
+            try:
+                with torch.cuda.stream(self._step_stream):
+                    yield
+            finally:
+                caller.wait_stream(self._step_stream)
+        return ordered()
 
     # ---- the fused rollout: ONE collective per launch, overlapped with the next launch --------------------------------
     def rollout_gather(self, steps: int, action_seed: int = 0, consumer=None) -> int:
@@ -248,8 +262,15 @@ class ShardedVecEnv:
         number of collectives issued (= launches)."""
         import torch
         loc = self.local
+        if int(loc.traj_slots) < 2:
+            raise ValueError(f"rollout_gather rotates two blocks of trajectory slots: traj_slots >= 2 is needed, this shard has "
+                             f"{int(loc.traj_slots)} (RGB observation modes keep a single slot: use step() with gather=True there)")
         F = max(1, min(int(loc.max_fused_steps), int(loc.traj_slots) // 2))
         W = self.world_size
+        # without the own-stream setup (gather=False at construction, a caller-supplied stream, a custom `make`, numpy outputs) nothing
+        # orders the shard's launches with the collective's stream or a block's next launch with its previous gather: synchronise
+        # the host around every collective instead (ADVICE r3) -- correct, not overlapped
+        host_ordered = self._step_stream is None
         rec_bytes = record_layout(self._max_local, int(np.prod(loc.image_shape)), self._sentence)["record_bytes"]
         n_coll, done = 0, 0
         if getattr(self, "_blk", None) is None:
@@ -270,6 +291,8 @@ class ShardedVecEnv:
                 self._comm_stream.wait_event(st["stepped"][b])
             else:
                 loc.rollout_block(T, action_seed, slot0)
+                if host_ordered and hasattr(loc, "sync"):
+                    loc.sync()                                         # the block is complete before the collective reads it
             view = loc.block_view(lo, T)                               # (T, this shard's slot bytes) u8
             with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else self._on_step_stream()):
                 if W > 1 and view.shape[1] != rec_bytes:                # ragged shard: pad the records to the largest shard's
@@ -290,6 +313,8 @@ class ShardedVecEnv:
                     consumer(out, T)
                 if self._comm_stream is not None:
                     st["gathered"][b] = self._comm_stream.record_event(st["gathered"][b])
+                elif host_ordered and out.is_cuda:
+                    torch.cuda.current_stream(out.device).synchronize()   # ... and has been read before the block is launched into again
             done += T
             k += 1
         self._blk_next = k
