@@ -459,9 +459,9 @@ def main(argv=None):
         steps_per_launch_avg = args.steps / n_launch    # (the last launch of the region may be shorter)
         survey_bytes_per_launch = bpe * n_per_gpu * steps_per_launch_avg
         obe = int(np_prod(env.image_shape))
-        # what a fused launch has to move per env-step: the outputs (obs + reward 8 + 5 flag/id bytes); the grid and the
-        # agent record are read and written once per launch, not per step
-        hbm_min = obe + 13 + (2 * (env.width * env.height) + 16) / spl
+        # what a fused launch has to move per env-step: the outputs (obs + the 16-byte mg_step_scalars: reward f64, four flag / id bytes, mission
+        # id u16, 2 bytes reserved); the grid and the agent record are read and written once per launch, not per step
+        hbm_min = obe + 16 + (2 * (env.width * env.height) + 16) / spl
         floor_bytes_per_launch = hbm_min * n_per_gpu * steps_per_launch_avg
         quotable = not args.obs_mode and args.view == 7 and use_gpu
         traffic = pmc_traffic_bytes(args.workload, n_per_gpu, spl) if quotable else None

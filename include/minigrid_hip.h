@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 2
+#define MG_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MG_API __attribute__((visibility("default")))
@@ -191,18 +191,30 @@ typedef struct mg_config {
 /* Borrowed device pointers to the outputs of the last step/reset = slot 0 of the trajectory ring.  The ring has
  * traj_slots slots of slot_bytes each; slot k holds the outputs of the step k calls before the last one (as far as
  * the last mg_rollout / mg_step_many call reaches), at every pointer below + k * slot_bytes.  The first record_bytes of a
- * slot, starting at `obs`, are one contiguous record {obs | reward | terminated | truncated | direction | mission_id |
- * action}: a multi-GPU consumer moves a whole step with ONE all-gather. */
+ * slot, starting at `obs`, are one contiguous record {obs (N, ...) | scalars (N) x mg_step_scalars [| sentence (N, 2)]}: a multi-GPU
+ * consumer moves a whole step with ONE all-gather.  Since ABI 3 the per-env scalars of a step are ONE 16-byte entry per env
+ * (mg_step_scalars: the step kernel writes them with one 16-byte store per env instead of six partial-line stores, which cost
+ * a tenth of the fused step's time: profiles/r4/attribution_split.txt); the pointers below address the first env's field and advance by
+ * scalar_stride (= sizeof(mg_step_scalars)) bytes per env -- strided views, e.g. reward[i] = *(double*)((char*)reward + i * scalar_stride). */
+typedef struct mg_step_scalars {
+  double reward;        /* 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245)      */
+  uint8_t terminated;   /* 0/1                                                                           */
+  uint8_t truncated;    /* 0/1 (minigrid_env.py:587-588)                                                 */
+  uint8_t direction;    /* agent_dir 0..3 (obs["direction"], minigrid_env.py:648)                        */
+  uint8_t action;       /* the action the step applied (device-policy rollouts record it here)           */
+  uint16_t mission_id;  /* index into the config's mission-string table (obs["mission"])                 */
+  uint16_t reserved;    /* 0                                                                             */
+} mg_step_scalars;
 typedef struct mg_outputs {
   uint8_t* obs;         /* (N, V,V,3) | (N, W,H,3) | (N, V,V,20) u8, (N, W,H,3) i8 or an RGB frame, C-contiguous */
-  double* reward;       /* (N) f64: 0 or 1 - 0.9*(step_count/max_steps), bit-exact (minigrid_env.py:240-245) */
-  uint8_t* terminated;  /* (N) u8 0/1                                                                 */
-  uint8_t* truncated;   /* (N) u8 0/1 (minigrid_env.py:587-588)                                       */
-  uint8_t* direction;   /* (N) u8 agent_dir 0..3 (obs["direction"], minigrid_env.py:648)              */
-  uint16_t* mission_id; /* (N) u16 index into the config's mission-string table (obs["mission"])      */
+  double* reward;       /* the fields of env 0's mg_step_scalars; env i's at + i * scalar_stride bytes */
+  uint8_t* terminated;
+  uint8_t* truncated;
+  uint8_t* direction;
+  uint16_t* mission_id;
   int64_t obs_bytes_per_env;
   int64_t num_envs;
-  uint8_t* action;      /* (N) u8 the action the step applied (device-policy rollouts record it here)   */
+  uint8_t* action;      /* (strided like reward)                                                        */
   int64_t traj_slots;
   int64_t slot_bytes;
   int64_t record_bytes;
@@ -212,6 +224,7 @@ typedef struct mg_outputs {
                            you " 3 " and ") | a << 2 | b << 5, children 0..3 = leaves, 4..6 = nodes.  leaf = verb (go to, pick up, open, put) |
                            desc << 2 | fixed desc << 11 (put X next to Y); desc = type (door key ball box) | colour << 2 (0 none, COLOR_TO_IDX
                            + 1) | loc << 5 (0 none, left right front behind) | article << 8 (1 = "a").  NULL for every other level.        */
+  int64_t scalar_stride; /* bytes between consecutive envs' scalars (16 = sizeof(mg_step_scalars))       */
 } mg_outputs;
 
 typedef struct mg_env mg_env;

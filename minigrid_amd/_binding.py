@@ -7,7 +7,7 @@ import os
 
 from . import build as _build
 
-MG_ABI_VERSION = 2
+MG_ABI_VERSION = 3
 MG_OK, MG_ERR_INVALID, MG_ERR_HIP, MG_ERR_BAD_ACTION, MG_ERR_GENERATOR, MG_ERR_NO_DEVICE, MG_ERR_OOB, MG_ERR_TRACKED = 0, -1, -2, -3, -4, -5, -6, -7
 OBS_PARTIAL, OBS_FULL, OBS_ONEHOT, OBS_SYMBOLIC, OBS_RGB_PARTIAL, OBS_RGB = 0, 1, 2, 3, 4, 5
 AUTORESET_NEXT_STEP, AUTORESET_DISABLED, AUTORESET_SAME_STEP = 0, 1, 2
@@ -28,7 +28,7 @@ class MgOutputs(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
                 ("direction", C.c_void_p), ("mission_id", C.c_void_p), ("obs_bytes_per_env", C.c_int64),
                 ("num_envs", C.c_int64), ("action", C.c_void_p), ("traj_slots", C.c_int64), ("slot_bytes", C.c_int64),
-                ("record_bytes", C.c_int64), ("max_fused_steps", C.c_int64), ("sentence", C.c_void_p)]
+                ("record_bytes", C.c_int64), ("max_fused_steps", C.c_int64), ("sentence", C.c_void_p), ("scalar_stride", C.c_int64)]
 
 
 class MiniGridHipError(RuntimeError):

@@ -7,6 +7,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -101,12 +102,14 @@ struct mg_env {
   bool rgb = false;
   // trajectory ring: S slots of { obs | reward | terminated | truncated | direction | mission | action }
   uint8_t* out = nullptr;
+  mg_step_scalars* h_scal = nullptr;   // pinned host staging of one slot's scalars (mg_copy_slot), on first use
   int S = 1;
   size_t slot_bytes = 0, record_bytes = 0, off_reward = 0, off_term = 0, off_trunc = 0, off_dir = 0, off_mission = 0, off_action = 0;
   uint32_t* err = nullptr;
   unsigned long long* counters = nullptr;
   size_t ncounters = 0;
   uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
+  unsigned long long burst_bytes = 0;   // output bytes of the launches enqueued since the step stream was last known idle (launch_step: nontemporal stores)
   uint64_t stat_base[3] = { 0, 0, 0 };   // episodes / maps / retries counted before the last mg_set_obs_config (its statistics slots are re-made)
   uint32_t launches = 0;      // k_step launches so far
   uint32_t t = 0;             // rollout step counter (Philox action counter)
@@ -274,24 +277,34 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
-struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, total; };
-static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions) {
+struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, total; };
+// split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
+static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + nw * 64 * e->GS + e->roll_guard + 15) & ~15;
+  const int ncodes = split ? nw - 1 : nw;
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
   const int K = e->roll_shadows;
   L.shadow_stride = (64 * e->GS + 15) & ~15;
-  L.off_shadow = L.off_codes + nw * L.codes_stride;
+  L.off_shadow = L.off_codes + ncodes * L.codes_stride;
   L.off_shadow_gt = L.off_shadow + K * L.shadow_stride;
   L.off_spr = L.off_shadow_gt + (e->fast_full ? K * L.codes_stride : 0);
   L.off_act = L.off_spr + K * 64 * 16;
-  L.total = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
+  L.off_log = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
+  L.total = L.off_log + (split ? ROLL_LOG_BYTES : 0);
   return L;
 }
-static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions) { return roll_layout(e, nw, with_actions).total; }
+static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split = false) { return roll_layout(e, nw, with_actions, split).total; }
+// Fused launches of the 7x7 view with three or four waves per workgroup run SPLIT (one dynamics wave + encode waves, mg_roll.h) instead of the
+// time split: the dynamics of a step run once instead of once per wave that has not reached it yet.  With two waves the time split wins
+// (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
+static bool roll_split_ok(const mg_env* e, int nw) {
+  static const bool on = [] { const char* s = getenv("MG_ROLL_SPLIT"); return !s || atoi(s) != 0; }();
+  return on && e->fast7 && !e->fast_full && !e->sentence && nw >= 3;
+}
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.grid = e->grid; P.agent = e->agent; P.aux = e->aux;
@@ -306,6 +319,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.instr = e->instr; P.spare_instr = e->spare_instr; P.off_sentence = e->off_sentence;
   P.out = e->out; P.slot_bytes = e->slot_bytes;
   P.obs = e->rgb ? e->tilemap : e->out; P.obs_stride = e->rgb ? 0ull : (unsigned long long)e->slot_bytes;
+  P.obs_wg_stride = 64ull * (unsigned long long)e->map_bytes;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
@@ -314,7 +328,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.see_through = e->cfg.see_through_walls; P.rule = e->rule; P.rule_cell = e->rule_cell; P.rule_div = e->rule_div;
   P.autoreset_next_step = e->cfg.autoreset_mode == MG_AUTORESET_NEXT_STEP;
   P.autoreset_same_step = e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP;
-  P.share = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0; P.h_magic = 0; P.shadow_stride = 0; P.spr_stride = 0;
+  P.share = 0; P.split_mode = 0; P.off_log = 0; P.nt = 0; P.codes_stride = ROLL_CODES_BYTES; P.off_shadow_gt = 0; P.w_magic = 0; P.h_magic = 0; P.shadow_stride = 0; P.spr_stride = 0;
   P.phase = phase; P.static_gen = e->static_gen; P.live_gen = e->live_gen ? 1 : 0; P.use_shadow = 0;
   P.off_grid = e->off_grid; P.off_shadow = e->off_shadow; P.off_spr = e->off_spr; P.off_act = e->off_act; P.off_trow = e->off_trow;
   P.off_T = e->off_T; P.OBE = e->map_bytes;
@@ -403,7 +417,22 @@ static int launch_step(mg_env* e, StepParams& P) {
     for (int w = 1; w < nw; w++) { x = x * (1.0 - ratio) + x1; P.split[w] = std::min(P.T - (nw - w), std::max(P.split[w - 1] + 1, (int)std::lround(x))); }
     for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
     const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
-    const RollLayout L = roll_layout(e, nw, acts);
+    const bool split = !share && P.T > 1 && nw >= 3 && roll_split_ok(e, nw);
+    const RollLayout L = roll_layout(e, nw, acts, split);
+    // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
+    static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
+    P.split_mode = split ? (drot == 0 ? 31 : drot) : 0; P.off_log = L.off_log;
+    {
+      // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
+      // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
+      // (DoorKey-8x8 x 262 144: 10.9 -> 8.8 us per step); a short burst, or a one-step launch whose observation the consumer reads next, is
+      // better off absorbed by the caches (one 20-step launch: 2.15 us per step plain, 2.39 nontemporal).  MG_NT_BYTES: the threshold in MB
+      // (0 = always nontemporal, negative = never).
+      static const long long nt_mb = [] { const char* s = getenv("MG_NT_BYTES"); return s ? atoll(s) : 256ll; }();
+      const unsigned long long wr = (unsigned long long)e->N * (unsigned long long)P.T * (unsigned long long)(e->obs_bytes + 16);
+      e->burst_bytes += wr;
+      P.nt = (nt_mb >= 0 && P.T > 1 && e->burst_bytes > (unsigned long long)nt_mb * 1000000ull) ? 1 : 0;
+    }
     if (share) nw = ROLL_MAX_WAVES;          // (layout of one private copy, four waves' worth of threads)
     P.off_grid = L.off_grid; P.off_T = L.off_codes; P.off_shadow = L.off_shadow; P.off_spr = L.off_spr; P.off_act = L.off_act;
     P.codes_stride = L.codes_stride; P.off_shadow_gt = L.off_shadow_gt;
@@ -453,6 +482,7 @@ static int launch_step(mg_env* e, StepParams& P) {
 static int check_device_errors(mg_env* e) {
   uint32_t bits = 0;
   HIP_TRY(e, wait_stream(e->stream));
+  e->burst_bytes = 0;                                      // the step stream is idle
   for (int k = 0; k < 4; k++) if (e->err_host[k]) { bits |= 1u << k; e->err_host[k] = 0u; }
   if (!bits) return MG_OK;
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
@@ -654,10 +684,10 @@ static const char* configure_obs(mg_env* e) {
     // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
     int nw = 4;
     if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
-    while (nw > 1 && roll_lds_bytes(e, nw, true) > 53 * 1024) nw--;
+    while (nw > 1 && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > 53 * 1024) nw--;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
-    e->lds_bytes = roll_lds_bytes(e, nw, true);
+    e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
   }
   if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";
   e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each
@@ -703,14 +733,16 @@ static int alloc_obs(mg_env* e) {
   {
     // one trajectory slot = one contiguous record: obs | reward | terminated | truncated | direction | mission | action
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // scalars: one 16-byte mg_step_scalars per env (ABI 3), written by the step kernels with ONE store per env
+    static_assert(sizeof(mg_step_scalars) == 16, "mg_step_scalars is one 16-byte store");
     e->off_reward = up(N * e->obs_bytes + 16);
-    e->off_term = e->off_reward + up(N * 8);
-    e->off_trunc = e->off_term + up(N);
-    e->off_dir = e->off_trunc + up(N);
-    e->off_mission = e->off_dir + up(N);
-    e->off_action = e->off_mission + up(2 * N);
-    e->off_sentence = e->off_action + up(N);                 // sentence levels: the mission as data, two u64 per env
-    e->record_bytes = e->sentence ? up(e->off_sentence + 16 * N) : up(e->off_action + N);
+    e->off_term = e->off_reward + offsetof(mg_step_scalars, terminated);
+    e->off_trunc = e->off_reward + offsetof(mg_step_scalars, truncated);
+    e->off_dir = e->off_reward + offsetof(mg_step_scalars, direction);
+    e->off_action = e->off_reward + offsetof(mg_step_scalars, action);
+    e->off_mission = e->off_reward + offsetof(mg_step_scalars, mission_id);
+    e->off_sentence = e->off_reward + up(N * sizeof(mg_step_scalars));   // sentence levels: the mission as data, two u64 per env
+    e->record_bytes = e->sentence ? up(e->off_sentence + 16 * N) : e->off_sentence;
     e->slot_bytes = e->record_bytes;
     if (e->slot_bytes >= ((size_t)1 << 32)) return fail(e, MG_ERR_INVALID, "one step record must stay below 4 GB (fewer envs per handle)");
     HIP_TRY(e, dalloc(&e->out, e->slot_bytes * (size_t)e->S));
@@ -1157,6 +1189,7 @@ int mg_destroy(mg_env* e) {
   for (const auto& a : e->allocs) (void)hipFree(a.base);
   e->allocs.clear();
   if (e->err_host) (void)hipHostFree((void*)e->err_host);
+  if (e->h_scal) (void)hipHostFree((void*)e->h_scal);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->ev_live) (void)hipEventDestroy(e->ev_live);
@@ -1322,6 +1355,7 @@ int mg_get_outputs(mg_env* e, mg_outputs* o) {
   o->action = e->out + e->off_action; o->traj_slots = e->S; o->slot_bytes = (int64_t)e->slot_bytes; o->record_bytes = (int64_t)e->record_bytes;
   o->max_fused_steps = e->max_fused;
   o->sentence = e->sentence ? (uint64_t*)(e->out + e->off_sentence) : nullptr;
+  o->scalar_stride = (int64_t)sizeof(mg_step_scalars);
   return MG_OK;
 }
 
@@ -1344,13 +1378,25 @@ int mg_copy_slot(mg_env* e, int slot, uint8_t* obs, double* reward, uint8_t* ter
   const size_t N = (size_t)e->N;
   const uint8_t* b = e->out + (size_t)slot * e->slot_bytes;
   if (obs) HIP_TRY(e, hipMemcpyAsync(obs, b, N * e->obs_bytes, hipMemcpyDeviceToHost, e->stream));
-  if (reward) HIP_TRY(e, hipMemcpyAsync(reward, b + e->off_reward, N * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  if (term) HIP_TRY(e, hipMemcpyAsync(term, b + e->off_term, N, hipMemcpyDeviceToHost, e->stream));
-  if (trunc) HIP_TRY(e, hipMemcpyAsync(trunc, b + e->off_trunc, N, hipMemcpyDeviceToHost, e->stream));
-  if (dir) HIP_TRY(e, hipMemcpyAsync(dir, b + e->off_dir, N, hipMemcpyDeviceToHost, e->stream));
-  if (mission) HIP_TRY(e, hipMemcpyAsync(mission, b + e->off_mission, 2 * N, hipMemcpyDeviceToHost, e->stream));
-  if (action) HIP_TRY(e, hipMemcpyAsync(action, b + e->off_action, N, hipMemcpyDeviceToHost, e->stream));
-  return check_device_errors(e);
+  const bool scal = reward || term || trunc || dir || mission || action;
+  if (scal) {
+    // the scalars travel as they lie -- (N) x mg_step_scalars -- into a pinned staging buffer and are dealt out on the host
+    if (!e->h_scal) HIP_TRY(e, hipHostMalloc((void**)&e->h_scal, N * sizeof(mg_step_scalars), hipHostMallocDefault));
+    HIP_TRY(e, hipMemcpyAsync(e->h_scal, b + e->off_reward, N * sizeof(mg_step_scalars), hipMemcpyDeviceToHost, e->stream));
+  }
+  { int rc = check_device_errors(e); if (rc) return rc; }        // (waits for the stream)
+  if (scal) {
+    const mg_step_scalars* sc = e->h_scal;
+    for (size_t i = 0; i < N; i++) {
+      if (reward) reward[i] = sc[i].reward;
+      if (term) term[i] = sc[i].terminated;
+      if (trunc) trunc[i] = sc[i].truncated;
+      if (dir) dir[i] = sc[i].direction;
+      if (mission) mission[i] = sc[i].mission_id;
+      if (action) action[i] = sc[i].action;
+    }
+  }
+  return MG_OK;
 }
 
 int mg_sync(mg_env* e) {
@@ -1538,6 +1584,7 @@ int mg_timer_stop(mg_env* e, float* ms) {
   if (!e || !ms) return MG_ERR_INVALID;
   HIP_TRY(e, hipEventRecord(e->ev1, e->stream));
   HIP_TRY(e, wait_event(e->ev1));
+  e->burst_bytes = 0;                                      // the step stream is idle
   HIP_TRY(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
   return MG_OK;
 }

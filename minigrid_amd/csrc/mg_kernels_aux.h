@@ -40,7 +40,7 @@ struct VerifyParams {
   const uint8_t* grid; uint64_t* agent; uint64_t* instr; const uint64_t* spare_instr;
   uint32_t* head; uint32_t ring_mask;
   uint8_t* rec;                      // the step record k_step just wrote
-  size_t off_reward, off_term, off_trunc, off_action, off_sentence;
+  size_t off_reward, off_term, off_trunc, off_action, off_sentence;   // fields of env 0's mg_step_scalars (16 bytes per env)
   uint32_t* err;
   int N, W, H, CS, phase, autoreset_next_step;
 };
@@ -68,11 +68,11 @@ __global__ void k_verify(const VerifyParams V) {
   sent[0] = I[IW_MISSION]; sent[1] = I[IW_MISSION + 1];
   if (V.phase != PHASE_STEP) return;
   uint32_t max_steps = 0, errbits = 0;
-  const uint32_t status = verify_action(I, V.grid + (size_t)e * V.CS, V.W, V.H, a, (uint32_t)V.rec[V.off_action + e], max_steps, errbits);
+  const uint32_t status = verify_action(I, V.grid + (size_t)e * V.CS, V.W, V.H, a, (uint32_t)V.rec[V.off_action + (size_t)e * 16], max_steps, errbits);
   const uint32_t term = status != R_CONTINUE, trunc = a.step >= max_steps;
-  *(double*)(V.rec + V.off_reward + (size_t)e * 8) = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
-  V.rec[V.off_term + e] = (uint8_t)term;
-  V.rec[V.off_trunc + e] = (uint8_t)trunc;
+  *(double*)(V.rec + V.off_reward + (size_t)e * 16) = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
+  V.rec[V.off_term + (size_t)e * 16] = (uint8_t)term;
+  V.rec[V.off_trunc + (size_t)e * 16] = (uint8_t)trunc;
   if ((term | trunc) && V.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; V.agent[e] = agent_pack(a); }
   if (errbits) report_errors(V.err, errbits);
 }

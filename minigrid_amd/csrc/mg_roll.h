@@ -303,9 +303,26 @@ MG_HD void obs7_quad(uint32_t u, const uint8_t* codes, const uint32_t* slut, uin
 #endif
 
 struct Out12 { uint32_t x, y, z; };                    // 4-byte aligned: one global_store_dwordx3
+// The trajectory is written once and not read again by the kernel: NONTEMPORAL stores (`nt`: streamed through L2 instead of staying
+// resident as dirty lines) -- measured in round 4 (profiles/r4/ab_nt.txt): Empty-8x8 x 65 536 2.36 -> 2.24 us per step, DoorKey-8x8 x 262 144
+// 10.95 -> 8.85: the batches that run in several rounds of workgroups re-read grids and spare episodes through the same L2.
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// ... while a SHORT burst that follows an idle stream is absorbed by the write-back caches (a single 20-step launch of the headline, 220 MB
+// against 256 MB of Infinity Cache: 2.15 us per step with plain stores, 2.39 nontemporal), and a one-step launch's observation is read by
+// the consumer right away.  The host decides per launch (StepParams::nt, mg_api.hip `launch_step`: bytes written since the stream was last
+// known idle); the scalars always take plain stores (nontemporal there measured slower: profiles/r4/ab_nt2.txt).
+MG_D void store12(uint8_t* p, const Out12& v, bool nt) {
+  if (nt) { u32x3_t w; w.x = v.x; w.y = v.y; w.z = v.z; __builtin_nontemporal_store(w, (u32x3_t*)p); }
+  else *(Out12*)p = v;
+}
+MG_D void store16(uint8_t* p, const uint4& v, bool nt) {
+  if (nt) { u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, (u32x4_t*)p); }
+  else *(uint4*)p = v;
+}
 // NQ quads by threads l0, l0 + STRIDE, ...: software-pipelined -- every code dword first, then the lookups of quad it + 1 are issued before
 // quad it is packed and stored
-template <int STRIDE, int NQ>
+template <int STRIDE, int NQ, bool NT>
 MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase, bool do_store = true) {
   constexpr int NIT = (NQ + STRIDE - 1) / STRIDE;
   uint32_t cw[NIT], tq[2][4];
@@ -319,12 +336,18 @@ MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8
     uint32_t o3[3];
     obs7_quad_pack(tq[it & 1], o3);
     Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) ((Out12*)obase)[u] = v;
+    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) store12(obase + (size_t)u * 12, v, NT);
   }
 }
 
 constexpr int ROLL_CODES_BYTES = 64 * VIEW_CELLS + 16;        // one wave's code staging (+ slack for the 8-byte accesses)
 constexpr int ROLL_MAX_WAVES = 4;
+#ifndef MG_DPRIO
+#define MG_DPRIO 1
+#endif
+constexpr int ROLL_LOG_STEPS = 8;                             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
+constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its progress counters
+constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
 
 // LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
 //   [0, 1024) code -> triple table | guard | NW private copies of the 64 grids (GS bytes per env) | guard | NW code stagings |
@@ -343,8 +366,8 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
   for (int x = 0; x < W; x++)
     for (int y = 0; y < H; y++) gt[x * H + y] = g[y * W + x];
 }
-template <int GG, bool FULL>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(((GG == GG_NONE || GG == GG_ROOMGRID) && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
+template <int GG, bool FULL, bool NT>
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
@@ -363,14 +386,22 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // SIMDs instead of all on the one that holds every workgroup's wave 0.
   const bool share = P.share != 0;
   const int sw = (share && P.share < 16) ? (int)(((uint32_t)wg >> (P.share - 1)) & (uint32_t)(NW - 1)) : 0;
+  // split (fused launches with three or four waves, round 4): wave 0 runs the DYNAMICS of every step once and logs them, waves 1.. keep
+  // their own grids current from the log and produce the observations, step j by encode wave j mod (NW - 1) -- see the loops below
+  const bool split_mode = !FULL && !share && P.split_mode != 0;
+  // Which wave is the dynamics wave rotates with the workgroup index (P.split_mode - 1 = the shift): a workgroup's wave i lands on SIMD i,
+  // so with wave 0 everywhere one SIMD of a CU would carry the dynamics waves of all its workgroups -- the longest instruction stream of
+  // the four -- and pace the launch (measured: profiles/r4/split_rotation.txt)
+  const int dw = split_mode ? (int)(((uint32_t)wg >> (P.split_mode - 1)) % (uint32_t)NW) : 0;
+  const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
   const int mycopy = share ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
-  uint8_t* scodes = smem + P.off_T + mycopy * P.codes_stride;        // the wave's code stream (FULL: its image-order stream of the 64 grids)
+  uint8_t* scodes = smem + P.off_T + (split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
   const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
-  const bool last_wave = share ? wave == sw : wave == NW - 1;
+  const bool last_wave = share ? wave == sw : split_mode ? wave == dw : wave == NW - 1;    // the wave that owns the final state
   // (split[] is read with compile-time indices: a register-indexed read of a kernel argument is a load from the argument segment)
   const int sp_lo = wave == 0 ? P.split[0] : wave == 1 ? P.split[1] : wave == 2 ? P.split[2] : P.split[3];
   const int sp_hi = wave == 0 ? P.split[1] : wave == 1 ? P.split[2] : wave == 2 ? P.split[3] : P.split[4];
@@ -400,7 +431,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the 64 grids, 16 B per lane, coalesced.  Time split: each wave stages its own private copy (the redundant reads hit L2); share: ONE
     // copy, staged by all the threads of the workgroup.  Four loads in flight per lane, then the four LDS writes.
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
-    const bool loads = share || j_end > 0;                           // wave-uniform
+    const bool loads = share || split_mode || j_end > 0;             // wave-uniform
     const int l0 = share ? tid : lane, lstride = share ? nthreads : 64;
     auto stage4 = [&](int base) {
       uint4 gv[4];
@@ -429,6 +460,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint32_t act0 = act_ld;
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
+  if (split_mode && tid < ROLL_LOG_SYNC_BYTES / 4) ((uint32_t*)(smem + P.off_log))[tid] = (tid >= 1 && tid < NW) ? 0u : (tid == 0 ? 0u : 0xFFFFFFFFu);   // [0] logged, [1 + k] consumed by encode wave k (absent waves: never behind)
   // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
   // (an env's ring position is lane ce's S.h: every wave has loaded its own copy of the 64 heads)
   for (int set = 0; set < P.use_shadow; set++) {
@@ -479,9 +511,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     S.cur = 0;
     for (int k = 0; k < P.cells; k++) S.cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
   }
-  const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
-                 o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
-                 o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
+  const uint32_t o_scal = (uint32_t)P.off_reward + (uint32_t)e * 16u;      // this env's mg_step_scalars inside a step record (16 bytes, ABI 3)
   S.rec_dirty = false; S.aux_dirty = false; S.wb_all = false; S.errbits = 0;
   uint32_t fin_total = 0, errs_mine = 0;
   uint32_t pw[4] = { 0, 0, 0, 0 };
@@ -489,10 +519,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   C.e = e; C.el = lane; C.sub = 0; C.active = active; C.lead = true; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
   C.mygrid = mygrid; C.myshadow = sshadow + lane * GS; C.sspr = sspr;
   const bool see_through = P.see_through != 0 || MG_EXPBIT(P, 1);
+  constexpr bool nt = NT;                                            // this launch's observation stores are nontemporal (see store12; the host picks the instantiation)
 
-  for (int j = 0; j < j_end; j++) {
-    const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
-    // ---- action ----
+  // ---- the pieces of a step ----
+  struct StepOut { uint32_t act_in, term, trunc; double reward; uint64_t sent0, sent1; bool show_taken; };
+  // action + MiniGridEnv.step / reset on this wave's copy of the grids (+ the sentence levels' verifier)
+  auto dynamics = [&](int j, StepOut& o) {
     MG_MARK("action");
     uint32_t act = A_DONE;
     if (P.phase == PHASE_STEP) {
@@ -503,43 +535,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         act = (uint32_t)(((uint64_t)w * 7u) >> 32);
       } else act = sact[j * 64 + lane];
     }
-    const uint32_t act_in = act;
+    o.act_in = act;
     if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
     if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
-    double reward = 0.0;
-    uint32_t term = 0, trunc = 0;
+    o.reward = 0.0; o.term = 0; o.trunc = 0; o.sent0 = 0; o.sent1 = 0;
     S.errbits = 0;
     MG_MARK("transition");
-    if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
+    if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
     MG_MARK("after_transition");
-    if constexpr (FULL) {
-      // The image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
-      // env at a time, lane k doing cell k (a lane re-imaging its own env cell by cell would make the whole wave walk W*H cells in
-      // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
-      unsigned long long rm = __ballot(active && S.ev_reset != 0u);
-      if (rm) {
-        const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u), from_set1 = __ballot(active && S.ev_reset == 1u && S.ev_shadow == 1u);
-        MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
-        while (rm) {
-          const int b = __ffsll((long long)rm) - 1;
-          rm &= rm - 1ull;
-          const uint8_t* sgt = smem + P.off_shadow_gt + (int)((from_set1 >> b) & 1ull) * P.codes_stride + b * cells;
-          const uint8_t* gb = sgrid + b * GS;
-          uint8_t* gt = scodes + b * cells;
-          if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }
-          else for (int k = lane; k < cells; k += 64) {
-            const uint32_t x = ((uint32_t)k * P.h_magic) >> 16, y = (uint32_t)k - x * (uint32_t)H;      // k = x * H + y
-            gt[k] = gb[y * (uint32_t)W + x];
-          }
-        }
-        MG_LDS_SYNC();
-      }
-      if (active && S.ev_dirty_idx >= 0) {
-        const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
-        scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
-      }
-    }
-    uint64_t sent0 = 0, sent1 = 0;
     if constexpr (GG == GG_SENTENCE) if (active) {
       // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): the env's
       // instruction record stays in global memory -- one lane per env, a few dependent loads per step, no other wave touches it (one
@@ -553,46 +556,49 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         a.flags &= ~FLAG_NEW_EPISODE;
       } else if (P.phase == PHASE_STEP) {
         uint32_t max_steps = 0, verr = 0;
-        const uint32_t status = verify_action(I, mygrid, W, H, a, act_in, max_steps, verr);
+        const uint32_t status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr);
         S.errbits |= verr;
-        term = status != R_CONTINUE; trunc = a.step >= max_steps;
-        reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
-        if ((term | trunc) && P.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; S.rec_dirty = true; }
+        o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
+        o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
+        if ((o.term | o.trunc) && P.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; S.rec_dirty = true; }
       }
-      sent0 = I[IW_MISSION]; sent1 = I[IW_MISSION + 1];
+      o.sent0 = I[IW_MISSION]; o.sent1 = I[IW_MISSION + 1];
     }
-    bool show_taken = false;
-    Agent av = a;
+    o.show_taken = false;
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
       // PutNext(start_carrying): the episode's first core observation shows the object where it was and empty hands (see k_step)
-      show_taken = true; av.carry = 0;
+      o.show_taken = true;
       a.flags &= ~FLAG_SHOW_TAKEN; S.rec_dirty = true;
     }
-    if (!emit) continue;
+  };
+  auto slot_of = [&](int j) { int s_ = P.slot0 - j; s_ += s_ < 0 ? P.S : 0; return s_; };   // (T <= S and slot0 < S: at most one wrap; a loop here compiled to a scalar division)
+  // reward / terminated / truncated / direction / mission id / action of step j -> its trajectory slot
+  auto store_scalars = [&](int slot_out, const StepOut& o) {
     MG_MARK("scalars");
     errs_mine |= S.errbits;
-    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (term | trunc)));
-
-    int slot_out = P.slot0 - j;                                      // (T <= S and slot0 < S: at most one wrap; a loop here compiled to a scalar division)
-    slot_out += slot_out < 0 ? P.S : 0;
+    if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (o.term | o.trunc)));
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
     if (active && !MG_EXPBIT(P, 8)) {
-      *(double*)(ob + o_rew) = reward;
-      ob[o_term] = (uint8_t)term;
-      ob[o_trunc] = (uint8_t)trunc;
-      ob[o_dir] = (uint8_t)a.dir;
-      *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
-      ob[o_act] = (uint8_t)act_in;
-      if constexpr (GG == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = sent0; sp[1] = sent1; }
+      // {reward f64 | terminated, truncated, direction, action u8 | mission id u16 | 0}: ONE 16-byte store per env (six partial-line
+      // stores cost the dynamics wave 0.3 of the 2.4 us of a 65 536-env step: profiles/r4/attribution_split.txt)
+      uint4 v;
+      v.x = (uint32_t)__double2loint(o.reward); v.y = (uint32_t)__double2hiint(o.reward);
+      v.z = o.term | (o.trunc << 8) | (a.dir << 16) | (o.act_in << 24);
+      v.w = a.mission & 0xFFFFu;
+      *(uint4*)(ob + o_scal) = v;
+      if constexpr (GG == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = o.sent0; sp[1] = o.sent1; }
     }
-    // ---- observation: 49 codes per env (lane = env), then the encode in output space (lane = four cells = 12 bytes) ----
-    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)a.carry;
+  };
+  // gen_obs of the 64 envs as they stand in this wave's grids -> the observation of trajectory slot slot_out:
+  // 49 codes per env (lane = env), then the encode in output space (lane = four cells = 12 bytes)
+  auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code) {
+    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)taken_code;
     MG_MARK("codes");
     uint32_t gt_pos = 0, gt_old = 0;
     if constexpr (FULL) {
       // the agent's own cell reads (10, 0, dir) in the observation: patched into the stream for the encode, restored after it
-      gt_pos = (uint32_t)(lane * cells) + a.x * (uint32_t)H + a.y;
-      if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (a.dir << 4)); }
+      gt_pos = (uint32_t)(lane * cells) + av.x * (uint32_t)H + av.y;
+      if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (av.dir << 4)); }
     } else if (!MG_EXPBIT(P, 4)) {
       View7 O;
       obs7_view(av, mygrid, W, H, see_through, O);
@@ -603,24 +609,24 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       obs7_stage(D, next0, lane, (uint32_t*)scodes);
     }
     MG_MARK("codes_end");
-    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[(int)(S.targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
+    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
     if (!MG_EXPBIT(P, 2) && !share) {
-      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)env0 * (size_t)OBE;   // 64 * OBE is a multiple of 16
+      uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)wg * P.obs_wg_stride;   // 64 * OBE is a multiple of 16
       const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
 #if MG_ENCODE_QUADS
       if (!FULL && nvalid == 64) {
         // 784 cell quads: thirteen rounds, the last one 16 lanes wide
-        encode_quads<64, 64 * VIEW_CELLS / 4>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));
+        encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));
       } else if (FULL && nvalid == 64) {
         const int nq = 16 * cells;                                                // 64 * cells / 4 quads
         for (int u = lane; u < nq; u += 64) {
           uint32_t o3[3];
           obs7_quad((uint32_t)u, scodes, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          ((Out12*)obase)[u] = v;
+          store12(obase + (size_t)u * 12, v, nt);
         }
       } else {
 #else
@@ -632,7 +638,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o4[4];
           obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), scodes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
-          if (it < NIT - 1 || c < NCH) ((uint4*)obase)[c] = v;
+          if (it < NIT - 1 || c < NCH) store16(obase + (size_t)c * 16, v, nt);
         }
       } else if (FULL && nvalid == 64) {
         const int nch = 12 * cells;                                               // 64 * 3 * cells / 16 chunks
@@ -640,7 +646,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o4[4];
           obs7_chunk((uint32_t)c, scodes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
-          ((uint4*)obase)[c] = v;
+          store16(obase + (size_t)c * 16, v, nt);
         }
       } else {
 #endif
@@ -649,7 +655,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         for (int c = lane; c <= nvec; c += 64) {
           uint32_t o4[4];
           obs7_chunk((uint32_t)c, scodes, slut, o4);
-          if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; ((uint4*)obase)[c] = v; }
+          if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase + (size_t)c * 16, v, nt); }
           else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
         }
       }
@@ -657,16 +663,138 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if constexpr (FULL) if (active && !share) scodes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
+  };
+
+  if (!split_mode) {
+    // ---- every wave steps for itself: one wave (NW = 1, or `share`), or the TIME SPLIT (wave w replays steps 0 .. split[w]-1 silently) ----
+    for (int j = 0; j < j_end; j++) {
+      const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
+      StepOut o;
+      dynamics(j, o);
+      if constexpr (FULL) {
+        // The image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
+        // env at a time, lane k doing cell k (a lane re-imaging its own env cell by cell would make the whole wave walk W*H cells in
+        // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
+        unsigned long long rm = __ballot(active && S.ev_reset != 0u);
+        if (rm) {
+          const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u), from_set1 = __ballot(active && S.ev_reset == 1u && S.ev_shadow == 1u);
+          MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
+          while (rm) {
+            const int b = __ffsll((long long)rm) - 1;
+            rm &= rm - 1ull;
+            const uint8_t* sgt = smem + P.off_shadow_gt + (int)((from_set1 >> b) & 1ull) * P.codes_stride + b * cells;
+            const uint8_t* gb = sgrid + b * GS;
+            uint8_t* gt = scodes + b * cells;
+            if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }
+            else for (int k = lane; k < cells; k += 64) {
+              const uint32_t x = ((uint32_t)k * P.h_magic) >> 16, y = (uint32_t)k - x * (uint32_t)H;      // k = x * H + y
+              gt[k] = gb[y * (uint32_t)W + x];
+            }
+          }
+          MG_LDS_SYNC();
+        }
+        if (active && S.ev_dirty_idx >= 0) {
+          const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
+          scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
+        }
+      }
+      if (!emit) continue;
+      const int slot_out = slot_of(j);
+      store_scalars(slot_out, o);
+      Agent av = a;
+      if (o.show_taken) av.carry = 0;
+      observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry);
+    }
+  } else if (wave == dw) {
+    // ---- DYNAMICS wave (round 4): every step's action, transition and scalar outputs, and ONE record per env and step for the encode waves --
+    // the pose the view needs and what the step did to the grid -- in a ring of ROLL_LOG_STEPS entries in LDS.  The time split made every wave
+    // replay the dynamics of the steps before its own (1.3 silent steps per produced step: a third of all instructions of a launch,
+    // profiles/r4/attribution.txt); here the dynamics run once.
+    // (an LDS-typed pointer: through a generic `volatile uint32_t*` the compiler emits FLAT loads / stores with system scope, which also
+    // count on vmcnt; the dynamic LDS starts at LDS address 0, checked above)
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps logged, [1 + k] = entries encode wave k has consumed
+    uint2* logbuf = (uint2*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES);
+    // the dynamics wave is the one serial chain everything else waits for: it wins issue arbitration against the encode waves on its SIMD
+    // (profiles/r4/ab_prio.txt: 2.42 -> 2.28 us per 65 536-env step)
+    __builtin_amdgcn_s_setprio(MG_DPRIO);
+    for (int j = 0; j < P.T; j++) {
+      StepOut o;
+      dynamics(j, o);
+      store_scalars(slot_of(j), o);
+      // pose: x | y << 8 | dir << 16 | what the agent's cell shows (the carried object; nothing under show_taken) << 24
+      const uint32_t pose = a.x | (a.y << 8) | (a.dir << 16) | ((o.show_taken ? 0u : a.carry) << 24);
+      // delta: [0:10) cell, [10:18) code, [18:20) reset kind (1 = staged shadow spare, 2 = ring slot in HBM), [20] shadow set, [21] show_taken
+      // (cell / code = where the taken object is drawn for this one observation), [22:30) ring slot, [30] the cell changed for good
+      uint32_t delta;
+      if (o.show_taken) delta = (uint32_t)(S.targets & 0x3FFull) | (a.carry << 10) | (1u << 21);
+      else delta = S.ev_dirty_idx >= 0 ? ((uint32_t)S.ev_dirty_idx | (S.ev_dirty_code << 10) | (1u << 30)) : 0u;
+      delta |= ((S.ev_reset & 3u) << 18) | ((S.ev_reset == 1u ? S.ev_shadow & 1u : 0u) << 20) | (((S.h - 1u) & P.ring_mask & 0xFFu) << 22);
+      if (j >= ROLL_LOG_STEPS) {
+        // flow control: entry j reuses the slot of entry j - ROLL_LOG_STEPS, which every encode wave must have consumed
+        const uint32_t need = (uint32_t)(j - ROLL_LOG_STEPS + 1);
+        while (true) {
+          const uint32_t p0 = sync[1], p1 = sync[2], p2 = sync[3];
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)min(p0, min(p1, p2))) >= need) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
+      // (DS operations of one wave execute in order: the counter cannot become visible before the entry; the compiler must keep that order)
+      asm volatile("" ::: "memory");
+      sync[0] = (uint32_t)(j + 1);
+    }
+  } else {
+    // ---- ENCODE waves: wave k + 1 keeps its own copy of the 64 grids current from the log (a byte write per step, a reset now and then)
+    // and produces the observations of steps j = k, k + NE, k + 2 NE, ...
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;
+    const uint2* logbuf = (const uint2*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES);
+    const int k = ek, NE = NW - 1;
+    int mine = k;                                                      // next step this wave produces
+    for (int j = 0; j < P.T; j++) {
+      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
+      const uint32_t delta = rec2.y;
+      const uint32_t rk = (delta >> 18) & 3u;
+      if (__ballot(rk != 0u)) {
+        if (rk == 1u) {
+          const uint32_t* s4 = (const uint32_t*)(C.myshadow + ((delta >> 20) & 1u) * (uint32_t)P.shadow_stride);
+          uint32_t* d4 = (uint32_t*)mygrid;
+          for (int q = 0; q < (CS >> 2); q++) d4[q] = s4[q];
+        } else if (rk == 2u) {
+          // the env's second reset of this launch: its spare comes straight from the ring in HBM (loads and their wait stay inside this branch)
+          const size_t se = (size_t)((delta >> 22) & 0xFFu) * N + (size_t)e;
+          const uint4* src = (const uint4*)(P.spare_grid + se * CS);
+          for (int c = 0; c < (CS >> 4); c++) {
+            const uint4 v = src[c];
+            uint32_t* d4 = (uint32_t*)(mygrid + c * 16);
+            d4[0] = v.x; d4[1] = v.y; d4[2] = v.z; d4[3] = v.w;
+          }
+        }
+      }
+      if (delta & (1u << 30)) mygrid[delta & 0x3FFu] = (uint8_t)(delta >> 10);
+      asm volatile("" ::: "memory");
+      sync[1 + k] = (uint32_t)(j + 1);                                 // (in order behind the entry's read)
+      if (j != mine) continue;
+      mine += NE;
+      Agent av;
+      av.x = rec2.x & 0xFFu; av.y = (rec2.x >> 8) & 0xFFu; av.dir = (rec2.x >> 16) & 3u; av.carry = rec2.x >> 24;
+      av.step = 0; av.flags = 0; av.mission = 0;
+      observe(slot_of(j), av, ((delta >> 21) & 1u) != 0u, delta & 0x3FFu, (delta >> 10) & 0xFFu);
+    }
+    return;          // (nothing to report, no state to write back: the dynamics wave owns both -- and the env state is dead on this path)
   }
 
   if (share) {
     // the one step's observation, encoded by every wave of the workgroup from the stepping wave's code stream
     __syncthreads();
     const uint8_t* codes0 = smem + P.off_T;
-    uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)env0 * (size_t)OBE;
+    uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)wg * P.obs_wg_stride;
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
     if (MG_ENCODE_QUADS && !FULL && nvalid == 64 && nthreads == 64 * ROLL_MAX_WAVES) {
-      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
+      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
     } else if (MG_ENCODE_QUADS && nvalid == 64) {
       const int nq = 16 * (FULL ? cells : VIEW_CELLS);
       if (!MG_EXPBIT(P, 2))
@@ -674,13 +802,13 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o3[3];
           obs7_quad((uint32_t)u, codes0, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          ((Out12*)obase)[u] = v;
+          store12(obase + (size_t)u * 12, v, nt);
         }
     } else if (!MG_EXPBIT(P, 2))
       for (int c = tid; c <= nvec; c += nthreads) {
         uint32_t o4[4];
         obs7_chunk((uint32_t)c, codes0, slut, o4);
-        if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; ((uint4*)obase)[c] = v; }
+        if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase + (size_t)c * 16, v, nt); }
         else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
       }
   }

@@ -49,8 +49,9 @@ struct StepParams {
   const uint8_t* obs_mask;                        // PHASE_OBSERVE of a masked reset(): only these envs take a new episode
   uint64_t* instr; const uint64_t* spare_instr; unsigned long long off_sentence;   // sentence levels through k_roll7<GG_SENTENCE>: the verifier runs inside the step loop
   // ---- outputs: slot s of the trajectory ring starts at out + s * slot_bytes; step j of this launch -> slot slot0 - j (mod S) ----
-  uint8_t* out; unsigned long long slot_bytes, off_reward, off_term, off_trunc, off_dir, off_mission, off_action;
+  uint8_t* out; unsigned long long slot_bytes, off_reward, off_term, off_trunc, off_dir, off_mission, off_action;   // field offsets of env 0's mg_step_scalars (16 bytes per env)
   uint8_t* obs; unsigned long long obs_stride;    // observation stream of slot s at obs + s * obs_stride (= out / slot_bytes, or the RGB tile map)
+  unsigned long long obs_wg_stride;               // k_roll7: ... + workgroup * obs_wg_stride (64 * OBE; S * 64 * OBE in the env-block-major trajectory layout)
   int T, slot0, S;
   // ---- tables / bookkeeping ----
   uint32_t* err; unsigned long long* counters;
@@ -69,6 +70,8 @@ struct StepParams {
   int codes_stride, off_shadow_gt; uint32_t w_magic, h_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W), ceil(2^16 / H)
   int share;              // k_roll7, one-step launches: the workgroup's waves share the output-space encode of wave 0's step
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
+  int nt;                    // k_roll7: observation stores are nontemporal (a long burst of launches; mg_api.hip launch_step)
+  int split_mode, off_log;   // k_roll7: 1 = wave 0 runs the dynamics once and logs them (ring at off_log), the other waves encode
 };
 
 // _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).
@@ -751,11 +754,8 @@ k_step(const StepParams P) {
     cur = 0;
     for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
   }
-  // per-lane byte offsets of this env's scalars inside a trajectory slot (slot_bytes < 4 GB): vector registers, so that
-  // the loop does not carry six 64-bit field offsets in scalar registers (the kernel is at the SGPR limit)
-  const uint32_t o_rew = (uint32_t)P.off_reward + (uint32_t)e * 8u, o_term = (uint32_t)P.off_term + (uint32_t)e,
-                 o_trunc = (uint32_t)P.off_trunc + (uint32_t)e, o_dir = (uint32_t)P.off_dir + (uint32_t)e,
-                 o_mis = (uint32_t)P.off_mission + (uint32_t)e * 2u, o_act = (uint32_t)P.off_action + (uint32_t)e;
+  // per-lane byte offset of this env's mg_step_scalars inside a trajectory slot (slot_bytes < 4 GB): a vector register
+  const uint32_t o_scal = (uint32_t)P.off_reward + (uint32_t)e * 16u;
   rec_dirty = false; aux_dirty = false; wb_all = false; errbits = 0;
   uint32_t fin_total = 0;
   LaneCtx C;
@@ -788,12 +788,11 @@ k_step(const StepParams P) {
 
     // ---- per-env scalar outputs: one coalesced store each ----
     if (active && lead) {
-      *(double*)(ob + o_rew) = reward;
-      ob[o_term] = (uint8_t)term;
-      ob[o_trunc] = (uint8_t)trunc;
-      ob[o_dir] = (uint8_t)a.dir;
-      *(uint16_t*)(ob + o_mis) = (uint16_t)a.mission;
-      ob[o_act] = (uint8_t)act_in;
+      uint4 v;                                                       // mg_step_scalars (include/minigrid_hip.h): one 16-byte store
+      v.x = (uint32_t)__double2loint(reward); v.y = (uint32_t)__double2hiint(reward);
+      v.z = term | (trunc << 8) | (a.dir << 16) | (act_in << 24);
+      v.w = a.mission & 0xFFFFu;
+      *(uint4*)(ob + o_scal) = v;
     }
 
     // ---- observation -> the wave's byte stream in LDS ----

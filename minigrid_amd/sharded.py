@@ -38,22 +38,37 @@ def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+SCALAR_STRIDE = 16          # sizeof(mg_step_scalars), include/minigrid_hip.h
+_SCALAR_FIELD = {"reward": 0, "terminated": 8, "truncated": 9, "direction": 10, "action": 11, "mission_id": 12}   # offsetof(...)
+
+
 def record_layout(n: int, obs_bytes: int, sentence: bool = False) -> dict:
     """Byte offsets of the fields of one step record for a shard of n envs -- the layout mg_create gives a trajectory slot
-    (minigrid_amd/csrc/mg_api.hip: every field starts on a 256-byte boundary; tests check it against mg_get_outputs)."""
+    (minigrid_amd/csrc/mg_api.hip; tests check it against mg_get_outputs): {image (n, ...) | (n) x mg_step_scalars [| sentence (n, 2) u64]},
+    every part on a 256-byte boundary.  The scalar entries are 16 bytes per env: the offsets below are env 0's fields, env i's lie
+    i * scalar_stride further."""
     up = lambda v: (v + 255) & ~255
-    off = {"image": 0}
-    off["reward"] = up(n * obs_bytes + 16)
-    off["terminated"] = off["reward"] + up(n * 8)
-    off["truncated"] = off["terminated"] + up(n)
-    off["direction"] = off["truncated"] + up(n)
-    off["mission_id"] = off["direction"] + up(n)
-    off["action"] = off["mission_id"] + up(2 * n)
-    off["record_bytes"] = up(off["action"] + n)
+    off = {"image": 0, "scalar_stride": SCALAR_STRIDE}
+    base = up(n * obs_bytes + 16)
+    for name, o in _SCALAR_FIELD.items():
+        off[name] = base + o
+    off["record_bytes"] = base + up(n * SCALAR_STRIDE)
     if sentence:                      # the sentence levels: the mission as data, two u64 per env (mg_outputs.sentence)
-        off["sentence"] = off["action"] + up(n)
+        off["sentence"] = off["record_bytes"]
         off["record_bytes"] = up(off["sentence"] + 16 * n)
     return off
+
+
+def scalar_field(raw, name: str, n: int, lay: dict):
+    """Zero-copy strided view of scalar field `name` of the n envs of one step record `raw` (1-D uint8 tensor of >= record_bytes)."""
+    import torch
+    base = lay["reward"]
+    area = raw[base: base + n * SCALAR_STRIDE]
+    if name == "reward":
+        return area.view(torch.float64)[0::2]
+    if name == "mission_id":
+        return area.view(torch.int16)[6::8]
+    return area.view(n, SCALAR_STRIDE)[:, _SCALAR_FIELD[name]]
 
 
 def _to_tensor(x):
@@ -153,12 +168,15 @@ class ShardedVecEnv:
         def put(name, t):
             b = _to_tensor(t).contiguous().view(torch.uint8).reshape(-1)
             rec[lay[name]: lay[name] + b.numel()] = b
+
+        def put_scalar(name, t):          # field `name` of the n mg_step_scalars entries
+            scalar_field(rec, name, n, lay).copy_(_to_tensor(t).reshape(n))
         put("image", image)
-        put("reward", _to_tensor(rew).to(torch.float64))
-        put("terminated", _to_tensor(np.asarray(term, np.uint8)))
-        put("truncated", _to_tensor(np.asarray(trunc, np.uint8)))
+        put_scalar("reward", _to_tensor(rew).to(torch.float64))
+        put_scalar("terminated", _to_tensor(np.asarray(term, np.uint8)))
+        put_scalar("truncated", _to_tensor(np.asarray(trunc, np.uint8)))
         if isinstance(obs, dict):
-            put("direction", _to_tensor(np.asarray(obs["direction"], np.uint8)))
+            put_scalar("direction", _to_tensor(np.asarray(obs["direction"], np.uint8)))
             if self._sentence:
                 from .sentence import encode
                 words = np.asarray([encode(str(m)) for m in np.asarray(obs["mission"]).tolist()], np.uint64).reshape(n, 2)
@@ -167,7 +185,7 @@ class ShardedVecEnv:
                 mis = obs.get("mission_id")
                 if mis is None:
                     mis = np.fromiter((self._mission_index[m] for m in np.asarray(obs["mission"]).tolist()), np.uint16, n)
-                put("mission_id", _to_tensor(np.asarray(mis, np.uint16).view(np.uint8)))
+                put_scalar("mission_id", _to_tensor(np.asarray(mis, np.uint16).view(np.int16)))
         return rec, obs_bytes
 
     def gather_record(self, rec=None, obs_bytes=None):
@@ -204,8 +222,11 @@ class ShardedVecEnv:
                 lo, hi = shard_range(self.num_envs, r, W)
                 n = hi - lo
                 lay = record_layout(n, obs_bytes, self._sentence)
-                raw = buf[r, lay[name]: lay[name] + n * esz]
-                parts.append(raw.view(dtype).reshape((n,) + tuple(tail)))
+                if name in _SCALAR_FIELD:
+                    parts.append(scalar_field(buf[r], name, n, lay))           # strided view into the gathered record
+                else:
+                    raw = buf[r, lay[name]: lay[name] + n * esz]
+                    parts.append(raw.view(dtype).reshape((n,) + tuple(tail)))
             return parts[0] if W == 1 else torch.cat(parts, 0)
         image = field("image", self._image_dtype, self._image_shape)
         rew_g = field("reward", torch.float64)
@@ -343,8 +364,11 @@ class ShardedVecEnv:
                 lo, hi = shard_range(self.num_envs, r, self.world_size)
                 n = hi - lo
                 lay = record_layout(n, obs_bytes, self._sentence)
-                raw = block[r, j, lay[name]: lay[name] + n * esz]
-                parts.append(raw.view(dt).reshape((n,) + tail))
+                if name in _SCALAR_FIELD:
+                    parts.append(scalar_field(block[r, j], name, n, lay))
+                else:
+                    raw = block[r, j, lay[name]: lay[name] + n * esz]
+                    parts.append(raw.view(dt).reshape((n,) + tail))
             out[name] = parts[0] if self.world_size == 1 else torch.cat(parts, 0)
         return out
 

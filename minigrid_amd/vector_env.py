@@ -42,9 +42,9 @@ _RNG = {"pcg64": B.RNG_PCG64, "philox": B.RNG_PHILOX}
 class _DeviceArray:
     """Zero-copy view of a library-owned device buffer (`__cuda_array_interface__` v3; torch.as_tensor accepts it)."""
 
-    def __init__(self, ptr: int, shape, typestr: str, owner):
+    def __init__(self, ptr: int, shape, typestr: str, owner, strides=None):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 3, "strides": None}
+                                         "version": 3, "strides": None if strides is None else tuple(strides)}
         self._owner = owner  # keep the env alive
 
 
@@ -226,24 +226,27 @@ class MiniGridVecEnv(_VectorEnvBase):
         if not 0 <= slot < self.traj_slots:
             raise ValueError(f"slot must be in 0..{self.traj_slots - 1}")
         n, o, off = self.num_envs, self._outs, slot * int(self._outs.slot_bytes)
+        st = (int(o.scalar_stride),)        # the scalars of a step are one 16-byte mg_step_scalars per env (ABI 3): strided views of its fields
         return {"image": _DeviceArray(o.obs + off, (n,) + self.image_shape, "|i1" if self.obs_mode == "symbolic" else "|u1", self),
-                "reward": _DeviceArray(o.reward + off, (n,), "<f8", self),
-                "terminated": _DeviceArray(o.terminated + off, (n,), "|u1", self),
-                "truncated": _DeviceArray(o.truncated + off, (n,), "|u1", self),
-                "direction": _DeviceArray(o.direction + off, (n,), "|u1", self),
-                "mission_id": _DeviceArray(o.mission_id + off, (n,), "<i2", self),     # 14-bit ids; int16 is the portable 2-byte dtype
-                "action": _DeviceArray(o.action + off, (n,), "|u1", self),
-                # the whole step as ONE contiguous byte record (obs | reward | terminated | truncated | direction |
-                # mission | action): what a multi-GPU consumer all-gathers (minigrid_amd/sharded.py)
+                "reward": _DeviceArray(o.reward + off, (n,), "<f8", self, st),
+                "terminated": _DeviceArray(o.terminated + off, (n,), "|u1", self, st),
+                "truncated": _DeviceArray(o.truncated + off, (n,), "|u1", self, st),
+                "direction": _DeviceArray(o.direction + off, (n,), "|u1", self, st),
+                "mission_id": _DeviceArray(o.mission_id + off, (n,), "<i2", self, st),     # 14-bit ids; int16 is the portable 2-byte dtype
+                "action": _DeviceArray(o.action + off, (n,), "|u1", self, st),
+                # the whole step as ONE contiguous byte record (obs | (N) x mg_step_scalars {reward, terminated, truncated, direction,
+                # action, mission id}): what a multi-GPU consumer all-gathers (minigrid_amd/sharded.py)
                 "record": _DeviceArray(o.obs + off, (int(o.record_bytes),), "|u1", self),
                 # sentence levels: the mission as data (minigrid_amd/sentence.py decodes it), two u64 per env
                 **({"sentence": _DeviceArray(o.sentence + off, (n, 2), "<u8", self)} if o.sentence else {})}
 
     def record_layout(self) -> dict:
-        """Byte offsets of the fields inside a step record (device_outputs()["record"])."""
+        """Byte offsets of env 0's fields inside a step record (device_outputs()["record"]); the scalar fields of env i lie
+        i * scalar_stride bytes further (one 16-byte mg_step_scalars per env)."""
         o = self._outs
         return {"image": 0, "reward": o.reward - o.obs, "terminated": o.terminated - o.obs, "truncated": o.truncated - o.obs,
                 "direction": o.direction - o.obs, "mission_id": o.mission_id - o.obs, "action": o.action - o.obs,
+                "scalar_stride": int(o.scalar_stride),
                 "record_bytes": int(o.record_bytes), **({"sentence": o.sentence - o.obs} if o.sentence else {})}
 
     def torch_outputs(self, slot: int = 0) -> dict:

@@ -28,7 +28,7 @@ def test_config_struct_layout_matches_header():
     assert B.MgConfig.env_index_base.offset == 96
     assert B.MgConfig.tile_size.offset == 104 and B.MgConfig.rgb_highlight.offset == 108
     assert B.MgConfig.spare_ring.offset == 112 and B.MgConfig.traj_slots.offset == 116
-    assert C.sizeof(B.MgOutputs) == 112 and B.MgOutputs.action.offset == 64 and B.MgOutputs.max_fused_steps.offset == 96 and B.MgOutputs.sentence.offset == 104
+    assert C.sizeof(B.MgOutputs) == 120 and B.MgOutputs.scalar_stride.offset == 112 and B.MgOutputs.action.offset == 64 and B.MgOutputs.max_fused_steps.offset == 96 and B.MgOutputs.sentence.offset == 104
 
 
 @pytest.mark.parametrize("obe", [147, 243, 27, 75, 363, 507, 675, 192, 980, 49, 64, 361 * 3, 5, 6, 7, 8, 9])

@@ -65,10 +65,13 @@ class OracleShard:
             img, rew, term, trunc, d, m = self.o.step(act)
             self._t += 1
             rec = self._slots[slot0 - j]
-            for name, arr in (("image", img), ("reward", rew), ("terminated", term.astype(np.uint8)), ("truncated", trunc.astype(np.uint8)),
-                              ("direction", d.astype(np.uint8)), ("mission_id", np.asarray(m, np.uint16)), ("action", act)):
-                b = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
-                rec[lay[name]: lay[name] + b.size] = b
+            b = np.ascontiguousarray(img).view(np.uint8).reshape(-1)
+            rec[: b.size] = b
+            # the scalars: one 16-byte mg_step_scalars per env (include/minigrid_hip.h, ABI 3)
+            sc = rec[lay["reward"]: lay["reward"] + 16 * n].reshape(n, 16)
+            sc[:, 0:8] = np.ascontiguousarray(rew, np.float64).view(np.uint8).reshape(n, 8)
+            sc[:, 8], sc[:, 9], sc[:, 10], sc[:, 11] = term.astype(np.uint8), trunc.astype(np.uint8), d.astype(np.uint8), act
+            sc[:, 12:14] = np.asarray(m, np.uint16).view(np.uint8).reshape(n, 2)
 
     def block_view(self, slot_lo, nslots):
         return torch.from_numpy(self._slots[slot_lo: slot_lo + nslots])
