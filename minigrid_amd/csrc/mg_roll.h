@@ -31,14 +31,6 @@
 #else
 #define MG_MARK(name) do { } while (0)
 #endif
-// attribution aid: -DMG_ATTRIBUTION builds (profiles/attr_build.py, a SEPARATE library selected with MINIGRID_AMD_LIB) read MG_EXP and
-// skip parts of a step so that their cost can be timed.  The product library is built without it: the switch folds to 0 and a stray
-// MG_EXP in somebody's environment cannot make it produce garbage.
-#if defined(MG_ATTRIBUTION)
-#define MG_EXPBIT(P, b) (((P).exp & (b)) != 0)
-#else
-#define MG_EXPBIT(P, b) false
-#endif
 
 namespace mg {
 
@@ -761,8 +753,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (__ballot(rk != 0u)) {
         if (rk == 1u) {
           const uint32_t* s4 = (const uint32_t*)(C.myshadow + ((delta >> 20) & 1u) * (uint32_t)P.shadow_stride);
-          uint32_t* d4 = (uint32_t*)mygrid;
-          for (int q = 0; q < (CS >> 2); q++) d4[q] = s4[q];
+          lds_copy_dwords((uint32_t*)mygrid, s4, CS >> 2);
         } else if (rk == 2u) {
           // the env's second reset of this launch: its spare comes straight from the ring in HBM (loads and their wait stay inside this branch)
           const size_t se = (size_t)((delta >> 22) & 0xFFu) * N + (size_t)e;

@@ -24,6 +24,15 @@
 #include "mg_tiles.h"
 #include "mg_rng.h"
 
+// attribution aid: -DMG_ATTRIBUTION builds (profiles/attr_build.py, a SEPARATE library selected with MINIGRID_AMD_LIB) read MG_EXP and
+// skip parts of a step so that their cost can be timed.  The product library is built without it: the switch folds to 0 and a stray
+// MG_EXP in somebody's environment cannot make it produce garbage.
+#if defined(MG_ATTRIBUTION)
+#define MG_EXPBIT(P, b) (((P).exp & (b)) != 0)
+#else
+#define MG_EXPBIT(P, b) false
+#endif
+
 namespace mg {
 
 constexpr int VIEW = 7;
@@ -312,6 +321,29 @@ MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, c
 // One env transition: MiniGridEnv.reset (take the next spare episode) | observe-only | MiniGridEnv.step + the level rule,
 // on the lane's registers (EnvRegs) and the env's LDS grid.  Shared by k_step and k_roll7 (mg_roll.h).
 // ======================================================================================================
+// LDS -> LDS copy of n dwords per lane, eight at a time: all eight reads are issued before the first write.  (Written as d[k] = s[k] the
+// compiler must assume the two ranges overlap and waits for every read before the next write: one LDS round trip per dword -- 16 for an
+// 8x8 grid, 0.85 us per reset of a GoToRedBall wave, whose 64 envs end an episode in nearly every step: profiles/r4/gotoredball_attr2.txt.)
+MG_D void lds_copy_dwords(uint32_t* d, const uint32_t* s, int n) {
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = s[k + i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[k + i] = t[i];
+  }
+  if (k + 4 <= n) {
+    uint32_t t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = s[k + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[k + i] = t[i];
+    k += 4;
+  }
+  for (; k < n; k++) d[k] = s[k];
+}
+
 struct EnvRegs {          // what lives in registers across the steps of a launch
   Agent a;
   uint64_t targets, cur;  // GoTo levels: tracked positions / where the described objects are now (see below)
@@ -389,7 +421,8 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         const uint32_t* s = (const uint32_t*)(C.myshadow + set * (uint32_t)P.shadow_stride);
         const uint64_t* sp = (const uint64_t*)((const uint8_t*)C.sspr + set * (uint32_t)P.spr_stride);
         uint32_t* d = (uint32_t*)mygrid;
-        for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
+        if (LPE == 1) lds_copy_dwords(d, s, CS >> 2);
+        else for (int k = sub; k < (CS >> 2); k += LPE) d[k] = s[k];
         a = agent_unpack(sp[0]);
         if (goto_rule) { targets = sp[1]; cur = targets; aux_dirty = true; }
         if (!P.static_gen) shadow_left--;
@@ -402,7 +435,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       if (!P.static_gen) h++;
   };
   if (active) {
-    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok) {
+    if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && !MG_EXPBIT(P, 64)) {
       take_spare();
     } else if (a.flags & FLAG_FRESH) {
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
@@ -455,7 +488,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       }
       if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
       trunc = a.step >= (uint32_t)P.max_steps;
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && !MG_EXPBIT(P, 128)) {
         // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
         // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
         // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
