@@ -69,6 +69,7 @@ struct mg_env {
   bool fast7 = false;         // the default 7x7 partial view: k_roll7 (mg_roll.h) instead of k_step
   bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
+  bool roll_split_on = true;  // MG_ROLL_SPLIT (read when the observation configuration is made): 0 = the round-3 time split at every width
   int roll_shadows = 1;       // spare episodes per env staged in LDS by a fused k_roll7 launch (2 unless the level draws nothing)
   int roll_guard = 0;
   int nwaves = 0;             // k_step workgroups (one wavefront of epw envs each) = refill request segments
@@ -302,8 +303,7 @@ static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split
 // time split: the dynamics of a step run once instead of once per wave that has not reached it yet.  With two waves the time split wins
 // (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
 static bool roll_split_ok(const mg_env* e, int nw) {
-  static const bool on = [] { const char* s = getenv("MG_ROLL_SPLIT"); return !s || atoi(s) != 0; }();
-  return on && e->fast7 && !e->fast_full && !e->sentence && nw >= 3;
+  return e->roll_split_on && e->fast7 && !e->fast_full && !e->sentence && nw >= 3;
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
@@ -675,6 +675,7 @@ static const char* configure_obs(mg_env* e) {
     if (roll_lds_bytes(e, 1, true) > 72 * 1024) e->fast_full = false;
     else { e->lpe = 1; e->epw = 64; e->nwaves = (e->N + 63) / 64; }
   }
+  { const char* s = getenv("MG_ROLL_SPLIT"); e->roll_split_on = !s || atoi(s) != 0; }
   if (e->fast7 || e->fast_full) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.

@@ -389,7 +389,12 @@ class MiniGridVecEnv(_VectorEnvBase):
             mask = done.to(torch.uint8).cpu().numpy()
             B.check(self._lib.mg_reset(self._h, None, self._p(np.ascontiguousarray(mask))), self._h)
             new_obs, _, _, _ = self._collect()
-            return new_obs, rew, term, trunc, {"final_obs": final, "final_obs_indices": idx, "_final_obs": done}
+            # torch outputs: the terminal observations of the finished envs as COMPACT tensors (row j belongs to env final_obs_indices[j])
+            # instead of Gymnasium's object array of per-env dicts; the mask keys are the same as on the numpy path.  (The `.any()`
+            # above is a host synchronisation per step: this mode composes two launches on the host and needs to know whether the second
+            # one is due; the fused entry points are the path without host round trips.)
+            return new_obs, rew, term, trunc, {"final_obs": final, "final_obs_indices": idx, "_final_obs": done,
+                                               "final_info": {}, "_final_info": done}
         done = term | trunc
         if not done.any():
             return obs, rew, term, trunc, {}

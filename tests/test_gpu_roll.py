@@ -31,13 +31,17 @@ def test_valu_primitives_device_equals_host():
         assert (host[k] == dev[k]).all(), name
 
 
-@pytest.mark.parametrize("nw", [1, 2, 3, 4])
+@pytest.mark.parametrize("nw,split", [(1, 1), (2, 1), (3, 1), (4, 1), (3, 0), (4, 0)])
 @pytest.mark.parametrize("env_id,max_steps,full_T", [("MiniGrid-DoorKey-8x8-v0", 3, 128), ("BabyAI-GoToRedBall-v0", 2, 96),
                                                       ("BabyAI-PutNextS5N2Carrying-v0", 4, 96), ("MiniGrid-MemoryS7-v0", 5, 96),
                                                       ("MiniGrid-LavaCrossingS9N1-v0", 40, 160)])
-def test_time_split_widths_equal_the_oracle(nw, env_id, max_steps, full_T, monkeypatch):
+def test_time_split_widths_equal_the_oracle(nw, split, env_id, max_steps, full_T, monkeypatch):
+    """Every shape of a fused k_roll7 launch: one wave, the time split (2 waves; 3 / 4 with MG_ROLL_SPLIT=0) and -- the default for 3 / 4
+    waves since round 4 -- one dynamics wave + encode waves fed by the LDS step log, under 2-5-step episodes (a reset in nearly every
+    step, second resets of a launch straight from the ring, PutNext's show_taken observation, the log ring wrapping every 8 steps)."""
     from test_gpu_fused import _fused_vs_oracle
     monkeypatch.setenv("MG_ROLL_NW", str(nw))
+    monkeypatch.setenv("MG_ROLL_SPLIT", str(split))
     nterm, ntrunc = _fused_vs_oracle(env_id, 1000 + nw, full_T, False, chunk=32, max_steps=max_steps)
     assert nterm + ntrunc > 1000
 
