@@ -33,6 +33,7 @@ UNITS = {
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
     "mg_step_sentence.hip": _STEP,
 }
+UNITS["mg_gen_lane.hip"] = _GEN + ["mg_genlane.h"]
 for _g in ("rooms", "sentence", "roomgrid", "light"):
     for _r in ("pcg", "philox"):
         for _k in ("refill", "generate"):

@@ -21,6 +21,7 @@
 #include "mg_kernels_aux.h"
 #include "mg_roll.h"
 #include "mg_launch.h"
+#include "mg_genlane.h"
 
 using namespace mg;
 
@@ -69,6 +70,7 @@ struct mg_env {
   bool fast7 = false;         // the default 7x7 partial view: k_roll7 (mg_roll.h) instead of k_step
   bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
+  bool lane_gen = false;      // the refills run one lane per episode (k_refill_lane: the single-room levels; MG_LANE_GEN=0: the wave-per-episode k_refill)
   bool roll_split_on = true;  // MG_ROLL_SPLIT (read when the observation configuration is made): 0 = the round-3 time split at every width
   int roll_shadows = 1;       // spare episodes per env staged in LDS by a fused k_roll7 launch (2 unless the level draws nothing)
   int roll_guard = 0;
@@ -215,6 +217,12 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
   const dim3 rgrid(e->nwaves * A.wps);
+  if (!live && e->lane_gen) {
+    // one LANE per episode (mg_genlane.h): a wavefront per request segment, each lane drawing its own request's episodes
+    A.wps = 2;
+    if (const char* s = getenv("MG_LANE_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
+    launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)64 * lane_grid_stride(e->CS), st, A);
+  } else
   MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemsetAsync(A.seg_count, 0, (size_t)e->nwaves * sizeof(uint32_t), st));
@@ -973,6 +981,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->GS = e->CS + 4;                                     // odd dword stride: conflict-free same-cell LDS reads
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
+  {
+    const char* s = getenv("MG_LANE_GEN");
+    e->lane_gen = lane_gen_kind(cfg->env_kind) && (!s || atoi(s) != 0) && 64 * lane_grid_stride(e->CS) <= 64 * 1024;
+  }
   e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
   {
@@ -985,18 +997,23 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // DoorKey-8x8 x 262 144: 19.0 (32), 17.9 (64), 16.8 (128); LavaCrossing FullyObs x 131 072: 18.1 (32), 15.2 (64), 13.5 (128).
     // Default: 128, and 64 for the BabyAI single-room generators (whole-map rejection sampling: their long refill chains do
     // worse with twice the work per refill).  Sized for 288 GB of HBM: 128 spare maps of 64 B are 8 KB per env (2 GB at 262 144
-    // envs); capped at 8 GB of ring (the sentence levels carry a 320 B instruction record per spare: the cap halves their ring at large batches).
+    // envs); capped at 16 GB of ring (the sentence levels carry a 320 B instruction record per spare: the cap halves their ring at large batches).
     int R = 1;
     if (!e->static_gen && !e->live_gen) {
       // (the sentence levels: 64 since their verifier runs inside the fused step loop -- with 16 a refill of ~0.6 ms, the length of its
       // longest LevelGen chain, was due every 8 steps and bounded BossLevel at 76 us per step; 64: 38 us, profiles/r3/bosslevel_ring.txt)
       R = cfg->spare_ring > 0 ? cfg->spare_ring : (gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID || e->sentence) ? 64 : 128;
+      // k_refill_lane (one lane per episode, round 4) does a fifth of k_refill's work per episode but a refill LASTS longer -- a wave runs as
+      // long as its unluckiest lane (GoToRedBall: 200-290 us) -- so its levels with many resets take the deepest ring: a refill is then due
+      // every 128 steps, not every 32 (GoToRedBall x 32 768: 6.8 us per step with R = 64, 3.9 with 128, 2.9 with 256: profiles/r4/lane_refill_ring.txt)
+      // (and the others gain as well -- DoorKey-8x8 x 262 144: 7.93 -> 7.49 us per step, LavaCrossing FullyObs x 131 072: 8.84 -> 8.32)
+      if (cfg->spare_ring <= 0 && e->lane_gen) R = 256;
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
-      // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 8 GB cap
+      // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 16 GB cap
       const size_t per_slot_env = (size_t)e->CS + 16 + 40 + (e->sentence ? 4 + INSTR_WORDS * 8 : 0);
-      while (R > 4 && (size_t)R * e->N * per_slot_env > ((size_t)8 << 30)) R >>= 1;
+      while (R > 4 && (size_t)R * e->N * per_slot_env > ((size_t)16 << 30)) R >>= 1;     // (16 GB of 288)
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
   }

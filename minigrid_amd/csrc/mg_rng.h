@@ -50,6 +50,8 @@ MG_HD void seedseq_words(uint64_t seed, uint64_t out[4]) {
 // ---------------- PCG64 (XSL-RR 128/64) with numpy's 32-bit half cache ----------------
 struct Pcg64Stream {
   static constexpr bool kEpisodic = false;   // carried state; nothing to do at an episode boundary
+  static constexpr bool kWave = false;       // one lane's own stream (k_move_obstacles, k_refill_lane)
+  MG_HD void checkpoint() {}                 // (generator restart points matter to the wave-cooperative draw buffers only)
   u128 state, inc;
   uint32_t has32, cache32;
 
@@ -113,6 +115,8 @@ MG_HD void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 // SoA words reuse the PCG layout: {seed, episode, block<<8|pos, buf01, buf23}.
 struct PhiloxStream {
   static constexpr bool kEpisodic = true;    // counter restarts per episode (begin_episode)
+  static constexpr bool kWave = false;
+  MG_HD void checkpoint() {}
   uint64_t key, episode;
   uint32_t block, pos;       // pos = next unread word of buf (4 = empty)
   uint32_t buf[4];
@@ -126,7 +130,10 @@ struct PhiloxStream {
       philox4x32_10(buf, (uint32_t)key, (uint32_t)(key >> 32));
       pos = 0;
     }
-    return buf[pos++];
+    // (selects, not buf[pos]: a register array indexed at run time goes to scratch memory)
+    const uint32_t v = pos == 0 ? buf[0] : pos == 1 ? buf[1] : pos == 2 ? buf[2] : buf[3];
+    pos++;
+    return v;
   }
   MG_HD void load(const uint64_t* base, size_t n, size_t i) {
     key = base[i]; episode = base[n + i];
@@ -192,6 +199,7 @@ MG_D u128 pcg_jump(u128 state, u128 inc, uint32_t k) {
 // high half).  A cached half carried in from the previous episode is simply the first word of the buffer.
 struct WavePcg64 {
   static constexpr bool kEpisodic = false;
+  static constexpr bool kWave = true;
   static constexpr uint32_t kRefillWords = 128;
   uint32_t* buf;               // LDS: [carried-in half][stream words ...]
   uint64_t* sbase;             // LDS: stream state after r refills (hi, lo), r < GEN_SBASE_ENTRIES
@@ -303,6 +311,7 @@ struct WavePcg64 {
 // Philox4x32-10: lane l computes counter block (64 r + l) of the episode; one refill = 256 draws.
 struct WavePhilox {
   static constexpr bool kEpisodic = true;
+  static constexpr bool kWave = true;
   static constexpr uint32_t kRefillWords = 256;
   uint32_t* buf;
   uint64_t key, episode;       // uniform
@@ -387,7 +396,7 @@ MG_HD int rand_int(R& r, int low, int high) {
   if (__builtin_expect(leftover < rng_excl, 0)) {
     uint32_t threshold = lemire_threshold(rng, rng_excl);
 #if defined(__HIP_DEVICE_COMPILE__)
-    threshold = uni32(threshold);     // a call result is not known to be wave-uniform; keep the draw position scalar
+    if constexpr (R::kWave) threshold = uni32(threshold);     // a call result is not known to be wave-uniform; keep the draw position scalar
 #endif
     while (leftover < threshold && !r.dead()) { m = (uint64_t)r.next32() * rng_excl; leftover = (uint32_t)m; }
   }
