@@ -197,6 +197,8 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask, hipStream
   // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
+  if (e->lane_gen) launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)64 * lane_grid_stride(e->CS), st, A);   // one lane per env (mg_genlane.h)
+  else
   MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, st, A);
   HIP_TRY(e, hipGetLastError());
   return MG_OK;
@@ -327,7 +329,8 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.instr = e->instr; P.spare_instr = e->spare_instr; P.off_sentence = e->off_sentence;
   P.out = e->out; P.slot_bytes = e->slot_bytes;
   P.obs = e->rgb ? e->tilemap : e->out; P.obs_stride = e->rgb ? 0ull : (unsigned long long)e->slot_bytes;
-  P.obs_wg_stride = 64ull * (unsigned long long)e->map_bytes;
+  P.epw = e->epw;
+  P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
@@ -697,6 +700,15 @@ static const char* configure_obs(mg_env* e) {
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
     e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
+  }
+  if (e->fast7 && !e->fast_full) {
+    // MG_ROLL_EPW=32: 32 envs per k_roll7 workgroup (lanes 32 .. 63 idle) = twice the workgroups for a batch that leaves the chip half
+    // empty.  Measured in round 4 and NOT adopted (profiles/r4/epw32.txt): GoToRedBall x 32 768 4.9 us per step against 2.9, Empty-8x8 x 32 768
+    // 1.60 against 1.37, x 16 384 1.28 against 1.32 -- the wave-instructions double and the chains do not get shorter.  The switch stays
+    // for A/B runs; tests/test_gpu_roll.py keeps the path exact.
+    int epw = 64;
+    if (const char* s = getenv("MG_ROLL_EPW")) { int v = atoi(s); if ((v == 32 && !e->sentence) || v == 64) epw = v; }
+    e->epw = epw; e->nwaves = (e->N + epw - 1) / epw;
   }
   if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";
   e->seg_cap = e->live_gen ? e->epw : e->epw * 2 * e->cb;  // at most 2*cb launches per batch, one request per env each

@@ -107,4 +107,18 @@ __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
   }
 }
 
+// Direct generation with one lane per env (explicit reset(seed=...): the live episode, then the ring slots; mg_set_rng): lane l of workgroup b
+// draws env 64 b + l.  The destination pointers are pre-offset to the ring slot by the host (gen_args), like k_generate's.
+template <class R>
+__global__ void __launch_bounds__(64) k_generate_lane(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = (int)threadIdx.x;
+  const int e = (int)blockIdx.x * 64 + lane;
+  if (e >= A.N) return;
+  if (A.mask && !A.mask[e]) return;
+  LaneGrid g;
+  g.p = smem + lane * lane_grid_stride(A.CS); g.W = A.gp.W; g.H = A.gp.H; g.lane = lane; g.nonempty = 0; g.walls = 0;
+  generate_one_lane<R>(A, e, 0u, g);
+}
+
 }  // namespace mg

@@ -364,9 +364,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
   const int wg = blockIdx.x;      // (an XCD-contiguous remap of the workgroups and a wait after every store were measured: no gain, profiles/r4/ab_store_variants.txt)
-  const int env0 = wg * 64, e = env0 + lane;
-  const bool active = e < P.N;
-  const int nvalid = min(64, P.N - env0);
+  // A workgroup's envs: 64 (one per lane), or 32 when the batch would otherwise leave the chip half empty (P.epw; lanes 32 .. 63 idle:
+  // twice the workgroups, and this kernel is bound by the latency of its per-wave chains long before it is bound by lanes)
+  const int EPW = P.epw;
+  const int env0 = wg * EPW, e = env0 + lane;
+  const bool active = lane < EPW && e < P.N;
+  const int nvalid = min(EPW, P.N - env0);
   const int W = P.W, H = P.H, CS = P.CS, GS = P.GS;
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint32_t h_ld = P.head ? P.head[ec] : 0u;
   const uint32_t mask_ld = P.obs_mask ? (uint32_t)P.obs_mask[ec] : 1u;
   const bool stage_acts = P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER;
-  const bool act_mine = tid < P.T * 64 && env0 + (tid & 63) < P.N;    // one-step launches: this lane's share of the caller's actions
+  const bool act_mine = tid < P.T * 64 && (tid & 63) < EPW && env0 + (tid & 63) < P.N;    // one-step launches: this lane's share of the caller's actions
   const uint32_t act_ld = stage_acts ? load_action(P, min(env0 + (tid & 63), P.N - 1), min(tid >> 6, P.T - 1)) : 0u;
   S.shadow_left = (uint32_t)P.use_shadow;
   const int cpe = CS >> 4, nchunks = nvalid * cpe;
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if (act_mine) sact[tid] = (uint8_t)act0;
     for (int k = tid + nthreads; k < P.T * 64; k += nthreads) {       // (fused launches with caller actions: the rest of the T x 64 block)
       const int j = k >> 6, l = k & 63;
-      if (env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
+      if (l < EPW && env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
     }
   }
   if constexpr (FULL) {
@@ -612,6 +615,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (!FULL && nvalid == 64) {
         // 784 cell quads: thirteen rounds, the last one 16 lanes wide
         encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));
+      } else if (!FULL && nvalid == 32) {
+        encode_quads<64, 32 * VIEW_CELLS / 4, NT>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));      // 32-env workgroups: 392 quads, seven rounds
       } else if (FULL && nvalid == 64) {
         const int nq = 16 * cells;                                                // 64 * cells / 4 quads
         for (int u = lane; u < nq; u += 64) {
@@ -786,6 +791,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
     if (MG_ENCODE_QUADS && !FULL && nvalid == 64 && nthreads == 64 * ROLL_MAX_WAVES) {
       if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
+    } else if (MG_ENCODE_QUADS && !FULL && nvalid == 32 && nthreads == 64 * ROLL_MAX_WAVES) {
+      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 32 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase);
     } else if (MG_ENCODE_QUADS && nvalid == 64) {
       const int nq = 16 * (FULL ? cells : VIEW_CELLS);
       if (!MG_EXPBIT(P, 2))

@@ -79,6 +79,7 @@ struct StepParams {
   int codes_stride, off_shadow_gt; uint32_t w_magic, h_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W), ceil(2^16 / H)
   int share;              // k_roll7, one-step launches: the workgroup's waves share the output-space encode of wave 0's step
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
+  int epw;                   // k_roll7: envs per workgroup (64, or 32 for small batches; mg_api.hip configure_obs)
   int nt;                    // k_roll7: observation stores are nontemporal (a long burst of launches; mg_api.hip launch_step)
   int split_mode, off_log;   // k_roll7: 1 = wave 0 runs the dynamics once and logs them (ring at off_log), the other waves encode
 };

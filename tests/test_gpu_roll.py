@@ -46,6 +46,15 @@ def test_time_split_widths_equal_the_oracle(nw, split, env_id, max_steps, full_T
     assert nterm + ntrunc > 1000
 
 
+@pytest.mark.parametrize("env_id,max_steps", [("MiniGrid-DoorKey-8x8-v0", 5), ("BabyAI-GoToRedBall-v0", 3)])
+def test_32_env_workgroups_equal_the_oracle(env_id, max_steps, monkeypatch):
+    """MG_ROLL_EPW=32 (an A/B switch: half-filled wavefronts, twice the workgroups): fused launches and single steps stay exact."""
+    from test_gpu_fused import _fused_vs_oracle
+    monkeypatch.setenv("MG_ROLL_EPW", "32")
+    nterm, ntrunc = _fused_vs_oracle(env_id, 1000, 96, False, chunk=32, max_steps=max_steps)
+    assert nterm + ntrunc > 1000
+
+
 def test_time_split_default_rings_caller_actions():
     """step_many (caller-supplied actions staged in LDS, shared by the workgroup's waves) == step by step."""
     import minigrid_amd as mg
