@@ -99,16 +99,22 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
     import re
     best = None
     for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl):
-        vals = {}
+        vals, parts = {}, {}
         for c, f in zip(("FETCH_SIZE", "WRITE_SIZE"), _pmc_files(d, workload, suffix)):
             if not os.path.exists(f):
                 break
             for line in open(f):
                 m = re.match(rf"{c},(?:void )?mg::(k_\w+<[^>]*>|k_render),calls=\d+,mean=([0-9.]+)(?:,total=[0-9.]+)?(?:,max=([0-9.]+))?", line)
                 if m and (m.group(1).startswith("k_step") or m.group(1).startswith("k_roll") or m.group(1) == "k_render"):
-                    # RGB workloads: k_step + k_render make one step.  A run mixes full launches with one-step reset observations:
-                    # the per-call maximum is the full launch when the summary has it
-                    vals[c] = vals.get(c, 0.0) + float(m.group(3) or m.group(2))
+                    # A run mixes full launches with one-step reset observations: the per-call maximum is the full launch when the summary
+                    # has it.  The step kernel has several instantiations in one run (k_roll7<., ., nontemporal | plain>: the first launches
+                    # of a burst and the reset observations take the plain one): the LARGEST is the full launch.  RGB workloads add k_render
+                    # (k_step + k_render make one step).
+                    v = float(m.group(3) or m.group(2))
+                    key = (c, "render" if m.group(1) == "k_render" else "step")
+                    parts[key] = max(parts.get(key, 0.0), v)
+        for (c, _part), v in parts.items():
+            vals[c] = vals.get(c, 0.0) + v
         if len(vals) == 2:
             best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return best
