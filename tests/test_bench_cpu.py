@@ -46,7 +46,10 @@ def test_committed_profiles_are_quoted_only_for_the_same_launch_shape():
         W = H = 9 if "Lava" in env_id else 8
         algo = b.algorithmic_bytes_per_env_step(env_id, obs_mode, W, H) * n * 32
         assert traffic is not None and 0.3 * algo < traffic < 1.0 * algo, (name, traffic, algo)     # the grids stay in LDS: about half
-        assert us is not None and abs(us - meta["full_launch_avg_us"] / 32) < 1e-9
+        # the latest round's pass of this launch shape is the one quoted
+        src = b.pmc_traffic_source(name, n, 32)
+        latest = json.load(open(os.path.join(ROOT, os.path.dirname(src), f"meta_{name}.json")))
+        assert us is not None and abs(us - latest["full_launch_avg_us"] / 32) < 1e-9
         # real bytes / kernel time stays below the part's peak
         assert traffic / (us * 32 * 1e-6) < b.HBM_PEAK_GBPS * 1e9
         # another launch length or another batch size must not be given these counters
@@ -69,6 +72,46 @@ def test_committed_bench_lines_are_self_consistent():
         assert abs(achieved - r["achieved"]) / r["achieved"] < 0.01, (f, achieved, r["achieved"])
         if d["steps"] == 20:
             assert r["traffic"] is None                    # (round 3 had no PMC pass of that launch shape; round 4 does: below)
+
+
+def test_round4_profiles_cover_both_launch_shapes():
+    """VERDICT r3 missing #2: the driver's own launch shape (bench.py --steps 20 --warmup 5: one 20-step launch) has committed kernel-trace
+    and PMC passes, so its line carries traffic / kernel_us_per_step; the counters agree with the analytic floor to a few per cent and the
+    real-bytes fraction stays below 1 for every BASELINE workload."""
+    b = _bench()
+    r4 = os.path.join(ROOT, "profiles", "r4")
+    for name, spl, sfx in (("empty8x8", 32, ""), ("empty8x8", 20, "_spl20"), ("doorkey8x8", 32, ""), ("lavacrossing_full", 32, ""), ("gotoredball", 32, "")):
+        env_id, n, obs_mode = b.WORKLOADS[name]
+        meta = json.load(open(os.path.join(r4, f"meta_{name}{sfx}.json")))
+        assert meta["envs_per_gpu"] == n and meta["steps_per_launch"] == spl
+        assert "attribution=0" in meta["library_build"] and not meta["environment"], meta      # the product build, no MG_* switch set
+        traffic, us = b.pmc_traffic_bytes(name, n, spl), b.rocprof_kernel_us_per_step(name, n, spl)
+        assert b.pmc_traffic_source(name, n, spl).startswith("profiles/r4/")
+        W = H = 9 if "Lava" in env_id else 8
+        obe = 3 * W * H if obs_mode == "full" else 147
+        floor = (obe + 16 + (2 * W * H + 16) / spl) * n * spl
+        assert 0.97 * floor < traffic < 1.12 * floor, (name, spl, traffic / floor)
+        frac = traffic / (us * spl * 1e-6) / (b.HBM_PEAK_GBPS * 1e9)
+        assert 0.25 < frac < 1.0, (name, frac)
+    # round 3's headline fraction on real bytes was 0.54 (VERDICT r3); round 4's committed passes
+    t, us = b.pmc_traffic_bytes("empty8x8", 65536, 32), b.rocprof_kernel_us_per_step("empty8x8", 65536, 32)
+    assert t / (us * 32e-6) / 8e12 > 0.60
+
+
+def test_round4_bench_lines_are_self_consistent():
+    for f in ("bench_empty8x8", "bench_doorkey8x8", "bench_lavacrossing_full", "bench_gotoredball", "bench_driver1", "bench_default_run"):
+        d = json.loads(open(os.path.join(ROOT, "profiles", "r4", f + ".json")).read().strip().splitlines()[-1])
+        r = d["roofline"]
+        assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] == "hbm"
+        assert r["traffic"] is not None and r["kernel_us_per_step"] is not None and r["traffic_source"].startswith("profiles/r4/")
+        assert abs(r["traffic_vs_floor"] - 1) < 0.12
+        n_launch = -(-d["steps"] // d["config"]["steps_per_launch"])
+        achieved = r["bytes_per_launch"] / (d["event_ms"] / 1e3 / n_launch) / 1e9
+        assert abs(achieved - r["achieved"]) / r["achieved"] < 0.01
+        assert d["event_ms"] <= d["host_ms"] * 1.001 <= d["host_ms_incl_device_sync"] * 1.002
+        assert abs(d["value"] - d["config"]["envs_per_gpu"] * d["steps"] / (d["host_ms"] / 1e3)) / d["value"] < 0.01
+        assert d["config"]["library_build"].startswith("attribution=0") and d["config"]["environment"] == {}
+        assert r["survey_8d"]["bytes_per_env_step"] in (324, 326, 516)
 
 
 def _run_bench(args, env_extra=None, timeout=240):
