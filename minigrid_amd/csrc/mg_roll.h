@@ -609,6 +609,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_MARK("chunks");
     if (!MG_EXPBIT(P, 2) && !share) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)wg * P.obs_wg_stride;   // 64 * OBE is a multiple of 16
+      // (attribution builds, MG_EXP bit 256: every workgroup's observations go to a 1.2 MB window that stays in L2 -- the same store
+      // instructions without the HBM write stream: is the observation stream's cost its issue or its bandwidth?)
+      if (MG_EXPBIT(P, 256)) obase = P.obs + (size_t)(wg & 127) * P.obs_wg_stride;
       const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
 #if MG_ENCODE_QUADS
