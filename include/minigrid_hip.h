@@ -186,6 +186,9 @@ typedef struct mg_config {
   int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default (128 / 64 / 16)      */
   int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (32, fewer when a slot is large);
                                  < 0 = -traj_slots preferred, halved like the default while the ring would exceed 2 GB       */
+  int32_t babyai_done_actions; /* envs/babyai/core/verifier.py:26 use_done_actions (the reference reads BABYAI_DONE_ACTIONS when it is imported):
+                                 only the `done` action reports -- success iff the previous action completed the instruction, failure
+                                 otherwise (verifier.py:228-242).  RoomGridLevel-based levels only; ignored elsewhere.  Default 0.           */
 } mg_config;
 
 /* Borrowed device pointers to the outputs of the last step/reset = slot 0 of the trajectory ring.  The ring has

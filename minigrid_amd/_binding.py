@@ -21,7 +21,8 @@ class MgConfig(C.Structure):
         "obs_mode", "autoreset_mode", "rng_mode", "num_envs", "agent_start_x", "agent_start_y", "agent_start_dir",
         "num_crossings", "obstacle_type", "num_dists", "null_stream_sync", "strip2_row", "no_death_mask")] + [
         ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("env_index_base", C.c_int64),
-        ("tile_size", C.c_int32), ("rgb_highlight", C.c_int32), ("spare_ring", C.c_int32), ("traj_slots", C.c_int32)]
+        ("tile_size", C.c_int32), ("rgb_highlight", C.c_int32), ("spare_ring", C.c_int32), ("traj_slots", C.c_int32),
+        ("babyai_done_actions", C.c_int32)]
 
 
 class MgOutputs(C.Structure):

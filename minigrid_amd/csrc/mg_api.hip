@@ -330,6 +330,13 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.out = e->out; P.slot_bytes = e->slot_bytes;
   P.obs = e->rgb ? e->tilemap : e->out; P.obs_stride = e->rgb ? 0ull : (unsigned long long)e->slot_bytes;
   P.epw = e->epw;
+  {
+    // use_done_actions applies to the levels built on RoomGridLevel (instrs.verify at the end of their step, roomgrid_level.py:87-104)
+    const int k = e->cfg.env_kind;
+    const bool babyai = k == MG_ENV_GOTO_REDBALL || (k >= MG_ENV_GOTO_REDBALLGREY && k <= MG_ENV_GOTO_LOCAL) || (k >= MG_ENV_PICKUPDIST && k <= MG_ENV_BABYAI_KEYCORRIDOR) ||
+                        (k >= MG_ENV_BABYAI_GOTO && k <= MG_ENV_LEVELGEN);
+    P.done_actions = (e->cfg.babyai_done_actions != 0 && babyai) ? 1 : 0;
+  }
   P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
@@ -473,7 +480,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     V.head = e->head; V.ring_mask = (uint32_t)(e->R - 1);
     V.rec = e->out + (size_t)P.slot0 * e->slot_bytes;
     V.off_reward = e->off_reward; V.off_term = e->off_term; V.off_trunc = e->off_trunc; V.off_action = e->off_action; V.off_sentence = e->off_sentence;
-    V.err = e->err; V.N = e->N; V.W = e->W; V.H = e->H; V.CS = e->CS; V.phase = P.phase; V.autoreset_next_step = P.autoreset_next_step;
+    V.err = e->err; V.N = e->N; V.W = e->W; V.H = e->H; V.CS = e->CS; V.phase = P.phase; V.autoreset_next_step = P.autoreset_next_step; V.done_actions = P.done_actions;
     hipLaunchKernelGGL(k_verify, dim3((e->N + 127) / 128), dim3(128), 0, e->stream, V);
     HIP_TRY(e, hipGetLastError());
   }
@@ -1180,7 +1187,8 @@ int mg_set_obs_config(mg_env* e, const mg_config* cfg) {
                       /* null_stream_sync: decided by the binding at create time */
                       g.strip2_row == w.strip2_row && g.no_death_mask == w.no_death_mask && g.death_cost == w.death_cost &&
                       g.room_size == w.room_size && g.random_length == w.random_length && g.env_index_base == w.env_index_base &&
-                      g.tile_size == w.tile_size && g.rgb_highlight == w.rgb_highlight && g.spare_ring == w.spare_ring && g.traj_slots == w.traj_slots;
+                      g.tile_size == w.tile_size && g.rgb_highlight == w.rgb_highlight && g.spare_ring == w.spare_ring && g.traj_slots == w.traj_slots &&
+                      g.babyai_done_actions == w.babyai_done_actions;
     if (!same)
       return fail(e, MG_ERR_INVALID, "set_obs_config: only obs_mode, agent_view_size, tile_size, rgb_highlight, no_death_mask, death_cost and traj_slots may change");
   }

@@ -154,6 +154,9 @@ constexpr uint32_t FLAG_NEW_EPISODE = 32u;    // sentence levels: k_step took a 
 // spare episodes only: drawing this episode met RoomGrid.place_agent's endless loop (mg_gen.h room_stuck) -- the reference would never
 // return from the reset() that reaches it.  Taking the episode out of the ring reports ERR_GENERATOR (take_spare, mg_step.h).
 constexpr uint32_t FLAG_STUCK = 64u;
+// BabyAI levels with ONE action instruction under use_done_actions (verifier.py:26, 222-242): ActionInstr.lastStepMatch -- the previous
+// action completed the instruction.  Cleared with the other flags when an episode is taken (a fresh instruction per mission).
+constexpr uint32_t FLAG_LAST_MATCH = 128u;
 struct Agent {
   uint32_t x, y, dir, carry, step, flags, mission;
 };

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         a.flags &= ~FLAG_NEW_EPISODE;
       } else if (P.phase == PHASE_STEP) {
         uint32_t max_steps = 0, verr = 0;
-        const uint32_t status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr);
+        const uint32_t status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
         S.errbits |= verr;
         o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
         o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;

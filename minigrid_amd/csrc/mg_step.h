@@ -79,6 +79,7 @@ struct StepParams {
   int codes_stride, off_shadow_gt; uint32_t w_magic, h_magic;   // k_roll7: bytes between the waves' code streams; FullyObs: shadow image stream, ceil(2^16 / W), ceil(2^16 / H)
   int share;              // k_roll7, one-step launches: the workgroup's waves share the output-space encode of wave 0's step
   int split[5];           // k_roll7 (mg_roll.h): wave w of a workgroup produces steps [split[w], split[w + 1])
+  int done_actions;          // BabyAI levels: verifier.py's use_done_actions (only the `done` action reports; mg_config.babyai_done_actions)
   int epw;                   // k_roll7: envs per workgroup (64, or 32 for small batches; mg_api.hip configure_obs)
   int nt;                    // k_roll7: observation stores are nontemporal (a long burst of launches; mg_api.hip launch_step)
   int split_mode, off_log;   // k_roll7: 1 = wave 0 runs the dynamics once and logs them (ring at off_log), the other waves encode
@@ -670,6 +671,15 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
           }
           term = 1; success = next_to;
         }
+      }
+      if (P.done_actions && P.rule != RULE_SENTENCE) {            // (the sentence levels: inside verify_action, per leaf)
+        // ActionInstr.verify with use_done_actions (verifier.py:228-242), levels with ONE action instruction (the rules above are its
+        // verify_action): `done` reports success iff the previous action completed the instruction, else failure; every other action only
+        // remembers whether it matched (the method returns None: RoomGridLevel.step carries on).  The host sets the switch for the
+        // RoomGridLevel-based levels only.
+        const bool matched = term != 0u && success;
+        if (act == A_DONE) { term = 1; success = (a.flags & FLAG_LAST_MATCH) != 0u; }
+        else { a.flags = matched ? (a.flags | FLAG_LAST_MATCH) : (a.flags & ~FLAG_LAST_MATCH); term = 0; success = false; }
       }
       if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
       if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {

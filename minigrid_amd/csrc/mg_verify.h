@@ -9,6 +9,7 @@ namespace mg {
 
 struct InstrRef {
   uint64_t* I; const uint8_t* g; int W, H;
+  bool done_actions;                 // verifier.py:26 use_done_actions
   uint32_t act, carry_id;            // carry_id: id + 1 of what the agent holds after the action
   int fidx; bool inb;                // the cell in front of the agent after the action
   uint32_t errbits;
@@ -31,8 +32,18 @@ struct InstrRef {
         else I[IW_STALE + j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
       }
   }
-  // verifier.py: GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431
+  // ActionInstr.verify (verifier.py:228-242): with use_done_actions only `done` reports -- success iff the previous action completed this
+  // instruction (lastStepMatch: bit 28 of the leaf word), failure otherwise; any other action runs verify_action, remembers whether it
+  // matched and returns None, which every caller treats like "continue"
   MG_D uint32_t leaf(int k) {
+    if (!done_actions) return leaf_action(k);
+    if (act == A_DONE) return ((I[IW_LEAF + k] >> 28) & 1ull) ? (uint32_t)R_SUCCESS : (uint32_t)R_FAILURE;
+    const uint32_t r = leaf_action(k);
+    I[IW_LEAF + k] = (I[IW_LEAF + k] & ~(1ull << 28)) | ((uint64_t)(r == R_SUCCESS) << 28);
+    return R_CONTINUE;
+  }
+  // verifier.py: GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431
+  MG_D uint32_t leaf_action(int k) {
     const uint64_t L = I[IW_LEAF + k];
     const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
     const uint64_t dset = I[IW_SET + 2 * k], fset = I[IW_SET + 2 * k + 1];
@@ -75,9 +86,10 @@ struct InstrRef {
 
 // One step's verification of one env AFTER the action was applied (agent `a`, grid `g`).  Returns the instruction's status
 // (R_CONTINUE / R_SUCCESS / R_FAILURE) and the episode's max_steps; OR-s tracking errors into errbits.
-MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits) {
+MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
+                            bool done_actions = false) {
   InstrRef R;
-  R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0;
+  R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0; R.done_actions = done_actions;
   R.act = act;
   const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
   R.inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;

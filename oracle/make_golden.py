@@ -38,6 +38,12 @@ from minigrid.wrappers import (FullyObsWrapper, NoDeath, OneHotPartialObsWrapper
                                ViewSizeWrapper)
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+# `BABYAI_DONE_ACTIONS=1 python oracle/make_golden.py done`: the reference reads the variable when its verifier module is imported
+# (envs/babyai/core/verifier.py:26), so the whole process runs in that mode and only writes the done_*.npz files
+DONE_MODE = bool(os.environ.get("BABYAI_DONE_ACTIONS"))
+DONE_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocal-v0", "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OpenRedDoor-v0",
+            "BabyAI-GoTo-v0", "BabyAI-PutNextLocal-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-ActionObjDoor-v0", "BabyAI-UnlockLocal-v0",
+            "BabyAI-OpenTwoDoors-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-MoveTwoAcrossS5N2-v0"]
 
 MISSIONS = {
     "MiniGrid-Empty": ["get to the green goal square"],
@@ -611,6 +617,8 @@ def rollout(env_id, seed, T, mode, noise=0.25):
             sa = solver_action(env_id, env.unwrapped)
             if sa is not None:
                 a = sa
+        if DONE_MODE and mode == "solver" and arng.random() < 0.2:
+            a = 6                                   # use_done_actions: only `done` reports; say it often enough right after a match
         if pending:
             obs, _ = env.reset()
             r, term, trunc = 0.0, False, False
@@ -1056,8 +1064,20 @@ def main_wide():
         print("done", env_id, flush=True)
 
 
+def main_done():
+    """Goldens of ActionInstr.verify with use_done_actions (verifier.py:26, 228-242): run as `BABYAI_DONE_ACTIONS=1 ... make_golden.py done`."""
+    from minigrid.envs.babyai.core import verifier
+    assert DONE_MODE and verifier.use_done_actions, "run with BABYAI_DONE_ACTIONS=1 in the environment"
+    for env_id in DONE_IDS:
+        np.savez_compressed(os.path.join(OUT, f"done_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 1337], 300))
+        print("done-actions", env_id, flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "done":
+        return main_done()
+    assert not DONE_MODE, "BABYAI_DONE_ACTIONS is set: only `make_golden.py done` may run in that mode"
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         return main_wide()
     if len(sys.argv) > 1 and sys.argv[1] == "wrappers":

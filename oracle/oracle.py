@@ -34,7 +34,7 @@ class OracleCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "width", "height", "max_steps", "see_through", "start_x", "start_y", "start_dir",
         "num_crossings", "obstacle_type", "num_dists", "full_obs", "strip2_row", "view_size", "no_death_mask")] + [
-        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32)]
+        ("death_cost", C.c_double), ("room_size", C.c_int32), ("random_length", C.c_int32), ("done_actions", C.c_int32)]
 
 
 OBS_KINDS = {"partial": 0, "full": 1, "onehot": 2, "symbolic": 3}
@@ -372,7 +372,8 @@ class OracleVec:
     """N independent reference-semantics envs stepped in lockstep on the CPU (scalar C)."""
 
     def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, obs: str | None = None, view_size: int = 7,
-                 no_death_types=(), death_cost: float = -1.0, tile_size: int = 8, highlight: bool = True, **overrides):
+                 no_death_types=(), death_cost: float = -1.0, tile_size: int = 8, highlight: bool = True, done_actions: bool = False,
+                 **overrides):
         """obs: "partial" | "full" (FullyObsWrapper) | "onehot" (OneHotPartialObsWrapper) | "symbolic"
         (SymbolicObsWrapper, returned as int8); view_size: ViewSizeWrapper; no_death_types/death_cost: NoDeath."""
         s = dict(spec(env_id))
@@ -389,6 +390,7 @@ class OracleVec:
         for t in no_death_types:
             mask |= 1 << OBJECT_TO_IDX[t]
         self.cfg = OracleCfg(full_obs=kind, view_size=int(view_size), no_death_mask=mask, death_cost=float(death_cost),
+                             done_actions=int(bool(done_actions)),      # BABYAI_DONE_ACTIONS (verifier.py:26)
                              **{k: int(v) for k, v in s.items()})
         self.n = num_envs
         self.W, self.H = self.cfg.width, self.cfg.height

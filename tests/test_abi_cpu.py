@@ -22,8 +22,8 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 
 def test_config_struct_layout_matches_header():
-    # 20 int32, double at 80, 2 int32, int64 at 96, 4 int32 = 120 bytes
-    assert C.sizeof(B.MgConfig) == 120
+    # 20 int32, double at 80, 2 int32, int64 at 96, 5 int32 (+ 4 bytes of tail padding) = 128 bytes
+    assert C.sizeof(B.MgConfig) == 128 and B.MgConfig.babyai_done_actions.offset == 120
     assert B.MgConfig.death_cost.offset == 80
     assert B.MgConfig.env_index_base.offset == 96
     assert B.MgConfig.tile_size.offset == 104 and B.MgConfig.rgb_highlight.offset == 108

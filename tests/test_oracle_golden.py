@@ -124,6 +124,40 @@ def test_rollouts_match_reference(env_id, mode, full):
             assert (v.mission_strings() == g[f"{mode}_mission_str"][:, t + 1]).all(), (env_id, t)
 
 
+DONE_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocal-v0", "BabyAI-PickupDist-v0", "BabyAI-PickupDistDebug-v0", "BabyAI-OpenRedDoor-v0",
+            "BabyAI-GoTo-v0", "BabyAI-PutNextLocal-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-ActionObjDoor-v0", "BabyAI-UnlockLocal-v0",
+            "BabyAI-OpenTwoDoors-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-MoveTwoAcrossS5N2-v0"]
+
+
+@pytest.mark.parametrize("env_id", DONE_IDS)
+@pytest.mark.parametrize("mode", ["random", "solver"])
+def test_done_actions_rollouts_match_reference(env_id, mode):
+    """use_done_actions (envs/babyai/core/verifier.py:26, 228-242; BABYAI_DONE_ACTIONS=1 when the reference is imported): only the `done`
+    action reports -- success iff the previous action completed the instruction, failure otherwise.  Goldens: the unmodified reference run
+    in that mode (`BABYAI_DONE_ACTIONS=1 python oracle/make_golden.py done`)."""
+    g = golden(f"done_{env_id}.npz")
+    seeds, acts = g["seeds"], g[f"{mode}_actions"]
+    S, T = acts.shape
+    v = O.OracleVec(env_id, S, done_actions=True)
+    obs, d, m = v.reset(seeds=seeds)
+    assert (obs == g[f"{mode}_obs"][:, 0]).all()
+    for t in range(T):
+        obs, rew, term, trunc, d, m = v.step(acts[:, t])
+        assert (obs == g[f"{mode}_obs"][:, t + 1]).all(), (env_id, t)
+        assert rew.tobytes() == g[f"{mode}_reward"][:, t].tobytes(), (env_id, t)
+        assert (term == g[f"{mode}_term"][:, t]).all() and (trunc == g[f"{mode}_trunc"][:, t]).all(), (env_id, t)
+        assert (d == g[f"{mode}_dir"][:, t + 1]).all() and (m == g[f"{mode}_mission"][:, t + 1]).all()
+    if mode == "solver":
+        # the mode is exercised: `done` ended episodes both ways, and nothing else ended one before its step limit
+        done_steps = acts == 6
+        assert (g["solver_term"] & done_steps).sum() >= 3 and not (g["solver_term"] & ~done_steps).any()
+
+
+def test_done_actions_goldens_hold_successes():
+    n = sum(int((golden(f"done_{e}.npz")["solver_reward"] > 0).sum()) for e in DONE_IDS)
+    assert n >= 10, n
+
+
 @pytest.mark.parametrize("env_id", MAIN_IDS)
 def test_goldens_cover_interesting_events(env_id):
     """The goldens must actually exercise success rewards / terminations / truncations / resets."""
