@@ -63,11 +63,12 @@ def test_bench_configuration_fused_default_rings_full_size(env_id, n, full, max_
     g1, a1 = env.get_state(); g2, a2 = orc.get_state()
     assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
     assert (env.get_rng_state() == orc.get_rng()).all()
-    # ---- phase B: launch by launch, every step's flags and two observations per launch
+    # ---- phase B: launch by launch, every step's flags; two observations per launch -- and EVERY slot's image in the last launch
+    # (the full-size checks sampled observations)
     for c in range(3):
         env.rollout(F, action_seed=seed, fused=True)
         for k in reversed(range(F)):
-            with_image = k in (F - 3, 0)
+            with_image = c == 2 or k in (F - 3, 0)
             out = orc.philox_step(seed, t, quiet=not with_image); t += 1
             _check_slot(env, out, k, (env_id, "phase B launch", c, "slot", k), with_image)
     g1, a1 = env.get_state(); g2, a2 = orc.get_state()
