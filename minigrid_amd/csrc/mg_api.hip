@@ -746,6 +746,10 @@ static const char* validate_obs_cfg(const mg_config* cfg) {
   const bool rgb = cfg->obs_mode == MG_OBS_RGB || cfg->obs_mode == MG_OBS_RGB_PARTIAL;
   if (rgb && (cfg->tile_size < 1 || cfg->tile_size > 64)) return "RGB observations: tile_size must be in 1..64";
   if (cfg->no_death_mask & (1 << T_GOAL)) return "goal cannot be a death cell (wrappers.py:854)";
+  // the sentence levels' SAME_STEP autoreset lives in k_roll7<GG_SENTENCE> (the verifier inside the step loop): the default 7x7 view only
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN &&
+      !(cfg->obs_mode == MG_OBS_PARTIAL && cfg->agent_view_size == 7))
+    return "SAME_STEP autoreset of the sentence levels is built for the default 7x7x3 observation only (their other observation modes end episodes in k_verify, after the step kernel)";
   return nullptr;
 }
 
@@ -893,8 +897,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (const char* bad = validate_obs_cfg(cfg)) return fail(nullptr, MG_ERR_INVALID, "%s", bad);
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->autoreset_mode < MG_AUTORESET_NEXT_STEP || cfg->autoreset_mode > MG_AUTORESET_SAME_STEP) return fail(nullptr, MG_ERR_INVALID, "unknown autoreset_mode");
-  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && (cfg->env_kind == MG_ENV_DYNOBS || (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)))
-    return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset is not built for DynamicObstacles (its reset draws on the stream its steps consume) and the sentence levels (k_verify ends their episodes after the step kernel)");
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS)
+    return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset is not built for DynamicObstacles (its reset draws on the stream its steps consume)");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;

@@ -555,9 +555,25 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         S.errbits |= verr;
         o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
         o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
-        if ((o.term | o.trunc) && P.autoreset_next_step) { a.flags |= FLAG_RESET_PENDING; S.rec_dirty = true; }
+        if ((o.term | o.trunc) && (P.autoreset_next_step || P.autoreset_same_step)) { a.flags |= FLAG_RESET_PENDING; S.rec_dirty = true; }
       }
       o.sent0 = I[IW_MISSION]; o.sent1 = I[IW_MISSION + 1];
+    }
+    if constexpr (GG == GG_SENTENCE) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
+      // Gymnasium's SAME_STEP autoreset for the sentence levels (round 4): their episodes end in the verifier, i.e. after env_transition's own
+      // SAME_STEP branch; the envs the verifier just ended take their next episode now (env_transition in reset-only mode), their instruction
+      // record comes with it, and the observation below is the new episode's first -- reward / terminated / truncated stay the ended one's
+      LaneCtx C2 = C;
+      C2.reset_enabled = true; C2.reset_only = true;
+      double r2 = 0.0; uint32_t t2 = 0, u2 = 0;
+      env_transition<GG, 1>(P, C2, S, A_DONE, r2, t2, u2);
+      if (active && (a.flags & FLAG_NEW_EPISODE)) {
+        uint64_t* I = P.instr + (size_t)e * INSTR_WORDS;
+        const uint64_t* src = P.spare_instr + ((size_t)((S.h - 1u) & P.ring_mask) * N + (size_t)e) * INSTR_WORDS;
+        for (int k = 0; k < INSTR_WORDS; k++) I[k] = src[k];
+        a.flags &= ~FLAG_NEW_EPISODE;
+        o.sent0 = I[IW_MISSION]; o.sent1 = I[IW_MISSION + 1];
+      }
     }
     o.show_taken = false;
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {

@@ -362,6 +362,7 @@ struct EnvRegs {          // what lives in registers across the steps of a launc
 struct LaneCtx {          // the lane's view of its env: loop-invariant
   int e, el, sub;
   bool active, lead, reset_enabled, maskok, goto_rule;
+  bool reset_only = false;   // only take the spare episode of the envs flagged RESET_PENDING (the sentence levels' SAME_STEP autoreset: their episodes end in the verifier, after the step)
   uint8_t* mygrid; const uint8_t* myshadow; const uint64_t* sspr;
 };
 
@@ -439,6 +440,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
   if (active) {
     if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && !MG_EXPBIT(P, 64)) {
       take_spare();
+    } else if (C.reset_only) {
     } else if (a.flags & FLAG_FRESH) {
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
       rec_dirty = true;

@@ -171,9 +171,47 @@ def test_same_step_with_final_obs_equals_the_oracle(env_id, full, max_steps, out
 
 def test_same_step_autoreset_is_refused_where_it_is_not_built():
     import minigrid_amd as mg
-    for env_id in ("MiniGrid-Dynamic-Obstacles-6x6-v0", "BabyAI-BossLevel-v0"):
-        with pytest.raises(ValueError):
-            mg.make_vec(env_id, 64, autoreset_mode="same_step")
+    with pytest.raises(ValueError):
+        mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", 64, autoreset_mode="same_step")
+    # the sentence levels: in the step kernel of the default 7x7 view only (round 4); their other observation modes end episodes in k_verify
+    with pytest.raises(ValueError):
+        mg.make_vec("BabyAI-BossLevel-v0", 64, autoreset_mode="same_step", obs_mode="symbolic")
+    env = mg.make_vec("BabyAI-GoToSeqS5R2-v0", 64, autoreset_mode="same_step")
+    with pytest.raises(ValueError):
+        mg.FullyObsWrapper(env)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["BabyAI-GoToSeqS5R2-v0", "BabyAI-OpenTwoDoors-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-PickupLoc-v0"])
+def test_same_step_autoreset_of_the_sentence_levels(env_id):
+    """SAME_STEP for the levels whose episodes end in the verifier (instruction trees): the step that ends an episode returns the NEXT
+    episode's first observation and mission sentence with the ended episode's reward and flags; stepped and fused, against the oracle."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 1200
+    env = mg.make_vec(env_id, n, autoreset_mode="same_step", traj_slots=16)
+    orc = O.OracleVec(env_id, n)
+    obs, _ = env.reset(seed=3)
+    assert (obs["image"] == orc.reset(seeds=np.arange(3, 3 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(9)
+    ended = 0
+    for t in range(150):
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.35, 0.1, 0.05, 0.1, 0.1]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=2)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (np.asarray(obs["mission"]) == orc.mission_strings()).all(), (env_id, t)
+        ended += int((term | trunc).sum())
+    assert ended >= 5, ended                  # (episodes of these levels are long; the fused part below adds more)
+    for c in range(3):
+        env.rollout(8, action_seed=5, fused=True)
+        for k in reversed(range(8)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act, autoreset=2)
+            assert (img == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, c, k)
+            assert (np.asarray(env.trajectory_missions(k)) == orc.mission_strings()).all() if k == 0 else True
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
 
 
 @pytest.mark.parametrize("env_id", ["BabyAI-BossLevel-v0", "BabyAI-GoToSeq-v0", "BabyAI-OpenDoorsOrderN4-v0", "BabyAI-MoveTwoAcrossS8N9-v0",
