@@ -25,13 +25,13 @@ OBJDIR = os.path.join(CSRC, ".obj")
 ABI_HEADER = os.path.join("..", "..", "include", "minigrid_hip.h")
 
 _COMMON = ["mg_device.h", "mg_rng.h", "mg_tiles.h", "mg_launch.h"]
-_STEP = _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_step_tu.inc"]
+_STEP = _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_step_tu.inc"]
 _GEN = _COMMON + ["mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
 # translation unit -> the headers it is built from (its own file included)
 UNITS = {
-    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", ABI_HEADER],
+    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", ABI_HEADER],
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
-    "mg_step_sentence.hip": _STEP,
+    "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP,
 }
 UNITS["mg_gen_lane.hip"] = _GEN + ["mg_genlane.h"]
 for _g in ("rooms", "sentence", "roomgrid", "light"):

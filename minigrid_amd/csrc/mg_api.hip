@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -71,6 +72,7 @@ struct mg_env {
   bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
   bool lane_gen = false;      // the refills run one lane per episode (k_refill_lane: the single-room levels; MG_LANE_GEN=0: the wave-per-episode k_refill)
+  bool dyn_inloop = false;    // DynamicObstacles, default 7x7 view: k_roll7<GG_DYNOBS> draws the level's moves and resets inside the step loop (mg_dynobs.h; MG_DYN_INLOOP=0: the round-3 launches)
   bool roll_split_on = true;  // MG_ROLL_SPLIT (read when the observation configuration is made): 0 = the round-3 time split at every width
   int roll_shadows = 1;       // spare episodes per env staged in LDS by a fused k_roll7 launch (2 unless the level draws nothing)
   int roll_guard = 0;
@@ -288,7 +290,7 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
-struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, total; };
+struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, total; };
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
@@ -298,14 +300,15 @@ static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool s
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
-  const int K = e->roll_shadows;
+  const int K = e->dyn_inloop ? 0 : e->roll_shadows;                   // (DynamicObstacles in the loop: no spare ring, nothing to stage)
   L.shadow_stride = (64 * e->GS + 15) & ~15;
   L.off_shadow = L.off_codes + ncodes * L.codes_stride;
   L.off_shadow_gt = L.off_shadow + K * L.shadow_stride;
   L.off_spr = L.off_shadow_gt + (e->fast_full ? K * L.codes_stride : 0);
   L.off_act = L.off_spr + K * 64 * 16;
   L.off_log = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
-  L.total = L.off_log + (split ? ROLL_LOG_BYTES : 0);
+  L.off_tmpl = L.off_log + (split ? ROLL_LOG_BYTES + (e->dyn_inloop ? ROLL_LOG_OBST_BYTES : 0) : 0);   // k_roll7<GG_DYNOBS>: the level's constant grid
+  L.total = L.off_tmpl + (e->dyn_inloop ? e->CS : 0);
   return L;
 }
 static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split = false) { return roll_layout(e, nw, with_actions, split).total; }
@@ -338,6 +341,8 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
     P.done_actions = (e->cfg.babyai_done_actions != 0 && babyai) ? 1 : 0;
   }
   P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
+  P.rng = e->rng; P.dyn_n = std::min(e->cfg.num_dists, 8); P.dyn_sx = e->cfg.agent_start_x; P.dyn_sy = e->cfg.agent_start_y; P.dyn_sdir = e->cfg.agent_start_dir;
+  P.off_tmpl = 0; P.stat_gen_off = STAT_EPISODES + e->nwaves;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
@@ -384,7 +389,7 @@ static int launch_step(mg_env* e, StepParams& P) {
       if (rc) return rc;
       if (live_on_gen) HIP_TRY(e, hipEventRecord(e->ev_gen[0], e->gen_stream));
     }
-    if (P.phase == PHASE_STEP) {
+    if (P.phase == PHASE_STEP && !e->dyn_inloop) {       // (in the loop: k_roll7<GG_DYNOBS> moves the obstacles itself)
       static const int epb = [] { const char* s = getenv("MG_MOVE_EPB"); const int v = s ? atoi(s) : 0; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : MOVE_EPB; }();
       const int nb = (e->N + epb - 1) / epb;
       const size_t mlds = (size_t)epb * (size_t)(e->CS + 4);          // the wave's staged grids (DynamicObstacles: at most 16 x 16)
@@ -405,7 +410,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     if (!e->static_gen) { P.seg = e->seg + (size_t)set * e->nwaves * e->seg_cap; P.seg_count = e->seg_count + (size_t)set * e->nwaves; }
   }
   // fused launches stage every env's next spare episode in its LDS shadow slot at launch start
-  P.use_shadow = P.T > 1 ? 1 : 0;
+  P.use_shadow = (P.T > 1 && !e->live_gen) ? 1 : 0;
   const size_t lds = (size_t)(P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP ? e->lds_bytes : e->off_act);
   dim3 grid(e->nwaves);
   const int mode = e->cfg.obs_mode == MG_OBS_FULL ? 1 : e->cfg.obs_mode == MG_OBS_SYMBOLIC ? 3 : e->cfg.obs_mode == MG_OBS_ONEHOT ? 2
@@ -439,7 +444,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     const RollLayout L = roll_layout(e, nw, acts, split);
     // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
-    P.split_mode = split ? (drot == 0 ? 31 : drot) : 0; P.off_log = L.off_log;
+    P.split_mode = split ? (drot == 0 ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
@@ -458,7 +463,8 @@ static int launch_step(mg_env* e, StepParams& P) {
     if (P.use_shadow) P.use_shadow = e->roll_shadows;
     P.w_magic = (65536u + (uint32_t)e->W - 1u) / (uint32_t)e->W; P.h_magic = (65536u + (uint32_t)e->H - 1u) / (uint32_t)e->H;
     const bool full = e->fast_full;
-    if (in_loop_verify) launch_roll_sentence(full, grid, nw, (size_t)L.total, e->stream, P);
+    if (e->dyn_inloop) launch_roll_dynobs(e->cfg.rng_mode == MG_RNG_PHILOX, grid, nw, (size_t)L.total, e->stream, P);
+    else if (in_loop_verify) launch_roll_sentence(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_ROOMGRID) launch_roll_roomgrid(full, grid, nw, (size_t)L.total, e->stream, P);
@@ -694,6 +700,7 @@ static const char* configure_obs(mg_env* e) {
     else { e->lpe = 1; e->epw = 64; e->nwaves = (e->N + 63) / 64; }
   }
   { const char* s = getenv("MG_ROLL_SPLIT"); e->roll_split_on = !s || atoi(s) != 0; }
+  { const char* s = getenv("MG_DYN_INLOOP"); e->dyn_inloop = e->live_gen && e->fast7 && !e->fast_full && (!s || atoi(s) != 0); }
   if (e->fast7 || e->fast_full) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
@@ -703,7 +710,10 @@ static const char* configure_obs(mg_env* e) {
     // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
     int nw = 4;
     if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
-    while (nw > 1 && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > 53 * 1024) nw--;
+    // (DynamicObstacles in the loop: its dynamics -- a 128-bit multiply per placement try -- are the long part of a step and must not be replayed
+    // by a time split: three waves, one of them the dynamics wave, even where that leaves two workgroups per CU (16 x 16: 66 KB))
+    const int lds_cap = e->dyn_inloop ? 80 * 1024 : 53 * 1024;
+    while (nw > (e->dyn_inloop ? 3 : 1) && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > lds_cap) nw--;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
     e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
@@ -733,7 +743,7 @@ static const char* configure_obs(mg_env* e) {
   // steps per fused launch: every step of a launch goes to its own slot; ring levels consume at most cb per launch
   // (never more than MAX_FUSED_STEPS = 32: k_step's LDS action staging and Philox blocks are sized for that, whatever S and R are)
   // (the sentence levels fuse only where their verifier runs inside the step loop: the default 7x7 view)
-  e->max_fused = (rgb || e->live_gen || (e->sentence && !e->fast7)) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), e->static_gen ? MAX_FUSED_STEPS :
+  e->max_fused = (rgb || (e->live_gen && !e->dyn_inloop) || (e->sentence && !e->fast7)) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), (e->static_gen || e->dyn_inloop) ? MAX_FUSED_STEPS :
                                                                         (e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP ? 1 : 2) * e->cb);
   if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   return nullptr;
@@ -750,6 +760,9 @@ static const char* validate_obs_cfg(const mg_config* cfg) {
   if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN &&
       !(cfg->obs_mode == MG_OBS_PARTIAL && cfg->agent_view_size == 7))
     return "SAME_STEP autoreset of the sentence levels is built for the default 7x7x3 observation only (their other observation modes end episodes in k_verify, after the step kernel)";
+  // DynamicObstacles' reset draws on the stream its steps consume: SAME_STEP needs the redraw inside the step kernel (k_roll7<GG_DYNOBS>, mg_dynobs.h)
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS && !(cfg->obs_mode == MG_OBS_PARTIAL && cfg->agent_view_size == 7))
+    return "SAME_STEP autoreset of DynamicObstacles is built for the default 7x7x3 observation only (the other observation modes redraw finished envs between launches)";
   return nullptr;
 }
 
@@ -794,7 +807,7 @@ static int alloc_obs(mg_env* e) {
     if (need > lds_max[e->device & 63]) {
       HIP_TRY(e, step_max_lds_none(need)); HIP_TRY(e, step_max_lds_light(need)); HIP_TRY(e, step_max_lds_roomgrid(need)); HIP_TRY(e, step_max_lds_rooms(need));
       HIP_TRY(e, roll_max_lds_none(need)); HIP_TRY(e, roll_max_lds_light(need)); HIP_TRY(e, roll_max_lds_roomgrid(need)); HIP_TRY(e, roll_max_lds_rooms(need));
-      HIP_TRY(e, roll_max_lds_sentence(need));
+      HIP_TRY(e, roll_max_lds_sentence(need)); HIP_TRY(e, roll_max_lds_dynobs(need));
       lds_max[e->device & 63] = need;
     }
   }
@@ -897,8 +910,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (const char* bad = validate_obs_cfg(cfg)) return fail(nullptr, MG_ERR_INVALID, "%s", bad);
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->autoreset_mode < MG_AUTORESET_NEXT_STEP || cfg->autoreset_mode > MG_AUTORESET_SAME_STEP) return fail(nullptr, MG_ERR_INVALID, "unknown autoreset_mode");
-  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS)
-    return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset is not built for DynamicObstacles (its reset draws on the stream its steps consume)");
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS && getenv("MG_DYN_INLOOP") && atoi(getenv("MG_DYN_INLOOP")) == 0)
+    return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset of DynamicObstacles needs the in-loop redraw (MG_DYN_INLOOP=0 switches it off)");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
     const int st = cfg->room_size - 1, k = cfg->env_kind;
@@ -1761,6 +1774,48 @@ int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const
   }
   return MG_OK;
 }
+// dynobs_place (mg_dynobs.h: DynamicObstacles' obstacle moves and reset draws as k_roll7<GG_DYNOBS> runs them per lane) on the host, for n envs in
+// the state exchange format: mode[i] = 0 nothing, 1 = the moves of one step, 2 = reset (the grid is rebuilt from the level's constant part).
+// flags[i]: bit 0 = a placement failed (the reference's reset() raises), bit 1 = the grid changed, bit 2 = the front cell was occupied (not_clear)
+int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t sy, int32_t sdir, int32_t philox, int32_t n, const uint8_t* mode,
+                       uint8_t* grid, int32_t* agent, uint64_t* rng_words, uint64_t* obst, uint8_t* flags) {
+  if (W < 3 || H < 3 || W > 16 || H > 16 || n_obst < 0 || n_obst > 8 || n < 0 || !mode || !grid || !agent || !rng_words || !obst || !flags) return MG_ERR_INVALID;
+  const int cells = W * H, CS = (cells + 15) & ~15;
+  const uint32_t w_magic = (65536u + (uint32_t)W - 1u) / (uint32_t)W;
+  std::vector<uint8_t> g((size_t)CS);
+  for (int i = 0; i < n; i++) {
+    uint8_t* t3 = grid + (size_t)i * cells * 3;
+    int32_t* ag = agent + (size_t)i * 8;
+    for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) { const uint8_t* t = t3 + ((size_t)x * H + y) * 3; g[y * W + x] = (uint8_t)cell_from_triple(t[0], t[1], t[2]); }
+    const bool regen = mode[i] == 2, move = mode[i] == 1;
+    if (regen) for (int k = 0; k < CS; k++) g[k] = (uint8_t)dynobs_template_cell(k, W, H, w_magic);
+    uint32_t ax = (uint32_t)ag[0], ay = (uint32_t)ag[1], adir = (uint32_t)ag[2] & 3u;
+    bool failed = false, changed = false, not_clear = false;
+    if (move) {
+      const int fx = (int)ax + dir_dx(adir), fy = (int)ay + dir_dy(adir);
+      const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)g[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
+      not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
+    }
+    uint64_t o = obst[i];
+    auto run = [&](auto& r) {
+      r.load(rng_words + (size_t)i * 5, 1, 0);
+      if (regen) { if constexpr (std::remove_reference_t<decltype(r)>::kEpisodic) r.begin_episode(); }
+      dynobs_place(r, g.data(), W, H, w_magic, n_obst, regen, move, sx, sy, sdir, ax, ay, adir, o, failed, changed);
+      r.store(rng_words + (size_t)i * 5, 1, 0);
+    };
+    if (philox) { PhiloxStream r; run(r); } else { Pcg64Stream r; run(r); }
+    obst[i] = o;
+    if (regen) { ag[0] = (int32_t)ax; ag[1] = (int32_t)ay; ag[2] = (int32_t)adir; }
+    flags[i] = (uint8_t)((failed ? 1 : 0) | (changed ? 2 : 0) | (not_clear ? 4 : 0));
+    for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {
+      const uint32_t tr = cell_triple((uint32_t)g[y * W + x]);
+      uint8_t* t = t3 + ((size_t)x * H + y) * 3;
+      t[0] = (uint8_t)tr; t[1] = (uint8_t)(tr >> 8); t[2] = (uint8_t)(tr >> 16);
+    }
+  }
+  return MG_OK;
+}
+
 // out = [perm_b32 | udot4 | brev32 | expand4 | vis_row_carry (m | up << 8) | MG_BYTE_X4 of the four bytes] x n of (a, b, c); on_device: by k_selftest_prims
 int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device) {
   if (n < 1 || !a || !b || !c || !out) return MG_ERR_INVALID;

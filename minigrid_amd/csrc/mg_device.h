@@ -218,7 +218,8 @@ __device__ __forceinline__ void report_errors(uint32_t* err, uint32_t bits) {
 }
 
 // generator / rule groups (see mg_gen.h "Groups")
-enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15 };
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15,
+              GG_DYNOBS = 16 };    // (step kernels only: k_roll7 with DynamicObstacles' moves and resets inside the step loop, mg_dynobs.h)
 MG_HD int gen_group_of_kind(int kind) { return (kind >= 50 && kind <= 53) ? GG_SENTENCE : (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 // `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env wave |

@@ -24,6 +24,7 @@
 #pragma once
 #include "mg_step.h"
 #include "mg_verify.h"
+#include "mg_dynobs.h"
 
 // analysis aid: -DMG_ISA_MARKS puts section comments into the device ISA (profiles/isa_stats.py --marks); never in the product build
 #if defined(MG_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)
@@ -340,6 +341,7 @@ constexpr int ROLL_MAX_WAVES = 4;
 constexpr int ROLL_LOG_STEPS = 8;                             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
 constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its progress counters
 constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
+constexpr int ROLL_LOG_OBST_BYTES = ROLL_LOG_STEPS * 64 * 8;   // k_roll7<GG_DYNOBS>: + the obstacle list after every logged step (behind the ring)
 
 // LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
 //   [0, 1024) code -> triple table | guard | NW private copies of the 64 grids (GS bytes per env) | guard | NW code stagings |
@@ -358,8 +360,12 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
   for (int x = 0; x < W; x++)
     for (int y = 0; y < H; y++) gt[x * H + y] = g[y * W + x];
 }
-template <int GG, bool FULL, bool NT>
+// GG_DYNOBS (round 4): DynamicObstacles with the draws of its step() and reset() inside the step loop -- RNG = the env streams' type, one
+// stream per lane in registers for the whole launch (mg_dynobs.h).  The level has no spare ring: an env whose episode ended is redrawn in
+// place by its own lane; the encode waves of the split follow the dynamics wave's grids through the obstacle LIST each step logs.
+template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream>
 __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
+  static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
@@ -414,7 +420,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint64_t rec_ld = P.agent[ec];
   EnvRegs S;
   Agent& a = S.a;
-  const uint64_t tg_ld = goto_rule ? P.aux[ec] : 0ull;
+  const uint64_t tg_ld = (goto_rule || GG == GG_DYNOBS) ? P.aux[ec] : 0ull;     // (GG_DYNOBS: the obstacle list)
+  RNG rng;                                                                        // GG_DYNOBS: this env's stream
+  if constexpr (GG == GG_DYNOBS) rng.load(P.rng, N, (size_t)ec);
   const uint32_t h_ld = P.head ? P.head[ec] : 0u;
   const uint32_t mask_ld = P.obs_mask ? (uint32_t)P.obs_mask[ec] : 1u;
   const bool stage_acts = P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER;
@@ -455,6 +463,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint32_t act0 = act_ld;
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
+  if constexpr (GG == GG_DYNOBS) for (int k = tid; k < CS; k += nthreads) smem[P.off_tmpl + k] = (uint8_t)dynobs_template_cell(k, W, H, P.w_magic);
   if (split_mode && tid < ROLL_LOG_SYNC_BYTES / 4) ((uint32_t*)(smem + P.off_log))[tid] = (tid >= 1 && tid < NW) ? 0u : (tid == 0 ? 0u : 0xFFFFFFFFu);   // [0] logged, [1 + k] consumed by encode wave k (absent waves: never behind)
   // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
   // (an env's ring position is lane ce's S.h: every wave has loaded its own copy of the 64 heads)
@@ -514,6 +523,47 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   C.e = e; C.el = lane; C.sub = 0; C.active = active; C.lead = true; C.reset_enabled = reset_enabled; C.maskok = maskok; C.goto_rule = goto_rule;
   C.mygrid = mygrid; C.myshadow = sshadow + lane * GS; C.sspr = sspr;
   const bool see_through = P.see_through != 0 || MG_EXPBIT(P, 1);
+  // GG_DYNOBS: the obstacle list (byte i = cell of obstacle i), what this launch did to it, episodes redrawn in the loop
+  uint64_t obst = active ? tg_ld : 0ull;
+  bool obst_dirty = false, step_regen = false;
+  uint32_t ngen = 0;
+  // DynamicObstaclesEnv's draws for one step of the 64 envs (mg_dynobs.h): `regen` lanes redraw their env's episode in place (reset():
+  // the constant grid copied from the template, one env at a time by the whole wave, then the agent and the obstacles placed by the lane),
+  // `move` lanes move their obstacles (step(), before MiniGridEnv.step) -- all under one loop of placement tries
+  auto dyn_draws = [&](bool regen, bool move, uint32_t flags_after_regen) __attribute__((always_inline)) {
+    if constexpr (GG == GG_DYNOBS) {
+      unsigned long long rm = __ballot(regen);
+      if (rm) {
+        const uint32_t* tm = (const uint32_t*)(smem + P.off_tmpl);
+        while (rm) {
+          const int b = __ffsll((long long)rm) - 1;
+          rm &= rm - 1ull;
+          uint32_t* gb = (uint32_t*)(sgrid + b * GS);
+          for (int k = lane; k < (CS >> 2); k += 64) gb[k] = tm[k];
+        }
+        asm volatile("" ::: "memory");                                 // (DS operations of a wave execute in order: the lanes below read what the wave wrote)
+      }
+      if (move) {
+        // `not_clear` (dynamicobstacles.py:142-144): what is in front of the agent BEFORE the obstacles move
+        const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
+        const uint32_t F = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? (uint32_t)mygrid[fy * W + fx] : (uint32_t)CELL_WALL_GREY;
+        const bool not_clear = F != CELL_EMPTY && cell_type(F) != T_GOAL;
+        a.flags = (a.flags & ~FLAG_NOT_CLEAR) | (not_clear ? FLAG_NOT_CLEAR : 0u);
+      }
+      if constexpr (RNG::kEpisodic) if (regen) rng.begin_episode();
+      uint32_t ax = a.x, ay = a.y, adir = a.dir;
+      bool failed = false, changed = false;
+      if (!MG_EXPBIT(P, 512))            // (attribution builds: the step without its placement loop)
+        dynobs_place(rng, mygrid, W, H, P.w_magic, P.dyn_n, regen, move, P.dyn_sx, P.dyn_sy, P.dyn_sdir, ax, ay, adir, obst, failed, changed);
+      if (regen) {
+        a.x = ax; a.y = ay; a.dir = adir; a.carry = 0; a.step = 0; a.mission = 0; a.flags = flags_after_regen;
+        S.rec_dirty = true; S.wb_all = true; obst_dirty = true; step_regen = true;
+        if (failed) S.errbits |= ERR_GENERATOR;                        // the reference's reset() raises RecursionError
+        if (last_wave) ngen++;
+      }
+      if (changed) { S.wb_all = true; obst_dirty = true; }
+    }
+  };
   constexpr bool nt = NT;                                            // this launch's observation stores are nontemporal (see store12; the host picks the instantiation)
 
   // ---- the pieces of a step ----
@@ -533,11 +583,26 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     o.act_in = act;
     if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
     if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+    if constexpr (GG == GG_DYNOBS) if (act >= 3u) act = A_LEFT;
     o.reward = 0.0; o.term = 0; o.trunc = 0; o.sent0 = 0; o.sent1 = 0;
     S.errbits = 0;
+    if constexpr (GG == GG_DYNOBS) {
+      step_regen = false;
+      if (P.phase == PHASE_STEP) {
+        // NEXT_STEP autoreset: the env whose episode the previous step ended is redrawn now and comes out FRESH (this step only observes it,
+        // like an env the host's live refill redrew before the launch); everyone else's obstacles move
+        const bool pend = (a.flags & FLAG_RESET_PENDING) != 0u;
+        dyn_draws(active && pend && reset_enabled && maskok, active && !(a.flags & (FLAG_RESET_PENDING | FLAG_FRESH)), FLAG_FRESH);
+      }
+    }
     MG_MARK("transition");
     if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
     MG_MARK("after_transition");
+    if constexpr (GG == GG_DYNOBS) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
+      // Gymnasium's SAME_STEP autoreset: the step that ended the episode also redraws the env; the observation below is the new episode's
+      // first, reward / terminated / truncated stay the ended one's
+      dyn_draws(active && (o.term | o.trunc) != 0u, false, 0u);
+    }
     if constexpr (GG == GG_SENTENCE) if (active) {
       // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): the env's
       // instruction record stays in global memory -- one lane per env, a few dependent loads per step, no other wave touches it (one
@@ -746,6 +811,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (o.show_taken) delta = (uint32_t)(S.targets & 0x3FFull) | (a.carry << 10) | (1u << 21);
       else delta = S.ev_dirty_idx >= 0 ? ((uint32_t)S.ev_dirty_idx | (S.ev_dirty_code << 10) | (1u << 30)) : 0u;
       delta |= ((S.ev_reset & 3u) << 18) | ((S.ev_reset == 1u ? S.ev_shadow & 1u : 0u) << 20) | (((S.h - 1u) & P.ring_mask & 0xFFu) << 22);
+      if constexpr (GG == GG_DYNOBS) delta |= step_regen ? (3u << 18) : 0u;      // reset kind 3: redrawn in place -- the template + the logged obstacle list
       if (j >= ROLL_LOG_STEPS) {
         // flow control: entry j reuses the slot of entry j - ROLL_LOG_STEPS, which every encode wave must have consumed
         const uint32_t need = (uint32_t)(j - ROLL_LOG_STEPS + 1);
@@ -756,6 +822,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
+      if constexpr (GG == GG_DYNOBS) ((uint64_t*)(smem + P.off_log + ROLL_LOG_BYTES))[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = obst;
       // (DS operations of one wave execute in order: the counter cannot become visible before the entry; the compiler must keep that order)
       asm volatile("" ::: "memory");
       sync[0] = (uint32_t)(j + 1);
@@ -774,6 +841,33 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
       const uint32_t delta = rec2.y;
       const uint32_t rk = (delta >> 18) & 3u;
+      if constexpr (GG == GG_DYNOBS) {
+        // this wave's grids follow the dynamics wave's through the obstacle list: a redrawn env = the template (copied by the whole wave, one
+        // env at a time) + its obstacles; otherwise the obstacles that moved, in list order (a cell one obstacle left may be the cell a later
+        // one enters)
+        const uint64_t on = ((const uint64_t*)(smem + P.off_log + ROLL_LOG_BYTES))[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
+        unsigned long long rm = __ballot(rk == 3u);
+        if (rm) {
+          const uint32_t* tm = (const uint32_t*)(smem + P.off_tmpl);
+          while (rm) {
+            const int b = __ffsll((long long)rm) - 1;
+            rm &= rm - 1ull;
+            uint32_t* gb = (uint32_t*)(sgrid + b * GS);
+            for (int c = lane; c < (CS >> 2); c += 64) gb[c] = tm[c];
+          }
+          asm volatile("" ::: "memory");
+        }
+        if (MG_EXPBIT(P, 1024)) { }       // (attribution builds: the encode waves without the obstacle updates)
+        else if (rk == 3u) {
+          for (int i = 0; i < P.dyn_n; i++) mygrid[(uint32_t)(on >> (8 * i)) & 0xFFu] = (uint8_t)CELL_BALL_BLUE;
+        } else if (on != obst) {
+          for (int i = 0; i < P.dyn_n; i++) {
+            const uint32_t was = (uint32_t)(obst >> (8 * i)) & 0xFFu, is = (uint32_t)(on >> (8 * i)) & 0xFFu;
+            if (was != is) { mygrid[was] = (uint8_t)CELL_EMPTY; mygrid[is] = (uint8_t)CELL_BALL_BLUE; }
+          }
+        }
+        obst = on;
+      } else
       if (__ballot(rk != 0u)) {
         if (rk == 1u) {
           const uint32_t* s4 = (const uint32_t*)(C.myshadow + ((delta >> 20) & 1u) * (uint32_t)P.shadow_stride);
@@ -834,6 +928,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (errs_mine && active) report_errors(P.err, errs_mine);
   if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
   if (!last_wave) return;
+  if constexpr (GG == GG_DYNOBS)         // episodes drawn inside the loop count like the generator kernels' (mg_get_counters sums the slots)
+    if (ngen) atomicAdd(&P.counters[(size_t)P.stat_gen_off + 2u * (((uint32_t)wg * 64u + (uint32_t)lane) & (STAT_GEN_SLOTS - 1u))], (unsigned long long)ngen);
   if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (S.cur != S.targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; S.rec_dirty = true; }
@@ -841,6 +937,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (active) {
     if (S.rec_dirty) P.agent[e] = agent_pack(a);
     if (goto_rule && S.aux_dirty) P.aux[e] = S.targets;
+    if constexpr (GG == GG_DYNOBS) {
+      if (obst_dirty) P.aux[e] = obst;
+      if (P.phase == PHASE_STEP) rng.store(P.rng, N, (size_t)e);
+    }
     // (sentence levels: k_verify publishes head, after it copied the consumed slot's instruction record)
     if (S.h != h_in && !(GG == GG_NONE && P.rule == RULE_SENTENCE)) P.head[e] = S.h;
   }

@@ -83,6 +83,11 @@ struct StepParams {
   int epw;                   // k_roll7: envs per workgroup (64, or 32 for small batches; mg_api.hip configure_obs)
   int nt;                    // k_roll7: observation stores are nontemporal (a long burst of launches; mg_api.hip launch_step)
   int split_mode, off_log;   // k_roll7: 1 = wave 0 runs the dynamics once and logs them (ring at off_log), the other waves encode
+  // k_roll7<GG_DYNOBS>: DynamicObstacles with its stream draws inside the step loop (mg_dynobs.h)
+  uint64_t* rng;             // the envs' streams (SoA words, mg_rng.h)
+  int dyn_n, dyn_sx, dyn_sy, dyn_sdir;   // n_obstacles; agent_start_pos / agent_start_dir (dyn_sx < 0: place_agent)
+  int off_tmpl;              // LDS: the level's constant grid (walls + goal), CS bytes
+  int stat_gen_off;          // first generator statistics slot in `counters`
 };
 
 // _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).
@@ -439,7 +444,8 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
   };
   if (active) {
     if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && !MG_EXPBIT(P, 64)) {
-      take_spare();
+      // (GG_DYNOBS has no spare ring: k_roll7 redraws the env in place before it gets here, the host's live refill before an observe launch)
+      if constexpr (GG == GG_DYNOBS) errbits |= ERR_GENERATOR; else take_spare();
     } else if (C.reset_only) {
     } else if (a.flags & FLAG_FRESH) {
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
@@ -684,9 +690,9 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         else { a.flags = matched ? (a.flags | FLAG_LAST_MATCH) : (a.flags & ~FLAG_LAST_MATCH); term = 0; success = false; }
       }
       if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
-      if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS) {
+      if constexpr (GG == GG_NONE || GG == GG_DYNOBS) if (GG == GG_DYNOBS || P.rule == RULE_DYNOBS) {
         // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
-        // obstacles moved (k_move_obstacles recorded it) costs -1 and ends the episode, whatever happened since
+        // obstacles moved (k_move_obstacles / k_roll7<GG_DYNOBS> recorded it) costs -1 and ends the episode, whatever happened since
         if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
         a.flags &= ~FLAG_NOT_CLEAR;
       }
@@ -708,7 +714,8 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       // Gymnasium's SAME_STEP autoreset (the vector semantics of gymnasium 0.28 / 0.29, which the reference pins as its minimum): the step
       // that ends an episode also resets the env; the observation returned is the new episode's first, reward / terminated / truncated
       // are the ended episode's
-      if ((term | trunc) && P.autoreset_same_step) { S.ev_dirty_idx = -1; take_spare(); }
+      // (GG_DYNOBS: k_roll7 redraws the env in place right after this call)
+      if constexpr (GG != GG_DYNOBS) if ((term | trunc) && P.autoreset_same_step) { S.ev_dirty_idx = -1; take_spare(); }
     }
   }
 }

@@ -198,7 +198,7 @@ def _cfg(**kw):
                                  dict(env_kind=9, width=11, height=6, room_size=5),      # Unlock: inconsistent room size
                                  dict(env_kind=19, width=9, height=9, num_dists=3),      # GoToLocal: room_size <= 8
                                  dict(obs_mode=5, tile_size=0), dict(obs_mode=4, tile_size=65),     # RGB: tile_size in 1..64
-                                 dict(autoreset_mode=3), dict(autoreset_mode=2, env_kind=15),          # SAME_STEP: not for DynamicObstacles
+                                 dict(autoreset_mode=3), dict(autoreset_mode=2, env_kind=15, obs_mode=1),      # SAME_STEP of DynamicObstacles: the 7x7 view only
                                  dict(env_kind=23, width=25, height=25, room_size=10, num_crossings=2, num_dists=7),   # MultiRoom: <= 6 rooms
                                  dict(env_kind=23, width=25, height=25, room_size=3, num_crossings=2, num_dists=2),    # maxRoomSize >= 4
                                  dict(env_kind=28, width=13, height=13, room_size=6),    # FindObj: 3*(room_size-1)+1
@@ -374,3 +374,58 @@ def test_roll7_observation_pipeline_on_the_host_equals_the_oracle(env_id, n, T):
         assert bad.size == 0, (env_id, t, bad[:5], agent[bad[:1]], out[bad[0]].reshape(49, 3)[:, 0].reshape(7, 7), obs[bad[0]].reshape(49, 3)[:, 0].reshape(7, 7))
         a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
         obs = orc.step(a)[0]
+
+
+DYNOBS_IDS = ["MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
+              "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0"]
+
+
+@pytest.mark.parametrize("env_id", DYNOBS_IDS)
+def test_dynobs_in_loop_draws_on_the_host_equal_the_oracle(env_id):
+    """mg_selftest_dynobs = dynobs_place (mg_dynobs.h), the per-lane loop k_roll7<GG_DYNOBS> runs for DynamicObstacles' obstacle moves and
+    in-place resets, compiled for the host: from numpy's freshly seeded PCG64 words it must reproduce the oracle's grids, agent poses and
+    stream positions reset after reset and step after step (the obstacle LIST order is carried by the function itself: a wrong order, a draw
+    too many or a wrong rejection shows up as a diverging grid or stream)."""
+    import ctypes as C
+    from oracle import oracle as O
+    L = B.load()
+    s = O.spec(env_id)
+    n, T = 48, 160
+    W, H, nob = s["width"], s["height"], s["num_dists"]
+    orc = O.OracleVec(env_id, n)
+    seeds = np.arange(100, 100 + n, dtype=np.uint64)
+    words = np.zeros((n, 5), np.uint64)
+    for i, sd in enumerate(seeds):
+        st = np.random.PCG64(np.random.SeedSequence(int(sd))).state["state"]
+        words[i] = [st["state"] >> 64, st["state"] & (2 ** 64 - 1), st["inc"] >> 64, st["inc"] & (2 ** 64 - 1), 0]
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    grid = np.zeros((n, W, H, 3), np.uint8)
+    agent = np.zeros((n, 8), np.int32)
+    obst = np.zeros(n, np.uint64)
+    flags = np.zeros(n, np.uint8)
+
+    def run(mode):
+        assert L.mg_selftest_dynobs(W, H, nob, s["start_x"], s["start_y"], s["start_dir"], 0, n, p(mode), p(grid), p(agent), p(words), p(obst), p(flags)) == 0
+
+    orc.reset(seeds=seeds)
+    run(np.full(n, 2, np.uint8))
+    g2, a2 = orc.get_state()
+    assert (grid == g2).all() and (agent[:, :3] == a2[:, :3]).all() and (words == orc.get_rng()).all() and not (flags & 1).any()
+    rng = np.random.default_rng(5)
+    pending = np.zeros(n, bool)
+    n_resets = n_minus = 0
+    for t in range(T):
+        act = rng.integers(0, 7 if t % 5 == 0 else 3, n).astype(np.uint8)           # (actions >= 3 are "invalid": left)
+        agent[:] = a2                                                                # the pose the moves must avoid / look ahead from
+        run(np.where(pending, 2, 1).astype(np.uint8))
+        _, rew, term, trunc, _, _ = orc.step(act)
+        g2, a2 = orc.get_state()
+        bad = np.argwhere((grid != g2).reshape(n, -1).any(1)).ravel()
+        assert bad.size == 0, (env_id, t, bad[:4], pending[bad[:4]])
+        assert (words == orc.get_rng()).all(), (env_id, t)
+        assert (agent[pending, :3] == a2[pending, :3]).all()
+        hit = (~pending) & (act == 2) & ((flags & 4) != 0)
+        assert (rew[hit] == -1.0).all() and term[hit].all() and not (rew[(~pending) & ~hit] == -1.0).any()
+        n_resets += int(pending.sum()); n_minus += int(hit.sum())
+        pending = term | trunc
+    assert n_resets > n // 2 and n_minus > 0

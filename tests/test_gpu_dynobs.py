@@ -1,0 +1,214 @@
+"""GPU parity of DynamicObstacles inside the fused step kernel (round 4; k_roll7<GG_DYNOBS>, mg_dynobs.h): the level's obstacle moves and its
+resets draw on the env's own stream, so rounds 1-3 ran a step as three launches and could not fuse; now one lane owns the stream for a whole
+launch.  Every registered id (fixed and random agent start, 2 .. 8 obstacles, 5x5 .. 16x16) against the CPU oracle: every slot of fused
+launches of every length (device Philox policy and caller-supplied actions incl. the "invalid" ones), the split and the time-split shapes of
+the kernel, 32-env workgroups, the one-step launches of Env.step(), Gymnasium's SAME_STEP autoreset (refused for this level until now), the
+Philox stream mode, and the hand-over to the observation modes that keep the round-3 launches.  The draw order itself is pinned on the CPU
+(tests/test_abi_cpu.py::test_dynobs_in_loop_draws_on_the_host_equal_the_oracle)."""
+import numpy as np
+import pytest
+
+from par_oracle import ParOracle
+from test_gpu_launch_lengths import LENGTHS, _check_launch, _final_state
+
+pytestmark = pytest.mark.gpu
+
+IDS = ["MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-Random-5x5-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0",
+       "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0"]
+
+
+@pytest.mark.parametrize("env_id,n,max_steps", [(IDS[0], 2085, None), (IDS[1], 2085, 7), (IDS[2], 2085, 9), (IDS[3], 2085, None),
+                                                 (IDS[4], 2085, 12), (IDS[5], 2085, 14), (IDS[5], 65536, None)])
+def test_every_launch_length_equals_the_oracle(env_id, n, max_steps):
+    """rollout(fused=True) under the device policy (seven actions: four of them "invalid" = left), every slot of every launch."""
+    import minigrid_amd as mg
+    kw = {} if max_steps is None else {"max_steps": max_steps}
+    env = mg.make_vec(env_id, n, **kw)
+    assert env.max_fused_steps == 32                                   # (1 until round 4)
+    orc = ParOracle(env_id, n, False, **kw)
+    obs, _ = env.reset(seed=0)
+    assert (obs["image"] == orc.reset(0)[0]).all()
+    seed, t, fin = 2, 0, 0
+    lengths = [5, 20] + LENGTHS + LENGTHS[::-1] if n < 10000 else [5, 20, 32, 32, 13, 1, 32]
+    for T in lengths:
+        env.rollout(T, action_seed=seed, fused=True)
+        t, f = _check_launch(env, orc, seed, t, T, (env_id, n, "T", T, "t", t))
+        fin += f
+    assert fin > n // 2, "episodes should have ended inside the launches"
+    _final_state(env, orc)
+    c = env.counters()
+    assert c["env_steps"] == n * t and fin // 2 <= c["episodes"] <= fin      # (`fin` counts a step that both terminated and truncated twice)
+    assert c["maps_generated"] >= n + c["episodes"] - n                       # every reset drew a map: the host's, the live refill's or the kernel's own
+    env.close(); orc.close()
+
+
+@pytest.mark.parametrize("knob", [{"MG_ROLL_SPLIT": "0"}, {"MG_ROLL_EPW": "32"}, {"MG_ROLL_NW": "4"}, {"MG_ROLL_NW": "2"}, {"MG_ROLL_NW": "1"},
+                                  {"MG_DYN_INLOOP": "0"}])
+@pytest.mark.parametrize("env_id", [IDS[3], IDS[5]])
+def test_kernel_shapes_equal_the_oracle(env_id, knob, monkeypatch):
+    """The same launches through the other shapes of the kernel: the time split (every wave replays the draws on its own copy of the stream),
+    32-env workgroups, four / two / one wave per workgroup -- and the round-3 launches (MG_DYN_INLOOP=0) as the A/B baseline."""
+    import minigrid_amd as mg
+    for k, v in knob.items():
+        monkeypatch.setenv(k, v)
+    n = 1500
+    env = mg.make_vec(env_id, n, max_steps=20)
+    orc = ParOracle(env_id, n, False, max_steps=20)
+    obs, _ = env.reset(seed=5)
+    assert (obs["image"] == orc.reset(5)[0]).all()
+    F = env.max_fused_steps
+    assert F == (1 if "MG_DYN_INLOOP" in knob else 32)
+    seed, t = 9, 0
+    for T in [F, 7, F, 20, 3]:
+        env.rollout(T, action_seed=seed, fused=True)
+        if T <= F:
+            t, _ = _check_launch(env, orc, seed, t, T, (env_id, knob, T))
+        else:                                                          # (unfused handle: T one-step launches, the ring holds them all)
+            t, _ = _check_launch(env, orc, seed, t, T, (env_id, knob, T))
+    _final_state(env, orc)
+    env.close(); orc.close()
+
+
+@pytest.mark.parametrize("env_id", IDS)
+def test_caller_actions_fused_and_stepped_equal_the_oracle(env_id):
+    """step_many (one launch per 32 steps, the caller's actions staged in LDS) and step() (one-step launches: the workgroup's waves share the
+    encode) on one handle, a forward-heavy three-action policy with invalid actions mixed in: the -1 reward of walking into an obstacle
+    (dynamicobstacles.py:162-165; the doctest value of wrappers.py:833-837's NoDeath example) must occur often."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 1300
+    env = mg.make_vec(env_id, n)
+    orc = O.OracleVec(env_id, n)
+    obs, _ = env.reset(seed=21)
+    assert (obs["image"] == orc.reset(seeds=np.arange(21, 21 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(1)
+    minus = ended = 0
+
+    def draw(shape):
+        a = rng.choice(3, size=shape, p=[0.2, 0.2, 0.6]).astype(np.uint8)
+        bad = rng.random(shape) < 0.05
+        a[bad] = rng.integers(3, 7, int(bad.sum()))
+        return a
+
+    for rnd in range(4):
+        acts = draw((32, n))
+        env.step_many(acts)
+        for j in range(32):
+            oo, orew, oterm, otrunc, od, om = orc.step(acts[j])
+            img, r2, t2, u2, d2, m2, act = env.trajectory(31 - j)
+            assert (img == oo).all(), (env_id, rnd, j, np.argwhere((img != oo).reshape(n, -1).any(1))[:5].ravel())
+            assert r2.tobytes() == orew.tobytes() and (t2 == oterm).all() and (u2 == otrunc).all() and (act == acts[j]).all() and (d2 == od).all()
+            minus += int((orew == -1.0).sum()); ended += int((oterm | otrunc).sum())
+        for j in range(9):
+            a = draw(n)
+            obs, rew, term, trunc, _ = env.step(a)
+            oo, orew, oterm, otrunc, od, om = orc.step(a)
+            assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, rnd, j)
+            assert (obs["direction"] == od).all()
+    assert minus > n // 4 and ended > n
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", [IDS[1], IDS[2], IDS[5]])
+def test_same_step_autoreset_equals_the_oracle(env_id):
+    """Gymnasium's SAME_STEP autoreset: the step that ends an episode redraws the env from the stream position the step's own obstacle moves
+    left (refused for this level in rounds 2-3: its reset cannot be drawn ahead).  Stepped, then fused."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    n = 1500
+    env = mg.make_vec(env_id, n, autoreset_mode="same_step", max_steps=15, traj_slots=16)
+    orc = O.OracleVec(env_id, n, max_steps=15)
+    obs, _ = env.reset(seed=8)
+    assert (obs["image"] == orc.reset(seeds=np.arange(8, 8 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(4)
+    ended = 0
+    for t in range(40):
+        a = rng.choice(3, size=n, p=[0.2, 0.2, 0.6]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=2)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (obs["direction"] == od).all()
+        ended += int((term | trunc).sum())
+    assert ended > n
+    assert env.max_fused_steps == 16
+    for c in range(4):
+        env.rollout(16, action_seed=5, fused=True)
+        for k in reversed(range(16)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act, autoreset=2)
+            assert (img == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, c, k)
+            assert (d == od).all()
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all() and (a1[:, 6] == 0).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+    with pytest.raises(ValueError):                                    # the other observation modes redraw finished envs between launches
+        mg.make_vec(env_id, 64, autoreset_mode="same_step", obs_mode="full")
+
+
+@pytest.mark.parametrize("env_id", [IDS[3], IDS[5]])
+def test_philox_streams_fused_equal_stepped(env_id):
+    """rng='philox' (counter-based env streams; no reference stream to compare with): the fused launches must equal one-step launches of a
+    second handle, and both the round-3 launches (MG_DYN_INLOOP=0)."""
+    import os
+    import minigrid_amd as mg
+    n, T = 1100, 96
+    a_env, b_env = mg.make_vec(env_id, n, rng="philox", max_steps=25), mg.make_vec(env_id, n, rng="philox", max_steps=25)
+    os.environ["MG_DYN_INLOOP"] = "0"
+    try:
+        c_env = mg.make_vec(env_id, n, rng="philox", max_steps=25)
+    finally:
+        del os.environ["MG_DYN_INLOOP"]
+    assert a_env.max_fused_steps == 32 and c_env.max_fused_steps == 1
+    for e in (a_env, b_env, c_env):
+        e.reset(seed=4)
+    rng = np.random.default_rng(3)
+    ended = 0
+    for rnd in range(T // 32):
+        acts = rng.choice(3, size=(32, n), p=[0.2, 0.2, 0.6]).astype(np.uint8)
+        a_env.step_many(acts)
+        for j in range(32):
+            obs, rew, term, trunc, _ = b_env.step(acts[j])
+            o3, r3, t3, u3, _ = c_env.step(acts[j])
+            img, r2, t2, u2, d2, m2, act = a_env.trajectory(31 - j)
+            assert (img == obs["image"]).all() and (o3["image"] == obs["image"]).all(), (env_id, rnd, j)
+            assert r2.tobytes() == rew.tobytes() == r3.tobytes() and (t2 == term).all() and (u2 == trunc).all() and (t3 == term).all()
+            ended += int((term | trunc).sum())
+    assert ended > n
+    assert (a_env.get_rng_state() == b_env.get_rng_state()).all() and (c_env.get_rng_state() == b_env.get_rng_state()).all()
+    ga, aa = a_env.get_state(); gb, ab = b_env.get_state()
+    assert (ga == gb).all() and (aa == ab).all()
+    for e in (a_env, b_env, c_env):
+        e.close()
+
+
+def test_fused_launches_then_full_observation_on_the_same_handle():
+    """FullyObsWrapper on a live handle after fused launches: the FullyObs encode keeps the round-3 launches (live redraw, k_move_obstacles,
+    step kernel); envs a fused launch left waiting for their autoreset, the obstacle lists and the stream positions carry over."""
+    import minigrid_amd as mg
+    from minigrid_amd.wrappers import FullyObsWrapper
+    from oracle import oracle as O
+    env_id, n = IDS[4], 900
+    env = mg.make_vec(env_id, n, max_steps=30)
+    orc_p, orc_f = O.OracleVec(env_id, n, max_steps=30), O.OracleVec(env_id, n, full_obs=True, max_steps=30)
+    seeds = np.arange(3, 3 + n, dtype=np.uint64)
+    env.reset(seed=3); orc_p.reset(seeds=seeds); orc_f.reset(seeds=seeds)
+    for c in range(3):
+        env.rollout(29, action_seed=6, fused=True)
+        for k in reversed(range(29)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo = orc_p.step(act); orc_f.step(act)
+            assert (img == oo[0]).all() and (term == oo[2]).all(), (c, k)
+    FullyObsWrapper(env)
+    assert env.obs_mode == "full" and env.max_fused_steps == 1
+    rng = np.random.default_rng(7)
+    for t in range(60):
+        a = rng.choice(3, size=n, p=[0.2, 0.2, 0.6]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc_f.step(a)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), t
+    assert (env.get_rng_state() == orc_f.get_rng()).all()
+    env.close()

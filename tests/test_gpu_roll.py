@@ -118,7 +118,7 @@ def test_same_step_autoreset_equals_the_oracle(env_id, full, max_steps):
 def test_same_step_with_final_obs_equals_the_oracle(env_id, full, max_steps, output):
     """Gymnasium 1.x's SAME_STEP report: the step that ends an episode returns the next episode's first observation AND the ended
     episode's last one in info["final_obs"] / info["_final_obs"].  Built by composition (vector_env._same_step_with_final_obs), so it
-    also covers the levels the in-kernel SAME_STEP refuses (sentence levels, DynamicObstacles).  Oracle: a step without autoreset (its
+    also covers the observation modes the in-kernel SAME_STEP refuses (sentence levels and DynamicObstacles outside the 7x7 view).  Oracle: a step without autoreset (its
     observation IS the terminal one), then a masked reset of the envs that finished, each continuing its own stream."""
     import minigrid_amd as mg
     from oracle import oracle as O
@@ -171,8 +171,9 @@ def test_same_step_with_final_obs_equals_the_oracle(env_id, full, max_steps, out
 
 def test_same_step_autoreset_is_refused_where_it_is_not_built():
     import minigrid_amd as mg
+    # DynamicObstacles: in the step kernel of the default 7x7 view only (round 4, tests/test_gpu_dynobs.py); the other modes redraw between launches
     with pytest.raises(ValueError):
-        mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", 64, autoreset_mode="same_step")
+        mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", 64, autoreset_mode="same_step", obs_mode="full")
     # the sentence levels: in the step kernel of the default 7x7 view only (round 4); their other observation modes end episodes in k_verify
     with pytest.raises(ValueError):
         mg.make_vec("BabyAI-BossLevel-v0", 64, autoreset_mode="same_step", obs_mode="symbolic")
