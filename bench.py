@@ -44,6 +44,8 @@ WORKLOADS = {
     "doorkey8x8_rgb_partial": ("MiniGrid-DoorKey-8x8-v0", 65536, "rgb_partial"),   # 56x56x3 agent-POV frame
     # step() itself draws (the obstacles move on the env's stream): live generation + k_move_obstacles + k_step per step
     "dynobs16x16": ("MiniGrid-Dynamic-Obstacles-16x16-v0", 65536, "partial"),
+    "dynobs8x8": ("MiniGrid-Dynamic-Obstacles-8x8-v0", 65536, "partial"),
+    "dynobs6x6": ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 65536, "partial"),
     # the sentence levels (instruction trees; the verifier runs inside the fused step loop since round 3)
     "bosslevel": ("BabyAI-BossLevel-v0", 131072, "partial"),
 }

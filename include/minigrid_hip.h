@@ -346,7 +346,8 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
  * envs/dynamicobstacles.py:110-157 + MiniGridEnv.place_obj / place_agent, minigrid_env.py:313-395), on the host, for n envs in the state
  * exchange format: grid (n, W, H, 3) u8 in/out, agent (n, 8) i32 in/out (x, y, dir), rng (n, 5) u64 in/out (mg_get_rng's words), obst (n) u64
  * in/out (byte i = cell index y * W + x of obstacle i, list order).  mode[i]: 0 = nothing, 1 = the obstacle moves of one step(), 2 = reset()
- * (agent_start = (sx, sy, sdir), sx < 0: place_agent).  flags[i]: bit 0 a placement failed, bit 1 the grid changed, bit 2 not_clear. */
+ * (agent_start = (sx, sy, sdir), sx < 0: place_agent).  flags[i]: bit 0 a placement failed, bit 1 the grid changed, bit 2 not_clear.
+ * philox: 0 = numpy PCG64 streams, 1 = Philox streams, 2 = PCG64 with every try taken through the rare-case (redo) path of the draw code. */
 MG_API int mg_selftest_dynobs(int32_t width, int32_t height, int32_t n_obstacles, int32_t sx, int32_t sy, int32_t sdir, int32_t philox, int32_t n,
                               const uint8_t* mode, uint8_t* grid, int32_t* agent, uint64_t* rng, uint64_t* obst, uint8_t* flags);
 

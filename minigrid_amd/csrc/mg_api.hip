@@ -294,9 +294,11 @@ struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_st
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
+  // (DynamicObstacles in the loop, split: ONE copy of the grids -- the dynamics wave's, which stages the codes itself -- and a ring of stagings)
+  const bool dsplit = split && e->dyn_inloop;
   L.off_grid = 1024 + e->roll_guard;
-  L.off_codes = (L.off_grid + nw * 64 * e->GS + e->roll_guard + 15) & ~15;
-  const int ncodes = split ? nw - 1 : nw;
+  L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * 64 * e->GS + e->roll_guard + 15) & ~15;
+  const int ncodes = dsplit ? ROLL_DSPLIT_RING : split ? nw - 1 : nw;
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
@@ -307,7 +309,7 @@ static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool s
   L.off_spr = L.off_shadow_gt + (e->fast_full ? K * L.codes_stride : 0);
   L.off_act = L.off_spr + K * 64 * 16;
   L.off_log = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
-  L.off_tmpl = L.off_log + (split ? ROLL_LOG_BYTES + (e->dyn_inloop ? ROLL_LOG_OBST_BYTES : 0) : 0);   // k_roll7<GG_DYNOBS>: the level's constant grid
+  L.off_tmpl = L.off_log + (dsplit ? ROLL_LOG_SYNC_BYTES : split ? ROLL_LOG_BYTES : 0);   // k_roll7<GG_DYNOBS>: the level's constant grid
   L.total = L.off_tmpl + (e->dyn_inloop ? e->CS : 0);
   return L;
 }
@@ -316,7 +318,7 @@ static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split
 // time split: the dynamics of a step run once instead of once per wave that has not reached it yet.  With two waves the time split wins
 // (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
 static bool roll_split_ok(const mg_env* e, int nw) {
-  return e->roll_split_on && e->fast7 && !e->fast_full && !e->sentence && nw >= 3;
+  return e->roll_split_on && e->fast7 && !e->fast_full && !e->sentence && nw >= (e->dyn_inloop ? 2 : 3);
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
@@ -444,7 +446,9 @@ static int launch_step(mg_env* e, StepParams& P) {
     const RollLayout L = roll_layout(e, nw, acts, split);
     // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
-    P.split_mode = split ? (drot == 0 ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl;
+    // (DynamicObstacles in the loop: always wave 0 -- three waves per workgroup rotate over a CU's four SIMDs by themselves; 12.5 us per step against
+    // 15.3 with the rotation, profiles/r4/dynobs_waves_sweep2.txt)
+    P.split_mode = split ? ((drot == 0 || (e->dyn_inloop && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
@@ -710,10 +714,10 @@ static const char* configure_obs(mg_env* e) {
     // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
     int nw = 4;
     if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
-    // (DynamicObstacles in the loop: its dynamics -- a 128-bit multiply per placement try -- are the long part of a step and must not be replayed
-    // by a time split: three waves, one of them the dynamics wave, even where that leaves two workgroups per CU (16 x 16: 66 KB))
-    const int lds_cap = e->dyn_inloop ? 80 * 1024 : 53 * 1024;
-    while (nw > (e->dyn_inloop ? 3 : 1) && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > lds_cap) nw--;
+    while (nw > 1 && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > 53 * 1024) nw--;
+    // DynamicObstacles in the loop: the dynamics wave + two encode waves over ONE copy of the grids (roll_layout; 31 KB at 16 x 16).  The level's
+    // step is its placement loop, so the encode waves idle most of the time: three waves of ~150 VGPRs leave room for four workgroups per CU.
+    if (e->dyn_inloop) nw = 3;
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
     e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
@@ -1800,10 +1804,11 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
     auto run = [&](auto& r) {
       r.load(rng_words + (size_t)i * 5, 1, 0);
       if (regen) { if constexpr (std::remove_reference_t<decltype(r)>::kEpisodic) r.begin_episode(); }
-      dynobs_place(r, g.data(), W, H, w_magic, n_obst, regen, move, sx, sy, sdir, ax, ay, adir, o, failed, changed);
+      if (philox == 2) dynobs_place<std::remove_reference_t<decltype(r)>, true>(r, g.data(), W, H, w_magic, n_obst, regen, move, sx, sy, sdir, ax, ay, adir, o, failed, changed);
+      else dynobs_place(r, g.data(), W, H, w_magic, n_obst, regen, move, sx, sy, sdir, ax, ay, adir, o, failed, changed);
       r.store(rng_words + (size_t)i * 5, 1, 0);
     };
-    if (philox) { PhiloxStream r; run(r); } else { Pcg64Stream r; run(r); }
+    if (philox == 1) { PhiloxStream r; run(r); } else { Pcg64Stream r; run(r); }      // (2: PCG64 with every try redone by the general draw code)
     obst[i] = o;
     if (regen) { ag[0] = (int32_t)ax; ag[1] = (int32_t)ay; ag[2] = (int32_t)adir; }
     flags[i] = (uint8_t)((failed ? 1 : 0) | (changed ? 2 : 0) | (not_clear ? 4 : 0));

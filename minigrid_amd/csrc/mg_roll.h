@@ -341,7 +341,12 @@ constexpr int ROLL_MAX_WAVES = 4;
 constexpr int ROLL_LOG_STEPS = 8;                             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
 constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its progress counters
 constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
-constexpr int ROLL_LOG_OBST_BYTES = ROLL_LOG_STEPS * 64 * 8;   // k_roll7<GG_DYNOBS>: + the obstacle list after every logged step (behind the ring)
+#ifndef MG_DYN_WPE
+// waves per SIMD the register allocation of k_roll7<GG_DYNOBS> aims at: 4 = 128 VGPRs (three spilled, outside the placement loop) against 149.
+// Measured (profiles/r4/dynobs_waves_sweep2.txt, 65 536 envs): 16x16 12.5 us per step against 18.2, 8x8 12.3 against 17.8, Random-6x6 17.6 against 24.5
+#define MG_DYN_WPE 4
+#endif
+constexpr int ROLL_DSPLIT_RING = 4;                           // k_roll7<GG_DYNOBS>, split: code stagings between the dynamics wave and the encode waves (power of two)
 
 // LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
 //   [0, 1024) code -> triple table | guard | NW private copies of the 64 grids (GS bytes per env) | guard | NW code stagings |
@@ -364,7 +369,7 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
 // stream per lane in registers for the whole launch (mg_dynobs.h).  The level has no spare ring: an env whose episode ended is redrawn in
 // place by its own lane; the encode waves of the split follow the dynamics wave's grids through the obstacle LIST each step logs.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : 3, 8))) k_roll7(const StepParams P) {
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -395,7 +400,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // the four -- and pace the launch (measured: profiles/r4/split_rotation.txt)
   const int dw = split_mode ? (int)(((uint32_t)wg >> (P.split_mode - 1)) % (uint32_t)NW) : 0;
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
-  const int mycopy = share ? 0 : wave;
+  // GG_DYNOBS splits differently (see the loops below): ONE copy of the grids, the dynamics wave's, which also stages every step's codes
+  const bool dsplit = GG == GG_DYNOBS && split_mode;
+  const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
   uint8_t* scodes = smem + P.off_T + (split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
   const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
@@ -435,7 +442,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // copy, staged by all the threads of the workgroup.  Four loads in flight per lane, then the four LDS writes.
     const uint4* live = (const uint4*)(P.grid + (size_t)env0 * CS);
     const bool loads = share || split_mode || j_end > 0;             // wave-uniform
-    const int l0 = share ? tid : lane, lstride = share ? nthreads : 64;
+    const int l0 = (share || dsplit) ? tid : lane, lstride = (share || dsplit) ? nthreads : 64;
     auto stage4 = [&](int base) {
       uint4 gv[4];
 #pragma unroll
@@ -525,7 +532,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const bool see_through = P.see_through != 0 || MG_EXPBIT(P, 1);
   // GG_DYNOBS: the obstacle list (byte i = cell of obstacle i), what this launch did to it, episodes redrawn in the loop
   uint64_t obst = active ? tg_ld : 0ull;
-  bool obst_dirty = false, step_regen = false;
+  bool obst_dirty = false;
   uint32_t ngen = 0;
   // DynamicObstaclesEnv's draws for one step of the 64 envs (mg_dynobs.h): `regen` lanes redraw their env's episode in place (reset():
   // the constant grid copied from the template, one env at a time by the whole wave, then the agent and the obstacles placed by the lane),
@@ -557,7 +564,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         dynobs_place(rng, mygrid, W, H, P.w_magic, P.dyn_n, regen, move, P.dyn_sx, P.dyn_sy, P.dyn_sdir, ax, ay, adir, obst, failed, changed);
       if (regen) {
         a.x = ax; a.y = ay; a.dir = adir; a.carry = 0; a.step = 0; a.mission = 0; a.flags = flags_after_regen;
-        S.rec_dirty = true; S.wb_all = true; obst_dirty = true; step_regen = true;
+        S.rec_dirty = true; S.wb_all = true; obst_dirty = true;
         if (failed) S.errbits |= ERR_GENERATOR;                        // the reference's reset() raises RecursionError
         if (last_wave) ngen++;
       }
@@ -587,7 +594,6 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     o.reward = 0.0; o.term = 0; o.trunc = 0; o.sent0 = 0; o.sent1 = 0;
     S.errbits = 0;
     if constexpr (GG == GG_DYNOBS) {
-      step_regen = false;
       if (P.phase == PHASE_STEP) {
         // NEXT_STEP autoreset: the env whose episode the previous step ended is redrawn now and comes out FRESH (this step only observes it,
         // like an env the host's live refill redrew before the launch); everyone else's obstacles move
@@ -667,28 +673,31 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   };
   // gen_obs of the 64 envs as they stand in this wave's grids -> the observation of trajectory slot slot_out:
   // 49 codes per env (lane = env), then the encode in output space (lane = four cells = 12 bytes)
-  auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code) {
+  // (codes / parts: the code staging to use and which half to run -- 1 = stage the codes, 2 = encode them; the split of GG_DYNOBS runs the
+  // halves in different waves, everything else passes its own staging and 3)
+  auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code, uint8_t* codes_arg, int parts) {
+    uint8_t* const codes = FULL ? scodes : codes_arg;
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)taken_code;
     MG_MARK("codes");
     uint32_t gt_pos = 0, gt_old = 0;
     if constexpr (FULL) {
       // the agent's own cell reads (10, 0, dir) in the observation: patched into the stream for the encode, restored after it
       gt_pos = (uint32_t)(lane * cells) + av.x * (uint32_t)H + av.y;
-      if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (av.dir << 4)); }
-    } else if (!MG_EXPBIT(P, 4)) {
+      if (active) { gt_old = codes[gt_pos]; codes[gt_pos] = (uint8_t)(T_AGENT_MARK | (av.dir << 4)); }
+    } else if ((parts & 1) && !MG_EXPBIT(P, 4)) {
       View7 O;
       obs7_view(av, mygrid, W, H, see_through, O);
       uint32_t D[13];
       view7_pack(O, D);
       // (every lane takes part in the shuffle: a lane that is masked off reads back as 0 -- lane 62 would lose env 63's first bytes)
       const uint32_t next0 = (uint32_t)__shfl_down((int)D[0], 1);
-      obs7_stage(D, next0, lane, (uint32_t*)scodes);
+      obs7_stage(D, next0, lane, (uint32_t*)codes);
     }
     MG_MARK("codes_end");
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
-    if (!MG_EXPBIT(P, 2) && !share) {
+    if ((parts & 2) && !MG_EXPBIT(P, 2) && !share) {
       uint8_t* obase = P.obs + (size_t)slot_out * P.obs_stride + (size_t)wg * P.obs_wg_stride;   // 64 * OBE is a multiple of 16
       // (attribution builds, MG_EXP bit 256: every workgroup's observations go to a 1.2 MB window that stays in L2 -- the same store
       // instructions without the HBM write stream: is the observation stream's cost its issue or its bandwidth?)
@@ -698,14 +707,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
 #if MG_ENCODE_QUADS
       if (!FULL && nvalid == 64) {
         // 784 cell quads: thirteen rounds, the last one 16 lanes wide
-        encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));
+        encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, codes, slut, obase, !MG_EXPBIT(P, 32));
       } else if (!FULL && nvalid == 32) {
-        encode_quads<64, 32 * VIEW_CELLS / 4, NT>(lane, scodes, slut, obase, !MG_EXPBIT(P, 32));      // 32-env workgroups: 392 quads, seven rounds
+        encode_quads<64, 32 * VIEW_CELLS / 4, NT>(lane, codes, slut, obase, !MG_EXPBIT(P, 32));      // 32-env workgroups: 392 quads, seven rounds
       } else if (FULL && nvalid == 64) {
         const int nq = 16 * cells;                                                // 64 * cells / 4 quads
         for (int u = lane; u < nq; u += 64) {
           uint32_t o3[3];
-          obs7_quad((uint32_t)u, scodes, slut, o3);
+          obs7_quad((uint32_t)u, codes, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
           store12(obase + (size_t)u * 12, v, nt);
         }
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         for (int it = 0; it < NIT; it++) {
           const int c = lane + 64 * it;
           uint32_t o4[4];
-          obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), scodes, slut, o4);
+          obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), codes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
           if (it < NIT - 1 || c < NCH) store16(obase + (size_t)c * 16, v, nt);
         }
@@ -725,7 +734,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         const int nch = 12 * cells;                                               // 64 * 3 * cells / 16 chunks
         for (int c = lane; c < nch; c += 64) {
           uint32_t o4[4];
-          obs7_chunk((uint32_t)c, scodes, slut, o4);
+          obs7_chunk((uint32_t)c, codes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
           store16(obase + (size_t)c * 16, v, nt);
         }
@@ -735,13 +744,13 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
 #pragma unroll 1
         for (int c = lane; c <= nvec; c += 64) {
           uint32_t o4[4];
-          obs7_chunk((uint32_t)c, scodes, slut, o4);
+          obs7_chunk((uint32_t)c, codes, slut, o4);
           if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase + (size_t)c * 16, v, nt); }
           else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
         }
       }
     }
-    if constexpr (FULL) if (active && !share) scodes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
+    if constexpr (FULL) if (active && !share) codes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
   };
@@ -784,7 +793,49 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       store_scalars(slot_out, o);
       Agent av = a;
       if (o.show_taken) av.carry = 0;
-      observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry);
+      observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, scodes, 3);
+    }
+  } else if constexpr (GG == GG_DYNOBS) {
+    // ---- DynamicObstacles, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
+    // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
+    // j by encode wave j mod (NW - 1).  The level's step is its placement loop (a 128-bit multiply per try, ~16 tries deep for the unluckiest
+    // of 64 lanes; profiles/r4/dynobs_attr_first.txt: 26 of 30 us), which the ~150 instructions of the staging do not lengthen noticeably --
+    // and ONE copy of the grids per workgroup instead of one per wave lets four workgroups share a CU at 16 x 16 instead of two, i.e. every
+    // workgroup of a 65 536-env batch is resident at once.
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps staged, [1 + k] = steps encode wave k has written out
+    uint8_t* ring = smem + P.off_T;
+    const int NE = NW - 1;
+    if (wave == dw) {
+      __builtin_amdgcn_s_setprio(MG_DPRIO);
+      int kq = 0; uint32_t mq = 0;                                              // (j - RING) mod NE and div NE: who consumed the staging about to be reused
+      for (int j = 0; j < P.T; j++) {
+        StepOut o;
+        dynamics(j, o);
+        store_scalars(slot_of(j), o);
+        if (j >= ROLL_DSPLIT_RING) {
+          while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[1 + kq]) < mq + 1u) __builtin_amdgcn_s_sleep(1);
+          if (++kq == NE) { kq = 0; mq++; }
+        }
+        asm volatile("" ::: "memory");
+        observe(0, a, false, 0u, 0u, ring + (j & (ROLL_DSPLIT_RING - 1)) * P.codes_stride, 1);
+        // (DS operations of one wave execute in order: the counter cannot become visible before the codes)
+        asm volatile("" ::: "memory");
+        sync[0] = (uint32_t)(j + 1);
+      }
+    } else {
+      const int k = ek;
+      uint32_t done = 0;
+      Agent av = agent_unpack(0ull);
+      for (int j = k; j < P.T; j += NE) {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        observe(slot_of(j), av, false, 0u, 0u, ring + (j & (ROLL_DSPLIT_RING - 1)) * P.codes_stride, 2);
+        MG_LDS_SYNC();                                                          // the staging's last read has returned
+        asm volatile("" ::: "memory");
+        sync[1 + k] = ++done;
+      }
+      return;        // (nothing to report, no state to write back: the dynamics wave owns both)
     }
   } else if (wave == dw) {
     // ---- DYNAMICS wave (round 4): every step's action, transition and scalar outputs, and ONE record per env and step for the encode waves --
@@ -811,7 +862,6 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (o.show_taken) delta = (uint32_t)(S.targets & 0x3FFull) | (a.carry << 10) | (1u << 21);
       else delta = S.ev_dirty_idx >= 0 ? ((uint32_t)S.ev_dirty_idx | (S.ev_dirty_code << 10) | (1u << 30)) : 0u;
       delta |= ((S.ev_reset & 3u) << 18) | ((S.ev_reset == 1u ? S.ev_shadow & 1u : 0u) << 20) | (((S.h - 1u) & P.ring_mask & 0xFFu) << 22);
-      if constexpr (GG == GG_DYNOBS) delta |= step_regen ? (3u << 18) : 0u;      // reset kind 3: redrawn in place -- the template + the logged obstacle list
       if (j >= ROLL_LOG_STEPS) {
         // flow control: entry j reuses the slot of entry j - ROLL_LOG_STEPS, which every encode wave must have consumed
         const uint32_t need = (uint32_t)(j - ROLL_LOG_STEPS + 1);
@@ -822,7 +872,6 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
-      if constexpr (GG == GG_DYNOBS) ((uint64_t*)(smem + P.off_log + ROLL_LOG_BYTES))[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = obst;
       // (DS operations of one wave execute in order: the counter cannot become visible before the entry; the compiler must keep that order)
       asm volatile("" ::: "memory");
       sync[0] = (uint32_t)(j + 1);
@@ -841,33 +890,6 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
       const uint32_t delta = rec2.y;
       const uint32_t rk = (delta >> 18) & 3u;
-      if constexpr (GG == GG_DYNOBS) {
-        // this wave's grids follow the dynamics wave's through the obstacle list: a redrawn env = the template (copied by the whole wave, one
-        // env at a time) + its obstacles; otherwise the obstacles that moved, in list order (a cell one obstacle left may be the cell a later
-        // one enters)
-        const uint64_t on = ((const uint64_t*)(smem + P.off_log + ROLL_LOG_BYTES))[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
-        unsigned long long rm = __ballot(rk == 3u);
-        if (rm) {
-          const uint32_t* tm = (const uint32_t*)(smem + P.off_tmpl);
-          while (rm) {
-            const int b = __ffsll((long long)rm) - 1;
-            rm &= rm - 1ull;
-            uint32_t* gb = (uint32_t*)(sgrid + b * GS);
-            for (int c = lane; c < (CS >> 2); c += 64) gb[c] = tm[c];
-          }
-          asm volatile("" ::: "memory");
-        }
-        if (MG_EXPBIT(P, 1024)) { }       // (attribution builds: the encode waves without the obstacle updates)
-        else if (rk == 3u) {
-          for (int i = 0; i < P.dyn_n; i++) mygrid[(uint32_t)(on >> (8 * i)) & 0xFFu] = (uint8_t)CELL_BALL_BLUE;
-        } else if (on != obst) {
-          for (int i = 0; i < P.dyn_n; i++) {
-            const uint32_t was = (uint32_t)(obst >> (8 * i)) & 0xFFu, is = (uint32_t)(on >> (8 * i)) & 0xFFu;
-            if (was != is) { mygrid[was] = (uint8_t)CELL_EMPTY; mygrid[is] = (uint8_t)CELL_BALL_BLUE; }
-          }
-        }
-        obst = on;
-      } else
       if (__ballot(rk != 0u)) {
         if (rk == 1u) {
           const uint32_t* s4 = (const uint32_t*)(C.myshadow + ((delta >> 20) & 1u) * (uint32_t)P.shadow_stride);
@@ -891,7 +913,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       Agent av;
       av.x = rec2.x & 0xFFu; av.y = (rec2.x >> 8) & 0xFFu; av.dir = (rec2.x >> 16) & 3u; av.carry = rec2.x >> 24;
       av.step = 0; av.flags = 0; av.mission = 0;
-      observe(slot_of(j), av, ((delta >> 21) & 1u) != 0u, delta & 0x3FFu, (delta >> 10) & 0xFFu);
+      observe(slot_of(j), av, ((delta >> 21) & 1u) != 0u, delta & 0x3FFu, (delta >> 10) & 0xFFu, scodes, 3);
     }
     return;          // (nothing to report, no state to write back: the dynamics wave owns both -- and the env state is dead on this path)
   }

@@ -380,12 +380,14 @@ DYNOBS_IDS = ["MiniGrid-Dynamic-Obstacles-5x5-v0", "MiniGrid-Dynamic-Obstacles-R
               "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Dynamic-Obstacles-16x16-v0"]
 
 
+@pytest.mark.parametrize("redo", [0, 2])
 @pytest.mark.parametrize("env_id", DYNOBS_IDS)
-def test_dynobs_in_loop_draws_on_the_host_equal_the_oracle(env_id):
+def test_dynobs_in_loop_draws_on_the_host_equal_the_oracle(env_id, redo):
     """mg_selftest_dynobs = dynobs_place (mg_dynobs.h), the per-lane loop k_roll7<GG_DYNOBS> runs for DynamicObstacles' obstacle moves and
     in-place resets, compiled for the host: from numpy's freshly seeded PCG64 words it must reproduce the oracle's grids, agent poses and
     stream positions reset after reset and step after step (the obstacle LIST order is carried by the function itself: a wrong order, a draw
-    too many or a wrong rejection shows up as a diverging grid or stream)."""
+    too many or a wrong rejection shows up as a diverging grid or stream).  redo = 2: every try through the draw code's rare-case path (a
+    Lemire rejection candidate: once in ~10^9 tries by chance), which restores the stream and redraws with the general bounded-integer code."""
     import ctypes as C
     from oracle import oracle as O
     L = B.load()
@@ -405,7 +407,7 @@ def test_dynobs_in_loop_draws_on_the_host_equal_the_oracle(env_id):
     flags = np.zeros(n, np.uint8)
 
     def run(mode):
-        assert L.mg_selftest_dynobs(W, H, nob, s["start_x"], s["start_y"], s["start_dir"], 0, n, p(mode), p(grid), p(agent), p(words), p(obst), p(flags)) == 0
+        assert L.mg_selftest_dynobs(W, H, nob, s["start_x"], s["start_y"], s["start_dir"], redo, n, p(mode), p(grid), p(agent), p(words), p(obst), p(flags)) == 0
 
     orc.reset(seeds=seeds)
     run(np.full(n, 2, np.uint8))

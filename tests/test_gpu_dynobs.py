@@ -38,7 +38,7 @@ def test_every_launch_length_equals_the_oracle(env_id, n, max_steps):
     _final_state(env, orc)
     c = env.counters()
     assert c["env_steps"] == n * t and fin // 2 <= c["episodes"] <= fin      # (`fin` counts a step that both terminated and truncated twice)
-    assert c["maps_generated"] >= n + c["episodes"] - n                       # every reset drew a map: the host's, the live refill's or the kernel's own
+    assert c["maps_generated"] >= c["episodes"]          # every autoreset drew a map: the live refill's (envs waiting at a launch's start) or the kernel's own
     env.close(); orc.close()
 
 
