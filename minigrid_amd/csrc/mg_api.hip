@@ -381,7 +381,12 @@ static int launch_step(mg_env* e, StepParams& P) {
     // bound by the SIMDs' issue rate, not by latency, so sharing the machine buys nothing.  Off by default.
     static const bool overlap_ok = [] { const char* s = getenv("MG_LIVE_OVERLAP"); return s && atoi(s) != 0; }();
     bool live_on_gen = false;
-    if (e->launches > 0) {
+    // DynamicObstacles in the loop: a STEP launch redraws the envs waiting for their autoreset itself, at its first step (mg_dynobs.h), and
+    // REPLACES the request list with the envs its last step left waiting (P.live_gen = 2) -- no redraw launch, no counter reset between step
+    // launches; an OBSERVE launch (reset) still finds exactly the waiting envs listed
+    const bool inloop_step = e->dyn_inloop && P.phase == PHASE_STEP;
+    if (inloop_step) P.live_gen = 2;
+    if (e->launches > 0 && !inloop_step) {
       live_on_gen = overlap_ok && P.phase == PHASE_STEP;
       if (live_on_gen) {
         HIP_TRY(e, hipEventRecord(e->ev_step[0], e->stream));

@@ -983,6 +983,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (P.seg_count) {
     const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (S.h != h_in));
     const unsigned long long m = __ballot(want);
+    if (GG == GG_DYNOBS && P.live_gen == 2) {
+      // (in-loop redraws: every earlier request was served by this launch's first step -- the list becomes the envs waiting NOW)
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (want) P.seg[(size_t)wg * P.seg_cap + rank] = (uint32_t)e;
+      if (lane == 0) P.seg_count[wg] = (uint32_t)__popcll(m);
+    } else
     if (m) {
       // (the segment's fill count is read here, where a request is filed -- in the prologue it was one more round trip before the grids)
       uint32_t qn = uni32(P.seg_count[wg]);

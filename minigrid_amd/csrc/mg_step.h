@@ -66,7 +66,7 @@ struct StepParams {
   uint32_t* err; unsigned long long* counters;
   // ---- config ----
   int N, W, H, CS, GS, cells, max_steps, see_through, rule, rule_cell, rule_div, autoreset_next_step, autoreset_same_step, phase, static_gen;
-  int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs
+  int live_gen;           // resets are drawn in place right before the step launch (DynamicObstacles): queue the ended envs (2: k_roll7<GG_DYNOBS> replaces the list, see launch_step)
   int use_shadow;         // spare episodes of every env staged in LDS (its shadow slots) at launch start: 0 (one-step launches), 1, or 2 (k_roll7)
   int shadow_stride, spr_stride;   // bytes between the shadow sets of the staged grids / of the staged (agent record, aux word) pairs
   int off_grid, off_shadow, off_spr, off_act, off_trow, off_T, OBE;   // LDS carve-up (bytes); OBE = obs bytes per env

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: DynamicObstacles in the loop, third cut = the defaults (128 VGPRs, dynamics wave 0 + two encode waves over one grid copy)
 export TMPDIR=/tmp
-ROOT=$PWD; OUT=$ROOT/gpurun_out/r4dyn4; mkdir -p $OUT
+ROOT=$PWD; OUT=$ROOT/gpurun_out/r4dyn5; mkdir -p $OUT
 line() { python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1 %.3f G %.2f us/step (event %.2f) host-event %.1f us' % (d['value']/1e9, d['ms_per_step']*1e3, r['avg_step_us'], (d['host_ms']-d['event_ms'])*1e3))"; }
 timeout 600 python -m pytest tests/test_gpu_dynobs.py -q -p no:cacheprovider > $OUT/pytest_dynobs.log 2>&1; echo "dynobs tests rc=$?" | tee $OUT/rc.txt
