@@ -518,8 +518,12 @@ def main(argv=None):
                                        "note": "SURVEY.md 8(d) prices the reference's 3 B/cell grid re-read and the agent record r/w in every step; "
                                                "a fused launch keeps them in LDS, so these bytes never reach HBM and this fraction can exceed 1 -- "
                                                "it is the secondary figure, not the roofline"},
-                         "note": "achieved = HBM bytes the launch really moves / its duration (HIP events, this run); the bound this kernel "
-                                 "runs against is the HBM WRITE stream"},
+                         "note": ("achieved = HBM bytes the launch really moves / its duration (HIP events, this run); this level's step is NOT "
+                                  "HBM-bound: its obstacle moves and resets draw on the env's own stream inside the step loop (a numpy-exact PCG64 step per "
+                                  "placement try, a wavefront waiting for its unluckiest lane) -- VALU issue-bound, DESIGN.md section 4"
+                                  if args.workload.startswith("dynobs") else
+                                  "achieved = HBM bytes the launch really moves / its duration (HIP events, this run); the bound this kernel "
+                                  "runs against is the HBM WRITE stream")},
         }
         if not args.no_cpu_baseline and world == 1 and use_gpu:
             if obs_mode.startswith("rgb"):

@@ -290,7 +290,7 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
-struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, total; };
+struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, off_instr, total; };
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
@@ -310,7 +310,8 @@ static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool s
   L.off_act = L.off_spr + K * 64 * 16;
   L.off_log = L.off_act + (with_actions ? MAX_FUSED_STEPS * 64 : 0);
   L.off_tmpl = L.off_log + (dsplit ? ROLL_LOG_SYNC_BYTES : split ? ROLL_LOG_BYTES : 0);   // k_roll7<GG_DYNOBS>: the level's constant grid
-  L.total = L.off_tmpl + (e->dyn_inloop ? e->CS : 0);
+  L.off_instr = (L.off_tmpl + (e->dyn_inloop ? e->CS : 0) + 15) & ~15;          // k_roll7<GG_SENTENCE>: the workgroup's instruction records
+  L.total = L.off_instr + ((e->sentence && e->fast7 && MG_INSTR_LDS) ? 64 * ROLL_INSTR_STRIDE * 8 : 0);
   return L;
 }
 static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split = false) { return roll_layout(e, nw, with_actions, split).total; }
@@ -344,7 +345,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   }
   P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
   P.rng = e->rng; P.dyn_n = std::min(e->cfg.num_dists, 8); P.dyn_sx = e->cfg.agent_start_x; P.dyn_sy = e->cfg.agent_start_y; P.dyn_sdir = e->cfg.agent_start_dir;
-  P.off_tmpl = 0; P.stat_gen_off = STAT_EPISODES + e->nwaves;
+  P.off_tmpl = 0; P.off_instr = 0; P.stat_gen_off = STAT_EPISODES + e->nwaves;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
@@ -453,7 +454,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
     // (DynamicObstacles in the loop: always wave 0 -- three waves per workgroup rotate over a CU's four SIMDs by themselves; 12.5 us per step against
     // 15.3 with the rotation, profiles/r4/dynobs_waves_sweep2.txt)
-    P.split_mode = split ? ((drot == 0 || (e->dyn_inloop && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl;
+    P.split_mode = split ? ((drot == 0 || (e->dyn_inloop && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
@@ -698,7 +699,15 @@ static const char* configure_obs(mg_env* e) {
   // loop, but the doubled staging costs more than that saves on every level tried (DoorKey-8x8 x 262 144: 12.3 -> 13.8 us per step,
   // LavaCrossing FullyObs: 13.0 -> 14.0, GoToRedBall: equal).  (Two need cb >= 2: a batch may take that many spares per env.)
   e->roll_shadows = 1;
-  if (const char* s = getenv("MG_ROLL_SHADOWS")) { if (atoi(s) == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2; }
+  // The sentence levels (22 x 22 grids, ONE wave per workgroup: the verifier's record is the wave's) do without: the staged spares are half of the
+  // workgroup's LDS (32 of 71 KB), i.e. two single-wave workgroups per CU instead of four, and their episodes are long (a reset in 1.4 % of
+  // the wave-steps).  BossLevel x 131 072: 126 -> 89 us per step, x 32 768: 36.8 -> 27.6 (profiles/r4/shadows_bosslevel.txt).
+  if (e->sentence) e->roll_shadows = 0;
+  if (const char* s = getenv("MG_ROLL_SHADOWS")) {
+    if (atoi(s) == 1) e->roll_shadows = 1;
+    if (atoi(s) == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
+    if (atoi(s) == 0 && !e->static_gen) e->roll_shadows = 0;          // no staging: every reset fetches its spare from the ring in HBM inside the loop
+  }
   e->fast_full = false;
   if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341 && !getenv("MG_NO_ROLL_FULL")) {
     // FullyObs through k_roll7<., true>: the row-major grids + their image-order streams, private per wave, and the shadow pair.  Only
@@ -733,7 +742,7 @@ static const char* configure_obs(mg_env* e) {
     // 1.60 against 1.37, x 16 384 1.28 against 1.32 -- the wave-instructions double and the chains do not get shorter.  The switch stays
     // for A/B runs; tests/test_gpu_roll.py keeps the path exact.
     int epw = 64;
-    if (const char* s = getenv("MG_ROLL_EPW")) { int v = atoi(s); if ((v == 32 && !e->sentence) || v == 64) epw = v; }
+    if (const char* s = getenv("MG_ROLL_EPW")) { int v = atoi(s); if (v == 32 || v == 64) epw = v; }
     e->epw = epw; e->nwaves = (e->N + epw - 1) / epw;
   }
   if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";

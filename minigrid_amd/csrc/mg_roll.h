@@ -346,6 +346,14 @@ constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
 // Measured (profiles/r4/dynobs_waves_sweep2.txt, 65 536 envs): 16x16 12.5 us per step against 18.2, 8x8 12.3 against 17.8, Random-6x6 17.6 against 24.5
 #define MG_DYN_WPE 4
 #endif
+#ifndef MG_INSTR_LDS
+// the sentence levels' instruction records staged in LDS for the launch (1) or left in global memory (0).  Measured after the verifier was
+// restated (mg_verify.h; profiles/r4/bosslevel_records_ab.txt): BossLevel x 131 072 73.3 us per step with the records in LDS, 64.7 in global
+// memory -- the 21 KB of records leave two single-wave workgroups per CU instead of four, and the verifier now makes few enough accesses
+// for that to cost more than their latency.  Both forms pass the sentence levels' GPU tests; the LDS form stays for A/B builds.
+#define MG_INSTR_LDS 0
+#endif
+constexpr int ROLL_INSTR_STRIDE = INSTR_WORDS + 1;            // k_roll7<GG_SENTENCE>: u64 words between the envs' instruction records in LDS (odd: conflict-free 8-byte reads)
 constexpr int ROLL_DSPLIT_RING = 4;                           // k_roll7<GG_DYNOBS>, split: code stagings between the dynamics wave and the encode waves (power of two)
 
 // LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
@@ -409,6 +417,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
   uint8_t* sact = smem + P.off_act;
+  uint64_t* sinstr = (uint64_t*)(smem + P.off_instr);                 // GG_SENTENCE: the 64 envs' instruction records, ROLL_INSTR_STRIDE words apart
   const bool last_wave = share ? wave == sw : split_mode ? wave == dw : wave == NW - 1;    // the wave that owns the final state
   // (split[] is read with compile-time indices: a register-indexed read of a kernel argument is a load from the argument segment)
   const int sp_lo = wave == 0 ? P.split[0] : wave == 1 ? P.split[1] : wave == 2 ? P.split[2] : P.split[3];
@@ -471,6 +480,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
   if constexpr (GG == GG_DYNOBS) for (int k = tid; k < CS; k += nthreads) smem[P.off_tmpl + k] = (uint8_t)dynobs_template_cell(k, W, H, P.w_magic);
+  if constexpr (GG == GG_SENTENCE && MG_INSTR_LDS) {
+    // the workgroup's instruction records: consecutive in global memory (INSTR_WORDS u64 per env), 8 bytes per lane, coalesced
+    const uint64_t* gi = P.instr + (size_t)env0 * INSTR_WORDS;
+    for (int k = tid; k < nvalid * INSTR_WORDS; k += nthreads) {
+      const uint32_t ce = ((uint32_t)k * 1639u) >> 16, w = (uint32_t)k - ce * (uint32_t)INSTR_WORDS;      // k / 40 for k < 64 * 40
+      sinstr[ce * ROLL_INSTR_STRIDE + w] = gi[k];
+    }
+  }
   if (split_mode && tid < ROLL_LOG_SYNC_BYTES / 4) ((uint32_t*)(smem + P.off_log))[tid] = (tid >= 1 && tid < NW) ? 0u : (tid == 0 ? 0u : 0xFFFFFFFFu);   // [0] logged, [1 + k] consumed by encode wave k (absent waves: never behind)
   // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
   // (an env's ring position is lane ce's S.h: every wave has loaded its own copy of the 64 heads)
@@ -610,10 +627,11 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       dyn_draws(active && (o.term | o.trunc) != 0u, false, 0u);
     }
     if constexpr (GG == GG_SENTENCE) if (active) {
-      // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): the env's
-      // instruction record stays in global memory -- one lane per env, a few dependent loads per step, no other wave touches it (one
-      // wave per workgroup: the time split would replay it) -- the grid it looks at is the LDS copy.
-      uint64_t* I = P.instr + (size_t)e * INSTR_WORDS;
+      // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): one lane per env on
+      // the env's instruction record, which no other wave touches (one wave per workgroup: the time split would replay it); the grid it looks
+      // at is the LDS copy.  (The record can be staged in LDS for the launch as well -- MG_INSTR_LDS above; what made the verifier 66 of the 90 us of
+      // a BossLevel step at 131 072 envs, profiles/r4/bosslevel_attr.txt, was its instruction count under divergence, not its loads: mg_verify.h.)
+      uint64_t* I = MG_INSTR_LDS ? sinstr + lane * ROLL_INSTR_STRIDE : P.instr + (size_t)e * INSTR_WORDS;
       if (a.flags & FLAG_NEW_EPISODE) {
         // the spare taken in this step brings its instruction record (its ring slot = the head before the take); head itself is
         // published at launch end, so no refill can have touched the slot
@@ -622,7 +640,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         a.flags &= ~FLAG_NEW_EPISODE;
       } else if (P.phase == PHASE_STEP) {
         uint32_t max_steps = 0, verr = 0;
-        const uint32_t status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
+        // (attribution builds, MG_EXP bit 2048: the step without its verifier -- nothing ever succeeds, the episode limit still comes from the record)
+        uint32_t status = R_CONTINUE;
+        if (MG_EXPBIT(P, 2048)) max_steps = (uint32_t)(I[0] >> 39) & 0xFFFFu;
+        else status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
         S.errbits |= verr;
         o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
         o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
@@ -639,7 +660,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       double r2 = 0.0; uint32_t t2 = 0, u2 = 0;
       env_transition<GG, 1>(P, C2, S, A_DONE, r2, t2, u2);
       if (active && (a.flags & FLAG_NEW_EPISODE)) {
-        uint64_t* I = P.instr + (size_t)e * INSTR_WORDS;
+        uint64_t* I = MG_INSTR_LDS ? sinstr + lane * ROLL_INSTR_STRIDE : P.instr + (size_t)e * INSTR_WORDS;
         const uint64_t* src = P.spare_instr + ((size_t)((S.h - 1u) & P.ring_mask) * N + (size_t)e) * INSTR_WORDS;
         for (int k = 0; k < INSTR_WORDS; k++) I[k] = src[k];
         a.flags &= ~FLAG_NEW_EPISODE;
@@ -955,6 +976,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (S.cur != S.targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; S.rec_dirty = true; }
+  }
+  if constexpr (GG == GG_SENTENCE && MG_INSTR_LDS) {
+    // the records go back the way they came (this wave is the only one that touched them; its own LDS writes are in order before these reads)
+    uint64_t* gi = P.instr + (size_t)env0 * INSTR_WORDS;
+    for (int k = lane; k < nvalid * INSTR_WORDS; k += 64) {
+      const uint32_t ce = ((uint32_t)k * 1639u) >> 16, w = (uint32_t)k - ce * (uint32_t)INSTR_WORDS;
+      gi[k] = sinstr[ce * ROLL_INSTR_STRIDE + w];
+    }
   }
   if (active) {
     if (S.rec_dirty) P.agent[e] = agent_pack(a);

@@ -7,22 +7,49 @@
 
 namespace mg {
 
+// Round 4: the verifier was 66 of the 90 us of a BossLevel step at 131 072 envs (profiles/r4/bosslevel_attr.txt) -- not for its memory accesses
+// (staging the records in LDS alone changed nothing) but for its INSTRUCTIONS under divergence: verify(action) is a tree walk whose leaf
+// check was inlined at nine call sites, each with up to two 63-entry scans of the position table, and with 64 envs per wavefront some lane
+// takes every path in every step.  Restated so that a wave executes each piece once:
+//   * the position table is scanned ONCE per step (id_at of the cell in front of the agent: every identity question of a step is about that
+//     cell); what the leaves see after this step's own bookkeeping follows from it (a picked-up / opened-away object has left the cell, a
+//     dropped one is the object that was carried: objects never share a cell);
+//   * the four leaves' verify_action results are computed up front in ONE rolled loop, side-effect free; the tree walk (And / Before / After,
+//     verifier.py:464-571) then only looks results up and notes which leaves it LOOKED AT; the side effects of looking at a leaf
+//     (preCarrying, lastStepMatch: ActionInstr.verify / PickupInstr / PutNextInstr) are applied to exactly those afterwards.
 struct InstrRef {
   uint64_t* I; const uint8_t* g; int W, H;
-  bool done_actions;                 // verifier.py:26 use_done_actions
+  uint32_t w_magic;                  // ceil(2^16 / W): cell index -> row without a division
   uint32_t act, carry_id;            // carry_id: id + 1 of what the agent holds after the action
   int fidx; bool inb;                // the cell in front of the agent after the action
+  int fid;                           // id of the object in that cell after this step's bookkeeping, -1 = none tracked
   uint32_t errbits;
   MG_D uint16_t* pos() const { return (uint16_t*)(I + IW_POS); }
-  MG_D int id_at(int cell) const { const uint16_t* p = pos(); for (int i = 0; i < 63; i++) if ((int)p[i] == cell) return i; return -1; }
+  // first id whose position is `cell` (ids 0 .. 62), two positions per word, from the top down so that the lowest index wins
+  MG_D int id_at(int cell) const {
+    const uint32_t* p32 = (const uint32_t*)(I + IW_POS);
+    int id = -1;
+#pragma unroll 4
+    for (int w = 31; w >= 0; w--) {
+      const uint32_t v = p32[w];
+      if ((int)(v >> 16) == cell && w != 31) id = 2 * w + 1;              // (index 63 is not an id)
+      if ((int)(v & 0xFFFFu) == cell) id = 2 * w;
+    }
+    return id;
+  }
   MG_D bool in_stale(int j, int cell) const {
     const uint64_t s = I[IW_STALE + j];
     bool hit = false;
     for (int k = 0; k < 4; k++) hit |= (int)((s >> (16 * k)) & 0xFFFFull) == cell;
     return hit;
   }
+  MG_D bool adjacent(uint32_t p, uint32_t q) const {                     // Manhattan distance 1 between two cell indices
+    const int py = (int)((p * w_magic) >> 16), px = (int)p - py * W, qy = (int)((q * w_magic) >> 16), qx = (int)q - qy * W;
+    return abs(px - qx) + abs(py - qy) == 1;
+  }
   // an object left `cell` without a refresh of obj_poss (picked up, or a box toggled away): every description tracking it keeps the cell
   MG_D void left(int id, int cell) {
+#pragma unroll 1
     for (int j = 0; j < 8; j++)
       if ((I[IW_SET + j] >> id) & 1ull) {
         uint64_t s = I[IW_STALE + j];
@@ -32,38 +59,26 @@ struct InstrRef {
         else I[IW_STALE + j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
       }
   }
-  // ActionInstr.verify (verifier.py:228-242): with use_done_actions only `done` reports -- success iff the previous action completed this
-  // instruction (lastStepMatch: bit 28 of the leaf word), failure otherwise; any other action runs verify_action, remembers whether it
-  // matched and returns None, which every caller treats like "continue"
-  MG_D uint32_t leaf(int k) {
-    if (!done_actions) return leaf_action(k);
-    if (act == A_DONE) return ((I[IW_LEAF + k] >> 28) & 1ull) ? (uint32_t)R_SUCCESS : (uint32_t)R_FAILURE;
-    const uint32_t r = leaf_action(k);
-    I[IW_LEAF + k] = (I[IW_LEAF + k] & ~(1ull << 28)) | ((uint64_t)(r == R_SUCCESS) << 28);
-    return R_CONTINUE;
-  }
-  // verifier.py: GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431
-  MG_D uint32_t leaf_action(int k) {
-    const uint64_t L = I[IW_LEAF + k];
+  // verify_action of leaf k on the state after this step's bookkeeping, WITHOUT its side effect (the preCarrying update of the pick-up and
+  // put-next instructions): verifier.py GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431.  L = the leaf word.
+  MG_D uint32_t leaf_result(int k, uint64_t L) const {
     const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
-    const uint64_t dset = I[IW_SET + 2 * k], fset = I[IW_SET + 2 * k + 1];
+    const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying as the leaf last saw it
+    const uint64_t dset = I[IW_SET + 2 * k];
     if (verb == V_GOTO) {
       if (!inb) return R_CONTINUE;
       const uint32_t c = g[fidx];
       bool hit = in_stale(2 * k, fidx);
-      if (!hit && c != CELL_EMPTY && cell_type(c) != T_WALL) { const int id = id_at(fidx); hit = id >= 0 && ((dset >> id) & 1ull); }
+      if (!hit && c != CELL_EMPTY && cell_type(c) != T_WALL) hit = fid >= 0 && ((dset >> fid) & 1ull);
       return hit ? R_SUCCESS : R_CONTINUE;
     }
     if (verb == V_OPEN) {
       if (act != A_TOGGLE || !inb) return R_CONTINUE;
       const uint32_t c = g[fidx];
       if (cell_ref_type(c) != T_DOOR || cell_type(c) == T_BOX_KEY) return R_CONTINUE;
-      const int id = id_at(fidx);
-      if (id >= 0 && ((dset >> id) & 1ull) && cell_type(c) == T_DOOR) return R_SUCCESS;
+      if (fid >= 0 && ((dset >> fid) & 1ull) && cell_type(c) == T_DOOR) return R_SUCCESS;
       return strict ? R_FAILURE : R_CONTINUE;
     }
-    const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying: updated only when this leaf is looked at
-    I[IW_LEAF + k] = (L & ~(127ull << 21)) | ((uint64_t)carry_id << 21);
     if (verb == V_PICKUP) {
       if (act != A_PICKUP) return R_CONTINUE;
       if (pre == 0u && carry_id != 0u && ((dset >> (carry_id - 1u)) & 1ull)) return R_SUCCESS;
@@ -74,12 +89,16 @@ struct InstrRef {
     if (pre == 0u || !((dset >> (pre - 1u)) & 1ull)) return R_CONTINUE;
     const uint32_t cur = pos()[pre - 1u];                                 // obj_a.cur_pos: where it was just dropped, or (-1, -1)
     if (cur >= POS_GONE) return R_CONTINUE;
-    const int cx = (int)cur % W, cy = (int)cur / W;
     bool next = false;
-    for (int m = 0; m < 63; m++)
-      if ((fset >> m) & 1ull) { const uint32_t q = pos()[m]; if (q < POS_GONE) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
+    uint64_t fs = I[IW_SET + 2 * k + 1] & 0x7FFFFFFFFFFFFFFFull;          // the fixed description's objects (ids 0 .. 62)
+    while (fs) {
+      const int m = __ffsll((long long)fs) - 1;
+      fs &= fs - 1ull;
+      const uint32_t q = pos()[m];
+      if (q < POS_GONE) next |= adjacent(cur, q);
+    }
     const uint64_t sf = I[IW_STALE + 2 * k + 1];
-    for (int j = 0; j < 4; j++) { const uint32_t q = (uint32_t)(sf >> (16 * j)) & 0xFFFFu; if (q != 0xFFFFu) next |= abs(cx - (int)q % W) + abs(cy - (int)q / W) == 1; }
+    for (int j = 0; j < 4; j++) { const uint32_t q = (uint32_t)(sf >> (16 * j)) & 0xFFFFu; if (q != 0xFFFFu) next |= adjacent(cur, q); }
     return next ? R_SUCCESS : R_CONTINUE;
   }
 };
@@ -89,26 +108,54 @@ struct InstrRef {
 MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
                             bool done_actions = false) {
   InstrRef R;
-  R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0; R.done_actions = done_actions;
+  R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0;
+  R.w_magic = (65536u + (uint32_t)W - 1u) / (uint32_t)W;                  // (W is uniform: scalar arithmetic)
   R.act = act;
   const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
   R.inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
   R.fidx = R.inb ? fy * W + fx : 0;
   uint64_t Hd = I[0];
   uint32_t carry_id = (uint32_t)(Hd >> 55) & 127u;
-  // object identity through the action (minigrid_env.py:556-577): a pickup / drop shows as a change of `carrying`
-  if (a.carry != 0u && carry_id == 0u && R.inb) {
-    const int id = R.id_at(R.fidx);
-    if (id >= 0) { carry_id = (uint32_t)id + 1u; R.pos()[id] = (uint16_t)POS_CARRIED; R.left(id, R.fidx); }
+  // object identity through the action (minigrid_env.py:556-577): a pickup / drop shows as a change of `carrying`; a box that was opened
+  // is gone (Box.toggle replaces it by its -- empty -- content).  At most one of the three happened, in the cell in front of the agent.
+  const bool picked = a.carry != 0u && carry_id == 0u && R.inb;
+  const bool dropped = a.carry == 0u && carry_id != 0u && R.inb;
+  const bool box_gone = !picked && !dropped && R.act == A_TOGGLE && R.inb && R.g[R.fidx] == CELL_EMPTY;
+  const int pid = R.inb ? R.id_at(R.fidx) : -1;                           // the step's one scan of the position table
+  R.fid = pid;
+  if (picked) {
+    if (pid >= 0) { carry_id = (uint32_t)pid + 1u; R.pos()[pid] = (uint16_t)POS_CARRIED; }
     else R.errbits |= ERR_TRACKED;
-  } else if (a.carry == 0u && carry_id != 0u && R.inb) {
+    R.fid = -1;
+  } else if (dropped) {
+    R.fid = (int)carry_id - 1;
     R.pos()[carry_id - 1u] = (uint16_t)R.fidx; carry_id = 0u;
-  } else if (R.act == A_TOGGLE && R.inb && R.g[R.fidx] == CELL_EMPTY) {
-    const int id = R.id_at(R.fidx);                                       // a box was opened: Box.toggle replaces it by its (empty) content
-    if (id >= 0) { R.pos()[id] = (uint16_t)POS_GONE; R.left(id, R.fidx); }
+  } else if (box_gone) {
+    if (pid >= 0) R.pos()[pid] = (uint16_t)POS_GONE;
+    R.fid = -1;
   }
+  if ((picked || box_gone) && pid >= 0) R.left(pid, R.fidx);
   R.carry_id = carry_id;
   if (R.act == A_DROP) for (int j = 0; j < 8; j++) I[IW_STALE + j] = ~0ull;          // update_objs_poss (roomgrid_level.py:92-93, 106-117)
+  // the four leaves' results, their lastStepMatch bits, which of them carry a preCarrying (pick up = 1, put next = 3: the odd verbs)
+  uint32_t res = 0, lastm = 0, side = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    const uint64_t L = I[IW_LEAF + k];
+    res |= R.leaf_result(k, L) << (2 * k);
+    lastm |= ((uint32_t)(L >> 28) & 1u) << k;
+    side |= ((uint32_t)L & 1u) << k;
+  }
+  // ActionInstr.verify (verifier.py:228-242): with use_done_actions only `done` reports -- success iff the previous action completed the
+  // instruction (lastStepMatch), failure otherwise; any other action runs verify_action, remembers whether it matched and returns None,
+  // which every caller treats like "continue"
+  uint32_t looked = 0;
+  auto leaf = [&](uint32_t k) -> uint32_t {
+    looked |= 1u << k;
+    if (!done_actions) return (res >> (2u * k)) & 3u;
+    if (act == A_DONE) return ((lastm >> k) & 1u) ? (uint32_t)R_SUCCESS : (uint32_t)R_FAILURE;
+    return R_CONTINUE;
+  };
   // instrs.verify(action): leaf | And (verifier.py:556-571) | Before / After (:464-486, :507-529) over leaves or And nodes
   const uint32_t root = (uint32_t)Hd & 7u;
   auto nodef = [&](uint32_t n) -> uint32_t { return (uint32_t)(Hd >> (3 + 8 * n)) & 255u; };
@@ -116,13 +163,13 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
   auto done_set = [&](uint32_t n, int which, uint32_t v) { Hd = (Hd & ~(3ull << (27 + 4 * n + 2 * which))) | ((uint64_t)v << (27 + 4 * n + 2 * which)); };
   auto and_verify = [&](uint32_t n) -> uint32_t {
     const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
-    if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, R.leaf((int)ia));
-    if (done_get(n, 1) != R_SUCCESS) done_set(n, 1, R.leaf((int)ib));
+    if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, leaf(ia));
+    if (done_get(n, 1) != R_SUCCESS) done_set(n, 1, leaf(ib));
     return (done_get(n, 0) == R_SUCCESS && done_get(n, 1) == R_SUCCESS) ? (uint32_t)R_SUCCESS : (uint32_t)R_CONTINUE;
   };
-  auto sub_verify = [&](uint32_t idx) -> uint32_t { return idx < 4u ? R.leaf((int)idx) : and_verify(idx - 4u); };
+  auto sub_verify = [&](uint32_t idx) -> uint32_t { return idx < 4u ? leaf(idx) : and_verify(idx - 4u); };
   uint32_t status;
-  if (root < 4u) status = R.leaf((int)root);
+  if (root < 4u) status = leaf(root);
   else {
     const uint32_t n = root - 4u, nd = nodef(n), kind = nd & 3u, ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
     if (kind == N_AND) status = and_verify(n);
@@ -143,6 +190,20 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
         if (r != R_CONTINUE) status = r;
       }
     }
+  }
+  // what looking at a leaf did to it: verify_action ran (unless use_done_actions answered a `done` from lastStepMatch alone) -- the pick-up and
+  // put-next instructions remember what the agent carries NOW (preCarrying is updated only when the leaf is looked at), use_done_actions
+  // remembers whether the action matched
+  if (looked != 0u && (!done_actions || act != A_DONE)) {
+#pragma unroll 1
+    for (int k = 0; k < 4; k++)
+      if ((looked >> k) & 1u) {
+        const uint64_t L = I[IW_LEAF + k];
+        uint64_t Ln = L;
+        if ((side >> k) & 1u) Ln = (Ln & ~(127ull << 21)) | ((uint64_t)carry_id << 21);
+        if (done_actions) Ln = (Ln & ~(1ull << 28)) | ((uint64_t)(((res >> (2 * k)) & 3u) == R_SUCCESS) << 28);
+        if (Ln != L) I[IW_LEAF + k] = Ln;
+      }
   }
   Hd = (Hd & ~(127ull << 55)) | ((uint64_t)carry_id << 55);
   I[0] = Hd;
