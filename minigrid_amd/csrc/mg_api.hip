@@ -290,15 +290,18 @@ static int flush_refills(mg_env* e) {
 
 // LDS carve-up of a k_roll7 workgroup with nw wavefronts (mg_roll.h): table | guard | nw private grid copies | guard | nw code
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
+// code stagings between the dynamics wave and the encode waves of the DynamicObstacles / sentence-level split (mg_roll.h): four, or two where the
+// 22 x 22 grids of the sentence levels leave no more (38.75 KB per workgroup = four workgroups per CU)
+static int roll_dring(const mg_env* e) { return e->sentence ? 2 : ROLL_DSPLIT_RING; }
 struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, off_instr, total; };
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
   // (DynamicObstacles in the loop, split: ONE copy of the grids -- the dynamics wave's, which stages the codes itself -- and a ring of stagings)
-  const bool dsplit = split && e->dyn_inloop;
+  const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7));
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * 64 * e->GS + e->roll_guard + 15) & ~15;
-  const int ncodes = dsplit ? ROLL_DSPLIT_RING : split ? nw - 1 : nw;
+  const int ncodes = dsplit ? roll_dring(e) : split ? nw - 1 : nw;
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
@@ -319,7 +322,7 @@ static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split
 // time split: the dynamics of a step run once instead of once per wave that has not reached it yet.  With two waves the time split wins
 // (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
 static bool roll_split_ok(const mg_env* e, int nw) {
-  return e->roll_split_on && e->fast7 && !e->fast_full && !e->sentence && nw >= (e->dyn_inloop ? 2 : 3);
+  return e->roll_split_on && e->fast7 && !e->fast_full && nw >= ((e->dyn_inloop || e->sentence) ? 2 : 3);
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
@@ -345,7 +348,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   }
   P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
   P.rng = e->rng; P.dyn_n = std::min(e->cfg.num_dists, 8); P.dyn_sx = e->cfg.agent_start_x; P.dyn_sy = e->cfg.agent_start_y; P.dyn_sdir = e->cfg.agent_start_dir;
-  P.off_tmpl = 0; P.off_instr = 0; P.stat_gen_off = STAT_EPISODES + e->nwaves;
+  P.off_tmpl = 0; P.off_instr = 0; P.dring = ROLL_DSPLIT_RING; P.stat_gen_off = STAT_EPISODES + e->nwaves;
   P.off_reward = e->off_reward; P.off_term = e->off_term; P.off_trunc = e->off_trunc; P.off_dir = e->off_dir;
   P.off_mission = e->off_mission; P.off_action = e->off_action;
   P.T = 1; P.slot0 = 0; P.S = e->S;
@@ -430,7 +433,9 @@ static int launch_step(mg_env* e, StepParams& P) {
     // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
     int nw = std::min(e->roll_nw, std::max(1, P.T));
     const bool in_loop_verify = e->sentence && e->fast7;       // k_roll7<GG_SENTENCE>: one wave per workgroup (the record is shared state)
-    if (in_loop_verify) nw = 1;
+    // (the split of the sentence levels: the stepping / verifying wave + ONE encode wave over one copy of the grids, mg_roll.h; MG_SENT_SPLIT=0: one wave)
+    static const bool sent_split = [] { const char* s = getenv("MG_SENT_SPLIT"); return !s || atoi(s) != 0; }();
+    if (in_loop_verify) nw = (sent_split && P.T > 1 && roll_split_ok(e, 2)) ? 2 : 1;
     // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
     // MG_ROLL_SHARE: 0 = off, 1..15 = the stepping wave is (workgroup >> (value - 1)) & 3, 16 = always wave 0
     static const int share_mode = [] { const char* s = getenv("MG_ROLL_SHARE"); const int v = s ? atoi(s) : 16; return v < 0 || v > 16 ? 16 : v; }();
@@ -448,13 +453,13 @@ static int launch_step(mg_env* e, StepParams& P) {
     for (int w = 1; w < nw; w++) { x = x * (1.0 - ratio) + x1; P.split[w] = std::min(P.T - (nw - w), std::max(P.split[w - 1] + 1, (int)std::lround(x))); }
     for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
     const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
-    const bool split = !share && P.T > 1 && nw >= 3 && roll_split_ok(e, nw);
+    const bool split = !share && P.T > 1 && roll_split_ok(e, nw);
     const RollLayout L = roll_layout(e, nw, acts, split);
     // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
     // (DynamicObstacles in the loop: always wave 0 -- three waves per workgroup rotate over a CU's four SIMDs by themselves; 12.5 us per step against
     // 15.3 with the rotation, profiles/r4/dynobs_waves_sweep2.txt)
-    P.split_mode = split ? ((drot == 0 || (e->dyn_inloop && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
+    P.split_mode = split ? ((drot == 0 || ((e->dyn_inloop || e->sentence) && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.dring = roll_dring(e); P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
@@ -735,6 +740,7 @@ static const char* configure_obs(mg_env* e) {
     if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
     e->roll_nw = nw;
     e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
+    if (e->sentence && e->fast7) e->lds_bytes = std::max(e->lds_bytes, roll_lds_bytes(e, 2, true, true));
   }
   if (e->fast7 && !e->fast_full) {
     // MG_ROLL_EPW=32: 32 envs per k_roll7 workgroup (lanes 32 .. 63 idle) = twice the workgroups for a batch that leaves the chip half

@@ -354,7 +354,7 @@ constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
 #define MG_INSTR_LDS 0
 #endif
 constexpr int ROLL_INSTR_STRIDE = INSTR_WORDS + 1;            // k_roll7<GG_SENTENCE>: u64 words between the envs' instruction records in LDS (odd: conflict-free 8-byte reads)
-constexpr int ROLL_DSPLIT_RING = 4;                           // k_roll7<GG_DYNOBS>, split: code stagings between the dynamics wave and the encode waves (power of two)
+constexpr int ROLL_DSPLIT_RING = 4;                           // k_roll7<GG_DYNOBS / GG_SENTENCE>, split: code stagings between the dynamics wave and the encode waves (P.dring: a power of two up to this)
 
 // LDS carve-up (bytes) of a k_roll7 workgroup, computed by the host (mg_api.hip roll_layout) and passed in StepParams:
 //   [0, 1024) code -> triple table | guard | NW private copies of the 64 grids (GS bytes per env) | guard | NW code stagings |
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int dw = split_mode ? (int)(((uint32_t)wg >> (P.split_mode - 1)) % (uint32_t)NW) : 0;
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
   // GG_DYNOBS splits differently (see the loops below): ONE copy of the grids, the dynamics wave's, which also stages every step's codes
-  const bool dsplit = GG == GG_DYNOBS && split_mode;
+  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
   uint8_t* scodes = smem + P.off_T + (split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
@@ -816,13 +816,16 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (o.show_taken) av.carry = 0;
       observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, scodes, 3);
     }
-  } else if constexpr (GG == GG_DYNOBS) {
-    // ---- DynamicObstacles, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
+  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE) {
+    // ---- DynamicObstacles and the sentence levels, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
     // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
     // j by encode wave j mod (NW - 1).  The level's step is its placement loop (a 128-bit multiply per try, ~16 tries deep for the unluckiest
     // of 64 lanes; profiles/r4/dynobs_attr_first.txt: 26 of 30 us), which the ~150 instructions of the staging do not lengthen noticeably --
     // and ONE copy of the grids per workgroup instead of one per wave lets four workgroups share a CU at 16 x 16 instead of two, i.e. every
     // workgroup of a 65 536-env batch is resident at once.
+    // The sentence levels (round 4, one encode wave): their step is ~5 000 dependent instructions in ONE wave per workgroup (the verifier's record
+    // is that wave's), four workgroups per CU -- one wave per SIMD at ~10 cycles per instruction.  Handing the output-space encode (a quarter of
+    // the instructions) to a second wave shortens the chain and puts a second wave on every SIMD without a second copy of the 22 x 22 grids.
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
     lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps staged, [1 + k] = steps encode wave k has written out
     uint8_t* ring = smem + P.off_T;
@@ -834,12 +837,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         StepOut o;
         dynamics(j, o);
         store_scalars(slot_of(j), o);
-        if (j >= ROLL_DSPLIT_RING) {
+        if (j >= P.dring) {
           while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[1 + kq]) < mq + 1u) __builtin_amdgcn_s_sleep(1);
           if (++kq == NE) { kq = 0; mq++; }
         }
         asm volatile("" ::: "memory");
-        observe(0, a, false, 0u, 0u, ring + (j & (ROLL_DSPLIT_RING - 1)) * P.codes_stride, 1);
+        observe(0, a, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 1);
         // (DS operations of one wave execute in order: the counter cannot become visible before the codes)
         asm volatile("" ::: "memory");
         sync[0] = (uint32_t)(j + 1);
@@ -851,7 +854,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       for (int j = k; j < P.T; j += NE) {
         while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        observe(slot_of(j), av, false, 0u, 0u, ring + (j & (ROLL_DSPLIT_RING - 1)) * P.codes_stride, 2);
+        observe(slot_of(j), av, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 2);
         MG_LDS_SYNC();                                                          // the staging's last read has returned
         asm volatile("" ::: "memory");
         sync[1 + k] = ++done;

@@ -87,6 +87,7 @@ struct StepParams {
   uint64_t* rng;             // the envs' streams (SoA words, mg_rng.h)
   int dyn_n, dyn_sx, dyn_sy, dyn_sdir;   // n_obstacles; agent_start_pos / agent_start_dir (dyn_sx < 0: place_agent)
   int off_tmpl;              // LDS: the level's constant grid (walls + goal), CS bytes
+  int dring;                 // k_roll7<GG_DYNOBS / GG_SENTENCE>, split: code stagings in the ring between the dynamics wave and the encode waves (2 or 4)
   int off_instr;             // k_roll7<GG_SENTENCE>, LDS: the workgroup's instruction records (mg_roll.h ROLL_INSTR_STRIDE)
   int stat_gen_off;          // first generator statistics slot in `counters`
 };
