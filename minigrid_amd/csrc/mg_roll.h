@@ -377,7 +377,7 @@ MG_D void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {     
 // stream per lane in registers for the whole launch (mg_dynobs.h).  The level has no spare ring: an env whose episode ended is redrawn in
 // place by its own lane; the encode waves of the split follow the dynamics wave's grids through the obstacle LIST each step logs.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : 3, 8))) k_roll7(const StepParams P) {
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -618,6 +618,11 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         dyn_draws(active && pend && reset_enabled && maskok, active && !(a.flags & (FLAG_RESET_PENDING | FLAG_FRESH)), FLAG_FRESH);
       }
     }
+    // the sentence levels: the hot words of the env's instruction record, requested BEFORE the step's own work so that the verifier below finds
+    // them arrived (mg_verify.h InstrWords; an env that takes a new episode in this step does not verify, and its record is replaced below)
+    InstrWords IWd;
+    if constexpr (GG == GG_SENTENCE) if (active && P.phase == PHASE_STEP && !MG_EXPBIT(P, 2048))
+      IWd.load(MG_INSTR_LDS ? sinstr + lane * ROLL_INSTR_STRIDE : P.instr + (size_t)e * INSTR_WORDS);
     MG_MARK("transition");
     if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
     MG_MARK("after_transition");
@@ -643,7 +648,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         // (attribution builds, MG_EXP bit 2048: the step without its verifier -- nothing ever succeeds, the episode limit still comes from the record)
         uint32_t status = R_CONTINUE;
         if (MG_EXPBIT(P, 2048)) max_steps = (uint32_t)(I[0] >> 39) & 0xFFFFu;
-        else status = verify_action(I, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
+        else status = verify_action(I, IWd, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
         S.errbits |= verr;
         o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
         o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;

@@ -16,7 +16,22 @@ namespace mg {
 //     dropped one is the object that was carried: objects never share a cell);
 //   * the four leaves' verify_action results are computed up front in ONE rolled loop, side-effect free; the tree walk (And / Before / After,
 //     verifier.py:464-571) then only looks results up and notes which leaves it LOOKED AT; the side effects of looking at a leaf
-//     (preCarrying, lastStepMatch: ActionInstr.verify / PickupInstr / PutNextInstr) are applied to exactly those afterwards.
+//     (preCarrying, lastStepMatch: ActionInstr.verify / PickupInstr / PutNextInstr) are applied to exactly those afterwards;
+// ... and (third cut) the record's hot words -- header, the four leaf words, the eight object sets, the eight stale-cell words: 21 of its 40 --
+// are LOADED ONCE per step into registers (InstrWords; k_roll7 issues the loads before MiniGridEnv.step's own work, so that their latency -- the
+// record lives in global memory, every lane on its own 320 bytes -- is hidden behind it), worked on there, and the changed ones stored back.
+// The position table (16 words) stays in memory: one scan, one or two writes.
+struct InstrWords {
+  uint64_t hd, leaf[4], set[8], stale[8];
+  MG_D void load(const uint64_t* I) {
+    hd = I[0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) leaf[k] = I[IW_LEAF + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { set[k] = I[IW_SET + k]; stale[k] = I[IW_STALE + k]; }
+  }
+};
+
 struct InstrRef {
   uint64_t* I; const uint8_t* g; int W, H;
   uint32_t w_magic;                  // ceil(2^16 / W): cell index -> row without a division
@@ -29,7 +44,7 @@ struct InstrRef {
   MG_D int id_at(int cell) const {
     const uint32_t* p32 = (const uint32_t*)(I + IW_POS);
     int id = -1;
-#pragma unroll 4
+#pragma unroll 8
     for (int w = 31; w >= 0; w--) {
       const uint32_t v = p32[w];
       if ((int)(v >> 16) == cell && w != 31) id = 2 * w + 1;              // (index 63 is not an id)
@@ -37,9 +52,9 @@ struct InstrRef {
     }
     return id;
   }
-  MG_D bool in_stale(int j, int cell) const {
-    const uint64_t s = I[IW_STALE + j];
+  static MG_D bool in_stale(uint64_t s, int cell) {
     bool hit = false;
+#pragma unroll
     for (int k = 0; k < 4; k++) hit |= (int)((s >> (16 * k)) & 0xFFFFull) == cell;
     return hit;
   }
@@ -48,27 +63,28 @@ struct InstrRef {
     return abs(px - qx) + abs(py - qy) == 1;
   }
   // an object left `cell` without a refresh of obj_poss (picked up, or a box toggled away): every description tracking it keeps the cell
-  MG_D void left(int id, int cell) {
-#pragma unroll 1
+  MG_D void left(InstrWords& R, int id, int cell) {
+#pragma unroll
     for (int j = 0; j < 8; j++)
-      if ((I[IW_SET + j] >> id) & 1ull) {
-        uint64_t s = I[IW_STALE + j];
+      if ((R.set[j] >> id) & 1ull) {
+        const uint64_t s = R.stale[j];
         int slot = -1;
+#pragma unroll
         for (int k = 3; k >= 0; k--) if (((s >> (16 * k)) & 0xFFFFull) == 0xFFFFull) slot = k;
         if (slot < 0) errbits |= ERR_TRACKED;
-        else I[IW_STALE + j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
+        else R.stale[j] = (s & ~(0xFFFFull << (16 * slot))) | ((uint64_t)cell << (16 * slot));
       }
   }
-  // verify_action of leaf k on the state after this step's bookkeeping, WITHOUT its side effect (the preCarrying update of the pick-up and
-  // put-next instructions): verifier.py GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431.  L = the leaf word.
-  MG_D uint32_t leaf_result(int k, uint64_t L) const {
+  // verify_action of a leaf on the state after this step's bookkeeping, WITHOUT its side effect (the preCarrying update of the pick-up and
+  // put-next instructions): verifier.py GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431.
+  // L = the leaf word, dset / fset = its description's and fixed description's objects, sd / sf = their stale cells.
+  MG_D uint32_t leaf_result(uint64_t L, uint64_t dset, uint64_t fset, uint64_t sd, uint64_t sf) const {
     const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
     const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying as the leaf last saw it
-    const uint64_t dset = I[IW_SET + 2 * k];
     if (verb == V_GOTO) {
       if (!inb) return R_CONTINUE;
       const uint32_t c = g[fidx];
-      bool hit = in_stale(2 * k, fidx);
+      bool hit = in_stale(sd, fidx);
       if (!hit && c != CELL_EMPTY && cell_type(c) != T_WALL) hit = fid >= 0 && ((dset >> fid) & 1ull);
       return hit ? R_SUCCESS : R_CONTINUE;
     }
@@ -90,23 +106,24 @@ struct InstrRef {
     const uint32_t cur = pos()[pre - 1u];                                 // obj_a.cur_pos: where it was just dropped, or (-1, -1)
     if (cur >= POS_GONE) return R_CONTINUE;
     bool next = false;
-    uint64_t fs = I[IW_SET + 2 * k + 1] & 0x7FFFFFFFFFFFFFFFull;          // the fixed description's objects (ids 0 .. 62)
+    uint64_t fs = fset & 0x7FFFFFFFFFFFFFFFull;                           // the fixed description's objects (ids 0 .. 62)
     while (fs) {
       const int m = __ffsll((long long)fs) - 1;
       fs &= fs - 1ull;
       const uint32_t q = pos()[m];
       if (q < POS_GONE) next |= adjacent(cur, q);
     }
-    const uint64_t sf = I[IW_STALE + 2 * k + 1];
+#pragma unroll
     for (int j = 0; j < 4; j++) { const uint32_t q = (uint32_t)(sf >> (16 * j)) & 0xFFFFu; if (q != 0xFFFFu) next |= adjacent(cur, q); }
     return next ? R_SUCCESS : R_CONTINUE;
   }
 };
 
-// One step's verification of one env AFTER the action was applied (agent `a`, grid `g`).  Returns the instruction's status
-// (R_CONTINUE / R_SUCCESS / R_FAILURE) and the episode's max_steps; OR-s tracking errors into errbits.
-MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
-                            bool done_actions = false) {
+// One step's verification of one env AFTER the action was applied (agent `a`, grid `g`); Wd = the record's hot words as loaded before the
+// step (InstrWords::load).  Returns the instruction's status (R_CONTINUE / R_SUCCESS / R_FAILURE) and the episode's max_steps; OR-s tracking
+// errors into errbits; stores the words it changed.
+MG_D uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out,
+                            uint32_t& errbits, bool done_actions = false) {
   InstrRef R;
   R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0;
   R.w_magic = (65536u + (uint32_t)W - 1u) / (uint32_t)W;                  // (W is uniform: scalar arithmetic)
@@ -114,8 +131,9 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
   const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
   R.inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
   R.fidx = R.inb ? fy * W + fx : 0;
-  uint64_t Hd = I[0];
+  uint64_t Hd = Wd.hd;
   uint32_t carry_id = (uint32_t)(Hd >> 55) & 127u;
+  const InstrWords W0 = Wd;                                               // (what to compare against when storing back)
   // object identity through the action (minigrid_env.py:556-577): a pickup / drop shows as a change of `carrying`; a box that was opened
   // is gone (Box.toggle replaces it by its -- empty -- content).  At most one of the three happened, in the cell in front of the agent.
   const bool picked = a.carry != 0u && carry_id == 0u && R.inb;
@@ -134,15 +152,18 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
     if (pid >= 0) R.pos()[pid] = (uint16_t)POS_GONE;
     R.fid = -1;
   }
-  if ((picked || box_gone) && pid >= 0) R.left(pid, R.fidx);
+  if ((picked || box_gone) && pid >= 0) R.left(Wd, pid, R.fidx);
   R.carry_id = carry_id;
-  if (R.act == A_DROP) for (int j = 0; j < 8; j++) I[IW_STALE + j] = ~0ull;          // update_objs_poss (roomgrid_level.py:92-93, 106-117)
+  if (R.act == A_DROP) {                                                  // update_objs_poss (roomgrid_level.py:92-93, 106-117)
+#pragma unroll
+    for (int j = 0; j < 8; j++) Wd.stale[j] = ~0ull;
+  }
   // the four leaves' results, their lastStepMatch bits, which of them carry a preCarrying (pick up = 1, put next = 3: the odd verbs)
   uint32_t res = 0, lastm = 0, side = 0;
-#pragma unroll 1
+#pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint64_t L = I[IW_LEAF + k];
-    res |= R.leaf_result(k, L) << (2 * k);
+    const uint64_t L = Wd.leaf[k];
+    res |= R.leaf_result(L, Wd.set[2 * k], Wd.set[2 * k + 1], Wd.stale[2 * k], Wd.stale[2 * k + 1]) << (2 * k);
     lastm |= ((uint32_t)(L >> 28) & 1u) << k;
     side |= ((uint32_t)L & 1u) << k;
   }
@@ -156,11 +177,13 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
     if (act == A_DONE) return ((lastm >> k) & 1u) ? (uint32_t)R_SUCCESS : (uint32_t)R_FAILURE;
     return R_CONTINUE;
   };
-  // instrs.verify(action): leaf | And (verifier.py:556-571) | Before / After (:464-486, :507-529) over leaves or And nodes
-  const uint32_t root = (uint32_t)Hd & 7u;
-  auto nodef = [&](uint32_t n) -> uint32_t { return (uint32_t)(Hd >> (3 + 8 * n)) & 255u; };
-  auto done_get = [&](uint32_t n, int which) -> uint32_t { return (uint32_t)(Hd >> (27 + 4 * n + 2 * which)) & 3u; };
-  auto done_set = [&](uint32_t n, int which, uint32_t v) { Hd = (Hd & ~(3ull << (27 + 4 * n + 2 * which))) | ((uint64_t)v << (27 + 4 * n + 2 * which)); };
+  // instrs.verify(action): leaf | And (verifier.py:556-571) | Before / After (:464-486, :507-529) over leaves or And nodes.
+  // (the node fields [3:27) and the done states [27:39) of the header as two 32-bit words: the walk shifts by run-time amounts)
+  const uint32_t root = (uint32_t)Hd & 7u, nodes = (uint32_t)(Hd >> 3) & 0xFFFFFFu;
+  uint32_t dn = (uint32_t)(Hd >> 27) & 0xFFFu;
+  auto nodef = [&](uint32_t n) -> uint32_t { return (nodes >> (8u * n)) & 255u; };
+  auto done_get = [&](uint32_t n, int which) -> uint32_t { return (dn >> (4u * n + 2u * (uint32_t)which)) & 3u; };
+  auto done_set = [&](uint32_t n, int which, uint32_t v) { const uint32_t sh = 4u * n + 2u * (uint32_t)which; dn = (dn & ~(3u << sh)) | (v << sh); };
   auto and_verify = [&](uint32_t n) -> uint32_t {
     const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
     if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, leaf(ia));
@@ -194,22 +217,34 @@ MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const A
   // what looking at a leaf did to it: verify_action ran (unless use_done_actions answered a `done` from lastStepMatch alone) -- the pick-up and
   // put-next instructions remember what the agent carries NOW (preCarrying is updated only when the leaf is looked at), use_done_actions
   // remembers whether the action matched
-  if (looked != 0u && (!done_actions || act != A_DONE)) {
-#pragma unroll 1
+  if (!done_actions || act != A_DONE) {
+#pragma unroll
     for (int k = 0; k < 4; k++)
       if ((looked >> k) & 1u) {
-        const uint64_t L = I[IW_LEAF + k];
-        uint64_t Ln = L;
+        uint64_t Ln = Wd.leaf[k];
         if ((side >> k) & 1u) Ln = (Ln & ~(127ull << 21)) | ((uint64_t)carry_id << 21);
         if (done_actions) Ln = (Ln & ~(1ull << 28)) | ((uint64_t)(((res >> (2 * k)) & 3u) == R_SUCCESS) << 28);
-        if (Ln != L) I[IW_LEAF + k] = Ln;
+        Wd.leaf[k] = Ln;
       }
   }
-  Hd = (Hd & ~(127ull << 55)) | ((uint64_t)carry_id << 55);
+  Hd = (Hd & ~((0xFFFull << 27) | (127ull << 55))) | ((uint64_t)dn << 27) | ((uint64_t)carry_id << 55);
+  Wd.hd = Hd;
+  // store what changed
   I[0] = Hd;
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (Wd.leaf[k] != W0.leaf[k]) I[IW_LEAF + k] = Wd.leaf[k];
+#pragma unroll
+  for (int k = 0; k < 8; k++) if (Wd.stale[k] != W0.stale[k]) I[IW_STALE + k] = Wd.stale[k];
   max_steps_out = (uint32_t)(Hd >> 39) & 0xFFFFu;
   errbits |= R.errbits;
   return status;
+}
+// (the form that loads the words itself: k_verify, after a step kernel)
+MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
+                            bool done_actions = false) {
+  InstrWords Wd;
+  Wd.load(I);
+  return verify_action(I, Wd, g, W, H, a, act, max_steps_out, errbits, done_actions);
 }
 
 }  // namespace mg

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: the sentence levels split (stepping / verifying wave + one encode wave over one grid copy): parity, BossLevel
 export TMPDIR=/tmp
-ROOT=$PWD; OUT=$ROOT/gpurun_out/r4boss5; mkdir -p $OUT
+ROOT=$PWD; OUT=$ROOT/gpurun_out/r4boss6; mkdir -p $OUT
 line() { python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('$1 %.3f G %.2f us/step (event %.2f)' % (d['value']/1e9, d['ms_per_step']*1e3, r['avg_step_us']))"; }
 timeout 900 python -m pytest tests -q -m gpu -n 4 -p no:cacheprovider -k "Boss or sentence or GoToSeq or Synth or OpenTwoDoors or done_actions or MoveTwo or PickupLoc or synths5r2 or wrapping or pickling or dynobs" > $OUT/pytest_sentence.log 2>&1; echo "sentence + dynobs tests rc=$?" | tee $OUT/rc.txt
