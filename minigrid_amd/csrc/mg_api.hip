@@ -73,6 +73,7 @@ struct mg_env {
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
   bool lane_gen = false;      // the refills run one lane per episode (k_refill_lane: the single-room levels; MG_LANE_GEN=0: the wave-per-episode k_refill)
   bool dyn_inloop = false;    // DynamicObstacles, default 7x7 view: k_roll7<GG_DYNOBS> draws the level's moves and resets inside the step loop (mg_dynobs.h; MG_DYN_INLOOP=0: the round-3 launches)
+  bool full_split = true;     // FullyObs (k_roll7<., true>): the dynamics wave + encode waves over staged copies of its image-order stream (MG_FULL_SPLIT=0: the two-wave time split)
   bool roll_split_on = true;  // MG_ROLL_SPLIT (read when the observation configuration is made): 0 = the round-3 time split at every width
   int roll_shadows = 1;       // spare episodes per env staged in LDS by a fused k_roll7 launch (2 unless the level draws nothing)
   int roll_guard = 0;
@@ -292,16 +293,19 @@ static int flush_refills(mg_env* e) {
 // stagings | shadow grids | shadow agent / aux words | caller-supplied actions
 // code stagings between the dynamics wave and the encode waves of the DynamicObstacles / sentence-level split (mg_roll.h): four, or two where the
 // 22 x 22 grids of the sentence levels leave no more (38.75 KB per workgroup = four workgroups per CU)
-static int roll_dring(const mg_env* e) { return e->sentence ? 2 : ROLL_DSPLIT_RING; }
+static int roll_dring(const mg_env* e) {
+  static const int forced = [] { const char* s = getenv("MG_DRING"); const int v = s ? atoi(s) : 0; return (v == 2 || v == 4) ? v : 0; }();
+  return forced ? forced : (e->sentence || e->fast_full) ? 2 : ROLL_DSPLIT_RING;
+}
 struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, off_instr, total; };
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
   // (DynamicObstacles in the loop, split: ONE copy of the grids -- the dynamics wave's, which stages the codes itself -- and a ring of stagings)
-  const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7));
+  const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full);
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * 64 * e->GS + e->roll_guard + 15) & ~15;
-  const int ncodes = dsplit ? roll_dring(e) : split ? nw - 1 : nw;
+  const int ncodes = dsplit ? roll_dring(e) + (e->fast_full ? 1 : 0) : split ? nw - 1 : nw;   // (FullyObs: the dynamics wave's own image-order stream + the ring of staged copies)
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
@@ -322,7 +326,8 @@ static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split
 // time split: the dynamics of a step run once instead of once per wave that has not reached it yet.  With two waves the time split wins
 // (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
 static bool roll_split_ok(const mg_env* e, int nw) {
-  return e->roll_split_on && e->fast7 && !e->fast_full && nw >= ((e->dyn_inloop || e->sentence) ? 2 : 3);
+  if (e->fast_full) return e->roll_split_on && e->full_split && nw >= 2;
+  return e->roll_split_on && e->fast7 && nw >= ((e->dyn_inloop || e->sentence) ? 2 : 3);
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
@@ -459,7 +464,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
     // (DynamicObstacles in the loop: always wave 0 -- three waves per workgroup rotate over a CU's four SIMDs by themselves; 12.5 us per step against
     // 15.3 with the rotation, profiles/r4/dynobs_waves_sweep2.txt)
-    P.split_mode = split ? ((drot == 0 || ((e->dyn_inloop || e->sentence) && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.dring = roll_dring(e); P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
+    P.split_mode = split ? ((drot == 0 || ((e->dyn_inloop || e->sentence || e->fast_full) && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.dring = roll_dring(e); P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
@@ -732,7 +737,10 @@ static const char* configure_obs(mg_env* e) {
     // 65 536: 2.64 us per step with 4, 2.71 with 3; DoorKey-8x8 x 262 144: 11.3 with 4, 11.8 with 3, 12.1 with 2).  (With the chunk
     // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
     int nw = 4;
-    if (e->fast_full) nw = std::min(nw, 2);      // FullyObs: the encode is most of a step, silent replays buy little (LavaCrossing x 131 072: 12.2 us with 2, 12.5 with 3, 14.6 with 4)
+    { const char* s = getenv("MG_FULL_SPLIT"); e->full_split = !s || atoi(s) != 0; }
+    // FullyObs: two waves -- the dynamics wave + ONE encode wave over staged copies of its image-order stream (round 4; LavaCrossing FullyObs x 131 072:
+    // 7.63 us per step, 7.92 with two encode waves, 8.42 with the round-3 time split, whose second wave replayed the dynamics: profiles/r4/lava_split.txt)
+    if (e->fast_full) nw = 2;
     while (nw > 1 && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > 53 * 1024) nw--;
     // DynamicObstacles in the loop: the dynamics wave + two encode waves over ONE copy of the grids (roll_layout; 31 KB at 16 x 16).  The level's
     // step is its placement loop, so the encode waves idle most of the time: three waves of ~150 VGPRs leave room for four workgroups per CU.

@@ -402,17 +402,17 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int sw = (share && P.share < 16) ? (int)(((uint32_t)wg >> (P.share - 1)) & (uint32_t)(NW - 1)) : 0;
   // split (fused launches with three or four waves, round 4): wave 0 runs the DYNAMICS of every step once and logs them, waves 1.. keep
   // their own grids current from the log and produce the observations, step j by encode wave j mod (NW - 1) -- see the loops below
-  const bool split_mode = !FULL && !share && P.split_mode != 0;
+  const bool split_mode = !share && P.split_mode != 0;              // (FullyObs: only ever the staged-codes split below -- the host sets nothing else)
   // Which wave is the dynamics wave rotates with the workgroup index (P.split_mode - 1 = the shift): a workgroup's wave i lands on SIMD i,
   // so with wave 0 everywhere one SIMD of a CU would carry the dynamics waves of all its workgroups -- the longest instruction stream of
   // the four -- and pace the launch (measured: profiles/r4/split_rotation.txt)
   const int dw = split_mode ? (int)(((uint32_t)wg >> (P.split_mode - 1)) % (uint32_t)NW) : 0;
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
   // GG_DYNOBS splits differently (see the loops below): ONE copy of the grids, the dynamics wave's, which also stages every step's codes
-  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE) && split_mode;
+  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
-  uint8_t* scodes = smem + P.off_T + (split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
+  uint8_t* scodes = smem + P.off_T + (dsplit ? 0 : split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
   const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
   uint8_t* sshadow = smem + P.off_shadow;
   uint64_t* sspr = (uint64_t*)(smem + P.off_spr) + lane * 2;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
   }
   __syncthreads();
-  if constexpr (FULL) { if (j_end > 0 && active) image_stream_build(sgrid + lane * GS, scodes + lane * cells, W, H); MG_LDS_SYNC(); }
+  if constexpr (FULL) { if ((dsplit ? wave == dw : j_end > 0) && active) image_stream_build(sgrid + lane * GS, scodes + lane * cells, W, H); MG_LDS_SYNC(); }
 
   a = agent_unpack(rec);
   const uint32_t h_in = S.h;
@@ -702,14 +702,14 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // (codes / parts: the code staging to use and which half to run -- 1 = stage the codes, 2 = encode them; the split of GG_DYNOBS runs the
   // halves in different waves, everything else passes its own staging and 3)
   auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code, uint8_t* codes_arg, int parts) {
-    uint8_t* const codes = FULL ? scodes : codes_arg;
+    uint8_t* const codes = (FULL && parts == 3) ? scodes : codes_arg;   // (FullyObs encodes its own image-order stream, or -- parts 2 -- a staged copy of one)
     if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)taken_code;
     MG_MARK("codes");
     uint32_t gt_pos = 0, gt_old = 0;
     if constexpr (FULL) {
       // the agent's own cell reads (10, 0, dir) in the observation: patched into the stream for the encode, restored after it
       gt_pos = (uint32_t)(lane * cells) + av.x * (uint32_t)H + av.y;
-      if (active) { gt_old = codes[gt_pos]; codes[gt_pos] = (uint8_t)(T_AGENT_MARK | (av.dir << 4)); }
+      if (active && parts == 3) { gt_old = codes[gt_pos]; codes[gt_pos] = (uint8_t)(T_AGENT_MARK | (av.dir << 4)); }
     } else if ((parts & 1) && !MG_EXPBIT(P, 4)) {
       View7 O;
       obs7_view(av, mygrid, W, H, see_through, O);
@@ -776,9 +776,39 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
     }
-    if constexpr (FULL) if (active && !share) codes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
+    if constexpr (FULL) if (active && !share && parts == 3) codes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
+  };
+
+  // FullyObs: the image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
+  // env at a time, lane k doing cell k (a lane re-imaging its own env cell by cell would make the whole wave walk W*H cells in
+  // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
+  auto full_follow = [&]() __attribute__((always_inline)) {
+    if constexpr (FULL) {
+      unsigned long long rm = __ballot(active && S.ev_reset != 0u);
+      if (rm) {
+        const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u), from_set1 = __ballot(active && S.ev_reset == 1u && S.ev_shadow == 1u);
+        MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
+        while (rm) {
+          const int b = __ffsll((long long)rm) - 1;
+          rm &= rm - 1ull;
+          const uint8_t* sgt = smem + P.off_shadow_gt + (int)((from_set1 >> b) & 1ull) * P.codes_stride + b * cells;
+          const uint8_t* gb = sgrid + b * GS;
+          uint8_t* gt = scodes + b * cells;
+          if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }
+          else for (int k = lane; k < cells; k += 64) {
+            const uint32_t x = ((uint32_t)k * P.h_magic) >> 16, y = (uint32_t)k - x * (uint32_t)H;      // k = x * H + y
+            gt[k] = gb[y * (uint32_t)W + x];
+          }
+        }
+        MG_LDS_SYNC();
+      }
+      if (active && S.ev_dirty_idx >= 0) {
+        const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
+        scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
+      }
+    }
   };
 
   if (!split_mode) {
@@ -787,33 +817,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
       StepOut o;
       dynamics(j, o);
-      if constexpr (FULL) {
-        // The image-order stream follows the grids.  A reset replaces a whole grid: the WAVE re-images the envs that took a spare, one
-        // env at a time, lane k doing cell k (a lane re-imaging its own env cell by cell would make the whole wave walk W*H cells in
-        // every step in which any env resets -- under a random policy on a lava level that is nearly every step).
-        unsigned long long rm = __ballot(active && S.ev_reset != 0u);
-        if (rm) {
-          const unsigned long long from_shadow = __ballot(active && S.ev_reset == 1u), from_set1 = __ballot(active && S.ev_reset == 1u && S.ev_shadow == 1u);
-          MG_LDS_SYNC();                                             // the lanes' grid writes of this step are done
-          while (rm) {
-            const int b = __ffsll((long long)rm) - 1;
-            rm &= rm - 1ull;
-            const uint8_t* sgt = smem + P.off_shadow_gt + (int)((from_set1 >> b) & 1ull) * P.codes_stride + b * cells;
-            const uint8_t* gb = sgrid + b * GS;
-            uint8_t* gt = scodes + b * cells;
-            if ((from_shadow >> b) & 1ull) { for (int k = lane; k < cells; k += 64) gt[k] = sgt[k]; }
-            else for (int k = lane; k < cells; k += 64) {
-              const uint32_t x = ((uint32_t)k * P.h_magic) >> 16, y = (uint32_t)k - x * (uint32_t)H;      // k = x * H + y
-              gt[k] = gb[y * (uint32_t)W + x];
-            }
-          }
-          MG_LDS_SYNC();
-        }
-        if (active && S.ev_dirty_idx >= 0) {
-          const uint32_t y = ((uint32_t)S.ev_dirty_idx * P.w_magic) >> 16, x = (uint32_t)S.ev_dirty_idx - y * (uint32_t)W;
-          scodes[lane * cells + x * H + y] = (uint8_t)S.ev_dirty_code;
-        }
-      }
+      full_follow();
       if (!emit) continue;
       const int slot_out = slot_of(j);
       store_scalars(slot_out, o);
@@ -821,7 +825,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (o.show_taken) av.carry = 0;
       observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, scodes, 3);
     }
-  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE) {
+  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) {
     // ---- DynamicObstacles and the sentence levels, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
     // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
     // j by encode wave j mod (NW - 1).  The level's step is its placement loop (a 128-bit multiply per try, ~16 tries deep for the unluckiest
@@ -831,9 +835,11 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // The sentence levels (round 4, one encode wave): their step is ~5 000 dependent instructions in ONE wave per workgroup (the verifier's record
     // is that wave's), four workgroups per CU -- one wave per SIMD at ~10 cycles per instruction.  Handing the output-space encode (a quarter of
     // the instructions) to a second wave shortens the chain and puts a second wave on every SIMD without a second copy of the 22 x 22 grids.
+    // FullyObs (round 4): what is staged is a COPY of the dynamics wave's image-order stream with the agents' cells patched in (64 x W*H bytes,
+    // a handful of 16-byte LDS moves per lane) -- the time split's second wave replayed every step's dynamics, resets and re-imaging included.
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
     lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps staged, [1 + k] = steps encode wave k has written out
-    uint8_t* ring = smem + P.off_T;
+    uint8_t* ring = smem + P.off_T + (FULL ? P.codes_stride : 0);              // (FullyObs: behind the dynamics wave's own stream)
     const int NE = NW - 1;
     if (wave == dw) {
       __builtin_amdgcn_s_setprio(MG_DPRIO);
@@ -847,6 +853,19 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           if (++kq == NE) { kq = 0; mq++; }
         }
         asm volatile("" ::: "memory");
+        if constexpr (FULL) {
+          full_follow();
+          // the stream as this step's observation shows it: the agent's own cell reads (10, 0, dir) (wrappers.py:422-424)
+          const uint32_t gt_pos = (uint32_t)(lane * cells) + a.x * (uint32_t)H + a.y;
+          uint32_t gt_old = 0;
+          if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (a.dir << 4)); }
+          MG_LDS_SYNC();
+          const uint4* src = (const uint4*)scodes;
+          uint4* dst = (uint4*)(ring + (j & (P.dring - 1)) * P.codes_stride);
+          for (int c = lane; c < 4 * cells; c += 64) dst[c] = src[c];            // 64 * cells bytes = 4 * cells 16-byte pieces
+          MG_LDS_SYNC();
+          if (active) scodes[gt_pos] = (uint8_t)gt_old;
+        } else
         observe(0, a, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 1);
         // (DS operations of one wave execute in order: the counter cannot become visible before the codes)
         asm volatile("" ::: "memory");

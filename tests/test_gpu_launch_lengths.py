@@ -35,26 +35,31 @@ def _final_state(env, orc):
     assert (env.get_rng_state() == orc.get_rng()).all()
 
 
-@pytest.mark.parametrize("env_id,n,max_steps", [("MiniGrid-Empty-8x8-v0", 65536, None),       # the headline batch as bench.py creates it
-                                                 ("MiniGrid-Empty-8x8-v0", 65536, 11),         # ... and with resets inside every launch
-                                                 ("MiniGrid-DoorKey-8x8-v0", 2085, 9), ("BabyAI-GoToRedBall-v0", 2085, 6),
-                                                 ("MiniGrid-LavaCrossingS9N1-v0", 2085, None)])
-def test_every_launch_length_equals_the_oracle(env_id, n, max_steps):
+@pytest.mark.parametrize("env_id,n,max_steps,full", [("MiniGrid-Empty-8x8-v0", 65536, None, False),       # the headline batch as bench.py creates it
+                                                      ("MiniGrid-Empty-8x8-v0", 65536, 11, False),         # ... and with resets inside every launch
+                                                      ("MiniGrid-DoorKey-8x8-v0", 2085, 9, False), ("BabyAI-GoToRedBall-v0", 2085, 6, False),
+                                                      ("MiniGrid-LavaCrossingS9N1-v0", 2085, None, False),
+                                                      # FullyObs (k_roll7<., true>: the dynamics wave + encode waves over staged copies of its image-order
+                                                      # stream since round 4): resets in nearly every step (lava), a door opened / a key carried, 11 x 11
+                                                      ("MiniGrid-LavaCrossingS9N1-v0", 2085, None, True), ("MiniGrid-DoorKey-8x8-v0", 2085, 9, True),
+                                                      ("BabyAI-GoToRedBall-v0", 2085, 6, True), ("MiniGrid-LavaCrossingS11N5-v0", 2085, 30, True),
+                                                      ("MiniGrid-LavaCrossingS9N1-v0", 131072, None, True)])
+def test_every_launch_length_equals_the_oracle(env_id, n, max_steps, full):
     import minigrid_amd as mg
     kw = {} if max_steps is None else {"max_steps": max_steps}
-    env = mg.make_vec(env_id, n, **kw)                       # default trajectory ring / spare ring, like bench.py
+    env = mg.make_vec(env_id, n, obs_mode="full" if full else "partial", **kw)      # default trajectory ring / spare ring, like bench.py
     assert env.max_fused_steps == 32
-    orc = ParOracle(env_id, n, False, **kw)
+    orc = ParOracle(env_id, n, full, **kw)
     obs, _ = env.reset(seed=0)
     assert (obs["image"] == orc.reset(0)[0]).all()
     seed, t, fin = 2, 0, 0
     # the driver's run: one 5-step warm-up launch, one 20-step timed launch (bench.py --steps 20 --warmup 5)
-    for T in [5, 20] + LENGTHS + LENGTHS[::-1]:
+    for T in ([5, 20] + LENGTHS + LENGTHS[::-1] if n < 100000 else [5, 20, 32, 32, 7, 32]):
         env.rollout(T, action_seed=seed, fused=True)
         t, f = _check_launch(env, orc, seed, t, T, (env_id, n, "T", T, "t", t))
         fin += f
     if max_steps is not None or "Lava" in env_id:
-        assert fin > n, "episodes should have ended inside the launches"
+        assert fin > (n if n < 100000 else n // 2), "episodes should have ended inside the launches"
     _final_state(env, orc)
     assert env.counters()["env_steps"] == n * t
     env.close(); orc.close()
