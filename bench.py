@@ -45,6 +45,11 @@ WORKLOADS = {
     # step() itself draws (the obstacles move on the env's stream): live generation + k_move_obstacles + k_step per step
     "dynobs16x16": ("MiniGrid-Dynamic-Obstacles-16x16-v0", 65536, "partial"),
     "dynobs8x8": ("MiniGrid-Dynamic-Obstacles-8x8-v0", 65536, "partial"),
+    # levels whose spare episodes come from the wavefront-per-episode generator (k_refill): multi-room MiniGrid / BabyAI
+    "keycorridor": ("MiniGrid-KeyCorridorS3R3-v0", 131072, "partial"),
+    "multiroom": ("MiniGrid-MultiRoom-N6-v0", 65536, "partial"),
+    "babyai_goto": ("BabyAI-GoTo-v0", 131072, "partial"),
+    "unlockpickup": ("MiniGrid-UnlockPickup-v0", 131072, "partial"),
     "dynobs6x6": ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 65536, "partial"),
     # the sentence levels (instruction trees; the verifier runs inside the fused step loop since round 3)
     "bosslevel": ("BabyAI-BossLevel-v0", 131072, "partial"),

@@ -217,6 +217,13 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   A.epoch = epoch;
   A.cap_words = e->sentence ? 4864 : 1024;    // a pass that runs out of buffered draws restarts from its checkpoint / doubles
   A.wps = std::max(1, e->epw / 4);            // a GoToRedBall batch files ~EPW/7 requests per segment (Poisson: some segments twice that)
+  // The generator stream outranks the step stream, and every generating wavefront is a workgroup of its own: on the big-grid levels -- long episodes,
+  // few requests per segment, a step kernel that needs every SIMD -- sixteen of them per segment mostly start, find nothing to do and still
+  // delay the step kernel's workgroups.  Measured (profiles/r4/bosslevel_generator2.txt, refill_wps_other_levels.txt): BossLevel x 131 072 50.0 us
+  // per step with 16, 33.4 with 2 (28.7 with the deeper ring below); BabyAI-GoTo x 131 072 122.8 with 16, 76.1 with 4; MultiRoom-N6 equal;
+  // KeyCorridorS3R3 (7 x 7 cells, short episodes: it needs the generator's throughput) 47.6 with 16, 52.5 with 4 -- hence by grid size.
+  if (e->sentence) A.wps = 2;
+  else if (e->cells > 256) A.wps = 4;
   if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
   const int gg = gen_group_of_kind(e->cfg.env_kind);
@@ -1070,7 +1077,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     if (!e->static_gen && !e->live_gen) {
       // (the sentence levels: 64 since their verifier runs inside the fused step loop -- with 16 a refill of ~0.6 ms, the length of its
       // longest LevelGen chain, was due every 8 steps and bounded BossLevel at 76 us per step; 64: 38 us, profiles/r3/bosslevel_ring.txt)
-      R = cfg->spare_ring > 0 ? cfg->spare_ring : (gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID || e->sentence) ? 64 : 128;
+      // (round 4: 128 for the sentence levels as well -- with two generating wavefronts per request segment a refill lasts longer and is due half
+      // as often: BossLevel x 131 072 33.4 -> 28.7 us per step, profiles/r4/bosslevel_generator2.txt)
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : (gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID) ? 64 : 128;
       // k_refill_lane (one lane per episode, round 4) does a fifth of k_refill's work per episode but a refill LASTS longer -- a wave runs as
       // long as its unluckiest lane (GoToRedBall: 200-290 us) -- so its levels with many resets take the deepest ring: a refill is then due
       // every 128 steps, not every 32 (GoToRedBall x 32 768: 6.8 us per step with R = 64, 3.9 with 128, 2.9 with 256: profiles/r4/lane_refill_ring.txt)
