@@ -1149,6 +1149,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // starves the refill until the launch drains: measured 161 us per LavaCrossing refill at equal priority)
     int lo = 0, hi = 0;
     TRY_OR_FREE(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    // (MG_GEN_PRIO=0: the generator stream at the step stream's priority -- A/B)
+    { const char* s = getenv("MG_GEN_PRIO"); if (s && atoi(s) == 0) hi = 0; }
     TRY_OR_FREE(hipStreamCreateWithPriority(&e->gen_stream, hipStreamNonBlocking, hi));
   }
   TRY_OR_FREE(hipEventCreate(&e->ev0));
