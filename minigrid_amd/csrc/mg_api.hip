@@ -1079,7 +1079,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       // longest LevelGen chain, was due every 8 steps and bounded BossLevel at 76 us per step; 64: 38 us, profiles/r3/bosslevel_ring.txt)
       // (round 4: 128 for the sentence levels as well -- with two generating wavefronts per request segment a refill lasts longer and is due half
       // as often: BossLevel x 131 072 33.4 -> 28.7 us per step, profiles/r4/bosslevel_generator2.txt)
-      R = cfg->spare_ring > 0 ? cfg->spare_ring : (gen_group_of_kind(cfg->env_kind) == GG_ROOMGRID) ? 64 : 128;
+      // (and for the single-room RoomGrid levels that still draw a wavefront per episode -- Unlock, KeyCorridor, ... --: round 2 gave them 64 because
+      // their whole-map retries made long refills worse; with today's refill KeyCorridorS3R3 x 131 072 runs 48.1 us per step with 64, 40.8 with 128,
+      // profiles/r4/ring_other_levels.txt)
+      R = cfg->spare_ring > 0 ? cfg->spare_ring : 128;
       // k_refill_lane (one lane per episode, round 4) does a fifth of k_refill's work per episode but a refill LASTS longer -- a wave runs as
       // long as its unluckiest lane (GoToRedBall: 200-290 us) -- so its levels with many resets take the deepest ring: a refill is then due
       // every 128 steps, not every 32 (GoToRedBall x 32 768: 6.8 us per step with R = 64, 3.9 with 128, 2.9 with 256: profiles/r4/lane_refill_ring.txt)
