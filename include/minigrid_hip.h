@@ -348,6 +348,13 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
  * in/out (byte i = cell index y * W + x of obstacle i, list order).  mode[i]: 0 = nothing, 1 = the obstacle moves of one step(), 2 = reset()
  * (agent_start = (sx, sy, sdir), sx < 0: place_agent).  flags[i]: bit 0 a placement failed, bit 1 the grid changed, bit 2 not_clear.
  * philox: 0 = numpy PCG64 streams, 1 = Philox streams, 2 = PCG64 with every try taken through the rare-case (redo) path of the draw code. */
+/* RoomGridLevel.step's second half for the levels whose mission is an instruction tree (envs/babyai/core/roomgrid_level.py:87-104,
+ * verifier.py:228-571: update_objs_poss, ActionInstr.verify incl. use_done_actions, And / Before / After, object identity through pickup / drop /
+ * Box.toggle) as the step kernels run it per lane (minigrid_amd/csrc/mg_verify.h), on the host, for n independent cases: grid (n, W, H, 3) u8 and
+ * agent (n, 8) i32 = the state AFTER the action (state exchange format), actions (n) u8, records (n, 40) u64 in / out (the instruction record:
+ * minigrid_amd/csrc/mg_device.h); status (n) i32 = 0 continue | 1 success | 2 failure, max_steps (n) i32, errbits (n) u32 (8 = tracking error). */
+MG_API int mg_selftest_verify(int32_t width, int32_t height, int32_t n, int32_t done_actions, const uint8_t* grid, const int32_t* agent,
+                              const uint8_t* actions, uint64_t* records, int32_t* status, int32_t* max_steps, uint32_t* errbits);
 MG_API int mg_selftest_dynobs(int32_t width, int32_t height, int32_t n_obstacles, int32_t sx, int32_t sy, int32_t sdir, int32_t philox, int32_t n,
                               const uint8_t* mode, uint8_t* grid, int32_t* agent, uint64_t* rng, uint64_t* obst, uint8_t* flags);
 

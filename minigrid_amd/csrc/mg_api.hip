@@ -1863,6 +1863,29 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
   return MG_OK;
 }
 
+// verify_action (mg_verify.h: RoomGridLevel.step's instrs.verify + object identity, as k_roll7<GG_SENTENCE> and k_verify run it per lane) on the host,
+// for n independent cases: grid (n, W, H, 3) u8 and agent (n, 8) i32 in the state exchange format (the state AFTER the action), actions (n) u8,
+// records (n, INSTR_WORDS) u64 in / out; out: status (n) i32 (0 continue, 1 success, 2 failure), max_steps (n) i32, errbits (n) u32
+int mg_selftest_verify(int32_t W, int32_t H, int32_t n, int32_t done_actions, const uint8_t* grid, const int32_t* agent, const uint8_t* actions,
+                       uint64_t* records, int32_t* status, int32_t* max_steps, uint32_t* errbits) {
+  if (W < 3 || H < 3 || W > 25 || H > 25 || n < 0 || !grid || !agent || !actions || !records || !status || !max_steps || !errbits) return MG_ERR_INVALID;
+  const int cells = W * H;
+  std::vector<uint8_t> g((size_t)cells + 16);
+  for (int i = 0; i < n; i++) {
+    const uint8_t* t3 = grid + (size_t)i * cells * 3;
+    for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) { const uint8_t* t = t3 + ((size_t)x * H + y) * 3; g[y * W + x] = (uint8_t)cell_from_triple(t[0], t[1], t[2]); }
+    const int32_t* o = agent + (size_t)i * 8;
+    Agent a = agent_unpack(0ull);
+    a.x = (uint32_t)o[0]; a.y = (uint32_t)o[1]; a.dir = (uint32_t)o[2] & 3u;
+    a.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
+    if (a.carry == CELL_EMPTY) a.carry = 0;
+    uint32_t ms = 0, err = 0;
+    status[i] = (int32_t)verify_action(records + (size_t)i * INSTR_WORDS, g.data(), W, H, a, (uint32_t)actions[i], ms, err, done_actions != 0);
+    max_steps[i] = (int32_t)ms; errbits[i] = err;
+  }
+  return MG_OK;
+}
+
 // out = [perm_b32 | udot4 | brev32 | expand4 | vis_row_carry (m | up << 8) | MG_BYTE_X4 of the four bytes] x n of (a, b, c); on_device: by k_selftest_prims
 int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device) {
   if (n < 1 || !a || !b || !c || !out) return MG_ERR_INVALID;

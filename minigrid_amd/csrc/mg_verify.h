@@ -2,6 +2,8 @@
 // instrs.verify(action) over the instruction record (mg_device.h INSTR_WORDS), and -- max_steps is per episode there (:71-85) -- the
 // truncation limit and the reward.  One lane per env on the env's instruction record `I` (global memory) and its grid `g` (wherever
 // it lives).  Used by k_verify (after a k_step launch; mg_kernels_aux.h) and inside the step loop of k_roll7<GG_SENTENCE> (mg_roll.h).
+// Host-callable (MG_HD): mg_selftest_verify runs it on the CPU against a literal restatement of ActionInstr / And / Before / After over
+// randomly built records and states (tests/test_verifier_cpu.py).
 #pragma once
 #include "mg_step.h"
 
@@ -23,7 +25,7 @@ namespace mg {
 // The position table (16 words) stays in memory: one scan, one or two writes.
 struct InstrWords {
   uint64_t hd, leaf[4], set[8], stale[8];
-  MG_D void load(const uint64_t* I) {
+  MG_HD void load(const uint64_t* I) {
     hd = I[0];
 #pragma unroll
     for (int k = 0; k < 4; k++) leaf[k] = I[IW_LEAF + k];
@@ -39,9 +41,9 @@ struct InstrRef {
   int fidx; bool inb;                // the cell in front of the agent after the action
   int fid;                           // id of the object in that cell after this step's bookkeeping, -1 = none tracked
   uint32_t errbits;
-  MG_D uint16_t* pos() const { return (uint16_t*)(I + IW_POS); }
+  MG_HD uint16_t* pos() const { return (uint16_t*)(I + IW_POS); }
   // first id whose position is `cell` (ids 0 .. 62), two positions per word, from the top down so that the lowest index wins
-  MG_D int id_at(int cell) const {
+  MG_HD int id_at(int cell) const {
     const uint32_t* p32 = (const uint32_t*)(I + IW_POS);
     int id = -1;
 #pragma unroll 8
@@ -52,18 +54,18 @@ struct InstrRef {
     }
     return id;
   }
-  static MG_D bool in_stale(uint64_t s, int cell) {
+  static MG_HD bool in_stale(uint64_t s, int cell) {
     bool hit = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) hit |= (int)((s >> (16 * k)) & 0xFFFFull) == cell;
     return hit;
   }
-  MG_D bool adjacent(uint32_t p, uint32_t q) const {                     // Manhattan distance 1 between two cell indices
+  MG_HD bool adjacent(uint32_t p, uint32_t q) const {                     // Manhattan distance 1 between two cell indices
     const int py = (int)((p * w_magic) >> 16), px = (int)p - py * W, qy = (int)((q * w_magic) >> 16), qx = (int)q - qy * W;
     return abs(px - qx) + abs(py - qy) == 1;
   }
   // an object left `cell` without a refresh of obj_poss (picked up, or a box toggled away): every description tracking it keeps the cell
-  MG_D void left(InstrWords& R, int id, int cell) {
+  MG_HD void left(InstrWords& R, int id, int cell) {
 #pragma unroll
     for (int j = 0; j < 8; j++)
       if ((R.set[j] >> id) & 1ull) {
@@ -78,7 +80,7 @@ struct InstrRef {
   // verify_action of a leaf on the state after this step's bookkeeping, WITHOUT its side effect (the preCarrying update of the pick-up and
   // put-next instructions): verifier.py GoToInstr :309-316, OpenInstr :270-287, PickupInstr :343-363, PutNextInstr :406-431.
   // L = the leaf word, dset / fset = its description's and fixed description's objects, sd / sf = their stale cells.
-  MG_D uint32_t leaf_result(uint64_t L, uint64_t dset, uint64_t fset, uint64_t sd, uint64_t sf) const {
+  MG_HD uint32_t leaf_result(uint64_t L, uint64_t dset, uint64_t fset, uint64_t sd, uint64_t sf) const {
     const uint32_t verb = (uint32_t)L & 3u, strict = (uint32_t)(L >> 20) & 1u;
     const uint32_t pre = (uint32_t)(L >> 21) & 127u;                      // preCarrying as the leaf last saw it
     if (verb == V_GOTO) {
@@ -108,7 +110,7 @@ struct InstrRef {
     bool next = false;
     uint64_t fs = fset & 0x7FFFFFFFFFFFFFFFull;                           // the fixed description's objects (ids 0 .. 62)
     while (fs) {
-      const int m = __ffsll((long long)fs) - 1;
+      const int m = __builtin_ffsll((long long)fs) - 1;
       fs &= fs - 1ull;
       const uint32_t q = pos()[m];
       if (q < POS_GONE) next |= adjacent(cur, q);
@@ -122,7 +124,7 @@ struct InstrRef {
 // One step's verification of one env AFTER the action was applied (agent `a`, grid `g`); Wd = the record's hot words as loaded before the
 // step (InstrWords::load).  Returns the instruction's status (R_CONTINUE / R_SUCCESS / R_FAILURE) and the episode's max_steps; OR-s tracking
 // errors into errbits; stores the words it changed.
-MG_D uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out,
+MG_HD uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out,
                             uint32_t& errbits, bool done_actions = false) {
   InstrRef R;
   R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0;
@@ -240,7 +242,7 @@ MG_D uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int W
   return status;
 }
 // (the form that loads the words itself: k_verify, after a step kernel)
-MG_D uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
+MG_HD uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
                             bool done_actions = false) {
   InstrWords Wd;
   Wd.load(I);
