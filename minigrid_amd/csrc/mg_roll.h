@@ -21,6 +21,17 @@
 //    words), visibility applied as byte masks.  No per-cell select, no per-cell bit insert.
 // Every function of the observation pipeline is host-callable: mg_selftest_obs7 runs it on the CPU for the test-suite
 // (tests/test_abi_cpu.py compares it with the oracle over rollouts); the primitives' device forms are checked on the GPU.
+//
+// Round 4: how a workgroup's waves share a fused launch now depends on the level (the host picks; mg_api.hip launch_step):
+//  * LOG SPLIT (the 7x7 view of the ring levels, three or four waves): one DYNAMICS wave runs every step's action / transition / scalar outputs
+//    once and logs (pose, changed cell, reset) per env and step in an LDS ring; the ENCODE waves keep private grid copies current from the log
+//    and produce the observations, step j by encode wave j mod (NW - 1).  The time split's silent replays are gone.
+//  * STAGED SPLIT (DynamicObstacles, the sentence levels, FullyObs): ONE copy of the grids; the dynamics wave also stages what the encode needs
+//    -- the 49 codes per env (DynamicObstacles: its step is the per-lane placement loop of mg_dynobs.h; the sentence levels: the verifier of
+//    mg_verify.h runs in the same wave) or a copy of its image-order stream (FullyObs) -- into a small ring of stagings; the other wave(s) run
+//    only the output-space encode and the stores.
+//  * the TIME SPLIT above remains for two-wave configurations that ask for it (MG_ROLL_SPLIT=0 / MG_FULL_SPLIT=0 / MG_SENT_SPLIT=0: A/B), the
+//    SHARED ENCODE for one-step launches (Env.step: one wave steps, all waves of the workgroup encode that step).
 #pragma once
 #include "mg_step.h"
 #include "mg_verify.h"
@@ -408,7 +419,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // the four -- and pace the launch (measured: profiles/r4/split_rotation.txt)
   const int dw = split_mode ? (int)(((uint32_t)wg >> (P.split_mode - 1)) % (uint32_t)NW) : 0;
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
-  // GG_DYNOBS splits differently (see the loops below): ONE copy of the grids, the dynamics wave's, which also stages every step's codes
+  // DynamicObstacles, the sentence levels and FullyObs split differently (the staged split, see the loops below): ONE copy of the grids, the
+  // dynamics wave's, which also stages every step's codes (FullyObs: a copy of its image-order stream)
   const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
@@ -699,7 +711,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   };
   // gen_obs of the 64 envs as they stand in this wave's grids -> the observation of trajectory slot slot_out:
   // 49 codes per env (lane = env), then the encode in output space (lane = four cells = 12 bytes)
-  // (codes / parts: the code staging to use and which half to run -- 1 = stage the codes, 2 = encode them; the split of GG_DYNOBS runs the
+  // (codes / parts: the code staging to use and which half to run -- 1 = stage the codes, 2 = encode them; the staged split runs the
   // halves in different waves, everything else passes its own staging and 3)
   auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code, uint8_t* codes_arg, int parts) {
     uint8_t* const codes = (FULL && parts == 3) ? scodes : codes_arg;   // (FullyObs encodes its own image-order stream, or -- parts 2 -- a staged copy of one)
