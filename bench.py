@@ -527,6 +527,10 @@ def main(argv=None):
                                   "HBM-bound: its obstacle moves and resets draw on the env's own stream inside the step loop (a numpy-exact PCG64 step per "
                                   "placement try, a wavefront waiting for its unluckiest lane) -- VALU issue-bound, DESIGN.md section 4"
                                   if args.workload.startswith("dynobs") else
+                                  "achieved = HBM bytes the launch really moves / its duration (HIP events, this run); this level's step is NOT "
+                                  "HBM-bound: its instruction-tree verifier (a long dependent chain per wavefront, one wave per SIMD at 22 x 22 "
+                                  "grids) and its wavefront-per-episode generator set the pace -- DESIGN.md section 4"
+                                  if args.workload in ("bosslevel", "babyai_goto", "keycorridor", "multiroom") else
                                   "achieved = HBM bytes the launch really moves / its duration (HIP events, this run); the bound this kernel "
                                   "runs against is the HBM WRITE stream")},
         }
