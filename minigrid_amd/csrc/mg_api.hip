@@ -886,6 +886,20 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
+// (mg_selftest_transition, below: one env, one step of env_transition<GG, 1> on the host)
+template <int GG>
+static void selftest_transition_one(const StepParams& P, uint8_t* g, Agent& a, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc, uint32_t& err) {
+  LaneCtx C;
+  C.e = 0; C.el = 0; C.sub = 0; C.active = true; C.lead = true; C.reset_enabled = false; C.maskok = true; C.goto_rule = false;
+  C.mygrid = g; C.myshadow = nullptr; C.sspr = nullptr;
+  EnvRegs S;
+  S.a = a; S.targets = 0; S.cur = 0; S.h = 0; S.shadow_left = 0; S.ev_shadow = 0; S.rec_dirty = false; S.aux_dirty = false; S.wb_all = false; S.errbits = 0;
+  S.ev_dirty_idx = -1; S.ev_dirty_code = 0; S.ev_reset = 0;
+  reward = 0.0; term = 0; trunc = 0;
+  env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
+  a = S.a; err = S.errbits;
+}
+
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
@@ -1858,6 +1872,53 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
       const uint32_t tr = cell_triple((uint32_t)g[y * W + x]);
       uint8_t* t = t3 + ((size_t)x * H + y) * 3;
       t[0] = (uint8_t)tr; t[1] = (uint8_t)(tr >> 8); t[2] = (uint8_t)(tr >> 16);
+    }
+  }
+  return MG_OK;
+}
+
+// env_transition (mg_step.h: MiniGridEnv.step + the level's own rule, as the step kernels run it per lane) on the host: ONE step of n independent envs
+// without autoreset, in the state exchange format -- grid (n, W, H, 3) u8 in / out, agent (n, 8) i32 in / out (x, y, dir, carried type, carried
+// colour, step count, -, mission id), actions (n) u8; out: reward (n) f64, terminated / truncated (n) u8, errbits (n) u32.  group / rule /
+// rule_cell / rule_div as mg_create derives them from the level (levels whose rule needs the auxiliary word -- the GoTo family, PutNear, PutNext,
+// OpenDoor -- and the sentence levels are not served).
+int mg_selftest_transition(int32_t group, int32_t rule, int32_t rule_cell, int32_t rule_div, int32_t W, int32_t H, int32_t max_steps, int32_t no_death_mask,
+                           double death_cost, int32_t n, uint8_t* grid, int32_t* agent, const uint8_t* actions, double* reward, uint8_t* term, uint8_t* trunc,
+                           uint32_t* errbits) {
+  if (W < 3 || H < 3 || W > 25 || H > 25 || n < 0 || !grid || !agent || !actions || !reward || !term || !trunc || !errbits) return MG_ERR_INVALID;
+  if (group != GG_NONE && group != GG_LIGHT && group != GG_ROOMGRID && group != GG_ROOMS) return MG_ERR_INVALID;
+  if (rule == RULE_GOTO || rule == RULE_GOTOOBJ || rule == RULE_PUTNEAR || rule == RULE_GOTO_BIG || rule == RULE_PUTNEXT || rule == RULE_OPENDOOR || rule == RULE_SENTENCE ||
+      rule == RULE_DYNOBS) return MG_ERR_INVALID;
+  const int cells = W * H, CS = (cells + 15) & ~15;
+  StepParams P;
+  memset(&P, 0, sizeof(P));
+  P.N = 1; P.W = W; P.H = H; P.CS = CS; P.GS = CS + 4; P.cells = cells; P.max_steps = max_steps; P.rule = rule; P.rule_cell = rule_cell; P.rule_div = rule_div;
+  P.phase = PHASE_STEP; P.T = 2;            // (T = 2: a changed cell is written to the staged grid only, like inside a fused launch)
+  P.no_death_mask = no_death_mask; P.death_cost = death_cost;
+  std::vector<uint8_t> g((size_t)CS + 16);
+  for (int i = 0; i < n; i++) {
+    uint8_t* t3 = grid + (size_t)i * cells * 3;
+    for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) { const uint8_t* t = t3 + ((size_t)x * H + y) * 3; g[y * W + x] = (uint8_t)cell_from_triple(t[0], t[1], t[2]); }
+    int32_t* o = agent + (size_t)i * 8;
+    Agent a = agent_unpack(0ull);
+    a.x = (uint32_t)o[0]; a.y = (uint32_t)o[1]; a.dir = (uint32_t)o[2] & 3u;
+    a.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
+    if (a.carry == CELL_EMPTY) a.carry = 0;
+    a.step = (uint32_t)o[5]; a.mission = (uint32_t)o[7];
+    uint32_t act = actions[i], tm = 0, tr = 0, err = 0;
+    if (rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;          // MemoryEnv.step (memory.py:151-153; the kernels remap before the transition too)
+    double rw = 0.0;
+    if (group == GG_NONE) selftest_transition_one<GG_NONE>(P, g.data(), a, act, rw, tm, tr, err);
+    else if (group == GG_LIGHT) selftest_transition_one<GG_LIGHT>(P, g.data(), a, act, rw, tm, tr, err);
+    else if (group == GG_ROOMGRID) selftest_transition_one<GG_ROOMGRID>(P, g.data(), a, act, rw, tm, tr, err);
+    else selftest_transition_one<GG_ROOMS>(P, g.data(), a, act, rw, tm, tr, err);
+    reward[i] = rw; term[i] = (uint8_t)tm; trunc[i] = (uint8_t)tr; errbits[i] = err;
+    const uint32_t ct = a.carry ? cell_triple(a.carry) : 0u;
+    o[0] = (int32_t)a.x; o[1] = (int32_t)a.y; o[2] = (int32_t)a.dir; o[3] = (int32_t)(ct & 0xFFu); o[4] = (int32_t)((ct >> 8) & 0xFFu); o[5] = (int32_t)a.step;
+    for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {
+      const uint32_t tr3 = cell_triple((uint32_t)g[y * W + x]);
+      uint8_t* t = t3 + ((size_t)x * H + y) * 3;
+      t[0] = (uint8_t)tr3; t[1] = (uint8_t)(tr3 >> 8); t[2] = (uint8_t)(tr3 >> 16);
     }
   }
   return MG_OK;

@@ -94,10 +94,26 @@ struct StepParams {
 
 // _reward() = 1 - 0.9 * (step_count / max_steps), three separately rounded f64 ops (minigrid_env.py:240-245).
 // Normally read from the host-built LUT; this exact device form covers step_count > max_steps (autoreset disabled).
-MG_D double reward_exact(uint32_t step, int max_steps) {
+// (host form, for mg_selftest_transition: the same three roundings -- the library is built with -ffp-contract=off, the volatiles keep the compiler
+// from re-associating)
+MG_HD double reward_exact(uint32_t step, int max_steps) {
+#if defined(__HIP_DEVICE_COMPILE__)
   double q = __ddiv_rn((double)step, (double)max_steps);
   double p = __dmul_rn(0.9, q);
   return __dsub_rn(1.0, p);
+#else
+  volatile double q = (double)step / (double)max_steps;
+  volatile double p = 0.9 * q;
+  return 1.0 - p;
+#endif
+}
+MG_HD double dadd_rn(double a, double b) {          // one IEEE-rounded addition
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dadd_rn(a, b);
+#else
+  volatile double r = a + b;
+  return r;
+#endif
 }
 
 // Uniform-random policy on the device: Philox4x32-10 keyed by action_seed, counter = (global env index, t / 4); the
@@ -333,7 +349,7 @@ MG_D void obs_full(const StepParams& P, const Agent& a, const uint8_t* mygrid, c
 // LDS -> LDS copy of n dwords per lane, eight at a time: all eight reads are issued before the first write.  (Written as d[k] = s[k] the
 // compiler must assume the two ranges overlap and waits for every read before the next write: one LDS round trip per dword -- 16 for an
 // 8x8 grid, 0.85 us per reset of a GoToRedBall wave, whose 64 envs end an episode in nearly every step: profiles/r4/gotoredball_attr2.txt.)
-MG_D void lds_copy_dwords(uint32_t* d, const uint32_t* s, int n) {
+MG_HD void lds_copy_dwords(uint32_t* d, const uint32_t* s, int n) {
   int k = 0;
   for (; k + 8 <= n; k += 8) {
     uint32_t t[8];
@@ -378,7 +394,7 @@ struct LaneCtx {          // the lane's view of its env: loop-invariant
 // `cur` = where the described objects are on the grid right now, kept up to date cell change by cell change, so that the
 // refresh is `targets = cur` instead of a scan of the grid in every step in which some env of the wave drops.  The two
 // differ only while a described object is carried; FLAG_TARGETS_STALE carries that fact across launches.
-MG_D uint32_t goto_desc(const StepParams& P, uint32_t mission) {
+MG_HD uint32_t goto_desc(const StepParams& P, uint32_t mission) {
   // rule_div 0 = fixed cell code (rule_cell), 1 = red/blue ball by mission id, 2 = (colour, type) by mission id,
   // 3 = a door by colour (GoToDoor: id % 6), 4 = (colour, key | ball | box | door) (GoToObjDoor: id % 24).  A door description
   // is returned as the OPEN door's code and matches the door in any state (desc_match).  5 = ActionObjDoor: as 4; id / 48 = the verb.
@@ -389,12 +405,13 @@ MG_D uint32_t goto_desc(const StepParams& P, uint32_t mission) {
        : P.rule_div == 3 ? make_cell(T_DOOR, color_from_sorted(mission % 6u))
                          : make_cell((m24 & 3u) == 3u ? (uint32_t)T_DOOR : (uint32_t)T_KEY + (m24 & 3u), color_from_sorted(m24 >> 2));
 }
-MG_D bool desc_match(uint32_t c, uint32_t desc) {
+MG_HD bool desc_match(uint32_t c, uint32_t desc) {
   return c == desc || (cell_type(desc) == T_DOOR && cell_ref_type(c) == T_DOOR && cell_color(c) == cell_color(desc));
 }
 
+// Host-callable (MG_HD): mg_selftest_transition runs the step core on the CPU against the oracle (tests/test_transition_cpu.py).
 template <int GG, int LPE>
-MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc) {
+MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc) {
   const int W = P.W, H = P.H, CS = P.CS, cpe = P.CS >> 4;
   const size_t N = (size_t)P.N;
   const int e = C.e, sub = C.sub;
@@ -460,7 +477,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
       // is computed for every lane and selected by the action instead; the only memory access is the front cell.
       rec_dirty = true;
       const uint32_t pre_carry = a.carry;
-      a.step = min(a.step + 1u, 0xFFFFu);
+      a.step = a.step + 1u < 0xFFFFu ? a.step + 1u : 0xFFFFu;
       const int fx = (int)a.x + dir_dx(a.dir), fy = (int)a.y + dir_dy(a.dir);
       const bool inb = (unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H;
       if (!inb) errbits |= ERR_OOB;                                  // reference asserts (core/grid.py:74-78)
@@ -589,7 +606,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         if (act == A_PICKUP && a.carry != 0 && a.carry != move) term = 1;           // picked up the wrong object
         if (act == A_DROP && pre_carry != 0) {
           if (newF != F && inb && targets) {                                        // `grid.get(ox, oy) is preCarrying`: the drop happened
-            const int tidx = __ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
+            const int tidx = __builtin_ffsll((long long)targets) - 1, tx = tidx % W, ty = tidx / W;
             if (abs(fx - tx) <= 1 && abs(fy - ty) <= 1) success = true;
           }
           term = 1;
@@ -704,7 +721,7 @@ MG_D void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uint
         const bool going = act == A_FORWARD && F != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(F)) & 1);
         const uint32_t U = mygrid[(int)a.y * W + (int)a.x];
         const bool in_death = U != CELL_EMPTY && ((P.no_death_mask >> cell_ref_type(U)) & 1);
-        if (going || in_death) { term = 0; reward = __dadd_rn(reward, P.death_cost); }
+        if (going || in_death) { term = 0; reward = dadd_rn(reward, P.death_cost); }
       }
       if ((term | trunc) && P.autoreset_next_step) a.flags |= FLAG_RESET_PENDING;
       if (dirty_idx >= 0) {
