@@ -351,11 +351,13 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
 /* MiniGridEnv.step (minigrid_env.py:525-595) + the level's own step rule (envs/*.py, e.g. fetch.py:162-175, unlock.py:90-98) as the step kernels run
  * them per lane (minigrid_amd/csrc/mg_step.h env_transition), on the host: ONE step of n independent envs, no autoreset, state exchange format
  * (grid (n, W, H, 3) u8 and agent (n, 8) i32 in / out: x, y, dir, carried type, carried colour, step count, -, mission id).  group / rule / rule_cell /
- * rule_div = the kernel variant and level rule mg_create derives from the config (enum values in mg_step.h; the rules that keep an auxiliary word
- * per env -- the GoTo family, PutNear, PutNext, OpenDoor -- and the sentence levels are refused). */
+ * rule_div = the kernel variant and level rule mg_create derives from the config (enum values in mg_step.h).  aux: NULL, or -- the single-room BabyAI
+ * GoTo levels, grids of at most 64 cells -- (n, 2) u64 in / out: GoToInstr's tracked positions and where the described objects are now (bit
+ * y * W + x).  The other rules that keep an auxiliary word per env (GoToObject, PutNear, the multi-room GoTo / PutNext / OpenDoor levels) and the
+ * sentence levels are refused. */
 MG_API int mg_selftest_transition(int32_t group, int32_t rule, int32_t rule_cell, int32_t rule_div, int32_t width, int32_t height, int32_t max_steps,
                                   int32_t no_death_mask, double death_cost, int32_t n, uint8_t* grid, int32_t* agent, const uint8_t* actions,
-                                  double* reward, uint8_t* terminated, uint8_t* truncated, uint32_t* errbits);
+                                  double* reward, uint8_t* terminated, uint8_t* truncated, uint32_t* errbits, uint64_t* aux);
 /* RoomGridLevel.step's second half for the levels whose mission is an instruction tree (envs/babyai/core/roomgrid_level.py:87-104,
  * verifier.py:228-571: update_objs_poss, ActionInstr.verify incl. use_done_actions, And / Before / After, object identity through pickup / drop /
  * Box.toggle) as the step kernels run it per lane (minigrid_amd/csrc/mg_verify.h), on the host, for n independent cases: grid (n, W, H, 3) u8 and

@@ -888,16 +888,18 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 // ---- C ABI ------------------------------------------------------------------------------------------------
 // (mg_selftest_transition, below: one env, one step of env_transition<GG, 1> on the host)
 template <int GG>
-static void selftest_transition_one(const StepParams& P, uint8_t* g, Agent& a, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc, uint32_t& err) {
+static void selftest_transition_one(const StepParams& P, uint8_t* g, Agent& a, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc, uint32_t& err,
+                                    uint64_t* aux) {
   LaneCtx C;
-  C.e = 0; C.el = 0; C.sub = 0; C.active = true; C.lead = true; C.reset_enabled = false; C.maskok = true; C.goto_rule = false;
+  C.e = 0; C.el = 0; C.sub = 0; C.active = true; C.lead = true; C.reset_enabled = false; C.maskok = true; C.goto_rule = aux != nullptr;
   C.mygrid = g; C.myshadow = nullptr; C.sspr = nullptr;
   EnvRegs S;
-  S.a = a; S.targets = 0; S.cur = 0; S.h = 0; S.shadow_left = 0; S.ev_shadow = 0; S.rec_dirty = false; S.aux_dirty = false; S.wb_all = false; S.errbits = 0;
+  S.a = a; S.targets = aux ? aux[0] : 0ull; S.cur = aux ? aux[1] : 0ull; S.h = 0; S.shadow_left = 0; S.ev_shadow = 0; S.rec_dirty = false; S.aux_dirty = false; S.wb_all = false; S.errbits = 0;
   S.ev_dirty_idx = -1; S.ev_dirty_code = 0; S.ev_reset = 0;
   reward = 0.0; term = 0; trunc = 0;
   env_transition<GG, 1>(P, C, S, act, reward, term, trunc);
   a = S.a; err = S.errbits;
+  if (aux) { aux[0] = S.targets; aux[1] = S.cur; }
 }
 
 extern "C" {
@@ -1884,11 +1886,14 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
 // OpenDoor -- and the sentence levels are not served).
 int mg_selftest_transition(int32_t group, int32_t rule, int32_t rule_cell, int32_t rule_div, int32_t W, int32_t H, int32_t max_steps, int32_t no_death_mask,
                            double death_cost, int32_t n, uint8_t* grid, int32_t* agent, const uint8_t* actions, double* reward, uint8_t* term, uint8_t* trunc,
-                           uint32_t* errbits) {
+                           uint32_t* errbits, uint64_t* aux) {
   if (W < 3 || H < 3 || W > 25 || H > 25 || n < 0 || !grid || !agent || !actions || !reward || !term || !trunc || !errbits) return MG_ERR_INVALID;
   if (group != GG_NONE && group != GG_LIGHT && group != GG_ROOMGRID && group != GG_ROOMS) return MG_ERR_INVALID;
-  if (rule == RULE_GOTO || rule == RULE_GOTOOBJ || rule == RULE_PUTNEAR || rule == RULE_GOTO_BIG || rule == RULE_PUTNEXT || rule == RULE_OPENDOOR || rule == RULE_SENTENCE ||
+  // (the single-room GoTo levels: `aux` (n, 2) u64 in / out = GoToInstr's tracked positions and where the described objects are now, bit y * W + x)
+  if (rule == RULE_GOTO && (!aux || group != GG_ROOMGRID || W * H > 64)) return MG_ERR_INVALID;
+  if (rule == RULE_GOTOOBJ || rule == RULE_PUTNEAR || rule == RULE_GOTO_BIG || rule == RULE_PUTNEXT || rule == RULE_OPENDOOR || rule == RULE_SENTENCE ||
       rule == RULE_DYNOBS) return MG_ERR_INVALID;
+  if (rule != RULE_GOTO) aux = nullptr;
   const int cells = W * H, CS = (cells + 15) & ~15;
   StepParams P;
   memset(&P, 0, sizeof(P));
@@ -1908,10 +1913,11 @@ int mg_selftest_transition(int32_t group, int32_t rule, int32_t rule_cell, int32
     uint32_t act = actions[i], tm = 0, tr = 0, err = 0;
     if (rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;          // MemoryEnv.step (memory.py:151-153; the kernels remap before the transition too)
     double rw = 0.0;
-    if (group == GG_NONE) selftest_transition_one<GG_NONE>(P, g.data(), a, act, rw, tm, tr, err);
-    else if (group == GG_LIGHT) selftest_transition_one<GG_LIGHT>(P, g.data(), a, act, rw, tm, tr, err);
-    else if (group == GG_ROOMGRID) selftest_transition_one<GG_ROOMGRID>(P, g.data(), a, act, rw, tm, tr, err);
-    else selftest_transition_one<GG_ROOMS>(P, g.data(), a, act, rw, tm, tr, err);
+    uint64_t* ax = aux ? aux + (size_t)i * 2 : nullptr;
+    if (group == GG_NONE) selftest_transition_one<GG_NONE>(P, g.data(), a, act, rw, tm, tr, err, ax);
+    else if (group == GG_LIGHT) selftest_transition_one<GG_LIGHT>(P, g.data(), a, act, rw, tm, tr, err, ax);
+    else if (group == GG_ROOMGRID) selftest_transition_one<GG_ROOMGRID>(P, g.data(), a, act, rw, tm, tr, err, ax);
+    else selftest_transition_one<GG_ROOMS>(P, g.data(), a, act, rw, tm, tr, err, ax);
     reward[i] = rw; term[i] = (uint8_t)tm; trunc[i] = (uint8_t)tr; errbits[i] = err;
     const uint32_t ct = a.carry ? cell_triple(a.carry) : 0u;
     o[0] = (int32_t)a.x; o[1] = (int32_t)a.y; o[2] = (int32_t)a.dir; o[3] = (int32_t)(ct & 0xFFu); o[4] = (int32_t)((ct >> 8) & 0xFFu); o[5] = (int32_t)a.step;

@@ -2,7 +2,8 @@
 minigrid_env.py:525-595, as the round-4 straight-line form: every effect of every action computed for every lane and selected, one memory access --
 plus the level's own step rule) compiled for the host, one step at a time on the oracle's states, against the oracle's own step: grid, agent pose,
 carried object, step count, reward bytes, terminated, truncated.  The levels are the ones whose state the exchange format carries completely (no box
-contents) and whose rule needs no auxiliary word; group / rule / rule_cell / rule_div are what mg_create derives for them (mg_api.hip).  Episodes are
+contents) and whose rule needs no auxiliary word -- plus the single-room BabyAI GoTo levels (GoToRedBall is BASELINE.json's configs[4]), whose tracked
+positions the test builds at every reset and the kernel code keeps current; group / rule / rule_cell / rule_div are what mg_create derives for them (mg_api.hip).  Episodes are
 stepped PAST their end now and then (the reference allows it; rewards past max_steps), finished envs reset in batches.
 (On the GPU the same code runs inside k_roll7 / k_step against the same oracle and the reference's goldens.)"""
 import ctypes as C
@@ -31,12 +32,37 @@ LEVELS = {
     "BabyAI-OpenRedDoor-v0": (GG_ROOMS, RULE_OPENFRONT, 0, 0), "BabyAI-PickupDist-v0": (GG_ROOMS, RULE_PICKUPDESC, 0, 1),
 }
 POLICY = [0.15, 0.15, 0.35, 0.12, 0.05, 0.13, 0.05]
+RULE_GOTO = 1
+# the single-room BabyAI GoTo levels (goto.py; BabyAI-GoToRedBall = BASELINE.json configs[4]): GoToInstr succeeds in front of a TRACKED POSITION of a
+# described object (verifier.py:309-316; positions refreshed at reset and by drop actions only): the kernel keeps two bitboards per env
+GOTO_LEVELS = {"BabyAI-GoToRedBall-v0": (6, 0), "BabyAI-GoToRedBallGrey-v0": (6, 0), "BabyAI-GoToLocal-v0": (0, 2), "BabyAI-GoToObj-v0": (0, 2)}
+SORTED_COLOR_TO_IDX = [2, 1, 5, 3, 0, 4]          # blue green grey purple red yellow -> COLOR_TO_IDX
+
+
+def _described(grid, mission, rule_div):
+    """bit y * W + x of every cell holding an object the mission describes (per env)"""
+    n, Wd, Ht = grid.shape[:3]
+    out = np.zeros(n, np.uint64)
+    for i in range(n):
+        if rule_div == 0:
+            want = (6, 0)                                    # the red ball
+        else:
+            m18 = int(mission[i]) % 18
+            want = (5 + m18 % 3, SORTED_COLOR_TO_IDX[m18 // 3])
+        bits = 0
+        for x in range(Wd):
+            for y in range(Ht):
+                if (int(grid[i, x, y, 0]), int(grid[i, x, y, 1])) == want:
+                    bits |= 1 << (y * Wd + x)
+        out[i] = bits
+    return out
 
 
 def _run(env_id, n, T, no_death=(), death_cost=-1.0):
     from oracle import oracle as O
     L = B.load()
-    group, rule, rule_cell, rule_div = LEVELS[env_id]
+    goto = env_id in GOTO_LEVELS
+    group, rule, rule_cell, rule_div = (GG_ROOMGRID, RULE_GOTO) + GOTO_LEVELS[env_id] if goto else LEVELS[env_id]
     kw = dict(no_death_types=no_death, death_cost=death_cost) if no_death else {}
     s = O.spec(env_id)
     Wd, Ht, max_steps = s["width"], s["height"], min(s["max_steps"], 60)       # (short episodes: truncation and steps past it in every run)
@@ -48,12 +74,16 @@ def _run(env_id, n, T, no_death=(), death_cost=-1.0):
     rew = np.zeros(n, np.float64); term = np.zeros(n, np.uint8); trunc = np.zeros(n, np.uint8); err = np.zeros(n, np.uint32)
     seen = {"term": 0, "trunc": 0, "reward": 0, "carry": 0, "grid": 0}
     done = np.zeros(n, bool)
+    aux = np.zeros((n, 2), np.uint64)
+    if goto:
+        g0, a0 = orc.get_state()
+        aux[:, 0] = aux[:, 1] = _described(g0, a0[:, 7], rule_div)
     for t in range(T):
         g0, a0 = orc.get_state()
         grid, agent = g0.copy(), a0.copy()
         act = rng.choice(7, size=n, p=POLICY).astype(np.uint8)
         assert L.mg_selftest_transition(group, rule, rule_cell, rule_div, Wd, Ht, max_steps, mask, float(death_cost), n, p(grid), p(agent), p(act),
-                                        p(rew), p(term), p(trunc), p(err)) == 0
+                                        p(rew), p(term), p(trunc), p(err), p(aux) if goto else None) == 0
         _, orew, oterm, otrunc, _, _ = orc.step(act, autoreset=0)
         g1, a1 = orc.get_state()
         what = (env_id, t)
@@ -69,11 +99,16 @@ def _run(env_id, n, T, no_death=(), death_cost=-1.0):
         # (in between, finished episodes keep being stepped -- except GoToDoor, whose episode ends with a toggle: past its end the agent can walk
         # through the opened door in the outer wall and face the outside of the grid, where the reference asserts)
         if (t % 7 == 6 or "GoToDoor" in env_id) and done.any():
-            orc.reset(mask=done.astype(np.uint8)); done[:] = False
+            orc.reset(mask=done.astype(np.uint8))
+            if goto:                                         # reset(): the instruction's positions are taken afresh
+                g2, a2 = orc.get_state()
+                d2 = _described(g2, a2[:, 7], rule_div)
+                aux[done, 0] = d2[done]; aux[done, 1] = d2[done]
+            done[:] = False
     return seen
 
 
-@pytest.mark.parametrize("env_id", sorted(LEVELS))
+@pytest.mark.parametrize("env_id", sorted(LEVELS) + sorted(GOTO_LEVELS))
 def test_step_core_on_the_host_equals_the_oracle(env_id):
     seen = _run(env_id, 96, 260 if "Memory" in env_id or "Four" in env_id else 180)
     assert seen["term"] + seen["trunc"] > 0 and seen["grid"] + seen["carry"] >= 0, (env_id, seen)
