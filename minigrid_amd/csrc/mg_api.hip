@@ -149,17 +149,23 @@ static void build_reward_lut(int max_steps, double* out) {
   }
 }
 
-static GenParams gen_params(const mg_env* e) {
+// the generators' view of a level's configuration (also used by mg_selftest_generate, which has no handle)
+static GenParams gen_params_of(const mg_config& c) {
   GenParams g;
-  g.kind = e->cfg.env_kind; g.W = e->W; g.H = e->H;
-  g.start_x = e->cfg.agent_start_x; g.start_y = e->cfg.agent_start_y; g.start_dir = e->cfg.agent_start_dir;
-  g.num_crossings = e->cfg.num_crossings;
-  g.obstacle_cell = e->cfg.obstacle_type == (int)T_WALL ? (int)CELL_WALL_GREY : (int)CELL_LAVA;
-  g.num_dists = e->cfg.num_dists;
-  g.strip2_row = e->cfg.strip2_row;
-  g.room_size = e->cfg.room_size;
-  g.random_length = e->cfg.random_length;
-  g.max_steps = e->cfg.max_steps; g.instr_off = 0; g.scratch_off = 0;
+  g.kind = c.env_kind; g.W = c.width; g.H = c.height;
+  g.start_x = c.agent_start_x; g.start_y = c.agent_start_y; g.start_dir = c.agent_start_dir;
+  g.num_crossings = c.num_crossings;
+  g.obstacle_cell = c.obstacle_type == (int)T_WALL ? (int)CELL_WALL_GREY : (int)CELL_LAVA;
+  g.num_dists = c.num_dists;
+  g.strip2_row = c.strip2_row;
+  g.room_size = c.room_size;
+  g.random_length = c.random_length;
+  g.max_steps = c.max_steps; g.instr_off = 0; g.scratch_off = 0;
+  return g;
+}
+static GenParams gen_params(const mg_env* e) {
+  GenParams g = gen_params_of(e->cfg);
+  g.W = e->W; g.H = e->H;
   return g;
 }
 
@@ -1874,6 +1880,43 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
       const uint32_t tr = cell_triple((uint32_t)g[y * W + x]);
       uint8_t* t = t3 + ((size_t)x * H + y) * 3;
       t[0] = (uint8_t)tr; t[1] = (uint8_t)(tr >> 8); t[2] = (uint8_t)(tr >> 16);
+    }
+  }
+  return MG_OK;
+}
+
+// generate_episode_lane (mg_genlane.h: the reference's _gen_grid of the single-room levels -- Empty, DoorKey, Crossing, LavaGap, DistShift, FourRooms,
+// Fetch, the single-room BabyAI GoTo levels, GoToObject -- as k_refill_lane / k_generate_lane run it, one lane per episode on the env's numpy PCG64
+// stream) on the host: n envs seeded like reset(seed = seeds[i]), `episodes` consecutive episodes each (the stream carries on, like autoresets).
+// Out: grid (episodes, n, W, H, 3) u8 and agent (episodes, n, 8) i32 in the state exchange format (x, y, dir, 0, 0, 0, 0, mission id), aux
+// (episodes, n) u64 (GoTo levels: the tracked positions), rng (episodes, n, 5) u64 = the stream words AFTER each episode, failed (episodes, n) u8.
+int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
+                         uint64_t* rng_words, uint8_t* failed) {
+  if (!cfg || n < 0 || episodes < 1 || !seeds || !grid || !agent || !aux || !rng_words || !failed) return MG_ERR_INVALID;
+  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !lane_gen_kind(cfg->env_kind)) return MG_ERR_INVALID;
+  const GenParams gp = gen_params_of(*cfg);
+  const int W = gp.W, H = gp.H, cells = W * H, CS = (cells + 15) & ~15;
+  std::vector<uint8_t> buf((size_t)CS + 16);
+  for (int i = 0; i < n; i++) {
+    Pcg64Stream r;
+    r.seed(seeds[i]);
+    for (int ep = 0; ep < episodes; ep++) {
+      LaneGrid g;
+      g.p = buf.data(); g.W = W; g.H = H; g.lane = 0; g.nonempty = 0; g.walls = 0;
+      GenResult out;
+      out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
+      generate_episode_lane(r, g, gp, out);
+      const size_t k = (size_t)ep * (size_t)n + (size_t)i;
+      uint8_t* t3 = grid + k * cells * 3;
+      for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {
+        const uint32_t tr = cell_triple((uint32_t)buf[y * W + x]);
+        uint8_t* t = t3 + ((size_t)x * H + y) * 3;
+        t[0] = (uint8_t)tr; t[1] = (uint8_t)(tr >> 8); t[2] = (uint8_t)(tr >> 16);
+      }
+      int32_t* o = agent + k * 8;
+      o[0] = (int32_t)out.ax; o[1] = (int32_t)out.ay; o[2] = (int32_t)out.dir; o[3] = o[4] = o[5] = o[6] = 0; o[7] = (int32_t)out.mission;
+      aux[k] = out.aux; failed[k] = out.failed ? 1 : 0;
+      r.store(rng_words + k * 5, 1, 0);
     }
   }
   return MG_OK;

@@ -71,6 +71,7 @@ struct GridRef {
   }
 };
 
+// (Host-callable -- MG_HD -- like the generators templated on the grid type below: mg_selftest_generate runs them on the CPU against the oracle.)
 // The same grid for ONE LANE (k_refill_lane, mg_genlane.h: a lane draws a whole episode by itself, 64 episodes per wavefront): the lane's
 // private byte grid in LDS, coordinates per lane.  For grids of at most 64 cells it also keeps the board of non-empty cells up to date,
 // so that reach_masks (two calls per GoToRedBall attempt) visits the handful of objects instead of scanning every cell.
@@ -79,13 +80,13 @@ struct LaneGrid {
   uint8_t* p; int W, H; int lane;
   uint64_t nonempty;                 // bit y*W+x: the cell is not None (valid while W*H <= 64)
   uint64_t walls;                    // ... the outer wall ring clear_with_walls drew
-  MG_D uint32_t get(int x, int y) const { return (uint32_t)p[y * W + x]; }
-  MG_D void set(int x, int y, uint32_t c) {
+  MG_HD uint32_t get(int x, int y) const { return (uint32_t)p[y * W + x]; }
+  MG_HD void set(int x, int y, uint32_t c) {
     const int k = y * W + x;
     p[k] = (uint8_t)c;
     if (W * H <= 64) nonempty = c == CELL_EMPTY ? nonempty & ~(1ull << k) : nonempty | (1ull << k);
   }
-  MG_D void clear_with_walls() {
+  MG_HD void clear_with_walls() {
     nonempty = 0;
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -95,16 +96,16 @@ struct LaneGrid {
       }
     walls = nonempty;
   }
-  MG_D void clear_empty() {
+  MG_HD void clear_empty() {
     nonempty = 0; walls = 0;
     for (int k = 0; k < W * H; k++) p[k] = (uint8_t)CELL_EMPTY;
   }
-  MG_D void reach_masks(uint64_t& passable, uint64_t& objects, uint32_t desc, uint64_t& matches) const {
+  MG_HD void reach_masks(uint64_t& passable, uint64_t& objects, uint32_t desc, uint64_t& matches) const {
     const uint64_t all = (W * H >= 64) ? ~0ull : ((1ull << (W * H)) - 1ull);
     uint64_t pa = ~nonempty & all, ob = 0, ma = 0;
     uint64_t m = nonempty & ~walls;                 // the outer walls are neither passable nor objects and match no description
     while (m) {
-      const int k = __ffsll((long long)m) - 1;
+      const int k = __builtin_ffsll((long long)m) - 1;
       const uint64_t bit = 1ull << k;
       m &= m - 1ull;
       const uint32_t c = (uint32_t)p[k], t = cell_type(c);
@@ -121,7 +122,7 @@ struct LaneGrid {
 // agent itself is being placed).  near_reject = core/roomgrid.py:11-20 reject_next_to.  max_tries < 0 = math.inf.
 // Returns false on the reference's RecursionError.
 template <class R, class G>
-MG_D bool place_obj(R& rng, G& g, uint32_t cell, int topx, int topy, int sx, int sy, int ax, int ay,
+MG_HD bool place_obj(R& rng, G& g, uint32_t cell, int topx, int topy, int sx, int sy, int ax, int ay,
                     bool near_reject, int max_tries, int& px, int& py) {
   topx = topx < 0 ? 0 : topx; topy = topy < 0 ? 0 : topy;
   const int hx = min(topx + sx, g.W), hy = min(topy + sy, g.H);
@@ -166,7 +167,7 @@ MG_D bool place_obj(R& rng, G& g, uint32_t cell, int topx, int topy, int sx, int
 }
 // MiniGridEnv.place_agent (minigrid_env.py:383-395)
 template <class R, class G>
-MG_D bool place_agent(R& rng, G& g, int topx, int topy, int sx, int sy, int max_tries, GenResult& out) {
+MG_HD bool place_agent(R& rng, G& g, int topx, int topy, int sx, int sy, int max_tries, GenResult& out) {
   int x, y;
   if (!place_obj(rng, g, CELL_EMPTY, topx, topy, sx, sy, -1, -1, false, max_tries, x, y)) return false;
   out.ax = (uint32_t)x; out.ay = (uint32_t)y;
@@ -176,7 +177,7 @@ MG_D bool place_agent(R& rng, G& g, int topx, int topy, int sx, int sy, int max_
 
 // envs/empty.py:97-114
 template <class R, class G>
-MG_D void gen_empty(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_empty(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   g.set(g.W - 2, g.H - 2, CELL_GOAL);
   if (P.start_x >= 0) { out.ax = P.start_x; out.ay = P.start_y; out.dir = P.start_dir; }
@@ -186,7 +187,7 @@ MG_D void gen_empty(R& rng, G& g, const GenParams& P, GenResult& out) {
 
 // envs/doorkey.py:74-99
 template <class R, class G>
-MG_D void gen_doorkey(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_doorkey(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   g.set(g.W - 2, g.H - 2, CELL_GOAL);
   int split = rand_int(rng, 2, g.W - 2);
@@ -204,7 +205,7 @@ MG_D void gen_doorkey(R& rng, G& g, const GenParams& P, GenResult& out) {
 // (S9: 3+3, S11: 4+4), so the shuffled river list is 8 bytes packed in a u64 (byte = orientation << 7 | position)
 // and the per-orientation sorted position lists are bitmasks.
 template <class R, class G>
-MG_D void gen_crossing(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_crossing(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H;
   g.clear_with_walls();
   out.ax = 1; out.ay = 1; out.dir = 0;
@@ -280,7 +281,7 @@ MG_D void gen_crossing(R& rng, G& g, const GenParams& P, GenResult& out) {
 // GoToObj / GoToLocal (article "a" ? 18 : 0) + COLOR_NAMES index * 3 + (key 0, ball 1, box 2).
 enum : int { GOTO_REDBALL = 3, GOTO_REDBALLGREY = 16, GOTO_REDBLUEBALL = 17, GOTO_OBJ = 18, GOTO_LOCAL = 19 };
 template <class R, class G>
-MG_D void gen_goto(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_goto(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H, kind = P.kind;
   // column masks of the W x H bitboard (bit y*W+x)
   uint64_t col0 = 0, colL = 0, all = 0;
@@ -345,7 +346,7 @@ MG_D void gen_goto(R& rng, G& g, const GenParams& P, GenResult& out) {
     if (kind == GOTO_OBJ || kind == GOTO_LOCAL) desc = make_cell(T_KEY + ((dtyp >> (4 * k)) & 15u), color_from_sorted((dcol >> (4 * k)) & 15u));
     g.reach_masks(passable, objects, desc, matches);
     out.aux = matches;                            // GoToInstr.reset_verifier -> desc.find_matching_objs: tracked positions
-    const uint32_t many = __popcll(matches) > 1 ? 1u : 0u;
+    const uint32_t many = __builtin_popcountll(matches) > 1 ? 1u : 0u;
     if (kind == GOTO_OBJ || kind == GOTO_LOCAL) out.mission = many * 18u + ((dcol >> (4 * k)) & 15u) * 3u + ((dtyp >> (4 * k)) & 15u);
     else if (kind == GOTO_REDBLUEBALL) out.mission = cell_color(desc) == C_BLUE ? 1u : 0u;
     else out.mission = many;                      // "go to the red ball" / "go to a red ball"
@@ -356,7 +357,7 @@ MG_D void gen_goto(R& rng, G& g, const GenParams& P, GenResult& out) {
 
 // envs/lavagap.py:100-135
 template <class R, class G>
-MG_D void gen_lavagap(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_lavagap(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   out.ax = 1; out.ay = 1; out.dir = 0;
   g.set(g.W - 2, g.H - 2, CELL_GOAL);
@@ -369,7 +370,7 @@ MG_D void gen_lavagap(R& rng, G& g, const GenParams& P, GenResult& out) {
 
 // envs/distshift.py:103-124
 template <class R, class G>
-MG_D void gen_distshift(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_distshift(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   g.set(g.W - 2, 1, CELL_GOAL);
   for (int i = 0; i < g.W - 6; i++) { g.set(3 + i, 1, CELL_LAVA); g.set(3 + i, P.strip2_row, CELL_LAVA); }
@@ -380,7 +381,7 @@ MG_D void gen_distshift(R& rng, G& g, const GenParams& P, GenResult& out) {
 
 // envs/fourrooms.py:77-130 with agent_pos = goal_pos = None (the registered configuration)
 template <class R, class G>
-MG_D void gen_fourrooms(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_fourrooms(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H;
   g.clear_with_walls();                                  // horz_wall(0,0), horz_wall(0,H-1), vert_wall(0,0), vert_wall(W-1,0)
   const int room_w = W / 2, room_h = H / 2;
@@ -406,7 +407,7 @@ MG_D void gen_fourrooms(R& rng, G& g, const GenParams& P, GenResult& out) {
 // envs/fetch.py:107-160 (P.num_dists = numObjs <= 8).  Mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1):
 // the step rule recovers the target (type, colour) from it, so no extra per-env state is needed.
 template <class R, class G>
-MG_D void gen_fetch(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_fetch(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   uint64_t objs = 0;                           // byte k = colour index * 2 + type index of object k
   int x, y;
@@ -427,7 +428,7 @@ MG_D void gen_fetch(R& rng, G& g, const GenParams& P, GenResult& out) {
 // envs/gotoobject.py:93-135 (P.num_dists = numObjs <= 8).  Mission id = COLOR_NAMES index * 3 + (key 0 | ball 1 | box 2);
 // out.aux = one-bit board of target_pos, which is a POSITION fixed at reset (the object may be carried away later).
 template <class R, class G>
-MG_D void gen_gotoobject(R& rng, G& g, const GenParams& P, GenResult& out) {
+MG_HD void gen_gotoobject(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   uint64_t objs = 0, poss = 0;                 // byte k = colour index * 3 + type index / cell index of object k
   uint32_t used = 0;                           // bit (colour index * 3 + type index)

@@ -24,7 +24,7 @@ MG_HD bool lane_gen_kind(int kind) {
 MG_HD int lane_grid_stride(int CS) { return CS + 4; }                 // odd dword stride: the 64 lanes' grids start in different LDS banks
 
 template <class R>
-MG_D void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
+MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
   switch (P.kind) {
     case 0: gen_empty(rng, g, P, out); return;

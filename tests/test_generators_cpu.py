@@ -1,0 +1,54 @@
+"""The lane-per-episode map generators on the CPU (no GPU needed): mg_selftest_generate runs generate_episode_lane (minigrid_amd/csrc/mg_genlane.h,
+mg_gen.h -- the reference's _gen_grid of the single-room levels restated on one lane's byte grid and numpy-exact PCG64 stream; the code of
+k_refill_lane / k_generate_lane, which draw every spare episode of the four BASELINE.json configs) compiled for the host: from reset(seed)'s seeded
+stream, four consecutive episodes per env must reproduce the oracle's reset()s -- which are pinned to the reference's own generated episodes
+(tests/golden/gen_*.npz, tests/test_oracle_golden.py) -- cell by cell, with the agent's pose, the mission id and the stream position after every
+episode (a draw too many or too few anywhere shows up there at the latest).  Every registered id the lane generators serve."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import importlib
+
+from minigrid_amd import _binding as B
+
+R = importlib.import_module("minigrid_amd.registry")      # (the package re-exports the `registry` dict under the module's name)
+
+LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20}            # lane_gen_kind(), mg_genlane.h
+IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
+
+
+def _cfg(s, n):
+    return B.MgConfig(abi_version=B.MG_ABI_VERSION, env_kind=s.env_kind, width=s.width, height=s.height, max_steps=s.max_steps,
+                      see_through_walls=int(s.see_through_walls), agent_view_size=7, obs_mode=0, autoreset_mode=0, rng_mode=0, num_envs=n,
+                      agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1], agent_start_dir=s.agent_start[2],
+                      num_crossings=s.num_crossings, obstacle_type=s.obstacle_type, num_dists=s.num_dists, strip2_row=s.strip2_row,
+                      room_size=s.room_size, random_length=int(s.random_length))
+
+
+@pytest.mark.parametrize("env_id", IDS)
+def test_lane_generators_on_the_host_equal_the_oracle(env_id):
+    from oracle import oracle as O
+    L = B.load()
+    s = R.spec(env_id)
+    n, E = 96, 4
+    W, H = s.width, s.height
+    seeds = np.arange(1000, 1000 + n, dtype=np.uint64)
+    grid = np.zeros((E, n, W, H, 3), np.uint8); agent = np.zeros((E, n, 8), np.int32)
+    aux = np.zeros((E, n), np.uint64); words = np.zeros((E, n, 5), np.uint64); failed = np.zeros((E, n), np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    cfg = _cfg(s, n)
+    assert L.mg_selftest_generate(C.byref(cfg), n, E, p(seeds), p(grid), p(agent), p(aux), p(words), p(failed)) == 0
+    assert not failed.any()
+    orc = O.OracleVec(env_id, n)
+    for ep in range(E):
+        _, _, m = orc.reset(seeds=seeds if ep == 0 else None)                      # (no seed: the env's stream carries on, like an autoreset)
+        g, a = orc.get_state()
+        bad = np.argwhere((grid[ep] != g).reshape(n, -1).any(1)).ravel()
+        assert bad.size == 0, (env_id, ep, bad[:5])
+        assert (agent[ep][:, :3] == a[:, :3]).all(), (env_id, ep, "agent pose")
+        assert (agent[ep][:, 7] == np.asarray(m).astype(np.int64)).all(), (env_id, ep, "mission id")
+        assert (words[ep] == orc.get_rng()).all(), (env_id, ep, "stream position")
+    if s.env_kind in (3, 16, 17, 18, 19):                                           # GoTo levels: the tracked positions = the described objects' cells
+        assert (aux[E - 1] != 0).all()
