@@ -340,6 +340,9 @@ MG_API int mg_selftest_pack_cell(int32_t type, int32_t color, int32_t state, uin
  * (perm / dot4 / bit reverse / bit-to-byte expand / visibility row / SDWA byte index) on the host or, on_device = 1, on the GPU: out[6][n]. */
 MG_API int mg_selftest_obs7(int32_t width, int32_t height, int32_t n, const uint8_t* grid, const int32_t* agent, int32_t see_through,
                             uint8_t* out);
+/* ... and FullyObsWrapper.observation (wrappers.py:419-426) as k_roll7<., true> produces it (the image-order code stream, the agent's cell, the same
+ * output-space encode): grid (n, W, H, 3) u8, agent (n, 8) i32 -> out (n, W, H, 3) u8. */
+MG_API int mg_selftest_obs_full(int32_t width, int32_t height, int32_t n, const uint8_t* grid, const int32_t* agent, uint8_t* out);
 MG_API int mg_selftest_vis_row_carry(uint32_t mask_in, uint32_t transparent, uint32_t* mask_out, uint32_t* up_out);
 MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out, int32_t on_device);
 /* DynamicObstaclesEnv's stream draws as the fused step kernel runs them per lane (minigrid_amd/csrc/mg_dynobs.h; reference:

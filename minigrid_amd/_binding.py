@@ -44,7 +44,7 @@ SYMBOLS = ["mg_create", "mg_destroy", "mg_set_obs_config", "mg_reset", "mg_step"
            "mg_sync", "mg_get_state", "mg_set_state", "mg_state_size", "mg_save_state", "mg_load_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
            "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_build_info", "mg_device_count", "mg_selftest_vis_row",
            "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles",
-           "mg_selftest_obs7", "mg_selftest_vis_row_carry", "mg_selftest_prims", "mg_selftest_dynobs", "mg_selftest_verify", "mg_selftest_transition", "mg_selftest_generate"]
+           "mg_selftest_obs7", "mg_selftest_vis_row_carry", "mg_selftest_prims", "mg_selftest_dynobs", "mg_selftest_verify", "mg_selftest_transition", "mg_selftest_generate", "mg_selftest_obs_full"]
 
 
 def lib_path() -> str:
@@ -105,6 +105,7 @@ def load():
     L.mg_selftest_prims.argtypes = [C.c_int32, vp, vp, vp, vp, C.c_int32]
     L.mg_selftest_dynobs.argtypes = [C.c_int32] * 8 + [vp] * 6
     L.mg_selftest_verify.argtypes = [C.c_int32] * 4 + [vp] * 7
+    L.mg_selftest_obs_full.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     L.mg_selftest_generate.argtypes = [C.POINTER(MgConfig), C.c_int32, C.c_int32] + [vp] * 6
     L.mg_selftest_transition.argtypes = [C.c_int32] * 8 + [C.c_double, C.c_int32] + [vp] * 8
     L.mg_selftest_pack_cell.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -1842,6 +1842,44 @@ int mg_selftest_obs7(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const
   }
   return MG_OK;
 }
+// FullyObsWrapper.observation (wrappers.py:419-426) as k_roll7<., true> produces it: the grids' image-order code stream (image_stream_build), the
+// agent's own cell patched to (10, 0, dir), the output-space encode over the stream (obs7_quad for a full 64-env workgroup, obs7_chunk for the ragged
+// last one) -- on the host, over states in the exchange format: grid (n, W, H, 3) u8, agent (n, 8) i32; out (n, W, H, 3) u8
+int mg_selftest_obs_full(int32_t W, int32_t H, int32_t n, const uint8_t* grid, const int32_t* agent, uint8_t* out) {
+  if (W < 3 || H < 3 || W > 25 || H > 25 || n < 0 || !grid || !agent || !out) return MG_ERR_INVALID;
+  const int cells = W * H;
+  std::vector<uint32_t> slut(256), stream_w((size_t)(64 * cells + 64) / 4 + 4);
+  for (uint32_t k = 0; k < 256; k++) slut[k] = cell_triple(k);
+  uint8_t* stream = (uint8_t*)stream_w.data();
+  std::vector<uint8_t> g((size_t)cells);
+  for (int g0 = 0; g0 < n; g0 += 64) {
+    const int nv = std::min(64, n - g0);
+    memset(stream, 0x5A, (size_t)64 * cells + 64);
+    for (int l = 0; l < nv; l++) {
+      const uint8_t* t3 = grid + (size_t)(g0 + l) * cells * 3;
+      for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) { const uint8_t* t = t3 + ((size_t)x * H + y) * 3; g[y * W + x] = (uint8_t)cell_from_triple(t[0], t[1], t[2]); }
+      image_stream_build(g.data(), stream + (size_t)l * cells, W, H);
+      const int32_t* o = agent + (size_t)(g0 + l) * 8;
+      stream[(size_t)l * cells + (size_t)o[0] * H + o[1]] = (uint8_t)(T_AGENT_MARK | (((uint32_t)o[2] & 3u) << 4));
+    }
+    const int nbytes = nv * cells * 3;
+    uint8_t* ob = out + (size_t)g0 * cells * 3;
+    if (MG_ENCODE_QUADS && nv == 64) {
+      for (int u = 0; u < 16 * cells; u++) {
+        uint32_t o3[3];
+        obs7_quad((uint32_t)u, stream, slut.data(), o3);
+        for (int b = 0; b < 12; b++) ob[u * 12 + b] = (uint8_t)(o3[b >> 2] >> (8 * (b & 3)));
+      }
+      continue;
+    }
+    for (int c = 0; c * 16 < nbytes; c++) {
+      uint32_t o4[4];
+      obs7_chunk((uint32_t)c, stream, slut.data(), o4);
+      for (int b = 0; b < 16 && c * 16 + b < nbytes; b++) ob[c * 16 + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
+    }
+  }
+  return MG_OK;
+}
 // dynobs_place (mg_dynobs.h: DynamicObstacles' obstacle moves and reset draws as k_roll7<GG_DYNOBS> runs them per lane) on the host, for n envs in
 // the state exchange format: mode[i] = 0 nothing, 1 = the moves of one step, 2 = reset (the grid is rebuilt from the level's constant part).
 // flags[i]: bit 0 = a placement failed (the reference's reset() raises), bit 1 = the grid changed, bit 2 = the front cell was occupied (not_clear)

@@ -431,3 +431,26 @@ def test_dynobs_in_loop_draws_on_the_host_equal_the_oracle(env_id, redo):
         n_resets += int(pending.sum()); n_minus += int(hit.sum())
         pending = term | trunc
     assert n_resets > n // 2 and n_minus > 0
+
+
+@pytest.mark.parametrize("env_id,n,T", [("MiniGrid-LavaCrossingS9N1-v0", 131, 50), ("MiniGrid-DoorKey-8x8-v0", 64, 60), ("MiniGrid-DoorKey-16x16-v0", 70, 40),
+                                        ("BabyAI-GoToRedBall-v0", 200, 40), ("MiniGrid-Empty-5x5-v0", 64, 20)])
+def test_full_observation_pipeline_on_the_host_equals_the_oracle(env_id, n, T):
+    """mg_selftest_obs_full = k_roll7<., true>'s FullyObs observation (image-order code stream, agent cell, output-space encode) compiled for the
+    host, against the oracle's FullyObsWrapper observation along random rollouts (doors in every state, carried objects gone from the grid,
+    ragged last workgroups)."""
+    import ctypes as C
+    from oracle import oracle as O
+    L = B.load()
+    orc = O.OracleVec(env_id, n, full_obs=True)
+    obs, _, _ = orc.reset(seeds=np.arange(n, dtype=np.uint64))
+    rng = np.random.default_rng(2)
+    out = np.zeros((n, orc.W, orc.H, 3), np.uint8)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    for t in range(T):
+        grid, agent = orc.get_state()
+        assert L.mg_selftest_obs_full(orc.W, orc.H, n, p(np.ascontiguousarray(grid)), p(np.ascontiguousarray(agent)), p(out)) == 0
+        bad = np.argwhere((out != obs).reshape(n, -1).any(1)).ravel()
+        assert bad.size == 0, (env_id, t, bad[:5])
+        a = rng.choice(7, size=n, p=[0.15, 0.15, 0.4, 0.1, 0.05, 0.1, 0.05]).astype(np.uint8)
+        obs = orc.step(a)[0]
