@@ -892,6 +892,24 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
+// (mg_selftest_generate, below: the lane generators the device kernels serve -- generate_episode_lane -- plus the ones that are templated on the grid
+// type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor.  Host only: k_refill_lane's code is untouched.)
+static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 30; }
+template <class R>
+static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
+  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
+  switch (P.kind) {
+    case 8: gen_gotodoor(rng, g, P, out); return;
+    case 9: gen_unlock_family(rng, g, P, out, 0); return;
+    case 10: gen_unlock_family(rng, g, P, out, 1); return;
+    case 11: gen_unlock_family(rng, g, P, out, 2); return;
+    case 12: gen_redbluedoors(rng, g, P, out); return;
+    case 13: gen_memory(rng, g, P, out); return;
+    case 14: gen_keycorridor(rng, g, P, out); return;
+    case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
+    default: generate_episode_lane(rng, g, P, out); return;
+  }
+}
 // (mg_selftest_transition, below: one env, one step of env_transition<GG, 1> on the host)
 template <int GG>
 static void selftest_transition_one(const StepParams& P, uint8_t* g, Agent& a, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc, uint32_t& err,
@@ -1931,7 +1949,7 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
 int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
                          uint64_t* rng_words, uint8_t* failed) {
   if (!cfg || n < 0 || episodes < 1 || !seeds || !grid || !agent || !aux || !rng_words || !failed) return MG_ERR_INVALID;
-  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !lane_gen_kind(cfg->env_kind)) return MG_ERR_INVALID;
+  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !selftest_lane_kind(cfg->env_kind)) return MG_ERR_INVALID;
   const GenParams gp = gen_params_of(*cfg);
   const int W = gp.W, H = gp.H, cells = W * H, CS = (cells + 15) & ~15;
   std::vector<uint8_t> buf((size_t)CS + 16);
@@ -1943,7 +1961,7 @@ int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, cons
       g.p = buf.data(); g.W = W; g.H = H; g.lane = 0; g.nonempty = 0; g.walls = 0;
       GenResult out;
       out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
-      generate_episode_lane(r, g, gp, out);
+      generate_episode_lane_host(r, g, gp, out);
       const size_t k = (size_t)ep * (size_t)n + (size_t)i;
       uint8_t* t3 = grid + k * cells * 3;
       for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {

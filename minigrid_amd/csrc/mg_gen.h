@@ -498,10 +498,13 @@ MG_D void gen_putnear(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 
 // envs/gotodoor.py:92-131.  The room is w x h <= W x H in the top-left corner; the rest of the grid stays None.
 // Mission id = COLOR_NAMES index of the target door (door colours are distinct, so it identifies the door).
-template <class R>
-MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+// (templated on the grid type like the generators above -- round 4: the per-lane form runs on the host against the oracle,
+// tests/test_generators_cpu.py; the device's lane kernels do not serve this level yet)
+template <class R, class G>
+MG_HD void gen_gotodoor(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int w = rand_int(rng, 5, g.W + 1);
   const int h = rand_int(rng, 5, g.H + 1);
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
   for (int y = 0; y < g.H; y++)
     if (g.lane < g.W) {
@@ -510,6 +513,10 @@ MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
       g.p[y * g.W + g.lane] = (uint8_t)((in_room && edge) ? CELL_WALL_GREY : CELL_EMPTY);      // wall_rect(0, 0, w, h)
     }
   MG_WAVE_LDS_SYNC();
+  } else {
+    g.clear_empty();
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) if (x == 0 || x == w - 1 || y == 0 || y == h - 1) g.set(x, y, CELL_WALL_GREY);
+  }
   int px[4], py[4];
   px[0] = rand_int(rng, 2, w - 2); py[0] = 0;
   px[1] = rand_int(rng, 2, w - 2); py[1] = h - 1;
@@ -532,8 +539,25 @@ MG_D void gen_gotodoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 // non-wall object in all four directions, the reference never returns (BabyAI-SynthS5R2: 18 objects in six 3 x 3 rooms, about 0.4 % of
 // the episodes).  Decided exactly, one lane per cell of the room's rs x rs rectangle, before anything is drawn.  (A room without any free
 // cell is not this case: place_obj's 1000 tries run out -- RecursionError, which the callers' retry loops handle.)
-MG_D bool room_stuck(GridRef& g, int topx, int topy, int rs) {
+template <class G>
+MG_HD bool room_stuck(G& g, int topx, int topy, int rs) {
   if (rs > 8) return false;
+  if constexpr (!G::kWave) {
+    // (one lane: the same decision cell by cell)
+    bool any_free = false, any_ok = false;
+    for (int ly = 0; ly < rs; ly++) for (int lx = 0; lx < rs; lx++) {
+      const int x = topx + lx, y = topy + ly;
+      if (x >= g.W || y >= g.H || (uint32_t)g.p[y * g.W + x] != CELL_EMPTY) continue;
+      any_free = true;
+      for (int d = 0; d < 4; d++) {
+        const int fx = x + dir_dx((uint32_t)d), fy = y + dir_dy((uint32_t)d);
+        if (fx < 0 || fy < 0 || fx >= g.W || fy >= g.H) continue;
+        const uint32_t f = (uint32_t)g.p[fy * g.W + fx];
+        any_ok = any_ok || f == CELL_EMPTY || cell_type(f) == T_WALL;
+      }
+    }
+    return any_free && !any_ok;
+  } else {
   MG_WAVE_LDS_SYNC();
   const int ly = g.lane / rs, lx = g.lane - ly * rs, x = topx + lx, y = topy + ly;
   const bool in = ly < rs && x < g.W && y < g.H;
@@ -549,10 +573,11 @@ MG_D bool room_stuck(GridRef& g, int topx, int topy, int rs) {
     }
   }
   return __ballot(is_free) != 0ull && __ballot(ok) == 0ull;
+  }
 }
 // RoomGrid.place_agent (roomgrid.py:313-334): place_agent in the room until the front cell is None or a wall
-template <class R>
-MG_D bool rg_place_agent(R& rng, GridRef& g, int topx, int topy, int rs, GenResult& out) {
+template <class R, class G>
+MG_HD bool rg_place_agent(R& rng, G& g, int topx, int topy, int rs, GenResult& out) {
   if (room_stuck(g, topx, topy, rs)) { out.stuck = 1u; return false; }     // ends the attempt like a RecursionError; the episode is marked
   for (;;) {
     if (!place_agent(rng, g, topx, topy, rs, rs, 1000, out)) return false;
@@ -561,11 +586,12 @@ MG_D bool rg_place_agent(R& rng, GridRef& g, int topx, int topy, int rs, GenResu
   }
 }
 // envs/unlock.py:75-88, envs/unlockpickup.py:82-97, envs/blockedunlockpickup.py:90-110 (variant 0 / 1 / 2)
-template <class R>
-MG_D void gen_unlock_family(R& rng, GridRef& g, const GenParams& P, GenResult& out, int variant) {
+template <class R, class G>
+MG_HD void gen_unlock_family(R& rng, G& g, const GenParams& P, GenResult& out, int variant) {
   const int rs = P.room_size, W = g.W, H = g.H;
   // RoomGrid._gen_grid (roomgrid.py:123-179): wall_rect per room; one door position drawn per room pair; the agent
   // "starts in the middle": that provisional position is what reject_next_to / place_obj see until place_agent
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
   for (int y = 0; y < H; y++)
     if (g.lane < W) {
@@ -573,6 +599,10 @@ MG_D void gen_unlock_family(R& rng, GridRef& g, const GenParams& P, GenResult& o
       g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
     }
   MG_WAVE_LDS_SYNC();
+  } else {
+    g.clear_empty();
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if (y == 0 || y == H - 1 || (x % (rs - 1)) == 0) g.set(x, y, CELL_WALL_GREY);
+  }
   const int door_x = rs - 1, door_y = rand_int(rng, 1, rs - 1);          // room (0,0).door_pos[0] = (x_m, rand(y_l, y_m))
   const int mid_x = (2 / 2) * (rs - 1) + rs / 2, mid_y = rs / 2;         // provisional agent_pos (num_cols = 2, num_rows = 1)
   int x, y;
@@ -601,16 +631,16 @@ struct RoomGridState {
   uint64_t right_y, down_x;     // nibble per room
   uint64_t doors;               // bit room*4 + k, k = right, down, left, up
   uint32_t locked;              // bit per room
-  MG_D int room(int i, int j) const { return j * ncols + i; }
-  MG_D bool has_nb(int i, int j, int k) const { return k == 0 ? i < ncols - 1 : k == 1 ? j < nrows - 1 : k == 2 ? i > 0 : j > 0; }
-  MG_D void door_pos(int i, int j, int k, int& x, int& y) const {     // Room.door_pos[k] (roomgrid.py:158-171)
+  MG_HD int room(int i, int j) const { return j * ncols + i; }
+  MG_HD bool has_nb(int i, int j, int k) const { return k == 0 ? i < ncols - 1 : k == 1 ? j < nrows - 1 : k == 2 ? i > 0 : j > 0; }
+  MG_HD void door_pos(int i, int j, int k, int& x, int& y) const {     // Room.door_pos[k] (roomgrid.py:158-171)
     if (k == 2) { i -= 1; k = 0; }
     if (k == 3) { j -= 1; k = 1; }
     const int r = room(i, j);
     if (k == 0) { x = i * (rs - 1) + rs - 1; y = (int)((right_y >> (4 * r)) & 15u); }
     else { x = (int)((down_x >> (4 * r)) & 15u); y = j * (rs - 1) + rs - 1; }
   }
-  MG_D void mark(int i, int j, int k) {                               // room.doors[k] and the neighbour's opposite side
+  MG_HD void mark(int i, int j, int k) {                               // room.doors[k] and the neighbour's opposite side
     doors |= 1ull << (room(i, j) * 4 + k);
     const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
     doors |= 1ull << (room(ni, nj) * 4 + ((k + 2) & 3));
@@ -619,16 +649,21 @@ struct RoomGridState {
 
 // envs/keycorridor.py:106-133 on RoomGrid._gen_grid / remove_wall / add_door / add_object / place_agent / connect_all
 // (roomgrid.py:123-394).  Mission id = COLOR_NAMES index of the ball.
-template <class R>
-MG_D void gen_keycorridor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_keycorridor(R& rng, G& g, const GenParams& P, GenResult& out) {
   RoomGridState S;
   S.rs = P.room_size; S.ncols = (g.W - 1) / (S.rs - 1); S.nrows = (g.H - 1) / (S.rs - 1);
   S.right_y = 0; S.down_x = 0; S.doors = 0; S.locked = 0;
   const int rs = S.rs, W = g.W, H = g.H;
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
   for (int y = 0; y < H; y++)
     if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % (rs - 1)) == 0 || (y % (rs - 1)) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
   MG_WAVE_LDS_SYNC();
+  } else {
+    g.clear_empty();
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % (rs - 1)) == 0 || (y % (rs - 1)) == 0) g.set(x, y, CELL_WALL_GREY);
+  }
   for (int j = 0; j < S.nrows; j++)
     for (int i = 0; i < S.ncols; i++) {
       const int tx = i * (rs - 1), ty = j * (rs - 1), r = S.room(i, j);
@@ -703,9 +738,10 @@ MG_D void gen_dynobs(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 }
 
 // envs/redbluedoors.py:78-102 (size = H, width = 2 * size)
-template <class R>
-MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_redbluedoors(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int S = g.H, W = g.W;
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
   for (int y = 0; y < S; y++)
     if (g.lane < W) {           // wall_rect(0, 0, 2S, S) and wall_rect(S/2, 0, S, S)
@@ -713,6 +749,11 @@ MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& ou
       g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
     }
   MG_WAVE_LDS_SYNC();
+  } else {
+    g.clear_empty();
+    for (int y = 0; y < S; y++) for (int x = 0; x < W; x++)
+      if (y == 0 || y == S - 1 || x == 0 || x == W - 1 || x == S / 2 || x == S / 2 + S - 1) g.set(x, y, CELL_WALL_GREY);
+  }
   if (!place_agent(rng, g, S / 2, 0, S, S, -1, out)) out.failed = true;
   g.set(S / 2, rand_int(rng, 1, S - 1), make_cell(T_DOOR_CLOSED, C_RED));
   g.set(S / 2 + S - 1, rand_int(rng, 1, S - 1), make_cell(T_DOOR_CLOSED, C_BLUE));
@@ -720,8 +761,8 @@ MG_D void gen_redbluedoors(R& rng, GridRef& g, const GenParams& P, GenResult& ou
 }
 
 // envs/memory.py:92-149
-template <class R>
-MG_D void gen_memory(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_memory(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H, mid = H / 2;
   g.clear_with_walls();
   const int upper = mid - 2, lower = mid + 2;

@@ -15,7 +15,10 @@ from minigrid_amd import _binding as B
 
 R = importlib.import_module("minigrid_amd.registry")      # (the package re-exports the `registry` dict under the module's name)
 
-LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20}            # lane_gen_kind(), mg_genlane.h
+# lane_gen_kind() (mg_genlane.h: what k_refill_lane serves on the device) + the generators that are templated on the grid type and pinned here
+# ahead of being switched over on the device: GoToDoor 8, Unlock / UnlockPickup / BlockedUnlockPickup 9-11, RedBlueDoors 12, Memory 13,
+# KeyCorridor 14 (and BabyAI's, 30)
+LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30}
 IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
 
 
