@@ -893,8 +893,9 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
 // (mg_selftest_generate, below: the lane generators the device kernels serve -- generate_episode_lane -- plus the ones that are templated on the grid
-// type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor.  Host only: k_refill_lane's code is untouched.)
-static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 30; }
+// type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor, LockedRoom, Playground,
+// PickupDist / OneRoom, OpenRedDoor, FindObj, UnlockLocal, ObstructedMaze, PutNear.  Host only: k_refill_lane's code is untouched.)
+static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 32); }
 template <class R>
 static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
@@ -907,6 +908,14 @@ static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, 
     case 13: gen_memory(rng, g, P, out); return;
     case 14: gen_keycorridor(rng, g, P, out); return;
     case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
+    case 21: gen_lockedroom(rng, g, P, out); return;
+    case 22: gen_playground(rng, g, P, out); return;
+    case 24: case 25: case 27: gen_pickup_level(rng, g, P, out); return;
+    case 26: gen_openreddoor(rng, g, P, out); return;
+    case 28: gen_findobj(rng, g, P, out); return;
+    case 29: gen_unlocklocal(rng, g, P, out); return;
+    case 31: gen_obstructedmaze(rng, g, P, out); return;
+    case 32: gen_putnear(rng, g, P, out); return;
     default: generate_episode_lane(rng, g, P, out); return;
   }
 }

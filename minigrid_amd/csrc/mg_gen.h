@@ -456,8 +456,8 @@ MG_HD void gen_gotoobject(R& rng, G& g, const GenParams& P, GenResult& out) {
 // distance 1 of an earlier one (place_obj's reject_fn near_obj; no max_tries); then the agent, the object to move and a
 // different target object.  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type over
 // COLOR_NAMES x [key, ball, box] (the order of putnear.py:72-80's placeholders); out.aux = one-bit board of target_pos.
-template <class R>
-MG_D void gen_putnear(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_putnear(R& rng, G& g, const GenParams& P, GenResult& out) {
   g.clear_with_walls();
   uint64_t objs = 0, poss = 0;                 // byte k = colour index * 3 + type index / cell index of object k
   uint32_t used = 0;
@@ -789,8 +789,8 @@ MG_HD void gen_memory(R& rng, G& g, const GenParams& P, GenResult& out) {
 // Mission id of "pick up " + ObjDesc.surface (verifier.py:73-103): article ("the" 0 | "a" 1) * 28 +
 // (no colour 0 | COLOR_NAMES index + 1) * 4 + ("object" 0 | key 1 | ball 2 | box 3).
 enum : int { KIND_PICKUPDIST = 24, KIND_ONEROOM = 25, KIND_OPENREDDOOR = 26, KIND_PICKUPDIST_DEBUG = 27 };
-template <class R>
-MG_D void gen_pickup_level(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_pickup_level(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H, mid = W / 2;      // 1x1 RoomGrid: the provisional agent_pos reject_next_to sees (roomgrid.py:174-179)
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
@@ -834,16 +834,21 @@ MG_D void gen_pickup_level(R& rng, GridRef& g, const GenParams& P, GenResult& ou
 // at random until every room is reachable; PickupInstr(ObjDesc(obj.type)) -> mission "pick up the <type>".
 // Room bookkeeping: the door offsets inside the room (1 .. rs-2: a nibble each; S7's absolute coordinates reach 17) and
 // one bit per (room, wall) for Room.doors.
-template <class R>
-MG_D void gen_findobj(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_findobj(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();                           // a RecursionError regenerates from the current stream position
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
     for (int y = 0; y < H; y++)
       if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
     MG_WAVE_LDS_SYNC();
+    } else {
+      g.clear_empty();
+      for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
+    }
     uint64_t right_y = 0, down_x = 0, doors = 0;
 #pragma unroll 1
     for (int j = 0; j < 3; j++)
@@ -902,16 +907,21 @@ MG_D void gen_findobj(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
 }
 // envs/babyai/unlock.py:167-174 (UnlockLocal / UnlockLocalDist: 3 x 3 rooms; a locked door on a random wall of the middle
 // room, its key and P.num_dists (0 | 3) distractors in that room, the agent too; OpenInstr(ObjDesc("door")) -> "open the door")
-template <class R>
-MG_D void gen_unlocklocal(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_unlocklocal(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
     for (int y = 0; y < H; y++)
       if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
     MG_WAVE_LDS_SYNC();
+    } else {
+      g.clear_empty();
+      for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
+    }
     uint64_t right_y = 0, down_x = 0;           // RoomGrid._gen_grid: one door offset per room and shared wall (roomgrid.py:158-171)
 #pragma unroll 1
     for (int j = 0; j < 3; j++)
@@ -950,18 +960,23 @@ MG_D void gen_unlocklocal(R& rng, GridRef& g, const GenParams& P, GenResult& out
 // place_in_room / place_agent (no connect_all).  room_size 6; P.num_crossings = flags (1 key_in_box, 2 blocked, 4 the v1
 // class, 8 the 1 x 2 class ObstructedMaze_1Dlhb); P.num_dists = num_quarters; P.start_x / start_y = agent_room.  The ball
 // to find is COLOR_NAMES[0] (blue), blocking balls COLOR_NAMES[1] (green), boxes COLOR_NAMES[2] (grey).
-template <class R>
-MG_D void gen_obstructedmaze(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_obstructedmaze(R& rng, G& g, const GenParams& P, GenResult& out) {
   RoomGridState S;
   S.rs = P.room_size; S.ncols = (g.W - 1) / (S.rs - 1); S.nrows = (g.H - 1) / (S.rs - 1);
   S.right_y = 0; S.down_x = 0; S.doors = 0; S.locked = 0;
   const int rs = S.rs, st = rs - 1, W = g.W, H = g.H;
   const int flags = P.num_crossings;
   const bool key_in_box = flags & 1, blocked = (flags >> 1) & 1, v1 = (flags >> 2) & 1, one_d = (flags >> 3) & 1;
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
   for (int y = 0; y < H; y++)
     if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
   MG_WAVE_LDS_SYNC();
+  } else {
+    g.clear_empty();
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
+  }
 #pragma unroll 1
   for (int j = 0; j < S.nrows; j++)
 #pragma unroll 1
@@ -1022,12 +1037,13 @@ MG_D void gen_obstructedmaze(R& rng, GridRef& g, const GenParams& P, GenResult& 
 }
 
 // envs/babyai/open.py:143-146 (OpenRedDoor: 1 x 2 rooms of size 5; add_door(0, 0, 0, "red", locked=False); place_agent(0, 0))
-template <class R>
-MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_openreddoor(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int rs = P.room_size, W = g.W, H = g.H;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
     for (int y = 0; y < H; y++)
       if (g.lane < W) {
@@ -1035,6 +1051,10 @@ MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out
         g.p[y * W + g.lane] = (uint8_t)(wall ? CELL_WALL_GREY : CELL_EMPTY);
       }
     MG_WAVE_LDS_SYNC();
+    } else {
+      g.clear_empty();
+      for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if (y == 0 || y == H - 1 || (x % (rs - 1)) == 0) g.set(x, y, CELL_WALL_GREY);
+    }
     const int door_y = rand_int(rng, 1, rs - 1);                      // room (0,0).door_pos[0] (roomgrid.py:158-163)
     g.set(rs - 1, door_y, make_cell(T_DOOR_CLOSED, C_RED));
     if (!rg_place_agent(rng, g, 0, 0, rs, out)) continue;
@@ -1047,8 +1067,8 @@ MG_D void gen_openreddoor(R& rng, GridRef& g, const GenParams& P, GenResult& out
 
 // envs/lockedroom.py:104-176 (19x19: six rooms off a central hallway, one locked with the goal inside, the key of its
 // colour in another room).  Mission id = COLOR_NAMES index of the locked room * 6 + COLOR_NAMES index of the key room.
-template <class R>
-MG_D void gen_lockedroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_lockedroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H;
   g.clear_with_walls();
   const int lw = W / 2 - 2, rw = W / 2 + 2, third = H / 3;
@@ -1092,8 +1112,8 @@ MG_D void gen_lockedroom(R& rng, GridRef& g, const GenParams& P, GenResult& out)
 }
 
 // envs/playground.py:31-91: 3x3 rooms, one door per shared wall, 12 random objects; no goal, one (empty) mission
-template <class R>
-MG_D void gen_playground(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_playground(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W, H = g.H;
   g.clear_with_walls();
   const int room_w = W / 3, room_h = H / 3;
