@@ -1254,7 +1254,43 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
 // (passable = None or any door; objects = every cell that is neither None nor a wall, doors included; reached).  One flood iteration = step one row up / down
 // (two lane shuffles) + an occluded fill along the row (Kogge-Stone, like vis_row), repeated until no row changes; an object
 // is reachable when it lies in or next to the reached set.
-MG_D bool maze_objs_reachable(GridRef& g, int ax, int ay) {
+template <class G>
+MG_HD bool maze_objs_reachable(G& g, int ax, int ay) {
+  if constexpr (!G::kWave) {
+    // (one lane: the same row bitboards, all H rows in this lane; pinned on the CPU, not yet used on the device)
+    const int W = g.W, H = g.H;
+    uint32_t pass[25], obj[25], R[25];
+    for (int y = 0; y < H; y++) {
+      uint32_t pm = 0, om = 0;
+      for (int x = 0; x < W; x++) {
+        const uint32_t c = g.p[y * W + x], t = cell_type(c);
+        const bool p = c == CELL_EMPTY || t == T_DOOR || t == T_DOOR_CLOSED || t == T_DOOR_LOCKED;
+        pm |= (uint32_t)p << x;
+        om |= (uint32_t)(c != CELL_EMPTY && t != T_WALL) << x;
+      }
+      pass[y] = pm; obj[y] = om; R[y] = y == ay ? 1u << ax : 0u;
+    }
+    for (int it = 0; it < 1024; it++) {
+      bool changed = false;
+      for (int y = 0; y < H; y++) {
+        const uint32_t up = y > 0 ? R[y - 1] : 0u, dn = y + 1 < H ? R[y + 1] : 0u;
+        const uint32_t seed = (R[y] | up | dn) & pass[y];
+        uint32_t fr = seed, pr = pass[y], fl = seed, pl = pass[y];
+        for (int s = 1; s < 32; s <<= 1) { fr |= pr & (fr << s); pr &= pr << s; fl |= pl & (fl >> s); pl &= pl >> s; }
+        const uint32_t Rn = R[y] | fr | fl;
+        changed |= Rn != R[y];
+        R[y] = Rn;
+      }
+      if (!changed) break;
+    }
+    bool all_near = true;
+    for (int y = 0; y < H; y++) {
+      const uint32_t up = y > 0 ? R[y - 1] : 0u, dn = y + 1 < H ? R[y + 1] : 0u;
+      const uint32_t near = R[y] | (R[y] << 1) | (R[y] >> 1) | up | dn;
+      all_near = all_near && (obj[y] & ~near) == 0u;
+    }
+    return all_near;
+  } else {
   MG_WAVE_LDS_SYNC();
   const int W = g.W, H = g.H;
   uint32_t pass = 0, obj = 0;
@@ -1284,23 +1320,29 @@ MG_D bool maze_objs_reachable(GridRef& g, int ax, int ay) {
   if (g.lane == 63) dn = 0u;
   const uint32_t near = R | (R << 1) | (R >> 1) | up | dn;
   return __ballot((obj & ~near) != 0u) == 0ull;
+  }
 }
 enum : int { KIND_BABYAI_GOTO = 33, KIND_BABYAI_PICKUP = 34, KIND_BABYAI_OPEN = 35 };
-MG_D uint32_t sorted_from_color(uint32_t c) {       // inverse of color_from_sorted: COLOR_TO_IDX -> position in the sorted COLOR_NAMES
+MG_HD uint32_t sorted_from_color(uint32_t c) {       // inverse of color_from_sorted: COLOR_TO_IDX -> position in the sorted COLOR_NAMES
   const uint32_t packed = (4u << (4 * C_RED)) | (1u << (4 * C_GREEN)) | (0u << (4 * C_BLUE)) | (3u << (4 * C_PURPLE)) | (5u << (4 * C_YELLOW)) | (2u << (4 * C_GREY));
   return (packed >> (4u * c)) & 15u;
 }
-template <class R>
-MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int rs = P.room_size, W = g.W, H = g.H, st = rs - 1;
   const int nc = (W - 1) / st, nr = (H - 1) / st, nrooms = nc * nr;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();                           // RecursionError / RejectSampling regenerate from the current stream position
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
     for (int y = 0; y < H; y++)
       if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
     MG_WAVE_LDS_SYNC();
+    } else {
+      g.clear_empty();
+      for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
+    }
     uint64_t right_y = 0, down_x = 0, doors = 0;     // nibble per room (r = j * nc + i): door offsets inside the room; bit 4r+k: room r has a door on side k
 #pragma unroll 1
     for (int j = 0; j < nr; j++)
@@ -1372,7 +1414,7 @@ MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out
       // Open.gen_mission (open.py:69-86): every room's doors in (column, row, right/down/left/up) order -- each door once per side --
       // one of them picked; the description is its colour; "a" when another door has that colour
       int cnt = 0;
-      for (int r = 0; r < nrooms; r++) cnt += __popc((uint32_t)(doors >> (4 * r)) & 15u);
+      for (int r = 0; r < nrooms; r++) cnt += __builtin_popcount((uint32_t)(doors >> (4 * r)) & 15u);
       const int pick = rand_int(rng, 0, cnt);
       uint32_t pc = 0;
       int seen = 0;
@@ -1386,12 +1428,16 @@ MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out
               if (seen == pick) { int dx, dy; door_xy(i, j, k, dx, dy); pc = cell_color(g.get(dx, dy)); }
               seen++;
             }
-      MG_WAVE_LDS_SYNC();
       uint32_t same = 0;
+      if constexpr (G::kWave) {
+      MG_WAVE_LDS_SYNC();
       for (int base = 0; base < W * H; base += 64) {
         const int q = base + g.lane;
         const uint32_t c = q < W * H ? (uint32_t)g.p[q] : 0u;
         same += (uint32_t)__popcll(__ballot(q < W * H && cell_ref_type(c) == T_DOOR && cell_type(c) != T_BOX_KEY && cell_color(c) == pc));
+      }
+      } else {
+        for (int q = 0; q < W * H; q++) { const uint32_t c = (uint32_t)g.p[q]; same += (cell_ref_type(c) == T_DOOR && cell_type(c) != T_BOX_KEY && cell_color(c) == pc) ? 1u : 0u; }
       }
       out.mission = (same > 1u ? 6u : 0u) + sorted_from_color(pc);
       out.aux = ~0ull;
@@ -1404,12 +1450,16 @@ MG_D void gen_babyai_maze(R& rng, GridRef& g, const GenParams& P, GenResult& out
     if (P.kind == KIND_BABYAI_GOTO) {
       out.mission = (matches > 1u ? 18u : 0u) + kc * 3u + kt;
       if (P.num_crossings) {                                         // open_all_doors (roomgrid_level.py:238-248)
+        if constexpr (G::kWave) {
         MG_WAVE_LDS_SYNC();
         for (int base = 0; base < W * H; base += 64) {
           const int q = base + g.lane;
           if (q < W * H && cell_type(g.p[q]) == T_DOOR_CLOSED) g.p[q] = (uint8_t)make_cell(T_DOOR, cell_color(g.p[q]));
         }
         MG_WAVE_LDS_SYNC();
+        } else {
+          for (int q = 0; q < W * H; q++) if (cell_type(g.p[q]) == T_DOOR_CLOSED) g.p[q] = (uint8_t)make_cell(T_DOOR, cell_color(g.p[q]));
+        }
       }
     } else {
       out.mission = (matches > 1u ? 28u : 0u) + (kc + 1u) * 4u + (kt + 1u);
