@@ -895,7 +895,7 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 // (mg_selftest_generate, below: the lane generators the device kernels serve -- generate_episode_lane -- plus the ones that are templated on the grid
 // type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor, LockedRoom, Playground,
 // PickupDist / OneRoom, OpenRedDoor, FindObj, UnlockLocal, ObstructedMaze, PutNear.  Host only: k_refill_lane's code is untouched.)
-static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 35); }
+static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 49); }
 template <class R>
 static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
@@ -917,6 +917,8 @@ static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, 
     case 31: gen_obstructedmaze(rng, g, P, out); return;
     case 32: gen_putnear(rng, g, P, out); return;
     case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
+    case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
+    case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
     default: generate_episode_lane(rng, g, P, out); return;
   }
 }

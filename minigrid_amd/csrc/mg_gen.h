@@ -1479,26 +1479,31 @@ struct RG {
   uint64_t right_off, down_off, doors;
   uint32_t locked;
   bool ok;                                          // false after a RecursionError (place_obj ran out of tries): regenerate
-  MG_D int room(int i, int j) const { return j * nc + i; }
-  MG_D bool has_nb(int i, int j, int k) const { return k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0; }
-  MG_D void door_xy(int i, int j, int k, int& dx, int& dy) const {
+  MG_HD int room(int i, int j) const { return j * nc + i; }
+  MG_HD bool has_nb(int i, int j, int k) const { return k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0; }
+  MG_HD void door_xy(int i, int j, int k, int& dx, int& dy) const {
     const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * nc + ri;
     const bool vertical_wall = k == 0 || k == 2;
     dx = vertical_wall ? ri * st + st : ri * st + (int)((down_off >> (4 * rr)) & 15u);
     dy = vertical_wall ? rj * st + (int)((right_off >> (4 * rr)) & 15u) : rj * st + st;
   }
-  MG_D void mark(int i, int j, int k) {
+  MG_HD void mark(int i, int j, int k) {
     const int r = room(i, j), nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
     doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
   }
   // RoomGrid._gen_grid (roomgrid.py:123-179)
-  template <class R> MG_D void gen_grid(R& rng, GridRef& g, int room_size) {
+  template <class R, class G> MG_HD void gen_grid(R& rng, G& g, int room_size) {
     rs = room_size; st = rs - 1; nc = (g.W - 1) / st; nr = (g.H - 1) / st;
     right_off = 0; down_off = 0; doors = 0; locked = 0; ok = true;
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
     for (int y = 0; y < g.H; y++)
       if (g.lane < g.W) g.p[y * g.W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
     MG_WAVE_LDS_SYNC();
+    } else {
+      g.clear_empty();
+      for (int y = 0; y < g.H; y++) for (int x = 0; x < g.W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
+    }
 #pragma unroll 1
     for (int j = 0; j < nr; j++)
 #pragma unroll 1
@@ -1510,7 +1515,7 @@ struct RG {
     ax = (nc / 2) * st + rs / 2; ay = (nr / 2) * st + rs / 2;
   }
   // RoomGrid.add_door (roomgrid.py:230-277); k / ci / locked < 0 = draw it.  Returns the COLOR_NAMES index used.
-  template <class R> MG_D int add_door(R& rng, GridRef& g, int i, int j, int k, int ci, int lock, int& dx, int& dy) {
+  template <class R, class G> MG_HD int add_door(R& rng, G& g, int i, int j, int k, int ci, int lock, int& dx, int& dy) {
     if (k < 0)
       for (;;) { k = rand_int(rng, 0, 4); if (rng.dead() || (has_nb(i, j, k) && !((doors >> (room(i, j) * 4 + k)) & 1ull))) break; }
     if (ci < 0) ci = rand_int(rng, 0, 6);                         // _rand_color()
@@ -1523,7 +1528,7 @@ struct RG {
     return ci;
   }
   // RoomGrid.add_object / place_in_room (roomgrid.py:181-228); ti / ci < 0 = draw (kind first, then colour)
-  template <class R> MG_D void add_object(R& rng, GridRef& g, int i, int j, int ti, int ci, int& ti_out, int& ci_out) {
+  template <class R, class G> MG_HD void add_object(R& rng, G& g, int i, int j, int ti, int ci, int& ti_out, int& ci_out) {
     if (ti < 0) ti = rand_int(rng, 0, 3);
     if (ci < 0) ci = rand_int(rng, 0, 6);
     int x, y;
@@ -1531,12 +1536,12 @@ struct RG {
     ti_out = ti; ci_out = ci;
   }
   // RoomGrid.place_agent(i, j) (roomgrid.py:313-334)
-  template <class R> MG_D void place_agent_in(R& rng, GridRef& g, int i, int j, GenResult& out) {
+  template <class R, class G> MG_HD void place_agent_in(R& rng, G& g, int i, int j, GenResult& out) {
     if (!rg_place_agent(rng, g, i * st, j * st, rs, out)) { ok = false; return; }
     ax = (int)out.ax; ay = (int)out.ay;
   }
   // RoomGrid.connect_all (roomgrid.py:336-394) with door_colors = COLOR_NAMES without index `exclude` (< 0: all six)
-  template <class R> MG_D void connect_all(R& rng, GridRef& g, int exclude) {
+  template <class R, class G> MG_HD void connect_all(R& rng, G& g, int exclude) {
     const int start = (ay / st) * nc + ax / st, nrooms = nc * nr;
     for (int itr = 0; !rng.dead(); itr++) {
       if (itr > 5000) { ok = false; return; }
@@ -1569,7 +1574,16 @@ struct RG {
   }
 };
 // number of cells on the grid that hold a door of COLOR_TO_IDX colour c / exactly the cell code `code`
-MG_D uint32_t count_cells(GridRef& g, bool doors_of_color, uint32_t c) {
+template <class G>
+MG_HD uint32_t count_cells(G& g, bool doors_of_color, uint32_t c) {
+  if constexpr (!G::kWave) {
+    uint32_t n = 0;
+    for (int q = 0; q < g.W * g.H; q++) {
+      const uint32_t v = (uint32_t)g.p[q];
+      n += (doors_of_color ? (cell_ref_type(v) == T_DOOR && cell_color(v) == c) : v == c) ? 1u : 0u;
+    }
+    return n;
+  } else {
   MG_WAVE_LDS_SYNC();
   uint32_t n = 0;
   for (int base = 0; base < g.W * g.H; base += 64) {
@@ -1579,6 +1593,7 @@ MG_D uint32_t count_cells(GridRef& g, bool doors_of_color, uint32_t c) {
     n += (uint32_t)__popcll(__ballot(hit));
   }
   return n;
+  }
 }
 
 enum : int { KIND_BABYAI_UNLOCKPICKUP = 36, KIND_BABYAI_BLOCKEDUNLOCKPICKUP = 37, KIND_UNLOCKTOUNLOCK = 38, KIND_KEYINBOX = 39, KIND_BABYAI_UNLOCK = 40,
@@ -1588,8 +1603,8 @@ enum : int { KIND_BABYAI_UNLOCKPICKUP = 36, KIND_BABYAI_BLOCKEDUNLOCKPICKUP = 37
 // pickup.py: UnblockPickup (:128-140), PickupAbove (:354-362).  One PickupInstr / OpenInstr / GoToInstr about one description.
 // Mission ids: "pick up" table (article * 28 + (colour + 1) * 4 + type + 1); Unlock / GoToDoor article * 6 + colour;
 // GoToObjDoor article * 24 + colour * 4 + (key, ball, box, door); GoToImpUnlock as GoToObj.
-template <class R>
-MG_D void gen_babyai_levels(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_babyai_levels(R& rng, G& g, const GenParams& P, GenResult& out) {
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
@@ -1768,8 +1783,8 @@ enum : int { KIND_PUTNEXTLOCAL = 46, KIND_PUTNEXT = 47, KIND_ACTIONOBJDOOR = 48,
 // verb * 48 + article * 24 + colour * 4 + (key, ball, box, door), verb = go to | pick up | open; OpenDoor colour (0..5) or
 // 6 + article * 4 + (left, right, front, behind).  out.aux: PutNext = the cell the carried object came from (start_carrying);
 // ActionObjDoor = no stale tracked position (RULE_GOTO_BIG); OpenDoor = COLOR_TO_IDX bit mask of the described doors.
-template <class R>
-MG_D void gen_babyai_put_open(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_babyai_put_open(R& rng, G& g, const GenParams& P, GenResult& out) {
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
@@ -1800,9 +1815,13 @@ MG_D void gen_babyai_put_open(R& rng, GridRef& g, const GenParams& P, GenResult&
         a = rand_int(rng, 0, n);                              // _rand_subset(objs, 2)
         b = rand_int(rng, 0, n - 1); if (b >= a) b++;
       } else {
+        if constexpr (G::kWave) {
         MG_WAVE_LDS_SYNC();                                   // remove_wall(0, 0, 0) (roomgrid.py:279-311)
         if (g.lane >= 1 && g.lane < rg.rs - 1) g.p[g.lane * g.W + rg.st] = (uint8_t)CELL_EMPTY;
         MG_WAVE_LDS_SYNC();
+        } else {
+          for (int y = 1; y < rg.rs - 1; y++) g.p[y * g.W + rg.st] = (uint8_t)CELL_EMPTY;
+        }
         a = rand_int(rng, 0, per);
         b = per + rand_int(rng, 0, per);
         if (rand_int(rng, 0, 2) == 0) { const int t = a; a = b; b = t; }

@@ -19,7 +19,7 @@ R = importlib.import_module("minigrid_amd.registry")      # (the package re-expo
 # ahead of being switched over on the device: GoToDoor 8, Unlock / UnlockPickup / BlockedUnlockPickup 9-11, RedBlueDoors 12, Memory 13,
 # KeyCorridor 14 (and BabyAI's, 30), LockedRoom 21, Playground 22, PickupDist / OneRoom 24 25 27, OpenRedDoor 26, FindObj 28, UnlockLocal 29,
 # ObstructedMaze 31, PutNear 32
-LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32} | {33, 34, 35}
+LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32} | set(range(33, 50))
 IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
 
 
