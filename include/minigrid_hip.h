@@ -355,9 +355,11 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
  * distshift.py, fourrooms.py, fetch.py, gotoobject.py, babyai/goto.py: GoToRedBall / GoToRedBallGrey / GoToRedBlueBall / GoToObj / GoToLocal) as the
  * lane-per-episode generator kernels run it on the env's numpy PCG64 stream (minigrid_amd/csrc/mg_genlane.h, mg_gen.h), on the host: n envs seeded
  * like reset(seed = seeds[i]), `episodes` consecutive episodes each.  grid (episodes, n, W, H, 3) u8, agent (episodes, n, 8) i32 (x, y, dir, 0, 0, 0,
- * 0, mission id), aux (episodes, n) u64, rng (episodes, n, 5) u64 = the stream after each episode (mg_get_rng's words), failed (episodes, n) u8. */
+ * 0, mission id), aux (episodes, n) u64, rng (episodes, n, 5) u64 = the stream after each episode (mg_get_rng's words), failed (episodes, n) u8,
+ * instr: NULL or (episodes, n, 40) u64 (the sentence levels' instruction record).  Also serves the generators whose per-lane form exists
+ * but is not yet used by the device kernels (every level except MultiRoom). */
 MG_API int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
-                                uint64_t* rng, uint8_t* failed);
+                                uint64_t* rng, uint8_t* failed, uint64_t* instr);
 /* MiniGridEnv.step (minigrid_env.py:525-595) + the level's own step rule (envs/*.py, e.g. fetch.py:162-175, unlock.py:90-98) as the step kernels run
  * them per lane (minigrid_amd/csrc/mg_step.h env_transition), on the host: ONE step of n independent envs, no autoreset, state exchange format
  * (grid (n, W, H, 3) u8 and agent (n, 8) i32 in / out: x, y, dir, carried type, carried colour, step count, -, mission id).  group / rule / rule_cell /

@@ -106,7 +106,7 @@ def load():
     L.mg_selftest_dynobs.argtypes = [C.c_int32] * 8 + [vp] * 6
     L.mg_selftest_verify.argtypes = [C.c_int32] * 4 + [vp] * 7
     L.mg_selftest_obs_full.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
-    L.mg_selftest_generate.argtypes = [C.POINTER(MgConfig), C.c_int32, C.c_int32] + [vp] * 6
+    L.mg_selftest_generate.argtypes = [C.POINTER(MgConfig), C.c_int32, C.c_int32] + [vp] * 7
     L.mg_selftest_transition.argtypes = [C.c_int32] * 8 + [C.c_double, C.c_int32] + [vp] * 8
     L.mg_selftest_pack_cell.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if L.mg_abi_version() != MG_ABI_VERSION:

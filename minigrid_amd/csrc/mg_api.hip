@@ -895,11 +895,13 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 // (mg_selftest_generate, below: the lane generators the device kernels serve -- generate_episode_lane -- plus the ones that are templated on the grid
 // type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor, LockedRoom, Playground,
 // PickupDist / OneRoom, OpenRedDoor, FindObj, UnlockLocal, ObstructedMaze, PutNear.  Host only: k_refill_lane's code is untouched.)
-static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 49); }
+static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 53); }
 template <class R>
-static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
+static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out, uint64_t* iw, uint32_t* st) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
   switch (P.kind) {
+    case 50: case 51: case 52: gen_babyai_seq(rng, g, P, out, iw); return;
+    case 53: gen_levelgen(rng, g, P, out, iw, st); return;
     case 8: gen_gotodoor(rng, g, P, out); return;
     case 9: gen_unlock_family(rng, g, P, out, 0); return;
     case 10: gen_unlock_family(rng, g, P, out, 1); return;
@@ -1957,9 +1959,10 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
 // Fetch, the single-room BabyAI GoTo levels, GoToObject -- as k_refill_lane / k_generate_lane run it, one lane per episode on the env's numpy PCG64
 // stream) on the host: n envs seeded like reset(seed = seeds[i]), `episodes` consecutive episodes each (the stream carries on, like autoresets).
 // Out: grid (episodes, n, W, H, 3) u8 and agent (episodes, n, 8) i32 in the state exchange format (x, y, dir, 0, 0, 0, 0, mission id), aux
-// (episodes, n) u64 (GoTo levels: the tracked positions), rng (episodes, n, 5) u64 = the stream words AFTER each episode, failed (episodes, n) u8.
+// (episodes, n) u64 (GoTo levels: the tracked positions), rng (episodes, n, 5) u64 = the stream words AFTER each episode, failed (episodes, n) u8,
+// instr: NULL or (episodes, n, INSTR_WORDS) u64 = the sentence levels' instruction record (LevelGen's locked_room carries from episode to episode).
 int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
-                         uint64_t* rng_words, uint8_t* failed) {
+                         uint64_t* rng_words, uint8_t* failed, uint64_t* instr) {
   if (!cfg || n < 0 || episodes < 1 || !seeds || !grid || !agent || !aux || !rng_words || !failed) return MG_ERR_INVALID;
   if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !selftest_lane_kind(cfg->env_kind)) return MG_ERR_INVALID;
   const GenParams gp = gen_params_of(*cfg);
@@ -1968,12 +1971,17 @@ int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, cons
   for (int i = 0; i < n; i++) {
     Pcg64Stream r;
     r.seed(seeds[i]);
+    uint32_t gstate = 0;
     for (int ep = 0; ep < episodes; ep++) {
       LaneGrid g;
       g.p = buf.data(); g.W = W; g.H = H; g.lane = 0; g.nonempty = 0; g.walls = 0;
       GenResult out;
       out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
-      generate_episode_lane_host(r, g, gp, out);
+      uint64_t iw[INSTR_WORDS + 2] = { 0 };
+      uint32_t st[2] = { gstate, gstate };
+      generate_episode_lane_host(r, g, gp, out, iw, st);
+      gstate = out.gstate;
+      if (instr) memcpy(instr + ((size_t)ep * (size_t)n + (size_t)i) * INSTR_WORDS, iw, sizeof(uint64_t) * INSTR_WORDS);
       const size_t k = (size_t)ep * (size_t)n + (size_t)i;
       uint8_t* t3 = grid + k * cells * 3;
       for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {

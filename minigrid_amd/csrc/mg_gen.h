@@ -1928,6 +1928,41 @@ MG_D Objs assign_ids(GridRef& g, uint64_t* iw) {
   o.y = o.pos < POS_GONE ? (int)o.pos / g.W : -9; o.x = o.pos < POS_GONE ? (int)o.pos - o.y * g.W : -9;
   return o;
 }
+// (one lane: the same ids -- cell order -- in the record's table; returns the object count.  Per-lane forms of the sentence generators: pinned on
+// the CPU against the oracle, tests/test_generators_cpu.py; not yet used on the device)
+MG_HD uint32_t assign_ids_lane(const LaneGrid& g, uint64_t* iw) {
+  uint16_t* pos = (uint16_t*)(iw + IW_POS);
+  for (int i = 0; i < 64; i++) pos[i] = (uint16_t)POS_GONE;
+  uint32_t count = 0;
+  const int cells = g.W * g.H;
+  for (int c = 0; c < cells; c++) {
+    const uint32_t code = (uint32_t)g.p[c];
+    if (code == CELL_EMPTY || cell_type(code) == T_WALL) continue;
+    if (count < 63u) pos[count] = (uint16_t)c;
+    count++;
+  }
+  return count;
+}
+MG_HD uint64_t desc_set_lane(const LaneGrid& g, const uint64_t* iw, uint32_t type, uint32_t colp1, uint32_t loc, int ax, int ay, uint32_t dir, int rs) {
+  const uint16_t* pos = (const uint16_t*)(iw + IW_POS);
+  uint64_t set = 0;
+  for (int i = 0; i < 63; i++) {
+    const uint32_t q = pos[i];
+    if (q >= POS_GONE) continue;
+    const uint32_t code = (uint32_t)g.p[q];
+    const int oy = (int)q / g.W, ox = (int)q - oy * g.W;
+    bool m = cell_ref_type(code) == type && (colp1 == 0u || cell_color(code) == colp1 - 1u);
+    if (loc) {
+      const int st = rs - 1, top_x = (ax / st) * st, top_y = (ay / st) * st;
+      const bool inside = ox >= top_x && ox < top_x + rs && oy >= top_y && oy < top_y + rs;
+      const int vx = ox - ax, vy = oy - ay, d1x = dir_dx(dir), d1y = dir_dy(dir), d2x = -d1y, d2y = d1x;
+      const int side = vx * d2x + vy * d2y, ahead = vx * d1x + vy * d1y;
+      m = m && inside && (loc == 1u ? side < 0 : loc == 2u ? side > 0 : loc == 3u ? ahead > 0 : ahead < 0);
+    }
+    set |= (uint64_t)m << i;
+  }
+  return set;
+}
 // ObjDesc.find_matching_objs(use_location=True) (verifier.py:105-171) as one ballot over the object ids
 MG_D uint64_t desc_set(const Objs& o, uint32_t type, uint32_t colp1, uint32_t loc, int ax, int ay, uint32_t dir, int rs) {
   bool m = o.pos < POS_GONE && cell_ref_type(o.code) == type && (colp1 == 0u || cell_color(o.code) == colp1 - 1u);
@@ -1941,8 +1976,9 @@ MG_D uint64_t desc_set(const Objs& o, uint32_t type, uint32_t colp1, uint32_t lo
   return __ballot(m);
 }
 // the record's constant parts once the tree is known: header, stale sets, mission words
-MG_D void sentence_finish(GridRef& g, uint64_t* iw, uint32_t root, const uint32_t node[3], uint32_t max_steps) {
-  if (g.lane == 0) {
+template <class G>
+MG_HD void sentence_finish(G& g, uint64_t* iw, uint32_t root, const uint32_t node[3], uint32_t max_steps) {
+  if (!G::kWave || g.lane == 0) {
     uint64_t h = (uint64_t)root | ((uint64_t)max_steps << 39);
     for (int n = 0; n < 3; n++) h |= (uint64_t)node[n] << (3 + 8 * n);
     iw[0] = h;
@@ -1952,11 +1988,12 @@ MG_D void sentence_finish(GridRef& g, uint64_t* iw, uint32_t root, const uint32_
     m1 = (iw[IW_LEAF + 3] & 0xFFFFFull) | ((uint64_t)node[0] << 20) | ((uint64_t)node[1] << 28) | ((uint64_t)node[2] << 36);
     iw[IW_MISSION] = m0; iw[IW_MISSION + 1] = m1; iw[IW_MISSION + 2] = 0ull;
   }
-  MG_WAVE_LDS_SYNC();
+  if constexpr (G::kWave) MG_WAVE_LDS_SYNC();
 }
-MG_D void sentence_leaf(GridRef& g, uint64_t* iw, int k, uint32_t verb, uint32_t d9, uint64_t dset, uint32_t f9, uint64_t fset, uint32_t strict) {
-  if (g.lane == 0) {
-    const uint32_t da = d9 | ((__popcll(dset) > 1 ? 1u : 0u) << 8), fa = f9 | ((__popcll(fset) > 1 ? 1u : 0u) << 8);
+template <class G>
+MG_HD void sentence_leaf(G& g, uint64_t* iw, int k, uint32_t verb, uint32_t d9, uint64_t dset, uint32_t f9, uint64_t fset, uint32_t strict) {
+  if (!G::kWave || g.lane == 0) {
+    const uint32_t da = d9 | ((__builtin_popcountll(dset) > 1 ? 1u : 0u) << 8), fa = f9 | ((__builtin_popcountll(fset) > 1 ? 1u : 0u) << 8);
     iw[IW_LEAF + k] = (uint64_t)leaf20(verb, da, fa) | ((uint64_t)strict << 20);
     iw[IW_SET + 2 * k] = dset; iw[IW_SET + 2 * k + 1] = fset;
   }
@@ -1965,8 +2002,8 @@ MG_D void sentence_leaf(GridRef& g, uint64_t* iw, int k, uint32_t verb, uint32_t
 // sequences of two instructions: OpenTwoDoors (open.py:306-325; P.start_x / P.start_y = first / second colour as a COLOR_NAMES index
 // or -1, P.strip2_row = strict), OpenDoorsOrder (:399-425; P.num_dists = num_doors, P.strip2_row = debug), MoveTwoAcross
 // (other.py:404-428; P.num_dists = objs_per_room).  max_steps is the class's fixed value (P.max_steps).
-template <class R>
-MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out, uint64_t* iw) {
+template <class R, class G>
+MG_HD void gen_babyai_seq(R& rng, G& g, const GenParams& P, GenResult& out, uint64_t* iw) {
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
@@ -1975,7 +2012,8 @@ MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out,
     int dx, dy;
     out.aux = ~0ull; out.carry = 0; out.mission = 0;
     uint32_t node[3] = { 0u, 0u, 0u }, root = 0;
-    if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull;
+    if constexpr (G::kWave) { if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull; }
+    else for (int k = 0; k < INSTR_WORDS; k++) iw[k] = 0ull;
     if (P.kind == KIND_OPENTWODOORS || P.kind == KIND_OPENDOORSORDER) {
       const int nsub = P.kind == KIND_OPENTWODOORS ? 2 : P.num_dists;
       uint32_t avail = 0x543210u;                             // _rand_subset(COLOR_NAMES, n)
@@ -2012,9 +2050,15 @@ MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out,
         if (mode == 0) root = 0; else { node[0] = node8(mode == 1 ? N_BEFORE : N_AFTER, 0, 1); root = 4; }
       }
       if (rng.dead()) continue;
-      const Objs o = assign_ids(g, iw);
       const uint32_t k1 = color_from_sorted((uint32_t)c1) + 1u, k2 = color_from_sorted((uint32_t)c2) + 1u;
-      const uint64_t s1 = desc_set(o, T_DOOR, k1, 0, rg.ax, rg.ay, out.dir, rg.rs), s2 = desc_set(o, T_DOOR, k2, 0, rg.ax, rg.ay, out.dir, rg.rs);
+      uint64_t s1, s2;
+      if constexpr (G::kWave) {
+      const Objs o = assign_ids(g, iw);
+      s1 = desc_set(o, T_DOOR, k1, 0, rg.ax, rg.ay, out.dir, rg.rs); s2 = desc_set(o, T_DOOR, k2, 0, rg.ax, rg.ay, out.dir, rg.rs);
+      } else {
+        assign_ids_lane(g, iw);
+        s1 = desc_set_lane(g, iw, T_DOOR, k1, 0, rg.ax, rg.ay, out.dir, rg.rs); s2 = desc_set_lane(g, iw, T_DOOR, k2, 0, rg.ax, rg.ay, out.dir, rg.rs);
+      }
       sentence_leaf(g, iw, 0, V_OPEN, desc9(T_DOOR, k1, 0, 0), s1, 0, 0, (uint32_t)P.strip2_row);
       sentence_leaf(g, iw, 1, V_OPEN, desc9(T_DOOR, k2, 0, 0), s2, 0, 0, strict2);
       sentence_finish(g, iw, root, node, (uint32_t)P.max_steps);
@@ -2039,9 +2083,13 @@ MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out,
         n++; k++;
       }
     if (!rg.ok || rng.dead()) continue;
+    if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();                                       // remove_wall(0, 0, 0)
     if (g.lane >= 1 && g.lane < rg.rs - 1) g.p[g.lane * g.W + rg.st] = (uint8_t)CELL_EMPTY;
     MG_WAVE_LDS_SYNC();
+    } else {
+      for (int y = 1; y < rg.rs - 1; y++) g.p[y * g.W + rg.st] = (uint8_t)CELL_EMPTY;
+    }
     const int l0 = rand_int(rng, 0, per); int l1 = rand_int(rng, 0, per - 1); if (l1 >= l0) l1++;       // _rand_subset(objs_l, 2)
     const int r0 = rand_int(rng, 0, per); int r1 = rand_int(rng, 0, per - 1); if (r1 >= r0) r1++;
     if (rng.dead()) continue;
@@ -2050,10 +2098,17 @@ MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out,
     auto kind_of = [&](int i) -> uint32_t { const uint64_t w = (i >> 3) == 0 ? okind[0] : (i >> 3) == 1 ? okind[1] : okind[2]; return (uint32_t)(w >> (8 * (i & 7))) & 31u; };
     auto adjacent = [&](int i, int j) -> bool { const int p = pos_of(i), q = pos_of(j); return abs((p & 15) - (q & 15)) + abs((p >> 4) - (q >> 4)) == 1; };
     if (adjacent(ia, ib) || adjacent(ic, id)) continue;       // validate_instrs: "objs already next to each other" (the objects are unique)
-    const Objs o = assign_ids(g, iw);
     auto d9_of = [&](int i) -> uint32_t { const uint32_t kd = kind_of(i); return desc9((uint32_t)T_KEY + kd % 3u, color_from_sorted(kd / 3u) + 1u, 0, 0); };
+    uint64_t sa, sb, sc, sd;
+    if constexpr (G::kWave) {
+    const Objs o = assign_ids(g, iw);
     auto set_of = [&](int i) -> uint64_t { const uint32_t kd = kind_of(i); return desc_set(o, (uint32_t)T_KEY + kd % 3u, color_from_sorted(kd / 3u) + 1u, 0, rg.ax, rg.ay, out.dir, rg.rs); };
-    const uint64_t sa = set_of(ia), sb = set_of(ib), sc = set_of(ic), sd = set_of(id);
+    sa = set_of(ia); sb = set_of(ib); sc = set_of(ic); sd = set_of(id);
+    } else {
+      assign_ids_lane(g, iw);
+      auto set_of = [&](int i) -> uint64_t { const uint32_t kd = kind_of(i); return desc_set_lane(g, iw, (uint32_t)T_KEY + kd % 3u, color_from_sorted(kd / 3u) + 1u, 0, rg.ax, rg.ay, out.dir, rg.rs); };
+      sa = set_of(ia); sb = set_of(ib); sc = set_of(ic); sd = set_of(id);
+    }
     sentence_leaf(g, iw, 0, V_PUTNEXT, d9_of(ia), sa, d9_of(ib), sb, 0);
     sentence_leaf(g, iw, 1, V_PUTNEXT, d9_of(ic), sc, d9_of(id), sd, 0);
     node[0] = node8(N_BEFORE, 0, 1); root = 4;
@@ -2068,20 +2123,24 @@ MG_D void gen_babyai_seq(R& rng, GridRef& g, const GenParams& P, GenResult& out,
 // bit 9 implicit_unlock; P.strip2_row = locked_room_prob in percent; P.num_dists distractors.  LevelGen.locked_room survives from
 // episode to episode (only __init__ clears it), and rand_obj looks at it: `st[0]` = (i | j << 4 | 0x100 valid) as the env's previous
 // episode left it, st[1] = as of the current attempt's checkpoint; out.gstate = as this episode leaves it.
-template <class R>
-MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, uint64_t* iw, uint32_t* st) {
+template <class R, class G>
+MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64_t* iw, uint32_t* st) {
   const int flags = P.num_crossings;
+  uint32_t locked;
+  if constexpr (G::kWave) {
   MG_WAVE_LDS_SYNC();
-  uint32_t locked = uni32(out.resume ? st[1] : st[0]);
+  locked = uni32(out.resume ? st[1] : st[0]);
+  } else locked = out.resume ? st[1] : st[0];
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
     rng.checkpoint();
-    if (g.lane == 0) st[1] = locked;
+    if (!G::kWave || g.lane == 0) st[1] = locked;
     bool fresh = false;
     RG rg;
     rg.gen_grid(rng, g, P.room_size);
     out.aux = ~0ull; out.carry = 0; out.mission = 0; out.gstate = locked;
-    if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull;
+    if constexpr (G::kWave) { if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull; }
+    else for (int k = 0; k < INSTR_WORDS; k++) iw[k] = 0ull;
     int dx, dy, ti, ci;
     // _rand_float(0, 1) = Generator.uniform: next_double = (next_uint64 >> 11) / 2^53
     const double u = (double)(rng.next64() >> 11) * (1.0 / 9007199254740992.0);
@@ -2120,7 +2179,9 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
     }
     if (!rg.ok || rng.dead()) continue;
     if (!((flags >> 8) & 1) && !maze_objs_reachable(g, rg.ax, rg.ay)) continue;
-    const Objs o = assign_ids(g, iw);
+    Objs o;
+    if constexpr (G::kWave) o = assign_ids(g, iw);
+    else { o.pos = 0; o.code = 0; o.x = 0; o.y = 0; o.count = assign_ids_lane(g, iw); }
     if (o.count > 63u) { out.failed = true; return; }
     // rand_instr (levelgen.py:157-211) without the recursion: root = action | And(action, action) | Before / After(sub, sub), sub =
     // action | And(action, action).  rand_obj (:113-155) = draw (colour | None, type, location?) until something matches.
@@ -2138,12 +2199,22 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
         uint32_t loc = 0;
         if ((flags >> 7) & 1) if (rand_int(rng, 0, 2) == 0) loc = 1u + (uint32_t)rand_int(rng, 0, 4);
         const uint32_t colp1 = c ? color_from_sorted((uint32_t)(c - 1)) + 1u : 0u;
-        const uint64_t set = desc_set(o, t, colp1, loc, rg.ax, rg.ay, out.dir, rg.rs);
+        uint64_t set;
+        if constexpr (G::kWave) set = desc_set(o, t, colp1, loc, rg.ax, rg.ay, out.dir, rg.rs);
+        else set = desc_set_lane(g, iw, t, colp1, loc, rg.ax, rg.ay, out.dir, rg.rs);
         if (set == 0ull) continue;
         if (!((flags >> 9) & 1) && (locked & 0x100u)) {       // isinstance(self.locked_room, Room): possibly last episode's
           const int tx = (int)(locked & 15u) * rg.st, ty = (int)((locked >> 4) & 15u) * rg.st;
+          if constexpr (G::kWave) {
           const bool outside = ((set >> g.lane) & 1ull) && !(o.x >= tx && o.x < tx + rg.rs && o.y >= ty && o.y < ty + rg.rs);
           if (__ballot(outside) == 0ull) continue;
+          } else {
+            bool any_outside = false;
+            const uint16_t* pos = (const uint16_t*)(iw + IW_POS);
+            for (int i = 0; i < 63; i++)
+              if ((set >> i) & 1ull) { const int oy = (int)pos[i] / g.W, ox = (int)pos[i] - oy * g.W; any_outside |= !(ox >= tx && ox < tx + rg.rs && oy >= ty && oy < ty + rg.rs); }
+            if (!any_outside) continue;
+          }
         }
         lastset = set;
         return desc9(t, colp1, loc, 0);
@@ -2194,9 +2265,10 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
     }
     if (fail || rng.dead()) continue;
     // validate_instrs (roomgrid_level.py:146-203)
-    MG_WAVE_LDS_SYNC();
     bool reject = false;
     uint32_t locked_colors = 0;
+    if constexpr (G::kWave) {
+    MG_WAVE_LDS_SYNC();
     if ((flags >> 8) & 1) {
       for (int base = 0; base < g.W * g.H; base += 64) {
         const int q = base + g.lane;
@@ -2205,11 +2277,17 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
         for (uint32_t c = 0; c < 6u; c++) if (__ballot(lk && cell_color(v) == c)) locked_colors |= 1u << c;
       }
     }
+    } else if ((flags >> 8) & 1) {
+      for (int q = 0; q < g.W * g.H; q++) { const uint32_t v = (uint32_t)g.p[q]; if (cell_type(v) == T_DOOR_LOCKED) locked_colors |= 1u << cell_color(v); }
+    }
     for (uint32_t k = 0; k < nleaf; k++) {
-      const uint32_t l20 = (uint32_t)uni64(iw[IW_LEAF + k]) & 0xFFFFFu, verb = l20 & 3u, d9 = (l20 >> 2) & 511u, f9 = (l20 >> 11) & 511u;
-      const uint64_t ds = uni64(iw[IW_SET + 2 * k]), fs = uni64(iw[IW_SET + 2 * k + 1]);
+      uint32_t l20; uint64_t ds, fs;
+      if constexpr (G::kWave) { l20 = (uint32_t)uni64(iw[IW_LEAF + k]) & 0xFFFFFu; ds = uni64(iw[IW_SET + 2 * k]); fs = uni64(iw[IW_SET + 2 * k + 1]); }
+      else { l20 = (uint32_t)iw[IW_LEAF + k] & 0xFFFFFu; ds = iw[IW_SET + 2 * k]; fs = iw[IW_SET + 2 * k + 1]; }
+      const uint32_t verb = l20 & 3u, d9 = (l20 >> 2) & 511u, f9 = (l20 >> 11) & 511u;
       if (verb == V_PUTNEXT) {
         if (ds & fs) reject = true;                           // "there are objects that match both lhs and rhs of PutNext"
+        if constexpr (G::kWave) {
         bool next = false;                                    // objs_next(): some object to move already lies next to a fixed one
         const bool mine = (ds >> g.lane) & 1ull;
         for (int m = 0; m < 63; m++)
@@ -2218,6 +2296,16 @@ MG_D void gen_levelgen(R& rng, GridRef& g, const GenParams& P, GenResult& out, u
             next |= mine && abs(o.x - fxm) + abs(o.y - fym) == 1;
           }
         if (__ballot(next)) reject = true;
+        } else {
+          const uint16_t* pos = (const uint16_t*)(iw + IW_POS);
+          for (int a_ = 0; a_ < 63; a_++)
+            if ((ds >> a_) & 1ull)
+              for (int m = 0; m < 63; m++)
+                if ((fs >> m) & 1ull) {
+                  const int ay_ = (int)pos[a_] / g.W, ax_ = (int)pos[a_] - ay_ * g.W, my = (int)pos[m] / g.W, mx = (int)pos[m] - my * g.W;
+                  if (abs(ax_ - mx) + abs(ay_ - my) == 1) reject = true;
+                }
+        }
       }
       if ((flags >> 8) & 1) {                                 // unblocking: "cannot do anything with/to a locked door's key"
         if (desc9_type(d9) == T_KEY && desc9_color(d9) && ((locked_colors >> (desc9_color(d9) - 1u)) & 1u)) reject = true;

@@ -18,8 +18,11 @@ R = importlib.import_module("minigrid_amd.registry")      # (the package re-expo
 # lane_gen_kind() (mg_genlane.h: what k_refill_lane serves on the device) + the generators that are templated on the grid type and pinned here
 # ahead of being switched over on the device: GoToDoor 8, Unlock / UnlockPickup / BlockedUnlockPickup 9-11, RedBlueDoors 12, Memory 13,
 # KeyCorridor 14 (and BabyAI's, 30), LockedRoom 21, Playground 22, PickupDist / OneRoom 24 25 27, OpenRedDoor 26, FindObj 28, UnlockLocal 29,
-# ObstructedMaze 31, PutNear 32
-LANE_KINDS = {0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32} | set(range(33, 50))
+# ObstructedMaze 31, PutNear 32, the multi-room BabyAI levels 33-49, and the sentence levels 50-53 (OpenTwoDoors / OpenDoorsOrder / MoveTwoAcross /
+# LevelGen = GoToSeq, Synth*, MiniBoss, BossLevel*), whose instruction record is compared through its mission sentence
+SENTENCE_KINDS = {50, 51, 52, 53}
+LANE_KINDS = ({0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32}
+              | set(range(33, 50)) | SENTENCE_KINDS)
 IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
 
 
@@ -41,9 +44,10 @@ def test_lane_generators_on_the_host_equal_the_oracle(env_id):
     seeds = np.arange(1000, 1000 + n, dtype=np.uint64)
     grid = np.zeros((E, n, W, H, 3), np.uint8); agent = np.zeros((E, n, 8), np.int32)
     aux = np.zeros((E, n), np.uint64); words = np.zeros((E, n, 5), np.uint64); failed = np.zeros((E, n), np.uint8)
+    instr = np.zeros((E, n, 40), np.uint64)
     p = lambda x: x.ctypes.data_as(C.c_void_p)
     cfg = _cfg(s, n)
-    assert L.mg_selftest_generate(C.byref(cfg), n, E, p(seeds), p(grid), p(agent), p(aux), p(words), p(failed)) == 0
+    assert L.mg_selftest_generate(C.byref(cfg), n, E, p(seeds), p(grid), p(agent), p(aux), p(words), p(failed), p(instr)) == 0
     assert not failed.any()
     orc = O.OracleVec(env_id, n)
     for ep in range(E):
@@ -52,7 +56,13 @@ def test_lane_generators_on_the_host_equal_the_oracle(env_id):
         bad = np.argwhere((grid[ep] != g).reshape(n, -1).any(1)).ravel()
         assert bad.size == 0, (env_id, ep, bad[:5])
         assert (agent[ep][:, :3] == a[:, :3]).all(), (env_id, ep, "agent pose")
-        assert (agent[ep][:, 7] == np.asarray(m).astype(np.int64)).all(), (env_id, ep, "mission id")
+        if s.env_kind in SENTENCE_KINDS:                                            # the instruction tree, as the sentence the reference prints
+            from minigrid_amd.sentence import decode
+            got = [decode(int(w[37]), int(w[38])) for w in instr[ep]]
+            want = list(orc.mission_strings())
+            assert got == want, (env_id, ep, [(a_, b_) for a_, b_ in zip(got, want) if a_ != b_][:3])
+        else:
+            assert (agent[ep][:, 7] == np.asarray(m).astype(np.int64)).all(), (env_id, ep, "mission id")
         assert (words[ep] == orc.get_rng()).all(), (env_id, ep, "stream position")
     if s.env_kind in (3, 16, 17, 18, 19):                                           # GoTo levels: the tracked positions = the described objects' cells
         assert (aux[E - 1] != 0).all()
