@@ -360,7 +360,7 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
  * but is not yet used by the device kernels (every level except MultiRoom). */
 MG_API int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
                                 uint64_t* rng, uint8_t* failed, uint64_t* instr);
-/* MiniGridEnv.step (minigrid_env.py:525-595) + the level's own step rule (envs/*.py, e.g. fetch.py:162-175, unlock.py:90-98) as the step kernels run
+/* MiniGridEnv.step (minigrid_env.py:525-595) + the level's own step rule (envs/<level>.py, e.g. fetch.py:162-175, unlock.py:90-98) as the step kernels run
  * them per lane (minigrid_amd/csrc/mg_step.h env_transition), on the host: ONE step of n independent envs, no autoreset, state exchange format
  * (grid (n, W, H, 3) u8 and agent (n, 8) i32 in / out: x, y, dir, carried type, carried colour, step count, -, mission id).  group / rule / rule_cell /
  * rule_div = the kernel variant and level rule mg_create derives from the config (enum values in mg_step.h).  aux: NULL, or -- the single-room BabyAI

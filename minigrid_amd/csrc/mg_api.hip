@@ -206,7 +206,7 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask, hipStream
   // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-  if (e->lane_gen) launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)64 * lane_grid_stride(e->CS), st, A);   // one lane per env (mg_genlane.h)
+  if (e->lane_gen) launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);   // one lane per env (mg_genlane.h)
   else
   MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, st, A);
   HIP_TRY(e, hipGetLastError());
@@ -239,7 +239,7 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
     // one LANE per episode (mg_genlane.h): a wavefront per request segment, each lane drawing its own request's episodes
     A.wps = 2;
     if (const char* s = getenv("MG_LANE_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
-    launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)64 * lane_grid_stride(e->CS), st, A);
+    launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
   } else
   MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
   HIP_TRY(e, hipGetLastError());
@@ -892,38 +892,8 @@ static int rebuild_live_requests(mg_env* e, const uint64_t* host_rec) {
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------
-// (mg_selftest_generate, below: the lane generators the device kernels serve -- generate_episode_lane -- plus the ones that are templated on the grid
-// type already but not yet switched over on the device: GoToDoor, the Unlock family, RedBlueDoors, Memory, KeyCorridor, LockedRoom, Playground,
-// PickupDist / OneRoom, OpenRedDoor, FindObj, UnlockLocal, ObstructedMaze, PutNear.  Host only: k_refill_lane's code is untouched.)
-static bool selftest_lane_kind(int kind) { return lane_gen_kind(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 53); }
-template <class R>
-static void generate_episode_lane_host(R& rng, LaneGrid& g, const GenParams& P, GenResult& out, uint64_t* iw, uint32_t* st) {
-  out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
-  switch (P.kind) {
-    case 50: case 51: case 52: gen_babyai_seq(rng, g, P, out, iw); return;
-    case 53: gen_levelgen(rng, g, P, out, iw, st); return;
-    case 8: gen_gotodoor(rng, g, P, out); return;
-    case 9: gen_unlock_family(rng, g, P, out, 0); return;
-    case 10: gen_unlock_family(rng, g, P, out, 1); return;
-    case 11: gen_unlock_family(rng, g, P, out, 2); return;
-    case 12: gen_redbluedoors(rng, g, P, out); return;
-    case 13: gen_memory(rng, g, P, out); return;
-    case 14: gen_keycorridor(rng, g, P, out); return;
-    case 30: gen_keycorridor(rng, g, P, out); out.mission = 2u; return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
-    case 21: gen_lockedroom(rng, g, P, out); return;
-    case 22: gen_playground(rng, g, P, out); return;
-    case 24: case 25: case 27: gen_pickup_level(rng, g, P, out); return;
-    case 26: gen_openreddoor(rng, g, P, out); return;
-    case 28: gen_findobj(rng, g, P, out); return;
-    case 29: gen_unlocklocal(rng, g, P, out); return;
-    case 31: gen_obstructedmaze(rng, g, P, out); return;
-    case 32: gen_putnear(rng, g, P, out); return;
-    case 33: case 34: case 35: gen_babyai_maze(rng, g, P, out); return;
-    case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: gen_babyai_levels(rng, g, P, out); return;
-    case 46: case 47: case 48: case 49: gen_babyai_put_open(rng, g, P, out); return;
-    default: generate_episode_lane(rng, g, P, out); return;
-  }
-}
+// (mg_selftest_generate, below, runs generate_episode_lane<R, true>: the lane generators the device kernels serve plus the ones that are templated
+// on the grid type already but switched over on the device in the MG_LANE_WIDE variant build only, mg_genlane.h)
 // (mg_selftest_transition, below: one env, one step of env_transition<GG, 1> on the host)
 template <int GG>
 static void selftest_transition_one(const StepParams& P, uint8_t* g, Agent& a, uint32_t act, double& reward, uint32_t& term, uint32_t& trunc, uint32_t& err,
@@ -952,7 +922,7 @@ const char* mg_build_info(void) {
 #endif
 #define MG_BI_STR2(x) #x
 #define MG_BI_STR(x) MG_BI_STR2(x)
-  return "attribution=" MG_BI_ATTR ";encode_quads=" MG_BI_STR(MG_ENCODE_QUADS) ";arch=gfx950";
+  return "attribution=" MG_BI_ATTR ";encode_quads=" MG_BI_STR(MG_ENCODE_QUADS) ";lane_wide=" MG_BI_STR(MG_LANE_WIDE) ";arch=gfx950";
 }
 
 int mg_device_count(void) {
@@ -1112,7 +1082,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   {
     const char* s = getenv("MG_LANE_GEN");
-    e->lane_gen = lane_gen_kind(cfg->env_kind) && (!s || atoi(s) != 0) && 64 * lane_grid_stride(e->CS) <= 64 * 1024;
+    e->lane_gen = lane_gen_kind(cfg->env_kind) && (!s || atoi(s) != 0) && lane_gen_lds_bytes(e->CS, cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) <= 64 * 1024;
   }
   e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
@@ -1964,7 +1934,7 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
 int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
                          uint64_t* rng_words, uint8_t* failed, uint64_t* instr) {
   if (!cfg || n < 0 || episodes < 1 || !seeds || !grid || !agent || !aux || !rng_words || !failed) return MG_ERR_INVALID;
-  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !selftest_lane_kind(cfg->env_kind)) return MG_ERR_INVALID;
+  if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !lane_gen_kind_wide(cfg->env_kind)) return MG_ERR_INVALID;
   const GenParams gp = gen_params_of(*cfg);
   const int W = gp.W, H = gp.H, cells = W * H, CS = (cells + 15) & ~15;
   std::vector<uint8_t> buf((size_t)CS + 16);
@@ -1979,7 +1949,7 @@ int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, cons
       out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
       uint64_t iw[INSTR_WORDS + 2] = { 0 };
       uint32_t st[2] = { gstate, gstate };
-      generate_episode_lane_host(r, g, gp, out, iw, st);
+      generate_episode_lane<Pcg64Stream, true>(r, g, gp, out, iw, st);
       gstate = out.gstate;
       if (instr) memcpy(instr + ((size_t)ep * (size_t)n + (size_t)i) * INSTR_WORDS, iw, sizeof(uint64_t) * INSTR_WORDS);
       const size_t k = (size_t)ep * (size_t)n + (size_t)i;

@@ -17,15 +17,75 @@
 
 namespace mg {
 
-MG_HD bool lane_gen_kind(int kind) {
+// MG_LANE_WIDE = 1 (a VARIANT build: `python profiles/variant_build.py lanewide --units=mg_gen_lane.hip,mg_api.hip -DMG_LANE_WIDE=1`; the product library is built with 0): the lane kernels also
+// serve every level whose generator has a per-lane form -- all but MultiRoom (mg_gen.h: templated on the grid type, the per-lane forms pinned on the
+// CPU by tests/test_generators_cpu.py through mg_selftest_generate, which runs generate_episode_lane<R, true> below).  Written in round 4 after the
+// GPU budget was spent: NOT yet run on a GPU; profiles/r5_lane_wide.sh is the validation + measurement run for it.
+#ifndef MG_LANE_WIDE
+#define MG_LANE_WIDE 0
+#endif
+MG_HD bool lane_gen_kind_base(int kind) {
   return kind == 0 || kind == 1 || kind == 2 || kind == 3 || kind == 4 || kind == 5 || kind == 6 || kind == 7 ||
          kind == 16 || kind == 17 || kind == 18 || kind == 19 || kind == 20;
 }
+// the levels whose per-lane generator exists (GoToDoor 8 .. KeyCorridor 14, LockedRoom 21, Playground 22, the BabyAI levels 24-53)
+MG_HD bool lane_gen_kind_wide(int kind) { return lane_gen_kind_base(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 53); }
+MG_HD bool lane_gen_kind(int kind) { return MG_LANE_WIDE ? lane_gen_kind_wide(kind) : lane_gen_kind_base(kind); }
 MG_HD int lane_grid_stride(int CS) { return CS + 4; }                 // odd dword stride: the 64 lanes' grids start in different LDS banks
+constexpr int LANE_INSTR_STRIDE = INSTR_WORDS + 1;                    // u64 per lane: the sentence levels' instruction record under construction
+// LDS of one generating wavefront: 64 private grids (+ 64 instruction records, sentence levels of the wide build)
+MG_HD int lane_gen_lds_bytes(int CS, bool sentence) { return 64 * lane_grid_stride(CS) + ((MG_LANE_WIDE && sentence) ? 64 * LANE_INSTR_STRIDE * 8 : 0); }
 
-template <class R>
-MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
+// The wide build's kernels are instantiated PER GENERATOR FUNCTION (FN below; 0 = the product kernel with the single-room levels' switch): one kernel
+// carrying every generator needs 512 VGPRs and spills (measured at compile time, profiles/r4/lane_wide_build.txt) -- a lane-per-episode kernel lives on
+// its occupancy.  gen_babyai_levels (ten levels behind one run-time switch: 512 VGPRs and 1 KB of scratch even alone) is instantiated per LEVEL:
+// FN = 100 + kind, the kind a compile-time constant.
+MG_HD int lane_fn_of_kind(int kind) {
+  if (lane_gen_kind_base(kind)) return 0;
+  switch (kind) {
+    case 8: return 1; case 9: case 10: case 11: return 2; case 12: return 3; case 13: return 4; case 14: case 30: return 5; case 21: return 6;
+    case 22: return 7; case 24: case 25: case 27: return 8; case 26: return 9; case 28: return 10; case 29: return 11; case 31: return 12;
+    case 32: return 13; case 33: case 34: case 35: return 14; case 50: case 51: case 52: return 17; case 53: return 18;
+    default: return kind >= 36 && kind <= 45 ? 100 + kind : kind >= 46 && kind <= 49 ? 16 : -1;
+  }
+}
+
+// iw: the lane's instruction record (sentence levels), st: LevelGen's locked_room words {as the previous episode left it, scratch} -- WIDE only.
+// FN = 0: every generator the build serves behind a run-time switch (the product kernel; WIDE: the host selftest); FN > 0: that function alone.
+#define MG_LANE_FN(n) if constexpr (FN == 0 || FN == (n))
+template <class R, bool WIDE = false, int FN = 0>
+MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenResult& out, uint64_t* iw = nullptr, uint32_t* st = nullptr) {
   out.ax = out.ay = 1; out.dir = 0; out.mission = 0; out.retries = 0; out.failed = false; out.aux = 0;
+  if constexpr (WIDE) {
+    switch (P.kind) {
+      case 8: MG_LANE_FN(1) gen_gotodoor(rng, g, P, out); return;
+      case 9: MG_LANE_FN(2) gen_unlock_family(rng, g, P, out, 0); return;
+      case 10: MG_LANE_FN(2) gen_unlock_family(rng, g, P, out, 1); return;
+      case 11: MG_LANE_FN(2) gen_unlock_family(rng, g, P, out, 2); return;
+      case 12: MG_LANE_FN(3) gen_redbluedoors(rng, g, P, out); return;
+      case 13: MG_LANE_FN(4) gen_memory(rng, g, P, out); return;
+      case 14: MG_LANE_FN(5) gen_keycorridor(rng, g, P, out); return;
+      case 30: MG_LANE_FN(5) { gen_keycorridor(rng, g, P, out); out.mission = 2u; } return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
+      case 21: MG_LANE_FN(6) gen_lockedroom(rng, g, P, out); return;
+      case 22: MG_LANE_FN(7) gen_playground(rng, g, P, out); return;
+      case 24: case 25: case 27: MG_LANE_FN(8) gen_pickup_level(rng, g, P, out); return;
+      case 26: MG_LANE_FN(9) gen_openreddoor(rng, g, P, out); return;
+      case 28: MG_LANE_FN(10) gen_findobj(rng, g, P, out); return;
+      case 29: MG_LANE_FN(11) gen_unlocklocal(rng, g, P, out); return;
+      case 31: MG_LANE_FN(12) gen_obstructedmaze(rng, g, P, out); return;
+      case 32: MG_LANE_FN(13) gen_putnear(rng, g, P, out); return;
+      case 33: case 34: case 35: MG_LANE_FN(14) gen_babyai_maze(rng, g, P, out); return;
+      case 36: case 37: case 38: case 39: case 40: case 41: case 42: case 43: case 44: case 45: 
+        if constexpr (FN == 0) gen_babyai_levels(rng, g, P, out);
+        else if constexpr (FN >= 136 && FN <= 145) { GenParams Pk = P; Pk.kind = FN - 100; gen_babyai_levels(rng, g, Pk, out); }
+        return;
+      case 46: case 47: case 48: case 49: MG_LANE_FN(16) gen_babyai_put_open(rng, g, P, out); return;
+      case 50: case 51: case 52: MG_LANE_FN(17) gen_babyai_seq(rng, g, P, out, iw); return;
+      case 53: MG_LANE_FN(18) gen_levelgen(rng, g, P, out, iw, st); return;
+      default: break;
+    }
+    if constexpr (FN != 0) { out.failed = true; return; }
+  }
   switch (P.kind) {
     case 0: gen_empty(rng, g, P, out); return;
     case 1: gen_doorkey(rng, g, P, out); return;
@@ -41,8 +101,10 @@ MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenRes
 }
 
 // one lane: the episode of env e for ring slot `slot`
-template <class R>
-MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g) {
+#undef MG_LANE_FN
+
+template <class R, int FN = 0>
+MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g, uint64_t* iw = nullptr) {
   const size_t N = (size_t)A.N;
   const size_t se = (size_t)slot * N + (size_t)e;
   R rng;
@@ -55,6 +117,15 @@ MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g)
   if constexpr (R::kEpisodic) rng.begin_episode();
   GenResult out;
   out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
+  if constexpr (FN != 0) {
+    // LevelGen's locked_room: what this env's previous episode left (generate_one, mg_genk.h); the value before this slot's episode is kept for ring restarts
+    uint32_t st[2] = { 0u, 0u };
+    if (A.gstate) { st[0] = st[1] = A.gstate[e]; if (A.gsnap) A.gsnap[se] = st[0]; }
+    if (A.dst_instr) for (int k = 0; k < INSTR_WORDS; k++) iw[k] = 0ull;
+    generate_episode_lane<R, true, FN>(rng, g, A.gp, out, iw, st);
+    if (A.gstate) A.gstate[e] = out.gstate;
+    if (A.dst_instr) for (int k = 0; k < INSTR_WORDS; k++) A.dst_instr[se * INSTR_WORDS + (size_t)k] = iw[k];
+  } else
   generate_episode_lane(rng, g, A.gp, out);
   rng.store(A.rng, N, (size_t)e);
   // the grid: CS bytes per (slot, env), cells past W*H zero
@@ -70,9 +141,13 @@ MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g)
     }
   }
   Agent ag; ag.x = out.ax; ag.y = out.ay; ag.dir = out.dir; ag.carry = 0; ag.step = 0; ag.mission = out.mission; ag.flags = 0;
+  if constexpr (FN != 0) {          // (generate_one's record: PutNext's start_carrying, RoomGrid.place_agent's endless loop)
+    ag.carry = out.carry;
+    ag.flags = (out.carry ? FLAG_SHOW_TAKEN : 0u) | ((out.stuck && A.stuck_mode == 0) ? FLAG_STUCK : 0u);
+  }
   A.dst_agent[se] = agent_pack(ag);
   if (A.dst_aux) A.dst_aux[se] = out.aux;
-  if (out.failed) report_errors(A.err, (uint32_t)ERR_GENERATOR);
+  if (out.failed || (FN != 0 && out.stuck && A.stuck_mode == 1)) report_errors(A.err, (uint32_t)ERR_GENERATOR);
   unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * 64u + threadIdx.x) & (STAT_GEN_SLOTS - 1u));
   atomicAdd(&st[0], 1ull);
   if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
@@ -82,7 +157,8 @@ MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g)
 // per lane.  Few requests per wave on purpose: the lanes of a wave wait for each other in every rejection loop and every whole-map retry
 // (the wave runs as long as its unluckiest lane), and a generator is a chain of dependent 128-bit multiplies -- many short waves overlap,
 // one wave with 36 diverging lanes does not (GoToRedBall x 32 768: 10.1 us per step with one wave per segment, see profiles/r4/lane_refill.txt).
-template <class R>
+// (FN: the wide build's kernels, one per generator function -- lane_fn_of_kind; 0 = the product kernel)
+template <class R, int FN = 0>
 __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = (int)threadIdx.x;
@@ -91,6 +167,8 @@ __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
   if (w >= cnt) return;
   LaneGrid g;
   g.p = smem + lane * lane_grid_stride(A.CS); g.W = A.gp.W; g.H = A.gp.H; g.lane = lane; g.nonempty = 0; g.walls = 0;
+  uint64_t* iw = nullptr;
+  if constexpr (FN != 0) iw = (uint64_t*)(smem + 64 * lane_grid_stride(A.CS)) + lane * LANE_INSTR_STRIDE;
   const uint32_t* seg = A.seg + (size_t)sidx * A.seg_cap;
   for (int k = w + lane * A.wps; k < cnt; k += 64 * A.wps) {
     const int e = (int)seg[k];
@@ -100,7 +178,7 @@ __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
     uint32_t t = A.tail[e];
     if (h - t > A.ring_mask + 1u) { report_errors(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
     while (t != h) {
-      generate_one_lane<R>(A, e, t & A.ring_mask, g);
+      generate_one_lane<R, FN>(A, e, t & A.ring_mask, g, iw);
       t++;
     }
     A.tail[e] = t;
@@ -109,7 +187,7 @@ __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
 
 // Direct generation with one lane per env (explicit reset(seed=...): the live episode, then the ring slots; mg_set_rng): lane l of workgroup b
 // draws env 64 b + l.  The destination pointers are pre-offset to the ring slot by the host (gen_args), like k_generate's.
-template <class R>
+template <class R, int FN = 0>
 __global__ void __launch_bounds__(64) k_generate_lane(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = (int)threadIdx.x;
@@ -118,7 +196,9 @@ __global__ void __launch_bounds__(64) k_generate_lane(const GenArgs A) {
   if (A.mask && !A.mask[e]) return;
   LaneGrid g;
   g.p = smem + lane * lane_grid_stride(A.CS); g.W = A.gp.W; g.H = A.gp.H; g.lane = lane; g.nonempty = 0; g.walls = 0;
-  generate_one_lane<R>(A, e, 0u, g);
+  uint64_t* iw = nullptr;
+  if constexpr (FN != 0) iw = (uint64_t*)(smem + 64 * lane_grid_stride(A.CS)) + lane * LANE_INSTR_STRIDE;
+  generate_one_lane<R, FN>(A, e, 0u, g, iw);
 }
 
 }  // namespace mg

@@ -135,6 +135,7 @@ struct PhiloxStream {
     pos++;
     return v;
   }
+  MG_HD uint64_t next64() { const uint32_t lo = next32(), hi = next32(); return (uint64_t)lo | ((uint64_t)hi << 32); }   // (WavePhilox::next64's order)
   MG_HD void load(const uint64_t* base, size_t n, size_t i) {
     key = base[i]; episode = base[n + i];
     uint64_t bp = base[2 * n + i]; block = (uint32_t)(bp >> 8); pos = (uint32_t)(bp & 0xFF);
