@@ -1152,11 +1152,22 @@ MG_HD void gen_playground(R& rng, G& g, const GenParams& P, GenResult& out) {
 // longest chain until one has numRooms rooms.  A room is one word: tx | ty << 5 | sx << 10 | sy << 14 | ex << 18 |
 // ey << 23.  The chain being built lives at the start of the (not yet drawn) grid; what has to survive a restart from
 // a checkpoint -- numRooms, the best chain -- in the wave's scratch words: an N6 map can take > 1000 draws, more than one buffer.
-MG_D uint32_t mr_pack(int tx, int ty, int sx, int sy, int ex, int ey) {
+MG_HD uint32_t mr_pack(int tx, int ty, int sx, int sy, int ex, int ey) {
   return (uint32_t)tx | ((uint32_t)ty << 5) | ((uint32_t)sx << 10) | ((uint32_t)sy << 14) | ((uint32_t)ex << 18) | ((uint32_t)ey << 23);
 }
-template <class R>
-MG_D bool mr_try_room(R& rng, const GridRef& g, const GenParams& P, uint32_t* cur, int& n, int wall, int ex, int ey) {
+// (templated on the grid type like the other generators: one lane's form keeps the state words in registers -- a lane's stream never runs dry,
+// there is no restart -- and is pinned on the CPU by tests/test_generators_cpu.py)
+template <class G> MG_HD uint32_t mr_word(uint32_t v) { if constexpr (G::kWave) return uni32(v); else return v; }
+template <bool WAVE> struct MrState {
+  uint32_t* p;
+  MG_HD MrState(uint8_t* grid, int off) : p((uint32_t*)(grid + off)) {}
+};
+template <> struct MrState<false> {
+  uint32_t w[8]; uint32_t* p;
+  MG_HD MrState(uint8_t*, int) : p(w) {}
+};
+template <class R, class G>
+MG_HD bool mr_try_room(R& rng, const G& g, const GenParams& P, uint32_t* cur, int& n, int wall, int ex, int ey) {
   const int sx = rand_int(rng, 4, P.room_size + 1), sy = rand_int(rng, 4, P.room_size + 1);
   int tx, ty;
   if (n == 0) { tx = ex; ty = ey; }
@@ -1168,7 +1179,7 @@ MG_D bool mr_try_room(R& rng, const GridRef& g, const GenParams& P, uint32_t* cu
   if (tx + sx > g.W || ty + sy >= g.H) return false;
 #pragma unroll 1
   for (int k = 0; k + 1 < n; k++) {                    // roomList[:-1]
-    const uint32_t r = uni32(cur[k]);
+    const uint32_t r = mr_word<G>(cur[k]);
     const int rtx = (int)(r & 31u), rty = (int)((r >> 5) & 31u), rsx = (int)((r >> 10) & 15u), rsy = (int)((r >> 14) & 15u);
     const bool non_overlap = tx + sx < rtx || rtx + rsx <= tx || ty + sy < rty || rty + rsy <= ty;
     if (!non_overlap) return false;
@@ -1176,24 +1187,25 @@ MG_D bool mr_try_room(R& rng, const GridRef& g, const GenParams& P, uint32_t* cu
   cur[n++] = mr_pack(tx, ty, sx, sy, ex, ey);
   return true;
 }
-template <class R>
-MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) {
+template <class R, class G>
+MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W;
   uint32_t* cur = (uint32_t*)g.p;               // the chain under construction (<= 6 words)
-  uint32_t* st = (uint32_t*)(g.p + P.scratch_off);   // [0] numRooms, [1] rooms in the best chain, [2..7] the best chain
+  MrState<G::kWave> state(g.p, P.scratch_off);
+  uint32_t* st = state.p;                       // [0] numRooms, [1] rooms in the best chain, [2..7] the best chain
   int num_rooms, nbest;
   if (!out.resume) {
     num_rooms = rand_int(rng, P.num_crossings, P.num_dists + 1);
     nbest = 0;
     st[0] = (uint32_t)num_rooms; st[1] = 0u;
-  } else { num_rooms = (int)uni32(st[0]); nbest = (int)uni32(st[1]); }
+  } else { num_rooms = (int)mr_word<G>(st[0]); nbest = (int)mr_word<G>(st[1]); }
   while (nbest < num_rooms && !rng.dead()) {
     rng.checkpoint();                           // st[] is consistent with the stream position here
     int n = 0, wall = 2;                        // entryDoorWall of the newest room
     const int ex = rand_int(rng, 0, W - 2), ey = rand_int(rng, 0, W - 2);
     if (mr_try_room(rng, g, P, cur, n, wall, ex, ey)) {
       while (n < num_rooms && !rng.dead()) {
-        const uint32_t r = uni32(cur[n - 1]);
+        const uint32_t r = mr_word<G>(cur[n - 1]);
         const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
         bool placed = false;
 #pragma unroll 1
@@ -1213,7 +1225,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
     if (rng.dead()) return;                     // out of buffered draws inside this attempt: restart it from the checkpoint
     if (n > nbest) {
 #pragma unroll 1
-      for (int k = 0; k < n; k++) st[2 + k] = uni32(cur[k]);
+      for (int k = 0; k < n; k++) st[2 + k] = mr_word<G>(cur[k]);
       nbest = n; st[1] = (uint32_t)n;
     }
   }
@@ -1223,7 +1235,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
   uint32_t prev = 6u;                           // COLOR_NAMES index of the previous door, 6 = none yet
 #pragma unroll 1
   for (int idx = 0; idx < nbest; idx++) {
-    const uint32_t r = uni32(st[2 + idx]);
+    const uint32_t r = mr_word<G>(st[2 + idx]);
     const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
     for (int i = 0; i < sx; i++) { g.set(tx + i, ty, CELL_WALL_GREY); g.set(tx + i, ty + sy - 1, CELL_WALL_GREY); }
     for (int j = 0; j < sy; j++) { g.set(tx, ty + j, CELL_WALL_GREY); g.set(tx + sx - 1, ty + j, CELL_WALL_GREY); }
@@ -1234,7 +1246,7 @@ MG_D void gen_multiroom(R& rng, GridRef& g, const GenParams& P, GenResult& out) 
       prev = c;
     }
   }
-  const uint32_t r0 = uni32(st[2]), rl = uni32(st[2 + nbest - 1]);
+  const uint32_t r0 = mr_word<G>(st[2]), rl = mr_word<G>(st[2 + nbest - 1]);
   if (!place_agent(rng, g, (int)(r0 & 31u), (int)((r0 >> 5) & 31u), (int)((r0 >> 10) & 15u), (int)((r0 >> 14) & 15u), -1, out)) out.failed = true;
   int x, y;
   if (!place_obj(rng, g, CELL_GOAL, (int)(rl & 31u), (int)((rl >> 5) & 31u), (int)((rl >> 10) & 15u), (int)((rl >> 14) & 15u),

@@ -11,7 +11,7 @@ namespace mg {
                                    else hipLaunchKernelGGL((K<Pcg64Stream, n>), grid, dim3(64), lds, st, A); return true;
 #define MG_LANE_CASES(K) MG_LANE_CASE(K, 1) MG_LANE_CASE(K, 2) MG_LANE_CASE(K, 3) MG_LANE_CASE(K, 4) MG_LANE_CASE(K, 5) MG_LANE_CASE(K, 6) \
   MG_LANE_CASE(K, 7) MG_LANE_CASE(K, 8) MG_LANE_CASE(K, 9) MG_LANE_CASE(K, 10) MG_LANE_CASE(K, 11) MG_LANE_CASE(K, 12) MG_LANE_CASE(K, 13) \
-  MG_LANE_CASE(K, 14) MG_LANE_CASE(K, 16) MG_LANE_CASE(K, 17) MG_LANE_CASE(K, 18) \
+  MG_LANE_CASE(K, 14) MG_LANE_CASE(K, 16) MG_LANE_CASE(K, 17) MG_LANE_CASE(K, 18) MG_LANE_CASE(K, 19) \
   MG_LANE_CASE(K, 136) MG_LANE_CASE(K, 137) MG_LANE_CASE(K, 138) MG_LANE_CASE(K, 139) MG_LANE_CASE(K, 140) MG_LANE_CASE(K, 141) MG_LANE_CASE(K, 142) \
   MG_LANE_CASE(K, 143) MG_LANE_CASE(K, 144) MG_LANE_CASE(K, 145)
 static bool launch_refill_lane_fn(int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {

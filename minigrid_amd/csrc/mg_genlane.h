@@ -18,7 +18,7 @@
 namespace mg {
 
 // MG_LANE_WIDE = 1 (a VARIANT build: `python profiles/variant_build.py lanewide --units=mg_gen_lane.hip,mg_api.hip -DMG_LANE_WIDE=1`; the product library is built with 0): the lane kernels also
-// serve every level whose generator has a per-lane form -- all but MultiRoom (mg_gen.h: templated on the grid type, the per-lane forms pinned on the
+// serve every level whose generator has a per-lane form -- all of them (mg_gen.h: templated on the grid type, the per-lane forms pinned on the
 // CPU by tests/test_generators_cpu.py through mg_selftest_generate, which runs generate_episode_lane<R, true> below).  Written in round 4 after the
 // GPU budget was spent: NOT yet run on a GPU; profiles/r5_lane_wide.sh is the validation + measurement run for it.
 #ifndef MG_LANE_WIDE
@@ -28,8 +28,9 @@ MG_HD bool lane_gen_kind_base(int kind) {
   return kind == 0 || kind == 1 || kind == 2 || kind == 3 || kind == 4 || kind == 5 || kind == 6 || kind == 7 ||
          kind == 16 || kind == 17 || kind == 18 || kind == 19 || kind == 20;
 }
-// the levels whose per-lane generator exists (GoToDoor 8 .. KeyCorridor 14, LockedRoom 21, Playground 22, the BabyAI levels 24-53)
-MG_HD bool lane_gen_kind_wide(int kind) { return lane_gen_kind_base(kind) || (kind >= 8 && kind <= 14) || kind == 21 || kind == 22 || (kind >= 24 && kind <= 53); }
+// the levels whose per-lane generator exists (GoToDoor 8 .. KeyCorridor 14, LockedRoom 21, Playground 22, MultiRoom 23, the BabyAI levels 24-53):
+// every level but DynamicObstacles, whose episodes are drawn inside the step kernel (mg_dynobs.h)
+MG_HD bool lane_gen_kind_wide(int kind) { return lane_gen_kind_base(kind) || (kind >= 8 && kind <= 14) || (kind >= 21 && kind <= 53); }
 MG_HD bool lane_gen_kind(int kind) { return MG_LANE_WIDE ? lane_gen_kind_wide(kind) : lane_gen_kind_base(kind); }
 MG_HD int lane_grid_stride(int CS) { return CS + 4; }                 // odd dword stride: the 64 lanes' grids start in different LDS banks
 constexpr int LANE_INSTR_STRIDE = INSTR_WORDS + 1;                    // u64 per lane: the sentence levels' instruction record under construction
@@ -44,7 +45,7 @@ MG_HD int lane_fn_of_kind(int kind) {
   if (lane_gen_kind_base(kind)) return 0;
   switch (kind) {
     case 8: return 1; case 9: case 10: case 11: return 2; case 12: return 3; case 13: return 4; case 14: case 30: return 5; case 21: return 6;
-    case 22: return 7; case 24: case 25: case 27: return 8; case 26: return 9; case 28: return 10; case 29: return 11; case 31: return 12;
+    case 22: return 7; case 23: return 19; case 24: case 25: case 27: return 8; case 26: return 9; case 28: return 10; case 29: return 11; case 31: return 12;
     case 32: return 13; case 33: case 34: case 35: return 14; case 50: case 51: case 52: return 17; case 53: return 18;
     default: return kind >= 36 && kind <= 45 ? 100 + kind : kind >= 46 && kind <= 49 ? 16 : -1;
   }
@@ -68,6 +69,7 @@ MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenRes
       case 30: MG_LANE_FN(5) { gen_keycorridor(rng, g, P, out); out.mission = 2u; } return;     // BabyAI KeyCorridor (other.py:252-272): "pick up the ball"
       case 21: MG_LANE_FN(6) gen_lockedroom(rng, g, P, out); return;
       case 22: MG_LANE_FN(7) gen_playground(rng, g, P, out); return;
+      case 23: MG_LANE_FN(19) gen_multiroom(rng, g, P, out); return;
       case 24: case 25: case 27: MG_LANE_FN(8) gen_pickup_level(rng, g, P, out); return;
       case 26: MG_LANE_FN(9) gen_openreddoor(rng, g, P, out); return;
       case 28: MG_LANE_FN(10) gen_findobj(rng, g, P, out); return;

@@ -22,7 +22,7 @@ R = importlib.import_module("minigrid_amd.registry")      # (the package re-expo
 # LevelGen = GoToSeq, Synth*, MiniBoss, BossLevel*), whose instruction record is compared through its mission sentence
 SENTENCE_KINDS = {50, 51, 52, 53}
 LANE_KINDS = ({0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32}
-              | set(range(33, 50)) | SENTENCE_KINDS)
+              | set(range(33, 50)) | SENTENCE_KINDS | {23})          # 23: MultiRoom
 IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
 
 
