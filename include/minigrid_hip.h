@@ -351,13 +351,14 @@ MG_API int mg_selftest_prims(int32_t n, const uint32_t* a, const uint32_t* b, co
  * in/out (byte i = cell index y * W + x of obstacle i, list order).  mode[i]: 0 = nothing, 1 = the obstacle moves of one step(), 2 = reset()
  * (agent_start = (sx, sy, sdir), sx < 0: place_agent).  flags[i]: bit 0 a placement failed, bit 1 the grid changed, bit 2 not_clear.
  * philox: 0 = numpy PCG64 streams, 1 = Philox streams, 2 = PCG64 with every try taken through the rare-case (redo) path of the draw code. */
-/* MiniGridEnv.reset's _gen_grid of the single-room levels (envs/empty.py:97-114, doorkey.py:74-99, crossing.py:131-188, lavagap.py:100-135,
- * distshift.py, fourrooms.py, fetch.py, gotoobject.py, babyai/goto.py: GoToRedBall / GoToRedBallGrey / GoToRedBlueBall / GoToObj / GoToLocal) as the
- * lane-per-episode generator kernels run it on the env's numpy PCG64 stream (minigrid_amd/csrc/mg_genlane.h, mg_gen.h), on the host: n envs seeded
- * like reset(seed = seeds[i]), `episodes` consecutive episodes each.  grid (episodes, n, W, H, 3) u8, agent (episodes, n, 8) i32 (x, y, dir, 0, 0, 0,
- * 0, mission id), aux (episodes, n) u64, rng (episodes, n, 5) u64 = the stream after each episode (mg_get_rng's words), failed (episodes, n) u8,
- * instr: NULL or (episodes, n, 40) u64 (the sentence levels' instruction record).  Also serves the generators whose per-lane form exists
- * but is not yet used by the device kernels (every level except MultiRoom). */
+/* MiniGridEnv.reset's _gen_grid of every level (envs/<level>.py _gen_grid, e.g. empty.py:97-114, doorkey.py:74-99, crossing.py:131-188, multiroom.py:118-300;
+ * core/roomgrid.py; envs/babyai/<family>.py gen_mission + core/levelgen.py:24-211) as the lane-per-episode generator kernels run it on the env's numpy PCG64
+ * stream (minigrid_amd/csrc/mg_genlane.h generate_one_lane, mg_gen.h), on the host: n envs seeded like reset(seed = seeds[i]), `episodes`
+ * consecutive episodes each, drawn into host arrays laid out like the device's spare ring (one ring slot per episode) and read back:
+ * grid (episodes, n, W, H, 3) u8, agent (episodes, n, 8) i32 (x, y, dir, carried type, carried colour, record flags, step count, mission id),
+ * aux (episodes, n) u64, rng (episodes, n, 5) u64 = the stream after each episode (mg_get_rng's words), failed (episodes, n) u8,
+ * instr: NULL or (episodes, n, 40) u64 (the sentence levels' instruction record).  The product library's lane kernels serve the single-room
+ * levels; the others' per-lane forms run on the device in the MG_LANE_WIDE build (mg_genlane.h).  DynamicObstacles: mg_selftest_dynobs. */
 MG_API int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
                                 uint64_t* rng, uint8_t* failed, uint64_t* instr);
 /* MiniGridEnv.step (minigrid_env.py:525-595) + the level's own step rule (envs/<level>.py, e.g. fetch.py:162-175, unlock.py:90-98) as the step kernels run

@@ -1925,46 +1925,77 @@ int mg_selftest_dynobs(int32_t W, int32_t H, int32_t n_obst, int32_t sx, int32_t
   return MG_OK;
 }
 
-// generate_episode_lane (mg_genlane.h: the reference's _gen_grid of the single-room levels -- Empty, DoorKey, Crossing, LavaGap, DistShift, FourRooms,
-// Fetch, the single-room BabyAI GoTo levels, GoToObject -- as k_refill_lane / k_generate_lane run it, one lane per episode on the env's numpy PCG64
-// stream) on the host: n envs seeded like reset(seed = seeds[i]), `episodes` consecutive episodes each (the stream carries on, like autoresets).
-// Out: grid (episodes, n, W, H, 3) u8 and agent (episodes, n, 8) i32 in the state exchange format (x, y, dir, 0, 0, 0, 0, mission id), aux
-// (episodes, n) u64 (GoTo levels: the tracked positions), rng (episodes, n, 5) u64 = the stream words AFTER each episode, failed (episodes, n) u8,
-// instr: NULL or (episodes, n, INSTR_WORDS) u64 = the sentence levels' instruction record (LevelGen's locked_room carries from episode to episode).
+// The lane-per-episode generators (mg_genlane.h: the reference's _gen_grid of every level, as k_refill_lane / k_generate_lane run it -- one lane per
+// episode on the env's numpy PCG64 stream; the product library's kernels serve the single-room levels, the MG_LANE_WIDE build every level) on the host,
+// through the kernels' own per-lane body generate_one_lane: n envs seeded like reset(seed = seeds[i]), `episodes` consecutive episodes each into ring
+// slots 0 .. episodes - 1 of host arrays laid out like the device's spare ring (SoA stream words, the stream snapshot before each slot, 16-byte padded
+// grids, packed agent records, instruction records, LevelGen's carried state), then read back in the state exchange format:
+// grid (episodes, n, W, H, 3) u8, agent (episodes, n, 8) i32 (x, y, dir, carried type, carried colour, record flags, 0, mission id), aux
+// (episodes, n) u64 (GoTo levels: the tracked positions), rng (episodes, n, 5) u64 = the stream words AFTER each episode (= the snapshot before the
+// next slot; the stream itself after the last), failed (episodes, n) u8 = the generator error word, instr: NULL or (episodes, n, INSTR_WORDS) u64 =
+// the sentence levels' instruction records.
+}  // extern "C"
+template <int FN>
+static void selftest_generate_fn(const GenArgs& A, int n, int episodes, int W, int H) {
+  std::vector<uint8_t> lds((size_t)lane_grid_stride(A.CS) + 16);
+  std::vector<uint64_t> iw((size_t)LANE_INSTR_STRIDE + 1);
+  for (int i = 0; i < n; i++)
+    for (int ep = 0; ep < episodes; ep++) {
+      LaneGrid g;
+      g.p = lds.data(); g.W = W; g.H = H; g.lane = 0; g.nonempty = 0; g.walls = 0;
+      generate_one_lane<Pcg64Stream, FN>(A, i, (uint32_t)ep, g, iw.data());
+    }
+}
+extern "C" {
 int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, const uint64_t* seeds, uint8_t* grid, int32_t* agent, uint64_t* aux,
                          uint64_t* rng_words, uint8_t* failed, uint64_t* instr) {
   if (!cfg || n < 0 || episodes < 1 || !seeds || !grid || !agent || !aux || !rng_words || !failed) return MG_ERR_INVALID;
   if (cfg->width < 3 || cfg->height < 3 || cfg->width > 25 || cfg->height > 25 || !lane_gen_kind_wide(cfg->env_kind)) return MG_ERR_INVALID;
-  const GenParams gp = gen_params_of(*cfg);
-  const int W = gp.W, H = gp.H, cells = W * H, CS = (cells + 15) & ~15;
-  std::vector<uint8_t> buf((size_t)CS + 16);
-  for (int i = 0; i < n; i++) {
-    Pcg64Stream r;
-    r.seed(seeds[i]);
-    uint32_t gstate = 0;
-    for (int ep = 0; ep < episodes; ep++) {
-      LaneGrid g;
-      g.p = buf.data(); g.W = W; g.H = H; g.lane = 0; g.nonempty = 0; g.walls = 0;
-      GenResult out;
-      out.gstate = 0; out.stuck = 0; out.carry = 0; out.resume = 0;
-      uint64_t iw[INSTR_WORDS + 2] = { 0 };
-      uint32_t st[2] = { gstate, gstate };
-      generate_episode_lane<Pcg64Stream, true>(r, g, gp, out, iw, st);
-      gstate = out.gstate;
-      if (instr) memcpy(instr + ((size_t)ep * (size_t)n + (size_t)i) * INSTR_WORDS, iw, sizeof(uint64_t) * INSTR_WORDS);
-      const size_t k = (size_t)ep * (size_t)n + (size_t)i;
+  const size_t N = (size_t)n, E = (size_t)episodes;
+  GenArgs A;
+  memset(&A, 0, sizeof(A));
+  A.gp = gen_params_of(*cfg);
+  const int W = A.gp.W, H = A.gp.H, cells = W * H, CS = (cells + 15) & ~15;
+  const bool sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
+  std::vector<uint8_t> d_grid(E * N * CS + 16);
+  std::vector<uint64_t> d_agent(E * N + 1), d_rng(5 * N + 1), d_snap(E * 5 * N + 1), d_aux(E * N + 1), d_instr(sentence ? E * N * INSTR_WORDS : 1);
+  std::vector<uint32_t> d_gstate(N + 1), d_gsnap(E * N + 1), d_err(ERR_WORDS + 3);
+  std::vector<unsigned long long> d_counters(STAT_EPISODES + 2);
+  for (int i = 0; i < n; i++) { Pcg64Stream r; r.seed(seeds[i]); r.store(d_rng.data(), N, (size_t)i); }
+  A.dst_grid = d_grid.data(); A.dst_agent = d_agent.data(); A.rng = d_rng.data(); A.rng_snap = d_snap.data(); A.dst_aux = d_aux.data();
+  A.dst_instr = sentence ? d_instr.data() : nullptr; A.gstate = sentence ? d_gstate.data() : nullptr; A.gsnap = sentence ? d_gsnap.data() : nullptr;
+  A.err = d_err.data(); A.counters = d_counters.data(); A.N = n; A.CS = CS; A.stat_gen_off = STAT_EPISODES;
+  A.stuck_mode = (cfg->env_kind == MG_ENV_LEVELGEN && ((cfg->num_crossings >> 10) & 1)) ? 2 : 0;
+  switch (lane_fn_of_kind(cfg->env_kind)) {
+#define MG_ST_FN(k) case k: selftest_generate_fn<k>(A, n, episodes, W, H); break;
+    MG_ST_FN(0) MG_ST_FN(1) MG_ST_FN(2) MG_ST_FN(3) MG_ST_FN(4) MG_ST_FN(5) MG_ST_FN(6) MG_ST_FN(7) MG_ST_FN(8) MG_ST_FN(9) MG_ST_FN(10) MG_ST_FN(11)
+    MG_ST_FN(12) MG_ST_FN(13) MG_ST_FN(14) MG_ST_FN(16) MG_ST_FN(17) MG_ST_FN(18) MG_ST_FN(19) MG_ST_FN(136) MG_ST_FN(137) MG_ST_FN(138) MG_ST_FN(139)
+    MG_ST_FN(140) MG_ST_FN(141) MG_ST_FN(142) MG_ST_FN(143) MG_ST_FN(144) MG_ST_FN(145)
+#undef MG_ST_FN
+    default: return MG_ERR_INVALID;
+  }
+  if (d_counters[STAT_EPISODES] != (unsigned long long)(E * N)) return MG_ERR_GENERATOR;          // one generated map counted per (slot, env)
+  for (size_t ep = 0; ep < E; ep++)
+    for (size_t i = 0; i < N; i++) {
+      const size_t k = ep * N + i;
+      const uint8_t* src = d_grid.data() + k * CS;
+      for (int c = cells; c < CS; c++) if (src[c] != 0) return MG_ERR_GENERATOR;                   // (the padding past W * H reads zero)
       uint8_t* t3 = grid + k * cells * 3;
       for (int x = 0; x < W; x++) for (int y = 0; y < H; y++) {
-        const uint32_t tr = cell_triple((uint32_t)buf[y * W + x]);
+        const uint32_t tr = cell_triple((uint32_t)src[y * W + x]);
         uint8_t* t = t3 + ((size_t)x * H + y) * 3;
         t[0] = (uint8_t)tr; t[1] = (uint8_t)(tr >> 8); t[2] = (uint8_t)(tr >> 16);
       }
+      const Agent a = agent_unpack(d_agent[k]);
+      const uint32_t ct = a.carry ? cell_triple(a.carry) : 0u;
       int32_t* o = agent + k * 8;
-      o[0] = (int32_t)out.ax; o[1] = (int32_t)out.ay; o[2] = (int32_t)out.dir; o[3] = o[4] = o[5] = o[6] = 0; o[7] = (int32_t)out.mission;
-      aux[k] = out.aux; failed[k] = out.failed ? 1 : 0;
-      r.store(rng_words + k * 5, 1, 0);
+      o[0] = (int32_t)a.x; o[1] = (int32_t)a.y; o[2] = (int32_t)a.dir; o[3] = (int32_t)(ct & 255u); o[4] = (int32_t)((ct >> 8) & 255u);
+      o[5] = (int32_t)a.flags; o[6] = (int32_t)a.step; o[7] = (int32_t)a.mission;
+      aux[k] = d_aux[k]; failed[k] = d_err[1] ? 1 : 0;                                            // (word 1 = ERR_GENERATOR)
+      for (size_t w = 0; w < 5; w++) rng_words[k * 5 + w] = ep + 1 < E ? d_snap[(ep + 1) * 5 * N + w * N + i] : d_rng[w * N + i];
+      if (instr && sentence) memcpy(instr + k * INSTR_WORDS, d_instr.data() + k * INSTR_WORDS, sizeof(uint64_t) * INSTR_WORDS);
+      if (sentence && ep == 0 && d_gsnap[k] != 0u) return MG_ERR_GENERATOR;                       // (LevelGen's carried state before the first episode: none)
     }
-  }
   return MG_OK;
 }
 

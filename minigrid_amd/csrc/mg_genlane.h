@@ -105,8 +105,9 @@ MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenRes
 // one lane: the episode of env e for ring slot `slot`
 #undef MG_LANE_FN
 
+// (host-callable: mg_selftest_generate runs it on the CPU, ring slot by ring slot, against the oracle -- tests/test_generators_cpu.py)
 template <class R, int FN = 0>
-MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g, uint64_t* iw = nullptr) {
+MG_HD void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g, uint64_t* iw = nullptr) {
   const size_t N = (size_t)A.N;
   const size_t se = (size_t)slot * N + (size_t)e;
   R rng;
@@ -150,9 +151,14 @@ MG_D void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g,
   A.dst_agent[se] = agent_pack(ag);
   if (A.dst_aux) A.dst_aux[se] = out.aux;
   if (out.failed || (FN != 0 && out.stuck && A.stuck_mode == 1)) report_errors(A.err, (uint32_t)ERR_GENERATOR);
+#if defined(__HIP_DEVICE_COMPILE__)
   unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * 64u + threadIdx.x) & (STAT_GEN_SLOTS - 1u));
   atomicAdd(&st[0], 1ull);
   if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
+#else
+  unsigned long long* st = A.counters + A.stat_gen_off;
+  st[0] += 1ull; st[1] += (unsigned long long)out.retries;
+#endif
 }
 
 // A.wps wavefronts per request segment (= per 64-env step workgroup): wave w of a segment serves its requests w, w + wps, w + 2 wps, ... one

@@ -1,9 +1,12 @@
-"""The lane-per-episode map generators on the CPU (no GPU needed): mg_selftest_generate runs generate_episode_lane (minigrid_amd/csrc/mg_genlane.h,
-mg_gen.h -- the reference's _gen_grid of the single-room levels restated on one lane's byte grid and numpy-exact PCG64 stream; the code of
-k_refill_lane / k_generate_lane, which draw every spare episode of the four BASELINE.json configs) compiled for the host: from reset(seed)'s seeded
-stream, four consecutive episodes per env must reproduce the oracle's reset()s -- which are pinned to the reference's own generated episodes
-(tests/golden/gen_*.npz, tests/test_oracle_golden.py) -- cell by cell, with the agent's pose, the mission id and the stream position after every
-episode (a draw too many or too few anywhere shows up there at the latest).  Every registered id the lane generators serve."""
+"""The lane-per-episode map generators on the CPU (no GPU needed): mg_selftest_generate runs generate_one_lane (minigrid_amd/csrc/mg_genlane.h,
+mg_gen.h -- the reference's _gen_grid restated on one lane's byte grid and numpy-exact PCG64 stream; the per-lane body of k_refill_lane /
+k_generate_lane, which draw every spare episode of the four BASELINE.json configs) compiled for the host, into host arrays laid out like the
+device's spare ring: from reset(seed)'s seeded stream, four consecutive episodes per env (= four ring slots) must reproduce the oracle's
+reset()s -- which are pinned to the reference's own generated episodes (tests/golden/gen_*.npz, tests/test_oracle_golden.py) -- cell by cell,
+with the agent's pose, the object it starts with in its hands, the mission (id, or the instruction record's sentence) and the stream position
+after every episode (a draw too many or too few anywhere shows up there at the latest; read from the ring's stream snapshots).  Every
+registered id: the product library's lane kernels serve the single-room levels, the MG_LANE_WIDE build all of them (DynamicObstacles draws
+inside its step kernel: tests/test_abi_cpu.py)."""
 import ctypes as C
 
 import numpy as np
@@ -24,6 +27,9 @@ SENTENCE_KINDS = {50, 51, 52, 53}
 LANE_KINDS = ({0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20} | {8, 9, 10, 11, 12, 13, 14, 30} | {21, 22, 24, 25, 26, 27, 28, 29, 31, 32}
               | set(range(33, 50)) | SENTENCE_KINDS | {23})          # 23: MultiRoom
 IDS = sorted(i for i, s_ in R.registry.items() if s_.env_kind in LANE_KINDS)
+
+
+FLAG_SHOW_TAKEN = 16          # mg_device.h: the episode starts with an object in the agent's hands (PutNext start_carrying)
 
 
 def _cfg(s, n):
@@ -56,6 +62,8 @@ def test_lane_generators_on_the_host_equal_the_oracle(env_id):
         bad = np.argwhere((grid[ep] != g).reshape(n, -1).any(1)).ravel()
         assert bad.size == 0, (env_id, ep, bad[:5])
         assert (agent[ep][:, :3] == a[:, :3]).all(), (env_id, ep, "agent pose")
+        assert (agent[ep][:, 3:5] == a[:, 3:5]).all(), (env_id, ep, "carried object")
+        assert ((agent[ep][:, 5] & FLAG_SHOW_TAKEN != 0) == (a[:, 3] != 0)).all() and (agent[ep][:, 6] == 0).all(), (env_id, ep, "record flags / step count")
         if s.env_kind in SENTENCE_KINDS:                                            # the instruction tree, as the sentence the reference prints
             from minigrid_amd.sentence import decode
             got = [decode(int(w[37]), int(w[38])) for w in instr[ep]]
