@@ -355,6 +355,8 @@ def main(argv=None):
     ap.add_argument("--stub", action="store_true", help="no GPU: a stub env; exercises the launcher / barriers / JSON line only")
     args = ap.parse_args(argv)
 
+    if not args.stub and "minigrid_emu" in os.path.basename(os.environ.get("MINIGRID_AMD_LIB", "")):
+        raise SystemExit("bench.py: MINIGRID_AMD_LIB points at the host emulator of tests/emu (test infrastructure): nothing to measure")
     have_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not have_launcher:
         raise SystemExit(spawn_ranks(args, argv))
@@ -402,6 +404,8 @@ def main(argv=None):
     if use_gpu:
         from minigrid_amd import _binding
         build_info = _binding.load().mg_build_info().decode()
+        if "emulator=1" in build_info:
+            raise SystemExit("bench.py: MINIGRID_AMD_LIB points at the host emulator of tests/emu (test infrastructure): nothing to measure")
     fused = bool(args.fused)
     spl = min(env.max_fused_steps, args.steps) if fused else 1          # steps per k_step launch in the timed region
     env.reset(seed=0)

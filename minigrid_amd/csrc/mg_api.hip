@@ -922,7 +922,11 @@ const char* mg_build_info(void) {
 #endif
 #define MG_BI_STR2(x) #x
 #define MG_BI_STR(x) MG_BI_STR2(x)
+#ifdef MG_EMU      // tests/emu: these sources compiled for the host SIMT emulator -- test infrastructure; bench.py and smoke() refuse such a library
+  return "attribution=" MG_BI_ATTR ";encode_quads=" MG_BI_STR(MG_ENCODE_QUADS) ";lane_wide=" MG_BI_STR(MG_LANE_WIDE) ";arch=host;emulator=1";
+#else
   return "attribution=" MG_BI_ATTR ";encode_quads=" MG_BI_STR(MG_ENCODE_QUADS) ";lane_wide=" MG_BI_STR(MG_LANE_WIDE) ";arch=gfx950";
+#endif
 }
 
 int mg_device_count(void) {

@@ -94,10 +94,14 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     GenParams gp = A.gp;
     gp.scratch_off = gen_wave_lds_bytes(A.CS, A.cap_words) - GEN_SCRATCH_BYTES;
     gp.instr_off = gp.scratch_off + GEN_SCRATCH_BYTES;
+#ifndef MG_EMU      // (the host emulator of tests/emu compiles these sources as plain C++: no register-class constraints there)
     asm volatile("" : "+s"(gp.kind), "+s"(gp.W), "+s"(gp.H), "+s"(gp.start_x), "+s"(gp.start_y), "+s"(gp.start_dir));
     asm volatile("" : "+s"(gp.num_crossings), "+s"(gp.obstacle_cell), "+s"(gp.num_dists), "+s"(gp.strip2_row), "+s"(gp.room_size), "+s"(gp.random_length), "+s"(gp.scratch_off));
+#endif
     g.W = gp.W; g.H = gp.H;
+#ifndef MG_EMU
     asm volatile("" : "+v"(g.p), "+v"(g.lane));
+#endif
     generate_episode<GG>(rng, g, gp, out);
     MG_STAMP(4);
     out.retries += retries_before;

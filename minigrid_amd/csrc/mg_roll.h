@@ -44,6 +44,26 @@
 #define MG_MARK(name) do { } while (0)
 #endif
 
+// LDS words addressed by their LDS offset (the dynamic LDS of k_roll7 starts at LDS address 0): the inter-wave counters of the split loops.
+// (tests/emu compiles these sources for the host: there the LDS is an ordinary array)
+// MG_WAVE_ORDER: the DS operations of one wave execute in order, so between "the wave wrote" and "the wave (or a polling neighbour) reads" only
+// the compiler has to be kept from reordering.  (tests/emu: a lane runs ahead of its neighbours between cross-lane operations -- a wave barrier there)
+// MG_LOCKSTEP: places that rely on the wave executing in lockstep with nothing for the compiler to be told (empty in the product build).
+#ifndef MG_EMU
+#define MG_WAVE_ORDER() asm volatile("" ::: "memory")
+#define MG_LOCKSTEP() do { } while (0)
+#else
+#define MG_WAVE_ORDER() emu_wave_barrier()
+#define MG_LOCKSTEP() emu_wave_barrier()
+#endif
+#ifndef MG_EMU
+#define MG_LDS_VU32 __attribute__((address_space(3))) volatile uint32_t
+#define MG_LDS_AT(off) ((MG_LDS_VU32*)(uintptr_t)(uint32_t)(off))
+#else
+#define MG_LDS_VU32 volatile uint32_t
+#define MG_LDS_AT(off) ((MG_LDS_VU32*)(smem + (off)))
+#endif
+
 namespace mg {
 
 // ---- VALU primitives with host equivalents ----
@@ -404,7 +424,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const size_t N = (size_t)P.N;
   uint32_t* slut = (uint32_t*)smem;
   // obs7_quad / obs7_chunk address the table by absolute LDS offsets: it must sit at LDS address 0 (no static LDS in this kernel)
+#ifndef MG_EMU
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
+#endif
   // share (one-step launches, Env.step): there is nothing to split in time, so ONE wave runs the step up to the staged codes and ALL waves
   // of the workgroup share the output-space encode behind one barrier (a quarter of the 784 cell quads each); the stepping wave owns the state.
   // Which wave steps rotates with the workgroup index (P.share - 1 = the shift): the workgroups resident on one CU then step on different
@@ -577,7 +599,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t* gb = (uint32_t*)(sgrid + b * GS);
           for (int k = lane; k < (CS >> 2); k += 64) gb[k] = tm[k];
         }
-        asm volatile("" ::: "memory");                                 // (DS operations of a wave execute in order: the lanes below read what the wave wrote)
+        MG_WAVE_ORDER();                                 // (DS operations of a wave execute in order: the lanes below read what the wave wrote)
       }
       if (move) {
         // `not_clear` (dynamicobstacles.py:142-144): what is in front of the agent BEFORE the obstacles move
@@ -788,6 +810,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
     }
+    if constexpr (FULL) if (parts == 3) MG_LOCKSTEP();
     if constexpr (FULL) if (active && !share && parts == 3) codes[gt_pos] = (uint8_t)gt_old;     // (in order behind the chunk reads)
     MG_MARK("step_end");
     // (no wait here: the LDS pipe is in order, so the next step's staging writes cannot pass this step's chunk reads)
@@ -849,8 +872,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the instructions) to a second wave shortens the chain and puts a second wave on every SIMD without a second copy of the 22 x 22 grids.
     // FullyObs (round 4): what is staged is a COPY of the dynamics wave's image-order stream with the agents' cells patched in (64 x W*H bytes,
     // a handful of 16-byte LDS moves per lane) -- the time split's second wave replayed every step's dynamics, resets and re-imaging included.
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps staged, [1 + k] = steps encode wave k has written out
+    typedef MG_LDS_VU32 lds_vu32;
+    lds_vu32* sync = MG_LDS_AT(P.off_log);                 // [0] = steps staged, [1 + k] = steps encode wave k has written out
     uint8_t* ring = smem + P.off_T + (FULL ? P.codes_stride : 0);              // (FullyObs: behind the dynamics wave's own stream)
     const int NE = NW - 1;
     if (wave == dw) {
@@ -864,7 +887,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[1 + kq]) < mq + 1u) __builtin_amdgcn_s_sleep(1);
           if (++kq == NE) { kq = 0; mq++; }
         }
-        asm volatile("" ::: "memory");
+        MG_WAVE_ORDER();
         if constexpr (FULL) {
           full_follow();
           // the stream as this step's observation shows it: the agent's own cell reads (10, 0, dir) (wrappers.py:422-424)
@@ -880,7 +903,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         } else
         observe(0, a, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 1);
         // (DS operations of one wave execute in order: the counter cannot become visible before the codes)
-        asm volatile("" ::: "memory");
+        MG_WAVE_ORDER();
         sync[0] = (uint32_t)(j + 1);
       }
     } else {
@@ -889,10 +912,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       Agent av = agent_unpack(0ull);
       for (int j = k; j < P.T; j += NE) {
         while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        MG_WAVE_ORDER();
         observe(slot_of(j), av, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 2);
         MG_LDS_SYNC();                                                          // the staging's last read has returned
-        asm volatile("" ::: "memory");
+        MG_WAVE_ORDER();
         sync[1 + k] = ++done;
       }
       return;        // (nothing to report, no state to write back: the dynamics wave owns both)
@@ -904,8 +927,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // profiles/r4/attribution.txt); here the dynamics run once.
     // (an LDS-typed pointer: through a generic `volatile uint32_t*` the compiler emits FLAT loads / stores with system scope, which also
     // count on vmcnt; the dynamic LDS starts at LDS address 0, checked above)
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;                 // [0] = steps logged, [1 + k] = entries encode wave k has consumed
+    typedef MG_LDS_VU32 lds_vu32;
+    lds_vu32* sync = MG_LDS_AT(P.off_log);                 // [0] = steps logged, [1 + k] = entries encode wave k has consumed
     uint2* logbuf = (uint2*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES);
     // the dynamics wave is the one serial chain everything else waits for: it wins issue arbitration against the encode waves on its SIMD
     // (profiles/r4/ab_prio.txt: 2.42 -> 2.28 us per 65 536-env step)
@@ -933,20 +956,20 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
       // (DS operations of one wave execute in order: the counter cannot become visible before the entry; the compiler must keep that order)
-      asm volatile("" ::: "memory");
+      MG_WAVE_ORDER();
       sync[0] = (uint32_t)(j + 1);
     }
   } else {
     // ---- ENCODE waves: wave k + 1 keeps its own copy of the 64 grids current from the log (a byte write per step, a reset now and then)
     // and produces the observations of steps j = k, k + NE, k + 2 NE, ...
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    lds_vu32* sync = (lds_vu32*)(uintptr_t)(uint32_t)P.off_log;
+    typedef MG_LDS_VU32 lds_vu32;
+    lds_vu32* sync = MG_LDS_AT(P.off_log);
     const uint2* logbuf = (const uint2*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES);
     const int k = ek, NE = NW - 1;
     int mine = k;                                                      // next step this wave produces
     for (int j = 0; j < P.T; j++) {
       while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
+      MG_WAVE_ORDER();
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
       const uint32_t delta = rec2.y;
       const uint32_t rk = (delta >> 18) & 3u;
@@ -966,7 +989,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
       if (delta & (1u << 30)) mygrid[delta & 0x3FFu] = (uint8_t)(delta >> 10);
-      asm volatile("" ::: "memory");
+      MG_WAVE_ORDER();
       sync[1 + k] = (uint32_t)(j + 1);                                 // (in order behind the entry's read)
       if (j != mine) continue;
       mine += NE;

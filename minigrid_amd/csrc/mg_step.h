@@ -203,7 +203,11 @@ struct StreamEmit {
 // for every global store still in flight: inside the T-step loop that would serialise each step behind the previous step's
 // observation stores (measured: 4.2 us per step instead of the store stream's own pace).  DS operations of one wave
 // execute in order, so a compiler barrier plus an LDS-counter wait is all the hand-off needs.
+#ifndef MG_EMU
 #define MG_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define MG_LDS_SYNC() emu_wave_barrier()      // (tests/emu: the lanes of a wave run one after the other between cross-lane operations)
+#endif
 
 // The agent's view for any odd view size V <= 15 (ViewSizeWrapper; the default 7x7x3 view runs k_roll7, mg_roll.h), the one-hot
 // encode (MODE 2) and the RGB tile map (MODE 4):

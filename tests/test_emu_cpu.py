@@ -1,0 +1,99 @@
+"""The REAL kernels on the CPU (no GPU needed): tests/emu compiles the product's HIP sources (minigrid_amd/csrc/*.hip, unchanged) as plain C++
+against a stand-in <hip/hip_runtime.h> and runs them on a host SIMT emulator -- one fiber per lane, cross-lane operations (__ballot, __shfl,
+readfirstlane, the sources' LDS hand-off markers, __syncthreads, s_sleep) resolved per wavefront, LDS an array, streams in enqueue order
+(tests/emu/emu_runtime.cpp).  Through the ordinary Python facade and C ABI (MINIGRID_AMD_LIB -> the emulated library, in a subprocess) this
+runs mg_create / reset / fused rollouts / single steps: the generator kernels and their ring protocol, every loop shape of k_roll7 (one wave, the
+time split, the LOG split with its LDS step log, the STAGED split of DynamicObstacles / FullyObs / the sentence levels, the shared encode of
+one-step launches), NEXT_STEP and in-kernel SAME_STEP autoreset -- against the oracle: every slot's image, reward bytes, flags, direction,
+mission, then the final state and every env's stream position.  What the per-function host selftests (test_abi_cpu / test_transition_cpu /
+test_verifier_cpu / test_generators_cpu) cannot see -- the wave-level plumbing -- is what this file adds on the CPU; the GPU suite stays the
+parity gate (timing, memory ordering and register limits are not modelled).
+
+The second half runs the MG_LANE_WIDE variant of the generator kernels (mg_genlane.h: one lane per episode for EVERY level, written after
+round 4's GPU minutes were spent): its kernels have not run on a GPU yet -- here they do run, for 30 levels of every kernel group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+PRODUCT_CASES = [
+    # the four BASELINE.json levels: fused launches of the driver's lengths, every split width, resets in nearly every step, then single steps
+    {"env": "MiniGrid-Empty-8x8-v0", "n": 200, "launches": [5, 20, 32], "max_steps": 11, "stepped": 5},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 130, "launches": [32, 7], "max_steps": 4, "knobs": {"MG_ROLL_NW": "4"}, "stepped": 3},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 130, "launches": [32, 7], "max_steps": 4, "knobs": {"MG_ROLL_NW": "3"}},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 130, "launches": [32, 7], "max_steps": 4, "knobs": {"MG_ROLL_NW": "2"}},
+    {"env": "MiniGrid-Empty-8x8-v0", "n": 100, "launches": [32], "max_steps": 5, "knobs": {"MG_ROLL_NW": "1"}},
+    {"env": "MiniGrid-Empty-8x8-v0", "n": 100, "launches": [32], "max_steps": 5, "knobs": {"MG_ROLL_SPLIT": "0", "MG_ROLL_NW": "4"}},
+    {"env": "BabyAI-GoToRedBall-v0", "n": 100, "launches": [32, 13], "max_steps": 3},
+    {"env": "MiniGrid-LavaCrossingS9N1-v0", "n": 100, "launches": [32, 5, 20], "full": True, "stepped": 3},
+    {"env": "MiniGrid-LavaCrossingS9N1-v0", "n": 100, "launches": [32, 5], "full": True, "knobs": {"MG_FULL_SPLIT": "0"}},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 100, "launches": [32, 5], "full": True, "max_steps": 9, "stepped": 3},
+    # DynamicObstacles inside the fused kernel, SAME_STEP autoreset inside the kernels
+    {"env": "MiniGrid-Dynamic-Obstacles-6x6-v0", "n": 100, "launches": [5, 20, 3], "stepped": 3},
+    {"env": "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", "n": 70, "launches": [20, 3], "autoreset": "same_step"},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [20, 3], "max_steps": 5, "autoreset": "same_step", "stepped": 4},
+    # other single-room levels of the lane generators
+    {"env": "MiniGrid-FourRooms-v0", "n": 70, "launches": [32, 13], "max_steps": 20},
+    {"env": "MiniGrid-Fetch-8x8-N3-v0", "n": 70, "launches": [32, 13], "max_steps": 20, "stepped": 3},
+    {"env": "BabyAI-GoToLocal-v0", "n": 70, "launches": [32, 13], "max_steps": 10},
+]
+_W = lambda env, n=40, **kw: dict({"env": env, "n": n, "launches": [32], "max_steps": 10}, **kw)
+WIDE_CASES = [
+    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 100, "launches": [32, 7], "max_steps": 12, "stepped": 3},
+    {"env": "BabyAI-BossLevel-v0", "n": 70, "launches": [32, 7], "stepped": 3},
+    {"env": "BabyAI-BossLevel-v0", "n": 70, "launches": [20, 3], "autoreset": "same_step", "stepped": 3},
+    {"env": "BabyAI-GoToSeqS5R2-v0", "n": 70, "launches": [32, 32, 32, 32]},            # (episodes end by success / their own step limit: refills)
+    _W("BabyAI-SynthS5R2-v0", 70), _W("BabyAI-MiniBossLevel-v0", 70),
+    _W("BabyAI-MoveTwoAcrossS5N2-v0", 70, max_steps=8), _W("BabyAI-OpenTwoDoors-v0", 70, max_steps=8), _W("BabyAI-OpenDoorsOrderN4-v0", 70, max_steps=8),
+    {"env": "MiniGrid-MultiRoom-N6-v0", "n": 70, "launches": [32, 7], "max_steps": 10},
+    _W("MiniGrid-MemoryS7-v0", 70, max_steps=5), _W("BabyAI-PutNextS5N2Carrying-v0", 70, max_steps=4), _W("MiniGrid-UnlockPickup-v0", 70),
+    _W("MiniGrid-BlockedUnlockPickup-v0", 70), _W("MiniGrid-GoToDoor-8x8-v0", 70, max_steps=6), _W("MiniGrid-RedBlueDoors-8x8-v0", 70),
+    _W("MiniGrid-LockedRoom-v0"), _W("MiniGrid-Playground-v0"), _W("MiniGrid-ObstructedMaze-Full-v1"), _W("MiniGrid-PutNear-8x8-N3-v0", 70, max_steps=5),
+    _W("BabyAI-GoTo-v0"), _W("BabyAI-Pickup-v0"), _W("BabyAI-UnblockPickup-v0"), _W("BabyAI-KeyInBox-v0"), _W("BabyAI-PutNextS7N4-v0"),
+    _W("BabyAI-ActionObjDoor-v0"), _W("BabyAI-FindObjS5-v0"), _W("BabyAI-UnlockLocal-v0"), _W("BabyAI-PickupDist-v0"), _W("BabyAI-OpenRedDoor-v0"),
+    _W("BabyAI-KeyCorridorS4R3-v0"),
+    # the single-room levels keep the product kernel (FN = 0) in the wide build
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [32], "max_steps": 4},
+]
+
+
+def _run(defines, cases):
+    import build_emu
+    lib = build_emu.build(defines)
+    env = dict(os.environ, MINIGRID_AMD_LIB=lib, MINIGRID_AMD_NO_TORCH="1")
+    for k in [k for k in env if k.startswith("MG_")]:
+        del env[k]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_cases.py"), json.dumps(cases)], env=env, capture_output=True, text=True,
+                         timeout=900)
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == len(cases), (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    bad = [(r["case"], r.get("error"), r.get("where")) for r in lines if not r["ok"]]
+    assert not bad, bad
+    return lines
+
+
+def test_product_kernels_on_the_emulator_equal_the_oracle():
+    lines = _run([], PRODUCT_CASES)
+    assert sum(r["episodes"] for r in lines) > 5000         # the cases are reset-heavy on purpose: spares taken, rings refilled
+
+
+def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
+    lines = _run(["-DMG_LANE_WIDE=1"], WIDE_CASES)
+    assert sum(r["episodes"] for r in lines) > 4000
+
+
+def test_the_product_never_loads_the_emulator():
+    """The emulated library is test infrastructure: it says so in mg_build_info(), and bench.py refuses it."""
+    import build_emu
+    lib = build_emu.build([])
+    env = dict(os.environ, MINIGRID_AMD_LIB=lib, MINIGRID_AMD_NO_TORCH="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode != 0 and "emulator" in (out.stderr + out.stdout)
+    from minigrid_amd import _binding as B
+    assert b"emulator=1" not in B.load().mg_build_info()
