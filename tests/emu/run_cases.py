@@ -5,7 +5,7 @@
     MINIGRID_AMD_LIB=tests/emu/_build/libminigrid_emu.so MINIGRID_AMD_NO_TORCH=1 python tests/emu/run_cases.py '<json list of cases>'
 
 A case: {"env": id, "n": envs, "launches": [T, ...], "full": bool, "max_steps": k | null, "knobs": {"MG_...": "v"}, "stepped": steps,
-"autoreset": "next_step" | "same_step"}: reset(seed=0), then fused launches of the given lengths under the device's Philox policy -- every slot's
+"autoreset": "next_step" | "same_step", "obs_mode": ..., "view": ViewSizeWrapper's size, "spare_ring": R}: reset(seed=0), then fused launches of the given lengths under the device's Philox policy -- every slot's
 image, reward bytes, flags, direction, mission (id or sentence) against the oracle -- then `stepped` single steps with caller actions, then the
 final state and every env's stream position."""
 import json
@@ -30,8 +30,13 @@ def run_case(c):
         env_id, n, full = c["env"], int(c["n"]), bool(c.get("full", False))
         kw = {} if c.get("max_steps") is None else {"max_steps": int(c["max_steps"])}
         mode = c.get("autoreset", "next_step")
-        env = mg.make_vec(env_id, n, obs_mode="full" if full else "partial", autoreset_mode=mode, **kw)
-        orc = ParOracle(env_id, n, full, threads=1, **kw)
+        obs_mode = c.get("obs_mode", "full" if full else "partial")               # partial | full | onehot | symbolic | rgb | rgb_partial
+        view = int(c.get("view", 7))
+        mk = dict(kw)
+        if c.get("spare_ring"):
+            mk["spare_ring"] = int(c["spare_ring"])
+        env = mg.make_vec(env_id, n, obs_mode=obs_mode, autoreset_mode=mode, agent_view_size=view, **mk)
+        orc = ParOracle(env_id, n, full, threads=1, obs=obs_mode, view_size=view, **kw)
         ar = 2 if mode == "same_step" else 1
         obs, _ = env.reset(seed=0)
         assert (obs["image"] == orc.reset(0)[0]).all(), "reset image"

@@ -41,6 +41,25 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-FourRooms-v0", "n": 70, "launches": [32, 13], "max_steps": 20},
     {"env": "MiniGrid-Fetch-8x8-N3-v0", "n": 70, "launches": [32, 13], "max_steps": 20, "stepped": 3},
     {"env": "BabyAI-GoToLocal-v0", "n": 70, "launches": [32, 13], "max_steps": 10},
+    # k_step: the other observation modes (one-hot, symbolic, ViewSizeWrapper, FullyObs above 341 cells), DynamicObstacles' round-3 launches
+    # (live refill + k_move_obstacles) under FullyObs, RGB frames (tile map + k_render)
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "obs_mode": "onehot", "stepped": 3},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "obs_mode": "symbolic", "stepped": 3},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "view": 5, "stepped": 3},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "view": 9},
+    {"env": "MiniGrid-FourRooms-v0", "n": 40, "launches": [16], "max_steps": 20, "full": True, "stepped": 3},
+    {"env": "MiniGrid-Dynamic-Obstacles-6x6-v0", "n": 70, "launches": [8], "full": True, "stepped": 4},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 20, "launches": [], "max_steps": 6, "obs_mode": "rgb", "stepped": 8},
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 20, "launches": [], "max_steps": 6, "obs_mode": "rgb_partial", "stepped": 8},
+    # the wavefront-per-episode generators (k_generate / k_refill: WavePcg64's jumped-ahead draws, ballots over the cells, the draw-budget restarts)
+    # of every generator group, a handful of envs with a ring of four so that refills happen; the sentence levels' k_roll7 with the verifier
+    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
+    {"env": "MiniGrid-MemoryS7-v0", "n": 6, "launches": [16, 16], "max_steps": 4, "spare_ring": 4},
+    {"env": "MiniGrid-MultiRoom-N4-S5-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
+    {"env": "BabyAI-PutNextS5N2Carrying-v0", "n": 6, "launches": [16, 16], "max_steps": 4, "spare_ring": 4},
+    {"env": "BabyAI-GoToObjMaze-v0", "n": 4, "launches": [16], "max_steps": 6, "spare_ring": 4},
+    {"env": "BabyAI-MiniBossLevel-v0", "n": 4, "launches": [16], "spare_ring": 4, "stepped": 3},
+    {"env": "BabyAI-BossLevel-v0", "n": 4, "launches": [16], "spare_ring": 4, "autoreset": "same_step"},
 ]
 _W = lambda env, n=40, **kw: dict({"env": env, "n": n, "launches": [32], "max_steps": 10}, **kw)
 WIDE_CASES = [
