@@ -156,8 +156,9 @@ MG_HD void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g
   atomicAdd(&st[0], 1ull);
   if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
 #else
+  // (host form: mg_selftest_generate -- and tests/emu, where the lanes of a launch are fibers and the thread sanitizer watches: atomics there too)
   unsigned long long* st = A.counters + A.stat_gen_off;
-  st[0] += 1ull; st[1] += (unsigned long long)out.retries;
+  __atomic_fetch_add(&st[0], 1ull, __ATOMIC_RELAXED); __atomic_fetch_add(&st[1], (unsigned long long)out.retries, __ATOMIC_RELAXED);
 #endif
 }
 

@@ -56,11 +56,23 @@
 #define MG_WAVE_ORDER() emu_wave_barrier()
 #define MG_LOCKSTEP() emu_wave_barrier()
 #endif
+// MG_MASKED_READS: obs7_view reads a view line as three aligned dwords; where the line leaves the grid those dwords hold a NEIGHBOUR env's cells
+// (or a guard band) and every such byte is replaced by a wall before use.  The thread-sanitizer build of tests/emu is told that these reads are
+// deliberate (another lane may be writing its own grid at that moment: the value is never used); empty everywhere else.
+#if defined(MG_EMU) && defined(MG_EMU_TSAN)
+extern "C" void AnnotateIgnoreReadsBegin(const char* file, int line);
+extern "C" void AnnotateIgnoreReadsEnd(const char* file, int line);
+#define MG_MASKED_READS_BEGIN(outside) const bool mg_masked_ = (outside); if (mg_masked_) AnnotateIgnoreReadsBegin(__FILE__, __LINE__)
+#define MG_MASKED_READS_END() if (mg_masked_) AnnotateIgnoreReadsEnd(__FILE__, __LINE__)
+#else
+#define MG_MASKED_READS_BEGIN(outside) do { } while (0)
+#define MG_MASKED_READS_END() do { } while (0)
+#endif
 #ifndef MG_EMU
 #define MG_LDS_VU32 __attribute__((address_space(3))) volatile uint32_t
 #define MG_LDS_AT(off) ((MG_LDS_VU32*)(uintptr_t)(uint32_t)(off))
 #else
-#define MG_LDS_VU32 volatile uint32_t
+#define MG_LDS_VU32 ::emu::SyncWord             /* (release store / acquire load: what "volatile LDS word + in-order DS operations" means to a host compiler) */
 #define MG_LDS_AT(off) ((MG_LDS_VU32*)(smem + (off)))
 #endif
 
@@ -193,7 +205,9 @@ MG_HD void obs7_view(const Agent& a, const uint8_t* mygrid, int W, int H, bool s
     const int off = off0 + t * lstep;
     const uint32_t* ap = (const uint32_t*)(mygrid + (off & ~3));
     const uint32_t sh = (uint32_t)off & 3u;
+    MG_MASKED_READS_BEGIN((off & ~3) < 0 || (off & ~3) + 12 > W * H);
     const uint32_t d0 = ap[0], d1 = ap[1], d2 = ap[2];
+    MG_MASKED_READS_END();
     const uint32_t rlo = funnel_bytes(d1, d0, sh), rhi = funnel_bytes(d2, d1, sh);
     const uint32_t on = 0u - ((lm >> t) & 1u);
     const uint32_t ml = bm_lo & on, mh = bm_hi & on;

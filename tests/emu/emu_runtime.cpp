@@ -23,9 +23,53 @@
 #include <cstring>
 #include <vector>
 
-namespace mg { alignas(256) uint8_t smem[160 * 1024]; }        // the workgroup's LDS (`extern __shared__ uint8_t smem[]` in the kernels)
+// (thread sanitizer: THIS file is compiled without -fsanitize=thread but with -DEMU_TSAN=1 -- the scheduler's own state is shared by every fiber by
+// design; the kernels, the library's host code and emu_probe.cpp are instrumented)
+// ---- sanitizer builds (build_emu.py --sanitize=...): the fibers announced to the runtime, exact-sized device buffers, the unused LDS poisoned ----
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#endif
+#if __has_feature(thread_sanitizer) && !defined(EMU_TSAN)
+#define EMU_TSAN 1
+#endif
+#endif
+#if defined(__SANITIZE_ADDRESS__) && !defined(EMU_ASAN)
+#define EMU_ASAN 1
+#endif
+#if defined(__SANITIZE_THREAD__) && !defined(EMU_TSAN)
+#define EMU_TSAN 1
+#endif
+#ifdef EMU_ASAN
+extern "C" {
+void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+void __asan_poison_memory_region(void const volatile* addr, size_t size);
+void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+}
+#endif
+#ifdef EMU_TSAN
+extern "C" {
+void* __tsan_get_current_fiber(void);
+void* __tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void* fiber);
+void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+void __tsan_acquire(void* addr);
+void __tsan_release(void* addr);
+}
+// (every switch is "no sync": the scheduler must not become a happens-before relay between the lanes -- the edges that exist on the device are
+// drawn explicitly: launch start / end, cross-lane operations within a wave, __syncthreads, the LDS counters' release / acquire in the sources)
+static constexpr unsigned TSAN_NO_SYNC = 1u;
+#endif
+
+namespace mg { alignas(4096) uint8_t smem[160 * 1024]; }        // the workgroup's LDS (`extern __shared__ uint8_t smem[]` in the kernels)
 
 namespace emu {
+
+// What uninitialised memory holds: EMU_FILL=<byte> XORs the fill patterns below (device buffers 0xA5, pinned host memory 0xBE, LDS at workgroup
+// start 0xCD).  A kernel whose results depend on memory nobody wrote gives different results under two fills -- tests/test_emu_cpu.py runs its cases
+// under a second fill (the poor man's MemorySanitizer: the real one needs an instrumented python).
+static unsigned fill_xor() { static const unsigned v = getenv("EMU_FILL") ? (unsigned)strtoul(getenv("EMU_FILL"), nullptr, 0) & 0xFFu : 0u; return v; }
 
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
@@ -38,6 +82,8 @@ struct Fiber {
   unsigned long long v = 0, result = 0;
   int arg = 0;
   const void* site = nullptr;
+  void* fake = nullptr;                     // (ASan: the fiber's fake-stack handle while it is switched out)
+  void* tsan = nullptr;                     // (TSan: the fiber's identity)
 };
 constexpr size_t STACK_BYTES = 512 * 1024;
 static std::vector<Fiber> F;
@@ -46,25 +92,74 @@ static ucontext_t g_sched;
 static void (*g_tramp)(void*) = nullptr;
 static void* g_closure = nullptr;
 static bool g_in_kernel = false;
+#ifdef EMU_ASAN
+static void* g_sched_fake = nullptr;
+static const void* g_sched_bottom = nullptr;
+static size_t g_sched_size = 0;
+#endif
+#ifdef EMU_TSAN
+static void* g_sched_tsan = nullptr;
+static char g_sync_launch, g_sync_done;          // happens-before carriers: launch start, launch end
+static char* g_carriers = nullptr;               // ... and, allocated per workgroup (nothing carries over to the next one): [0..15] per wave, [16] the workgroup
+#endif
+
+// lane -> scheduler (the lane parks or ends)
+static inline void to_sched(Fiber& f, bool last) {
+#ifdef EMU_ASAN
+  __sanitizer_start_switch_fiber(last ? nullptr : &f.fake, g_sched_bottom, g_sched_size);
+#endif
+#ifdef EMU_TSAN
+  if (last) __tsan_release(&g_sync_done);                  // what the lane did happens-before whatever follows the launch (stream order)
+  __tsan_switch_to_fiber(g_sched_tsan, TSAN_NO_SYNC);
+#endif
+  swapcontext(&f.ctx, &g_sched);
+#ifdef EMU_ASAN
+  __sanitizer_finish_switch_fiber(f.fake, nullptr, nullptr);
+#endif
+}
 
 static void fiber_main() {
+#ifdef EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);
+#endif
+#ifdef EMU_TSAN
+  __tsan_acquire(&g_sync_launch);                          // everything the host (and earlier launches) did happens-before the kernel
+#endif
   g_tramp(g_closure);
   F[g_cur].state = DONE;
-  swapcontext(&F[g_cur].ctx, &g_sched);
+  to_sched(F[g_cur], true);
 }
 
 unsigned long long xlane(Op op, unsigned long long v, int arg, const void* site) {
   if (!g_in_kernel) { fprintf(stderr, "emu: cross-lane operation outside a kernel\n"); abort(); }
   Fiber& f = F[g_cur];
   f.op = op; f.v = v; f.arg = arg; f.site = site; f.state = PARKED;
-  swapcontext(&f.ctx, &g_sched);
+#ifdef EMU_TSAN
+  // a cross-lane operation orders the lanes that take part in it: everything a lane did before it happens-before what any lane of the wave
+  // (the workgroup, for __syncthreads) does after it.  s_sleep (OP_YIELD) orders nothing.
+  char* carrier = g_carriers + (op == OP_BLOCK_BARRIER ? 16 : (g_cur / 64) & 15);
+  if (op != OP_YIELD) __tsan_release(carrier);
+#endif
+  to_sched(f, false);
+#ifdef EMU_TSAN
+  if (op != OP_YIELD) __tsan_acquire(carrier);
+#endif
   return f.result;
 }
 
 static void resume(int i) {
   g_cur = i;
   g_threadIdx = dim3((unsigned)i, 0, 0);
+#ifdef EMU_ASAN
+  __sanitizer_start_switch_fiber(&g_sched_fake, F[i].stack, STACK_BYTES);
+#endif
+#ifdef EMU_TSAN
+  __tsan_switch_to_fiber(F[i].tsan, TSAN_NO_SYNC);
+#endif
   swapcontext(&g_sched, &F[i].ctx);
+#ifdef EMU_ASAN
+  __sanitizer_finish_switch_fiber(g_sched_fake, nullptr, nullptr);
+#endif
   g_cur = -1;
 }
 
@@ -86,6 +181,22 @@ static bool resolve_wave(int w, bool& yielded) {
       if (first < 0) first = i;
       if (op == OP_BALLOT && F[i].v) ballot |= 1ull << (i - lo);
     }
+  static const bool trace = getenv("EMU_TRACE_DIVERGE") != nullptr;
+  if (trace) {
+    // a group resolved while other lanes of the wave wait at ANOTHER cross-lane site: real divergence, or this emulator's reconvergence order
+    for (int i = lo; i < hi; i++)
+      if (F[i].state == PARKED && F[i].op != OP_BLOCK_BARRIER && !in[i - lo]) {
+        static std::vector<std::pair<const void*, const void*>> seen;
+        std::pair<const void*, const void*> key(site, F[i].site);
+        bool dup = false;
+        for (auto& k : seen) dup |= k == key;
+        if (!dup) {
+          seen.push_back(key);
+          fprintf(stderr, "emu: diverged: resolving op %d at %p (lane %d) while lane %d waits at %p (op %d), workgroup %u\n", (int)op, site, first, i, F[i].site, (int)F[i].op, g_blockIdx.x);
+        }
+        break;
+      }
+  }
   unsigned long long res[64];
   for (int l = 0; l < hi - lo; l++) {
     if (!in[l]) continue;
@@ -162,9 +273,31 @@ void launch(void (*tramp)(void*), void* closure, dim3 grid, dim3 block, size_t l
   g_tramp = tramp; g_closure = closure; g_n = n;
   g_blockDim = block; g_gridDim = grid;
   g_in_kernel = true;
+#ifdef EMU_ASAN
+  __asan_poison_memory_region(mg::smem + lds, sizeof(mg::smem) - lds);      // an access past the launch's dynamic LDS size is an error
+#endif
+#ifdef EMU_TSAN
+  g_sched_tsan = __tsan_get_current_fiber();
+#endif
   for (unsigned b = 0; b < grid.x; b++) {
     g_blockIdx = dim3(b, 0, 0);
-    memset(mg::smem, 0xCD, lds);                     // (LDS contents are undefined at workgroup start: not zero)
+#ifdef EMU_TSAN
+    // The workgroups of a grid are unordered on the device and stay unordered here (two workgroups touching one global word without an atomic is
+    // reported).  What the emulator REUSES from workgroup to workgroup -- the LDS array, the fibers' stacks -- is mapped afresh (the sanitizer
+    // forgets a remapped range and books it as written by the mapping thread = this scheduler, whose release below the lanes acquire when
+    // they start); every workgroup gets fresh fiber identities and fresh happens-before carriers.
+    if (mmap(mg::smem, sizeof(mg::smem), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED, -1, 0) != (void*)mg::smem) { perror("emu: mmap LDS"); abort(); }
+    g_carriers = (char*)malloc(32);
+    for (int i = 0; i < n; i++) {
+      if (mmap(F[i].stack, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) != F[i].stack) { perror("emu: mmap stack"); abort(); }
+      if (F[i].tsan) __tsan_destroy_fiber(F[i].tsan);
+      F[i].tsan = __tsan_create_fiber(0);
+    }
+#endif
+    memset(mg::smem, (int)(0xCDu ^ fill_xor()), lds);  // (LDS contents are undefined at workgroup start: not zero)
+#ifdef EMU_TSAN
+    __tsan_release(&g_sync_launch);
+#endif
     for (int i = 0; i < n; i++) {
       getcontext(&F[i].ctx);
       F[i].ctx.uc_stack.ss_sp = F[i].stack; F[i].ctx.uc_stack.ss_size = STACK_BYTES; F[i].ctx.uc_link = nullptr;
@@ -172,7 +305,16 @@ void launch(void (*tramp)(void*), void* closure, dim3 grid, dim3 block, size_t l
       F[i].state = RUNNABLE;
     }
     run_block();
+#ifdef EMU_TSAN
+    free(g_carriers); g_carriers = nullptr;
+#endif
   }
+#ifdef EMU_TSAN
+  __tsan_acquire(&g_sync_done);
+#endif
+#ifdef EMU_ASAN
+  __asan_unpoison_memory_region(mg::smem, sizeof(mg::smem));
+#endif
   g_in_kernel = false;
 }
 
@@ -192,9 +334,14 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   return hipSuccess;
 }
 hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
-hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); if (*p) memset(*p, 0xA5, n); return *p ? hipSuccess : hipErrorInvalidValue; }
+#ifdef MG_EMU_SANITIZE
+// exact size: the sanitizer's red zone starts at the first byte the library did not ask for
+hipError_t hipMalloc(void** p, size_t n) { *p = nullptr; if (posix_memalign(p, 256, n ? n : 1)) *p = nullptr; if (*p) memset(*p, (int)(0xA5u ^ emu::fill_xor()), n); return *p ? hipSuccess : hipErrorInvalidValue; }
+#else
+hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); if (*p) memset(*p, (int)(0xA5u ^ emu::fill_xor()), (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+#endif
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); if (*p) memset(*p, (int)(0xBEu ^ emu::fill_xor()), n); return *p ? hipSuccess : hipErrorInvalidValue; }   // (pinned host memory is not zeroed either)
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }

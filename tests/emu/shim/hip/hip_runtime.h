@@ -53,15 +53,24 @@ void launch(void (*tramp)(void*), void* closure, dim3 grid, dim3 block, size_t l
 
 // ---- cross-lane operations ----
 #define EMU_SITE() __builtin_return_address(0)
-static inline __attribute__((noinline)) unsigned long long __ballot(int pred) { return ::emu::xlane(::emu::OP_BALLOT, pred ? 1ull : 0ull, 0, EMU_SITE()); }
-static inline __attribute__((noinline)) int __shfl(int v, int src, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL, (unsigned)v, src, EMU_SITE()); }
-static inline __attribute__((noinline)) int __shfl_down(int v, unsigned d, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_DOWN, (unsigned)v, (int)d, EMU_SITE()); }
-static inline __attribute__((noinline)) int __shfl_up(int v, unsigned d, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_UP, (unsigned)v, (int)d, EMU_SITE()); }
-static inline __attribute__((noinline)) int __shfl_xor(int v, int m, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_XOR, (unsigned)v, m, EMU_SITE()); }
-static inline __attribute__((noinline)) int emu_readfirstlane(int v) { return (int)(unsigned)::emu::xlane(::emu::OP_FIRST, (unsigned)v, 0, EMU_SITE()); }
-static inline __attribute__((noinline)) void emu_wave_barrier() { ::emu::xlane(::emu::OP_WAVE_BARRIER, 0, 0, EMU_SITE()); }
-static inline __attribute__((noinline)) void __syncthreads() { ::emu::xlane(::emu::OP_BLOCK_BARRIER, 0, 0, EMU_SITE()); }
-static inline __attribute__((noinline)) void emu_yield() { ::emu::xlane(::emu::OP_YIELD, 0, 0, EMU_SITE()); }
+// A cross-lane operation is CONVERGENT: the device compiler never duplicates or sinks one across control flow (the lanes that reach a call
+// site are the lanes that take part).  The host compiler has to be told: without the attributes, jump threading may clone a call into both arms of
+// a lane-dependent branch (seen with the ASan build of k_roll7's spare staging loop: lanes 0-15 and 16-63 of a wave at two copies of one
+// __shfl), and the emulator -- which groups lanes by call site -- would resolve the two halves separately.
+#if defined(__clang__)
+#define EMU_XLANE __attribute__((noinline, convergent, noduplicate))
+#else
+#define EMU_XLANE __attribute__((noinline))
+#endif
+static inline EMU_XLANE unsigned long long __ballot(int pred) { return ::emu::xlane(::emu::OP_BALLOT, pred ? 1ull : 0ull, 0, EMU_SITE()); }
+static inline EMU_XLANE int __shfl(int v, int src, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL, (unsigned)v, src, EMU_SITE()); }
+static inline EMU_XLANE int __shfl_down(int v, unsigned d, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_DOWN, (unsigned)v, (int)d, EMU_SITE()); }
+static inline EMU_XLANE int __shfl_up(int v, unsigned d, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_UP, (unsigned)v, (int)d, EMU_SITE()); }
+static inline EMU_XLANE int __shfl_xor(int v, int m, int = 64) { return (int)(unsigned)::emu::xlane(::emu::OP_SHFL_XOR, (unsigned)v, m, EMU_SITE()); }
+static inline EMU_XLANE int emu_readfirstlane(int v) { return (int)(unsigned)::emu::xlane(::emu::OP_FIRST, (unsigned)v, 0, EMU_SITE()); }
+static inline EMU_XLANE void emu_wave_barrier() { ::emu::xlane(::emu::OP_WAVE_BARRIER, 0, 0, EMU_SITE()); }
+static inline EMU_XLANE void __syncthreads() { ::emu::xlane(::emu::OP_BLOCK_BARRIER, 0, 0, EMU_SITE()); }
+static inline EMU_XLANE void emu_yield() { ::emu::xlane(::emu::OP_YIELD, 0, 0, EMU_SITE()); }
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 #define __builtin_amdgcn_readlane(v, l) __shfl((v), (l))
 #define __builtin_amdgcn_s_sleep(n) emu_yield()
@@ -95,14 +104,24 @@ static inline unsigned min(int a, unsigned b) { return (unsigned)a < b ? (unsign
 static inline unsigned max(unsigned a, int b) { return a > (unsigned)b ? a : (unsigned)b; }
 static inline unsigned max(int a, unsigned b) { return (unsigned)a > b ? (unsigned)a : b; }
 
-// ---- atomics: one OS thread, lanes interleave only at cross-lane operations ----
-template <class T, class U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
-template <class T, class U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
-template <class T, class U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
-template <class T, class U> static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
-template <class T, class U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
-template <class T, class U> static inline T atomicCAS(T* p, U c, U v) { T o = *p; if (o == (T)c) *p = (T)v; return o; }
+// ---- atomics: one OS thread, lanes interleave only at cross-lane operations; real atomic builtins so that the thread-sanitizer build sees them as such ----
+template <class T, class U> static inline T atomicAdd(T* p, U v) { return __atomic_fetch_add(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicMax(T* p, U v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while ((T)v > o && !__atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { } return o; }
+template <class T, class U> static inline T atomicMin(T* p, U v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while ((T)v < o && !__atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { } return o; }
+template <class T, class U> static inline T atomicOr(T* p, U v) { return __atomic_fetch_or(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicAnd(T* p, U v) { return __atomic_fetch_and(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicExch(T* p, U v) { return __atomic_exchange_n(p, (T)v, __ATOMIC_RELAXED); }
+template <class T, class U> static inline T atomicCAS(T* p, U c, U v) { T o = (T)c; __atomic_compare_exchange_n(p, &o, (T)v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return o; }
+// An LDS word that one wave publishes and another polls (k_roll7's step counters, mg_roll.h MG_LDS_VU32).  On the device: a volatile LDS word; the DS
+// operations of a wave execute in order, so what the wave wrote before the counter is visible to whoever has seen the counter.  For the host
+// compiler and its thread sanitizer that contract is a release store / an acquire load.
+namespace emu {
+struct SyncWord {
+  uint32_t v;
+  operator uint32_t() const { return __atomic_load_n(&v, __ATOMIC_ACQUIRE); }
+  uint32_t operator=(uint32_t x) { __atomic_store_n(&v, x, __ATOMIC_RELEASE); return x; }
+};
+}
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 

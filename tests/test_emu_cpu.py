@@ -81,12 +81,13 @@ WIDE_CASES = [
 ]
 
 
-def _run(defines, cases):
+def _run(defines, cases, **extra_env):
     import build_emu
     lib = build_emu.build(defines)
     env = dict(os.environ, MINIGRID_AMD_LIB=lib, MINIGRID_AMD_NO_TORCH="1")
-    for k in [k for k in env if k.startswith("MG_")]:
+    for k in [k for k in env if k.startswith("MG_") or k.startswith("EMU_")]:
         del env[k]
+    env.update(extra_env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_cases.py"), json.dumps(cases)], env=env, capture_output=True, text=True,
                          timeout=900)
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
@@ -104,6 +105,16 @@ def test_product_kernels_on_the_emulator_equal_the_oracle():
 def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
     lines = _run(["-DMG_LANE_WIDE=1"], WIDE_CASES)
     assert sum(r["episodes"] for r in lines) > 4000
+
+
+def test_results_do_not_depend_on_uninitialised_memory():
+    """The emulator fills what nobody has written yet with patterns -- device buffers 0xA5, pinned host memory 0xBE, the LDS at workgroup start 0xCD
+    -- and EMU_FILL xors them: 0xFF = the complements, 0xA5 = device memory that happens to be ZERO (a fresh box).  The same parity under every fill
+    means no kernel's result depends on memory it (or the host) did not write first.  (Uninitialised REGISTERS / locals were checked once with
+    -ftrivial-auto-var-init=pattern)"""
+    for fill in ("0xFF", "0xA5"):
+        _run([], PRODUCT_CASES, EMU_FILL=fill)
+    _run(["-DMG_LANE_WIDE=1"], WIDE_CASES, EMU_FILL="0xFF")
 
 
 def test_the_product_never_loads_the_emulator():

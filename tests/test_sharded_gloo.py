@@ -137,6 +137,64 @@ def test_two_rank_batch_equals_single_process_batch(tmp_path, env_id, n, full):
             assert g.shape == np.asarray(w).shape and (g == w).all(), (r, i)
 
 
+def _emu_make(env_id, num_envs, **kw):
+    import minigrid_amd as mg
+    kw["output"] = "numpy"
+    return mg.make_vec(env_id, num_envs, **kw)
+
+
+def _worker_emu(rank, world, port, lib, env_id, n, full, out_dir):
+    """The same two-rank run on the PRODUCT's own shard class (MiniGridVecEnv over the C ABI) with the library built for the host SIMT emulator of
+    tests/emu: the real kernels, the real env_index_base seeding, the real facade under ShardedVecEnv -- only the device is emulated."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MINIGRID_AMD_LIB=lib)
+    for k in [k for k in os.environ if k.startswith("MG_")]:
+        del os.environ[k]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from minigrid_amd import _binding as B
+        assert b"emulator=1" in B.load().mg_build_info()
+        env = ShardedVecEnv(env_id, n, gather=True, make=_emu_make, obs_mode="full" if full else "partial")
+        assert (env.lo, env.hi) == shard_range(n, rank, world) and env.local.env_index_base == env.lo
+        obs, _ = env.reset(seed=5)
+        log = [obs["image"].numpy().copy(), obs["direction"].numpy().copy()]
+        rng = np.random.default_rng(3)
+        for t in range(40):
+            a = rng.integers(0, 7, n, dtype=np.uint8)
+            obs, rew, term, trunc, _ = env.step(a if t % 2 == 0 else a[env.lo:env.hi])
+            log += [obs["image"].numpy().copy(), rew.numpy().copy(), term.numpy().copy(), trunc.numpy().copy(),
+                    np.asarray(obs["mission"]).astype(str)]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), *log)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env_id,n,full", [("MiniGrid-DoorKey-8x8-v0", 130, False),            # 65 + 65: two workgroups per rank, the second ragged
+                                            ("MiniGrid-LavaCrossingS9N1-v0", 37, True),        # ragged shards: 19 + 18
+                                            ("BabyAI-BossLevel-v0", 21, False)])                # sentences travel as data
+def test_two_rank_batch_on_the_emulated_library_equals_the_oracle(tmp_path, env_id, n, full):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build([])
+    world = 2
+    mp.spawn(_worker_emu, args=(world, _free_port(), lib, env_id, n, full, str(tmp_path)), nprocs=world, join=True)
+    ref = OracleShard(env_id, n, obs_mode="full" if full else "partial")
+    obs, _ = ref.reset(seed=5)
+    want = [obs["image"], obs["direction"]]
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        a = rng.integers(0, 7, n, dtype=np.uint8)
+        obs, rew, term, trunc, _ = ref.step(a)
+        want += [obs["image"], rew, term, trunc, np.asarray(obs["mission"]).astype(str)]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        arrs = [got[k] for k in got.files]
+        assert len(arrs) == len(want)
+        for i, (g, w) in enumerate(zip(arrs, want)):
+            assert g.shape == np.asarray(w).shape and (g == w).all(), (r, i)
+
+
 def test_shard_range_partitions_exactly():
     for n in (1, 2, 7, 8, 9, 1000, 1 << 20):
         for w in (1, 2, 3, 4, 8):
@@ -188,6 +246,74 @@ def test_fused_block_gather_one_collective_per_launch(tmp_path, env_id, n, steps
         act = O.philox_actions(4, t, n)
         obs, rew, term, trunc, _ = ref.step(act)
         want += [obs["image"], rew, term.astype(np.uint8), act]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"blocks{r}.npz"))
+        arrs = [got[k] for k in got.files]
+        assert len(arrs) == len(want)
+        for i, (g, w) in enumerate(zip(arrs, want)):
+            assert g.shape == np.asarray(w).shape and (g == w).all(), (r, i)
+
+
+def _emu_make_blocks(env_id, num_envs, **kw):
+    """The product's shard class on the emulated library; only block_view differs: the trajectory ring of an emulated device is host memory."""
+    import ctypes
+    import minigrid_amd as mg
+
+    class EmuShard(mg.MiniGridVecEnv):
+        def block_view(self, slot_lo, nslots):
+            assert 0 <= slot_lo and slot_lo + nslots <= self.traj_slots
+            sb = int(self._outs.slot_bytes)
+            buf = (ctypes.c_uint8 * (nslots * sb)).from_address(int(self._outs.obs) + slot_lo * sb)
+            return torch.frombuffer(buf, dtype=torch.uint8).reshape(nslots, sb)
+    kw["output"] = "numpy"
+    kw.setdefault("traj_slots", 64)
+    return EmuShard(env_id, num_envs, **kw)
+
+
+def _worker_blocks_emu(rank, world, port, lib, env_id, n, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MINIGRID_AMD_LIB=lib)
+    for k in [k for k in os.environ if k.startswith("MG_")]:
+        del os.environ[k]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = ShardedVecEnv(env_id, n, gather=True, make=_emu_make_blocks)
+        env.reset(seed=9)
+        log = []
+
+        def consumer(block, T):
+            assert block.shape[0] == world and block.shape[1] == T
+            for j in reversed(range(T)):
+                f = env.unpack_block(block, j)
+                log.extend([f["image"].numpy().copy(), f["reward"].numpy().copy(), f["terminated"].numpy().copy(), f["action"].numpy().copy(),
+                            f["direction"].numpy().copy(), f["truncated"].numpy().copy()])
+        c0 = env.collectives
+        launches = env.rollout_gather(steps, action_seed=4, consumer=consumer)
+        assert launches == -(-steps // 32) and env.collectives - c0 == launches
+        np.savez(os.path.join(out_dir, f"blocks{rank}.npz"), *log)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env_id,n,steps", [("MiniGrid-DoorKey-8x8-v0", 48, 80), ("BabyAI-GoToRedBall-v0", 37, 64)])   # 37: ragged 19 + 18
+def test_fused_block_gather_on_the_emulated_library(tmp_path, env_id, n, steps):
+    """rollout_gather with the REAL library underneath (mg_rollout_block on the host SIMT emulator of tests/emu): the kernels write the step records,
+    rank 1's device policy draws the actions of ITS global env indices (env_index_base), the gathered blocks unpacked with the host-side record
+    layout equal a single-process oracle rollout -- what tests/test_gpu_multi.py checks over RCCL, here over gloo without a GPU."""
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build([])
+    world = 2
+    mp.spawn(_worker_blocks_emu, args=(world, _free_port(), lib, env_id, n, steps, str(tmp_path)), nprocs=world, join=True)
+    ref = OracleShard(env_id, n)
+    ref.reset(seed=9)
+    want = []
+    for t in range(steps):
+        act = O.philox_actions(4, t, n)
+        obs, rew, term, trunc, _ = ref.step(act)
+        want += [obs["image"], rew, term.astype(np.uint8), act, obs["direction"].astype(np.uint8), trunc.astype(np.uint8)]
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"blocks{r}.npz"))
         arrs = [got[k] for k in got.files]
