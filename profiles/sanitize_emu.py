@@ -71,6 +71,23 @@ def main():
             with open(name, "w") as f:
                 f.write("\n".join(log) + "\n")
             print(f"{name}: {sum(1 for r in lines if r['ok'])}/{len(cases)} cases ok, {len(reports)} reports", flush=True)
+    # uninitialised locals: every automatic variable the code does not initialise starts as 0xAA.. (-ftrivial-auto-var-init=pattern) -- same parity?
+    import json
+    for variant, defines, cases in (("product", [], T.PRODUCT_CASES), ("lanewide", ["-DMG_LANE_WIDE=1"], T.WIDE_CASES)):
+        lib = build_emu.build(defines + ["-ftrivial-auto-var-init=pattern"])
+        env = dict(os.environ, MINIGRID_AMD_LIB=lib, MINIGRID_AMD_NO_TORCH="1")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "run_cases.py"), json.dumps(cases)], env=env, capture_output=True, text=True)
+        lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        ok = sum(1 for r in lines if r["ok"])
+        name = os.path.join(outdir, f"uninit_locals_{variant}.txt")
+        with open(name, "w") as f:
+            f.write(f"# {os.path.basename(lib)}: the emulated library built with -ftrivial-auto-var-init=pattern (uninitialised locals read 0xAA..), tree {head}\n")
+            f.write(f"# {len(cases)} parity cases of tests/test_emu_cpu.py: {ok} ok\n")
+            for r in lines:
+                f.write(f"{'ok  ' if r['ok'] else 'FAIL'} {r['case']['env']} {'' if r['ok'] else r.get('error')}\n")
+        print(f"{name}: {ok}/{len(cases)} cases ok", flush=True)
+        if ok != len(cases):
+            rc = 1
     sys.exit(rc)
 
 

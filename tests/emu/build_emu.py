@@ -76,17 +76,31 @@ def sanitizer_env(sanitize):
             "TSAN_OPTIONS": "report_bugs=1:halt_on_error=0:exitcode=0:report_thread_leaks=0:report_signal_unsafe=0:history_size=4"}
 
 
+def _kernel_deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc", ".hip"))] + \
+           [os.path.join(HERE, "shim", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "minigrid_hip.h")]
+
+
+def _switches(defines, sanitize):
+    return " ".join(FLAGS) + " | " + " ".join(defines) + " | sanitize=" + str(sanitize) + " | v2"
+
+
 def _plan(defines, sanitize):
     """(library path, stamp path, digest of everything the build depends on: sources, flags, switches)"""
     tag = "".join("_" + d.lstrip("-D").replace("=", "") for d in defines)
     if sanitize:
         tag += "_san_" + sanitize.replace(",", "_")
     lib = os.path.join(OUT, f"libminigrid_emu{tag}.so")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc", ".hip"))]
-    deps += [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "emu_probe.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h"),
-             os.path.join(ROOT, "include", "minigrid_hip.h")]
-    want = _digest(deps, " ".join(FLAGS) + " | " + " ".join(defines) + " | sanitize=" + str(sanitize) + " | v2")
+    deps = _kernel_deps() + [os.path.join(HERE, "emu_runtime.cpp")] + ([os.path.join(HERE, "emu_probe.cpp")] if sanitize else [])
+    want = _digest(deps, _switches(defines, sanitize) + " | v3")
     return tag, lib, lib + ".srchash", want
+
+
+def _object_digest(src, defines, sanitize):
+    """What ONE object depends on: the kernel translation units on every kernel header, the emulator's own two files on themselves and the shim."""
+    own = os.path.basename(src) in ("emu_runtime.cpp", "emu_probe.cpp")
+    deps = [src, os.path.join(HERE, "shim", "hip", "hip_runtime.h")] if own else _kernel_deps()
+    return _digest(deps, _switches(defines, sanitize) + " | " + os.path.basename(src))
 
 
 def up_to_date(defines=(), sanitize=None):
@@ -112,6 +126,9 @@ def build(defines=(), verbose=False, sanitize=None):
 
     def one(src):
         obj = os.path.join(OUT, os.path.basename(src).rsplit(".", 1)[0] + tag + ".o")
+        odig = _object_digest(src, defines, sanitize)
+        if os.path.exists(obj) and os.path.exists(obj + ".srchash") and open(obj + ".srchash").read().strip() == odig:
+            return obj                                  # (an edit of the emulator's runtime does not recompile the 24 kernel translation units)
         flags = san
         if "thread" in (sanitize or "") and os.path.basename(src) == "emu_runtime.cpp":
             # the scheduler's own state is shared by every fiber by design: the runtime is not instrumented, it only talks to the sanitizer's fiber API
@@ -120,6 +137,8 @@ def build(defines=(), verbose=False, sanitize=None):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(obj + ".srchash", "w") as f:
+            f.write(odig)
         return obj
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(2, (os.cpu_count() or 4))) as ex:
         objs = list(ex.map(one, srcs + [os.path.join(HERE, "emu_runtime.cpp")] + ([os.path.join(HERE, "emu_probe.cpp")] if sanitize else [])))

@@ -18,7 +18,7 @@ static void probe_body(void* c) {
   switch (a.what) {
     case 1: if (tid == 0) sink = a.buf[100]; break;
     case 2: if (tid == 0) mg::smem[a.lds] = 1; break;
-    case 3: if (tid == 0) { sink = *(volatile uint32_t*)(a.buf + 1); volatile int sh = 32; sink = (uint32_t)(1 << sh); } break;
+    case 3: if (tid == 0) { const uint32_t* mis = (const uint32_t*)(a.buf + 1 + (a.lds & 1)); sink = mis[0]; volatile int sh = 32; sink = (uint32_t)(1 << sh); } break;   // (UBSan does not check volatile accesses: a plain load, like the kernels')
     case 4: if (lane == 0) lds[0] = (uint32_t)tid; break;
     case 5: {
       if (tid == 0) lds[0] = 7u;

@@ -221,21 +221,47 @@ static bool resolve_wave(int w, bool& yielded) {
   return true;
 }
 
+// EMU_SCHED_SEED=<n != 0>: another legal schedule.  The default one is fixed (waves in index order, each until it polls or blocks; lanes in index
+// order; workgroups in index order).  The device promises none of that, so a seeded run shuffles what it is free to shuffle: the order of the
+// workgroups of a grid, the order in which the waves of a workgroup get their turn, where a wave is preempted (after any cross-lane operation, with
+// probability 1/4), and whether the lanes of a wave run in ascending or descending order between two cross-lane operations.  Parity under several
+// seeds (tests/test_emu_cpu.py) = the inter-wave protocols and ring hand-offs do not lean on the one schedule the default run happens to take.
+static uint64_t g_sched_state = 0;
+static bool sched_fuzz() {
+  static const bool on = [] { const char* s = getenv("EMU_SCHED_SEED"); const uint64_t v = s ? strtoull(s, nullptr, 0) : 0ull; g_sched_state = v * 0x9E3779B97F4A7C15ull + 1ull; if (v) fprintf(stderr, "emu: seeded schedule %llu\n", (unsigned long long)v); return v != 0ull; }();
+  return on;
+}
+static uint32_t sched_rand() {                       // xorshift64*
+  g_sched_state ^= g_sched_state >> 12; g_sched_state ^= g_sched_state << 25; g_sched_state ^= g_sched_state >> 27;
+  return (uint32_t)((g_sched_state * 0x2545F4914F6CDD1Dull) >> 32);
+}
+
 static void run_block() {
   const int nw = (g_n + 63) / 64;
+  const bool fuzz = sched_fuzz();
   for (;;) {
     bool progress = false, alive = false;
-    for (int w = 0; w < nw; w++) {
+    int order[16];
+    for (int w = 0; w < nw; w++) order[w] = w;
+    if (fuzz) for (int w = nw - 1; w > 0; w--) std::swap(order[w], order[sched_rand() % (uint32_t)(w + 1)]);
+    for (int wi = 0; wi < nw; wi++) {
+      const int w = order[wi];
       const int lo = w * 64, hi = std::min(g_n, lo + 64);
       // the wave runs until it yields (s_sleep: a polling loop) or nothing in it can move
       for (int rounds = 0;; rounds++) {
         bool ran = false;
-        for (int i = lo; i < hi; i++)
-          while (F[i].state == RUNNABLE) { resume(i); ran = true; }
+        if (fuzz && (sched_rand() & 1u)) {
+          for (int i = hi - 1; i >= lo; i--)
+            while (F[i].state == RUNNABLE) { resume(i); ran = true; }
+        } else {
+          for (int i = lo; i < hi; i++)
+            while (F[i].state == RUNNABLE) { resume(i); ran = true; }
+        }
         bool yielded = false;
         if (!resolve_wave(w, yielded)) { progress |= ran; break; }
         progress = true;
         if (yielded) break;
+        if (fuzz && (sched_rand() & 3u) == 0u) break;          // preempted: the other waves get a turn first
       }
     }
     // __syncthreads: every lane that is not finished has arrived
@@ -279,7 +305,11 @@ void launch(void (*tramp)(void*), void* closure, dim3 grid, dim3 block, size_t l
 #ifdef EMU_TSAN
   g_sched_tsan = __tsan_get_current_fiber();
 #endif
-  for (unsigned b = 0; b < grid.x; b++) {
+  // (seeded schedules: the workgroups of a grid in a rotated, possibly reversed order -- the device runs them in no particular one)
+  const unsigned rot = sched_fuzz() ? sched_rand() % grid.x : 0u;
+  const bool rev = sched_fuzz() && (sched_rand() & 1u);
+  for (unsigned bi = 0; bi < grid.x; bi++) {
+    const unsigned bb = (bi + rot) % grid.x, b = rev ? grid.x - 1u - bb : bb;
     g_blockIdx = dim3(b, 0, 0);
 #ifdef EMU_TSAN
     // The workgroups of a grid are unordered on the device and stay unordered here (two workgroups touching one global word without an atomic is

@@ -94,6 +94,8 @@ def _run(defines, cases, **extra_env):
     assert len(lines) == len(cases), (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
     bad = [(r["case"], r.get("error"), r.get("where")) for r in lines if not r["ok"]]
     assert not bad, bad
+    if "EMU_SCHED_SEED" in extra_env:
+        assert f"emu: seeded schedule {int(extra_env['EMU_SCHED_SEED'])}" in out.stderr
     return lines
 
 
@@ -105,6 +107,16 @@ def test_product_kernels_on_the_emulator_equal_the_oracle():
 def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
     lines = _run(["-DMG_LANE_WIDE=1"], WIDE_CASES)
     assert sum(r["episodes"] for r in lines) > 4000
+
+
+def test_product_kernels_under_other_legal_schedules():
+    """The emulator's default schedule is one of many the device may take.  EMU_SCHED_SEED shuffles what is free: the order of a grid's workgroups, whose
+    turn it is among the waves of a workgroup, where a wave is preempted (after any cross-lane operation), ascending or descending lanes.  The LOG /
+    STAGED split rings of k_roll7 (a dynamics wave ahead of its encode waves by up to the ring depth, or starved by them), the shared encode, the
+    generator rings: same parity under every seed."""
+    for seed in ("1", "2"):
+        _run([], PRODUCT_CASES, EMU_SCHED_SEED=seed)
+    _run(["-DMG_LANE_WIDE=1"], WIDE_CASES, EMU_SCHED_SEED="4")
 
 
 def test_results_do_not_depend_on_uninitialised_memory():

@@ -14,7 +14,7 @@
 Negative controls (tests/emu/emu_probe.cpp) prove each detector fires on a one-line wrong kernel and stays silent on the hand-offs the kernels use.
 
 What runs by default: the probes and a subset of the parity cases under the thread sanitizer (its build takes a minute).  With
-MINIGRID_AMD_SANITIZER_TESTS=1 (or when the libraries are already built, e.g. by `python profiles/sanitize_emu.py`): every case of test_emu_cpu.py
+MINIGRID_AMD_SANITIZER_TESTS=1: every case of test_emu_cpu.py
 -- the product kernels and the MG_LANE_WIDE variant -- under both sanitizer builds (the address,undefined builds take ~5 minutes each).  The logs of
 that full run on the committed tree are under profiles/r4/sanitizer_*.txt."""
 import json
@@ -31,12 +31,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FULL = os.environ.get("MINIGRID_AMD_SANITIZER_TESTS", "0") == "1"
 REPORT = re.compile(r"ThreadSanitizer|AddressSanitizer|runtime error:|LeakSanitizer|DEADLOCK")
-
-
-def _built(defines, sanitize):
-    """The sanitizer library if it is already built for the current sources (never builds)."""
-    import build_emu
-    return build_emu.up_to_date(defines, sanitize)
 
 
 def run_cases(defines, sanitize, cases, timeout=3000):
@@ -95,7 +89,7 @@ def test_thread_sanitizer_probes():
     assert out.returncode == 0 and "rc 0" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
 
 
-@pytest.mark.skipif(not FULL and not _built([], "address,undefined"), reason="address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
+@pytest.mark.skipif(not FULL, reason="address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
 def test_address_and_undefined_sanitizer_probes():
     out = probe("address,undefined", 1)
     assert "AddressSanitizer: heap-buffer-overflow" in out.stderr and out.returncode != 0, out.stderr[-2000:]
@@ -116,19 +110,19 @@ def test_product_kernels_under_the_thread_sanitizer():
     check([], "thread", T.PRODUCT_CASES if FULL else _subset())
 
 
-@pytest.mark.skipif(not FULL and not _built([], "address,undefined"), reason="address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
+@pytest.mark.skipif(not FULL, reason="address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
 def test_product_kernels_under_the_address_and_undefined_sanitizers():
     import test_emu_cpu as T
     check([], "address,undefined", T.PRODUCT_CASES)
 
 
-@pytest.mark.skipif(not FULL and not _built(["-DMG_LANE_WIDE=1"], "thread"), reason="MG_LANE_WIDE variant under the thread sanitizer: MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
+@pytest.mark.skipif(not FULL, reason="MG_LANE_WIDE variant under the thread sanitizer: MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
 def test_lane_wide_variant_under_the_thread_sanitizer():
     import test_emu_cpu as T
     check(["-DMG_LANE_WIDE=1"], "thread", T.WIDE_CASES)
 
 
-@pytest.mark.skipif(not FULL and not _built(["-DMG_LANE_WIDE=1"], "address,undefined"), reason="MG_LANE_WIDE variant, address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
+@pytest.mark.skipif(not FULL, reason="MG_LANE_WIDE variant, address,undefined build (~5 min): MINIGRID_AMD_SANITIZER_TESTS=1; logs: profiles/r4/sanitizer_*.txt")
 def test_lane_wide_variant_under_the_address_and_undefined_sanitizers():
     import test_emu_cpu as T
     check(["-DMG_LANE_WIDE=1"], "address,undefined", T.WIDE_CASES)

@@ -16,7 +16,13 @@ def _mk(env_id, n, **kw):
 
 
 def _assert_native_loaded():
+    import os
     maps = open("/proc/self/maps").read()
+    if os.environ.get("MINIGRID_AMD_EMU_RERUN") == "1":
+        # tests/test_emu_gpu_suite_cpu.py re-runs a part of this module on the CPU: the same HIP sources built for the host SIMT emulator of tests/emu
+        from minigrid_amd import _binding as B
+        assert "libminigrid_emu" in maps and b"emulator=1" in B.load().mg_build_info(), "the emulated library is what this re-run is about"
+        return
     assert "libminigrid_hip.so" in maps, "HIP extension not loaded"
 
 

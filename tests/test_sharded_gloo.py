@@ -140,6 +140,7 @@ def test_two_rank_batch_equals_single_process_batch(tmp_path, env_id, n, full):
 def _emu_make(env_id, num_envs, **kw):
     import minigrid_amd as mg
     kw["output"] = "numpy"
+    kw.setdefault("spare_ring", 4)         # (an explicit reset fills the whole ring: 64-256 episodes per env by default, each a wavefront of fibers here)
     return mg.make_vec(env_id, num_envs, **kw)
 
 
