@@ -1496,13 +1496,24 @@ struct RG {
   MG_HD void door_xy(int i, int j, int k, int& dx, int& dy) const {
     const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * nc + ri;
     const bool vertical_wall = k == 0 || k == 2;
-    dx = vertical_wall ? ri * st + st : ri * st + (int)((down_off >> (4 * rr)) & 15u);
-    dy = vertical_wall ? rj * st + (int)((right_off >> (4 * rr)) & 15u) : rj * st + st;
+    // MG_SHC: add_door may arrive here with a side that has NO neighbour when the stream's draw budget ran out (its loop leaves on rng.dead()): rr / nrm
+    // are negative then, the shift count is negative, and the episode is discarded and redrawn.  The hardware masks a 64-bit shift count to six bits;
+    // in C++ the shift is undefined -- found by UBSan on the emulator (profiles/r4/emu_all_ids_address_undefined.txt: the only report of the round).
+    // Host builds mask explicitly.  The device build keeps the expression the GPU suite validated (writing the mask there too changes the
+    // register allocation of eight generator translation units, profiles/isa_diff.py -- to be switched over with a GPU at hand).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MG_SHC(x) (x)
+#else
+#define MG_SHC(x) ((x) & 63)
+#endif
+    dx = vertical_wall ? ri * st + st : ri * st + (int)((down_off >> MG_SHC(4 * rr)) & 15u);
+    dy = vertical_wall ? rj * st + (int)((right_off >> MG_SHC(4 * rr)) & 15u) : rj * st + st;
   }
   MG_HD void mark(int i, int j, int k) {
     const int r = room(i, j), nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
-    doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
+    doors |= (1ull << (r * 4 + k)) | (1ull << MG_SHC(nrm * 4 + ((k + 2) & 3)));
   }
+#undef MG_SHC
   // RoomGrid._gen_grid (roomgrid.py:123-179)
   template <class R, class G> MG_HD void gen_grid(R& rng, G& g, int room_size) {
     rs = room_size; st = rs - 1; nc = (g.W - 1) / st; nr = (g.H - 1) / st;
