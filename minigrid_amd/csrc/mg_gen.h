@@ -1501,7 +1501,8 @@ struct RG {
     // in C++ the shift is undefined -- found by UBSan on the emulator (profiles/r4/emu_all_ids_address_undefined.txt: the only report of the round).
     // Host builds mask explicitly.  The device build keeps the expression the GPU suite validated (writing the mask there too changes the
     // register allocation of eight generator translation units, profiles/isa_diff.py -- to be switched over with a GPU at hand).
-#if defined(__HIP_DEVICE_COMPILE__)
+    // (-DMG_SHC_MASK_DEVICE=1: the masked form on the device too -- the variant build profiles/r5_shift_mask.sh validates on a GPU)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MG_SHC_MASK_DEVICE)
 #define MG_SHC(x) (x)
 #else
 #define MG_SHC(x) ((x) & 63)

@@ -2,7 +2,7 @@
 """Every registered env id on the host SIMT emulator of tests/emu (no GPU): the product's kernels -- generator, fused k_roll7 launch, single steps -- against
 the oracle, one small case per id (tests/emu/run_cases.py), in parallel subprocesses.  Writes profiles/<round>/emu_all_ids.txt.
 
-    python profiles/emu_all_ids.py [r4] [--sanitize=thread]"""
+    python profiles/emu_all_ids.py [r4] [--sanitize=thread] [--wide]      # --wide: the MG_LANE_WIDE variant of the generator kernels (mg_genlane.h)"""
 import concurrent.futures
 import json
 import os
@@ -15,23 +15,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 import build_emu  # noqa: E402
-from conftest import ALL_IDS, SENTENCE_IDS, STUCK_IDS  # noqa: E402
+import test_emu_cpu as T  # noqa: E402
 
 
 def main():
     rnd = next((a for a in sys.argv[1:] if not a.startswith("--")), "r4")
     san = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--sanitize=")), None)
-    lib = build_emu.build([], sanitize=san)
+    wide = "--wide" in sys.argv
+    lib = build_emu.build(["-DMG_LANE_WIDE=1"] if wide else [], sanitize=san)
     env = dict(os.environ, MINIGRID_AMD_LIB=lib, MINIGRID_AMD_NO_TORCH="1", **(build_emu.sanitizer_env(san) if san else {}))
-    ids = list(ALL_IDS) + [i for i in STUCK_IDS if i not in ALL_IDS]
-    cases = []
-    for i in ids:
-        c = {"env": i, "n": 40, "launches": [16, 5], "spare_ring": 4, "stepped": 2}
-        if i in STUCK_IDS:
-            continue                          # (its resets hang in the reference on some seeds: covered by its own GPU test with stuck_place_agent="redraw")
-        if i not in SENTENCE_IDS:
-            c["max_steps"] = 6                # episodes end every few steps: spares taken, rings refilled
-        cases.append(c)
+    cases = T.all_id_cases()
     chunks = [cases[k::7] for k in range(7)]
     t0 = time.time()
 
@@ -46,7 +39,7 @@ def main():
     reports = [r for _, rs, _ in res for r in rs]
     ok = sum(1 for r in lines if r["ok"])
     head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
-    name = os.path.join(ROOT, "profiles", rnd, "emu_all_ids" + ("_" + san.replace(",", "_") if san else "") + ".txt")
+    name = os.path.join(ROOT, "profiles", rnd, "emu_all_ids" + ("_lanewide" if wide else "") + ("_" + san.replace(",", "_") if san else "") + ".txt")
     with open(name, "w") as f:
         f.write(f"# {os.path.basename(lib)} (tree {head}): every registered id but BabyAI-SynthS5R2-v0, 40 envs, reset(seed=0), fused launches of 16 and 5 steps under the\n"
                 f"# device policy, 2 single steps, ring of 4 spares, max_steps 6 (the sentence levels keep their own): every slot's image, reward bytes, flags,\n"

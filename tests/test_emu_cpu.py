@@ -109,6 +109,29 @@ def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
     assert sum(r["episodes"] for r in lines) > 4000
 
 
+def all_id_cases():
+    """One small case per registered id (BabyAI-SynthS5R2-v0 aside: its reference resets hang on some seeds, tests/test_gpu_synths5r2.py): 40 envs, fused
+    launches of 16 and 5 steps, 2 single steps, a ring of 4 spares, episodes ending every few steps (the sentence levels keep their own step limit)."""
+    from conftest import ALL_IDS, SENTENCE_IDS, STUCK_IDS
+    cases = []
+    for i in ALL_IDS:
+        if i in STUCK_IDS:
+            continue
+        c = {"env": i, "n": 40, "launches": [16, 5], "spare_ring": 4, "stepped": 2}
+        if i not in SENTENCE_IDS:
+            c["max_steps"] = 6
+        cases.append(c)
+    return cases
+
+
+def test_every_id_on_the_lane_wide_variant():
+    """All 171 ids through the MG_LANE_WIDE variant's kernels (one lane per episode for every level: 64 episodes per emulated wavefront, which is why this
+    takes seconds -- the product's wavefront-per-episode generators take two minutes for the same list: profiles/emu_all_ids.py, profiles/r4/emu_all_ids*.txt)."""
+    cases = all_id_cases()
+    assert len(cases) >= 170
+    _run(["-DMG_LANE_WIDE=1"], cases)
+
+
 def test_product_kernels_under_other_legal_schedules():
     """The emulator's default schedule is one of many the device may take.  EMU_SCHED_SEED shuffles what is free: the order of a grid's workgroups, whose
     turn it is among the waves of a workgroup, where a wave is preempted (after any cross-lane operation), ascending or descending lanes.  The LOG /
