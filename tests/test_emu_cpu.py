@@ -10,7 +10,8 @@ test_verifier_cpu / test_generators_cpu) cannot see -- the wave-level plumbing -
 parity gate (timing, memory ordering and register limits are not modelled).
 
 The second half runs the MG_LANE_WIDE variant of the generator kernels (mg_genlane.h: one lane per episode for EVERY level, written after
-round 4's GPU minutes were spent): its kernels have not run on a GPU yet -- here they do run, for 30 levels of every kernel group."""
+round 4's GPU minutes were spent): its kernels have not run on a GPU yet -- here they do run, for 30 levels of every kernel group in depth and for every
+registered id once."""
 import json
 import os
 import subprocess
