@@ -43,3 +43,9 @@ def test_reference_goldens_of_the_baseline_levels_on_the_emulated_kernels():
 
 def test_facade_behaviour_tests_on_the_emulated_kernels():
     _rerun("test_gpu_parity.py", " or ".join(FUNCTIONAL), len(FUNCTIONAL))
+
+
+def test_philox_generator_kernels_on_the_emulator():
+    """MG_RNG_PHILOX (tests/test_gpu_philox.py): the Philox-keyed generator kernels' episodes injected into the oracle and stepped side by side, and the
+    fused path against stepping -- with 200 envs instead of thousands (the tests scale themselves down under MINIGRID_AMD_EMU_RERUN)."""
+    _rerun("test_gpu_philox.py", "state_injection or deterministic", 5)

@@ -6,6 +6,11 @@ Philox layouts differ from numpy's PCG64 layouts by construction, so parity is e
 import numpy as np
 import pytest
 
+def _on_emu():
+    import os
+    return os.environ.get("MINIGRID_AMD_EMU_RERUN") == "1"
+
+
 pytestmark = pytest.mark.gpu
 
 N_CHI = 10240
@@ -135,7 +140,7 @@ def test_philox_generated_episodes_step_like_the_reference_after_state_injection
     """device-generated (Philox) episodes injected into the oracle; 300 identical steps, every output."""
     import minigrid_amd as mg
     from oracle import oracle as O
-    n = 4096
+    n = 4096 if not _on_emu() else 200       # (tests/test_emu_gpu_suite_cpu.py re-runs this on the host emulator: the same kernels, fewer envs)
     mode = "full" if full else "partial"
     env = mg.make_vec(env_id, n, rng="philox", obs_mode=mode, autoreset_mode="disabled")
     orc = O.OracleVec(env_id, n, full_obs=full)
@@ -153,7 +158,7 @@ def test_philox_generated_episodes_step_like_the_reference_after_state_injection
         assert rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
         assert (obs["direction"] == od).all()
         nterm += int(term.sum())
-    if "Empty" in env_id or "Lava" in env_id:
+    if ("Empty" in env_id or "Lava" in env_id) and not _on_emu():
         assert nterm > n // 4
     g1, a1 = env.get_state(); g2, a2 = orc.get_state()
     assert (g1 == g2).all() and (a1[:, :6] == a2[:, :6]).all()
@@ -163,7 +168,7 @@ def test_philox_generated_episodes_step_like_the_reference_after_state_injection
 def test_philox_fused_rollout_is_deterministic_and_matches_stepping():
     """Philox mode through the fused path: two handles agree, and fused == step-by-step with the recorded actions."""
     import minigrid_amd as mg
-    n = 3000
+    n = 3000 if not _on_emu() else 200
     a = mg.make_vec("BabyAI-GoToRedBall-v0", n, rng="philox", traj_slots=16)
     b = mg.make_vec("BabyAI-GoToRedBall-v0", n, rng="philox")
     a.reset(seed=8); b.reset(seed=8)
