@@ -18,7 +18,7 @@ import build_emu  # noqa: E402
 import test_emu_cpu as T  # noqa: E402
 import test_emu_sanitizers_cpu as S  # noqa: E402
 
-EXPECT = {"thread": {4: "report", 5: "clean", 6: "report", 7: "report"}, "address,undefined": {1: "report", 2: "report", 3: "report", 5: "clean"}}
+EXPECT = {"thread": {4: "report", 5: "clean", 6: "report", 7: "report", 8: "report"}, "address,undefined": {1: "report", 2: "report", 3: "report", 5: "clean"}}
 
 
 def main():

@@ -6,7 +6,8 @@ namespace mg { extern uint8_t smem[160 * 1024]; }
 // (tests/test_emu_sanitizers_cpu.py) Tiny kernels that each do ONE thing on purpose, so that "no report" from the real kernels means something.
 //   expected to be REPORTED: 1 a global load one byte past a device buffer; 2 an LDS store one byte past the launch's dynamic LDS size;
 //   3 a misaligned 4-byte load and a shift by the operand's width; 4 two waves store to one LDS word with nothing between them; 6 two workgroups
-//   store to one global word; 7 lane 1 reads the LDS word lane 0 of its wave wrote with no wave-order marker between them (a lockstep assumption)
+//   store to one global word; 7 lane 1 reads the LDS word lane 0 of its wave wrote with no wave-order marker between them (a lockstep assumption);
+//   8 a step counter published before the data it announces, read by a polling wave
 //   expected to be CLEAN: 5 the hand-offs the kernels use -- __syncthreads between a write and another wave's read, a SyncWord counter published
 //   behind the data and polled by another wave, a wave barrier between two lanes of a wave, atomics from two workgroups
 struct ProbeArgs { int what; uint8_t* buf; int lds; };
@@ -35,6 +36,14 @@ static void probe_body(void* c) {
     }
     case 6: if (tid == 0) ((uint32_t*)a.buf)[1] = blockIdx.x; break;
     case 7: if (tid == 0) lds[3] = 1u; if (tid == 1) sink = lds[3]; break;
+    case 8: {                              // a counter published BEFORE the data it announces
+      ::emu::SyncWord* sync = (::emu::SyncWord*)(mg::smem + 64);
+      if (tid == 0) *sync = 0u;
+      __syncthreads();
+      if (wave == 0) { if (lane == 0) { *sync = 1u; lds[1] = 9u; } }
+      else { while ((uint32_t)emu_readfirstlane((int)(uint32_t)*sync) < 1u) emu_yield(); if (lane == 0) sink = lds[1]; }
+      break;
+    }
     default: break;
   }
   (void)sink;
@@ -43,7 +52,7 @@ extern "C" int emu_san_probe(int what) {
   ProbeArgs a; a.what = what; a.lds = 256; a.buf = nullptr;
   if (hipMalloc((void**)&a.buf, 100) != hipSuccess) return -1;
   memset(a.buf, 0, 100);
-  emu::launch(probe_body, &a, dim3(what == 6 || what == 5 ? 2 : 1), dim3(what == 4 || what == 5 ? 128 : 64), (size_t)a.lds);
+  emu::launch(probe_body, &a, dim3(what == 6 || what == 5 ? 2 : 1), dim3(what == 4 || what == 5 || what == 8 ? 128 : 64), (size_t)a.lds);
   hipFree(a.buf);
   return 0;
 }

@@ -101,7 +101,7 @@ def _subset():
 
 def test_thread_sanitizer_probes():
     _require_runtime("thread")
-    for what in (4, 6, 7):              # two waves / two workgroups / two lanes of a wave on one word with nothing between them
+    for what in (4, 6, 7, 8):           # two waves / two workgroups / two lanes of a wave on one word with nothing between them; a counter published before its data
         out = probe("thread", what)
         assert out.returncode == 0 and "rc 0" in out.stdout, (what, out.stderr[-2000:])
         assert "ThreadSanitizer: data race" in out.stderr and "emu_probe.cpp" in out.stderr, (what, out.stderr[-2000:])
