@@ -7,7 +7,7 @@ What it is for: after the round's GPU minutes are spent, source edits that are m
 emulator / sanitizer annotations under MG_EMU, comments) are checked to produce the SAME device code as the tree the GPU suite last ran on.
 Prints one line per translation unit (identical / DIFFERENT + the number of differing lines) and exits 1 on any difference.
 Compared: the assembly text without comments and .ident / .file / .loc lines, the compilation unit's id symbol normalised.
-    --reuse: compare the assembly already under .scratch/isa_diff/ (no recompile)."""
+    --reuse: compare the assembly already under $MINIGRID_AMD_SCRATCH/isa_diff/ (default /tmp/minigrid_scratch) (no recompile)."""
 import concurrent.futures
 import os
 import re
@@ -16,7 +16,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCRATCH = os.path.join(ROOT, ".scratch", "isa_diff")
+SCRATCH = os.path.join(os.environ.get("MINIGRID_AMD_SCRATCH") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "minigrid_scratch"), "isa_diff")   # out of the tree
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S"]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE: builds tests/emu/_build/libminigrid_emu.so = the product's HIP sources (minigrid_amd/csrc/*.hip, unchanged) compiled as plain
+"""TEST INFRASTRUCTURE: builds $MINIGRID_AMD_EMU_BUILD/libminigrid_emu.so (default /tmp/minigrid_emu_build, out of the tree) = the product's HIP sources (minigrid_amd/csrc/*.hip, unchanged) compiled as plain
 C++ against tests/emu/shim/hip/hip_runtime.h + the host SIMT emulator tests/emu/emu_runtime.cpp.  Used only by tests/test_emu_cpu.py (through
 MINIGRID_AMD_LIB in a subprocess); the product never loads it.
 
@@ -17,7 +17,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "minigrid_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# generated objects NEVER live inside the repo (a 600 MB tests/emu/_build once made the tree too big for the GPU box snapshot)
+OUT = os.environ.get("MINIGRID_AMD_EMU_BUILD") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "minigrid_emu_build")
 CXX_CANDIDATES = ["/opt/rocm/lib/llvm/bin/clang++", "clang++", "g++"]
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fno-strict-aliasing", "-Wno-unknown-attributes", "-Wno-unused-value", "-Wno-attributes", "-w",
          "-I" + os.path.join(HERE, "shim"), "-I" + os.path.join(ROOT, "include")]

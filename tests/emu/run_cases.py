@@ -2,7 +2,7 @@
 """TEST INFRASTRUCTURE: runs product-level parity cases against a library built for the host SIMT emulator (tests/emu/build_emu.py) in THIS process
 (the library is chosen once per process: MINIGRID_AMD_LIB) and prints one JSON line per case.  tests/test_emu_cpu.py drives it.
 
-    MINIGRID_AMD_LIB=tests/emu/_build/libminigrid_emu.so MINIGRID_AMD_NO_TORCH=1 python tests/emu/run_cases.py '<json list of cases>'
+    MINIGRID_AMD_LIB=/tmp/minigrid_emu_build/libminigrid_emu.so MINIGRID_AMD_NO_TORCH=1 python tests/emu/run_cases.py '<json list of cases>'
 
 A case: {"env": id, "n": envs, "launches": [T, ...], "full": bool, "max_steps": k | null, "knobs": {"MG_...": "v"}, "stepped": steps,
 "autoreset": "next_step" | "same_step", "obs_mode": ..., "view": ViewSizeWrapper's size, "spare_ring": R}: reset(seed=0), then fused launches of the given lengths under the device's Philox policy -- every slot's
