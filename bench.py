@@ -31,6 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILES_DIR = os.path.join(ROOT, "profiles")
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
@@ -73,13 +74,13 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, v
     return b
 
 
-def _profile_metas(workload: str, n_per_gpu: int, spl: int):
+def _profile_metas(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
     """Committed rocprofv3 passes of `workload` taken at THIS batch size and THIS steps-per-launch: (directory, meta, suffix) for every
-    profiles/r*/meta_<workload><suffix>.json that matches (suffix "" = the 32-step launches of a long run, "_spl20" = the driver-sized
+    profiles/r*/meta_<workload><suffix>.json that matches AND was taken on this build of the step kernels (suffix "" = the 32-step launches of a long run, "_spl20" = the driver-sized
     run; the collection scripts write the run's parameters into the meta file next to the counters), oldest round first."""
     import glob
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"meta_{workload}*.json"))):
+    for f in sorted(glob.glob(os.path.join(PROFILES_DIR, "r*", f"meta_{workload}*.json"))):
         suffix = os.path.basename(f)[len(f"meta_{workload}"):-len(".json")]
         if suffix and not suffix.startswith("_spl"):
             continue                                   # meta_<workload>_<other workload suffix>.json of a longer name
@@ -87,16 +88,30 @@ def _profile_metas(workload: str, n_per_gpu: int, spl: int):
             meta = json.load(open(f))
         except Exception:
             continue
-        if int(meta.get("envs_per_gpu", -1)) == n_per_gpu and int(meta.get("steps_per_launch", -1)) == spl:
-            out.append((os.path.dirname(f), meta, suffix))
-    return out
+        if int(meta.get("envs_per_gpu", -1)) == n_per_gpu and int(meta.get("steps_per_launch", -1)) == spl \
+                and (any_build or meta.get("step_kernel_srchash") == step_kernel_srchash()):
+            out.append((os.path.dirname(f), meta, suffix))     # (a pass of ANOTHER build of the step kernels is never quoted: its bytes and
+    return out                                                 #  durations price a different kernel -- the line falls back to the analytic floor)
+
+
+_SRCHASH = None
+
+
+def step_kernel_srchash():
+    """Hash of the step kernels' sources + flags of THIS tree (minigrid_amd/build.py step_kernel_hash; the library is rebuilt whenever its
+    sources change, so this is the hash of the kernels that run)."""
+    global _SRCHASH
+    if _SRCHASH is None:
+        from minigrid_amd import build as _b
+        _SRCHASH = _b.step_kernel_hash()
+    return _SRCHASH
 
 
 def _pmc_files(d: str, workload: str, suffix: str):
     return [os.path.join(d, f"pmc_{c}_{workload}{suffix}.txt") for c in ("FETCH_SIZE", "WRITE_SIZE")]
 
 
-def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
+def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload><suffix>.txt, separate --pmc runs, written by profiles/collect*.sh).
     Units and gfx950 correction as MI355X_MICROARCH.md prescribes: the counters are in KiB (x1024); FETCH_SIZE reads
@@ -105,7 +120,7 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
     batch size and steps per launch (the per-call maximum = the full launches) -- or None."""
     import re
     best = None
-    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl):
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
         vals, parts = {}, {}
         for c, f in zip(("FETCH_SIZE", "WRITE_SIZE"), _pmc_files(d, workload, suffix)):
             if not os.path.exists(f):
@@ -127,12 +142,12 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int):
     return best
 
 
-def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int):
+def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
     """Average duration of a FULL step launch / steps per launch from the committed `rocprofv3 --kernel-trace --stats` summary of
     this command (profiles/<round>/kernel_stats_<workload><suffix>.csv; meta_<workload><suffix>.json holds the full-launch average
     computed from the trace by the collection script), or None."""
     best = None
-    for _d, meta, _suffix in _profile_metas(workload, n_per_gpu, spl):
+    for _d, meta, _suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
         try:
             best = float(meta["full_launch_avg_us"]) / spl
         except Exception:
@@ -140,9 +155,9 @@ def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int):
     return best
 
 
-def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int):
+def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
     src = None
-    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl):
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
         if all(os.path.exists(f) for f in _pmc_files(d, workload, suffix)):
             src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}{suffix}.txt"
     return src
@@ -348,6 +363,8 @@ def main(argv=None):
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
     ap.add_argument("--obs-mode", default="", help="override the workload's obs mode: partial|full|onehot|symbolic|rgb|rgb_partial")
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper) for partial/onehot")
+    ap.add_argument("--spl", type=int, default=0, help="cap the steps per fused launch (profiling the driver's launch shape, 20 steps, over many "
+                    "launches: --steps 400 --spl 20); 0 = min(max_fused_steps, steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets the multi-process path be exercised "
@@ -408,11 +425,16 @@ def main(argv=None):
             raise SystemExit("bench.py: MINIGRID_AMD_LIB points at the host emulator of tests/emu (test infrastructure): nothing to measure")
     fused = bool(args.fused)
     spl = min(env.max_fused_steps, args.steps) if fused else 1          # steps per k_step launch in the timed region
+    if fused and args.spl:
+        spl = max(1, min(spl, args.spl))
     env.reset(seed=0)
     env.sync()
 
     def run(k, seed):
-        if not gather:
+        if not gather and fused and args.spl:
+            for c in range(0, k, spl):
+                env.rollout(min(spl, k - c), action_seed=seed + 7919 * c, fused=True)
+        elif not gather:
             env.rollout(k, action_seed=seed, fused=fused)
         elif fused:
             # ONE all_gather_into_tensor per fused launch (its max_fused_steps step records = one contiguous block of the trajectory
@@ -497,7 +519,7 @@ def main(argv=None):
                                   if spl > 1 else f"one {kname} launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "steps_per_launch": spl,
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"],
-                       "library_build": build_info, "environment": mg_environment(), "stub": not use_gpu,
+                       "library_build": build_info, "step_kernel_srchash": step_kernel_srchash(), "environment": mg_environment(), "stub": not use_gpu,
                        "clock": "host_ms: perf_counter from just before the first launch is enqueued until the stop event on the step stream, the "
                                 "generator stream and (gather) the communication stream have each been waited for; "
                                 "host_ms_incl_device_sync adds the closing torch.cuda.synchronize()",
@@ -513,7 +535,7 @@ def main(argv=None):
                          "bytes_per_launch": real_bytes_per_launch,
                          "bytes_source": ("rocprofv3 PMC counters (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) of a committed pass of this launch shape"
                                           if traffic else "analytic floor: outputs of every step + grids / agent records once per launch (no committed "
-                                                          "PMC pass has this batch size and steps per launch)"),
+                                                          "PMC pass has this batch size, steps per launch AND this build's step_kernel_srchash)"),
                          "traffic": traffic,
                          "traffic_unit": "bytes per full step-kernel launch (rocprofv3 PMC of the same command, committed under profiles/; not measured in this run)",
                          "traffic_source": pmc_traffic_source(args.workload, n_per_gpu, spl) if quotable else None,

@@ -61,6 +61,15 @@ def _source_hash() -> str:
     return _hash_files(SOURCES + HEADERS, me)
 
 
+def step_kernel_hash() -> str:
+    """sha256 (first 16 hex digits) of what the step kernels (k_roll7 / k_step, the kernels bench.py's roofline prices) are compiled from:
+    the step translation units, their headers and the compiler flags -- NOT mg_api.hip's host code and NOT the generator units.  A committed
+    rocprofv3 pass carries the hash of the build it measured (profiles/r*/meta_*.json "step_kernel_srchash"); bench.py refuses to quote a
+    pass whose hash differs from the tree it runs on."""
+    units = sorted(u for u in UNITS if u.startswith("mg_step_"))
+    return _hash_files(units + sorted(set(_STEP)), " ".join(CFLAGS) + " gfx950")[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True

@@ -41,20 +41,20 @@ def test_committed_profiles_are_quoted_only_for_the_same_launch_shape():
         env_id, n, obs_mode = b.WORKLOADS[name]
         meta = json.load(open(os.path.join(ROOT, "profiles", "r3", f"meta_{name}.json")))
         assert meta["envs_per_gpu"] == n and meta["steps_per_launch"] == 32
-        traffic = b.pmc_traffic_bytes(name, n, 32)
-        us = b.rocprof_kernel_us_per_step(name, n, 32)
+        traffic = b.pmc_traffic_bytes(name, n, 32, any_build=True)
+        us = b.rocprof_kernel_us_per_step(name, n, 32, any_build=True)
         W = H = 9 if "Lava" in env_id else 8
         algo = b.algorithmic_bytes_per_env_step(env_id, obs_mode, W, H) * n * 32
         assert traffic is not None and 0.3 * algo < traffic < 1.0 * algo, (name, traffic, algo)     # the grids stay in LDS: about half
         # the latest round's pass of this launch shape is the one quoted
-        src = b.pmc_traffic_source(name, n, 32)
+        src = b.pmc_traffic_source(name, n, 32, any_build=True)
         latest = json.load(open(os.path.join(ROOT, os.path.dirname(src), f"meta_{name}.json")))
         assert us is not None and abs(us - latest["full_launch_avg_us"] / 32) < 1e-9
         # real bytes / kernel time stays below the part's peak
         assert traffic / (us * 32 * 1e-6) < b.HBM_PEAK_GBPS * 1e9
         # another launch length or another batch size must not be given these counters
-        assert b.pmc_traffic_bytes(name, n, 19) is None and b.rocprof_kernel_us_per_step(name, n, 19) is None
-        assert b.pmc_traffic_bytes(name, n // 2, 32) is None
+        assert b.pmc_traffic_bytes(name, n, 19, any_build=True) is None and b.rocprof_kernel_us_per_step(name, n, 19, any_build=True) is None
+        assert b.pmc_traffic_bytes(name, n // 2, 32, any_build=True) is None
 
 
 def test_committed_bench_lines_are_self_consistent():
@@ -85,8 +85,8 @@ def test_round4_profiles_cover_both_launch_shapes():
         meta = json.load(open(os.path.join(r4, f"meta_{name}{sfx}.json")))
         assert meta["envs_per_gpu"] == n and meta["steps_per_launch"] == spl
         assert "attribution=0" in meta["library_build"] and not meta["environment"], meta      # the product build, no MG_* switch set
-        traffic, us = b.pmc_traffic_bytes(name, n, spl), b.rocprof_kernel_us_per_step(name, n, spl)
-        assert b.pmc_traffic_source(name, n, spl).startswith("profiles/r4/")
+        traffic, us = b.pmc_traffic_bytes(name, n, spl, any_build=True), b.rocprof_kernel_us_per_step(name, n, spl, any_build=True)
+        assert b.pmc_traffic_source(name, n, spl, any_build=True).startswith("profiles/r4/")
         W = H = 9 if "Lava" in env_id else 8
         obe = 3 * W * H if obs_mode == "full" else 147
         floor = (obe + 16 + (2 * W * H + 16) / spl) * n * spl
@@ -94,8 +94,34 @@ def test_round4_profiles_cover_both_launch_shapes():
         frac = traffic / (us * spl * 1e-6) / (b.HBM_PEAK_GBPS * 1e9)
         assert 0.25 < frac < 1.0, (name, frac)
     # round 3's headline fraction on real bytes was 0.54; round 4's committed passes
-    t, us = b.pmc_traffic_bytes("empty8x8", 65536, 32), b.rocprof_kernel_us_per_step("empty8x8", 65536, 32)
+    t, us = b.pmc_traffic_bytes("empty8x8", 65536, 32, any_build=True), b.rocprof_kernel_us_per_step("empty8x8", 65536, 32, any_build=True)
     assert t / (us * 32e-6) / 8e12 > 0.60
+
+
+def test_profiles_are_bound_to_the_build_of_the_step_kernels(tmp_path, monkeypatch):
+    """a committed PMC / kernel-trace pass is quoted only for the build of the step kernels it measured
+    (meta "step_kernel_srchash" == minigrid_amd.build.step_kernel_hash() of this tree); host-only edits (mg_api.hip) do not change the hash."""
+    b = _bench()
+    from minigrid_amd import build as B
+    h = B.step_kernel_hash()
+    assert len(h) == 16 and h == b.step_kernel_srchash()
+    # rounds 3 and 4 carry no hash: never quoted by a live line any more
+    assert b.pmc_traffic_bytes("empty8x8", 65536, 32) is None or \
+        any(m.get("step_kernel_srchash") == h for _d, m, _s in b._profile_metas("empty8x8", 65536, 32))
+    d = tmp_path / "r9"
+    d.mkdir()
+    for hh, expect in ((h, True), ("0" * 16, False)):
+        (d / "meta_empty8x8.json").write_text(json.dumps({"envs_per_gpu": 65536, "steps_per_launch": 32, "full_launch_avg_us": 64.0,
+                                                          "step_kernel_srchash": hh}))
+        (d / "pmc_FETCH_SIZE_empty8x8.txt").write_text("FETCH_SIZE,void mg::k_roll7<0, false, true>,calls=20,mean=100.0,total=2000.0,max=120.0\n")
+        (d / "pmc_WRITE_SIZE_empty8x8.txt").write_text("WRITE_SIZE,void mg::k_roll7<0, false, true>,calls=20,mean=300000.0,total=1.0,max=340000.0\n")
+        monkeypatch.setattr(b, "PROFILES_DIR", str(tmp_path))
+        t = b.pmc_traffic_bytes("empty8x8", 65536, 32)
+        assert (t == (2 * 120.0 + 340000.0) * 1024) if expect else (t is None)
+        assert (b.rocprof_kernel_us_per_step("empty8x8", 65536, 32) == 2.0) if expect else (b.rocprof_kernel_us_per_step("empty8x8", 65536, 32) is None)
+    # the hash covers the step units, their headers and the flags -- not the host runtime and not the generators
+    units = [u for u in B.UNITS if u.startswith("mg_step_")]
+    assert units and "mg_api.hip" not in units and all("mg_gen" not in x for x in units + B._STEP)
 
 
 def test_round4_bench_lines_are_self_consistent():
@@ -151,7 +177,7 @@ def test_roofline_fraction_is_priced_on_real_bytes():
     quotes them; the section-8(d) figure is a named secondary field."""
     b = _bench()
     n, spl = 65536, 32
-    traffic = b.pmc_traffic_bytes("empty8x8", n, spl)
+    traffic = b.pmc_traffic_bytes("empty8x8", n, spl, any_build=True)
     floor = (147 + 16 + (2 * 64 + 16) / spl) * n * spl
     assert traffic is not None and 0.95 * floor < traffic < 1.10 * floor, (traffic, floor)      # the counters agree with the analytic floor
     assert b.algorithmic_bytes_per_env_step("MiniGrid-Empty-8x8-v0", "partial", 8, 8) * n * spl > 1.8 * traffic   # section 8(d) overcounts ~2x

@@ -297,8 +297,11 @@ def _worker_blocks_emu(rank, world, port, lib, env_id, n, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("env_id,n,steps", [("MiniGrid-DoorKey-8x8-v0", 48, 80), ("BabyAI-GoToRedBall-v0", 37, 64)])   # 37: ragged 19 + 18
-def test_fused_block_gather_on_the_emulated_library(tmp_path, env_id, n, steps):
+@pytest.mark.parametrize("env_id,n,steps,world", [("MiniGrid-DoorKey-8x8-v0", 48, 80, 2), ("BabyAI-GoToRedBall-v0", 37, 64, 2),   # 37: ragged 19 + 18
+                                                  # THREE ranks and N % 3 != 0 (13 + 12 + 12, then 34 + 33 + 33 = two workgroups' worth on no rank):
+                                                  # the padded all-gather of sharded.py is the path an 8-GPU node with a ragged batch takes first
+                                                  ("BabyAI-GoToRedBall-v0", 37, 40, 3), ("MiniGrid-DoorKey-8x8-v0", 100, 33, 3)])
+def test_fused_block_gather_on_the_emulated_library(tmp_path, env_id, n, steps, world):
     """rollout_gather with the REAL library underneath (mg_rollout_block on the host SIMT emulator of tests/emu): the kernels write the step records,
     rank 1's device policy draws the actions of ITS global env indices (env_index_base), the gathered blocks unpacked with the host-side record
     layout equal a single-process oracle rollout -- what tests/test_gpu_multi.py checks over RCCL, here over gloo without a GPU."""
@@ -306,7 +309,6 @@ def test_fused_block_gather_on_the_emulated_library(tmp_path, env_id, n, steps):
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
     import build_emu
     lib = build_emu.build([])
-    world = 2
     mp.spawn(_worker_blocks_emu, args=(world, _free_port(), lib, env_id, n, steps, str(tmp_path)), nprocs=world, join=True)
     ref = OracleShard(env_id, n)
     ref.reset(seed=9)
