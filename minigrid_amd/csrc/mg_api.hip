@@ -1121,7 +1121,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
       // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 16 GB cap
       const size_t per_slot_env = (size_t)e->CS + 16 + 40 + (e->sentence ? 4 + INSTR_WORDS * 8 : 0);
-      while (R > 4 && (size_t)R * e->N * per_slot_env > ((size_t)16 << 30)) R >>= 1;     // (16 GB of 288)
+      // ... and against a quarter of what the device has free right now (several handles per GPU, or a part with less HBM: ADVICE r4)
+      size_t ring_cap = (size_t)16 << 30;                                                  // (16 GB of 288)
+      { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) ring_cap = std::min(ring_cap, fr / 4); }
+      while (R > 4 && (size_t)R * e->N * per_slot_env > ring_cap) R >>= 1;
     }
     e->R = R; e->cb = std::max(1, R / REFILL_LAG);
   }
@@ -1970,7 +1973,7 @@ int mg_selftest_generate(const mg_config* cfg, int32_t n, int32_t episodes, cons
   A.dst_instr = sentence ? d_instr.data() : nullptr; A.gstate = sentence ? d_gstate.data() : nullptr; A.gsnap = sentence ? d_gsnap.data() : nullptr;
   A.err = d_err.data(); A.counters = d_counters.data(); A.N = n; A.CS = CS; A.stat_gen_off = STAT_EPISODES;
   A.stuck_mode = (cfg->env_kind == MG_ENV_LEVELGEN && ((cfg->num_crossings >> 10) & 1)) ? 2 : 0;
-  switch (lane_fn_of_kind(cfg->env_kind)) {
+  switch (lane_fn_of_kind_all(cfg->env_kind)) {
 #define MG_ST_FN(k) case k: selftest_generate_fn<k>(A, n, episodes, W, H); break;
     MG_ST_FN(0) MG_ST_FN(1) MG_ST_FN(2) MG_ST_FN(3) MG_ST_FN(4) MG_ST_FN(5) MG_ST_FN(6) MG_ST_FN(7) MG_ST_FN(8) MG_ST_FN(9) MG_ST_FN(10) MG_ST_FN(11)
     MG_ST_FN(12) MG_ST_FN(13) MG_ST_FN(14) MG_ST_FN(16) MG_ST_FN(17) MG_ST_FN(18) MG_ST_FN(19) MG_ST_FN(136) MG_ST_FN(137) MG_ST_FN(138) MG_ST_FN(139)

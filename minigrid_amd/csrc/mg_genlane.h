@@ -17,10 +17,14 @@
 
 namespace mg {
 
-// MG_LANE_WIDE = 1 (a VARIANT build: `python profiles/variant_build.py lanewide --units=mg_gen_lane.hip,mg_api.hip -DMG_LANE_WIDE=1`; the product library is built with 0): the lane kernels also
-// serve every level whose generator has a per-lane form -- all of them (mg_gen.h: templated on the grid type, the per-lane forms pinned on the
-// CPU by tests/test_generators_cpu.py through mg_selftest_generate, which runs generate_episode_lane<R, true> below).  Written in round 4 after the
-// GPU budget was spent: NOT yet run on a GPU; profiles/r5_lane_wide.sh is the validation + measurement run for it.
+// Which levels the lane kernels serve.  Round 5 ran the "wide" build (every generator on lanes, one kernel per generator function) on MI355X
+// (profiles/r5/lane_wide_*: the whole GPU suite green with it; lane refill against the wavefront-per-episode refill of the SAME library, G env-steps/s):
+//   KeyCorridorS3R3 x 131 072   3.18 -> 14.53      UnlockPickup x 131 072   21.0 -> 23.5      BabyAI-GoTo x 131 072   1.66 -> 1.80
+//   BossLevel x 131 072         4.58 ->  3.07      MultiRoom-N6 x 65 536     2.40 ->  2.18
+// so the product build moves the levels where it wins -- the Unlock family (kinds 9-11: one locked door, whole-map retries are rare) and KeyCorridor
+// (14, 30) -- and leaves the maze / sentence levels (long reachability floods and whole-map retries: 64 diverging lanes wait for the unluckiest) and
+// MultiRoom with k_refill.  MG_LANE_WIDE = 1 (a VARIANT build: `python profiles/variant_build.py lanewide --units=mg_gen_lane.hip,mg_api.hip
+// -DMG_LANE_WIDE=1`) still moves every level, for A/B runs.
 #ifndef MG_LANE_WIDE
 #define MG_LANE_WIDE 0
 #endif
@@ -28,10 +32,12 @@ MG_HD bool lane_gen_kind_base(int kind) {
   return kind == 0 || kind == 1 || kind == 2 || kind == 3 || kind == 4 || kind == 5 || kind == 6 || kind == 7 ||
          kind == 16 || kind == 17 || kind == 18 || kind == 19 || kind == 20;
 }
+// the levels of the per-function lane kernels the PRODUCT build instantiates: FN 2 (gen_unlock_family) and FN 5 (gen_keycorridor)
+MG_HD bool lane_gen_kind_product_fn(int kind) { return kind == 9 || kind == 10 || kind == 11 || kind == 14 || kind == 30; }
 // the levels whose per-lane generator exists (GoToDoor 8 .. KeyCorridor 14, LockedRoom 21, Playground 22, MultiRoom 23, the BabyAI levels 24-53):
 // every level but DynamicObstacles, whose episodes are drawn inside the step kernel (mg_dynobs.h)
 MG_HD bool lane_gen_kind_wide(int kind) { return lane_gen_kind_base(kind) || (kind >= 8 && kind <= 14) || (kind >= 21 && kind <= 53); }
-MG_HD bool lane_gen_kind(int kind) { return MG_LANE_WIDE ? lane_gen_kind_wide(kind) : lane_gen_kind_base(kind); }
+MG_HD bool lane_gen_kind(int kind) { return MG_LANE_WIDE ? lane_gen_kind_wide(kind) : (lane_gen_kind_base(kind) || lane_gen_kind_product_fn(kind)); }
 MG_HD int lane_grid_stride(int CS) { return CS + 4; }                 // odd dword stride: the 64 lanes' grids start in different LDS banks
 constexpr int LANE_INSTR_STRIDE = INSTR_WORDS + 1;                    // u64 per lane: the sentence levels' instruction record under construction
 // LDS of one generating wavefront: 64 private grids (+ 64 instruction records, sentence levels of the wide build)
@@ -41,7 +47,7 @@ MG_HD int lane_gen_lds_bytes(int CS, bool sentence) { return 64 * lane_grid_stri
 // carrying every generator needs 512 VGPRs and spills (measured at compile time, profiles/r4/lane_wide_build.txt) -- a lane-per-episode kernel lives on
 // its occupancy.  gen_babyai_levels (ten levels behind one run-time switch: 512 VGPRs and 1 KB of scratch even alone) is instantiated per LEVEL:
 // FN = 100 + kind, the kind a compile-time constant.
-MG_HD int lane_fn_of_kind(int kind) {
+MG_HD int lane_fn_of_kind_all(int kind) {            // every level that has a per-lane generator (the host self-test runs them all)
   if (lane_gen_kind_base(kind)) return 0;
   switch (kind) {
     case 8: return 1; case 9: case 10: case 11: return 2; case 12: return 3; case 13: return 4; case 14: case 30: return 5; case 21: return 6;
@@ -50,6 +56,8 @@ MG_HD int lane_fn_of_kind(int kind) {
     default: return kind >= 36 && kind <= 45 ? 100 + kind : kind >= 46 && kind <= 49 ? 16 : -1;
   }
 }
+// the kernel THIS build launches for a level (-1: the level keeps k_refill / k_generate)
+MG_HD int lane_fn_of_kind(int kind) { return lane_gen_kind(kind) ? lane_fn_of_kind_all(kind) : -1; }
 
 // iw: the lane's instruction record (sentence levels), st: LevelGen's locked_room words {as the previous episode left it, scratch} -- WIDE only.
 // FN = 0: every generator the build serves behind a run-time switch (the product kernel; WIDE: the host selftest); FN > 0: that function alone.

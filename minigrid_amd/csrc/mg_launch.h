@@ -42,7 +42,6 @@ MG_DECL_GEN_TU(light_philox) MG_DECL_GEN_TU(roomgrid_philox) MG_DECL_GEN_TU(room
 // k_refill_lane (mg_genlane.h): one lane per episode, for the single-room levels (lane_gen_kind)
 void launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
 void launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
-hipError_t refill_lane_max_lds(int bytes);
 // dispatch on (generator group, stream kind)
 #define MG_GEN_DISPATCH(FN, gg, philox, ...)                                                       \
   do {                                                                                             \

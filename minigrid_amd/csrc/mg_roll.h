@@ -350,11 +350,34 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // against 256 MB of Infinity Cache: 2.15 us per step with plain stores, 2.39 nontemporal), and a one-step launch's observation is read by
 // the consumer right away.  The host decides per launch (StepParams::nt, mg_api.hip `launch_step`: bytes written since the stream was last
 // known idle); the scalars always take plain stores (nontemporal there measured slower: profiles/r4/ab_nt2.txt).
-MG_D void store12(uint8_t* p, const Out12& v, bool nt) {
+// A/B builds only (profiles/variant_build.py ... -DMG_OBS_STORE_AUX=<aux>): the nontemporal instantiation's observation stores as BUFFER stores with
+// explicit cache-policy bits (aux: 1 = sc0, 2 = nt, 16 = sc1; sc1 = write-through, the line is dropped from the XCD's L2 -- MI355X_MICROARCH.md); the
+// product build (-1) keeps the flat stores below
+#ifndef MG_OBS_STORE_AUX
+#define MG_OBS_STORE_AUX -1
+#endif
+// base: wave-uniform (a workgroup's observation block of one step), off: this lane's byte offset inside it
+MG_D void store12(uint8_t* base, uint32_t off, const Out12& v, bool nt) {
+#if MG_OBS_STORE_AUX >= 0 && defined(__HIP_DEVICE_COMPILE__)
+  if (nt) {
+    u32x3_t w; w.x = v.x; w.y = v.y; w.z = v.z;
+    __builtin_amdgcn_raw_buffer_store_b96(w, __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000), (int)off, 0, MG_OBS_STORE_AUX);
+    return;
+  }
+#endif
+  uint8_t* p = base + off;
   if (nt) { u32x3_t w; w.x = v.x; w.y = v.y; w.z = v.z; __builtin_nontemporal_store(w, (u32x3_t*)p); }
   else *(Out12*)p = v;
 }
-MG_D void store16(uint8_t* p, const uint4& v, bool nt) {
+MG_D void store16(uint8_t* base, uint32_t off, const uint4& v, bool nt) {
+#if MG_OBS_STORE_AUX >= 0 && defined(__HIP_DEVICE_COMPILE__)
+  if (nt) {
+    u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(w, __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000), (int)off, 0, MG_OBS_STORE_AUX);
+    return;
+  }
+#endif
+  uint8_t* p = base + off;
   if (nt) { u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, (u32x4_t*)p); }
   else *(uint4*)p = v;
 }
@@ -374,7 +397,7 @@ MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8
     uint32_t o3[3];
     obs7_quad_pack(tq[it & 1], o3);
     Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) store12(obase + (size_t)u * 12, v, NT);
+    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) store12(obase, (uint32_t)u * 12u, v, NT);
   }
 }
 
@@ -383,7 +406,11 @@ constexpr int ROLL_MAX_WAVES = 4;
 #ifndef MG_DPRIO
 #define MG_DPRIO 1
 #endif
-constexpr int ROLL_LOG_STEPS = 8;                             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
+#ifndef MG_ROLL_LOG_STEPS
+#define MG_ROLL_LOG_STEPS 8       // (the inter-wave protocol's stress build, tests/test_gpu_lds_protocol.py, makes it 2: the dynamics wave then waits on the encode waves in nearly every step)
+#endif
+constexpr int ROLL_LOG_STEPS = MG_ROLL_LOG_STEPS;             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
+static_assert(ROLL_LOG_STEPS >= 2 && (ROLL_LOG_STEPS & (ROLL_LOG_STEPS - 1)) == 0, "the step log is a power-of-two ring");
 constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its progress counters
 constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
 #ifndef MG_DYN_WPE
@@ -790,7 +817,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o3[3];
           obs7_quad((uint32_t)u, codes, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          store12(obase + (size_t)u * 12, v, nt);
+          store12(obase, (uint32_t)u * 12u, v, nt);
         }
       } else {
 #else
@@ -802,7 +829,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o4[4];
           obs7_chunk((uint32_t)(it == NIT - 1 ? min(c, NCH - 1) : c), codes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
-          if (it < NIT - 1 || c < NCH) store16(obase + (size_t)c * 16, v, nt);
+          if (it < NIT - 1 || c < NCH) store16(obase, (uint32_t)c * 16u, v, nt);
         }
       } else if (FULL && nvalid == 64) {
         const int nch = 12 * cells;                                               // 64 * 3 * cells / 16 chunks
@@ -810,7 +837,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o4[4];
           obs7_chunk((uint32_t)c, codes, slut, o4);
           uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3];
-          store16(obase + (size_t)c * 16, v, nt);
+          store16(obase, (uint32_t)c * 16u, v, nt);
         }
       } else {
 #endif
@@ -819,7 +846,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         for (int c = lane; c <= nvec; c += 64) {
           uint32_t o4[4];
           obs7_chunk((uint32_t)c, codes, slut, o4);
-          if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase + (size_t)c * 16, v, nt); }
+          if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase, (uint32_t)c * 16u, v, nt); }
           else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
         }
       }
@@ -1032,13 +1059,13 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           uint32_t o3[3];
           obs7_quad((uint32_t)u, codes0, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          store12(obase + (size_t)u * 12, v, nt);
+          store12(obase, (uint32_t)u * 12u, v, nt);
         }
     } else if (!MG_EXPBIT(P, 2))
       for (int c = tid; c <= nvec; c += nthreads) {
         uint32_t o4[4];
         obs7_chunk((uint32_t)c, codes0, slut, o4);
-        if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase + (size_t)c * 16, v, nt); }
+        if (c < nvec) { uint4 v; v.x = o4[0]; v.y = o4[1]; v.z = o4[2]; v.w = o4[3]; store16(obase, (uint32_t)c * 16u, v, nt); }
         else for (int b = 0; b < (nbytes & 15); b++) obase[(nvec << 4) + b] = (uint8_t)(o4[b >> 2] >> (8 * (b & 3)));
       }
   }

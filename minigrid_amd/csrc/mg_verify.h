@@ -186,6 +186,8 @@ MG_HD uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int 
   auto nodef = [&](uint32_t n) -> uint32_t { return (nodes >> (8u * n)) & 255u; };
   auto done_get = [&](uint32_t n, int which) -> uint32_t { return (dn >> (4u * n + 2u * (uint32_t)which)) & 3u; };
   auto done_set = [&](uint32_t n, int which, uint32_t v) { const uint32_t sh = 4u * n + 2u * (uint32_t)which; dn = (dn & ~(3u << sh)) | (v << sh); };
+  // (AndInstr.verify's `use_done_actions and action is self.env.actions.done` branch, verifier.py:561-563, is an IDENTITY test against the enum member:
+  // integer actions -- the only kind a vector of actions holds -- never take it.  This is the integer behaviour)
   auto and_verify = [&](uint32_t n) -> uint32_t {
     const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
     if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, leaf(ia));

@@ -142,6 +142,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+static inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = (size_t)64 << 30; *tot = (size_t)64 << 30; return hipSuccess; }   // (the emulated device: host memory)
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
 hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned flags);

@@ -42,6 +42,13 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-FourRooms-v0", "n": 70, "launches": [32, 13], "max_steps": 20},
     {"env": "MiniGrid-Fetch-8x8-N3-v0", "n": 70, "launches": [32, 13], "max_steps": 20, "stepped": 3},
     {"env": "BabyAI-GoToLocal-v0", "n": 70, "launches": [32, 13], "max_steps": 10},
+    # round 5: the Unlock family and KeyCorridor on the per-function lane kernels (k_refill_lane<R, 2> / <R, 5>) in the PRODUCT build
+    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 100, "launches": [32, 7], "max_steps": 12, "stepped": 3},
+    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
+    {"env": "BabyAI-KeyCorridorS4R3-v0", "n": 40, "launches": [32], "max_steps": 10},
+    {"env": "MiniGrid-Unlock-v0", "n": 70, "launches": [32, 13], "max_steps": 10},
+    {"env": "MiniGrid-UnlockPickup-v0", "n": 70, "launches": [32], "max_steps": 10, "stepped": 3},
+    {"env": "MiniGrid-BlockedUnlockPickup-v0", "n": 70, "launches": [32], "max_steps": 10, "autoreset": "same_step"},
     # k_step: the other observation modes (one-hot, symbolic, ViewSizeWrapper, FullyObs above 341 cells), DynamicObstacles' round-3 launches
     # (live refill + k_move_obstacles) under FullyObs, RGB frames (tile map + k_render)
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "obs_mode": "onehot", "stepped": 3},
@@ -54,7 +61,7 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 20, "launches": [], "max_steps": 6, "obs_mode": "rgb_partial", "stepped": 8},
     # the wavefront-per-episode generators (k_generate / k_refill: WavePcg64's jumped-ahead draws, ballots over the cells, the draw-budget restarts)
     # of every generator group, a handful of envs with a ring of four so that refills happen; the sentence levels' k_roll7 with the verifier
-    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
+    {"env": "MiniGrid-RedBlueDoors-8x8-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
     {"env": "MiniGrid-MemoryS7-v0", "n": 6, "launches": [16, 16], "max_steps": 4, "spare_ring": 4},
     {"env": "MiniGrid-MultiRoom-N4-S5-v0", "n": 6, "launches": [16, 16], "max_steps": 6, "spare_ring": 4},
     {"env": "BabyAI-PutNextS5N2Carrying-v0", "n": 6, "launches": [16, 16], "max_steps": 4, "spare_ring": 4},
