@@ -51,6 +51,8 @@ WORKLOADS = {
     "multiroom": ("MiniGrid-MultiRoom-N6-v0", 65536, "partial"),
     "babyai_goto": ("BabyAI-GoTo-v0", 131072, "partial"),
     "unlockpickup": ("MiniGrid-UnlockPickup-v0", 131072, "partial"),
+    "unlock": ("MiniGrid-Unlock-v0", 131072, "partial"),
+    "blockedunlockpickup": ("MiniGrid-BlockedUnlockPickup-v0", 131072, "partial"),
     "dynobs6x6": ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 65536, "partial"),
     # the sentence levels (instruction trees; the verifier runs inside the fused step loop since round 3)
     "bosslevel": ("BabyAI-BossLevel-v0", 131072, "partial"),

@@ -448,7 +448,11 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // GG_DYNOBS (round 4): DynamicObstacles with the draws of its step() and reset() inside the step loop -- RNG = the env streams' type, one
 // stream per lane in registers for the whole launch (mg_dynobs.h).  The level has no spare ring: an env whose episode ended is redrawn in
 // place by its own lane; the encode waves of the split follow the dynamics wave's grids through the obstacle LIST each step logs.
-template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream>
+// ONE (round 5): the ONE-STEP specialisation -- Env.step() and the reset observation (T = 1).  A one-step launch runs through its code exactly once, so what it
+// costs beyond the launch itself is largely instruction fetch: the general kernel carries four loop shapes (time split, log split, staged split, encode
+// waves), each with its own copy of the dynamics / observation code, and the shadow-spare staging of fused launches.  ONE compiles all of that out: one
+// wave steps, the workgroup's waves share the encode (`share`) or it is the only wave; a spare episode comes straight from the ring in HBM.
+template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false>
 __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : 3, 8))) k_roll7(const StepParams P) {
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int sw = (share && P.share < 16) ? (int)(((uint32_t)wg >> (P.share - 1)) & (uint32_t)(NW - 1)) : 0;
   // split (fused launches with three or four waves, round 4): wave 0 runs the DYNAMICS of every step once and logs them, waves 1.. keep
   // their own grids current from the log and produce the observations, step j by encode wave j mod (NW - 1) -- see the loops below
-  const bool split_mode = !share && P.split_mode != 0;              // (FullyObs: only ever the staged-codes split below -- the host sets nothing else)
+  const bool split_mode = !ONE && !share && P.split_mode != 0;      // (FullyObs: only ever the staged-codes split below -- the host sets nothing else)
   // Which wave is the dynamics wave rotates with the workgroup index (P.split_mode - 1 = the shift): a workgroup's wave i lands on SIMD i,
   // so with wave 0 everywhere one SIMD of a CU would carry the dynamics waves of all its workgroups -- the longest instruction stream of
   // the four -- and pace the launch (measured: profiles/r4/split_rotation.txt)
@@ -566,6 +570,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (split_mode && tid < ROLL_LOG_SYNC_BYTES / 4) ((uint32_t*)(smem + P.off_log))[tid] = (tid >= 1 && tid < NW) ? 0u : (tid == 0 ? 0u : 0xFFFFFFFFu);   // [0] logged, [1 + k] consumed by encode wave k (absent waves: never behind)
   // the next use_shadow (1 or 2) spare episodes of every env: a batch may take up to cb >= 2 per env, so ring slots head and head + 1 are drawn
   // (an env's ring position is lane ce's S.h: every wave has loaded its own copy of the 64 heads)
+  if constexpr (!ONE)
   for (int set = 0; set < P.use_shadow; set++) {
     if (wave == 0 && active) {
       const size_t se = (size_t)((S.h + (uint32_t)set) & P.ring_mask) * N + (size_t)e;
@@ -595,7 +600,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   }
   if constexpr (FULL) {
     // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
-    if (P.use_shadow) {
+    if (!ONE && P.use_shadow) {
       __syncthreads();
       for (int set = wave; set < P.use_shadow; set += NW)
         if (active) image_stream_build(sshadow + set * P.shadow_stride + lane * GS, smem + P.off_shadow_gt + set * P.codes_stride + lane * cells, W, H);
@@ -887,8 +892,20 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
   };
 
-  if (!split_mode) {
+  if (ONE || !split_mode) {
     // ---- every wave steps for itself: one wave (NW = 1, or `share`), or the TIME SPLIT (wave w replays steps 0 .. split[w]-1 silently) ----
+    if constexpr (ONE) {
+      if (j_end > 0) {
+        StepOut o;
+        dynamics(0, o);
+        full_follow();
+        const int slot_out = slot_of(0);
+        store_scalars(slot_out, o);
+        Agent av = a;
+        if (o.show_taken) av.carry = 0;
+        observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, scodes, 3);
+      }
+    } else
     for (int j = 0; j < j_end; j++) {
       const bool emit = j >= j_begin;                                  // wave-uniform: silent replay before the wave's own steps
       StepOut o;
@@ -901,6 +918,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (o.show_taken) av.carry = 0;
       observe(slot_out, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, scodes, 3);
     }
+  } else if constexpr (ONE) {
+    // (never: the one-step kernel has no split)
   } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) {
     // ---- DynamicObstacles and the sentence levels, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
     // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
