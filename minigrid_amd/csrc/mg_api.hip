@@ -1734,7 +1734,7 @@ int mg_get_counters(mg_env* e, uint64_t out[4]) {
   return MG_OK;
 }
 
-#ifdef MG_DEBUG_TIMING
+#if defined(MG_DEBUG_TIMING) || defined(MG_ATTRIBUTION)
 MG_API int mg_debug_stamps(mg_env* e, uint64_t out[12]) {
   HIP_TRY(e, hipMemcpyAsync(out, e->counters + 4, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));

@@ -1498,15 +1498,10 @@ struct RG {
     const bool vertical_wall = k == 0 || k == 2;
     // MG_SHC: add_door may arrive here with a side that has NO neighbour when the stream's draw budget ran out (its loop leaves on rng.dead()): rr / nrm
     // are negative then, the shift count is negative, and the episode is discarded and redrawn.  The hardware masks a 64-bit shift count to six bits;
-    // in C++ the shift is undefined -- found by UBSan on the emulator (profiles/r4/emu_all_ids_address_undefined.txt: the only report of the round).
-    // Host builds mask explicitly.  The device build keeps the expression the GPU suite validated (writing the mask there too changes the
-    // register allocation of eight generator translation units, profiles/isa_diff.py -- to be switched over with a GPU at hand).
-    // (-DMG_SHC_MASK_DEVICE=1: the masked form on the device too -- the variant build profiles/r5_shift_mask.sh validates on a GPU)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MG_SHC_MASK_DEVICE)
-#define MG_SHC(x) (x)
-#else
+    // in C++ the shift is undefined -- found by UBSan on the emulator (profiles/r4/emu_all_ids_address_undefined.txt).  The count is masked explicitly,
+    // on the device too since round 5 (the masked form ran the RoomGrid / BabyAI GPU tests as a variant build first: 1 415 passed, same refill rates --
+    // profiles/r5/shift_mask_*.txt).
 #define MG_SHC(x) ((x) & 63)
-#endif
     dx = vertical_wall ? ri * st + st : ri * st + (int)((down_off >> MG_SHC(4 * rr)) & 15u);
     dy = vertical_wall ? rj * st + (int)((right_off >> MG_SHC(4 * rr)) & 15u) : rj * st + st;
   }

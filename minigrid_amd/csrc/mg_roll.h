@@ -44,6 +44,22 @@
 #define MG_MARK(name) do { } while (0)
 #endif
 
+// -DMG_ATTRIBUTION -DMG_SPIN_COUNTS builds only (profiles/spin_counts.py): how often the waves of the log split wait for each other -- iterations of the
+// dynamics wave's flow-control loop (kind 0) and of the encode waves' wait for the next log entry (kind 1), summed into the statistics buffer's scratch
+// words 8 / 9 (mg_debug_stamps).  Measured in round 5 (profiles/r5/spin_counts.txt): at 65 536 Empty envs the dynamics wave waits 3-4 iterations per
+// step (~5 % of its time), each encode wave ~1 (~1-2 %); at 32 768 envs the dynamics wave never waits and the encode waves ~6-7 % -- neither side idles:
+// what paces a full chip is the SIMDs' shared issue (the same build runs 1.80 us per step at 32 768 envs = two waves per SIMD, 2.93 at 65 536 = four).
+// (The counters themselves cost the attribution build 0.7 us per step: a separate switch.)
+#if defined(MG_ATTRIBUTION) && defined(MG_SPIN_COUNTS) && defined(__HIP_DEVICE_COMPILE__)
+#define MG_SPIN_DECL uint32_t mg_spins_[2] = { 0u, 0u }
+#define MG_SPIN_COUNT(k) (mg_spins_[k]++)
+#define MG_SPIN_REPORT(k) do { if (lane == 0 && mg_spins_[k]) atomicAdd(&P.counters[8 + (k)], (unsigned long long)mg_spins_[k]); } while (0)
+#else
+#define MG_SPIN_DECL do { } while (0)
+#define MG_SPIN_COUNT(k) do { } while (0)
+#define MG_SPIN_REPORT(k) do { } while (0)
+#endif
+
 // LDS words addressed by their LDS offset (the dynamic LDS of k_roll7 starts at LDS address 0): the inter-wave counters of the split loops.
 // (tests/emu compiles these sources for the host: there the LDS is an ordinary array)
 // MG_WAVE_ORDER: the DS operations of one wave execute in order, so between "the wave wrote" and "the wave (or a polling neighbour) reads" only
@@ -668,6 +684,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (changed) { S.wb_all = true; obst_dirty = true; }
     }
   };
+  MG_SPIN_DECL;
   constexpr bool nt = NT;                                            // this launch's observation stores are nontemporal (see store12; the host picks the instantiation)
 
   // ---- the pieces of a step ----
@@ -1012,6 +1029,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           const uint32_t p0 = sync[1], p1 = sync[2], p2 = sync[3];
           if ((uint32_t)__builtin_amdgcn_readfirstlane((int)min(p0, min(p1, p2))) >= need) break;
           __builtin_amdgcn_s_sleep(1);
+          MG_SPIN_COUNT(0);
         }
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
@@ -1019,6 +1037,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       MG_WAVE_ORDER();
       sync[0] = (uint32_t)(j + 1);
     }
+    MG_SPIN_REPORT(0);
   } else {
     // ---- ENCODE waves: wave k + 1 keeps its own copy of the 64 grids current from the log (a byte write per step, a reset now and then)
     // and produces the observations of steps j = k, k + NE, k + 2 NE, ...
@@ -1028,7 +1047,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const int k = ek, NE = NW - 1;
     int mine = k;                                                      // next step this wave produces
     for (int j = 0; j < P.T; j++) {
-      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
+      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) { __builtin_amdgcn_s_sleep(1); MG_SPIN_COUNT(1); }
       MG_WAVE_ORDER();
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
       const uint32_t delta = rec2.y;
@@ -1058,6 +1077,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       av.step = 0; av.flags = 0; av.mission = 0;
       observe(slot_of(j), av, ((delta >> 21) & 1u) != 0u, delta & 0x3FFu, (delta >> 10) & 0xFFu, scodes, 3);
     }
+    MG_SPIN_REPORT(1);
     return;          // (nothing to report, no state to write back: the dynamics wave owns both -- and the env state is dead on this path)
   }
 
