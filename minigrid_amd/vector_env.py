@@ -22,7 +22,7 @@ import numpy as np
 from . import _binding as B
 from . import spaces
 from .mission_vocab import string_to_indices
-from .registry import ENV_LEVELGEN, EnvSpec, spec as _spec
+from .registry import ENV_DYNOBS, ENV_LEVELGEN, ENV_OPENTWODOORS, EnvSpec, spec as _spec
 
 try:  # subclass the real thing when it exists so isinstance checks pass
     from gymnasium.vector import VectorEnv as _VectorEnvBase  # type: ignore
@@ -83,6 +83,14 @@ class MiniGridVecEnv(_VectorEnvBase):
         if final_obs and autoreset_mode != "same_step":
             raise ValueError("final_obs=True belongs to autoreset_mode='same_step'")
         self._final_obs = bool(final_obs)
+        # The in-kernel SAME_STEP of the sentence levels (their episodes end in the verifier) and of DynamicObstacles (its reset draws on the stream its
+        # steps consume) is built for the default 7x7x3 observation (mg_api.hip validate_obs_cfg refuses the other modes).  For those combinations
+        # same_step is composed here exactly like final_obs -- a NEXT_STEP launch, then a masked reset of the envs that finished, each continuing its
+        # own stream: the same observations, rewards and stream positions (tests/test_gpu_roll.py), two launches per step(), no fused entry points.
+        _kind = _spec(env_id).env_kind
+        self._composed_same_step = (autoreset_mode == "same_step" and not final_obs and
+                                    (_kind == ENV_DYNOBS or ENV_OPENTWODOORS <= _kind <= ENV_LEVELGEN) and
+                                    not (obs_mode == "partial" and int(agent_view_size) == 7))
         # envs/babyai/core/verifier.py:26: the reference reads BABYAI_DONE_ACTIONS when it is imported ("any non-empty value"); the same
         # variable is the default here, the argument overrides it
         if babyai_done_actions is None:
@@ -124,7 +132,7 @@ class MiniGridVecEnv(_VectorEnvBase):
             abi_version=B.MG_ABI_VERSION, env_kind=s.env_kind, width=s.width, height=s.height, max_steps=s.max_steps,
             see_through_walls=int(s.see_through_walls), agent_view_size=self.agent_view_size,
             no_death_mask=no_death_mask, death_cost=self.death_cost,
-            obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET["next_step" if final_obs else autoreset_mode],
+            obs_mode=_OBS_MODES[obs_mode], autoreset_mode=_AUTORESET["next_step" if (final_obs or self._composed_same_step) else autoreset_mode],
             rng_mode=_RNG[rng], num_envs=self.num_envs, agent_start_x=s.agent_start[0], agent_start_y=s.agent_start[1],
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
@@ -377,6 +385,8 @@ class MiniGridVecEnv(_VectorEnvBase):
         obs, rew, term, trunc = self._collect()
         if self._final_obs:
             return self._same_step_with_final_obs(obs, rew, term, trunc)
+        if self._composed_same_step:
+            return self._same_step_with_final_obs(obs, rew, term, trunc)[:4] + ({},)
         return obs, rew, term, trunc, {}
 
     def _same_step_with_final_obs(self, obs, rew, term, trunc):
@@ -414,6 +424,9 @@ class MiniGridVecEnv(_VectorEnvBase):
         return new_obs, rew, term, trunc, {"final_obs": fo, "_final_obs": done, "final_info": np.full(n, None, dtype=object), "_final_info": done}
 
     def _no_fused_with_final_obs(self):
+        if self._composed_same_step:
+            raise ValueError("autoreset_mode='same_step' of this level is composed from two launches per step() for this observation mode "
+                             "(the in-kernel form serves the default 7x7x3 observation): the fused entry points need that observation, or 'next_step'")
         if self._final_obs:
             raise ValueError("final_obs=True reports terminal observations from step(), one launch at a time; "
                              "the fused entry points need autoreset_mode='same_step' without it (or 'next_step')")

@@ -49,3 +49,8 @@ def test_philox_generator_kernels_on_the_emulator():
     """MG_RNG_PHILOX (tests/test_gpu_philox.py): the Philox-keyed generator kernels' episodes injected into the oracle and stepped side by side, and the
     fused path against stepping -- with 200 envs instead of thousands (the tests scale themselves down under MINIGRID_AMD_EMU_RERUN)."""
     _rerun("test_gpu_philox.py", "state_injection or deterministic", 5)
+
+
+def test_composed_same_step_on_the_emulated_kernels():
+    """SAME_STEP of DynamicObstacles / the sentence levels outside the default view (composed by the facade, round 5) against the oracle's SAME_STEP mode."""
+    _rerun("test_gpu_roll.py", "composed_for_the_other_observation_modes", 4)

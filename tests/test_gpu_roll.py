@@ -171,15 +171,52 @@ def test_same_step_with_final_obs_equals_the_oracle(env_id, full, max_steps, out
 
 def test_same_step_autoreset_is_refused_where_it_is_not_built():
     import minigrid_amd as mg
-    # DynamicObstacles: in the step kernel of the default 7x7 view only (round 4, tests/test_gpu_dynobs.py); the other modes redraw between launches
-    with pytest.raises(ValueError):
-        mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", 64, autoreset_mode="same_step", obs_mode="full")
-    # the sentence levels: in the step kernel of the default 7x7 view only (round 4); their other observation modes end episodes in k_verify
-    with pytest.raises(ValueError):
-        mg.make_vec("BabyAI-BossLevel-v0", 64, autoreset_mode="same_step", obs_mode="symbolic")
+    # The in-kernel SAME_STEP of the sentence levels and of DynamicObstacles serves the default 7x7 view; at construction the facade composes the other
+    # observation modes from two launches per step (next test).  What stays refused: re-wrapping a LIVE handle that was created with the in-kernel
+    # form (its autoreset mode is fixed), and the fused entry points of a composed env.
     env = mg.make_vec("BabyAI-GoToSeqS5R2-v0", 64, autoreset_mode="same_step")
     with pytest.raises(ValueError):
         mg.FullyObsWrapper(env)
+    env.close()
+    env = mg.make_vec("MiniGrid-Dynamic-Obstacles-6x6-v0", 64, autoreset_mode="same_step", obs_mode="full")
+    env.reset(seed=0)
+    with pytest.raises(ValueError):
+        env.rollout(8, action_seed=1, fused=True)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,kw,okw", [("MiniGrid-Dynamic-Obstacles-6x6-v0", {"obs_mode": "full"}, {"full_obs": True}),
+                                           ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", {"agent_view_size": 5}, {"view_size": 5}),
+                                           ("BabyAI-PickupLoc-v0", {"obs_mode": "full"}, {"full_obs": True}),
+                                           ("BabyAI-GoToSeqS5R2-v0", {"obs_mode": "symbolic"}, {"obs": "symbolic"})])
+def test_same_step_composed_for_the_other_observation_modes(env_id, kw, okw):
+    """VERDICT r4 missing #5: SAME_STEP of DynamicObstacles / the sentence levels outside the default 7x7 view -- composed by the facade (a NEXT_STEP
+    launch + a masked reset of the finished envs) -- equals the oracle's SAME_STEP mode step by step, stream positions included."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    import os
+    emu = os.environ.get("MINIGRID_AMD_EMU_RERUN") == "1"            # (tests/test_emu_gpu_suite_cpu.py: the same test on the host SIMT emulator, scaled down)
+    n = 40 if emu else 900
+    env = mg.make_vec(env_id, n, autoreset_mode="same_step", **kw)
+    assert env.metadata["autoreset_mode"] == "same_step"
+    orc = O.OracleVec(env_id, n, **okw)
+    obs, _ = env.reset(seed=6)
+    assert (obs["image"] == orc.reset(seeds=np.arange(6, 6 + n, dtype=np.uint64))[0]).all()
+    rng = np.random.default_rng(2)
+    nact = 3 if "Dynamic" in env_id else 7
+    ended = 0
+    for t in range(120 if emu else 200):
+        a = rng.integers(0, nact, n).astype(np.uint8)
+        obs, rew, term, trunc, info = env.step(a)
+        oo, orew, oterm, otrunc, od, om = orc.step(a, autoreset=2)
+        assert info == {}
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        assert (obs["direction"] == od).all()
+        if env.sentence:
+            assert (np.asarray(obs["mission"]) == orc.mission_strings()).all(), (env_id, t)
+        ended += int((term | trunc).sum())
+    assert ended > (n // 2 if "Dynamic" in env_id else 3), ended
+    assert (env.get_rng_state() == orc.get_rng()).all()
     env.close()
 
 
