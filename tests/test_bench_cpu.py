@@ -124,6 +124,34 @@ def test_profiles_are_bound_to_the_build_of_the_step_kernels(tmp_path, monkeypat
     assert units and "mg_api.hip" not in units and all("mg_gen" not in x for x in units + B._STEP)
 
 
+def test_round5_profiles_are_quotable_on_this_tree():
+    """The committed round-5 passes were taken on THIS build of the step kernels (hash-matched), for both launch shapes of the four BASELINE workloads: a
+    live bench line on this tree quotes counters, not the analytic floor; the counters agree with the floor and the real-bytes fraction stays below 1."""
+    b = _bench()
+    from minigrid_amd import build as B
+    r5 = os.path.join(ROOT, "profiles", "r5")
+    for name in ("empty8x8", "doorkey8x8", "lavacrossing_full", "gotoredball"):
+        env_id, n, obs_mode = b.WORKLOADS[name]
+        for spl, sfx in ((32, ""), (20, "_spl20")):
+            meta = json.load(open(os.path.join(r5, f"meta_{name}{sfx}.json")))
+            assert meta["step_kernel_srchash"] == B.step_kernel_hash(), (name, sfx, "re-collect profiles/r5 after a change of the step kernels (profiles/r5_final.sh)")
+            assert meta["envs_per_gpu"] == n and meta["steps_per_launch"] == spl and meta["full_launches"] >= 15
+            assert "attribution=0" in meta["library_build"] and not meta["environment"], meta
+            traffic, us = b.pmc_traffic_bytes(name, n, spl), b.rocprof_kernel_us_per_step(name, n, spl)
+            assert traffic is not None and us is not None and b.pmc_traffic_source(name, n, spl).startswith("profiles/r5/")
+            W = H = 9 if "Lava" in env_id else 8
+            obe = 3 * W * H if obs_mode == "full" else 147
+            floor = (obe + 16 + (2 * W * H + 16) / spl) * n * spl
+            assert 0.97 * floor < traffic < 1.15 * floor, (name, spl, traffic / floor)
+            frac = traffic / (us * spl * 1e-6) / (b.HBM_PEAK_GBPS * 1e9)
+            assert 0.2 < frac < 1.0, (name, spl, frac)
+    # the driver's own line of this round (bench.py --gpus 1 --steps 20 --warmup 5) carries hash-matched traffic
+    d = json.loads(open(os.path.join(r5, "bench_driver1.json")).read().strip().splitlines()[-1])
+    assert d["config"]["step_kernel_srchash"] == B.step_kernel_hash() and d["roofline"]["traffic"] is not None
+    assert d["roofline"]["traffic_source"].startswith("profiles/r5/") and 0 < d["roofline"]["frac"] <= 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
 def test_round4_bench_lines_are_self_consistent():
     for f in ("bench_empty8x8", "bench_doorkey8x8", "bench_lavacrossing_full", "bench_gotoredball", "bench_driver1", "bench_default_run"):
         d = json.loads(open(os.path.join(ROOT, "profiles", "r4", f + ".json")).read().strip().splitlines()[-1])
