@@ -76,13 +76,13 @@ def algorithmic_bytes_per_env_step(env_id: str, obs_mode: str, W: int, H: int, v
     return b
 
 
-def _profile_metas(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
+def _profile_metas(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
     """Committed rocprofv3 passes of `workload` taken at THIS batch size and THIS steps-per-launch: (directory, meta, suffix) for every
     profiles/r*/meta_<workload><suffix>.json that matches AND was taken on this build of the step kernels (suffix "" = the 32-step launches of a long run, "_spl20" = the driver-sized
     run; the collection scripts write the run's parameters into the meta file next to the counters), oldest round first."""
     import glob
     out = []
-    for f in sorted(glob.glob(os.path.join(PROFILES_DIR, "r*", f"meta_{workload}*.json"))):
+    for f in sorted(glob.glob(os.path.join(PROFILES_DIR, only_round or "r*", f"meta_{workload}*.json"))):
         suffix = os.path.basename(f)[len(f"meta_{workload}"):-len(".json")]
         if suffix and not suffix.startswith("_spl"):
             continue                                   # meta_<workload>_<other workload suffix>.json of a longer name
@@ -113,7 +113,7 @@ def _pmc_files(d: str, workload: str, suffix: str):
     return [os.path.join(d, f"pmc_{c}_{workload}{suffix}.txt") for c in ("FETCH_SIZE", "WRITE_SIZE")]
 
 
-def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
+def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes of this same command
     (profiles/<round>/pmc_{FETCH,WRITE}_SIZE_<workload><suffix>.txt, separate --pmc runs, written by profiles/collect*.sh).
     Units and gfx950 correction as MI355X_MICROARCH.md prescribes: the counters are in KiB (x1024); FETCH_SIZE reads
@@ -122,7 +122,7 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int, any_build: bool =
     batch size and steps per launch (the per-call maximum = the full launches) -- or None."""
     import re
     best = None
-    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build, only_round):
         vals, parts = {}, {}
         for c, f in zip(("FETCH_SIZE", "WRITE_SIZE"), _pmc_files(d, workload, suffix)):
             if not os.path.exists(f):
@@ -144,12 +144,12 @@ def pmc_traffic_bytes(workload: str, n_per_gpu: int, spl: int, any_build: bool =
     return best
 
 
-def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
+def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
     """Average duration of a FULL step launch / steps per launch from the committed `rocprofv3 --kernel-trace --stats` summary of
     this command (profiles/<round>/kernel_stats_<workload><suffix>.csv; meta_<workload><suffix>.json holds the full-launch average
     computed from the trace by the collection script), or None."""
     best = None
-    for _d, meta, _suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
+    for _d, meta, _suffix in _profile_metas(workload, n_per_gpu, spl, any_build, only_round):
         try:
             best = float(meta["full_launch_avg_us"]) / spl
         except Exception:
@@ -157,9 +157,9 @@ def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int, any_buil
     return best
 
 
-def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int, any_build: bool = False):
+def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
     src = None
-    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build):
+    for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build, only_round):
         if all(os.path.exists(f) for f in _pmc_files(d, workload, suffix)):
             src = os.path.relpath(d, ROOT) + f"/pmc_{{FETCH,WRITE}}_SIZE_{workload}{suffix}.txt"
     return src

@@ -24,10 +24,11 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_roll7" in r["Kernel_N
 dur = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
 line = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
 spl = line["config"]["steps_per_launch"]
-# the FULL launches (spl steps): everything longer than 0.7 x the longest (a 5-step warm-up launch or a one-step reset observation is shorter)
-full = [d for d in dur if d > 0.7 * dur[-1]]
+# the FULL launches (spl steps): everything longer than half the MEDIAN duration (the full launches are the majority; a one-step reset observation is a
+# tenth of one).  (Round 4's "0.7 x the longest" dropped every normal launch of a run that held one slow outlier.)
+full = [d for d in dur if d > 0.5 * dur[len(dur) // 2]]
 meta = {"workload": sys.argv[4], "envs_per_gpu": line["config"]["envs_per_gpu"], "steps_per_launch": spl,
-        "full_launches": len(full), "full_launch_avg_us": sum(full) / len(full) / 1e3, "full_launch_max_us": full[-1] / 1e3,
+        "full_launches": len(full), "full_launch_filter": "> 0.5 x median duration", "full_launch_avg_us": sum(full) / len(full) / 1e3, "full_launch_max_us": full[-1] / 1e3,
         "all_step_kernel_launches_us": [d / 1e3 for d in dur],
         "library_build": line["config"].get("library_build"), "step_kernel_srchash": line["config"]["step_kernel_srchash"], "environment": line["config"].get("environment"),
         "command": "bench.py --gpus 1 --workload %s %s --no-cpu-baseline under rocprofv3 --kernel-trace --stats" % (sys.argv[4], sys.argv[5])}

@@ -85,8 +85,8 @@ def test_round4_profiles_cover_both_launch_shapes():
         meta = json.load(open(os.path.join(r4, f"meta_{name}{sfx}.json")))
         assert meta["envs_per_gpu"] == n and meta["steps_per_launch"] == spl
         assert "attribution=0" in meta["library_build"] and not meta["environment"], meta      # the product build, no MG_* switch set
-        traffic, us = b.pmc_traffic_bytes(name, n, spl, any_build=True), b.rocprof_kernel_us_per_step(name, n, spl, any_build=True)
-        assert b.pmc_traffic_source(name, n, spl, any_build=True).startswith("profiles/r4/")
+        traffic, us = b.pmc_traffic_bytes(name, n, spl, any_build=True, only_round="r4"), b.rocprof_kernel_us_per_step(name, n, spl, any_build=True, only_round="r4")
+        assert b.pmc_traffic_source(name, n, spl, any_build=True, only_round="r4").startswith("profiles/r4/")
         W = H = 9 if "Lava" in env_id else 8
         obe = 3 * W * H if obs_mode == "full" else 147
         floor = (obe + 16 + (2 * W * H + 16) / spl) * n * spl
@@ -94,7 +94,7 @@ def test_round4_profiles_cover_both_launch_shapes():
         frac = traffic / (us * spl * 1e-6) / (b.HBM_PEAK_GBPS * 1e9)
         assert 0.25 < frac < 1.0, (name, frac)
     # round 3's headline fraction on real bytes was 0.54; round 4's committed passes
-    t, us = b.pmc_traffic_bytes("empty8x8", 65536, 32, any_build=True), b.rocprof_kernel_us_per_step("empty8x8", 65536, 32, any_build=True)
+    t, us = b.pmc_traffic_bytes("empty8x8", 65536, 32, any_build=True, only_round="r4"), b.rocprof_kernel_us_per_step("empty8x8", 65536, 32, any_build=True, only_round="r4")
     assert t / (us * 32e-6) / 8e12 > 0.60
 
 
