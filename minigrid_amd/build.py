@@ -33,13 +33,14 @@ UNITS = {
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
     "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP,
 }
-UNITS["mg_gen_lane.hip"] = _GEN + ["mg_genlane.h"]
+for _u in ("", "_a", "_b", "_c", "_d"):          # the lane-per-episode generator kernels, by generator function (mg_gen_lane_tu.inc)
+    UNITS[f"mg_gen_lane{_u}.hip"] = _GEN + ["mg_genlane.h", "mg_gen_lane_tu.inc"]
 for _g in ("rooms", "sentence", "roomgrid", "light"):
     for _r in ("pcg", "philox"):
         for _k in ("refill", "generate"):
             UNITS[f"mg_gen_{_g}_{_r}_{_k}.hip"] = _GEN
 # the slowest units (minutes) first, so that the pool does not end on one of them
-SOURCES = sorted(UNITS, key=lambda n: (not n.startswith("mg_gen_rooms"), not n.startswith("mg_gen_sentence")))
+SOURCES = sorted(UNITS, key=lambda n: (not n.startswith(("mg_gen_rooms", "mg_gen_lane_")), not n.startswith("mg_gen_sentence")))
 HEADERS = sorted({h for deps in UNITS.values() for h in deps})
 
 STAMP = LIB + ".srchash"      # sha256 of the sources the library was built from (travels with the .so; mtimes do not)

@@ -72,6 +72,7 @@ struct mg_env {
   bool fast_full = false;     // FullyObs on grids whose two images fit the LDS: k_roll7<., true>
   int roll_nw = 1;            // wavefronts per 64-env workgroup in fused k_roll7 launches (1, 2 or 4: time split)
   bool lane_gen = false;      // the refills run one lane per episode (k_refill_lane: the single-room levels; MG_LANE_GEN=0: the wave-per-episode k_refill)
+  bool lane_direct = false;   // direct generation (reset(seed): the live episode and the ring fill) runs one lane per env (k_generate_lane): every level with a lane generator
   bool dyn_inloop = false;    // DynamicObstacles, default 7x7 view: k_roll7<GG_DYNOBS> draws the level's moves and resets inside the step loop (mg_dynobs.h; MG_DYN_INLOOP=0: the round-3 launches)
   bool full_split = true;     // FullyObs (k_roll7<., true>): the dynamics wave + encode waves over staged copies of its image-order stream (MG_FULL_SPLIT=0: the two-wave time split)
   bool roll_split_on = true;  // MG_ROLL_SPLIT (read when the observation configuration is made): 0 = the round-3 time split at every width
@@ -93,6 +94,9 @@ struct mg_env {
   uint64_t *instr = nullptr, *spare_instr = nullptr; uint32_t *gstate = nullptr, *gsnap = nullptr; size_t off_sentence = 0;
   uint64_t *agent = nullptr, *spare_agent = nullptr, *rng = nullptr, *rng_snap = nullptr, *rng_tmp = nullptr, *seeds = nullptr;
   uint32_t *head = nullptr, *tail = nullptr, *claim = nullptr, *seg = nullptr, *seg_count = nullptr;
+  uint32_t* seg_off = nullptr;    // packed lane refill: nwaves + 1 prefix sums behind the segment counts (the same allocation)
+  bool lane_packed = false;       // the level's refill numbers its requests across the segments and fills whole wavefronts (mg_genlane.h)
+  int lane_lpw = 64;              // ... with this many busy lanes each
   uint8_t *mask = nullptr, *actions = nullptr;
   uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
   bool goto_kind = false;
@@ -191,6 +195,7 @@ static GenArgs gen_args(mg_env* e, int slot) {
   // LevelGen, num_crossings bit 10: an episode whose drawing met RoomGrid.place_agent's endless loop is redrawn and accepted
   A.stuck_mode = (e->cfg.env_kind == MG_ENV_LEVELGEN && ((e->cfg.num_crossings >> 10) & 1)) ? 2 : (to_spare ? 0 : 1);
   A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
+  A.seg_off = nullptr; A.nseg = 0; A.lpw = 64;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
 }
@@ -206,7 +211,10 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask, hipStream
   // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-  if (e->lane_gen) launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);   // one lane per env (mg_genlane.h)
+  if (e->lane_direct) {             // one lane per env (mg_genlane.h)
+    if (!launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A))
+      return fail(e, MG_ERR_INVALID, "internal: no lane generator kernel for env_kind %d", e->cfg.env_kind);
+  }
   else
   MG_GEN_DISPATCH(launch_generate_, gg, philox, dim3(blocks), lds, st, A);
   HIP_TRY(e, hipGetLastError());
@@ -237,9 +245,18 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   const dim3 rgrid(e->nwaves * A.wps);
   if (!live && e->lane_gen) {
     // one LANE per episode (mg_genlane.h): a wavefront per request segment, each lane drawing its own request's episodes
-    A.wps = 2;
-    if (const char* s = getenv("MG_LANE_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
-    launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
+    bool ok;
+    if (e->lane_packed) {
+      // the batch's requests numbered across the segments (k_seg_scan), lane_lpw of them per wavefront; a grid-stride loop covers any count
+      A.seg_off = e->seg_off; A.nseg = e->nwaves; A.lpw = e->lane_lpw;
+      const unsigned blocks = (unsigned)std::min<long long>(((long long)e->N + A.lpw - 1) / A.lpw, 16384);
+      ok = launch_refill_lane_packed(philox, dim3(blocks), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
+    } else {
+      A.wps = 2;
+      if (const char* s = getenv("MG_LANE_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
+      ok = launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
+    }
+    if (!ok) return fail(e, MG_ERR_INVALID, "internal: no lane refill kernel for env_kind %d (packed %d)", e->cfg.env_kind, (int)e->lane_packed);
   } else
   MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
   HIP_TRY(e, hipGetLastError());
@@ -818,8 +835,9 @@ static int alloc_obs(mg_env* e) {
   const size_t N = (size_t)e->N;
   const size_t nseg = (size_t)(e->live_gen ? 1 : QSETS) * e->nwaves;
   HIP_TRY(e, dalloc(&e->seg, nseg * e->seg_cap));
-  HIP_TRY(e, dalloc(&e->seg_count, nseg));
-  HIP_TRY(e, hipMemsetAsync(e->seg_count, 0, nseg * sizeof(uint32_t), e->stream));
+  HIP_TRY(e, dalloc(&e->seg_count, nseg + (size_t)e->nwaves + 1));              // (+ the packed lane refill's prefix sums: seg_off)
+  HIP_TRY(e, hipMemsetAsync(e->seg_count, 0, (nseg + (size_t)e->nwaves + 1) * sizeof(uint32_t), e->stream));
+  e->seg_off = e->seg_count + nseg;
   {
     // one trajectory slot = one contiguous record: obs | reward | terminated | truncated | direction | mission | action
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1086,7 +1104,23 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   {
     const char* s = getenv("MG_LANE_GEN");
-    e->lane_gen = lane_gen_kind(cfg->env_kind) && (!s || atoi(s) != 0) && lane_gen_lds_bytes(e->CS, cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) <= 64 * 1024;
+    const bool lane_on = (!s || atoi(s) != 0) && lane_gen_lds_bytes(e->CS, cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) <= 64 * 1024;
+    // REFILL on lanes: the single-room levels, the Unlock family and KeyCorridor (per request segment: what they were tuned on, rounds 4-5).  For the
+    // others -- the mazes, MultiRoom, the sentence levels -- lanes lose as a refill in either form (profiles/r5/lane_wide_bench_lines.txt: a few busy
+    // lanes per wave; ab_packed_lane_refill.txt: whole waves of busy lanes, requests numbered across the segments -- a wave of 64 diverging maze
+    // generators runs 4-7 ms, BabyAI-GoTo 1.70 -> 1.42 G, BossLevel 4.51 -> 1.76): they keep the wavefront-per-episode k_refill.
+    // DIRECT generation on lanes: every level with a lane generator -- reset(seed) draws one episode per env and ring slot, every lane is busy, and
+    // there lanes win everywhere (ring fill of BabyAI-GoTo x 131 072: 30.4 -> 8.0 ms per slot, BossLevel 25.3 -> 11.8, MultiRoom-N6 2.0 -> 1.8).
+    // MG_LANE_PACKED=1: the levels whose refill runs on lanes refill PACKED (A/B; KeyCorridor / UnlockPickup +3 %, GoToRedBall x 32 768 -50 %);
+    // MG_LANE_LPW: busy lanes per wavefront of the packed refill (1..64); MG_LANE_DIRECT=0: direct generation as the refill runs.
+    const bool tuned_sparse = lane_gen_kind_base(cfg->env_kind) || lane_gen_kind_product_fn(cfg->env_kind);
+    const char* pk = getenv("MG_LANE_PACKED");
+    e->lane_gen = lane_on && tuned_sparse;
+    e->lane_packed = e->lane_gen && pk && atoi(pk) == 1;
+    const char* dg = getenv("MG_LANE_DIRECT");
+    e->lane_direct = lane_on && lane_gen_kind(cfg->env_kind) && (e->lane_gen || !dg || atoi(dg) != 0);
+    e->lane_lpw = 64;
+    if (const char* l = getenv("MG_LANE_LPW")) { int v = atoi(l); if (v >= 1 && v <= 64) e->lane_lpw = v; }
   }
   e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;

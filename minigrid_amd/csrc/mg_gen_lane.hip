@@ -1,38 +1,30 @@
-// k_refill_lane (mg_genlane.h): one lane per episode, numpy PCG64 and Philox streams
-#define MG_GEN_TU_ONLY 1
-#include "mg_launch.h"
-#include "mg_genlane.h"
+// The lane-per-episode generator kernels (mg_genlane.h), numpy PCG64 and Philox streams: this unit holds FN 0 (the single-room levels behind one
+// run-time switch), FN 2 (the Unlock family) and FN 5 (KeyCorridor) with all three kernels -- the levels whose REFILL runs on lanes --, the request scan
+// of the packed refill, and the dispatch over the sibling units mg_gen_lane_{a,b,c,d}.hip (every other generator function: direct generation only --
+// reset(seed) and its ring fill draw one episode per env and slot, i.e. every lane is busy, which is where lanes win on every level).
+#define MG_LANE_TU_NAME main
+#define MG_LANE_TU_REFILL 1
+#define MG_LANE_TU_FNS(X) X(0) X(2) X(5)
+#include "mg_gen_lane_tu.inc"
 
 namespace mg {
 
-// kernel FN = lane_fn_of_kind(level) (mg_genlane.h): the product build instantiates FN 2 (the Unlock family) and FN 5 (KeyCorridor), the wide
-// variant build every generator function
-#define MG_LANE_CASE(K, n) case n: if (philox) hipLaunchKernelGGL((K<PhiloxStream, n>), grid, dim3(64), lds, st, A); \
-                                   else hipLaunchKernelGGL((K<Pcg64Stream, n>), grid, dim3(64), lds, st, A); return true;
-#if MG_LANE_WIDE
-#define MG_LANE_CASES(K) MG_LANE_CASE(K, 1) MG_LANE_CASE(K, 2) MG_LANE_CASE(K, 3) MG_LANE_CASE(K, 4) MG_LANE_CASE(K, 5) MG_LANE_CASE(K, 6) \
-  MG_LANE_CASE(K, 7) MG_LANE_CASE(K, 8) MG_LANE_CASE(K, 9) MG_LANE_CASE(K, 10) MG_LANE_CASE(K, 11) MG_LANE_CASE(K, 12) MG_LANE_CASE(K, 13) \
-  MG_LANE_CASE(K, 14) MG_LANE_CASE(K, 16) MG_LANE_CASE(K, 17) MG_LANE_CASE(K, 18) MG_LANE_CASE(K, 19) \
-  MG_LANE_CASE(K, 136) MG_LANE_CASE(K, 137) MG_LANE_CASE(K, 138) MG_LANE_CASE(K, 139) MG_LANE_CASE(K, 140) MG_LANE_CASE(K, 141) MG_LANE_CASE(K, 142) \
-  MG_LANE_CASE(K, 143) MG_LANE_CASE(K, 144) MG_LANE_CASE(K, 145)
-#else
-#define MG_LANE_CASES(K) MG_LANE_CASE(K, 2) MG_LANE_CASE(K, 5)
-#endif
-static bool launch_refill_lane_fn(int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
-  switch (fn) { MG_LANE_CASES(k_refill_lane) default: return false; }
+static bool launch_lane_any(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
+  return launch_lane_main(which, fn, philox, grid, lds, st, A) || launch_lane_a(which, fn, philox, grid, lds, st, A) ||
+         launch_lane_b(which, fn, philox, grid, lds, st, A) || launch_lane_c(which, fn, philox, grid, lds, st, A) ||
+         launch_lane_d(which, fn, philox, grid, lds, st, A);
 }
-static bool launch_generate_lane_fn(int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
-  switch (fn) { MG_LANE_CASES(k_generate_lane) default: return false; }
+// per-segment refill (A.wps wavefronts per request segment)
+bool launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
+  return launch_lane_any(0, lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A);
+}
+// packed refill: the batch's requests numbered across the segments first (A.seg_off, written here), A.lpw busy lanes per wavefront
+bool launch_refill_lane_packed(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
+  hipLaunchKernelGGL(k_seg_scan<0>, dim3(1), dim3(SEG_SCAN_THREADS), SEG_SCAN_THREADS * sizeof(uint32_t), st, A.seg_count, const_cast<uint32_t*>(A.seg_off), A.nseg);
+  return launch_lane_any(1, lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A);
+}
+bool launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
+  return launch_lane_any(2, lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A);
 }
 
-void launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
-  if (launch_refill_lane_fn(lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A)) return;
-  if (philox) hipLaunchKernelGGL((k_refill_lane<PhiloxStream>), grid, dim3(64), lds, st, A);
-  else hipLaunchKernelGGL((k_refill_lane<Pcg64Stream>), grid, dim3(64), lds, st, A);
-}
-void launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
-  if (launch_generate_lane_fn(lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A)) return;
-  if (philox) hipLaunchKernelGGL((k_generate_lane<PhiloxStream>), grid, dim3(64), lds, st, A);
-  else hipLaunchKernelGGL((k_generate_lane<Pcg64Stream>), grid, dim3(64), lds, st, A);
-}
 }  // namespace mg

@@ -32,6 +32,9 @@ struct GenArgs {
   const uint32_t* seg; uint32_t* seg_count; int seg_cap;
   int wps;                                           // generating workgroups (one wavefront each) per request segment
   const uint32_t* head; uint32_t* tail; uint32_t* claim; uint32_t epoch; uint32_t ring_mask;
+  // packed lane refill (k_refill_lane_packed, mg_genlane.h): exclusive prefix sums of the nseg request counts (seg_off[nseg] = all requests of the batch),
+  // lanes used per generating wavefront
+  const uint32_t* seg_off; int nseg; int lpw;
 };
 
 

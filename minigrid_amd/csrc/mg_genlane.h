@@ -17,14 +17,18 @@
 
 namespace mg {
 
-// Which levels the lane kernels serve.  Round 5 ran the "wide" build (every generator on lanes, one kernel per generator function) on MI355X
-// (profiles/r5/lane_wide_*: the whole GPU suite green with it; lane refill against the wavefront-per-episode refill of the SAME library, G env-steps/s):
-//   KeyCorridorS3R3 x 131 072   3.18 -> 14.53      UnlockPickup x 131 072   21.0 -> 23.5      BabyAI-GoTo x 131 072   1.66 -> 1.80
-//   BossLevel x 131 072         4.58 ->  3.07      MultiRoom-N6 x 65 536     2.40 ->  2.18
-// so the product build moves the levels where it wins -- the Unlock family (kinds 9-11: one locked door, whole-map retries are rare) and KeyCorridor
-// (14, 30) -- and leaves the maze / sentence levels (long reachability floods and whole-map retries: 64 diverging lanes wait for the unluckiest) and
-// MultiRoom with k_refill.  MG_LANE_WIDE = 1 (a VARIANT build: `python profiles/variant_build.py lanewide --units=mg_gen_lane.hip,mg_api.hip
-// -DMG_LANE_WIDE=1`) still moves every level, for A/B runs.
+// Which levels the lane kernels serve (round 5: measured on MI355X, profiles/r5/lane_wide_*, ab_lane_generators_product_build.txt,
+// ab_packed_lane_refill.txt; G env-steps/s, lane refill against the wavefront-per-episode refill of the SAME library):
+//   KeyCorridorS3R3 x 131 072   3.21 -> 14.78     Unlock 17.6 -> 20.1     UnlockPickup 21.1 -> 22.7     BlockedUnlockPickup 22.8 -> 23.4
+//   BabyAI-GoTo x 131 072       1.66 ->  1.80 (a few busy lanes per wave) / 1.42 (packed: whole waves of busy lanes)
+//   BossLevel x 131 072         4.58 ->  3.07 / 1.76       MultiRoom-N6 x 65 536   2.40 -> 2.18 / 2.47
+// REFILL on lanes: the single-room levels (FN 0), the Unlock family (FN 2) and KeyCorridor (FN 5).  The maze / sentence levels and MultiRoom keep
+// k_refill: their long reachability floods and whole-map retries diverge across a wave's lanes (a wave of 64 maze generators runs 4-7 ms, a cooperative
+// wavefront 0.8 ms per episode), and a refill is latency-critical -- one generator stream, batch after batch.
+// DIRECT generation on lanes: EVERY level (one kernel per generator function, lane_fn_of_kind: one kernel with every generator needs 512 VGPRs and
+// spills): reset(seed) and its ring fill draw one episode per env and slot -- every lane busy, throughput counts, and lanes win everywhere (ring fill of
+// BabyAI-GoTo x 131 072: 30.4 -> 8.0 ms per slot; BossLevel 25.3 -> 11.8; MultiRoom-N6 2.0 -> 1.8).  Which path a handle takes: mg_api.hip mg_create.
+// (MG_LANE_WIDE is accepted for old scripts and changes nothing any more: every lane kernel is in the product build.)
 #ifndef MG_LANE_WIDE
 #define MG_LANE_WIDE 0
 #endif
@@ -32,16 +36,17 @@ MG_HD bool lane_gen_kind_base(int kind) {
   return kind == 0 || kind == 1 || kind == 2 || kind == 3 || kind == 4 || kind == 5 || kind == 6 || kind == 7 ||
          kind == 16 || kind == 17 || kind == 18 || kind == 19 || kind == 20;
 }
-// the levels of the per-function lane kernels the PRODUCT build instantiates: FN 2 (gen_unlock_family) and FN 5 (gen_keycorridor)
+// the levels besides the single-room ones whose REFILL runs on lanes: FN 2 (gen_unlock_family) and FN 5 (gen_keycorridor)
 MG_HD bool lane_gen_kind_product_fn(int kind) { return kind == 9 || kind == 10 || kind == 11 || kind == 14 || kind == 30; }
 // the levels whose per-lane generator exists (GoToDoor 8 .. KeyCorridor 14, LockedRoom 21, Playground 22, MultiRoom 23, the BabyAI levels 24-53):
 // every level but DynamicObstacles, whose episodes are drawn inside the step kernel (mg_dynobs.h)
 MG_HD bool lane_gen_kind_wide(int kind) { return lane_gen_kind_base(kind) || (kind >= 8 && kind <= 14) || (kind >= 21 && kind <= 53); }
-MG_HD bool lane_gen_kind(int kind) { return MG_LANE_WIDE ? lane_gen_kind_wide(kind) : (lane_gen_kind_base(kind) || lane_gen_kind_product_fn(kind)); }
+// (every level that has lane kernels in the build; which of them USE their lane kernels is the host's choice: mg_api.hip mg_create)
+MG_HD bool lane_gen_kind(int kind) { return lane_gen_kind_wide(kind); }
 MG_HD int lane_grid_stride(int CS) { return CS + 4; }                 // odd dword stride: the 64 lanes' grids start in different LDS banks
 constexpr int LANE_INSTR_STRIDE = INSTR_WORDS + 1;                    // u64 per lane: the sentence levels' instruction record under construction
 // LDS of one generating wavefront: 64 private grids (+ 64 instruction records, sentence levels of the wide build)
-MG_HD int lane_gen_lds_bytes(int CS, bool sentence) { return 64 * lane_grid_stride(CS) + ((MG_LANE_WIDE && sentence) ? 64 * LANE_INSTR_STRIDE * 8 : 0); }
+MG_HD int lane_gen_lds_bytes(int CS, bool sentence) { return 64 * lane_grid_stride(CS) + (sentence ? 64 * LANE_INSTR_STRIDE * 8 : 0); }
 
 // The wide build's kernels are instantiated PER GENERATOR FUNCTION (FN below; 0 = the product kernel with the single-room levels' switch): one kernel
 // carrying every generator needs 512 VGPRs and spills (measured at compile time, profiles/r4/lane_wide_build.txt) -- a lane-per-episode kernel lives on
@@ -175,6 +180,21 @@ MG_HD void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g
 // (the wave runs as long as its unluckiest lane), and a generator is a chain of dependent 128-bit multiplies -- many short waves overlap,
 // one wave with 36 diverging lanes does not (GoToRedBall x 32 768: 10.1 us per step with one wave per segment, see profiles/r4/lane_refill.txt).
 // (FN: the wide build's kernels, one per generator function -- lane_fn_of_kind; 0 = the product kernel)
+// one refill request on one lane: env e, every ring slot from tail to head + R - 1 in stream order
+template <class R, int FN>
+MG_D void refill_lane_request(const GenArgs& A, int e, LaneGrid& g, uint64_t* iw) {
+  const uint32_t old = atomicMax(&A.claim[e], A.epoch);
+  if (old >= A.epoch) return;                                 // another request of this batch already covers the env
+  const uint32_t h = A.head[e] + A.ring_mask + 1u;            // every slot below head + R is free to fill
+  uint32_t t = A.tail[e];
+  if (h - t > A.ring_mask + 1u) { report_errors(A.err, (uint32_t)ERR_GENERATOR); return; }   // ring bookkeeping broken: never spin
+  while (t != h) {
+    generate_one_lane<R, FN>(A, e, t & A.ring_mask, g, iw);
+    t++;
+  }
+  A.tail[e] = t;
+}
+
 template <class R, int FN = 0>
 __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -187,18 +207,55 @@ __global__ void __launch_bounds__(64) k_refill_lane(const GenArgs A) {
   uint64_t* iw = nullptr;
   if constexpr (FN != 0) iw = (uint64_t*)(smem + 64 * lane_grid_stride(A.CS)) + lane * LANE_INSTR_STRIDE;
   const uint32_t* seg = A.seg + (size_t)sidx * A.seg_cap;
-  for (int k = w + lane * A.wps; k < cnt; k += 64 * A.wps) {
-    const int e = (int)seg[k];
-    const uint32_t old = atomicMax(&A.claim[e], A.epoch);
-    if (old >= A.epoch) continue;                               // another request of this batch already covers the env
-    const uint32_t h = A.head[e] + A.ring_mask + 1u;            // every slot below head + R is free to fill
-    uint32_t t = A.tail[e];
-    if (h - t > A.ring_mask + 1u) { report_errors(A.err, (uint32_t)ERR_GENERATOR); continue; }   // ring bookkeeping broken: never spin
-    while (t != h) {
-      generate_one_lane<R, FN>(A, e, t & A.ring_mask, g, iw);
-      t++;
-    }
-    A.tail[e] = t;
+  for (int k = w + lane * A.wps; k < cnt; k += 64 * A.wps) refill_lane_request<R, FN>(A, (int)seg[k], g, iw);
+}
+
+// PACKED refill (round 5).  k_refill_lane above gives every request SEGMENT (the 64 envs of a step workgroup) its own wavefronts, so a wave holds as many
+// busy lanes as its segment filed requests -- a handful for the short-episode single-room levels it was tuned on, ONE OR TWO for the levels with long
+// episodes and big grids (BabyAI-GoTo x 131 072: ~5 requests per segment and batch): a lane-per-episode kernel with one busy lane is a very slow scalar
+// core (measured with the wide build: BossLevel 4.6 -> 3.1 G, MultiRoom-N6 2.4 -> 2.2).  Here the batch's requests are first numbered across the
+// segments (k_seg_scan: exclusive prefix sums of the segment counts) and wavefront b serves requests [b lpw, (b + 1) lpw): every lane of a generating
+// wave is busy, a refill of ten thousand episodes is a few hundred wavefronts instead of eight thousand, and the chip is left to the step kernel.
+// lpw (lanes per wave, <= 64) trades lane utilisation against how long a wave waits for its unluckiest lane.
+constexpr int SEG_SCAN_THREADS = 256;                        // one workgroup; launch with SEG_SCAN_THREADS * 4 bytes of dynamic LDS
+template <int UNUSED = 0>      // (a template only so that the header can be included by several translation units)
+__global__ void __launch_bounds__(SEG_SCAN_THREADS) k_seg_scan(const uint32_t* seg_count, uint32_t* seg_off, int nseg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* part = (uint32_t*)smem;
+  const int tid = (int)threadIdx.x;
+  const int per = (nseg + SEG_SCAN_THREADS - 1) / SEG_SCAN_THREADS, lo = min(nseg, tid * per), hi = min(nseg, lo + per);
+  uint32_t sum = 0;
+  for (int k = lo; k < hi; k++) sum += seg_count[k];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < SEG_SCAN_THREADS; d <<= 1) {           // Hillis-Steele inclusive scan of the partial sums
+    const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - sum;                            // exclusive
+  for (int k = lo; k < hi; k++) { seg_off[k] = run; run += seg_count[k]; }
+  if (tid == SEG_SCAN_THREADS - 1) seg_off[nseg] = part[SEG_SCAN_THREADS - 1];
+}
+
+template <class R, int FN = 0>
+__global__ void __launch_bounds__(64) k_refill_lane_packed(const GenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = (int)threadIdx.x;
+  const uint32_t total = A.seg_off[A.nseg];
+  if ((uint32_t)blockIdx.x * (uint32_t)A.lpw >= total) return;
+  LaneGrid g;
+  g.p = smem + lane * lane_grid_stride(A.CS); g.W = A.gp.W; g.H = A.gp.H; g.lane = lane; g.nonempty = 0; g.walls = 0;
+  uint64_t* iw = nullptr;
+  if constexpr (FN != 0) iw = (uint64_t*)(smem + 64 * lane_grid_stride(A.CS)) + lane * LANE_INSTR_STRIDE;
+  for (uint32_t base = (uint32_t)blockIdx.x * (uint32_t)A.lpw; base < total; base += gridDim.x * (uint32_t)A.lpw) {
+    const uint32_t q = base + (uint32_t)lane;
+    if (lane >= A.lpw || q >= total) continue;
+    int lo = 0, hi = A.nseg;                                 // the segment of request q: the last s with seg_off[s] <= q
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.seg_off[mid] <= q) lo = mid; else hi = mid; }
+    const int e = (int)A.seg[(size_t)lo * A.seg_cap + (q - A.seg_off[lo])];
+    refill_lane_request<R, FN>(A, e, g, iw);
   }
 }
 

@@ -40,8 +40,16 @@ MG_DECL_GEN_TU(light_pcg) MG_DECL_GEN_TU(roomgrid_pcg) MG_DECL_GEN_TU(rooms_pcg)
 MG_DECL_GEN_TU(light_philox) MG_DECL_GEN_TU(roomgrid_philox) MG_DECL_GEN_TU(rooms_philox) MG_DECL_GEN_TU(sentence_philox)
 #undef MG_DECL_GEN_TU
 // k_refill_lane (mg_genlane.h): one lane per episode, for the single-room levels (lane_gen_kind)
-void launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
-void launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+// (false: the build holds no such kernel for the level)
+bool launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_refill_lane_packed(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+// the lane kernels' translation units (mg_gen_lane_tu.inc): which = 0 per-segment refill | 1 packed refill | 2 direct generation
+bool launch_lane_main(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_lane_a(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_lane_b(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_lane_c(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+bool launch_lane_d(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
 // dispatch on (generator group, stream kind)
 #define MG_GEN_DISPATCH(FN, gg, philox, ...)                                                       \
   do {                                                                                             \
