@@ -68,7 +68,9 @@ def step_kernel_hash() -> str:
     rocprofv3 pass carries the hash of the build it measured (profiles/r*/meta_*.json "step_kernel_srchash"); bench.py refuses to quote a
     pass whose hash differs from the tree it runs on."""
     units = sorted(u for u in UNITS if u.startswith("mg_step_"))
-    return _hash_files(units + sorted(set(_STEP)), " ".join(CFLAGS) + " gfx950")[:16]
+    # (mg_launch.h: declarations of the HOST launch functions of every unit -- the part a step unit sees, under MG_STEP_TU_ONLY, names the functions
+    # mg_step_tu.inc defines, which is hashed; the rest belongs to the generators)
+    return _hash_files(units + sorted(set(_STEP) - {"mg_launch.h"}), " ".join(CFLAGS) + " gfx950")[:16]
 
 
 def _stale() -> bool:
