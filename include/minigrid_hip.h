@@ -183,8 +183,9 @@ typedef struct mg_config {
   int64_t env_index_base;     /* global index of env 0 of this shard (multi-GPU: seed = base_seed + global index) */
   int32_t tile_size;          /* RGB modes: pixels per cell, 1..64 (wrappers.py:305, 355: default 8; 4 | 8 | 12 | 16 take the fast blit); else ignored */
   int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
-  int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default: 256 for the levels drawn one lane per
-                                 episode, 128 for the others, halved while the ring would exceed min(16 GB, a quarter of the free device memory) */
+  int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default: 256 for the levels whose refill runs
+                                 one lane per episode and for the big-grid maze levels, 128 for the others, halved while the ring would exceed
+                                 min(32 GB, a quarter of the free device memory) */
   int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (32, fewer when a slot is large);
                                  < 0 = -traj_slots preferred, halved like the default while the ring would exceed 2 GB       */
   int32_t babyai_done_actions; /* envs/babyai/core/verifier.py:26 use_done_actions (the reference reads BABYAI_DONE_ACTIONS when it is imported):

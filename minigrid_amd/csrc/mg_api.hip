@@ -97,6 +97,7 @@ struct mg_env {
   uint32_t* seg_off = nullptr;    // packed lane refill: nwaves + 1 prefix sums behind the segment counts (the same allocation)
   bool lane_packed = false;       // the level's refill numbers its requests across the segments and fills whole wavefronts (mg_genlane.h)
   int lane_lpw = 64;              // ... with this many busy lanes each
+  long long lane_burst_min = 0;   // burst hybrid of the wavefront-per-episode levels: batches of at least this many requests refill on packed lanes (0 = off)
   uint8_t *mask = nullptr, *actions = nullptr;
   uint64_t *aux = nullptr, *spare_aux = nullptr;   // auxiliary word per env: DynamicObstacles obstacle list / GoTo targets
   bool goto_kind = false;
@@ -195,7 +196,7 @@ static GenArgs gen_args(mg_env* e, int slot) {
   // LevelGen, num_crossings bit 10: an episode whose drawing met RoomGrid.place_agent's endless loop is redrawn and accepted
   A.stuck_mode = (e->cfg.env_kind == MG_ENV_LEVELGEN && ((e->cfg.num_crossings >> 10) & 1)) ? 2 : (to_spare ? 0 : 1);
   A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
-  A.seg_off = nullptr; A.nseg = 0; A.lpw = 64;
+  A.seg_off = nullptr; A.nseg = 0; A.lpw = 64; A.burst_min = 0u;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
 }
@@ -257,8 +258,17 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
       ok = launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
     }
     if (!ok) return fail(e, MG_ERR_INVALID, "internal: no lane refill kernel for env_kind %d (packed %d)", e->cfg.env_kind, (int)e->lane_packed);
-  } else
-  MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
+  } else {
+    if (!live && e->lane_burst_min > 0) {
+      // burst hybrid: the packed lane refill takes a batch of >= lane_burst_min requests (every env of a long-episode level truncating at once),
+      // k_refill everything smaller; both are launched, the request count (k_seg_scan) decides on the device
+      A.seg_off = e->seg_off; A.nseg = e->nwaves; A.lpw = e->lane_lpw; A.burst_min = (uint32_t)e->lane_burst_min;
+      const unsigned blocks = (unsigned)std::min<long long>(((long long)e->N + A.lpw - 1) / A.lpw, 16384);
+      if (!launch_refill_lane_packed(philox, dim3(blocks), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A))
+        return fail(e, MG_ERR_INVALID, "internal: no packed lane refill kernel for env_kind %d", e->cfg.env_kind);
+    }
+    MG_GEN_DISPATCH(launch_refill_, gg, philox, rgrid, lds, st, A);
+  }
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemsetAsync(A.seg_count, 0, (size_t)e->nwaves * sizeof(uint32_t), st));
   return MG_OK;
@@ -1119,6 +1129,12 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     e->lane_packed = e->lane_gen && pk && atoi(pk) == 1;
     const char* dg = getenv("MG_LANE_DIRECT");
     e->lane_direct = lane_on && lane_gen_kind(cfg->env_kind) && (e->lane_gen || !dg || atoi(dg) != 0);
+    // BURST HYBRID (the levels whose refill stays with k_refill): a batch of at least lane_burst_min requests -- the synchronized truncation burst of a
+    // long-episode level, every env at once -- refills on packed lanes (dense: BabyAI-GoTo x 131 072 draws 131 072 episodes in 8 ms on lanes, 30 ms on
+    // cooperative wavefronts), everything smaller on k_refill.  The crossover is where k_refill's throughput (~4 M episodes/s) costs more than a lane
+    // wave's latency (4-7 ms): ~32 768 requests.  MG_LANE_BURST: the threshold (0 = off).
+    e->lane_burst_min = (e->lane_direct && !e->lane_gen) ? 32768 : 0;
+    if (const char* b = getenv("MG_LANE_BURST")) { const long long v = atoll(b); if (v >= 0 && e->lane_direct && !e->lane_gen) e->lane_burst_min = v; }
     e->lane_lpw = 64;
     if (const char* l = getenv("MG_LANE_LPW")) { int v = atoi(l); if (v >= 1 && v <= 64) e->lane_lpw = v; }
   }
@@ -1134,7 +1150,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // DoorKey-8x8 x 262 144: 19.0 (32), 17.9 (64), 16.8 (128); LavaCrossing FullyObs x 131 072: 18.1 (32), 15.2 (64), 13.5 (128).
     // Default: 128, and 64 for the BabyAI single-room generators (whole-map rejection sampling: their long refill chains do
     // worse with twice the work per refill).  Sized for 288 GB of HBM: 128 spare maps of 64 B are 8 KB per env (2 GB at 262 144
-    // envs); capped at 16 GB of ring (the sentence levels carry a 320 B instruction record per spare: the cap halves their ring at large batches).
+    // envs); capped at min(32 GB, a quarter of the free device memory) of ring (the sentence levels carry a 320 B instruction record per spare).
     int R = 1;
     if (!e->static_gen && !e->live_gen) {
       // (the sentence levels: 64 since their verifier runs inside the fused step loop -- with 16 a refill of ~0.6 ms, the length of its
@@ -1150,13 +1166,18 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       // every 128 steps, not every 32 (GoToRedBall x 32 768: 6.8 us per step with R = 64, 3.9 with 128, 2.9 with 256: profiles/r4/lane_refill_ring.txt)
       // (and the others gain as well -- DoorKey-8x8 x 262 144: 7.93 -> 7.49 us per step, LavaCrossing FullyObs x 131 072: 8.84 -> 8.32)
       if (cfg->spare_ring <= 0 && e->lane_gen) R = 256;
+      // (round 5: the big-grid maze levels too -- their wavefront-per-episode refill is latency-bound, ~0.8 ms per episode in a chain of one to three per
+      // wave, so a refill of twice the episodes takes about as long and is due half as often: BabyAI-GoTo x 131 072 48.8 -> 41.1 us per step in a window
+      // without a truncation burst, 77.6 -> 65.3 with one, profiles/r5/babyai_goto_ring.txt; MultiRoom-N6 and BossLevel: no difference)
+      if (cfg->spare_ring <= 0 && e->cells > 256 && !(cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) R = 256;
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
       // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 16 GB cap
       const size_t per_slot_env = (size_t)e->CS + 16 + 40 + (e->sentence ? 4 + INSTR_WORDS * 8 : 0);
       // ... and against a quarter of what the device has free right now (several handles per GPU, or a part with less HBM: ADVICE r4)
-      size_t ring_cap = (size_t)16 << 30;                                                  // (16 GB of 288)
+      size_t ring_cap = (size_t)32 << 30;                                                  // (32 GB of 288; 18.5 GB for BabyAI-GoTo x 131 072 at R = 256)
+      if (const char* s = getenv("MG_RING_CAP_GB")) { const long long v = atoll(s); if (v >= 1 && v <= 256) ring_cap = (size_t)v << 30; }
       { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) ring_cap = std::min(ring_cap, fr / 4); }
       while (R > 4 && (size_t)R * e->N * per_slot_env > ring_cap) R >>= 1;
     }

@@ -35,6 +35,10 @@ struct GenArgs {
   // packed lane refill (k_refill_lane_packed, mg_genlane.h): exclusive prefix sums of the nseg request counts (seg_off[nseg] = all requests of the batch),
   // lanes used per generating wavefront
   const uint32_t* seg_off; int nseg; int lpw;
+  // burst hybrid (round 5): a batch with at least burst_min requests (a synchronized truncation burst: every env of a long-episode level at once) is
+  // served by k_refill_lane_packed -- dense lanes, throughput --, a smaller one by k_refill -- cooperative wavefronts, latency; both kernels are
+  // launched and the one whose case it is not returns at once (0 = off: no such check)
+  uint32_t burst_min;
 };
 
 
@@ -173,6 +177,7 @@ __global__ void __launch_bounds__(64) k_refill(const GenArgs A) {
   const int sidx = (int)(blockIdx.x / (uint32_t)A.wps), wave = (int)(blockIdx.x % (uint32_t)A.wps);
   const int cnt = (int)uni32(A.seg_count[sidx]);
   if (wave >= cnt) return;
+  if (A.burst_min && uni32(A.seg_off[A.nseg]) >= A.burst_min) return;      // a burst: the packed lane refill launched beside this kernel serves it
   RNG rng;
   rng.prefetch(lane);
   uint8_t* lds = smem;

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(64) k_refill_lane_packed(const GenArgs A) {
   const int lane = (int)threadIdx.x;
   const uint32_t total = A.seg_off[A.nseg];
   if ((uint32_t)blockIdx.x * (uint32_t)A.lpw >= total) return;
+  if (A.burst_min && total < A.burst_min) return;              // (burst hybrid: a small batch is k_refill's, mg_genk.h)
   LaneGrid g;
   g.p = smem + lane * lane_grid_stride(A.CS); g.W = A.gp.W; g.H = A.gp.H; g.lane = lane; g.nonempty = 0; g.walls = 0;
   uint64_t* iw = nullptr;

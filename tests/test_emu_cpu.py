@@ -49,6 +49,15 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-Unlock-v0", "n": 70, "launches": [32, 13], "max_steps": 10},
     {"env": "MiniGrid-UnlockPickup-v0", "n": 70, "launches": [32], "max_steps": 10, "stepped": 3},
     {"env": "MiniGrid-BlockedUnlockPickup-v0", "n": 70, "launches": [32], "max_steps": 10, "autoreset": "same_step"},
+    # round 5: the burst hybrid of the wavefront-per-episode levels -- a batch of at least MG_LANE_BURST requests (default 32 768: a synchronized truncation
+    # burst) refills on packed lanes (k_seg_scan + k_refill_lane_packed), a smaller one on k_refill; thresholds that make both halves run here
+    {"env": "BabyAI-GoTo-v0", "n": 200, "launches": [32, 32, 7], "max_steps": 10, "knobs": {"MG_LANE_BURST": "150"}},
+    {"env": "MiniGrid-MultiRoom-N6-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 10, "knobs": {"MG_LANE_BURST": "200"}},
+    {"env": "BabyAI-GoToSeqS5R2-v0", "n": 130, "launches": [32, 32, 32], "knobs": {"MG_LANE_BURST": "2", "MG_LANE_LPW": "7"}},
+    {"env": "BabyAI-PutNextS5N2Carrying-v0", "n": 100, "launches": [32, 16], "max_steps": 4, "knobs": {"MG_LANE_BURST": "60"}},
+    # ... and the packed refill for the levels whose refill runs on lanes (MG_LANE_PACKED=1: A/B)
+    {"env": "MiniGrid-DoorKey-8x8-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 4, "knobs": {"MG_LANE_PACKED": "1"}},
+    {"env": "BabyAI-GoToRedBall-v0", "n": 200, "launches": [32, 13], "max_steps": 3, "knobs": {"MG_LANE_PACKED": "1", "MG_LANE_LPW": "16"}},
     # k_step: the other observation modes (one-hot, symbolic, ViewSizeWrapper, FullyObs above 341 cells), DynamicObstacles' round-3 launches
     # (live refill + k_move_obstacles) under FullyObs, RGB frames (tile map + k_render)
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "obs_mode": "onehot", "stepped": 3},
