@@ -184,7 +184,7 @@ typedef struct mg_config {
   int32_t tile_size;          /* RGB modes: pixels per cell, 1..64 (wrappers.py:305, 355: default 8; 4 | 8 | 12 | 16 take the fast blit); else ignored */
   int32_t rgb_highlight;      /* MG_OBS_RGB: MiniGridEnv.highlight (minigrid_env.py:47, 109; default 1)                    */
   int32_t spare_ring;         /* pre-generated episodes kept per env (power of two, 4..256); 0 = default: 256 for the levels whose refill runs
-                                 one lane per episode and for the big-grid maze levels, 128 for the others, halved while the ring would exceed
+                                 one lane per episode and for the big-grid maze levels at 32 768 envs or more, 128 for the others, halved while the ring would exceed
                                  min(32 GB, a quarter of the free device memory) */
   int32_t traj_slots;         /* trajectory ring slots S (see mg_outputs); 0 = default (32, fewer when a slot is large);
                                  < 0 = -traj_slots preferred, halved like the default while the ring would exceed 2 GB       */

@@ -1169,7 +1169,8 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       // (round 5: the big-grid maze levels too -- their wavefront-per-episode refill is latency-bound, ~0.8 ms per episode in a chain of one to three per
       // wave, so a refill of twice the episodes takes about as long and is due half as often: BabyAI-GoTo x 131 072 48.8 -> 41.1 us per step in a window
       // without a truncation burst, 77.6 -> 65.3 with one, profiles/r5/babyai_goto_ring.txt; MultiRoom-N6 and BossLevel: no difference)
-      if (cfg->spare_ring <= 0 && e->cells > 256 && !(cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) R = 256;
+      // (large batches only: a small batch's refill is short whatever the ring, and every seeded reset fills the whole ring)
+      if (cfg->spare_ring <= 0 && e->cells > 256 && e->N >= 32768 && !(cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) R = 256;
       if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the

@@ -122,7 +122,7 @@ def test_product_kernels_on_the_emulator_equal_the_oracle():
 
 
 def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
-    lines = _run(["-DMG_LANE_WIDE=1"], WIDE_CASES)
+    lines = _run([], WIDE_CASES, MG_LANE_BURST="1")
     assert sum(r["episodes"] for r in lines) > 4000
 
 
@@ -142,11 +142,12 @@ def all_id_cases():
 
 
 def test_every_id_on_the_lane_wide_variant():
-    """All 171 ids through the MG_LANE_WIDE variant's kernels (one lane per episode for every level: 64 episodes per emulated wavefront, which is why this
-    takes seconds -- the product's wavefront-per-episode generators take two minutes for the same list: profiles/emu_all_ids.py, profiles/r4/emu_all_ids*.txt)."""
+    """All 171 ids with EVERY refill on packed lanes (MG_LANE_BURST=1: the burst half of the hybrid refill takes every batch; since round 5 every lane
+    kernel is in the product build -- direct generation runs on lanes for every level anyway): 64 episodes per emulated wavefront, which is why this takes
+    a minute -- the wavefront-per-episode generators take two for the same list (profiles/emu_all_ids.py, profiles/r4/emu_all_ids*.txt)."""
     cases = all_id_cases()
     assert len(cases) >= 170
-    _run(["-DMG_LANE_WIDE=1"], cases)
+    _run([], cases, MG_LANE_BURST="1")
 
 
 def test_product_kernels_under_other_legal_schedules():
@@ -156,7 +157,7 @@ def test_product_kernels_under_other_legal_schedules():
     generator rings: same parity under every seed."""
     for seed in ("1", "2"):
         _run([], PRODUCT_CASES, EMU_SCHED_SEED=seed)
-    _run(["-DMG_LANE_WIDE=1"], WIDE_CASES, EMU_SCHED_SEED="4")
+    _run([], WIDE_CASES, EMU_SCHED_SEED="4", MG_LANE_BURST="1")
 
 
 def test_results_do_not_depend_on_uninitialised_memory():
@@ -166,7 +167,7 @@ def test_results_do_not_depend_on_uninitialised_memory():
     -ftrivial-auto-var-init=pattern)"""
     for fill in ("0xFF", "0xA5"):
         _run([], PRODUCT_CASES, EMU_FILL=fill)
-    _run(["-DMG_LANE_WIDE=1"], WIDE_CASES, EMU_FILL="0xFF")
+    _run([], WIDE_CASES, EMU_FILL="0xFF", MG_LANE_BURST="1")
 
 
 def test_the_product_never_loads_the_emulator():

@@ -284,3 +284,36 @@ def test_pickling_a_live_env_continues_identically(env_id):
     g1, a1 = env.get_state(); g2, a2 = twin.get_state()
     assert (g1 == g2).all() and (a1 == a2).all()
     env.close(); twin.close()
+
+
+def test_big_grid_maze_level_at_a_large_batch_default_rings():
+    """Round 5: BabyAI-GoTo at 32 768 envs takes the deeper default ring (256 spare episodes per env) and the burst hybrid refill (MG_LANE_BURST at its
+    default: a batch in which every env truncates at once refills on packed lanes, the sparse ones on k_refill).  Episodes are cut to 40 steps so that
+    two truncation bursts fall inside 96 fused steps; every flag of every step, sampled observations, the final state and every env's stream position
+    against the oracle."""
+    import minigrid_amd as mg
+    from par_oracle import ParOracle
+    env_id, n = "BabyAI-GoTo-v0", 32768
+    env = mg.make_vec(env_id, n, max_steps=40)
+    assert env.spare_ring == 0 and env.max_fused_steps == 32
+    orc = ParOracle(env_id, n, False, max_steps=40)
+    obs, _ = env.reset(seed=21)
+    assert (obs["image"] == orc.reset(21)[0]).all()
+    t = 0
+    for c in range(3):
+        env.rollout(32, action_seed=9, fused=True)
+        for k in reversed(range(32)):
+            with_image = k in (31, 7, 0)
+            out = orc.philox_step(9, t, quiet=not with_image); t += 1
+            img, rew, term, trunc, d, m, act = env.trajectory(k, image=with_image)
+            if with_image:
+                oo, orew, oterm, otrunc, od, om, oact = out
+                assert (img == oo).all() and (d == od).all() and (m == om).all(), (c, k)
+            else:
+                orew, oterm, otrunc, oact = out
+            assert (act == oact).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (c, k)
+    g1, a1 = env.get_state(); g2, a2 = orc.get_state()
+    assert (g1 == g2).all() and (a1[:, :7] == a2[:, :7]).all()
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    assert env.counters()["episodes"] >= 2 * n
+    env.close(); orc.close()
