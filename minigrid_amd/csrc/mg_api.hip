@@ -1122,13 +1122,16 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // DIRECT generation on lanes: every level with a lane generator -- reset(seed) draws one episode per env and ring slot, every lane is busy, and
     // there lanes win everywhere (ring fill of BabyAI-GoTo x 131 072: 30.4 -> 8.0 ms per slot, BossLevel 25.3 -> 11.8, MultiRoom-N6 2.0 -> 1.8).
     // MG_LANE_PACKED=1: the levels whose refill runs on lanes refill PACKED (A/B; KeyCorridor / UnlockPickup +3 %, GoToRedBall x 32 768 -50 %);
-    // MG_LANE_LPW: busy lanes per wavefront of the packed refill (1..64); MG_LANE_DIRECT=0: direct generation as the refill runs.
+    // MG_LANE_LPW: busy lanes per wavefront of the packed refill (1..64).
     const bool tuned_sparse = lane_gen_kind_base(cfg->env_kind) || lane_gen_kind_product_fn(cfg->env_kind);
     const char* pk = getenv("MG_LANE_PACKED");
     e->lane_gen = lane_on && tuned_sparse;
     e->lane_packed = e->lane_gen && pk && atoi(pk) == 1;
+    // (from 16 384 envs on: a call of k_generate_lane lasts as long as its slowest lane -- ~5 ms for a maze level whatever the batch --, a call of the
+    // cooperative k_generate ~0.8 ms + N / 4.3 M episodes/s: lanes win above ~18 000 envs.  MG_LANE_DIRECT: 0 = never, 1 = at every batch size)
     const char* dg = getenv("MG_LANE_DIRECT");
-    e->lane_direct = lane_on && lane_gen_kind(cfg->env_kind) && (e->lane_gen || !dg || atoi(dg) != 0);
+    const int dmode = dg ? atoi(dg) : -1;
+    e->lane_direct = lane_on && lane_gen_kind(cfg->env_kind) && (e->lane_gen || dmode == 1 || (dmode != 0 && cfg->num_envs >= 16384));
     // BURST HYBRID (the levels whose refill stays with k_refill): a batch of at least lane_burst_min requests -- the synchronized truncation burst of a
     // long-episode level, every env at once -- refills on packed lanes (dense: BabyAI-GoTo x 131 072 draws 131 072 episodes in 8 ms on lanes, 30 ms on
     // cooperative wavefronts), everything smaller on k_refill.  The crossover is where k_refill's throughput (~4 M episodes/s) costs more than a lane

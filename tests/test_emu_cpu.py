@@ -51,10 +51,10 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-BlockedUnlockPickup-v0", "n": 70, "launches": [32], "max_steps": 10, "autoreset": "same_step"},
     # round 5: the burst hybrid of the wavefront-per-episode levels -- a batch of at least MG_LANE_BURST requests (default 32 768: a synchronized truncation
     # burst) refills on packed lanes (k_seg_scan + k_refill_lane_packed), a smaller one on k_refill; thresholds that make both halves run here
-    {"env": "BabyAI-GoTo-v0", "n": 200, "launches": [32, 32, 7], "max_steps": 10, "knobs": {"MG_LANE_BURST": "150"}},
-    {"env": "MiniGrid-MultiRoom-N6-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 10, "knobs": {"MG_LANE_BURST": "200"}},
-    {"env": "BabyAI-GoToSeqS5R2-v0", "n": 130, "launches": [32, 32, 32], "knobs": {"MG_LANE_BURST": "2", "MG_LANE_LPW": "7"}},
-    {"env": "BabyAI-PutNextS5N2Carrying-v0", "n": 100, "launches": [32, 16], "max_steps": 4, "knobs": {"MG_LANE_BURST": "60"}},
+    {"env": "BabyAI-GoTo-v0", "n": 200, "launches": [32, 32, 7], "max_steps": 10, "spare_ring": 8, "knobs": {"MG_LANE_BURST": "150", "MG_LANE_DIRECT": "1"}},
+    {"env": "MiniGrid-MultiRoom-N6-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 10, "spare_ring": 8, "knobs": {"MG_LANE_BURST": "200", "MG_LANE_DIRECT": "1"}},
+    {"env": "BabyAI-GoToSeqS5R2-v0", "n": 130, "launches": [32, 32, 32], "spare_ring": 8, "knobs": {"MG_LANE_BURST": "2", "MG_LANE_LPW": "7", "MG_LANE_DIRECT": "1"}},
+    {"env": "BabyAI-PutNextS5N2Carrying-v0", "n": 100, "launches": [32, 16], "max_steps": 4, "spare_ring": 8, "knobs": {"MG_LANE_BURST": "60", "MG_LANE_DIRECT": "1"}},
     # ... and the packed refill for the levels whose refill runs on lanes (MG_LANE_PACKED=1: A/B)
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 4, "knobs": {"MG_LANE_PACKED": "1"}},
     {"env": "BabyAI-GoToRedBall-v0", "n": 200, "launches": [32, 13], "max_steps": 3, "knobs": {"MG_LANE_PACKED": "1", "MG_LANE_LPW": "16"}},
@@ -122,7 +122,7 @@ def test_product_kernels_on_the_emulator_equal_the_oracle():
 
 
 def test_lane_wide_variant_on_the_emulator_equals_the_oracle():
-    lines = _run([], WIDE_CASES, MG_LANE_BURST="1")
+    lines = _run([], WIDE_CASES, MG_LANE_BURST="1", MG_LANE_DIRECT="1")
     assert sum(r["episodes"] for r in lines) > 4000
 
 
@@ -147,7 +147,7 @@ def test_every_id_on_the_lane_wide_variant():
     a minute -- the wavefront-per-episode generators take two for the same list (profiles/emu_all_ids.py, profiles/r4/emu_all_ids*.txt)."""
     cases = all_id_cases()
     assert len(cases) >= 170
-    _run([], cases, MG_LANE_BURST="1")
+    _run([], cases, MG_LANE_BURST="1", MG_LANE_DIRECT="1")
 
 
 def test_product_kernels_under_other_legal_schedules():
@@ -157,7 +157,7 @@ def test_product_kernels_under_other_legal_schedules():
     generator rings: same parity under every seed."""
     for seed in ("1", "2"):
         _run([], PRODUCT_CASES, EMU_SCHED_SEED=seed)
-    _run([], WIDE_CASES, EMU_SCHED_SEED="4", MG_LANE_BURST="1")
+    _run([], WIDE_CASES, EMU_SCHED_SEED="4", MG_LANE_BURST="1", MG_LANE_DIRECT="1")
 
 
 def test_results_do_not_depend_on_uninitialised_memory():
@@ -167,7 +167,7 @@ def test_results_do_not_depend_on_uninitialised_memory():
     -ftrivial-auto-var-init=pattern)"""
     for fill in ("0xFF", "0xA5"):
         _run([], PRODUCT_CASES, EMU_FILL=fill)
-    _run([], WIDE_CASES, EMU_FILL="0xFF", MG_LANE_BURST="1")
+    _run([], WIDE_CASES, EMU_FILL="0xFF", MG_LANE_BURST="1", MG_LANE_DIRECT="1")
 
 
 def test_the_product_never_loads_the_emulator():
