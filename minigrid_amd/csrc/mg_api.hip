@@ -1104,6 +1104,9 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (ndev < 1) return fail(nullptr, MG_ERR_NO_DEVICE, "no HIP device visible: libminigrid_hip has no CPU fallback");
   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
   if (device >= ndev) return fail(nullptr, MG_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+  // (before anything below asks the runtime about "the" device: the ring cap reads the free memory of the device the handle lives on, not of the
+  // calling thread's current one -- ADVICE r5)
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, MG_ERR_HIP, "hipSetDevice(%d) failed", device);
 
   mg_env* e = new mg_env();
   e->cfg = *cfg; e->device = device;
@@ -1793,7 +1796,7 @@ int mg_get_counters(mg_env* e, uint64_t out[4]) {
   return MG_OK;
 }
 
-#if defined(MG_DEBUG_TIMING) || defined(MG_ATTRIBUTION)
+#if defined(MG_DEBUG_TIMING) || defined(MG_ATTRIBUTION) || defined(MG_GEN_ATTR)
 MG_API int mg_debug_stamps(mg_env* e, uint64_t out[12]) {
   HIP_TRY(e, hipMemcpyAsync(out, e->counters + 4, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(e, hipStreamSynchronize(e->stream));

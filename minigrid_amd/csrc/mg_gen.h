@@ -9,6 +9,23 @@
 
 namespace mg {
 
+// -DMG_GEN_ATTR builds only (profiles/variant_build.py genattr --units=<generator units>,mg_api.hip -DMG_GEN_ATTR; never the product library):
+// per-phase cycle attribution of the wave-cooperative generators.  MG_GA(out, k) charges the s_memtime cycles since the previous mark to phase k
+// (wave-uniform: SGPRs); generate_one adds the sums of every generated episode to counters[4 + k] (mg_debug_stamps).  Phases:
+//   0 prologue (stream load, draw-buffer refills)   1 room lattice + door offsets   2 agent placement   3 connect_all
+//   4 object placement (distractors, locked room)   5 reachability flood   6 mission / instruction drawing + validation
+//   7 epilogue (stream position, stores)   8 MultiRoom: room-chain search   9 MultiRoom: walls + doors
+//   [10] attempts (whole-level tries), [11] episodes -- counts, not cycles
+#if defined(MG_GEN_ATTR) && defined(__HIP_DEVICE_COMPILE__)
+constexpr int MG_GA_N = 10;
+struct GenAttr { uint64_t t; uint64_t ph[MG_GA_N]; uint32_t attempts; };
+#define MG_GA(out, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (out).ga.ph[k] += now_ - (out).ga.t; (out).ga.t = now_; } while (0)
+#define MG_GA_ATTEMPT(out) do { (out).ga.attempts++; } while (0)
+#else
+#define MG_GA(out, k) do { } while (0)
+#define MG_GA_ATTEMPT(out) do { } while (0)
+#endif
+
 struct GenParams {
   int kind, W, H;
   int start_x, start_y, start_dir;   // Empty
@@ -32,6 +49,9 @@ struct GenResult {
   bool failed;        // retry bound exhausted
   uint32_t stuck;     // RoomGrid.place_agent's endless loop was met (room_stuck); set by generate_one to 0 before the first pass
   uint32_t resume;    // set by generate_one: this pass restarts from the generator's last checkpoint (state in the wave's scratch words)
+#if defined(MG_GEN_ATTR) && defined(__HIP_DEVICE_COMPILE__)
+  GenAttr ga;
+#endif
 };
 
 // Byte grid owned by one wave, row-major index y*W+x (core/grid.py:28-35,65-78).  get/set take wave-uniform
@@ -1200,6 +1220,7 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
     st[0] = (uint32_t)num_rooms; st[1] = 0u;
   } else { num_rooms = (int)mr_word<G>(st[0]); nbest = (int)mr_word<G>(st[1]); }
   while (nbest < num_rooms && !rng.dead()) {
+    MG_GA_ATTEMPT(out);
     rng.checkpoint();                           // st[] is consistent with the stream position here
     int n = 0, wall = 2;                        // entryDoorWall of the newest room
     const int ex = rand_int(rng, 0, W - 2), ey = rand_int(rng, 0, W - 2);
@@ -1222,13 +1243,14 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
         if (!placed) break;
       }
     }
-    if (rng.dead()) return;                     // out of buffered draws inside this attempt: restart it from the checkpoint
+    if (rng.dead()) { MG_GA(out, 8); return; }  // out of buffered draws inside this attempt: restart it from the checkpoint
     if (n > nbest) {
 #pragma unroll 1
       for (int k = 0; k < n; k++) st[2 + k] = mr_word<G>(cur[k]);
       nbest = n; st[1] = (uint32_t)n;
     }
   }
+  MG_GA(out, 8);
   if (rng.dead()) return;
   rng.checkpoint();                             // the chain is final: from here on only the drawing below is replayed
   g.clear_empty();
@@ -1246,12 +1268,14 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
       prev = c;
     }
   }
+  MG_GA(out, 9);
   const uint32_t r0 = mr_word<G>(st[2]), rl = mr_word<G>(st[2 + nbest - 1]);
   if (!place_agent(rng, g, (int)(r0 & 31u), (int)((r0 >> 5) & 31u), (int)((r0 >> 10) & 15u), (int)((r0 >> 14) & 15u), -1, out)) out.failed = true;
   int x, y;
   if (!place_obj(rng, g, CELL_GOAL, (int)(rl & 31u), (int)((rl >> 5) & 31u), (int)((rl >> 10) & 15u), (int)((rl >> 14) & 15u),
                  (int)out.ax, (int)out.ay, false, -1, x, y)) out.failed = true;
   out.mission = 0;
+  MG_GA(out, 2);
 }
 
 
@@ -1345,6 +1369,7 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int nc = (W - 1) / st, nr = (H - 1) / st, nrooms = nc * nr;
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
+    MG_GA_ATTEMPT(out);
     rng.checkpoint();                           // RecursionError / RejectSampling regenerate from the current stream position
     if constexpr (G::kWave) {
     MG_WAVE_LDS_SYNC();
@@ -1365,8 +1390,11 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
         if (j < nr - 1) down_x |= (uint64_t)(rand_int(rng, tx + 1, tx + rs - 1) - tx) << (4 * r);
       }
     // RoomGrid.place_agent(i=None, j=None) (roomgrid.py:313-334): a random room, then until the front cell is free
+    MG_GA(out, 1);
     const int ai = rand_int(rng, 0, nc), aj = rand_int(rng, 0, nr);
-    if (!rg_place_agent(rng, g, ai * st, aj * st, rs, out)) continue;
+    const bool agent_ok = rg_place_agent(rng, g, ai * st, aj * st, rs, out);
+    MG_GA(out, 2);
+    if (!agent_ok) continue;
     const int ax = (int)out.ax, ay = (int)out.ay;
     // connect_all (roomgrid.py:336-394)
     const int start = (ay / st) * nc + ax / st;
@@ -1406,6 +1434,7 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
       const int nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
       doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
     }
+    MG_GA(out, 3);
     if (fail || rng.dead()) continue;
     // add_distractors(num_distractors, all_unique=False) (roomgrid.py:396-438): colour, type, then a random room; reject_next_to
     // sees the agent where it now stands
@@ -1420,8 +1449,11 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
       ok = place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), ri * st, rj * st, rs, rs, ax, ay, true, 1000, x, y);
       ocol |= (uint64_t)ci << (3 * n); otyp |= (uint64_t)ti << (2 * n);
     }
+    MG_GA(out, 4);
     if (!ok || rng.dead()) continue;
-    if (!maze_objs_reachable(g, ax, ay)) continue;                   // RejectSampling
+    const bool reachable = maze_objs_reachable(g, ax, ay);
+    MG_GA(out, 5);
+    if (!reachable) continue;                                        // RejectSampling
     if (P.kind == KIND_BABYAI_OPEN) {
       // Open.gen_mission (open.py:69-86): every room's doors in (column, row, right/down/left/up) order -- each door once per side --
       // one of them picked; the description is its colour; "a" when another door has that colour
@@ -1453,6 +1485,7 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
       }
       out.mission = (same > 1u ? 6u : 0u) + sorted_from_color(pc);
       out.aux = ~0ull;
+      MG_GA(out, 6);
       return;
     }
     const int k = rand_int(rng, 0, nd);
@@ -1477,6 +1510,7 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
       out.mission = (matches > 1u ? 28u : 0u) + (kc + 1u) * 4u + (kt + 1u);
     }
     out.aux = ~0ull;                            // GoToInstr on a large grid: no stale tracked position yet (see k_step, RULE_GOTO_BIG)
+    MG_GA(out, 6);
     return;
   }
   out.failed = true;
@@ -2152,11 +2186,14 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
   } else locked = out.resume ? st[1] : st[0];
   for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
     out.retries = attempt;
+    MG_GA(out, 6);                              // (what the previous attempt spent since its last mark: instruction drawing + validation)
+    MG_GA_ATTEMPT(out);
     rng.checkpoint();
     if (!G::kWave || g.lane == 0) st[1] = locked;
     bool fresh = false;
     RG rg;
     rg.gen_grid(rng, g, P.room_size);
+    MG_GA(out, 1);
     out.aux = ~0ull; out.carry = 0; out.mission = 0; out.gstate = locked;
     if constexpr (G::kWave) { if (g.lane < INSTR_WORDS) iw[g.lane] = 0ull; }
     else for (int k = 0; k < INSTR_WORDS; k++) iw[k] = 0ull;
@@ -2179,8 +2216,10 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
         break;
       }
     }
+    MG_GA(out, 4);
     if (!rg.ok || rng.dead()) continue;
     rg.connect_all(rng, g, -1);
+    MG_GA(out, 3);
     if (!rg.ok || rng.dead()) continue;
 #pragma unroll 1
     for (int n = 0; n < P.num_dists && rg.ok && !rng.dead(); n++) {     // add_distractors(all_unique=False) over random rooms
@@ -2188,6 +2227,7 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
       const int ri = rand_int(rng, 0, rg.nc), rj = rand_int(rng, 0, rg.nr);
       rg.add_object(rng, g, ri, rj, t2, c2, ti, ci);
     }
+    MG_GA(out, 4);
     if (!rg.ok || rng.dead()) continue;
     while (!rng.dead()) {
       const int ai = rand_int(rng, 0, rg.nc), aj = rand_int(rng, 0, rg.nr);
@@ -2196,8 +2236,11 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
       if (fresh && rg.ax / rg.st == (int)(locked & 15u) && rg.ay / rg.st == (int)((locked >> 4) & 15u)) continue;
       break;
     }
+    MG_GA(out, 2);
     if (!rg.ok || rng.dead()) continue;
-    if (!((flags >> 8) & 1) && !maze_objs_reachable(g, rg.ax, rg.ay)) continue;
+    const bool reachable = ((flags >> 8) & 1) || maze_objs_reachable(g, rg.ax, rg.ay);
+    MG_GA(out, 5);
+    if (!reachable) continue;
     Objs o;
     if constexpr (G::kWave) o = assign_ids(g, iw);
     else { o.pos = 0; o.code = 0; o.x = 0; o.y = 0; o.count = assign_ids_lane(g, iw); }
@@ -2335,6 +2378,7 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
     // RoomGridLevel.reset (roomgrid_level.py:71-85): max_steps = num_navs_needed * room_size**2 * num_rows * num_cols
     sentence_finish(g, iw, root, node, navs * (uint32_t)(rg.rs * rg.rs * rg.nc * rg.nr));
     out.gstate = locked;
+    MG_GA(out, 6);
     return;
   }
   out.gstate = locked;

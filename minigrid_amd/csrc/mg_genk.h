@@ -66,6 +66,10 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
 
   uint8_t* mygrid = lds;
   MG_STAMP(1);
+#if defined(MG_GEN_ATTR) && defined(__HIP_DEVICE_COMPILE__)
+  GenAttr ga0; ga0.t = __builtin_readcyclecounter(); ga0.attempts = 0;
+  for (int k = 0; k < MG_GA_N; k++) ga0.ph[k] = 0;
+#endif
   rng.load(A.rng, N, (size_t)e, lds + A.CS);
   MG_STAMP(2);
   if (A.rng_snap && lane < 5u) A.rng_snap[(size_t)slot * 5u * N + lane * N + (size_t)e] = pick5(rng.w_in, lane);
@@ -80,6 +84,9 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     if (lane == 0) { ((uint32_t*)(mygrid + scratch0))[0] = gs; if (A.gsnap) A.gsnap[se] = gs; }
   }
   out.gstate = 0; out.stuck = 0;
+#if defined(MG_GEN_ATTR) && defined(__HIP_DEVICE_COMPILE__)
+  out.ga = ga0;
+#endif
   // draw-budget loop: buffer `budget` draws, run the generator.  A pass that ran out of draws restarts from its
   // last checkpoint (GoToRedBall: the start of the current whole-map attempt) with a fresh buffer, or -- no
   // checkpoint passed -- is replayed from the start (same draws, same path) with twice the budget.  One refill
@@ -95,6 +102,7 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     budget = min(budget, cap);
     while (rng.limit < rng.off + budget) rng.refill();
     MG_STAMP(3);
+    MG_GA(out, 0);
     rng.begin_pass();
     // The generator parameters are made opaque per pass: otherwise every switch case's loop-invariant set-up is
     // hoisted out of this (rarely repeated) loop and all of it is live at once -- 160+ VGPRs instead of < 70.
@@ -132,6 +140,12 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
     if (A.dst_aux) A.dst_aux[se] = out.aux;
     if (A.gstate) A.gstate[e] = out.gstate;
     if (out.failed || (out.stuck && A.stuck_mode == 1)) report_errors(A.err, (uint32_t)ERR_GENERATOR);
+#if defined(MG_GEN_ATTR) && defined(__HIP_DEVICE_COMPILE__)
+    MG_GA(out, 7);
+    for (int k = 0; k < MG_GA_N; k++) if (out.ga.ph[k]) atomicAdd(&A.counters[4 + k], (unsigned long long)out.ga.ph[k]);
+    atomicAdd(&A.counters[4 + MG_GA_N], (unsigned long long)out.ga.attempts);
+    atomicAdd(&A.counters[4 + MG_GA_N + 1], 1ull);
+#endif
     unsigned long long* st = A.counters + A.stat_gen_off + 2u * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (STAT_GEN_SLOTS - 1u));
     atomicAdd(&st[0], 1ull);                                         // (mostly) private slot per generating wave
     if (out.retries) atomicAdd(&st[1], (unsigned long long)out.retries);
