@@ -157,6 +157,34 @@ def rocprof_kernel_us_per_step(workload: str, n_per_gpu: int, spl: int, any_buil
     return best
 
 
+CU_SIMDS = 256 * 4            # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+ENGINE_CLOCK_MHZ = 2400.0     # peak engine clock; a wave64 VALU instruction occupies its SIMD's 16-lane VALU for 4 cycles
+
+
+def sq_valu_issue(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
+    """SURVEY.md 8(d) asks for VALU utilisation next to the HBM fraction: from the committed SQ pass of the same command on the same build of the step
+    kernels (profiles/<round>/sq_counters_<workload>.txt beside the hash-matched meta file; separate --pmc passes): SQ_INSTS_VALU per full launch x 4
+    cycles / (1024 SIMDs x the committed full-launch duration x 2.4 GHz).  Returns (fraction, VALU instructions per launch, source) or None."""
+    import re
+    best = None
+    for d, meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build, only_round):
+        f = os.path.join(d, f"sq_counters_{workload}{suffix}.txt")
+        if not os.path.exists(f):
+            continue
+        valu = 0.0
+        for line in open(f):
+            m = re.match(r"SQ_INSTS_VALU,(?:void )?mg::(k_\w+<[^>]*>|k_render),calls=\d+,mean=([0-9.]+)(?:,total=[0-9.]+)?(?:,max=([0-9.]+))?", line)
+            if m and m.group(1).startswith(("k_step", "k_roll")):
+                valu = max(valu, float(m.group(3) or m.group(2)))          # (the per-call maximum: the full launch, as for the traffic counters)
+        try:
+            us = float(meta["full_launch_avg_us"])
+        except Exception:
+            continue
+        if valu > 0 and us > 0:
+            best = (valu * 4.0 / (CU_SIMDS * us * ENGINE_CLOCK_MHZ), valu, os.path.relpath(f, ROOT))
+    return best
+
+
 def pmc_traffic_source(workload: str, n_per_gpu: int, spl: int, any_build: bool = False, only_round: str = ""):
     src = None
     for d, _meta, suffix in _profile_metas(workload, n_per_gpu, spl, any_build, only_round):
@@ -328,7 +356,9 @@ class _StubEnv:
     def __init__(self, n, base):
         self.num_envs, self.env_index_base = n, base
 
-    def reset(self, seed=0): pass
+    max_steps = 256
+
+    def reset(self, seed=None, options=None): pass
     def sync(self): pass
     def timer_start(self): self._t = time.perf_counter()
     def timer_stop(self): return (time.perf_counter() - self._t) * 1e3
@@ -368,6 +398,10 @@ def main(argv=None):
     ap.add_argument("--spl", type=int, default=0, help="cap the steps per fused launch (profiling the driver's launch shape, 20 steps, over many "
                     "launches: --steps 400 --spl 20); 0 = min(max_fused_steps, steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dephase", type=int, default=1, help="1 (default): an UNTIMED pre-roll before the warm-up staggers the envs' episode phases -- "
+                    "32 groups, group g reset (reset_mask) after g x max_steps/32 steps -- so that any timed window, the driver's 20 steps included, "
+                    "holds its steady-state share of truncations, autoresets and episode refills instead of none (a batch reset together truncates "
+                    "together, every max_steps steps); 0: the batch as reset(seed) leaves it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets the multi-process path be exercised "
                          "on a box with fewer GPUs than ranks: ranks then share devices round-robin)")
@@ -431,6 +465,21 @@ def main(argv=None):
         spl = max(1, min(spl, args.spl))
     env.reset(seed=0)
     env.sync()
+    dephase_groups, dephase_stride = 0, 0
+    if args.dephase:
+        # UNTIMED pre-roll (VERDICT r5 "next" #3): reset(seed) starts every env at step 0, so under a random policy nearly all of them truncate together
+        # every max_steps steps and a short timed window sees either the whole burst or nothing.  Stagger the phases: group g (envs with index % 32 == g) is
+        # reset -- its own next episode, reset_mask -- after (g + 1) x stride steps, stride = max_steps / 32 (at most 1 024 steps in all).  From here on
+        # every window of K steps ends about K / max_steps of the batch's episodes, the steady state of minigrid/benchmark.py:36-43's loop.
+        import numpy as np
+        dephase_groups = 32
+        ms = int(getattr(env, "max_steps", 0) or 256)
+        dephase_stride = max(1, min(ms, 1024) // dephase_groups)
+        idx = np.arange(n_per_gpu)
+        for g in range(dephase_groups):
+            env.rollout(dephase_stride, action_seed=977 + g, fused=fused)
+            env.reset(options={"reset_mask": (idx % dephase_groups == g).astype(np.uint8)})
+        env.sync()
 
     def run(k, seed):
         if not gather and fused and args.spl:
@@ -446,7 +495,7 @@ def main(argv=None):
             with senv._on_step_stream():
                 for _ in range(k):
                     env.rollout(1, action_seed=seed)
-                    senv.gather_record()         # ONE all_gather_into_tensor of the step record, stream-ordered (no host sync)
+                    senv.gather_record()         # the step's gather, field-major (images, scalar entries), stream-ordered (no host sync)
 
     def barrier():
         if world > 1:
@@ -458,6 +507,7 @@ def main(argv=None):
     run(args.warmup, 1)
     env.timer_stop()
     env.sync()
+    episodes_before = env.counters()["episodes"]     # (a device read: before the bracket opens)
     barrier()                            # opening side of the bracket: barrier + torch.cuda.synchronize()
     env.timer_start()                    # HIP event on the step stream (an enqueue; measurement apparatus, not step work) ...
     t0 = time.perf_counter()             # ... and the host clock, opened before the first launch is enqueued
@@ -486,6 +536,7 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # ... and the job's: the slowest rank
         dt, dt_dev_sync = float(t[0].item()), float(t[1].item())
     counters = env.counters()
+    episodes_timed = counters["episodes"] - episodes_before
     # the step kernel this configuration runs (mg_api.hip: k_roll7 for the default 7x7 view and for FullyObs of grids up to 341 cells)
     kname = ("k_roll7" if (obs_mode == "partial" and args.view == 7) else
              "k_roll7<., FullyObs>" if (obs_mode == "full" and env.width * env.height <= 341) else "k_step")
@@ -509,6 +560,11 @@ def main(argv=None):
         # the counters are per FULL launch (spl steps); a region whose last launch is shorter moves proportionally less on average
         real_bytes_per_launch = traffic * steps_per_launch_avg / spl if traffic else floor_bytes_per_launch
         achieved = real_bytes_per_launch / launch_s / 1e9
+        # what a reader recomputes from profiles/ alone: the committed counters over the committed kernel-trace duration of the same launch shape
+        # (VERDICT r5 "next" #3; the in-run figure prices the same bytes with THIS run's HIP-event time -- a lone cold launch in the driver's shape)
+        prof_us = rocprof_kernel_us_per_step(args.workload, n_per_gpu, spl) if quotable else None
+        frac_profile = (traffic / (prof_us * spl * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and prof_us) else None
+        valu = sq_valu_issue(args.workload, n_per_gpu, spl) if quotable else None
         out = {
             "metric": "env-steps/s (random policy)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -521,6 +577,11 @@ def main(argv=None):
                                   if spl > 1 else f"one {kname} launch per step") + (" + one k_render" if obs_mode.startswith("rgb") else ""),
                        "steps_per_launch": spl,
                        "gather_obs": gather, "episodes_finished_rank0": counters["episodes"],
+                       "episodes_finished_in_timed_region_rank0": episodes_timed,
+                       "autoreset_share_timed": episodes_timed / float(n_per_gpu * args.steps),
+                       "dephase": ({"groups": dephase_groups, "stride_steps": dephase_stride,
+                                    "how": "untimed pre-roll: group g = envs with index % 32 == g, reset (reset_mask) after (g + 1) x stride steps"}
+                                   if dephase_groups else None),
                        "library_build": build_info, "step_kernel_srchash": step_kernel_srchash(), "environment": mg_environment(), "stub": not use_gpu,
                        "clock": "host_ms: perf_counter from just before the first launch is enqueued until the stop event on the step stream, the "
                                 "generator stream and (gather) the communication stream have each been waited for; "
@@ -530,10 +591,16 @@ def main(argv=None):
                                        "per_rank_us_per_step": per_rank_us,
                                        "collective": (("one all_gather_into_tensor per fused launch (its %d step records, one contiguous block), on a "
                                                        "communication stream overlapped with the next launch" % spl) if gather and fused else
-                                                      "one all_gather_into_tensor of the step record per step" if gather else "none on the data path"),
-                                       "collectives_rank0": (senv.collectives if senv is not None else 0)}},
+                                                      "one gather per step: all_gather_into_tensor of the images + one of the 16-byte scalar entries, field-major (global tensors are views)" if gather else "none on the data path"),
+                                       "collectives_rank0": (senv.collectives if senv is not None else 0),
+                                       "collective_calls_rank0": (senv.collective_calls if senv is not None else 0)}},
             "roofline": {"bound": "hbm", "kernel": "k_step + k_render (one step)" if obs_mode.startswith("rgb") else kname,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "frac_this_run": achieved / HBM_PEAK_GBPS, "frac_profile": frac_profile,
+                         "frac_profile_how": "committed PMC bytes / committed rocprofv3 kernel-trace full-launch duration of the same launch shape and build (profiles/: meta_*.json, pmc_*.txt) / peak",
+                         "valu_issue_frac": valu[0] if valu else None,
+                         "valu_issue_how": ("SQ_INSTS_VALU per full launch (%d, %s) x 4 cycles / (%d SIMDs x committed full-launch duration x %.0f MHz)"
+                                            % (int(valu[1]), valu[2], CU_SIMDS, ENGINE_CLOCK_MHZ)) if valu else None,
                          "bytes_per_launch": real_bytes_per_launch,
                          "bytes_source": ("rocprofv3 PMC counters (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) of a committed pass of this launch shape"
                                           if traffic else "analytic floor: outputs of every step + grids / agent records once per launch (no committed "

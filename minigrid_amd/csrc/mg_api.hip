@@ -378,7 +378,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.seg = e->static_gen ? nullptr : e->seg + (size_t)set * e->nwaves * e->seg_cap;
   P.seg_count = e->static_gen ? nullptr : e->seg_count + (size_t)set * e->nwaves;
   P.seg_cap = e->seg_cap;
-  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0;
+  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0; P.act_stage = 0;
   P.obs_mask = nullptr;
   P.instr = e->instr; P.spare_instr = e->spare_instr; P.off_sentence = e->off_sentence;
   P.out = e->out; P.slot_bytes = e->slot_bytes;
@@ -497,8 +497,14 @@ static int launch_step(mg_env* e, StepParams& P) {
     P.split[0] = 0;
     for (int w = 1; w < nw; w++) { x = x * (1.0 - ratio) + x1; P.split[w] = std::min(P.T - (nw - w), std::max(P.split[w - 1] + 1, (int)std::lround(x))); }
     for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
-    const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
     const bool split = !share && P.T > 1 && roll_split_ok(e, nw);
+    // the device policy's actions staged in LDS by the whole workgroup instead of drawn by the dynamics wave inside the loop (mg_roll.h): the LOG split
+    // of the 7x7 view (one dynamics wave + encode waves over private grids) -- the staged split's workgroups (DynamicObstacles, the sentence levels,
+    // FullyObs) sit at an LDS size where 2 KB more would cost a resident workgroup per CU.  MG_ACT_STAGE=0: A/B.
+    static const bool act_stage_on = [] { const char* s = getenv("MG_ACT_STAGE"); return !s || atoi(s) != 0; }();
+    const bool dsplit_cfg = e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full;
+    P.act_stage = (act_stage_on && split && !dsplit_cfg && P.act_src == ACT_SRC_PHILOX && P.phase == PHASE_STEP) ? 1 : 0;
+    const bool acts = (P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP) || P.act_stage;
     const RollLayout L = roll_layout(e, nw, acts, split);
     // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
     static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
@@ -753,6 +759,12 @@ static const char* configure_obs(mg_env* e) {
   // workgroup's LDS (32 of 71 KB), i.e. two single-wave workgroups per CU instead of four, and their episodes are long (a reset in 1.4 % of
   // the wave-steps).  BossLevel x 131 072: 126 -> 89 us per step, x 32 768: 36.8 -> 27.6 (profiles/r4/shadows_bosslevel.txt).
   if (e->sentence) e->roll_shadows = 0;
+  // (round 6) ... and so do all the big grids (more than 256 cells: the 22 x 22 mazes, MultiRoom's 25 x 25): one staged spare per env is a second copy of
+  // the workgroup's grids -- 32 of 70 KB at 22 x 22 (two resident single-wave workgroups per CU instead of four), 41 of 84 KB at 25 x 25 (one instead of
+  // three) -- for episodes of 120-576 steps, i.e. a handful of resets per workgroup and launch, which fetch their spare from the ring in HBM instead.
+  // BabyAI-GoTo x 131 072: 4.29 -> 6.03 G env-steps/s, MultiRoom-N6 x 65 536: 2.48 -> 3.93 (profiles/r6/ab_connect_all_shadows.txt); KeyCorridorS3R3 (small
+  // grid) is indifferent (23.5 / 23.1).
+  if (e->cells > 256) e->roll_shadows = 0;
   if (const char* s = getenv("MG_ROLL_SHADOWS")) {
     if (atoi(s) == 1) e->roll_shadows = 1;
     if (atoi(s) == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;

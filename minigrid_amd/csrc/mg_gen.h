@@ -76,6 +76,21 @@ struct GridRef {
       if (lane < W) p[y * W + lane] = (uint8_t)CELL_EMPTY;
     MG_WAVE_LDS_SYNC();
   }
+  // RoomGrid._gen_grid's wall lattice (roomgrid.py:123-150): a wall on every st-th row and column, None elsewhere.  One row per instruction;
+  // the row phase is a counter and the column test is taken once (a `y % st` in the loop is a scalar division per row: this loop was 6-7 % of a
+  // maze episode, profiles/r6/refill_attribution_goto_before.txt)
+  MG_D void lattice(int st) {
+    MG_WAVE_LDS_SYNC();
+    const bool colwall = (lane % st) == 0;
+    uint8_t* q = p + lane;
+    int ph = 0;
+    for (int y = 0; y < H; y++) {
+      if (lane < W) *q = (uint8_t)((colwall || ph == 0) ? CELL_WALL_GREY : CELL_EMPTY);
+      q += W;
+      if (++ph == st) ph = 0;
+    }
+    MG_WAVE_LDS_SYNC();
+  }
   // 8x8 grids only (bit index = y*8+x = lane): cells the reachability flood may pass (None or any door), cells
   // holding a non-wall object, and the number of red balls
   // grids of at most 64 cells (bit index = y*W+x = lane): cells the reachability flood may pass (None or any door),
@@ -643,6 +658,85 @@ MG_HD void gen_unlock_family(R& rng, G& g, const GenParams& P, GenResult& out, i
   out.mission = variant == 0 ? 0u : (variant == 1 ? box_ci : box_ci * 2u);
 }
 
+// ---- lane-parallel draws of the wave form (round 6) ----
+// Lane-parallel Lemire draw out of the draw buffer: this lane's value for logical draw p and a range of r >= 2 values, and whether the draw is
+// SAFE -- numpy's rejection step cannot apply to it (buffered_bounded_lemire_uint32 looks at its threshold only when leftover < r, and the
+// threshold of a power-of-two range is 0).  An unsafe draw is never used speculatively: the caller falls back to the scalar rand_int there.
+template <class R>
+MG_D uint32_t peek_bounded(const R& rng, uint32_t p, uint32_t r, bool& safe) {
+  const uint64_t m = (uint64_t)rng.peek_lane(p) * r;
+  safe = (uint32_t)m >= r || (r & (r - 1u)) == 0u;
+  return (uint32_t)(m >> 32);
+}
+// Four bounded draws in a row (_rand_int over r0 .. r3 values, each >= 2): lanes 0..3 evaluate them in one pass.  false = not applicable here
+// (too few buffered draws, or an unsafe draw): nothing was consumed, the caller draws them one by one.
+template <class R, class G>
+MG_D bool draw4_spec(R& rng, const G& g, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, int v[4]) {
+  if (rng.dead() || rng.wpos + 4u > rng.window() || r0 < 2u || r1 < 2u || r2 < 2u || r3 < 2u) return false;
+  const uint32_t l = (uint32_t)g.lane < 3u ? (uint32_t)g.lane : 3u;
+  const uint32_t r = l == 0u ? r0 : l == 1u ? r1 : l == 2u ? r2 : r3;
+  bool safe;
+  const uint32_t val = peek_bounded(rng, rng.wpos + l, r, safe);
+  if (__ballot(!safe)) return false;
+  v[0] = (int)lane32(val, 0u); v[1] = (int)lane32(val, 1u); v[2] = (int)lane32(val, 2u); v[3] = (int)lane32(val, 3u);
+  rng.wpos += 4u;
+  return true;
+}
+// RoomGrid.connect_all's loop (roomgrid.py:362-394), speculatively: until a pick is accepted nothing the loop looks at changes, so lane t can
+// evaluate iteration t -- the picks (i, j, k) from draws wpos + per * t .., per = the draws an iteration consumes -- against the CURRENT doors, and
+// the first lane whose pick is a free wall between two unlocked rooms is the iteration the reference accepts; the lanes before it are its rejected
+// iterations.  Returns the iterations consumed (their draws are consumed too); `acc`: the last of them was accepted, with its (i, j, k).  0 = nothing
+// could be evaluated (no buffered draws left, or iteration 0 holds an unsafe draw): the caller runs one iteration the scalar way.
+template <class R, class G>
+MG_D int connect_spec(R& rng, const G& g, int nc, int nr, uint64_t doors, uint32_t locked, int max_iters, bool& acc, int& i, int& j, int& k) {
+  acc = false;
+  if (rng.dead()) return 0;
+  const uint32_t di = nc > 1 ? 1u : 0u, dj = nr > 1 ? 1u : 0u, per = di + dj + 1u;      // (_rand_int over one value draws nothing)
+  const uint32_t p0 = rng.wpos + per * (uint32_t)g.lane;
+  const bool have = p0 + per <= rng.window() && g.lane < max_iters;
+  bool s0 = true, s1 = true, s2 = true;
+  const int li = di ? (int)peek_bounded(rng, p0, (uint32_t)nc, s0) : 0;
+  const int lj = dj ? (int)peek_bounded(rng, p0 + di, (uint32_t)nr, s1) : 0;
+  const int lk = (int)peek_bounded(rng, p0 + di + dj, 4u, s2);
+  const unsigned long long unsafe = __ballot(have && !(s0 && s1 && s2));
+  const int nhave = __popcll(__ballot(have));                                           // (the lanes that have their draws are a prefix)
+  const int n = unsafe ? min(nhave, __ffsll((long long)unsafe) - 1) : nhave;
+  if (n == 0) return 0;
+  const bool nb = lk == 0 ? li < nc - 1 : lk == 1 ? lj < nr - 1 : lk == 2 ? li > 0 : lj > 0;
+  const int r = lj * nc + li, r2 = r + (lk == 0 ? 1 : lk == 1 ? nc : lk == 2 ? -1 : -nc);
+  const bool free_wall = nb && !((doors >> ((r * 4 + lk) & 63)) & 1ull);
+  const bool unlocked = !(((locked >> (r & 31)) | (locked >> (r2 & 31))) & 1u);
+  const unsigned long long okm = __ballot(g.lane < n && free_wall && unlocked);
+  if (okm) {
+    const int t = __ffsll((long long)okm) - 1;
+    rng.wpos += per * (uint32_t)(t + 1);
+    i = (int)lane32((uint32_t)li, (uint32_t)t); j = (int)lane32((uint32_t)lj, (uint32_t)t); k = (int)lane32((uint32_t)lk, (uint32_t)t);
+    acc = true;
+    return t + 1;
+  }
+  rng.wpos += per * (uint32_t)n;
+  return n;
+}
+
+// RoomGrid.connect_all's find_reach (roomgrid.py:345-360) on the door nibbles (bit 4r+k: room r has a door on side k = right, down, left, up):
+// the set of rooms reachable from `start` through doors, as bit 4r per room.  One pass = every reached room's four neighbours at once (a dozen
+// 64-bit scalar operations); at most nrooms - 1 passes.  The reference recomputes the set in every iteration of connect_all's loop, rejected
+// picks included; it is a function of the doors alone, so the callers recompute it only after a door was added (round 6: the per-room loops this
+// replaces were 60-70 % of a maze episode's instructions, profiles/r6/refill_attribution_*.txt).
+constexpr uint64_t ROOM_LSB = 0x1111111111111111ull;
+MG_HD uint64_t rooms_reach(uint64_t doors, int start, int nc, int nrooms) {
+  const uint64_t mR = doors & ROOM_LSB, mD = (doors >> 1) & ROOM_LSB, mL = (doors >> 2) & ROOM_LSB, mU = (doors >> 3) & ROOM_LSB;
+  uint64_t reach = 1ull << (4 * start);
+#pragma unroll 1
+  for (int it = 0; it < nrooms; it++) {
+    const uint64_t next = reach | ((reach & mR) << 4) | ((reach & mD) << (4 * nc)) | ((reach & mL) >> 4) | ((reach & mU) >> (4 * nc));
+    if (next == reach) break;
+    reach = next;
+  }
+  return reach;
+}
+MG_HD uint64_t rooms_all(int nrooms) { return ROOM_LSB & ((1ull << (4 * nrooms)) - 1ull); }
+
 // ---- general RoomGrid (core/roomgrid.py) for KeyCorridor: 3 columns x up to 3 rows of rooms.  Room bookkeeping is
 //      packed: 4 bits per room for the right-door y and the down-door x, one bit per (room, wall) for "has a door or
 //      no wall" (Room.doors truthiness), one bit per room for Room.locked. ----
@@ -676,10 +770,7 @@ MG_HD void gen_keycorridor(R& rng, G& g, const GenParams& P, GenResult& out) {
   S.right_y = 0; S.down_x = 0; S.doors = 0; S.locked = 0;
   const int rs = S.rs, W = g.W, H = g.H;
   if constexpr (G::kWave) {
-  MG_WAVE_LDS_SYNC();
-  for (int y = 0; y < H; y++)
-    if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % (rs - 1)) == 0 || (y % (rs - 1)) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-  MG_WAVE_LDS_SYNC();
+  g.lattice(rs - 1);
   } else {
     g.clear_empty();
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % (rs - 1)) == 0 || (y % (rs - 1)) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -712,29 +803,27 @@ MG_HD void gen_keycorridor(R& rng, G& g, const GenParams& P, GenResult& out) {
   // connect_all (roomgrid.py:336-394)
   const int start = S.room((int)out.ax / (rs - 1), (int)out.ay / (rs - 1));
   const int nrooms = S.ncols * S.nrows;
+  bool connected = rooms_reach(S.doors, start, S.ncols, nrooms) == rooms_all(nrooms);
   for (int itr = 0; !rng.dead(); itr++) {
     if (itr > 5000) { out.failed = true; break; }
-    uint32_t reach = 1u << start;
-    for (;;) {
-      uint32_t next = reach;
-      for (int r = 0; r < nrooms; r++)
-        if ((reach >> r) & 1u) {
-          const int i = r % S.ncols, j = r / S.ncols;
-          for (int k = 0; k < 4; k++)
-            if ((S.doors >> (r * 4 + k)) & 1ull) next |= 1u << S.room(i + (k == 0) - (k == 2), j + (k == 1) - (k == 3));
-        }
-      if (next == reach) break;
-      reach = next;
+    if (connected) break;
+    int i = 0, j = 0, k = 0;
+    bool picked = false;
+    if constexpr (G::kWave) {
+      const int n = connect_spec(rng, g, S.ncols, S.nrows, S.doors, S.locked, 5001 - itr, picked, i, j, k);
+      if (n > 0) { itr += n - 1; if (!picked) continue; }
     }
-    if (reach == (1u << nrooms) - 1u) break;
-    const int i = rand_int(rng, 0, S.ncols), j = rand_int(rng, 0, S.nrows), k = rand_int(rng, 0, 4);
-    if (!S.has_nb(i, j, k) || ((S.doors >> (S.room(i, j) * 4 + k)) & 1ull)) continue;
-    const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
-    if (((S.locked >> S.room(i, j)) | (S.locked >> S.room(ni, nj))) & 1u) continue;
+    if (!picked) {
+      i = rand_int(rng, 0, S.ncols); j = rand_int(rng, 0, S.nrows); k = rand_int(rng, 0, 4);
+      if (!S.has_nb(i, j, k) || ((S.doors >> (S.room(i, j) * 4 + k)) & 1ull)) continue;
+      const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+      if (((S.locked >> S.room(i, j)) | (S.locked >> S.room(ni, nj))) & 1u) continue;
+    }
     const uint32_t ci = (uint32_t)rand_int(rng, 0, 6);
     S.door_pos(i, j, k, x, y);
     g.set(x, y, make_cell(T_DOOR_CLOSED, color_from_sorted(ci)));
     S.mark(i, j, k);
+    connected = rooms_reach(S.doors, start, S.ncols, nrooms) == rooms_all(nrooms);
   }
   out.mission = ball_ci;
 }
@@ -861,10 +950,7 @@ MG_HD void gen_findobj(R& rng, G& g, const GenParams& P, GenResult& out) {
     out.retries = attempt;
     rng.checkpoint();                           // a RecursionError regenerates from the current stream position
     if constexpr (G::kWave) {
-    MG_WAVE_LDS_SYNC();
-    for (int y = 0; y < H; y++)
-      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-    MG_WAVE_LDS_SYNC();
+    g.lattice(st);
     } else {
       g.clear_empty();
       for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -887,28 +973,22 @@ MG_HD void gen_findobj(R& rng, G& g, const GenParams& P, GenResult& out) {
     // connect_all (roomgrid.py:336-394)
     const int start = ((int)out.ay / st) * 3 + (int)out.ax / st;
     bool fail = false;
+    bool connected = rooms_reach(doors, start, 3, 9) == rooms_all(9);
     for (int itr = 0; !rng.dead(); itr++) {
       if (itr > 5000) { fail = true; break; }
-      uint32_t reach = 1u << start;
-      for (;;) {
-        uint32_t next = reach;
-#pragma unroll 1
-        for (int r = 0; r < 9; r++)
-          if ((reach >> r) & 1u) {
-            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
-            if (d & 1u) next |= 1u << (r + 1);
-            if (d & 2u) next |= 1u << (r + 3);
-            if (d & 4u) next |= 1u << (r - 1);
-            if (d & 8u) next |= 1u << (r - 3);
-          }
-        if (next == reach) break;
-        reach = next;
+      if (connected) break;
+      int i = 0, j = 0, k = 0;
+      bool picked = false;
+      if constexpr (G::kWave) {
+        const int n = connect_spec(rng, g, 3, 3, doors, 0u, 5001 - itr, picked, i, j, k);
+        if (n > 0) { itr += n - 1; if (!picked) continue; }
       }
-      if (reach == 0x1FFu) break;
-      const int i = rand_int(rng, 0, 3), j = rand_int(rng, 0, 3), k = rand_int(rng, 0, 4);
-      const bool has_nb = k == 0 ? i < 2 : k == 1 ? j < 2 : k == 2 ? i > 0 : j > 0;
+      if (!picked) {
+        i = rand_int(rng, 0, 3); j = rand_int(rng, 0, 3); k = rand_int(rng, 0, 4);
+        const bool has_nb = k == 0 ? i < 2 : k == 1 ? j < 2 : k == 2 ? i > 0 : j > 0;
+        if (!has_nb || ((doors >> ((j * 3 + i) * 4 + k)) & 1ull)) continue;
+      }
       const int r = j * 3 + i;
-      if (!has_nb || ((doors >> (r * 4 + k)) & 1ull)) continue;
       const uint32_t dc = (uint32_t)rand_int(rng, 0, 6);
       // Room.door_pos[k] (roomgrid.py:158-171): the left / up door is the neighbour's right / down door
       const int ri = k == 2 ? i - 1 : i, rj = k == 3 ? j - 1 : j, rr = rj * 3 + ri;
@@ -918,6 +998,7 @@ MG_HD void gen_findobj(R& rng, G& g, const GenParams& P, GenResult& out) {
       g.set(dx, dy, make_cell(T_DOOR_CLOSED, color_from_sorted(dc)));
       const int nr = r + (k == 0 ? 1 : k == 1 ? 3 : k == 2 ? -1 : -3);
       doors |= (1ull << (r * 4 + k)) | (1ull << (nr * 4 + ((k + 2) & 3)));
+      connected = rooms_reach(doors, start, 3, 9) == rooms_all(9);
     }
     if (fail) continue;
     out.mission = ti + 1u;                      // "pick up the key / ball / box"
@@ -934,10 +1015,7 @@ MG_HD void gen_unlocklocal(R& rng, G& g, const GenParams& P, GenResult& out) {
     out.retries = attempt;
     rng.checkpoint();
     if constexpr (G::kWave) {
-    MG_WAVE_LDS_SYNC();
-    for (int y = 0; y < H; y++)
-      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-    MG_WAVE_LDS_SYNC();
+    g.lattice(st);
     } else {
       g.clear_empty();
       for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -989,10 +1067,7 @@ MG_HD void gen_obstructedmaze(R& rng, G& g, const GenParams& P, GenResult& out) 
   const int flags = P.num_crossings;
   const bool key_in_box = flags & 1, blocked = (flags >> 1) & 1, v1 = (flags >> 2) & 1, one_d = (flags >> 3) & 1;
   if constexpr (G::kWave) {
-  MG_WAVE_LDS_SYNC();
-  for (int y = 0; y < H; y++)
-    if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-  MG_WAVE_LDS_SYNC();
+  g.lattice(st);
   } else {
     g.clear_empty();
     for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -1372,10 +1447,7 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
     MG_GA_ATTEMPT(out);
     rng.checkpoint();                           // RecursionError / RejectSampling regenerate from the current stream position
     if constexpr (G::kWave) {
-    MG_WAVE_LDS_SYNC();
-    for (int y = 0; y < H; y++)
-      if (g.lane < W) g.p[y * W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-    MG_WAVE_LDS_SYNC();
+    g.lattice(st);
     } else {
       g.clear_empty();
       for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -1405,34 +1477,29 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
       dx = vertical_wall ? ri * st + st : ri * st + (int)((down_x >> (4 * rr)) & 15u);
       dy = vertical_wall ? rj * st + (int)((right_y >> (4 * rr)) & 15u) : rj * st + st;
     };
+    bool connected = nrooms == 1;                  // (no door yet: only a one-room grid is connected)
     for (int itr = 0; !rng.dead(); itr++) {
       if (itr > 5000) { fail = true; break; }
-      uint32_t reach = 1u << start;
-      for (;;) {
-        uint32_t next = reach;
-#pragma unroll 1
-        for (int r = 0; r < nrooms; r++)
-          if ((reach >> r) & 1u) {
-            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
-            if (d & 1u) next |= 1u << (r + 1);
-            if (d & 2u) next |= 1u << (r + nc);
-            if (d & 4u) next |= 1u << (r - 1);
-            if (d & 8u) next |= 1u << (r - nc);
-          }
-        if (next == reach) break;
-        reach = next;
+      if (connected) break;
+      int i = 0, j = 0, k = 0;
+      bool picked = false;
+      if constexpr (G::kWave) {
+        const int n = connect_spec(rng, g, nc, nr, doors, 0u, 5001 - itr, picked, i, j, k);
+        if (n > 0) { itr += n - 1; if (!picked) continue; }
       }
-      if (reach == (1u << nrooms) - 1u) break;
-      const int i = rand_int(rng, 0, nc), j = rand_int(rng, 0, nr), k = rand_int(rng, 0, 4);
-      const bool has_nb = k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0;
+      if (!picked) {
+        i = rand_int(rng, 0, nc); j = rand_int(rng, 0, nr); k = rand_int(rng, 0, 4);
+        const bool has_nb = k == 0 ? i < nc - 1 : k == 1 ? j < nr - 1 : k == 2 ? i > 0 : j > 0;
+        if (!has_nb || ((doors >> ((j * nc + i) * 4 + k)) & 1ull)) continue;
+      }
       const int r = j * nc + i;
-      if (!has_nb || ((doors >> (r * 4 + k)) & 1ull)) continue;
       const uint32_t dc = (uint32_t)rand_int(rng, 0, 6);
       int dx, dy;
       door_xy(i, j, k, dx, dy);
       g.set(dx, dy, make_cell(T_DOOR_CLOSED, color_from_sorted(dc)));
       const int nrm = r + (k == 0 ? 1 : k == 1 ? nc : k == 2 ? -1 : -nc);
       doors |= (1ull << (r * 4 + k)) | (1ull << (nrm * 4 + ((k + 2) & 3)));
+      connected = rooms_reach(doors, start, nc, nrooms) == rooms_all(nrooms);      // find_reach, after the one thing that changes it
     }
     MG_GA(out, 3);
     if (fail || rng.dead()) continue;
@@ -1444,8 +1511,12 @@ MG_HD void gen_babyai_maze(R& rng, G& g, const GenParams& P, GenResult& out) {
     int x, y;
 #pragma unroll 1
     for (int n = 0; n < nd && ok && !rng.dead(); n++) {
-      const uint32_t ci = (uint32_t)rand_int(rng, 0, 6), ti = (uint32_t)rand_int(rng, 0, 3);
-      const int ri = rand_int(rng, 0, nc), rj = rand_int(rng, 0, nr);
+      uint32_t ci, ti;
+      int ri, rj, v4[4];
+      bool four = false;
+      if constexpr (G::kWave) four = draw4_spec(rng, g, 6u, 3u, (uint32_t)nc, (uint32_t)nr, v4);      // colour, type, room column, room row: one pass
+      if (four) { ci = (uint32_t)v4[0]; ti = (uint32_t)v4[1]; ri = v4[2]; rj = v4[3]; }
+      else { ci = (uint32_t)rand_int(rng, 0, 6); ti = (uint32_t)rand_int(rng, 0, 3); ri = rand_int(rng, 0, nc); rj = rand_int(rng, 0, nr); }
       ok = place_obj(rng, g, make_cell((uint32_t)T_KEY + ti, color_from_sorted(ci)), ri * st, rj * st, rs, rs, ax, ay, true, 1000, x, y);
       ocol |= (uint64_t)ci << (3 * n); otyp |= (uint64_t)ti << (2 * n);
     }
@@ -1549,10 +1620,7 @@ struct RG {
     rs = room_size; st = rs - 1; nc = (g.W - 1) / st; nr = (g.H - 1) / st;
     right_off = 0; down_off = 0; doors = 0; locked = 0; ok = true;
     if constexpr (G::kWave) {
-    MG_WAVE_LDS_SYNC();
-    for (int y = 0; y < g.H; y++)
-      if (g.lane < g.W) g.p[y * g.W + g.lane] = (uint8_t)(((g.lane % st) == 0 || (y % st) == 0) ? CELL_WALL_GREY : CELL_EMPTY);
-    MG_WAVE_LDS_SYNC();
+    g.lattice(st);
     } else {
       g.clear_empty();
       for (int y = 0; y < g.H; y++) for (int x = 0; x < g.W; x++) if ((x % st) == 0 || (y % st) == 0) g.set(x, y, CELL_WALL_GREY);
@@ -1596,33 +1664,29 @@ struct RG {
   // RoomGrid.connect_all (roomgrid.py:336-394) with door_colors = COLOR_NAMES without index `exclude` (< 0: all six)
   template <class R, class G> MG_HD void connect_all(R& rng, G& g, int exclude) {
     const int start = (ay / st) * nc + ax / st, nrooms = nc * nr;
+    // (find_reach is a function of the doors alone: recomputed after a door was added, not in every iteration -- see rooms_reach)
+    bool connected = rooms_reach(doors, start, nc, nrooms) == rooms_all(nrooms);
     for (int itr = 0; !rng.dead(); itr++) {
       if (itr > 5000) { ok = false; return; }
-      uint32_t reach = 1u << start;
-      for (;;) {
-        uint32_t next = reach;
-#pragma unroll 1
-        for (int r = 0; r < nrooms; r++)
-          if ((reach >> r) & 1u) {
-            const uint32_t d = (uint32_t)(doors >> (r * 4)) & 15u;
-            if (d & 1u) next |= 1u << (r + 1);
-            if (d & 2u) next |= 1u << (r + nc);
-            if (d & 4u) next |= 1u << (r - 1);
-            if (d & 8u) next |= 1u << (r - nc);
-          }
-        if (next == reach) break;
-        reach = next;
+      if (connected) return;
+      int i = 0, j = 0, k = 0;
+      bool picked = false;
+      if constexpr (G::kWave) {
+        const int n = connect_spec(rng, g, nc, nr, doors, locked, 5001 - itr, picked, i, j, k);
+        if (n > 0) { itr += n - 1; if (!picked) continue; }
       }
-      if (reach == (1u << nrooms) - 1u) return;
-      const int i = rand_int(rng, 0, nc), j = rand_int(rng, 0, nr), k = rand_int(rng, 0, 4);
-      if (!has_nb(i, j, k) || ((doors >> (room(i, j) * 4 + k)) & 1ull)) continue;
-      const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
-      if (((locked >> room(i, j)) | (locked >> room(ni, nj))) & 1u) continue;
+      if (!picked) {
+        i = rand_int(rng, 0, nc); j = rand_int(rng, 0, nr); k = rand_int(rng, 0, 4);
+        if (!has_nb(i, j, k) || ((doors >> (room(i, j) * 4 + k)) & 1ull)) continue;
+        const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+        if (((locked >> room(i, j)) | (locked >> room(ni, nj))) & 1u) continue;
+      }
       int ci = rand_int(rng, 0, exclude >= 0 ? 5 : 6), dx, dy;
       if (exclude >= 0 && ci >= exclude) ci++;
       const uint32_t keep = locked;                                // connect_all's add_door(..., locked=False) on an unlocked room
       add_door(rng, g, i, j, k, ci, 0, dx, dy);
       locked = keep;
+      connected = rooms_reach(doors, start, nc, nrooms) == rooms_all(nrooms);
     }
   }
 };
@@ -2223,8 +2287,11 @@ MG_HD void gen_levelgen(R& rng, G& g, const GenParams& P, GenResult& out, uint64
     if (!rg.ok || rng.dead()) continue;
 #pragma unroll 1
     for (int n = 0; n < P.num_dists && rg.ok && !rng.dead(); n++) {     // add_distractors(all_unique=False) over random rooms
-      const int c2 = rand_int(rng, 0, 6), t2 = rand_int(rng, 0, 3);
-      const int ri = rand_int(rng, 0, rg.nc), rj = rand_int(rng, 0, rg.nr);
+      int c2, t2, ri, rj, v4[4];
+      bool four = false;
+      if constexpr (G::kWave) four = draw4_spec(rng, g, 6u, 3u, (uint32_t)rg.nc, (uint32_t)rg.nr, v4);
+      if (four) { c2 = v4[0]; t2 = v4[1]; ri = v4[2]; rj = v4[3]; }
+      else { c2 = rand_int(rng, 0, 6); t2 = rand_int(rng, 0, 3); ri = rand_int(rng, 0, rg.nc); rj = rand_int(rng, 0, rg.nr); }
       rg.add_object(rng, g, ri, rj, t2, c2, ti, ci);
     }
     MG_GA(out, 4);

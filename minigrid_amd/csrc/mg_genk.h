@@ -93,7 +93,11 @@ MG_D void generate_one(const GenArgs& A, RNG& rng, int e, uint32_t slot, uint32_
   // covers every DoorKey/Crossing episode; GoToRedBall (about 60 draws per attempt, 15.6 % of attempts rejected)
   // starts with three.
   const uint32_t cap = ((uint32_t)A.cap_words / RNG::kRefillWords) * RNG::kRefillWords;
-  const uint32_t want0 = A.gp.kind == 3 ? 384u : A.gp.kind == 53 ? 512u : 1u;        // GoToRedBall; LevelGen (an attempt draws 150-500 words)
+  // (round 6: the multi-room levels start with what an attempt typically draws -- a 3 x 3 maze attempt ~250 words (5 attempts per BabyAI-GoTo episode),
+  // a MultiRoom-N6 chain search > 1000 words per episode: with one refill of 128 nearly every attempt ran twice, once into the end of the buffer and
+  // once more from its checkpoint: profiles/r6/refill_attribution_*_before.txt "prologue")
+  const int kd = A.gp.kind;
+  const uint32_t want0 = kd == 3 ? 384u : kd == 53 ? 512u : (kd >= 33 && kd <= 35) ? 768u : kd == 23 ? 512u : (kd >= 21 && kd <= 52) ? 256u : 1u;
   const uint32_t budget0 = ((want0 + RNG::kRefillWords - 1u) / RNG::kRefillWords) * RNG::kRefillWords;
   uint32_t budget = budget0, retries_before = 0;
   out.resume = 0;

@@ -268,14 +268,12 @@ struct WavePcg64 {
     const uint32_t lo = next32(), hi = next32();
     return (uint64_t)lo | ((uint64_t)hi << 32);
   }
-  // lane-parallel look-ahead for speculative rejection sampling: logical draw p (a different p per lane) out of the
-  // register window; only meaningful for p < window()
-  MG_D uint32_t window() const { return limit < 128u ? limit : 128u; }
-  MG_D uint32_t peek_lane(uint32_t p_) const {
-    const uint32_t p = word_of(p_);
-    const uint32_t e = (uint32_t)__shfl((int)reg_even, (int)(p >> 1)), o = (uint32_t)__shfl((int)reg_odd, (int)(p >> 1));
-    return (p & 1u) ? o : e;
-  }
+  // lane-parallel look-ahead for speculative rejection sampling: logical draw p (a different p per lane); only meaningful for p < window().
+  // Round 6: straight out of the draw buffer in LDS (one gather per peek, every buffered draw: logical draw q sits at buf[word_of(q)]) -- the
+  // register window of round 2 (two ds_bpermutes per peek) ended at draw 128, so the later attempts of a maze episode (5 whole-level attempts of
+  // ~250 draws each) placed their objects one scalar try at a time.
+  MG_D uint32_t window() const { return limit; }
+  MG_D uint32_t peek_lane(uint32_t p_) const { return buf[min(word_of(p_), limit ? limit - 1u : 0u)]; }
   // stream position after `pos` draws, in numpy's terms.  Every lane computes the same words.
   MG_D void final_words(uint64_t w[5]) const { words_at(wpos, w); }
   // make the checkpoint the new origin of the draw buffer (the draws before it are never replayed)
@@ -362,13 +360,8 @@ struct WavePhilox {
     return v;
   }
   MG_D uint64_t next64() { const uint32_t lo = next32(), hi = next32(); return (uint64_t)lo | ((uint64_t)hi << 32); }
-  MG_D uint32_t window() const { const uint32_t w = limit + skip < 256u ? limit + skip : 256u; return w - skip; }
-  MG_D uint32_t peek_lane(uint32_t p) const {
-    const uint32_t q = p + skip, l = q >> 2, k = q & 3u;
-    const uint32_t a = (uint32_t)__shfl((int)reg[0], (int)l), b = (uint32_t)__shfl((int)reg[1], (int)l);
-    const uint32_t c = (uint32_t)__shfl((int)reg[2], (int)l), d = (uint32_t)__shfl((int)reg[3], (int)l);
-    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
-  }
+  MG_D uint32_t window() const { return limit; }
+  MG_D uint32_t peek_lane(uint32_t p) const { return buf[min(p, limit ? limit - 1u : 0u) + skip]; }       // (logical draw p = buffer word p + skip)
   MG_D void final_words(uint64_t w[5]) const {
     const uint32_t q = wpos + skip;                  // words consumed from the buffer origin
     const uint32_t nblk = (q + 3u) >> 2;

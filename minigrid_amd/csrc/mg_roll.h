@@ -614,6 +614,25 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (l < EPW && env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
     }
   }
+  if (!ONE && P.act_stage) {
+    // The device policy's actions of the WHOLE launch, drawn up front by every wave of the workgroup (round 6): a Philox4x32-10 block is ~40
+    // quarter-rate multiplies and gives one env four steps' actions; inside the loop it sat on the dynamics wave -- the one serial chain the
+    // workgroup's pace depends on -- every fourth step.  Here the launch's <= 9 blocks per env are spread over all the
+    // threads, and the loop reads one LDS byte per step, exactly as it does for caller-supplied actions.  Block b covers steps t = 4b .. 4b + 3
+    // of the env's action stream (t = P.t0 + j, mod 2^32): thread (l, g) draws block (t0 >> 2) + g of env l and files the steps that lie in the launch.
+    const uint32_t nblk = ((uint32_t)P.T + (P.t0 & 3u) + 3u) >> 2;
+    for (uint32_t k = (uint32_t)tid; k < nblk * 64u; k += (uint32_t)nthreads) {
+      const uint32_t l = k & 63u, g = k >> 6;
+      const uint32_t t_first = (P.t0 & ~3u) + 4u * g;
+      uint32_t w[4];
+      philox_action_block(P, min(env0 + (int)l, P.N - 1), t_first >> 2, w);
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t j = t_first + q - P.t0;                      // (mod 2^32: a block that straddles the launch's first step gives j >= T for the steps before it)
+        if (j < (uint32_t)P.T) sact[j * 64u + l] = (uint8_t)(((uint64_t)w[q] * 7u) >> 32);
+      }
+    }
+  }
   if constexpr (FULL) {
     // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
     if (!ONE && P.use_shadow) {
@@ -694,12 +713,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_MARK("action");
     uint32_t act = A_DONE;
     if (P.phase == PHASE_STEP) {
-      if (P.act_src == ACT_SRC_PHILOX) {
+      if (P.act_src == ACT_SRC_PHILOX && (ONE || !P.act_stage)) {
         const uint32_t t = P.t0 + (uint32_t)j;
         if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
         const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
         act = (uint32_t)(((uint64_t)w * 7u) >> 32);
-      } else act = sact[j * 64 + lane];
+      } else act = sact[j * 64 + lane];                            // the caller's actions, or the device policy's staged in the prologue
     }
     o.act_in = act;
     if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)

@@ -3,12 +3,17 @@
 Environments never interact (the reference's `MiniGridEnv` instances share nothing on this path), so the batch
 shards with NO data-path collective: rank g owns the contiguous global env indices [lo_g, hi_g) and seeds env i of
 the whole batch with `seed + i` exactly like a single-process batch would (`gymnasium.vector.VectorEnv.reset(seed=int)`
-semantics), which makes every result independent of the number of ranks.  The only exchange is optional and is exactly
-ONE collective per step: an all-gather of the step RECORD when one consumer needs the whole batch on every rank.  The
-step kernel writes a step's outputs as one contiguous record {image | reward f64 | terminated | truncated | direction |
-mission id | action} (mg_outputs in include/minigrid_hip.h), so the record is gathered zero-copy with a single
-`all_gather_into_tensor` (RCCL over xGMI under `torch.distributed` backend "nccl"; the same code runs on the "gloo"
-backend with CPU tensors in the test-suite) and the per-field tensors are views into the gathered buffer.
+semantics), which makes every result independent of the number of ranks.  The only exchange is optional: an all-gather of the
+step's outputs when one consumer needs the whole batch on every rank.  The step kernel writes a step's outputs as one
+contiguous record {image (n, ...) | (n) x mg_step_scalars 16 B [| sentence (n, 2) u64]} (mg_outputs in include/minigrid_hip.h).
+Per step the record's PARTS are gathered field-major -- one `all_gather_into_tensor` for the images, one for the 16-byte scalar
+entries (one more for the sentence levels' mission words), each straight out of the record (zero-copy send) into a persistent
+(world x per-rank) buffer -- so that the GLOBAL per-field tensors are views of the gathered buffers: the image is the image
+buffer itself, reward / terminated / ... are strided views of the scalar buffer; nothing is re-assembled by a second pass
+(round 5 gathered whole records, [rank][image | scalars], and concatenated every field again: 255 MB per step for
+LavaCrossing FullyObs x 1 048 576 on 8 GPUs).  RCCL over xGMI under `torch.distributed` backend "nccl"; the same code runs on
+the "gloo" backend with CPU tensors in the test-suite.  Ragged batches (N % world != 0): the short ranks send from a
+persistent padded buffer (allocated once) and the global tensors are compacted (the only case with a copy).
 
 Stream ordering, no host synchronisation: with `output="torch"` the shard's HIP stream is created BLOCKING when torch's
 current stream is the legacy NULL stream (vector_env.py), i.e. NULL-stream work -- which is what RCCL's launch is ordered
@@ -123,7 +128,10 @@ class ShardedVecEnv:
         self._zero_copy = hasattr(self.local, "torch_outputs") and getattr(self.local, "output", "") == "torch"
         self._image_shape = None
         self._image_dtype = None
-        self.collectives = 0               # all-gathers issued so far (tests: exactly one per step / reset)
+        self.collectives = 0               # gathers issued so far: one per step / reset / fused launch (tests count them)
+        self.collective_calls = 0          # all_gather_into_tensor calls behind them (a step's gather = one per record part)
+        self._equal = self.num_envs % self.world_size == 0
+        self._gparts = {}                  # persistent buffers of the per-step gather: part -> (receive buffer, padded send buffer or None)
 
     # ---- the one collective on the path -------------------------------------------------------------------
     def all_gather(self, x):
@@ -134,8 +142,9 @@ class ShardedVecEnv:
         if self.world_size == 1:
             return x
         self.collectives += 1
+        self.collective_calls += 1
         tail = tuple(x.shape[1:])
-        if self.num_envs % self.world_size == 0:
+        if self._equal:
             out = torch.empty((self.num_envs,) + tail, dtype=x.dtype, device=x.device)
             self._dist.all_gather_into_tensor(out, x, group=self.group)
             return out
@@ -143,10 +152,18 @@ class ShardedVecEnv:
         pad[: x.shape[0]] = x
         out = torch.empty((self.world_size * self._max_local,) + tail, dtype=x.dtype, device=x.device)
         self._dist.all_gather_into_tensor(out, pad, group=self.group)
+        return self._compact(out)
+
+    def _compact(self, t):
+        """(world * per_rank, ...) rows as gathered -> the (num_envs, ...) global tensor: the tensor itself for equal shards (a view of the
+        gather buffer), the ranks' valid rows concatenated for a ragged batch."""
+        import torch
+        if self._equal:
+            return t
         parts = []
         for r in range(self.world_size):
             lo, hi = shard_range(self.num_envs, r, self.world_size)
-            parts.append(out[r * self._max_local: r * self._max_local + (hi - lo)])
+            parts.append(t[r * self._max_local: r * self._max_local + (hi - lo)])
         return torch.cat(parts, 0)
 
     def _local_record(self, obs, rew, term, trunc):
@@ -189,60 +206,75 @@ class ShardedVecEnv:
         return rec, obs_bytes
 
     def gather_record(self, rec=None, obs_bytes=None):
-        """The collective itself: this rank's record -> (world_size, record_bytes) u8 on every rank."""
+        """The exchange of one step: this rank's record, part by part, into persistent FIELD-MAJOR buffers on every rank --
+        {"image": (world * per_rank, obs_bytes) u8, "scalars": (world * per_rank, 16) u8 [, "sentence": (world * per_rank, 16) u8]},
+        per_rank = the largest shard.  One all_gather_into_tensor per part, sent straight out of the record (a short rank of a ragged
+        batch sends from its persistent padded buffer).  The buffers are reused by the next step's gather."""
         import torch
         if rec is None:
             rec = self.local.torch_outputs()["record"]
             obs_bytes = int(np.prod(self.local.image_shape))
-        W = self.world_size
-        max_bytes = record_layout(self._max_local, obs_bytes, self._sentence)["record_bytes"]
-        if W == 1:
-            return rec.reshape(1, -1)
-        self.collectives += 1
-        if rec.numel() != max_bytes:                        # ragged shard: pad to the largest record
-            pad = torch.zeros(max_bytes, dtype=torch.uint8, device=rec.device)
-            pad[: rec.numel()] = rec
-            rec = pad
-        if getattr(self, "_gbuf", None) is None or self._gbuf.shape != (W, max_bytes) or self._gbuf.device != rec.device:
-            self._gbuf = torch.empty((W, max_bytes), dtype=torch.uint8, device=rec.device)
-        self._dist.all_gather_into_tensor(self._gbuf.reshape(-1), rec.contiguous(), group=self.group)
-        return self._gbuf
+        W, n, per = self.world_size, self.local_num_envs, self._max_local
+        lay = record_layout(n, obs_bytes, self._sentence)
+        parts = [("image", lay["image"], obs_bytes), ("scalars", lay["reward"], SCALAR_STRIDE)]
+        if self._sentence:
+            parts.append(("sentence", lay["sentence"], 16))
+        out = {}
+        if W > 1:
+            self.collectives += 1
+        for name, off, row in parts:
+            send = rec[off: off + n * row].reshape(n, row)
+            if W == 1:
+                out[name] = send
+                continue
+            bufs = self._gparts.get(name)
+            if bufs is None or bufs[0].shape != (W * per, row) or bufs[0].device != rec.device:
+                recv = torch.empty((W * per, row), dtype=torch.uint8, device=rec.device)
+                pad = torch.zeros((per, row), dtype=torch.uint8, device=rec.device) if n != per else None     # allocated ONCE
+                bufs = self._gparts[name] = (recv, pad)
+            recv, pad = bufs
+            if pad is not None:
+                pad[:n].copy_(send)
+                send = pad
+            self.collective_calls += 1
+            self._dist.all_gather_into_tensor(recv.reshape(-1), send.reshape(-1), group=self.group)
+            out[name] = recv
+        return out
+
+    @staticmethod
+    def _scalar_view(area, name):
+        """Strided view of field `name` of an (rows, 16) u8 array of mg_step_scalars entries."""
+        import torch
+        if name == "reward":
+            return area.view(torch.float64)[:, 0]
+        if name == "mission_id":
+            return area.view(torch.int16)[:, 6]
+        return area[:, _SCALAR_FIELD[name]]
 
     def _gather_step(self, obs, rew, term, trunc):
-        """ONE all_gather_into_tensor of the step record; the global per-field tensors are views of its result."""
+        """The step's gather (gather_record); the global per-field tensors are VIEWS of the gathered buffers (equal shards)."""
         import torch
         rec, obs_bytes = self._local_record(obs, rew, term, trunc)
-        W = self.world_size
-        buf = self.gather_record(rec, obs_bytes)
+        g = self.gather_record(rec, obs_bytes)
+        rows = self.num_envs if self._equal else g["image"].shape[0]
 
-        def field(name, dtype, tail=()):
-            parts = []
-            esz = torch.empty(0, dtype=dtype).element_size() * int(np.prod(tail)) if tail else torch.empty(0, dtype=dtype).element_size()
-            for r in range(W):
-                lo, hi = shard_range(self.num_envs, r, W)
-                n = hi - lo
-                lay = record_layout(n, obs_bytes, self._sentence)
-                if name in _SCALAR_FIELD:
-                    parts.append(scalar_field(buf[r], name, n, lay))           # strided view into the gathered record
-                else:
-                    raw = buf[r, lay[name]: lay[name] + n * esz]
-                    parts.append(raw.view(dtype).reshape((n,) + tuple(tail)))
-            return parts[0] if W == 1 else torch.cat(parts, 0)
-        image = field("image", self._image_dtype, self._image_shape)
-        rew_g = field("reward", torch.float64)
-        term_g = field("terminated", torch.uint8).bool()
-        trunc_g = field("truncated", torch.uint8).bool()
+        def scal(name):
+            return self._compact(self._scalar_view(g["scalars"], name))
+        image = self._compact(g["image"].view(self._image_dtype).reshape((rows,) + tuple(self._image_shape)))
+        rew_g = scal("reward")
+        term_g = scal("terminated").bool()
+        trunc_g = scal("truncated").bool()
         if isinstance(obs, dict) and self._sentence:
-            words = field("sentence", torch.int64, (2,))
-            out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}
+            words = self._compact(g["sentence"].view(torch.int64))
+            out = {"image": image, "direction": scal("direction").to(torch.int64)}
             if "mission_id" in obs:          # device outputs: the words stay a tensor (minigrid_amd.sentence.decode turns a row into text)
                 out["sentence"] = words
             else:
                 out["mission"] = self._decode_sentences(words.cpu().numpy().view(np.uint64))
             return out, rew_g, term_g, trunc_g
         if isinstance(obs, dict):
-            ids = field("mission_id", torch.int16)
-            out = {"image": image, "direction": field("direction", torch.uint8).to(torch.int64)}
+            ids = scal("mission_id")
+            out = {"image": image, "direction": scal("direction").to(torch.int64)}
             if "mission_id" in obs:
                 out["mission_id"] = ids
             else:
@@ -317,15 +349,18 @@ class ShardedVecEnv:
             view = loc.block_view(lo, T)                               # (T, this shard's slot bytes) u8
             with (torch.cuda.stream(self._comm_stream) if self._comm_stream is not None else self._on_step_stream()):
                 if W > 1 and view.shape[1] != rec_bytes:                # ragged shard: pad the records to the largest shard's
-                    pad = torch.zeros((T, rec_bytes), dtype=torch.uint8, device=view.device)
-                    pad[:, : view.shape[1]] = view
-                    view = pad
+                    pad = st.get("pad")                                # (one persistent buffer per block, allocated once: the collective of block b reads it
+                    if pad is None:                                    #  while block 1 - b is being stepped into)
+                        pad = st["pad"] = [torch.zeros((F, rec_bytes), dtype=torch.uint8, device=view.device) for _ in range(2)]
+                    pad[b][:T, : view.shape[1]].copy_(view)
+                    view = pad[b][:T]
                 g = st["gbuf"][b]
                 if g is None or g.shape != (W, F, view.shape[1]) or g.device != view.device:
                     g = st["gbuf"][b] = torch.empty((W, F, view.shape[1]), dtype=torch.uint8, device=view.device)
                 out = g if T == F else torch.empty((W, T, view.shape[1]), dtype=torch.uint8, device=view.device)
                 if W > 1:
                     self.collectives += 1
+                    self.collective_calls += 1
                     self._dist.all_gather_into_tensor(out.reshape(-1), view.reshape(-1), group=self.group)
                 else:
                     out = view.reshape(1, T, -1)
@@ -347,11 +382,33 @@ class ShardedVecEnv:
             self._comm_stream.synchronize()
             self._step_stream.synchronize()
 
-    def unpack_block(self, block, j: int) -> dict:
+    def unpack_block(self, block, j: int, stacked: bool = False) -> dict:
         """Per-field GLOBAL tensors of step record j of a gathered block ((world, T, bytes) uint8; record j = the launch's step
-        T - 1 - j, like trajectory slots): image, reward, terminated, truncated, direction, mission_id, action."""
+        T - 1 - j, like trajectory slots): image, reward, terminated, truncated, direction, mission_id, action.
+        A block is gathered record-major ([rank][step][image | scalars]: the launch's records ARE the send buffer), so a flat (num_envs, ...)
+        tensor of one field is a concatenation over the ranks (a copy).  stacked=True returns zero-copy strided VIEWS of the block instead,
+        shaped (world, per_rank, ...): env i of the batch is [i // per_rank, i % per_rank] (equal shards; for a ragged batch the
+        rows of a short rank beyond its envs are padding)."""
         import torch
         loc = self.local
+        if stacked:
+            if not self._equal:
+                raise ValueError("unpack_block(stacked=True) needs equal shards (num_envs % world_size == 0): a short rank's records keep their own layout")
+            obs_bytes = int(np.prod(loc.image_shape))
+            per = self._max_local
+            lay = record_layout(per, obs_bytes, self._sentence)       # (the block's records are padded to the largest shard's layout)
+            img_dtype = torch.int8 if getattr(loc, "obs_mode", "") == "symbolic" else torch.uint8
+            recs = block[:, j]                                          # (world, record bytes), rows F * record bytes apart
+            area = recs[:, lay["reward"]: lay["reward"] + per * SCALAR_STRIDE].unflatten(1, (per, SCALAR_STRIDE))
+            out = {"image": recs[:, : per * obs_bytes].view(img_dtype).unflatten(1, (per,) + tuple(loc.image_shape))}
+            for name in _SCALAR_FIELD:
+                if name == "reward":
+                    out[name] = area.view(torch.float64)[..., 0]
+                elif name == "mission_id":
+                    out[name] = area.view(torch.int16)[..., 6]
+                else:
+                    out[name] = area[..., _SCALAR_FIELD[name]]
+            return out
         obs_bytes = int(np.prod(loc.image_shape))
         img_dtype = torch.int8 if getattr(loc, "obs_mode", "") == "symbolic" else torch.uint8
         fields = {"image": (img_dtype, tuple(loc.image_shape)), "reward": (torch.float64, ()), "terminated": (torch.uint8, ()),
