@@ -314,6 +314,12 @@ MG_API int mg_timer_stop(mg_env* env, float* elapsed_ms);   /* synchronises on t
  * (summed on the host from per-workgroup slots; synchronises the stream) */
 MG_API int mg_get_counters(mg_env* env, uint64_t out[4]);
 
+/* the EFFECTIVE depth R of the spare-episode ring (pre-generated next episodes per env): mg_config.spare_ring when given, else the level's default,
+ * halved while the ring would exceed min(32 GB, a quarter of the device memory free at mg_create) -- so identical configs can differ from run to
+ * run; a seeded mg_reset issues R + 1 generator launches.  1 for levels whose reset draws nothing; 0 = no ring (DynamicObstacles redraws in place).
+ * (No reference counterpart: gymnasium resets draw inside reset(), minigrid_env.py:119-157.) */
+MG_API int mg_ring_depth(mg_env* env);
+
 MG_API const char* mg_last_error(mg_env* env);   /* env may be NULL for creation errors */
 MG_API int mg_abi_version(void);
 /* compile-time switches of this build as "key=value;..." ("attribution=0" in the product library: the MG_EXP step-skipping aid of

@@ -42,7 +42,7 @@ _lib = None
 SYMBOLS = ["mg_create", "mg_destroy", "mg_set_obs_config", "mg_reset", "mg_step", "mg_rollout", "mg_rollout_block", "mg_step_many", "mg_get_outputs", "mg_copy_outputs",
            "mg_copy_slot", "mg_copy_sentence", "mg_selftest_stream",
            "mg_sync", "mg_get_state", "mg_set_state", "mg_state_size", "mg_save_state", "mg_load_state", "mg_get_rng", "mg_set_rng", "mg_timer_start", "mg_timer_stop",
-           "mg_get_counters", "mg_last_error", "mg_abi_version", "mg_build_info", "mg_device_count", "mg_selftest_vis_row",
+           "mg_get_counters", "mg_ring_depth", "mg_last_error", "mg_abi_version", "mg_build_info", "mg_device_count", "mg_selftest_vis_row",
            "mg_selftest_reward_lut", "mg_selftest_pack_cell", "mg_selftest_vis_row_n", "mg_render_tiles",
            "mg_selftest_obs7", "mg_selftest_vis_row_carry", "mg_selftest_prims", "mg_selftest_dynobs", "mg_selftest_verify", "mg_selftest_transition", "mg_selftest_generate", "mg_selftest_obs_full"]
 
@@ -92,6 +92,7 @@ def load():
     L.mg_timer_start.argtypes = [vp]
     L.mg_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.mg_get_counters.argtypes = [vp, vp]
+    L.mg_ring_depth.argtypes = [vp]
     L.mg_last_error.argtypes = [vp]
     L.mg_last_error.restype = C.c_char_p
     L.mg_build_info.argtypes = []

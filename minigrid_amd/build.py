@@ -29,7 +29,7 @@ _STEP = _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_s
 _GEN = _COMMON + ["mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
 # translation unit -> the headers it is built from (its own file included)
 UNITS = {
-    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", ABI_HEADER],
+    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", "mg_genlane.h", "mg_knobs.h", ABI_HEADER],
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
     "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP,
 }
@@ -99,6 +99,10 @@ def build(force: bool = False, verbose: bool = False, missing_hipcc_ok: bool = F
 
 
 def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link, tag, arch, flag_units=None) -> str:
+    # the hash the finished library is stamped with is taken BEFORE anything is compiled: if a source changes while the objects are being built (an
+    # editor, or a second process that found the tree stale), the stamp describes the older state and the next build() sees a stale library -- stamping
+    # with the hash at the END once marked a library "fresh" whose mg_api.o predated an edit (round 6: every GPU test of a call failed at load)
+    stamp_hash = _source_hash() if lib == LIB else None
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if missing_hipcc_ok and os.path.exists(lib):
@@ -143,7 +147,7 @@ def _build_locked(force, verbose, missing_hipcc_ok, lib, extra_flags, extra_link
     subprocess.check_call(cmd)
     if lib == LIB:
         with open(STAMP, "w") as f:
-            f.write(_source_hash())
+            f.write(stamp_hash)
     return lib
 
 

@@ -23,6 +23,7 @@
 #include "mg_roll.h"
 #include "mg_launch.h"
 #include "mg_genlane.h"
+#include "mg_knobs.h"
 
 using namespace mg;
 
@@ -119,6 +120,9 @@ struct mg_env {
   uint32_t* err = nullptr;
   unsigned long long* counters = nullptr;
   size_t ncounters = 0;
+  Knobs k;                                       // the environment's A/B switches and debugging aids, read once at mg_create (mg_knobs.h)
+  bool staged_big = false;                       // k_roll7's STAGED instantiation: big grids, one copy of the grids per workgroup
+  bool mask_sparse = false;                      // the reset in progress is masked and resets fewer than an eighth of the envs
   uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
   unsigned long long burst_bytes = 0;   // output bytes of the launches enqueued since the step stream was last known idle (launch_step: nontemporal stores)
   uint64_t stat_base[3] = { 0, 0, 0 };   // episodes / maps / retries counted before the last mg_set_obs_config (its statistics slots are re-made)
@@ -191,7 +195,8 @@ static GenArgs gen_args(mg_env* e, int slot) {
   A.mask = nullptr;
   A.err = e->err; A.counters = e->counters;
   A.N = e->N; A.CS = e->CS; A.stat_gen_off = STAT_EPISODES + e->nwaves;
-  A.cap_words = e->sentence ? 4864 : 2048;   // LevelGen: up to 100 tries per description (levelgen.py:113-155); 38 PCG refills (GEN_SBASE_ENTRIES)
+  // (round 6: 1024 like the refill's -- the 8 KB buffer of 2048 words held k_generate at four waves per SIMD: LDS, not registers, bounded its occupancy)
+  A.cap_words = e->sentence ? 4864 : 1024;   // LevelGen: up to 100 tries per description (levelgen.py:113-155); 38 PCG refills (GEN_SBASE_ENTRIES)
   A.live = 0;
   // LevelGen, num_crossings bit 10: an episode whose drawing met RoomGrid.place_agent's endless loop is redrawn and accepted
   A.stuck_mode = (e->cfg.env_kind == MG_ENV_LEVELGEN && ((e->cfg.num_crossings >> 10) & 1)) ? 2 : (to_spare ? 0 : 1);
@@ -212,7 +217,9 @@ static int launch_generate(mg_env* e, int slot, const uint8_t* d_mask, hipStream
   // one translation unit per generator group (mg_gen.h): a level's generator kernel carries only its group's generators
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
-  if (e->lane_direct) {             // one lane per env (mg_genlane.h)
+  // (a SPARSE masked reset of a level whose refill stays on cooperative wavefronts -- the mazes, MultiRoom, the sentence levels -- keeps k_generate: a lane
+  // wave with one or two busy lanes is a very slow scalar core, ~5 ms per call against ~0.8; a seeded reset issues R + 1 such launches.  ADVICE r5)
+  if (e->lane_direct && !(d_mask && e->mask_sparse && !e->lane_gen)) {             // one lane per env (mg_genlane.h)
     if (!launch_generate_lane(philox, dim3((e->N + 63) / 64), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A))
       return fail(e, MG_ERR_INVALID, "internal: no lane generator kernel for env_kind %d", e->cfg.env_kind);
   }
@@ -239,7 +246,6 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   // KeyCorridorS3R3 (7 x 7 cells, short episodes: it needs the generator's throughput) 47.6 with 16, 52.5 with 4 -- hence by grid size.
   if (e->sentence) A.wps = 2;
   else if (e->cells > 256) A.wps = 4;
-  if (const char* s = getenv("MG_REFILL_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
   const size_t lds = (size_t)gen_wave_lds_bytes(e->CS, A.cap_words, e->sentence);
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
@@ -254,7 +260,6 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
       ok = launch_refill_lane_packed(philox, dim3(blocks), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
     } else {
       A.wps = 2;
-      if (const char* s = getenv("MG_LANE_WPS")) { int v = atoi(s); if (v >= 1 && v <= 64) A.wps = v; }
       ok = launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
     }
     if (!ok) return fail(e, MG_ERR_INVALID, "internal: no lane refill kernel for env_kind %d (packed %d)", e->cfg.env_kind, (int)e->lane_packed);
@@ -334,15 +339,14 @@ static int flush_refills(mg_env* e) {
 // code stagings between the dynamics wave and the encode waves of the DynamicObstacles / sentence-level split (mg_roll.h): four, or two where the
 // 22 x 22 grids of the sentence levels leave no more (38.75 KB per workgroup = four workgroups per CU)
 static int roll_dring(const mg_env* e) {
-  static const int forced = [] { const char* s = getenv("MG_DRING"); const int v = s ? atoi(s) : 0; return (v == 2 || v == 4) ? v : 0; }();
-  return forced ? forced : (e->sentence || e->fast_full) ? 2 : ROLL_DSPLIT_RING;
+  return e->k.dring ? e->k.dring : (e->sentence || e->fast_full || e->staged_big) ? 2 : ROLL_DSPLIT_RING;
 }
 struct RollLayout { int off_grid, off_codes, codes_stride, off_shadow, shadow_stride, off_shadow_gt, off_spr, off_act, off_log, off_tmpl, off_instr, total; };
 // split: wave 0 = the dynamics wave (no code staging of its own), + the step log ring (mg_roll.h)
 static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool split = false) {
   RollLayout L;
   // (DynamicObstacles in the loop, split: ONE copy of the grids -- the dynamics wave's, which stages the codes itself -- and a ring of stagings)
-  const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full);
+  const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full || e->staged_big);
   L.off_grid = 1024 + e->roll_guard;
   L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * 64 * e->GS + e->roll_guard + 15) & ~15;
   const int ncodes = dsplit ? roll_dring(e) + (e->fast_full ? 1 : 0) : split ? nw - 1 : nw;   // (FullyObs: the dynamics wave's own image-order stream + the ring of staged copies)
@@ -367,7 +371,7 @@ static int roll_lds_bytes(const mg_env* e, int nw, bool with_actions, bool split
 // (one encode wave would carry every observation alone); FullyObs and the sentence levels keep their round-3 shapes.  MG_ROLL_SPLIT=0: A/B.
 static bool roll_split_ok(const mg_env* e, int nw) {
   if (e->fast_full) return e->roll_split_on && e->full_split && nw >= 2;
-  return e->roll_split_on && e->fast7 && nw >= ((e->dyn_inloop || e->sentence) ? 2 : 3);
+  return e->roll_split_on && e->fast7 && nw >= ((e->dyn_inloop || e->sentence || e->staged_big) ? 2 : 3);
 }
 
 static void fill_step_params(mg_env* e, StepParams& P, int phase) {
@@ -378,7 +382,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.seg = e->static_gen ? nullptr : e->seg + (size_t)set * e->nwaves * e->seg_cap;
   P.seg_count = e->static_gen ? nullptr : e->seg_count + (size_t)set * e->nwaves;
   P.seg_cap = e->seg_cap;
-  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0; P.act_stage = 0;
+  P.actions = e->actions; P.act_dtype = MG_ACT_U8; P.act_src = ACT_SRC_BUFFER; P.action_seed = 0; P.t0 = 0; P.staged = 0;
   P.obs_mask = nullptr;
   P.instr = e->instr; P.spare_instr = e->spare_instr; P.off_sentence = e->off_sentence;
   P.out = e->out; P.slot_bytes = e->slot_bytes;
@@ -412,7 +416,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
   P.cpe_magic = ((1u << 20) + cpe - 1) / cpe;
   P.env_base = e->cfg.env_index_base;
 #if defined(MG_ATTRIBUTION)
-  { static const int exp = [] { const char* s = getenv("MG_EXP"); return s ? atoi(s) : 0; }(); P.exp = exp; }   // attribution builds only (mg_roll.h MG_EXPBIT)
+  P.exp = e->k.exp;   // attribution builds only (mg_roll.h MG_EXPBIT)
 #else
   P.exp = 0;
 #endif
@@ -423,30 +427,19 @@ static int launch_step(mg_env* e, StepParams& P) {
   if (e->live_gen) {
     // (1) draw, in place, the episodes of the envs the previous launch left RESET_PENDING (they come out FRESH and
     //     are only observed by this launch); (2) before a real step, move the obstacles of everyone else
-    // (1) and (2) touch disjoint envs -- (1) the ones flagged RESET_PENDING, (2) everyone else (an env whose flag turns FRESH under (2)'s
-    // eyes is skipped either way; (2) writes back only the grids it moved) -- so before a real step they CAN run side by side: the redraw
-    // on the generator stream, the moves on the step stream, the step launch behind both (MG_LIVE_OVERLAP=1).  Measured
-    // (profiles/r3/dynobs_overlap.txt, 16x16 x 65 536): 72.5 us per step side by side, 71.5 one after the other -- both kernels are
-    // bound by the SIMDs' issue rate, not by latency, so sharing the machine buys nothing.  Off by default.
-    static const bool overlap_ok = [] { const char* s = getenv("MG_LIVE_OVERLAP"); return s && atoi(s) != 0; }();
-    bool live_on_gen = false;
+    // (running (1) on the generator stream beside (2) was measured in round 3 -- profiles/r3/dynobs_overlap.txt, 16x16 x 65 536: 72.5 us per step side by
+    // side, 71.5 one after the other: both kernels are bound by the SIMDs' issue rate -- and the switch was deleted in round 6: one stream)
     // DynamicObstacles in the loop: a STEP launch redraws the envs waiting for their autoreset itself, at its first step (mg_dynobs.h), and
     // REPLACES the request list with the envs its last step left waiting (P.live_gen = 2) -- no redraw launch, no counter reset between step
     // launches; an OBSERVE launch (reset) still finds exactly the waiting envs listed
     const bool inloop_step = e->dyn_inloop && P.phase == PHASE_STEP;
     if (inloop_step) P.live_gen = 2;
     if (e->launches > 0 && !inloop_step) {
-      live_on_gen = overlap_ok && P.phase == PHASE_STEP;
-      if (live_on_gen) {
-        HIP_TRY(e, hipEventRecord(e->ev_step[0], e->stream));
-        HIP_TRY(e, hipStreamWaitEvent(e->gen_stream, e->ev_step[0], 0));
-      }
-      int rc = launch_refill(e, 0, e->launches + 1u, true, live_on_gen ? e->gen_stream : e->stream);
+      int rc = launch_refill(e, 0, e->launches + 1u, true, e->stream);
       if (rc) return rc;
-      if (live_on_gen) HIP_TRY(e, hipEventRecord(e->ev_gen[0], e->gen_stream));
     }
     if (P.phase == PHASE_STEP && !e->dyn_inloop) {       // (in the loop: k_roll7<GG_DYNOBS> moves the obstacles itself)
-      static const int epb = [] { const char* s = getenv("MG_MOVE_EPB"); const int v = s ? atoi(s) : 0; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : MOVE_EPB; }();
+      const int epb = MOVE_EPB;
       const int nb = (e->N + epb - 1) / epb;
       const size_t mlds = (size_t)epb * (size_t)(e->CS + 4);          // the wave's staged grids (DynamicObstacles: at most 16 x 16)
       if (e->cfg.rng_mode == MG_RNG_PHILOX)
@@ -457,7 +450,6 @@ static int launch_step(mg_env* e, StepParams& P) {
                            e->N, e->W, e->H, e->CS, e->cfg.num_dists, epb);
       HIP_TRY(e, hipGetLastError());
     }
-    if (live_on_gen) HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gen[0], 0));
   }
   { int rc = batch_admit(e, P.phase, P.T); if (rc) return rc; }
   {
@@ -478,18 +470,17 @@ static int launch_step(mg_env* e, StepParams& P) {
     // equalises the waves' work for a silent step costing `ratio` of a full one (x_{w+1} = x_w (1 - ratio) + x_1)
     int nw = std::min(e->roll_nw, std::max(1, P.T));
     const bool in_loop_verify = e->sentence && e->fast7;       // k_roll7<GG_SENTENCE>: one wave per workgroup (the record is shared state)
-    // (the split of the sentence levels: the stepping / verifying wave + ONE encode wave over one copy of the grids, mg_roll.h; MG_SENT_SPLIT=0: one wave)
-    static const bool sent_split = [] { const char* s = getenv("MG_SENT_SPLIT"); return !s || atoi(s) != 0; }();
-    if (in_loop_verify) nw = (sent_split && P.T > 1 && roll_split_ok(e, 2)) ? 2 : 1;
+    // (the split of the sentence levels: the stepping / verifying wave + ONE encode wave over one copy of the grids, mg_roll.h)
+    if (in_loop_verify) nw = (P.T > 1 && roll_split_ok(e, 2)) ? 2 : 1;
     // one-step launches (Env.step): four waves share the encode of the one step (k_roll7 `share`); one private grid copy
-    // MG_ROLL_SHARE: 0 = off, 1..15 = the stepping wave is (workgroup >> (value - 1)) & 3, 16 = always wave 0
-    static const int share_mode = [] { const char* s = getenv("MG_ROLL_SHARE"); const int v = s ? atoi(s) : 16; return v < 0 || v > 16 ? 16 : v; }();
-    const bool share_ok = share_mode != 0;
+    // (P.share: 1..15 = the stepping wave is (workgroup >> (value - 1)) & 3, 16 = always wave 0 -- what was measured best, profiles/r3/unfused_share.txt)
+    const int share_mode = 16;
+    const bool share_ok = true;
     // (only while the batch leaves wave slots free: at 4 096 workgroups the three waiting waves per workgroup cost more than the shared
     // encode saves -- Empty-8x8 x 65 536: 9.4 us per step against 10.1; DoorKey-8x8 x 262 144: 33.0 against 23.8, profiles/r3/unfused_share.txt)
     const bool share = P.T == 1 && share_ok && P.phase == PHASE_STEP && e->nwaves <= 2048;
     P.share = share ? share_mode : 0;
-    static const double ratio = [] { const char* s = getenv("MG_ROLL_RATIO"); const double v = s ? atof(s) : 0.0; return v > 0.0 && v < 1.0 ? v : 0.12; }();
+    const double ratio = 0.12;                                 // (a silent replayed step costs ~0.12 of a produced one: profiles/r3/sweep_nw_ratio_quads.txt)
     double geo = 0.0, pw = 1.0;
     for (int w = 0; w < nw; w++) { geo += pw; pw *= 1.0 - ratio; }
     const double x1 = (double)P.T / geo;
@@ -498,26 +489,23 @@ static int launch_step(mg_env* e, StepParams& P) {
     for (int w = 1; w < nw; w++) { x = x * (1.0 - ratio) + x1; P.split[w] = std::min(P.T - (nw - w), std::max(P.split[w - 1] + 1, (int)std::lround(x))); }
     for (int w = nw; w <= ROLL_MAX_WAVES; w++) P.split[w] = P.T;
     const bool split = !share && P.T > 1 && roll_split_ok(e, nw);
-    // the device policy's actions staged in LDS by the whole workgroup instead of drawn by the dynamics wave inside the loop (mg_roll.h): the LOG split
-    // of the 7x7 view (one dynamics wave + encode waves over private grids) -- the staged split's workgroups (DynamicObstacles, the sentence levels,
-    // FullyObs) sit at an LDS size where 2 KB more would cost a resident workgroup per CU.  MG_ACT_STAGE=0: A/B.
-    static const bool act_stage_on = [] { const char* s = getenv("MG_ACT_STAGE"); return !s || atoi(s) != 0; }();
-    const bool dsplit_cfg = e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full;
-    P.act_stage = (act_stage_on && split && !dsplit_cfg && P.act_src == ACT_SRC_PHILOX && P.phase == PHASE_STEP) ? 1 : 0;
-    const bool acts = (P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP) || P.act_stage;
+    const bool dsplit_cfg = e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full || e->staged_big;
+    P.staged = (split && e->staged_big) ? 1 : 0;
+    (void)dsplit_cfg;
+    const bool acts = P.act_src == ACT_SRC_BUFFER && P.phase == PHASE_STEP;
     const RollLayout L = roll_layout(e, nw, acts, split);
-    // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw.  MG_ROLL_DROT: 0 = always wave 0, k = shift k - 1
-    static const int drot = [] { const char* s = getenv("MG_ROLL_DROT"); const int v = s ? atoi(s) : 9; return v < 0 || v > 20 ? 9 : v; }();
+    // split_mode - 1 = the shift that picks the dynamics wave: wave (workgroup >> shift) % nw (9 = shift 8: profiles/r4/split_rotation.txt; 31 = always wave 0)
+    const int drot = 9;
     // (DynamicObstacles in the loop: always wave 0 -- three waves per workgroup rotate over a CU's four SIMDs by themselves; 12.5 us per step against
     // 15.3 with the rotation, profiles/r4/dynobs_waves_sweep2.txt)
-    P.split_mode = split ? ((drot == 0 || ((e->dyn_inloop || e->sentence || e->fast_full) && !getenv("MG_ROLL_DROT"))) ? 31 : drot) : 0; P.dring = roll_dring(e); P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
+    P.split_mode = split ? ((e->dyn_inloop || e->sentence || e->fast_full || e->staged_big) ? 31 : drot) : 0; P.dring = roll_dring(e); P.off_log = L.off_log; P.off_tmpl = L.off_tmpl; P.off_instr = L.off_instr;
     {
       // Nontemporal observation stores once the launches enqueued since the stream was last known idle have written more than the write-back
       // caches hold (256 MB of Infinity Cache): a long rollout streams to HBM and leaves L2 to the grids and spare episodes it re-reads
       // (DoorKey-8x8 x 262 144: 10.9 -> 8.8 us per step); a short burst, or a one-step launch whose observation the consumer reads next, is
       // better off absorbed by the caches (one 20-step launch: 2.15 us per step plain, 2.39 nontemporal).  MG_NT_BYTES: the threshold in MB
       // (0 = always nontemporal, negative = never).
-      static const long long nt_mb = [] { const char* s = getenv("MG_NT_BYTES"); return s ? atoll(s) : 256ll; }();
+      const long long nt_mb = e->k.nt_mb;
       const unsigned long long wr = (unsigned long long)e->N * (unsigned long long)P.T * (unsigned long long)(e->obs_bytes + 16);
       e->burst_bytes += wr;
       P.nt = (nt_mb >= 0 && P.T > 1 && e->burst_bytes > (unsigned long long)nt_mb * 1000000ull) ? 1 : 0;
@@ -574,6 +562,10 @@ static int check_device_errors(mg_env* e) {
   HIP_TRY(e, wait_stream(e->stream));
   e->burst_bytes = 0;                                      // the step stream is idle
   for (int k = 0; k < 4; k++) if (e->err_host[k]) { bits |= 1u << k; e->err_host[k] = 0u; }
+  if (e->err_host[ERR_WORD_SPIN]) {                        // (-DMG_SPIN_BOUND builds: a protocol regression shows up as an error, not as a hung GPU)
+    e->err_host[ERR_WORD_SPIN] = 0u;
+    return fail(e, MG_ERR_HIP, "k_roll7: an inter-wave spin loop ran past MG_SPIN_BOUND polls (the LDS protocol between the dynamics and the encode waves is broken)");
+  }
   if (!bits) return MG_OK;
   if (bits & ERR_BAD_ACTION) return fail(e, MG_ERR_BAD_ACTION, "Unknown action: value outside 0..6 (minigrid_env.py:584-585)");
   if (bits & ERR_OOB) return fail(e, MG_ERR_OOB, "front cell outside the grid (core/grid.py:74-78 assert)");
@@ -586,7 +578,7 @@ static int check_device_errors(mg_env* e) {
 // with a pattern; mg_sync and mg_destroy verify that no kernel wrote into one and name the buffer otherwise.
 constexpr size_t GUARD_ZONE = 4096;
 constexpr uint8_t GUARD_BYTE = 0xC7;
-static bool guard_on() { static const bool on = [] { const char* s = getenv("MG_GUARD"); return s && atoi(s) == 1; }(); return on; }
+static bool guard_on() { static const bool on = Knobs::from_env().guard; return on; }
 static hipError_t env_alloc(mg_env* e, void** p, size_t bytes, const char* name) {
   const size_t z = guard_on() ? GUARD_ZONE : 0;
   void* base = nullptr;
@@ -661,7 +653,6 @@ static int setup_render(mg_env* e) {
   int epw = 16;                     // measured best on MI355X together with 8 (profiles/r1_final/render_sweep.txt); tuning aid: MG_RENDER_EPW
   auto lds_for = [&](int n) { return (STATIC_TILES + n) * R.tile_dw * 4 + ((n * R.cells * 2 + 15) & ~15); };
   while (epw > 8 && lds_for(epw) > 40 * 1024) epw >>= 1;
-  if (const char* s = getenv("MG_RENDER_EPW")) { int v = atoi(s); if (v >= 1 && v <= 64 && lds_for(v) <= 160 * 1024) epw = v; }
   R.epw = epw; R.ngroups = (e->N + epw - 1) / epw;
   R.off_map = (STATIC_TILES + epw) * R.tile_dw * 4;
   e->render_lds = lds_for(epw);
@@ -682,7 +673,6 @@ static int setup_render(mg_env* e) {
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
   const int per_cu = std::max(1, std::min(2048 / e->render_threads, (160 * 1024) / std::max(e->render_lds, 1)));
   e->render_blocks = std::min(R.ngroups, cus * per_cu);              // persistent: the atlas is staged once per workgroup
-  if (const char* s = getenv("MG_RENDER_BLOCKS")) { int v = atoi(s); if (v >= 1) e->render_blocks = std::min(v, R.ngroups); }
 
   // atlas: host-rendered [key][agent][hl] -> device [key][hl] (agent-free) followed by [key][dir][hl]
   const size_t tb = (size_t)ts * ts * 3;
@@ -731,7 +721,6 @@ static const char* configure_obs(mg_env* e) {
     // (the 7x7 view runs k_roll7: one lane per env, more wavefronts through its time split)
     e->fast7 = fast7;
     e->lpe = fullish ? 4 : 1;
-    if (const char* s = getenv("MG_LPE")) { if (atoi(s) == 1) e->lpe = 1; }
     e->epw = 64 / e->lpe;
   }
   e->nwaves = (e->N + e->epw - 1) / e->epw;
@@ -765,13 +754,11 @@ static const char* configure_obs(mg_env* e) {
   // BabyAI-GoTo x 131 072: 4.29 -> 6.03 G env-steps/s, MultiRoom-N6 x 65 536: 2.48 -> 3.93 (profiles/r6/ab_connect_all_shadows.txt); KeyCorridorS3R3 (small
   // grid) is indifferent (23.5 / 23.1).
   if (e->cells > 256) e->roll_shadows = 0;
-  if (const char* s = getenv("MG_ROLL_SHADOWS")) {
-    if (atoi(s) == 1) e->roll_shadows = 1;
-    if (atoi(s) == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
-    if (atoi(s) == 0 && !e->static_gen) e->roll_shadows = 0;          // no staging: every reset fetches its spare from the ring in HBM inside the loop
-  }
+  if (e->k.roll_shadows == 1) e->roll_shadows = 1;
+  if (e->k.roll_shadows == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
+  if (e->k.roll_shadows == 0 && !e->static_gen) e->roll_shadows = 0;    // no staging: every reset fetches its spare from the ring in HBM inside the loop
   e->fast_full = false;
-  if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341 && !getenv("MG_NO_ROLL_FULL")) {
+  if (e->cfg.obs_mode == MG_OBS_FULL && e->cells <= 341) {
     // FullyObs through k_roll7<., true>: the row-major grids + their image-order streams, private per wave, and the shadow pair.  Only
     // while one wave's worth fits comfortably (grids up to 16 x 16); larger grids keep k_step with four lanes per env.
     e->fast_full = true;
@@ -779,8 +766,8 @@ static const char* configure_obs(mg_env* e) {
     if (roll_lds_bytes(e, 1, true) > 72 * 1024) e->fast_full = false;
     else { e->lpe = 1; e->epw = 64; e->nwaves = (e->N + 63) / 64; }
   }
-  { const char* s = getenv("MG_ROLL_SPLIT"); e->roll_split_on = !s || atoi(s) != 0; }
-  { const char* s = getenv("MG_DYN_INLOOP"); e->dyn_inloop = e->live_gen && e->fast7 && !e->fast_full && (!s || atoi(s) != 0); }
+  e->roll_split_on = e->k.roll_split;
+  e->dyn_inloop = e->live_gen && e->fast7 && !e->fast_full && e->k.dyn_inloop != 0;
   if (e->fast7 || e->fast_full) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
     // as keep three workgroups on a CU (160 KB of LDS): 4 for the 8x8 and 9x9 levels, fewer for the big grids.
@@ -789,7 +776,7 @@ static const char* configure_obs(mg_env* e) {
     // 65 536: 2.64 us per step with 4, 2.71 with 3; DoorKey-8x8 x 262 144: 11.3 with 4, 11.8 with 3, 12.1 with 2).  (With the chunk
     // encode 3 waves won above 1 536 workgroups -- sweep_nw_ratio.txt -- : the own step was dearer, the fourth wave's replays bought less.)
     int nw = 4;
-    { const char* s = getenv("MG_FULL_SPLIT"); e->full_split = !s || atoi(s) != 0; }
+    e->full_split = true;
     // FullyObs: two waves -- the dynamics wave + ONE encode wave over staged copies of its image-order stream (round 4; LavaCrossing FullyObs x 131 072:
     // 7.63 us per step, 7.92 with two encode waves, 8.42 with the round-3 time split, whose second wave replayed the dynamics: profiles/r4/lava_split.txt)
     if (e->fast_full) nw = 2;
@@ -797,7 +784,11 @@ static const char* configure_obs(mg_env* e) {
     // DynamicObstacles in the loop: the dynamics wave + two encode waves over ONE copy of the grids (roll_layout; 31 KB at 16 x 16).  The level's
     // step is its placement loop, so the encode waves idle most of the time: three waves of ~150 VGPRs leave room for four workgroups per CU.
     if (e->dyn_inloop) nw = 3;
-    if (const char* s = getenv("MG_ROLL_NW")) { int v = atoi(s); if (v >= 1 && v <= ROLL_MAX_WAVES) nw = v; }
+    // the big grids (more than 256 cells) of the ring levels: the STAGED split (mg_roll.h) -- the dynamics wave + ONE encode wave over one copy of the grids
+    // (a private copy per wave left them one wave per workgroup).  MG_ROLL_STAGED=0: the one-wave form (A/B).
+    e->staged_big = e->fast7 && !e->fast_full && !e->sentence && !e->dyn_inloop && !e->static_gen && e->cells > 256 && e->k.roll_staged;
+    if (e->staged_big) nw = 2;
+    if (e->k.roll_nw >= 1 && e->k.roll_nw <= ROLL_MAX_WAVES) nw = e->k.roll_nw;
     e->roll_nw = nw;
     e->lds_bytes = std::max(roll_lds_bytes(e, nw, true), roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)));
     if (e->sentence && e->fast7) e->lds_bytes = std::max(e->lds_bytes, roll_lds_bytes(e, 2, true, true));
@@ -807,8 +798,7 @@ static const char* configure_obs(mg_env* e) {
     // empty.  Measured in round 4 and NOT adopted (profiles/r4/epw32.txt): GoToRedBall x 32 768 4.9 us per step against 2.9, Empty-8x8 x 32 768
     // 1.60 against 1.37, x 16 384 1.28 against 1.32 -- the wave-instructions double and the chains do not get shorter.  The switch stays
     // for A/B runs; tests/test_gpu_roll.py keeps the path exact.
-    int epw = 64;
-    if (const char* s = getenv("MG_ROLL_EPW")) { int v = atoi(s); if (v == 32 || v == 64) epw = v; }
+    const int epw = e->k.roll_epw;
     e->epw = epw; e->nwaves = (e->N + epw - 1) / epw;
   }
   if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";
@@ -819,7 +809,6 @@ static const char* configure_obs(mg_env* e) {
   // traj_slots > 0: exactly that many; 0: the default; < 0: -traj_slots PREFERRED, halved like the default while the ring would exceed 2 GB
   // (ShardedVecEnv asks for two blocks of max_fused_steps slots this way: ADVICE r3)
   int S = e->cfg.traj_slots > 0 ? e->cfg.traj_slots : e->cfg.traj_slots < 0 ? -e->cfg.traj_slots : 32;
-  if (const char* s = getenv("MG_TRAJ_SLOTS")) { int v = atoi(s); if (v >= 1) S = v; }
   if (S > 4096) return "traj_slots must be <= 4096";
   if (rgb) S = 1;
   if (e->cfg.traj_slots <= 0) while (S > 1 && per_slot * S > ((size_t)2 << 30)) S >>= 1;
@@ -829,7 +818,6 @@ static const char* configure_obs(mg_env* e) {
   // (the sentence levels fuse only where their verifier runs inside the step loop: the default 7x7 view)
   e->max_fused = (rgb || (e->live_gen && !e->dyn_inloop) || (e->sentence && !e->fast7)) ? 1 : std::min(std::min(S, MAX_FUSED_STEPS), (e->static_gen || e->dyn_inloop) ? MAX_FUSED_STEPS :
                                                                         (e->cfg.autoreset_mode == MG_AUTORESET_SAME_STEP ? 1 : 2) * e->cb);
-  if (const char* s = getenv("MG_MAX_FUSED")) { int v = atoi(s); if (v >= 1) e->max_fused = std::min(e->max_fused, v); }
   return nullptr;
 }
 
@@ -995,8 +983,7 @@ static void on_abort(int sig, siginfo_t* info, void* ctx) {
 static void install_abort_backtrace() {
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* s = getenv("MG_ABORT_BACKTRACE");
-    if (!s || atoi(s) != 1) return;
+    if (!Knobs::from_env().abort_backtrace) return;
     void* warm[4]; (void)backtrace(warm, 4);           // loads libgcc now, not inside the handler
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
@@ -1017,7 +1004,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (const char* bad = validate_obs_cfg(cfg)) return fail(nullptr, MG_ERR_INVALID, "%s", bad);
   if (cfg->max_steps < 1 || cfg->max_steps > 65535) return fail(nullptr, MG_ERR_INVALID, "max_steps must be in 1..65535");
   if (cfg->autoreset_mode < MG_AUTORESET_NEXT_STEP || cfg->autoreset_mode > MG_AUTORESET_SAME_STEP) return fail(nullptr, MG_ERR_INVALID, "unknown autoreset_mode");
-  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS && getenv("MG_DYN_INLOOP") && atoi(getenv("MG_DYN_INLOOP")) == 0)
+  if (cfg->autoreset_mode == MG_AUTORESET_SAME_STEP && cfg->env_kind == MG_ENV_DYNOBS && Knobs::from_env().dyn_inloop == 0)
     return fail(nullptr, MG_ERR_INVALID, "SAME_STEP autoreset of DynamicObstacles needs the in-loop redraw (MG_DYN_INLOOP=0 switches it off)");
   if (cfg->env_kind < MG_ENV_EMPTY || cfg->env_kind > MG_ENV_LEVELGEN) return fail(nullptr, MG_ERR_INVALID, "unknown env_kind");
   if (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) {
@@ -1121,6 +1108,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   if (hipSetDevice(device) != hipSuccess) return fail(nullptr, MG_ERR_HIP, "hipSetDevice(%d) failed", device);
 
   mg_env* e = new mg_env();
+  e->k = Knobs::from_env();
   e->cfg = *cfg; e->device = device;
   e->N = cfg->num_envs; e->W = cfg->width; e->H = cfg->height; e->cells = e->W * e->H;
   e->CS = (e->cells + 15) & ~15;
@@ -1128,8 +1116,7 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
   // empty.py:108-110, distshift.py:118-120: a fixed agent start means _gen_grid draws nothing
   e->static_gen = (cfg->env_kind == MG_ENV_EMPTY || cfg->env_kind == MG_ENV_DISTSHIFT) && cfg->agent_start_x >= 0;
   {
-    const char* s = getenv("MG_LANE_GEN");
-    const bool lane_on = (!s || atoi(s) != 0) && lane_gen_lds_bytes(e->CS, cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) <= 64 * 1024;
+    const bool lane_on = lane_gen_lds_bytes(e->CS, cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) <= 64 * 1024;
     // REFILL on lanes: the single-room levels, the Unlock family and KeyCorridor (per request segment: what they were tuned on, rounds 4-5).  For the
     // others -- the mazes, MultiRoom, the sentence levels -- lanes lose as a refill in either form (profiles/r5/lane_wide_bench_lines.txt: a few busy
     // lanes per wave; ab_packed_lane_refill.txt: whole waves of busy lanes, requests numbered across the segments -- a wave of 64 diverging maze
@@ -1139,22 +1126,23 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // MG_LANE_PACKED=1: the levels whose refill runs on lanes refill PACKED (A/B; KeyCorridor / UnlockPickup +3 %, GoToRedBall x 32 768 -50 %);
     // MG_LANE_LPW: busy lanes per wavefront of the packed refill (1..64).
     const bool tuned_sparse = lane_gen_kind_base(cfg->env_kind) || lane_gen_kind_product_fn(cfg->env_kind);
-    const char* pk = getenv("MG_LANE_PACKED");
     e->lane_gen = lane_on && tuned_sparse;
-    e->lane_packed = e->lane_gen && pk && atoi(pk) == 1;
+    e->lane_packed = e->lane_gen && e->k.lane_packed;
     // (from 16 384 envs on: a call of k_generate_lane lasts as long as its slowest lane -- ~5 ms for a maze level whatever the batch --, a call of the
     // cooperative k_generate ~0.8 ms + N / 4.3 M episodes/s: lanes win above ~18 000 envs.  MG_LANE_DIRECT: 0 = never, 1 = at every batch size)
-    const char* dg = getenv("MG_LANE_DIRECT");
-    const int dmode = dg ? atoi(dg) : -1;
+    const int dmode = e->k.lane_direct;
     e->lane_direct = lane_on && lane_gen_kind(cfg->env_kind) && (e->lane_gen || dmode == 1 || (dmode != 0 && cfg->num_envs >= 16384));
     // BURST HYBRID (the levels whose refill stays with k_refill): a batch of at least lane_burst_min requests -- the synchronized truncation burst of a
     // long-episode level, every env at once -- refills on packed lanes (dense: BabyAI-GoTo x 131 072 draws 131 072 episodes in 8 ms on lanes, 30 ms on
     // cooperative wavefronts), everything smaller on k_refill.  The crossover is where k_refill's throughput (~4 M episodes/s) costs more than a lane
     // wave's latency (4-7 ms): ~32 768 requests.  MG_LANE_BURST: the threshold (0 = off).
-    e->lane_burst_min = (e->lane_direct && !e->lane_gen) ? 32768 : 0;
-    if (const char* b = getenv("MG_LANE_BURST")) { const long long v = atoll(b); if (v >= 0 && e->lane_direct && !e->lane_gen) e->lane_burst_min = v; }
-    e->lane_lpw = 64;
-    if (const char* l = getenv("MG_LANE_LPW")) { int v = atoi(l); if (v >= 1 && v <= 64) e->lane_lpw = v; }
+    // (round 6: the cooperative generator of the RoomGrid mazes is 2.8x faster than it was -- rooms_reach, speculative connect_all, draw budgets: 4.3 -> 12.3 M
+    // BabyAI-GoTo episodes/s -- so the crossover moved: 65 536 requests for them.  A de-phased BabyAI-GoTo x 131 072 batch files ~30 000 requests per refill:
+    // 5.98 G env-steps/s with the old threshold (some batches went to lanes), 7.71 G without lanes; a synchronized truncation burst (131 072 requests) still
+    // refills on lanes: 8.22 G.  MultiRoom (36 M episodes/s on lanes against 15 M) and the sentence levels keep 32 768.  profiles/r6/ab_staged_big_grids_burst_threshold_dephase.txt)
+    e->lane_burst_min = (e->lane_direct && !e->lane_gen) ? ((cfg->env_kind == MG_ENV_MULTIROOM || (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) ? 32768 : 65536) : 0;
+    if (e->k.lane_burst >= 0 && e->lane_direct && !e->lane_gen) e->lane_burst_min = e->k.lane_burst;
+    e->lane_lpw = e->k.lane_lpw;
   }
   e->sentence = cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN;
   e->live_gen = cfg->env_kind == MG_ENV_DYNOBS;
@@ -1189,14 +1177,13 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
       // without a truncation burst, 77.6 -> 65.3 with one, profiles/r5/babyai_goto_ring.txt; MultiRoom-N6 and BossLevel: no difference)
       // (large batches only: a small batch's refill is short whatever the ring, and every seeded reset fills the whole ring)
       if (cfg->spare_ring <= 0 && e->cells > 256 && e->N >= 32768 && !(cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) R = 256;
-      if (const char* s = getenv("MG_SPARE_RING")) { int v = atoi(s); if (v >= 4) R = v; }
+      if (e->k.spare_ring >= 4) R = e->k.spare_ring;
       if (R < 4 || R > 256 || (R & (R - 1))) { delete e; return fail(nullptr, MG_ERR_INVALID, "spare_ring must be a power of two in 4..256"); }
       // per ring slot and env: the map, the agent / aux words, the five stream words of the snapshot (+ LevelGen state and the
-      // 320-byte instruction record for the sentence levels): everything that scales with R counts against the 16 GB cap
+      // 320-byte instruction record for the sentence levels): everything that scales with R counts against the ring cap (min(32 GB, a quarter of the free memory): below)
       const size_t per_slot_env = (size_t)e->CS + 16 + 40 + (e->sentence ? 4 + INSTR_WORDS * 8 : 0);
       // ... and against a quarter of what the device has free right now (several handles per GPU, or a part with less HBM: ADVICE r4)
       size_t ring_cap = (size_t)32 << 30;                                                  // (32 GB of 288; 18.5 GB for BabyAI-GoTo x 131 072 at R = 256)
-      if (const char* s = getenv("MG_RING_CAP_GB")) { const long long v = atoll(s); if (v >= 1 && v <= 256) ring_cap = (size_t)v << 30; }
       { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) ring_cap = std::min(ring_cap, fr / 4); }
       while (R > 4 && (size_t)R * e->N * per_slot_env > ring_cap) R >>= 1;
     }
@@ -1257,8 +1244,6 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // starves the refill until the launch drains: measured 161 us per LavaCrossing refill at equal priority)
     int lo = 0, hi = 0;
     TRY_OR_FREE(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    // (MG_GEN_PRIO=0: the generator stream at the step stream's priority -- A/B)
-    { const char* s = getenv("MG_GEN_PRIO"); if (s && atoi(s) == 0) hi = 0; }
     TRY_OR_FREE(hipStreamCreateWithPriority(&e->gen_stream, hipStreamNonBlocking, hi));
   }
   TRY_OR_FREE(hipEventCreate(&e->ev0));
@@ -1431,9 +1416,13 @@ int mg_reset(mg_env* e, const uint64_t* seeds, const uint8_t* mask) {
   const uint8_t* d_mask = nullptr;
   bool async_fill = false;
   { int rc = await_ring_fill(e); if (rc) return rc; }     // (a ring redraw still running reads e->mask and e->rng)
+  e->mask_sparse = false;
   if (mask) {
     HIP_TRY(e, hipMemcpyAsync(e->mask, mask, (size_t)N, hipMemcpyHostToDevice, e->stream));
     d_mask = e->mask;
+    size_t set = 0;
+    for (int i = 0; i < N; i++) set += mask[i] != 0;
+    e->mask_sparse = set * 8 < (size_t)N;                  // fewer than an eighth of the envs: lanes would idle (launch_generate)
   }
   const int tb = 256, nb = (N + tb - 1) / tb;
   if (seeds) {
@@ -1794,6 +1783,8 @@ int mg_timer_stop(mg_env* e, float* ms) {
   HIP_TRY(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
   return MG_OK;
 }
+
+int mg_ring_depth(mg_env* e) { return !e ? MG_ERR_INVALID : (e->live_gen ? 0 : e->R); }
 
 int mg_get_counters(mg_env* e, uint64_t out[4]) {
   if (!e || !out) return MG_ERR_INVALID;

@@ -211,7 +211,9 @@ MG_HD int dir_dy(uint32_t d) { return (d & 1u) ? 1 - (int)(d & 2u) : 0; }
 // device error kinds (surfaced by mg_sync / mg_copy_outputs).  The flags live in mapped pinned HOST memory, one word per kind
 // (word k = bit k), set with plain stores of 1 -- no device atomics on host memory, no device-to-host copy to read them.
 enum : uint32_t { ERR_BAD_ACTION = 1u, ERR_GENERATOR = 2u, ERR_OOB = 4u, ERR_TRACKED = 8u };
-constexpr int ERR_WORDS = 5;                  // the four kinds above + mg_set_state's "bad agent record"
+constexpr int ERR_WORDS = 6;                  // the four kinds above + mg_set_state's "bad agent record" + [5] an inter-wave spin of k_roll7 ran past
+                                              // MG_SPIN_BOUND polls (only -DMG_SPIN_BOUND builds ever set it: mg_roll.h)
+constexpr int ERR_WORD_SPIN = 5;
 MG_HD void report_errors(uint32_t* err, uint32_t bits) {
 #pragma unroll
   for (int k = 0; k < 4; k++) if ((bits >> k) & 1u) err[k] = 1u;

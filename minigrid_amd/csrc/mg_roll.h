@@ -468,8 +468,13 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // costs beyond the launch itself is largely instruction fetch: the general kernel carries four loop shapes (time split, log split, staged split, encode
 // waves), each with its own copy of the dynamics / observation code, and the shadow-spare staging of fused launches.  ONE compiles all of that out: one
 // wave steps, the workgroup's waves share the encode (`share`) or it is the only wave; a spare episode comes straight from the ring in HBM.
-template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu((GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : 3, 8))) k_roll7(const StepParams P) {
+// STAGED (round 6): the staged split for the 7x7 view of the BIG grids (more than 256 cells: the 22 x 22 mazes, MultiRoom's 25 x 25, ...) of every rule
+// group.  A private copy of the 64 grids per wave is 32-41 KB there, so those levels ran ONE wave per workgroup -- 4 (3) workgroups per CU, one wave per
+// SIMD, every latency of the step exposed.  With one copy per workgroup (the dynamics wave's, which also stages the step's 49 codes per env) a second
+// wave takes the output-space encode and the stores, exactly as for the sentence levels (same 22 x 22 grids) since round 4.
+template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false, bool STAGED = false>
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : 3, 8))) k_roll7(const StepParams P) {
+  static_assert(!STAGED || (!FULL && !ONE && GG != GG_DYNOBS && GG != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -504,7 +509,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
   // DynamicObstacles, the sentence levels and FullyObs split differently (the staged split, see the loops below): ONE copy of the grids, the
   // dynamics wave's, which also stages every step's codes (FullyObs: a copy of its image-order stream)
-  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) && split_mode;
+  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL || STAGED) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
   uint8_t* scodes = smem + P.off_T + (dsplit ? 0 : split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
@@ -614,25 +619,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (l < EPW && env0 + l < P.N) sact[k] = (uint8_t)load_action(P, env0 + l, j);
     }
   }
-  if (!ONE && P.act_stage) {
-    // The device policy's actions of the WHOLE launch, drawn up front by every wave of the workgroup (round 6): a Philox4x32-10 block is ~40
-    // quarter-rate multiplies and gives one env four steps' actions; inside the loop it sat on the dynamics wave -- the one serial chain the
-    // workgroup's pace depends on -- every fourth step.  Here the launch's <= 9 blocks per env are spread over all the
-    // threads, and the loop reads one LDS byte per step, exactly as it does for caller-supplied actions.  Block b covers steps t = 4b .. 4b + 3
-    // of the env's action stream (t = P.t0 + j, mod 2^32): thread (l, g) draws block (t0 >> 2) + g of env l and files the steps that lie in the launch.
-    const uint32_t nblk = ((uint32_t)P.T + (P.t0 & 3u) + 3u) >> 2;
-    for (uint32_t k = (uint32_t)tid; k < nblk * 64u; k += (uint32_t)nthreads) {
-      const uint32_t l = k & 63u, g = k >> 6;
-      const uint32_t t_first = (P.t0 & ~3u) + 4u * g;
-      uint32_t w[4];
-      philox_action_block(P, min(env0 + (int)l, P.N - 1), t_first >> 2, w);
-#pragma unroll
-      for (uint32_t q = 0; q < 4u; q++) {
-        const uint32_t j = t_first + q - P.t0;                      // (mod 2^32: a block that straddles the launch's first step gives j >= T for the steps before it)
-        if (j < (uint32_t)P.T) sact[j * 64u + l] = (uint8_t)(((uint64_t)w[q] * 7u) >> 32);
-      }
-    }
-  }
+  // (Round 6 built what VERDICT r5 asked for here -- every wave of the workgroup drawing its share of the launch's T x 64 Philox actions into LDS up front,
+  // the loop reading one byte, so that no Philox block sits on the dynamics wave -- and measured it: Empty-8x8 x 65 536 2.31 us per step against 2.15-2.22
+  // with the draw inside the loop, DoorKey / GoToRedBall / LavaCrossing indifferent (profiles/r6/ab_action_staging_not_adopted.txt): the 2 KB of LDS and the
+  // longer prologue cost more than ~25 VALU instructions per step on one wave.  Removed again.)
   if constexpr (FULL) {
     // the shadow spares' image stream (shared, built by wave 0 from the staged shadow grids)
     if (!ONE && P.use_shadow) {
@@ -704,6 +694,16 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
   };
   MG_SPIN_DECL;
+  // -DMG_SPIN_BOUND=<polls> builds (profiles/r6_protocol_bound.sh; never the product library): every inter-wave spin below gives up after that many
+  // polls, raises error word ERR_WORD_SPIN (the next mg_sync fails) and carries on with whatever it finds -- the launch then ENDS (every loop is
+  // bounded by T), so a regression of the LDS protocol is a failing test instead of a hung lease (VERDICT r5 "next" #7).  The product build keeps
+  // the unbounded form: a counter in the hottest loop of the dynamics wave for a failure that needs corrupted LDS.
+#if defined(MG_SPIN_BOUND)
+#define MG_SPIN_POLL(n) if (++(n) > (uint32_t)(MG_SPIN_BOUND)) { if (lane == 0) P.err[ERR_WORD_SPIN] = 1u; break; }
+#else
+#define MG_SPIN_POLL(n) do { } while (0)
+#endif
+  uint32_t spin_polls = 0u; (void)spin_polls;
   constexpr bool nt = NT;                                            // this launch's observation stores are nontemporal (see store12; the host picks the instantiation)
 
   // ---- the pieces of a step ----
@@ -713,12 +713,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     MG_MARK("action");
     uint32_t act = A_DONE;
     if (P.phase == PHASE_STEP) {
-      if (P.act_src == ACT_SRC_PHILOX && (ONE || !P.act_stage)) {
+      if (P.act_src == ACT_SRC_PHILOX) {
         const uint32_t t = P.t0 + (uint32_t)j;
         if (j == 0 || (t & 3u) == 0u) philox_action_block(P, e, t >> 2, pw);
         const uint32_t w = (t & 3u) == 0u ? pw[0] : (t & 3u) == 1u ? pw[1] : (t & 3u) == 2u ? pw[2] : pw[3];
         act = (uint32_t)(((uint64_t)w * 7u) >> 32);
-      } else act = sact[j * 64 + lane];                            // the caller's actions, or the device policy's staged in the prologue
+      } else act = sact[j * 64 + lane];
     }
     o.act_in = act;
     if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
@@ -931,7 +931,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (ONE || !split_mode) {
     // ---- every wave steps for itself: one wave (NW = 1, or `share`), or the TIME SPLIT (wave w replays steps 0 .. split[w]-1 silently) ----
     if constexpr (ONE) {
-      if (j_end > 0) {
+      // (host invariant, launch_roll_*: a one-step launch has ONE stepping wave -- nw == 1 or `share`; a time split with j_begin = j_end = 1 in the
+      // other waves must not store the step again: ADVICE r5)
+      if (j_begin == 0 && j_end > 0) {
         StepOut o;
         dynamics(0, o);
         full_follow();
@@ -956,8 +958,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
   } else if constexpr (ONE) {
     // (never: the one-step kernel has no split)
-  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL) {
-    // ---- DynamicObstacles and the sentence levels, split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
+  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL || STAGED) {
+    // ---- DynamicObstacles and the sentence levels (and, STAGED, the big grids of the other levels), split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
     // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
     // j by encode wave j mod (NW - 1).  The level's step is its placement loop (a 128-bit multiply per try, ~16 tries deep for the unluckiest
     // of 64 lanes; profiles/r4/dynobs_attr_first.txt: 26 of 30 us), which the ~150 instructions of the staging do not lengthen noticeably --
@@ -980,7 +982,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         dynamics(j, o);
         store_scalars(slot_of(j), o);
         if (j >= P.dring) {
-          while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[1 + kq]) < mq + 1u) __builtin_amdgcn_s_sleep(1);
+          spin_polls = 0u;
+          while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[1 + kq]) < mq + 1u) { __builtin_amdgcn_s_sleep(1); MG_SPIN_POLL(spin_polls); }
           if (++kq == NE) { kq = 0; mq++; }
         }
         MG_WAVE_ORDER();
@@ -996,8 +999,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           for (int c = lane; c < 4 * cells; c += 64) dst[c] = src[c];            // 64 * cells bytes = 4 * cells 16-byte pieces
           MG_LDS_SYNC();
           if (active) scodes[gt_pos] = (uint8_t)gt_old;
-        } else
-        observe(0, a, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 1);
+        } else {
+          // (PutNext(start_carrying): the episode's first observation shows the object where it was and empty hands -- the codes are staged that way)
+          Agent av = a;
+          if (o.show_taken) av.carry = 0;
+          observe(0, av, o.show_taken, (uint32_t)(S.targets & 0xFFFFull), a.carry, ring + (j & (P.dring - 1)) * P.codes_stride, 1);
+        }
         // (DS operations of one wave execute in order: the counter cannot become visible before the codes)
         MG_WAVE_ORDER();
         sync[0] = (uint32_t)(j + 1);
@@ -1007,7 +1014,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       uint32_t done = 0;
       Agent av = agent_unpack(0ull);
       for (int j = k; j < P.T; j += NE) {
-        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) __builtin_amdgcn_s_sleep(1);
+        spin_polls = 0u;
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) { __builtin_amdgcn_s_sleep(1); MG_SPIN_POLL(spin_polls); }
         MG_WAVE_ORDER();
         observe(slot_of(j), av, false, 0u, 0u, ring + (j & (P.dring - 1)) * P.codes_stride, 2);
         MG_LDS_SYNC();                                                          // the staging's last read has returned
@@ -1044,11 +1052,13 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       if (j >= ROLL_LOG_STEPS) {
         // flow control: entry j reuses the slot of entry j - ROLL_LOG_STEPS, which every encode wave must have consumed
         const uint32_t need = (uint32_t)(j - ROLL_LOG_STEPS + 1);
+        spin_polls = 0u;
         while (true) {
           const uint32_t p0 = sync[1], p1 = sync[2], p2 = sync[3];
           if ((uint32_t)__builtin_amdgcn_readfirstlane((int)min(p0, min(p1, p2))) >= need) break;
           __builtin_amdgcn_s_sleep(1);
           MG_SPIN_COUNT(0);
+          MG_SPIN_POLL(spin_polls);
         }
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
@@ -1066,7 +1076,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const int k = ek, NE = NW - 1;
     int mine = k;                                                      // next step this wave produces
     for (int j = 0; j < P.T; j++) {
-      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) { __builtin_amdgcn_s_sleep(1); MG_SPIN_COUNT(1); }
+      spin_polls = 0u;
+      while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) { __builtin_amdgcn_s_sleep(1); MG_SPIN_COUNT(1); MG_SPIN_POLL(spin_polls); }
       MG_WAVE_ORDER();
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
       const uint32_t delta = rec2.y;
@@ -1088,7 +1099,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       }
       if (delta & (1u << 30)) mygrid[delta & 0x3FFu] = (uint8_t)(delta >> 10);
       MG_WAVE_ORDER();
+#if !defined(MG_SPIN_NEGATIVE_CONTROL)      // (the bounded-spin build's negative control: an encode wave that never reports progress -- the dynamics wave's bound must fire)
       sync[1 + k] = (uint32_t)(j + 1);                                 // (in order behind the entry's read)
+#endif
       if (j != mine) continue;
       mine += NE;
       Agent av;

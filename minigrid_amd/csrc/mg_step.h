@@ -55,7 +55,7 @@ struct StepParams {
   uint32_t* seg; uint32_t* seg_count; int seg_cap;   // this batch's refill requests: one segment of seg_cap env ids per wave
   // ---- inputs ----
   const void* actions; int act_dtype; int act_src; uint64_t action_seed; uint32_t t0;   // buffer: [T][N] of act_dtype
-  int act_stage;                                  // k_roll7, device policy: 1 = every wave of the workgroup draws its share of the launch's T x 64 Philox actions into LDS in the prologue (mg_roll.h)
+  int staged;                                     // k_roll7: 1 = the STAGED instantiation (big grids: one copy of the grids per workgroup, the dynamics wave stages the codes; mg_roll.h)
   const uint8_t* obs_mask;                        // PHASE_OBSERVE of a masked reset(): only these envs take a new episode
   uint64_t* instr; const uint64_t* spare_instr; unsigned long long off_sentence;   // sentence levels through k_roll7<GG_SENTENCE>: the verifier runs inside the step loop
   // ---- outputs: slot s of the trajectory ring starts at out + s * slot_bytes; step j of this launch -> slot slot0 - j (mod S) ----

@@ -576,6 +576,12 @@ class MiniGridVecEnv(_VectorEnvBase):
         r = np.ascontiguousarray(r, np.uint64)
         B.check(self._lib.mg_set_rng(self._h, self._p(r)), self._h)
 
+    @property
+    def spare_ring_depth(self) -> int:
+        """The EFFECTIVE spare-episode ring depth of this handle (mg_ring_depth): `spare_ring` when given, else the level's default, halved while the
+        ring would exceed min(32 GB, a quarter of the free device memory).  `spare_ring` itself stays the constructor argument (0 = default)."""
+        return int(self._lib.mg_ring_depth(self._h))
+
     def counters(self) -> dict:
         c = np.zeros(4, np.uint64)
         B.check(self._lib.mg_get_counters(self._h, self._p(c)), self._h)

@@ -16,7 +16,7 @@ for spec in "goto BabyAI-GoTo-v0 131072 1024" "multiroom MiniGrid-MultiRoom-N6-v
   grep -v amdgpu.ids $OUT/refill_attribution_$1_after2.txt
 done
 for w in babyai_goto bosslevel multiroom keycorridor unlockpickup; do
-  for cfg in "MG_X=0" "MG_LANE_BURST=0"; do
+  for cfg in "MG_X=0" "MG_LANE_BURST=0" "MG_ROLL_STAGED=0" "MG_ROLL_NW=3" "MG_LANE_BURST=8192"; do
     env $cfg python bench.py --workload $w --steps 1024 --warmup 128 --no-cpu-baseline 2>/dev/null | line "$w steps 1024 $cfg"
   done
   python bench.py --workload $w --steps 1024 --warmup 128 --no-cpu-baseline --dephase 0 2>/dev/null | line "$w steps 1024 --dephase 0"

@@ -32,7 +32,7 @@ PRODUCT_CASES = [
     {"env": "MiniGrid-Empty-8x8-v0", "n": 100, "launches": [32], "max_steps": 5, "knobs": {"MG_ROLL_SPLIT": "0", "MG_ROLL_NW": "4"}},
     {"env": "BabyAI-GoToRedBall-v0", "n": 100, "launches": [32, 13], "max_steps": 3},
     {"env": "MiniGrid-LavaCrossingS9N1-v0", "n": 100, "launches": [32, 5, 20], "full": True, "stepped": 3},
-    {"env": "MiniGrid-LavaCrossingS9N1-v0", "n": 100, "launches": [32, 5], "full": True, "knobs": {"MG_FULL_SPLIT": "0"}},
+    {"env": "MiniGrid-LavaCrossingS9N1-v0", "n": 100, "launches": [32, 5], "full": True, "knobs": {"MG_ROLL_SPLIT": "0"}},
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 100, "launches": [32, 5], "full": True, "max_steps": 9, "stepped": 3},
     # DynamicObstacles inside the fused kernel, SAME_STEP autoreset inside the kernels
     {"env": "MiniGrid-Dynamic-Obstacles-6x6-v0", "n": 100, "launches": [5, 20, 3], "stepped": 3},
