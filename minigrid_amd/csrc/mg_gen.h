@@ -153,6 +153,16 @@ struct LaneGrid {
   }
 };
 
+// ---- lane-parallel draws of the wave form (round 6) ----
+// Lane-parallel Lemire draw out of the draw buffer: this lane's value for logical draw p and a range of r >= 2 values, and whether the draw is
+// SAFE -- numpy's rejection step cannot apply to it (buffered_bounded_lemire_uint32 looks at its threshold only when leftover < r, and the
+// threshold of a power-of-two range is 0).  An unsafe draw is never used speculatively: the caller falls back to the scalar rand_int there.
+template <class R>
+MG_D uint32_t peek_bounded(const R& rng, uint32_t p, uint32_t r, bool& safe) {
+  const uint64_t m = (uint64_t)rng.peek_lane(p) * r;
+  safe = (uint32_t)m >= r || (r & (r - 1u)) == 0u;
+  return (uint32_t)(m >> 32);
+}
 // MiniGridEnv.place_obj (minigrid_env.py:313-372).  (ax, ay) is the agent position to avoid ((-1,-1) while the
 // agent itself is being placed).  near_reject = core/roomgrid.py:11-20 reject_next_to.  max_tries < 0 = math.inf.
 // Returns false on the reference's RecursionError.
@@ -162,20 +172,25 @@ MG_HD bool place_obj(R& rng, G& g, uint32_t cell, int topx, int topy, int sx, in
   topx = topx < 0 ? 0 : topx; topy = topy < 0 ? 0 : topy;
   const int hx = min(topx + sx, g.W), hy = min(topy + sy, g.H);
   int tries = 0;
-  // Speculative rejection sampling: when both ranges are powers of two (numpy's Lemire draw then never rejects:
-  // threshold (2^32 - r) % r == 0, value = top bits) every try consumes exactly two draws, so lane t can evaluate
-  // try t from draws wpos+2t, wpos+2t+1 and the first acceptable lane is the reference's accepted try.
+  // Speculative rejection sampling: a try consumes exactly two draws as long as numpy's Lemire step does not reject one of them (never for a
+  // power-of-two range: threshold (2^32 - r) % r == 0; otherwise only when the draw's low product word is below the range -- peek_bounded's
+  // `safe`), so lane t can evaluate try t from draws wpos+2t, wpos+2t+1 and the first acceptable lane is the reference's accepted try.  The
+  // tries before the first unsafe one are evaluated here; that one is taken by the scalar loop below.  (Round 6: any range -- rooms whose size
+  // is not a power of two, MultiRoom's, placed their objects one scalar try at a time.)
   const uint32_t rx = (uint32_t)(hx - topx), ry = (uint32_t)(hy - topy);
-  if constexpr (G::kWave) if (rx >= 2u && ry >= 2u && (rx & (rx - 1u)) == 0u && (ry & (ry - 1u)) == 0u && !rng.dead()) {
+  if constexpr (G::kWave) if (rx >= 2u && ry >= 2u && (int)rx > 0 && (int)ry > 0 && !rng.dead()) {
     const uint32_t win = rng.window();
     const uint32_t p0 = rng.wpos + 2u * (uint32_t)g.lane;
     const bool valid = p0 + 1u < win;
-    const uint32_t w0 = rng.peek_lane(p0), w1 = rng.peek_lane(p0 + 1u);
-    const int x = topx + (int)(((uint64_t)w0 * rx) >> 32), y = topy + (int)(((uint64_t)w1 * ry) >> 32);
-    const uint32_t c = valid ? (uint32_t)g.p[y * g.W + x] : 0u;
-    const bool ok = valid && c == CELL_EMPTY && !(x == ax && y == ay) && !(near_reject && (abs(ax - x) + abs(ay - y)) < 2);
+    bool sa, sb;
+    const uint32_t vx = peek_bounded(rng, p0, rx, sa), vy = peek_bounded(rng, p0 + 1u, ry, sb);
+    const int x = topx + (int)vx, y = topy + (int)vy;
+    const unsigned long long unsafe = __ballot(valid && !(sa && sb));
+    const int nhave = win > rng.wpos ? (int)min((win - rng.wpos) >> 1, 64u) : 0;
+    const int nvalid = unsafe ? min(nhave, __ffsll((long long)unsafe) - 1) : nhave;
+    const uint32_t c = g.lane < nvalid ? (uint32_t)g.p[y * g.W + x] : 0u;
+    const bool ok = g.lane < nvalid && c == CELL_EMPTY && !(x == ax && y == ay) && !(near_reject && (abs(ax - x) + abs(ay - y)) < 2);
     const unsigned long long m = __ballot(ok);
-    const int nvalid = win > rng.wpos ? (int)min((win - rng.wpos) >> 1, 64u) : 0;
     if (m) {
       const int t = __ffsll((long long)m) - 1;
       if (max_tries >= 0 && t > max_tries) return false;
@@ -184,7 +199,7 @@ MG_HD bool place_obj(R& rng, G& g, uint32_t cell, int topx, int topy, int sx, in
       if (cell != CELL_EMPTY) g.set(px, py, cell);
       return true;
     }
-    tries = nvalid; rng.wpos += 2u * (uint32_t)nvalid;     // every buffered try was rejected: carry on one by one
+    tries = nvalid; rng.wpos += 2u * (uint32_t)nvalid;     // every evaluated try was rejected: carry on one by one
   }
   for (;;) {
     if (max_tries >= 0 && tries > max_tries) return false;
@@ -658,16 +673,7 @@ MG_HD void gen_unlock_family(R& rng, G& g, const GenParams& P, GenResult& out, i
   out.mission = variant == 0 ? 0u : (variant == 1 ? box_ci : box_ci * 2u);
 }
 
-// ---- lane-parallel draws of the wave form (round 6) ----
-// Lane-parallel Lemire draw out of the draw buffer: this lane's value for logical draw p and a range of r >= 2 values, and whether the draw is
-// SAFE -- numpy's rejection step cannot apply to it (buffered_bounded_lemire_uint32 looks at its threshold only when leftover < r, and the
-// threshold of a power-of-two range is 0).  An unsafe draw is never used speculatively: the caller falls back to the scalar rand_int there.
-template <class R>
-MG_D uint32_t peek_bounded(const R& rng, uint32_t p, uint32_t r, bool& safe) {
-  const uint64_t m = (uint64_t)rng.peek_lane(p) * r;
-  safe = (uint32_t)m >= r || (r & (r - 1u)) == 0u;
-  return (uint32_t)(m >> 32);
-}
+// (peek_bounded: above place_obj)
 // Four bounded draws in a row (_rand_int over r0 .. r3 values, each >= 2): lanes 0..3 evaluate them in one pass.  false = not applicable here
 // (too few buffered draws, or an unsafe draw): nothing was consumed, the caller draws them one by one.
 template <class R, class G>
@@ -1282,6 +1288,58 @@ MG_HD bool mr_try_room(R& rng, const G& g, const GenParams& P, uint32_t* cur, in
   cur[n++] = mr_pack(tx, ty, sx, sy, ex, ey);
   return true;
 }
+// _placeRoom's `for i in range(0, 8)` loop (multiroom.py:247-281) of the newest room, speculatively (round 6): until a child room is accepted nothing the
+// loop looks at changes, and every try draws the same number of values whatever its outcome (exit wall, door offset, [sizeX, sizeY], top offset: the checks of
+// :223-241 come after the draws), so lane t evaluates try t from draws wpos + per * t .. against the rooms placed so far; the first lane whose room fits is
+// the try the reference accepts, the lanes before it are its rejected tries.  Returns the tries consumed (with their draws); `acc`: the last of them placed
+// `room` behind entry wall `entry`.  0 = nothing could be evaluated (no buffered draws left, or try 0 holds a draw numpy's Lemire step might reject): the
+// caller runs one try the scalar way.  The scalar chain search was 65 % of a MultiRoom-N6 episode (profiles/r6/refill_attribution_multiroom_*.txt).
+template <class R, class G>
+MG_D int mr_spec(R& rng, const G& g, const GenParams& P, const uint32_t* cur, int n, int wall, int max_tries, bool& acc, uint32_t& room, int& entry) {
+  acc = false;
+  if (rng.dead()) return 0;
+  const uint32_t par = uni32(cur[n - 1]);
+  const int ptx = (int)(par & 31u), pty = (int)((par >> 5) & 31u), psx = (int)((par >> 10) & 15u), psy = (int)((par >> 14) & 15u);
+  const uint32_t nsz = P.room_size > 4 ? 2u : 0u;                   // _rand_int(4, maxSz + 1) over one value draws nothing
+  const uint32_t per = 3u + nsz;
+  const uint32_t p0 = rng.wpos + per * (uint32_t)g.lane;
+  const bool have = p0 + per <= rng.window() && g.lane < max_tries;
+  bool s0 = true, s1 = true, s2 = true, s3 = true, s4 = true;
+  const int k = (int)peek_bounded(rng, p0, 3u, s0);                 // _rand_elem(sorted({0,1,2,3} - {entryDoorWall}))
+  const int exit_wall = k >= wall ? k + 1 : k, next_entry = (exit_wall + 2) & 3;
+  const bool ew_x = (exit_wall & 1) == 0;                            // exit on the right / left wall: the door's y is drawn
+  const int d = 1 + (int)peek_bounded(rng, p0 + 1u, (uint32_t)((ew_x ? psy : psx) - 2), s1);
+  const int ex = exit_wall == 0 ? ptx + psx - 1 : exit_wall == 2 ? ptx : ptx + d;
+  const int ey = exit_wall == 1 ? pty + psy - 1 : exit_wall == 3 ? pty : pty + d;
+  int sx = 4, sy = 4;
+  if (nsz) { sx += (int)peek_bounded(rng, p0 + 2u, (uint32_t)(P.room_size - 3), s2); sy += (int)peek_bounded(rng, p0 + 3u, (uint32_t)(P.room_size - 3), s3); }
+  const bool ne_x = (next_entry & 1) == 0;                           // entry on the child's right / left wall: its topY is drawn
+  const int t = (int)peek_bounded(rng, p0 + 2u + nsz, (uint32_t)((ne_x ? sy : sx) - 2), s4);
+  const int tx = next_entry == 0 ? ex - sx + 1 : next_entry == 2 ? ex : ex - sx + 2 + t;
+  const int ty = next_entry == 1 ? ey - sy + 1 : next_entry == 3 ? ey : ey - sy + 2 + t;
+  const unsigned long long unsafe = __ballot(have && !(s0 && s1 && s2 && s3 && s4));
+  const int nhave = __popcll(__ballot(have));                       // (the lanes that have their draws are a prefix)
+  const int nt = unsafe ? min(nhave, __ffsll((long long)unsafe) - 1) : nhave;
+  if (nt == 0) return 0;
+  bool ok = tx >= 0 && ty >= 0 && tx + sx <= g.W && ty + sy < g.H;
+#pragma unroll 1
+  for (int q = 0; q + 1 < n; q++) {                                  // roomList[:-1]
+    const uint32_t r = uni32(cur[q]);
+    const int rtx = (int)(r & 31u), rty = (int)((r >> 5) & 31u), rsx = (int)((r >> 10) & 15u), rsy = (int)((r >> 14) & 15u);
+    ok = ok && (tx + sx < rtx || rtx + rsx <= tx || ty + sy < rty || rty + rsy <= ty);
+  }
+  const unsigned long long okm = __ballot(g.lane < nt && ok);
+  if (okm) {
+    const int a = __ffsll((long long)okm) - 1;
+    rng.wpos += per * (uint32_t)(a + 1);
+    room = lane32(mr_pack(tx, ty, sx, sy, ex, ey), (uint32_t)a);
+    entry = (int)lane32((uint32_t)next_entry, (uint32_t)a);
+    acc = true;
+    return a + 1;
+  }
+  rng.wpos += per * (uint32_t)nt;
+  return nt;
+}
 template <class R, class G>
 MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W;
@@ -1306,6 +1364,16 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
         bool placed = false;
 #pragma unroll 1
         for (int i = 0; i < 8 && !placed && !rng.dead(); i++) {
+          if constexpr (G::kWave) {
+            MG_WAVE_LDS_SYNC();                                     // (cur[] was written by this wave: the lanes read it below)
+            uint32_t room = 0; int entry = 0;
+            const int cnt = mr_spec(rng, g, P, cur, n, wall, 8 - i, placed, room, entry);
+            if (cnt > 0) {
+              i += cnt - 1;
+              if (placed) { cur[n++] = room; wall = entry; }
+              continue;
+            }
+          }
           const int k = rand_int(rng, 0, 3);                       // _rand_elem(sorted({0,1,2,3} - {entryDoorWall}))
           const int exit_wall = k >= wall ? k + 1 : k, next_entry = (exit_wall + 2) & 3;
           int dx, dy;
@@ -1334,8 +1402,16 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   for (int idx = 0; idx < nbest; idx++) {
     const uint32_t r = mr_word<G>(st[2 + idx]);
     const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
+    if constexpr (G::kWave) {
+      // (the room's four walls, lane = position along the wall; in room order like the reference: a later room's walls go over an earlier door)
+      MG_WAVE_LDS_SYNC();
+      if (g.lane < sx) { g.p[ty * W + tx + g.lane] = (uint8_t)CELL_WALL_GREY; g.p[(ty + sy - 1) * W + tx + g.lane] = (uint8_t)CELL_WALL_GREY; }
+      if (g.lane < sy) { g.p[(ty + g.lane) * W + tx] = (uint8_t)CELL_WALL_GREY; g.p[(ty + g.lane) * W + tx + sx - 1] = (uint8_t)CELL_WALL_GREY; }
+      MG_WAVE_LDS_SYNC();
+    } else {
     for (int i = 0; i < sx; i++) { g.set(tx + i, ty, CELL_WALL_GREY); g.set(tx + i, ty + sy - 1, CELL_WALL_GREY); }
     for (int j = 0; j < sy; j++) { g.set(tx, ty + j, CELL_WALL_GREY); g.set(tx + sx - 1, ty + j, CELL_WALL_GREY); }
+    }
     if (idx > 0) {
       const uint32_t k = (uint32_t)rand_int(rng, 0, prev < 6u ? 5 : 6);        // sorted(COLOR_NAMES - {prevDoorColor})
       const uint32_t c = (prev < 6u && k >= prev) ? k + 1u : k;

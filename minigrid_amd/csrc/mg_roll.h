@@ -706,6 +706,58 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   uint32_t spin_polls = 0u; (void)spin_polls;
   constexpr bool nt = NT;                                            // this launch's observation stores are nontemporal (see store12; the host picks the instantiation)
 
+  // COOPERATIVE SPARE FETCH (round 6; the levels that stage no shadow spares: the big grids and the sentence levels).  An env that resets takes its next
+  // episode from the ring in HBM; env_transition's take_spare does that per lane -- CS / 16 dependent 16-byte loads in ONE lane (40 for MultiRoom's 25 x 25)
+  // under a divergent branch the other 63 lanes wait at: with 64 envs per wave and a reset in 0.1-0.8 % of the env-steps that is every second to tenth step
+  // of the dynamics wave.  Here the WAVE fetches the grid -- lane c takes 16-byte piece c: one load instruction, one round trip -- and, fused launches, one
+  // step AHEAD: RESET_PENDING is raised by the step that ends the episode and honoured by the next one, so the load is issued at the end of step j and
+  // its result is written into the LDS grid at the start of step j + 1, behind step j's observation (up to two envs per step; a third falls back to the
+  // per-lane copy).  The first step of a launch fetches and commits in place.
+  constexpr bool COOP = STAGED || GG == GG_SENTENCE || ONE;
+  const bool coop = COOP && GG != GG_DYNOBS && P.use_shadow == 0 && !P.static_gen && P.head != nullptr && cpe > 8 && cpe <= 64 && !MG_EXPBIT(P, 4096);
+  uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
+  unsigned long long pf_mask = 0ull;
+  auto coop_fetch = [&]() __attribute__((always_inline)) {
+    if constexpr (COOP) if (coop) {
+      const bool pend = active && (a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && S.shadow_left == 0u && !MG_EXPBIT(P, 64);
+      unsigned long long m = __ballot(pend);
+      pf_mask = 0ull;
+      if (m) {
+        const uint32_t slot = S.h & P.ring_mask;
+        const int cl = min(lane, cpe - 1);
+        const int b0 = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const size_t se0 = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)slot, b0) * N + (size_t)(env0 + b0);
+        pf0 = ((const uint4*)(P.spare_grid + se0 * CS))[cl];
+        pf_mask = 1ull << b0;
+        if (m) {
+          const int b1 = __ffsll((long long)m) - 1;
+          const size_t se1 = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)slot, b1) * N + (size_t)(env0 + b1);
+          pf1 = ((const uint4*)(P.spare_grid + se1 * CS))[cl];
+          pf_mask |= 1ull << b1;
+        }
+      }
+    }
+  };
+  auto coop_commit = [&]() __attribute__((always_inline)) {
+    if constexpr (COOP) {
+      C.spare_in_lds = false;
+      if (coop && pf_mask) {
+        unsigned long long m = pf_mask;
+        const int b0 = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        if (lane < cpe) { uint32_t* d = (uint32_t*)(sgrid + b0 * GS + lane * 16); d[0] = pf0.x; d[1] = pf0.y; d[2] = pf0.z; d[3] = pf0.w; }
+        if (m) {
+          const int b1 = __ffsll((long long)m) - 1;
+          if (lane < cpe) { uint32_t* d = (uint32_t*)(sgrid + b1 * GS + lane * 16); d[0] = pf1.x; d[1] = pf1.y; d[2] = pf1.z; d[3] = pf1.w; }
+        }
+        C.spare_in_lds = ((pf_mask >> lane) & 1ull) != 0ull;
+        pf_mask = 0ull;
+        MG_WAVE_ORDER();                                   // (DS operations of a wave execute in order: the lanes below read what the wave wrote)
+      }
+    }
+  };
+
   // ---- the pieces of a step ----
   struct StepOut { uint32_t act_in, term, trunc; double reward; uint64_t sent0, sent1; bool show_taken; };
   // action + MiniGridEnv.step / reset on this wave's copy of the grids (+ the sentence levels' verifier)
@@ -740,7 +792,10 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if constexpr (GG == GG_SENTENCE) if (active && P.phase == PHASE_STEP && !MG_EXPBIT(P, 2048))
       IWd.load(MG_INSTR_LDS ? sinstr + lane * ROLL_INSTR_STRIDE : P.instr + (size_t)e * INSTR_WORDS);
     MG_MARK("transition");
+    if (j == 0) coop_fetch();                                // (later steps: issued at the end of the step before)
+    coop_commit();
     if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
+    if constexpr (COOP) C.spare_in_lds = false;
     MG_MARK("after_transition");
     if constexpr (GG == GG_DYNOBS) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
       // Gymnasium's SAME_STEP autoreset: the step that ended the episode also redraws the env; the observation below is the new episode's
@@ -788,6 +843,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         o.sent0 = I[IW_MISSION]; o.sent1 = I[IW_MISSION + 1];
       }
     }
+    if constexpr (!ONE) if (P.phase == PHASE_STEP && j + 1 < P.T) coop_fetch();
     o.show_taken = false;
     if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
       // PutNext(start_carrying): the episode's first core observation shows the object where it was and empty hands (see k_step)

@@ -390,6 +390,7 @@ struct EnvRegs {          // what lives in registers across the steps of a launc
 struct LaneCtx {          // the lane's view of its env: loop-invariant
   int e, el, sub;
   bool active, lead, reset_enabled, maskok, goto_rule;
+  bool spare_in_lds = false; // k_roll7 (round 6): the wave has already copied this env's next spare grid from the ring into its LDS grid (cooperatively, 16 B per lane): take_spare skips its own copy
   bool reset_only = false;   // only take the spare episode of the envs flagged RESET_PENDING (the sentence levels' SAME_STEP autoreset: their episodes end in the verifier, after the step)
   uint8_t* mygrid; const uint8_t* myshadow; const uint64_t* sspr;
 };
@@ -439,6 +440,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         // live LDS grid -- the loads and their wait stay inside this branch
         const size_t se = (size_t)(h & P.ring_mask) * N + (size_t)e;
         const uint4* src = (const uint4*)(P.spare_grid + se * CS);
+        if (!C.spare_in_lds)
         for (int c = sub; c < cpe; c += LPE) {
           const uint4 v = src[c];
           uint32_t* d = (uint32_t*)(mygrid + c * 16);
