@@ -1340,6 +1340,111 @@ MG_D int mr_spec(R& rng, const G& g, const GenParams& P, const uint32_t* cur, in
   rng.wpos += per * (uint32_t)nt;
   return nt;
 }
+// ---- MultiRoom's chain search for ONE LANE per episode (k_refill_lane_packed / k_generate_lane), round 6 ----
+// The c (<= 5) next 32-bit draws of a lane's stream at once.  numpy hands out the halves of one 64-bit PCG64 output one after the other (mg_rng.h
+// Pcg64Stream::next32), so the lanes of a wave disagree about WHICH of two consecutive draws needs the 128-bit LCG step and a wave walking through
+// next32() five times executes five steps, each for half of its lanes.  Here every lane takes ceil((c - has_uint32) / 2) steps -- the first two under no
+// lane condition at all for c = 4 or 5 -- and picks its words out of [cached half] o1.lo o1.hi o2.lo o2.hi o3.lo o3.hi; what is left over is the new
+// cached half: the stream position afterwards is exactly that of c calls of next32().
+template <class R> MG_HD void next32_block(R& r, int c, uint32_t w[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) w[k] = k < c ? r.next32() : 0u;
+}
+MG_HD void next32_block(Pcg64Stream& r, int c, uint32_t w[5]) {
+  const uint32_t h = r.has32;
+  const int need = (c - (int)h + 1) >> 1;
+  uint64_t o1 = 0, o2 = 0, o3 = 0;
+  if (need >= 1) o1 = r.next64();
+  if (need >= 2) o2 = r.next64();
+  if (need >= 3) o3 = r.next64();
+  const uint32_t L[8] = { r.cache32, (uint32_t)o1, (uint32_t)(o1 >> 32), (uint32_t)o2, (uint32_t)(o2 >> 32), (uint32_t)o3, (uint32_t)(o3 >> 32), 0u };
+#pragma unroll
+  for (int k = 0; k < 5; k++) w[k] = h ? L[k] : L[k + 1];
+  // the word after the last one handed out, if a step produced it: index c (cached half in front) or c + 1
+  const int j = h ? c : c + 1;
+  const uint32_t next = j == 1 ? L[1] : j == 2 ? L[2] : j == 3 ? L[3] : j == 4 ? L[4] : j == 5 ? L[5] : L[6];
+  const bool left = (int)h + 2 * need - c == 1;
+  r.has32 = left ? 1u : 0u;
+  r.cache32 = left ? next : r.cache32;
+}
+// _gen_grid's `while len(roomList) < numRooms` (multiroom.py:123-141) with _placeRoom's recursion (:193-283) as ONE flat loop: an iteration is one
+// room placement try -- the first room of a new attempt (draws: entry x, entry y, [sizeX, sizeY]) or one of the eight tries at the next room (draws:
+// exit wall, door offset, [sizeX, sizeY], top offset) -- so the 64 lanes of a wave, each on its own episode, execute the same instructions whatever
+// attempt / room / try they are at, and a wave runs max-over-lanes(tries) iterations instead of the sum of the maxima of three nested loops.
+// The try is evaluated from the raw words with Lemire's multiply; a draw numpy's rejection step could apply to (low product word below the range:
+// probability ~ range / 2^32) sends that lane through the same evaluation on rand_int, from the stream position saved before the block.
+// `bw` = the best chain (what gen_multiroom draws), `cur` = the chain under construction at the start of the lane's (not yet drawn) grid.
+template <class R>
+MG_HD void mr_search_lane(R& rng, const LaneGrid& g, const GenParams& P, int num_rooms, uint32_t bw[6], int& nbest) {
+  const int W = g.W, H = g.H;
+  uint32_t* cur = (uint32_t*)g.p;
+  const int nsz = P.room_size > 4 ? 2 : 0;                 // _rand_int(4, maxSz + 1) over one value draws nothing
+  const uint32_t rsz = (uint32_t)(P.room_size - 3);
+  int n = 0, wall = 2, i = 0;
+  uint32_t parent = 0;
+  nbest = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) bw[k] = 0u;
+  while (nbest < num_rooms) {
+    const bool first = n == 0;
+    const int ptx = (int)(parent & 31u), pty = (int)((parent >> 5) & 31u), psx = (int)((parent >> 10) & 15u), psy = (int)((parent >> 14) & 15u);
+    bool ok = false; uint32_t room = 0; int entry = 2;
+    // one try, its draws taken from `draw(k, r)` = the try's k-th draw over r >= 2 values
+    auto eval = [&](auto&& draw) {
+      const int a = draw(0, first ? (uint32_t)(W - 2) : 3u);
+      const int exit_wall = a >= wall ? a + 1 : a, next_entry = first ? 2 : (exit_wall + 2) & 3;
+      const bool ew_x = (exit_wall & 1) == 0;
+      const int b = draw(1, first ? (uint32_t)(W - 2) : (uint32_t)((ew_x ? psy : psx) - 2));
+      const int d = 1 + b;
+      const int ex = first ? a : exit_wall == 0 ? ptx + psx - 1 : exit_wall == 2 ? ptx : ptx + d;
+      const int ey = first ? b : exit_wall == 1 ? pty + psy - 1 : exit_wall == 3 ? pty : pty + d;
+      int sx = 4, sy = 4;
+      if (nsz) { sx += draw(2, rsz); sy += draw(3, rsz); }
+      int tx = ex, ty = ey;
+      if (!first) {
+        const bool ne_x = (next_entry & 1) == 0;
+        const int t = draw(2 + nsz, (uint32_t)((ne_x ? sy : sx) - 2));
+        tx = next_entry == 0 ? ex - sx + 1 : next_entry == 2 ? ex : ex - sx + 2 + t;
+        ty = next_entry == 1 ? ey - sy + 1 : next_entry == 3 ? ey : ey - sy + 2 + t;
+      }
+      bool fits = tx >= 0 && ty >= 0 && tx + sx <= W && ty + sy < H;
+      for (int q = 0; q + 1 < n; q++) {                    // roomList[:-1]
+        const uint32_t r = cur[q];
+        const int rtx = (int)(r & 31u), rty = (int)((r >> 5) & 31u), rsx = (int)((r >> 10) & 15u), rsy = (int)((r >> 14) & 15u);
+        fits = fits && (tx + sx < rtx || rtx + rsx <= tx || ty + sy < rty || rty + rsy <= ty);
+      }
+      ok = fits; room = mr_pack(tx, ty, sx, sy, ex, ey); entry = next_entry;
+    };
+    const R saved = rng;
+    uint32_t w[5];
+    next32_block(rng, (first ? 2 : 3) + nsz, w);
+    bool unsafe = false;
+    eval([&](int k, uint32_t r) {
+      const uint32_t word = k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : k == 3 ? w[3] : w[4];
+      const uint64_t m = (uint64_t)word * r;
+      unsafe = unsafe || ((uint32_t)m < r && (r & (r - 1u)) != 0u);
+#ifdef MG_MR_TEST_UNSAFE      // (test builds: most tries take the rand_int path from the saved stream position -- tests/test_generators_cpu.py)
+      unsafe = unsafe || (word & 3u) != 0u;
+#endif
+      return (int)(m >> 32);
+    });
+    if (__builtin_expect(unsafe, 0)) {
+      rng = saved;
+      eval([&](int, uint32_t r) { return rand_int(rng, 0, (int)r); });
+    }
+    if (ok) { cur[n] = room; n++; wall = entry; i = 0; parent = room; }
+    else if (!first) i++;
+    const bool end = n >= num_rooms || (first ? !ok : i >= 8);
+    if (end) {
+      if (n > nbest) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) bw[k] = k < n ? cur[k] : bw[k];
+        nbest = n;
+      }
+      n = 0; wall = 2; i = 0;
+    }
+  }
+}
 template <class R, class G>
 MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   const int W = g.W;
@@ -1347,11 +1452,18 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   MrState<G::kWave> state(g.p, P.scratch_off);
   uint32_t* st = state.p;                       // [0] numRooms, [1] rooms in the best chain, [2..7] the best chain
   int num_rooms, nbest;
+  uint32_t bw[6] = { 0u, 0u, 0u, 0u, 0u, 0u };  // the lane form's best chain (registers: the grid it is built in is cleared below)
   if (!out.resume) {
     num_rooms = rand_int(rng, P.num_crossings, P.num_dists + 1);
     nbest = 0;
     st[0] = (uint32_t)num_rooms; st[1] = 0u;
   } else { num_rooms = (int)mr_word<G>(st[0]); nbest = (int)mr_word<G>(st[1]); }
+  if constexpr (!G::kWave) mr_search_lane(rng, g, P, num_rooms, bw, nbest);
+  auto best_room = [&](int idx) -> uint32_t {
+    if constexpr (G::kWave) return mr_word<G>(st[2 + idx]);
+    else return idx == 0 ? bw[0] : idx == 1 ? bw[1] : idx == 2 ? bw[2] : idx == 3 ? bw[3] : idx == 4 ? bw[4] : bw[5];
+  };
+  if constexpr (G::kWave)
   while (nbest < num_rooms && !rng.dead()) {
     MG_GA_ATTEMPT(out);
     rng.checkpoint();                           // st[] is consistent with the stream position here
@@ -1400,7 +1512,7 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
   uint32_t prev = 6u;                           // COLOR_NAMES index of the previous door, 6 = none yet
 #pragma unroll 1
   for (int idx = 0; idx < nbest; idx++) {
-    const uint32_t r = mr_word<G>(st[2 + idx]);
+    const uint32_t r = best_room(idx);
     const int tx = (int)(r & 31u), ty = (int)((r >> 5) & 31u), sx = (int)((r >> 10) & 15u), sy = (int)((r >> 14) & 15u);
     if constexpr (G::kWave) {
       // (the room's four walls, lane = position along the wall; in room order like the reference: a later room's walls go over an earlier door)
@@ -1420,7 +1532,7 @@ MG_HD void gen_multiroom(R& rng, G& g, const GenParams& P, GenResult& out) {
     }
   }
   MG_GA(out, 9);
-  const uint32_t r0 = mr_word<G>(st[2]), rl = mr_word<G>(st[2 + nbest - 1]);
+  const uint32_t r0 = best_room(0), rl = best_room(nbest - 1);
   if (!place_agent(rng, g, (int)(r0 & 31u), (int)((r0 >> 5) & 31u), (int)((r0 >> 10) & 15u), (int)((r0 >> 14) & 15u), -1, out)) out.failed = true;
   int x, y;
   if (!place_obj(rng, g, CELL_GOAL, (int)(rl & 31u), (int)((rl >> 5) & 31u), (int)((rl >> 10) & 15u), (int)((rl >> 14) & 15u),

@@ -210,6 +210,8 @@ struct WavePcg64 {
   uint32_t reg_even, reg_odd;  // per lane: logical draws 2*lane and 2*lane+1 (the first 128 draws live in registers:
                                // v_readlane is ~10x quicker than the LDS round trip, and most episodes need < 128)
   u128 reg_st;                 // per lane: stream state after lane+1 outputs of the first refill
+  u128 si, c64;                // per episode (round 6): S_(lane+1) * inc and S_64 * inc -- the increment's share of a jump does not depend on the state, so a
+                               // refill is two 128-bit multiplies (A_(lane+1) * base, A_64 * base) instead of four; the maze levels refill 4-8 times per episode
   uint64_t w_in[5];            // the words as loaded (the caller snapshots them)
 
   MG_D void prefetch(uint32_t lane_) { lane = lane_; }
@@ -219,6 +221,8 @@ struct WavePcg64 {
 #pragma unroll
     for (int k = 0; k < 5; k++) w_in[k] = uni64(b[k * n + i]);
     inc = ((u128)w_in[2] << 64) | w_in[3];
+    si = (((u128)kPcgJump.s_hi[lane + 1u] << 64) | kPcgJump.s_lo[lane + 1u]) * inc;
+    c64 = (((u128)kPcgJump.s_hi[64] << 64) | kPcgJump.s_lo[64]) * inc;
     off = (uint32_t)(w_in[4] >> 32) & 1u; cache_in = (uint32_t)w_in[4];
     sbase[0] = w_in[0]; sbase[1] = w_in[1];
     buf[0] = cache_in;                       // overwritten by stream word 0 when nothing was carried in
@@ -227,7 +231,7 @@ struct WavePcg64 {
   }
   MG_D void refill() {
     const u128 base = ((u128)uni64(sbase[2 * refills]) << 64) | uni64(sbase[2 * refills + 1]);
-    const u128 st = pcg_jump(base, inc, lane + 1u);
+    const u128 st = (((u128)kPcgJump.a_hi[lane + 1u] << 64) | kPcgJump.a_lo[lane + 1u]) * base + si;
     const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
     const uint64_t x = hi ^ lo;
     const uint32_t rot = (uint32_t)(hi >> 58);
@@ -241,7 +245,7 @@ struct WavePcg64 {
       reg_odd = off ? (uint32_t)o : (uint32_t)(o >> 32);
       reg_st = st;
     }
-    const u128 nb = pcg_jump(base, inc, 64u);
+    const u128 nb = (((u128)kPcgJump.a_hi[64] << 64) | kPcgJump.a_lo[64]) * base + c64;
     sbase[2 * refills + 2] = (uint64_t)(nb >> 64); sbase[2 * refills + 3] = (uint64_t)nb;
     refills++; limit = off + kRefillWords * refills;
     MG_WAVE_LDS_SYNC();

@@ -717,17 +717,24 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const bool coop = COOP && GG != GG_DYNOBS && P.use_shadow == 0 && !P.static_gen && P.head != nullptr && cpe > 8 && cpe <= 64 && !MG_EXPBIT(P, 4096);
   uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
   unsigned long long pf_mask = 0ull;
+  uint64_t pf_agent = 0ull, pf_aux = 0ull;                 // every pending lane's own spare record (a lane-level load, issued with the grids')
+  bool pf_rec = false;
   auto coop_fetch = [&]() __attribute__((always_inline)) {
     if constexpr (COOP) if (coop) {
       const bool pend = active && (a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && S.shadow_left == 0u && !MG_EXPBIT(P, 64);
       unsigned long long m = __ballot(pend);
       pf_mask = 0ull;
+      pf_rec = pend;
       if (m) {
         const uint32_t slot = S.h & P.ring_mask;
         const int cl = min(lane, cpe - 1);
         const int b0 = __ffsll((long long)m) - 1;
         m &= m - 1ull;
         const size_t se0 = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)slot, b0) * N + (size_t)(env0 + b0);
+        // (no lane condition around the load -- a load under a divergent branch is waited for at the branch's end --: the lanes with nothing pending read the first pending env's record)
+        const size_t se_mine = pend ? (size_t)slot * N + (size_t)e : se0;
+        pf_agent = P.spare_agent[se_mine];
+        pf_aux = goto_rule ? P.spare_aux[se_mine] : 0ull;
         pf0 = ((const uint4*)(P.spare_grid + se0 * CS))[cl];
         pf_mask = 1ull << b0;
         if (m) {
@@ -742,6 +749,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   auto coop_commit = [&]() __attribute__((always_inline)) {
     if constexpr (COOP) {
       C.spare_in_lds = false;
+      C.spare_rec_pf = coop && pf_rec; C.pf_agent = pf_agent; C.pf_aux = pf_aux;
+      pf_rec = false;
       if (coop && pf_mask) {
         unsigned long long m = pf_mask;
         const int b0 = __ffsll((long long)m) - 1;
@@ -795,7 +804,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if (j == 0) coop_fetch();                                // (later steps: issued at the end of the step before)
     coop_commit();
     if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
-    if constexpr (COOP) C.spare_in_lds = false;
+    if constexpr (COOP) { C.spare_in_lds = false; C.spare_rec_pf = false; }
     MG_MARK("after_transition");
     if constexpr (GG == GG_DYNOBS) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
       // Gymnasium's SAME_STEP autoreset: the step that ended the episode also redraws the env; the observation below is the new episode's

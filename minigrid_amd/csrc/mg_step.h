@@ -391,6 +391,8 @@ struct LaneCtx {          // the lane's view of its env: loop-invariant
   int e, el, sub;
   bool active, lead, reset_enabled, maskok, goto_rule;
   bool spare_in_lds = false; // k_roll7 (round 6): the wave has already copied this env's next spare grid from the ring into its LDS grid (cooperatively, 16 B per lane): take_spare skips its own copy
+  bool spare_rec_pf = false; // ... and this lane has its next spare's agent record / auxiliary word in pf_agent / pf_aux (loaded one step ahead)
+  uint64_t pf_agent = 0, pf_aux = 0;
   bool reset_only = false;   // only take the spare episode of the envs flagged RESET_PENDING (the sentence levels' SAME_STEP autoreset: their episodes end in the verifier, after the step)
   uint8_t* mygrid; const uint8_t* myshadow; const uint64_t* sspr;
 };
@@ -446,8 +448,8 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           uint32_t* d = (uint32_t*)(mygrid + c * 16);
           d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        a = agent_unpack(P.spare_agent[se]);
-        if (goto_rule) { targets = P.spare_aux[se]; cur = targets; aux_dirty = true; }
+        a = agent_unpack(C.spare_rec_pf ? C.pf_agent : P.spare_agent[se]);
+        if (goto_rule) { targets = C.spare_rec_pf ? C.pf_aux : P.spare_aux[se]; cur = targets; aux_dirty = true; }
         S.ev_reset = 2;
       } else {
         // shadow set 0 first, then set 1 (a level that draws nothing has ONE constant spare and takes it again and again)
