@@ -428,7 +428,15 @@ constexpr int ROLL_MAX_WAVES = 4;
 constexpr int ROLL_LOG_STEPS = MG_ROLL_LOG_STEPS;             // split mode: entries of the dynamics wave's step log (a ring in LDS; power of two)
 static_assert(ROLL_LOG_STEPS >= 2 && (ROLL_LOG_STEPS & (ROLL_LOG_STEPS - 1)) == 0, "the step log is a power-of-two ring");
 constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its progress counters
-constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8;
+// -DMG_SCAL_BY_ENCODE=1 (A/B builds, profiles/variant_build.py; round 6): the 16-byte scalar record of a step stored by the step's ENCODE wave instead of
+// the dynamics wave.  The store-only model of this launch shape (profiles/microbench/rollstore2.hip, profiles/r6/rollstore2.txt) runs 2.27 us per step with
+// the scalars stored by a wave that is up to eight steps ahead of the observations and 2.05 with the scalars stored next to their observations; the kernel
+// does not follow: Empty-8x8 x 65 536 2.19-2.23 -> 2.18 us per step, DoorKey-8x8 x 262 144 8.15 -> 8.46-8.49 (profiles/r6/ab_scalars_by_encode_wave.txt).
+// Measured, not adopted; the whole GPU suite is green with it.
+#ifndef MG_SCAL_BY_ENCODE
+#define MG_SCAL_BY_ENCODE 0
+#endif
+constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8 + (MG_SCAL_BY_ENCODE ? ROLL_LOG_STEPS * 64 * 2 : 0);   // (pose, delta) per env and entry (+ the step count the reward is priced on)
 #ifndef MG_DYN_WPE
 // waves per SIMD the register allocation of k_roll7<GG_DYNOBS> aims at: 4 = 128 VGPRs (three spilled, outside the placement loop) against 149.
 // Measured (profiles/r4/dynobs_waves_sweep2.txt, 65 536 envs): 16x16 12.5 us per step against 18.2, 8x8 12.3 against 17.8, Random-6x6 17.6 against 24.5
@@ -862,12 +870,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   };
   auto slot_of = [&](int j) { int s_ = P.slot0 - j; s_ += s_ < 0 ? P.S : 0; return s_; };   // (T <= S and slot0 < S: at most one wrap; a loop here compiled to a scalar division)
   // reward / terminated / truncated / direction / mission id / action of step j -> its trajectory slot
-  auto store_scalars = [&](int slot_out, const StepOut& o) {
+  auto store_scalars = [&](int slot_out, const StepOut& o, bool mine = true) {
     MG_MARK("scalars");
     errs_mine |= S.errbits;
     if (P.phase == PHASE_STEP) fin_total += (uint32_t)__popcll(__ballot(active && (o.term | o.trunc)));
     uint8_t* ob = P.out + (size_t)slot_out * P.slot_bytes;
-    if (active && !MG_EXPBIT(P, 8)) {
+    if (active && mine && !MG_EXPBIT(P, 8)) {
       // {reward f64 | terminated, truncated, direction, action u8 | mission id u16 | 0}: ONE 16-byte store per env (six partial-line
       // stores cost the dynamics wave 0.3 of the 2.4 us of a 65 536-env step: profiles/r4/attribution_split.txt)
       uint4 v;
@@ -1102,18 +1110,32 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the dynamics wave is the one serial chain everything else waits for: it wins issue arbitration against the encode waves on its SIMD
     // (profiles/r4/ab_prio.txt: 2.42 -> 2.28 us per 65 536-env step)
     __builtin_amdgcn_s_setprio(MG_DPRIO);
+    uint16_t* log3 = (uint16_t*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8);
     for (int j = 0; j < P.T; j++) {
       StepOut o;
       dynamics(j, o);
-      store_scalars(slot_of(j), o);
-      // pose: x | y << 8 | dir << 16 | what the agent's cell shows (the carried object; nothing under show_taken) << 24
-      const uint32_t pose = a.x | (a.y << 8) | (a.dir << 16) | ((o.show_taken ? 0u : a.carry) << 24);
+      // SCALARS BY THE STEP'S ENCODE WAVE (round 6).  The 16-byte scalar record of a step was stored here, by the dynamics wave -- up to ROLL_LOG_STEPS
+      // steps ahead of the observations, i.e. into trajectory slots the observation stream reaches microseconds later: two write streams 10 MB apart.
+      // profiles/microbench/rollstore2.hip (this launch shape, stores only): 2.27 us per step that way, 2.05 with the step's scalars stored by the wave
+      // that stores its observations (= the observation stream alone).  The log entry carries what the record needs beyond the pose: terminated,
+      // truncated, the action, and the reward as a CODE -- 0 = 0.0, 1 = reward_exact(step count, max_steps) (the step count rides in a third,
+      // 16-bit log word), 2 = -1.0, 3 = anything else: that lane's record is stored here, as before, and the encode wave leaves it alone.
+      // (the mission id is followed by the encode waves themselves: it changes with the episode only)
+      uint32_t rcode = 3u;
+      if constexpr (MG_SCAL_BY_ENCODE) { rcode = 0u;
+      if (__builtin_bit_cast(uint64_t, o.reward) != 0ull)
+        rcode = __builtin_bit_cast(uint64_t, o.reward) == __builtin_bit_cast(uint64_t, reward_exact(a.step, P.max_steps)) ? 1u : o.reward == -1.0 ? 2u : 3u;
+      if (o.act_in > 7u) rcode = 3u;                                   // (an unknown action from the caller: the record as it always was; the call raises anyway)
+      }
+      store_scalars(slot_of(j), o, rcode == 3u);
+      // pose: x | y << 8 | dir << 16 | terminated << 18 | truncated << 19 | action << 20 | reward code bit 0 << 23 | what the agent's cell shows (the carried object; nothing under show_taken) << 24
+      const uint32_t pose = a.x | (a.y << 8) | (a.dir << 16) | (o.term << 18) | (o.trunc << 19) | ((o.act_in & 7u) << 20) | ((rcode & 1u) << 23) | ((o.show_taken ? 0u : a.carry) << 24);
       // delta: [0:10) cell, [10:18) code, [18:20) reset kind (1 = staged shadow spare, 2 = ring slot in HBM), [20] shadow set, [21] show_taken
       // (cell / code = where the taken object is drawn for this one observation), [22:30) ring slot, [30] the cell changed for good
       uint32_t delta;
       if (o.show_taken) delta = (uint32_t)(S.targets & 0x3FFull) | (a.carry << 10) | (1u << 21);
       else delta = S.ev_dirty_idx >= 0 ? ((uint32_t)S.ev_dirty_idx | (S.ev_dirty_code << 10) | (1u << 30)) : 0u;
-      delta |= ((S.ev_reset & 3u) << 18) | ((S.ev_reset == 1u ? S.ev_shadow & 1u : 0u) << 20) | (((S.h - 1u) & P.ring_mask & 0xFFu) << 22);
+      delta |= ((S.ev_reset & 3u) << 18) | ((S.ev_reset == 1u ? S.ev_shadow & 1u : 0u) << 20) | (((S.h - 1u) & P.ring_mask & 0xFFu) << 22) | ((rcode >> 1) << 31);
       if (j >= ROLL_LOG_STEPS) {
         // flow control: entry j reuses the slot of entry j - ROLL_LOG_STEPS, which every encode wave must have consumed
         const uint32_t need = (uint32_t)(j - ROLL_LOG_STEPS + 1);
@@ -1127,6 +1149,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         }
       }
       logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = make_uint2(pose, active ? delta : 0u);
+      if constexpr (MG_SCAL_BY_ENCODE) log3[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] = (uint16_t)a.step;
       // (DS operations of one wave execute in order: the counter cannot become visible before the entry; the compiler must keep that order)
       MG_WAVE_ORDER();
       sync[0] = (uint32_t)(j + 1);
@@ -1140,20 +1163,25 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     const uint2* logbuf = (const uint2*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES);
     const int k = ek, NE = NW - 1;
     int mine = k;                                                      // next step this wave produces
+    const uint16_t* log3 = (const uint16_t*)(smem + P.off_log + ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8);
+    uint32_t mission = a.mission;                                      // this lane's env's mission id: the episode's (followed through the resets below)
     for (int j = 0; j < P.T; j++) {
       spin_polls = 0u;
       while ((uint32_t)__builtin_amdgcn_readfirstlane((int)sync[0]) <= (uint32_t)j) { __builtin_amdgcn_s_sleep(1); MG_SPIN_COUNT(1); MG_SPIN_POLL(spin_polls); }
       MG_WAVE_ORDER();
       const uint2 rec2 = logbuf[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane];
+      const uint32_t st16 = MG_SCAL_BY_ENCODE ? log3[(j & (ROLL_LOG_STEPS - 1)) * 64 + lane] : 0u;      // (read before the entry is reported consumed below)
       const uint32_t delta = rec2.y;
       const uint32_t rk = (delta >> 18) & 3u;
       if (__ballot(rk != 0u)) {
         if (rk == 1u) {
           const uint32_t* s4 = (const uint32_t*)(C.myshadow + ((delta >> 20) & 1u) * (uint32_t)P.shadow_stride);
           lds_copy_dwords((uint32_t*)mygrid, s4, CS >> 2);
+          if constexpr (MG_SCAL_BY_ENCODE) mission = agent_unpack(*(const uint64_t*)((const uint8_t*)C.sspr + ((delta >> 20) & 1u) * (uint32_t)P.spr_stride)).mission;
         } else if (rk == 2u) {
           // the env's second reset of this launch: its spare comes straight from the ring in HBM (loads and their wait stay inside this branch)
           const size_t se = (size_t)((delta >> 22) & 0xFFu) * N + (size_t)e;
+          if constexpr (MG_SCAL_BY_ENCODE) mission = agent_unpack(P.spare_agent[se]).mission;
           const uint4* src = (const uint4*)(P.spare_grid + se * CS);
           for (int c = 0; c < (CS >> 4); c++) {
             const uint4 v = src[c];
@@ -1172,6 +1200,20 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       Agent av;
       av.x = rec2.x & 0xFFu; av.y = (rec2.x >> 8) & 0xFFu; av.dir = (rec2.x >> 16) & 3u; av.carry = rec2.x >> 24;
       av.step = 0; av.flags = 0; av.mission = 0;
+      {
+        // the step's scalar record, ahead of its observation rounds (see the dynamics wave; mg_step_scalars: {reward f64 | terminated, truncated,
+        // direction, action u8 | mission id u16 | 0}, ONE 16-byte store per env)
+        const uint32_t rcode = ((rec2.x >> 23) & 1u) | ((delta >> 31) << 1);
+        if (MG_SCAL_BY_ENCODE && active && rcode != 3u && !MG_EXPBIT(P, 8)) {
+          double rew = 0.0;
+          if (rcode == 1u) rew = reward_exact(st16, P.max_steps); else if (rcode == 2u) rew = -1.0;
+          uint4 v;
+          v.x = (uint32_t)__double2loint(rew); v.y = (uint32_t)__double2hiint(rew);
+          v.z = ((rec2.x >> 18) & 1u) | (((rec2.x >> 19) & 1u) << 8) | (av.dir << 16) | (((rec2.x >> 20) & 7u) << 24);
+          v.w = mission & 0xFFFFu;
+          *(uint4*)(P.out + (size_t)slot_of(j) * P.slot_bytes + o_scal) = v;
+        }
+      }
       observe(slot_of(j), av, ((delta >> 21) & 1u) != 0u, delta & 0x3FFu, (delta >> 10) & 0xFFu, scodes, 3);
     }
     MG_SPIN_REPORT(1);
