@@ -34,7 +34,7 @@ UNITS = {
     "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP,
 }
 for _u in ("", "_a", "_b", "_c", "_d"):          # the lane-per-episode generator kernels, by generator function (mg_gen_lane_tu.inc)
-    UNITS[f"mg_gen_lane{_u}.hip"] = _GEN + ["mg_genlane.h", "mg_gen_lane_tu.inc"]
+    UNITS[f"mg_gen_lane{_u}.hip"] = _GEN + ["mg_genlane.h", "mg_genmr.h", "mg_gen_lane_tu.inc"]
 for _g in ("rooms", "sentence", "roomgrid", "light"):
     for _r in ("pcg", "philox"):
         for _k in ("refill", "generate"):

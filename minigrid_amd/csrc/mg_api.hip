@@ -122,6 +122,7 @@ struct mg_env {
   size_t ncounters = 0;
   Knobs k;                                       // the environment's A/B switches and debugging aids, read once at mg_create (mg_knobs.h)
   bool staged_big = false;                       // k_roll7's STAGED instantiation: big grids, one copy of the grids per workgroup
+  int k_epw = 64;                                // envs per k_roll7 workgroup of the 7x7 view (64 | 32): decides the LDS carve-up (roll_layout)
   bool mask_sparse = false;                      // the reset in progress is masked and resets fewer than an eighth of the envs
   uint64_t env_steps = 0;     // env-steps executed (host-side count: N per step)
   unsigned long long burst_bytes = 0;   // output bytes of the launches enqueued since the step stream was last known idle (launch_step: nontemporal stores)
@@ -348,13 +349,14 @@ static RollLayout roll_layout(const mg_env* e, int nw, bool with_actions, bool s
   // (DynamicObstacles in the loop, split: ONE copy of the grids -- the dynamics wave's, which stages the codes itself -- and a ring of stagings)
   const bool dsplit = split && (e->dyn_inloop || (e->sentence && e->fast7) || e->fast_full || e->staged_big);
   L.off_grid = 1024 + e->roll_guard;
-  L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * 64 * e->GS + e->roll_guard + 15) & ~15;
+  const int epw = (e->fast7 && !e->fast_full) ? e->k_epw : 64;            // envs per workgroup (the 7x7 view: 64, or 32 -- mg_env::k_epw)
+  L.off_codes = (L.off_grid + (dsplit ? 1 : nw) * epw * e->GS + e->roll_guard + 15) & ~15;
   const int ncodes = dsplit ? roll_dring(e) + (e->fast_full ? 1 : 0) : split ? nw - 1 : nw;   // (FullyObs: the dynamics wave's own image-order stream + the ring of staged copies)
   // per wave: the 7x7 view's code staging, or (FullyObs) the image-order stream of its 64 grids
   L.codes_stride = e->fast_full ? ((64 * e->cells + 16 + 15) & ~15) : ROLL_CODES_BYTES;
   // the shadow sets (the next one or two spare episodes of every env): grids, (FullyObs) their image streams, agent / aux words
   const int K = e->dyn_inloop ? 0 : e->roll_shadows;                   // (DynamicObstacles in the loop: no spare ring, nothing to stage)
-  L.shadow_stride = (64 * e->GS + 15) & ~15;
+  L.shadow_stride = (epw * e->GS + 15) & ~15;
   L.off_shadow = L.off_codes + ncodes * L.codes_stride;
   L.off_shadow_gt = L.off_shadow + K * L.shadow_stride;
   L.off_spr = L.off_shadow_gt + (e->fast_full ? K * L.codes_stride : 0);
@@ -767,6 +769,7 @@ static const char* configure_obs(mg_env* e) {
     else { e->lpe = 1; e->epw = 64; e->nwaves = (e->N + 63) / 64; }
   }
   e->roll_split_on = e->k.roll_split;
+  e->k_epw = e->k.roll_epw;
   e->dyn_inloop = e->live_gen && e->fast7 && !e->fast_full && e->k.dyn_inloop != 0;
   if (e->fast7 || e->fast_full) {
     // k_roll7 (mg_roll.h): NW wavefronts per workgroup, each with a private copy of the 64 grids and its own code staging.  As many
@@ -798,7 +801,7 @@ static const char* configure_obs(mg_env* e) {
     // empty.  Measured in round 4 and NOT adopted (profiles/r4/epw32.txt): GoToRedBall x 32 768 4.9 us per step against 2.9, Empty-8x8 x 32 768
     // 1.60 against 1.37, x 16 384 1.28 against 1.32 -- the wave-instructions double and the chains do not get shorter.  The switch stays
     // for A/B runs; tests/test_gpu_roll.py keeps the path exact.
-    const int epw = e->k.roll_epw;
+    const int epw = e->k_epw;
     e->epw = epw; e->nwaves = (e->N + epw - 1) / epw;
   }
   if (e->lds_bytes > 160 * 1024) return "grid too large for the LDS staging";
@@ -1140,7 +1143,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // BabyAI-GoTo episodes/s -- so the crossover moved: 65 536 requests for them.  A de-phased BabyAI-GoTo x 131 072 batch files ~30 000 requests per refill:
     // 5.98 G env-steps/s with the old threshold (some batches went to lanes), 7.71 G without lanes; a synchronized truncation burst (131 072 requests) still
     // refills on lanes: 8.22 G.  MultiRoom (36 M episodes/s on lanes against 15 M) and the sentence levels keep 32 768.  profiles/r6/ab_staged_big_grids_burst_threshold_dephase.txt)
-    e->lane_burst_min = (e->lane_direct && !e->lane_gen) ? ((cfg->env_kind == MG_ENV_MULTIROOM || (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN)) ? 32768 : 65536) : 0;
+    // (MultiRoom since mg_genmr.h -- the chain search as one flat loop, no grid per lane, 8 KB of LDS per generating wavefront: lanes take every batch
+    // of 1 024 requests or more.  MultiRoom-N6 x 65 536, de-phased: 5.9-6.0 G env-steps/s on k_refill, 7.5-7.6 on lanes; synchronized bursts 6.2 / 9.2;
+    // 64 lanes per wavefront -- 32: 7.6 / 8.7, 16: 6.8 / 7.5, 8: 6.0 / 6.7.  profiles/r6/bench_lines_multiroom_lanes.txt)
+    e->lane_burst_min = (e->lane_direct && !e->lane_gen) ? (cfg->env_kind == MG_ENV_MULTIROOM ? 1024 : (cfg->env_kind >= MG_ENV_OPENTWODOORS && cfg->env_kind <= MG_ENV_LEVELGEN) ? 32768 : 65536) : 0;
     if (e->k.lane_burst >= 0 && e->lane_direct && !e->lane_gen) e->lane_burst_min = e->k.lane_burst;
     e->lane_lpw = e->k.lane_lpw;
   }

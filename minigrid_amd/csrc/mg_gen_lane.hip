@@ -6,6 +6,7 @@
 #define MG_LANE_TU_REFILL 1
 #define MG_LANE_TU_FNS(X) X(0) X(2) X(5)
 #include "mg_gen_lane_tu.inc"
+#include "mg_genmr.h"
 
 namespace mg {
 
@@ -21,9 +22,11 @@ bool launch_refill_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, cons
 // packed refill: the batch's requests numbered across the segments first (A.seg_off, written here), A.lpw busy lanes per wavefront
 bool launch_refill_lane_packed(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
   hipLaunchKernelGGL(k_seg_scan<0>, dim3(1), dim3(SEG_SCAN_THREADS), SEG_SCAN_THREADS * sizeof(uint32_t), st, A.seg_count, const_cast<uint32_t*>(A.seg_off), A.nseg);
+  if (mr_lanes_ok(A.gp, A.CS)) return launch_lane_mr(1, philox, grid, st, A);         // MultiRoom: no grid per lane (mg_genmr.h)
   return launch_lane_any(1, lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A);
 }
 bool launch_generate_lane(bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A) {
+  if (mr_lanes_ok(A.gp, A.CS)) return launch_lane_mr(2, philox, grid, st, A);
   return launch_lane_any(2, lane_fn_of_kind(A.gp.kind), philox, grid, lds, st, A);
 }
 

@@ -50,6 +50,8 @@ bool launch_lane_a(int which, int fn, bool philox, dim3 grid, size_t lds, hipStr
 bool launch_lane_b(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
 bool launch_lane_c(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
 bool launch_lane_d(int which, int fn, bool philox, dim3 grid, size_t lds, hipStream_t st, const GenArgs& A);
+// MultiRoom's grid-free lane kernels (mg_genmr.h, unit a): which = 1 packed refill | 2 direct generation; the launch sizes its own LDS
+bool launch_lane_mr(int which, bool philox, dim3 grid, hipStream_t st, const GenArgs& A);
 // dispatch on (generator group, stream kind)
 #define MG_GEN_DISPATCH(FN, gg, philox, ...)                                                       \
   do {                                                                                             \

@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // dynamics wave's, which also stages every step's codes (FullyObs: a copy of its image-order stream)
   const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL || STAGED) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
-  uint8_t* sgrid = smem + P.off_grid + mycopy * (64 * GS);           // this wave's private copy of the 64 grids
+  uint8_t* sgrid = smem + P.off_grid + mycopy * (EPW * GS);          // this wave's private copy of the workgroup's grids
   uint8_t* scodes = smem + P.off_T + (dsplit ? 0 : split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
   const int cells = P.cells, OBE = FULL ? cells * 3 : PARTIAL_OBS_BYTES;                           // observation bytes per env
   uint8_t* sshadow = smem + P.off_shadow;
