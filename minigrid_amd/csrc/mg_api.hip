@@ -202,7 +202,7 @@ static GenArgs gen_args(mg_env* e, int slot) {
   // LevelGen, num_crossings bit 10: an episode whose drawing met RoomGrid.place_agent's endless loop is redrawn and accepted
   A.stuck_mode = (e->cfg.env_kind == MG_ENV_LEVELGEN && ((e->cfg.num_crossings >> 10) & 1)) ? 2 : (to_spare ? 0 : 1);
   A.seg = nullptr; A.seg_count = nullptr; A.seg_cap = e->seg_cap; A.wps = 1;
-  A.seg_off = nullptr; A.nseg = 0; A.lpw = 64; A.burst_min = 0u;
+  A.seg_off = nullptr; A.nseg = 0; A.lpw = 64; A.burst_min = 0u; A.slot_cap = 0u;
   A.head = e->head; A.tail = e->tail; A.claim = e->claim; A.epoch = 0; A.ring_mask = (uint32_t)(e->R - 1);
   return A;
 }
@@ -251,6 +251,9 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
   const int gg = gen_group_of_kind(e->cfg.env_kind);
   const bool philox = e->cfg.rng_mode == MG_RNG_PHILOX;
   const dim3 rgrid(e->nwaves * A.wps);
+  // (lane refills: GenArgs::slot_cap -- a request draws a quarter of its env's free slots, at least two; MG_LANE_CAP: the minimum, 0 = every free slot as
+  // before.  GoToRedBall x 32 768: 2.76 us per step without, 2.39-2.55 with a fixed cap of 2-4: profiles/r6/ab_lane_cap.txt)
+  if (!live && (e->lane_gen || e->lane_burst_min > 0) && e->R >= 16) A.slot_cap = e->k.lane_cap >= 0 ? (uint32_t)e->k.lane_cap : 2u;
   if (!live && e->lane_gen) {
     // one LANE per episode (mg_genlane.h): a wavefront per request segment, each lane drawing its own request's episodes
     bool ok;
@@ -260,7 +263,7 @@ static int launch_refill(mg_env* e, int set, uint32_t epoch, bool live, hipStrea
       const unsigned blocks = (unsigned)std::min<long long>(((long long)e->N + A.lpw - 1) / A.lpw, 16384);
       ok = launch_refill_lane_packed(philox, dim3(blocks), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
     } else {
-      A.wps = 2;
+      A.wps = 2;                               // (round 6, profiles/r6/ab_lane_wps.txt: GoToRedBall x 32 768 2.7 us per step with 2, 3.2 with 3, 3.6 with 4, 4.3 with 1 -- what a refill costs is wavefronts x longest lane chain)
       ok = launch_refill_lane(philox, dim3(e->nwaves * A.wps), (size_t)lane_gen_lds_bytes(e->CS, e->sentence), st, A);
     }
     if (!ok) return fail(e, MG_ERR_INVALID, "internal: no lane refill kernel for env_kind %d (packed %d)", e->cfg.env_kind, (int)e->lane_packed);
@@ -788,8 +791,8 @@ static const char* configure_obs(mg_env* e) {
     // step is its placement loop, so the encode waves idle most of the time: three waves of ~150 VGPRs leave room for four workgroups per CU.
     if (e->dyn_inloop) nw = 3;
     // the big grids (more than 256 cells) of the ring levels: the STAGED split (mg_roll.h) -- the dynamics wave + ONE encode wave over one copy of the grids
-    // (a private copy per wave left them one wave per workgroup).  MG_ROLL_STAGED=0: the one-wave form (A/B).
-    e->staged_big = e->fast7 && !e->fast_full && !e->sentence && !e->dyn_inloop && !e->static_gen && e->cells > 256 && e->k.roll_staged;
+    // (a private copy per wave left them one wave per workgroup).
+    e->staged_big = e->fast7 && !e->fast_full && !e->sentence && !e->dyn_inloop && !e->static_gen && e->cells > 256;
     if (e->staged_big) nw = 2;
     if (e->k.roll_nw >= 1 && e->k.roll_nw <= ROLL_MAX_WAVES) nw = e->k.roll_nw;
     e->roll_nw = nw;
@@ -1130,7 +1133,10 @@ int mg_create(const mg_config* cfg, int device, void* stream, mg_env** out) {
     // MG_LANE_LPW: busy lanes per wavefront of the packed refill (1..64).
     const bool tuned_sparse = lane_gen_kind_base(cfg->env_kind) || lane_gen_kind_product_fn(cfg->env_kind);
     e->lane_gen = lane_on && tuned_sparse;
-    e->lane_packed = e->lane_gen && e->k.lane_packed;
+    // (round 6: the Unlock family and KeyCorridor refill PACKED by default -- long episodes, ~30 requests per segment and batch: whole wavefronts of busy
+    // lanes instead of two half-empty ones per segment.  KeyCorridorS3R3 x 131 072: 20.7 -> 22.4 G env-steps/s, profiles/r6/ab_lane_wps.txt; the
+    // single-room levels with many resets keep the per-segment form -- GoToRedBall x 32 768: 11.0 per segment, 5.5 packed.  MG_LANE_PACKED=0 / 1: A/B)
+    e->lane_packed = e->lane_gen && (e->k.lane_packed >= 0 ? e->k.lane_packed == 1 : lane_gen_kind_product_fn(cfg->env_kind));
     // (from 16 384 envs on: a call of k_generate_lane lasts as long as its slowest lane -- ~5 ms for a maze level whatever the batch --, a call of the
     // cooperative k_generate ~0.8 ms + N / 4.3 M episodes/s: lanes win above ~18 000 envs.  MG_LANE_DIRECT: 0 = never, 1 = at every batch size)
     const int dmode = e->k.lane_direct;

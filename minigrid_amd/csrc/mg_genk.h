@@ -39,6 +39,12 @@ struct GenArgs {
   // served by k_refill_lane_packed -- dense lanes, throughput --, a smaller one by k_refill -- cooperative wavefronts, latency; both kernels are
   // launched and the one whose case it is not returns at once (0 = off: no such check)
   uint32_t burst_min;
+  // lane refills (round 6): a request draws max(slot_cap, a quarter) of its env's free ring slots while the ring is at least half full (0 = all of them;
+  // refill_slots, mg_genlane.h).  A lane draws its
+  // env's free slots one after the other (one stream), so a wavefront runs as long as its longest chain -- BabyAI-GoToRedBall consumes 2.3 spares per env
+  // and batch on average, the unluckiest of 64 lanes 7-10 -- and what the refill costs the chip is wavefronts x longest chain.  The ring is 256 deep: a slot
+  // left for the env's next request (it resets again soon: that is why it had so many) is drawn then; nothing reads a ring's fill level but the kernels.
+  uint32_t slot_cap;
 };
 
 

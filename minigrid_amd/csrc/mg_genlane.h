@@ -181,13 +181,22 @@ MG_HD void generate_one_lane(const GenArgs& A, int e, uint32_t slot, LaneGrid& g
 // one wave with 36 diverging lanes does not (GoToRedBall x 32 768: 10.1 us per step with one wave per segment, see profiles/r4/lane_refill.txt).
 // (FN: the wide build's kernels, one per generator function -- lane_fn_of_kind; 0 = the product kernel)
 // one refill request on one lane: env e, every ring slot from tail to head + R - 1 in stream order
+// How many of an env's `want` free ring slots one request draws now (GenArgs::slot_cap, mg_genk.h): all of them without a cap or once the ring is more
+// than half empty; otherwise a quarter of them, at least slot_cap -- the backlog of an env that consumes c spares per batch settles near 4 c, every lane's
+// chain near c, instead of the Poisson tail of the 64 lanes' own last batch.
+MG_HD uint32_t refill_slots(const GenArgs& A, uint32_t want) {
+  if (!A.slot_cap || want > (A.ring_mask + 1u) / 2u) return want;
+  const uint32_t q = (want + 3u) >> 2;
+  return min(want, max(A.slot_cap, q));
+}
 template <class R, int FN>
 MG_D void refill_lane_request(const GenArgs& A, int e, LaneGrid& g, uint64_t* iw) {
   const uint32_t old = atomicMax(&A.claim[e], A.epoch);
   if (old >= A.epoch) return;                                 // another request of this batch already covers the env
-  const uint32_t h = A.head[e] + A.ring_mask + 1u;            // every slot below head + R is free to fill
+  uint32_t h = A.head[e] + A.ring_mask + 1u;                  // every slot below head + R is free to fill
   uint32_t t = A.tail[e];
   if (h - t > A.ring_mask + 1u) { report_errors(A.err, (uint32_t)ERR_GENERATOR); return; }   // ring bookkeeping broken: never spin
+  h = t + refill_slots(A, h - t);                              // (GenArgs::slot_cap: the rest with the env's next request)
   while (t != h) {
     generate_one_lane<R, FN>(A, e, t & A.ring_mask, g, iw);
     t++;

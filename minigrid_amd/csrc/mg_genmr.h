@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(64) k_refill_lane_packed_mr(const GenArgs A) {
         t = A.tail[e];
         if (h - t > A.ring_mask + 1u) report_errors(A.err, (uint32_t)ERR_GENERATOR);   // ring bookkeeping broken: never spin
         else work = true;
+        if (work) h = t + refill_slots(A, h - t);               // (GenArgs::slot_cap)
       }
     }
     while (__ballot(work && t != h)) {                         // (wave-uniform: a round draws one ring slot of every lane that has one left)

@@ -58,6 +58,11 @@ PRODUCT_CASES = [
     # ... and the packed refill for the levels whose refill runs on lanes (MG_LANE_PACKED=1: A/B)
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 300, "launches": [32, 32, 7], "max_steps": 4, "knobs": {"MG_LANE_PACKED": "1"}},
     {"env": "BabyAI-GoToRedBall-v0", "n": 200, "launches": [32, 13], "max_steps": 3, "knobs": {"MG_LANE_PACKED": "1", "MG_LANE_LPW": "16"}},
+    # round 6: lane refills draw at most MG_LANE_CAP ring slots per request while the ring is half full (GenArgs::slot_cap; rings of 16: the cap is live);
+    # MultiRoom's grid-free lane kernels (mg_genmr.h) with every refill on packed lanes
+    {"env": "BabyAI-GoToRedBall-v0", "n": 100, "launches": [32, 32, 13, 32], "max_steps": 3, "spare_ring": 16, "knobs": {"MG_LANE_CAP": "1"}},
+    {"env": "MiniGrid-KeyCorridorS3R3-v0", "n": 100, "launches": [32, 7, 32], "max_steps": 5, "spare_ring": 16, "knobs": {"MG_LANE_CAP": "2"}},
+    {"env": "MiniGrid-MultiRoom-N6-v0", "n": 200, "launches": [32, 32, 7, 32], "max_steps": 5, "spare_ring": 16, "knobs": {"MG_LANE_BURST": "1", "MG_LANE_DIRECT": "1", "MG_LANE_CAP": "2"}},
     # k_step: the other observation modes (one-hot, symbolic, ViewSizeWrapper, FullyObs above 341 cells), DynamicObstacles' round-3 launches
     # (live refill + k_move_obstacles) under FullyObs, RGB frames (tile map + k_render)
     {"env": "MiniGrid-DoorKey-8x8-v0", "n": 70, "launches": [16], "max_steps": 6, "obs_mode": "onehot", "stepped": 3},
