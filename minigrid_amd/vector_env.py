@@ -386,10 +386,10 @@ class MiniGridVecEnv(_VectorEnvBase):
         if self._final_obs:
             return self._same_step_with_final_obs(obs, rew, term, trunc)
         if self._composed_same_step:
-            return self._same_step_with_final_obs(obs, rew, term, trunc)[:4] + ({},)
+            return self._same_step_with_final_obs(obs, rew, term, trunc, want_final=False)
         return obs, rew, term, trunc, {}
 
-    def _same_step_with_final_obs(self, obs, rew, term, trunc):
+    def _same_step_with_final_obs(self, obs, rew, term, trunc, want_final=True):
         """SAME_STEP by composition (see __init__): `obs` is the step kernel's NEXT_STEP output, i.e. the terminal observation for the envs
         that just finished.  Those envs take their next episode now (masked reset, each continuing its own stream) and the returned
         observation shows it; the terminal one goes to info["final_obs"]."""
@@ -401,11 +401,14 @@ class MiniGridVecEnv(_VectorEnvBase):
                 return obs, rew, term, trunc, {}
             # the outputs are views of trajectory slot 0, which the reset launch rewrites: keep what this step reported
             rew, term, trunc = rew.clone(), term.clone(), trunc.clone()
-            idx = torch.nonzero(done).flatten()
-            final = obs[idx].clone() if self.image_only else {k: v[idx].clone() for k, v in obs.items()}
+            if want_final:
+                idx = torch.nonzero(done).flatten()
+                final = obs[idx].clone() if self.image_only else {k: v[idx].clone() for k, v in obs.items()}
             mask = done.to(torch.uint8).cpu().numpy()
             B.check(self._lib.mg_reset(self._h, None, self._p(np.ascontiguousarray(mask))), self._h)
             new_obs, _, _, _ = self._collect()
+            if not want_final:          # (composed SAME_STEP without final_obs=True: only the masked reset and the new observations -- ADVICE r5)
+                return new_obs, rew, term, trunc, {}
             # torch outputs: the terminal observations of the finished envs as COMPACT tensors (row j belongs to env final_obs_indices[j])
             # instead of Gymnasium's object array of per-env dicts; the mask keys are the same as on the numpy path.  (The `.any()`
             # above is a host synchronisation per step: this mode composes two launches on the host and needs to know whether the second
@@ -415,12 +418,17 @@ class MiniGridVecEnv(_VectorEnvBase):
         done = term | trunc
         if not done.any():
             return obs, rew, term, trunc, {}
-        idx = np.flatnonzero(done)
-        fo = np.full(n, None, dtype=object)
-        for i in idx:
-            fo[i] = obs[i] if self.image_only else {"image": obs["image"][i], "direction": obs["direction"][i], "mission": obs["mission"][i]}
+        if want_final:
+            idx = np.flatnonzero(done)
+            fo = np.full(n, None, dtype=object)
+            for i in idx:
+                fo[i] = obs[i] if self.image_only else {"image": obs["image"][i], "direction": obs["direction"][i], "mission": obs["mission"][i]}
+        else:
+            rew, term, trunc = rew.copy(), term.copy(), trunc.copy()      # (views of trajectory slot 0, which the reset launch rewrites)
         B.check(self._lib.mg_reset(self._h, None, self._p(np.ascontiguousarray(done.astype(np.uint8)))), self._h)
         new_obs, _, _, _ = self._collect()
+        if not want_final:
+            return new_obs, rew, term, trunc, {}
         return new_obs, rew, term, trunc, {"final_obs": fo, "_final_obs": done, "final_info": np.full(n, None, dtype=object), "_final_info": done}
 
     def _no_fused_with_final_obs(self):
