@@ -6,6 +6,7 @@
 #pragma once
 #include "mg_device.h"
 #include "mg_rng.h"
+#include "mg_dynobs.h"      // dynobs_draw_xy: one PCG64 step per pair of bounded draws (gen_goto_lane)
 
 namespace mg {
 
@@ -122,6 +123,17 @@ struct LaneGrid {
     if (W * H <= 64) nonempty = c == CELL_EMPTY ? nonempty & ~(1ull << k) : nonempty | (1ull << k);
   }
   MG_HD void clear_with_walls() {
+    if (W == 8 && H == 8 && ((uintptr_t)p & 3u) == 0u) {
+      // the 8 x 8 room of the single-room levels as sixteen dword stores (round 6; the byte loop below is ~600 instructions per lane and episode)
+      uint32_t* q = (uint32_t*)p;
+      const uint32_t w4 = CELL_WALL_GREY * 0x01010101u, e4 = CELL_EMPTY * 0x01010101u;
+      const uint32_t left = (e4 & 0xFFFFFF00u) | (uint32_t)CELL_WALL_GREY, right = (e4 & 0x00FFFFFFu) | ((uint32_t)CELL_WALL_GREY << 24);
+      q[0] = w4; q[1] = w4; q[14] = w4; q[15] = w4;
+#pragma unroll
+      for (int y = 1; y < 7; y++) { q[2 * y] = left; q[2 * y + 1] = right; }
+      nonempty = walls = 0xFF818181818181FFull;
+      return;
+    }
     nonempty = 0;
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) {
@@ -400,6 +412,110 @@ MG_HD void gen_goto(R& rng, G& g, const GenParams& P, GenResult& out) {
     if (kind == GOTO_OBJ || kind == GOTO_LOCAL) out.mission = many * 18u + ((dcol >> (4 * k)) & 15u) * 3u + ((dtyp >> (4 * k)) & 15u);
     else if (kind == GOTO_REDBLUEBALL) out.mission = cell_color(desc) == C_BLUE ? 1u : 0u;
     else out.mission = many;                      // "go to the red ball" / "go to a red ball"
+    return;
+  }
+  out.failed = true;
+}
+
+// gen_goto for ONE LANE (k_refill_lane / k_generate_lane: 64 episodes per wavefront) as ONE loop of draws -- round 6.  The literal form above
+// runs a rejection loop per object: under SIMT every one of them lasts as long as its unluckiest lane (a try lands in the 8 x 8 room's free interior
+// about every other time: the mean is two tries per object, the maximum over 64 lanes seven), nine objects one after the other, which is why the
+// BabyAI-GoToRedBall refill ran best with a third of the lanes busy and still kept the chip busier than the step kernel it feeds (profiles/r6/
+// kernel_stats_gotoredball_who_is_busy.txt).  Here a lane is a state machine -- job 0 the agent, then the red ball (GoToRedBall / -Grey), then the
+// distractors, each a header (colour, type) and tries -- and every loop iteration takes exactly one PAIR of bounded draws (dynobs_draw_xy: one PCG64
+// step whichever half of a 64-bit output the stream stands at): a lane whose try is accepted moves on by itself, so the wave runs as long as the lane
+// with the largest TOTAL, not the sum of the per-object maxima.  Same draws in the same order as gen_goto (mg_selftest_generate against the oracle;
+// the GPU goldens): header = rand_int(0, 6), rand_int(0, 3) (add_distractors, roomgrid.py:419-420), a try = x then y (place_obj,
+// minigrid_env.py:347-350), the agent's direction after its accepted try (place_agent, :391-393).
+template <class R>
+MG_HD void gen_goto_lane(R& rng, LaneGrid& g, const GenParams& P, GenResult& out) {
+  const int W = g.W, H = g.H, kind = P.kind;
+  uint64_t col0 = 0, colL = 0, all = 0;
+  for (int y = 0; y < H; y++) { col0 |= 1ull << (y * W); colL |= 1ull << (y * W + W - 1); }
+  all = (W * H >= 64) ? ~0ull : ((1ull << (W * H)) - 1ull);
+  const int ndist = kind == GOTO_OBJ ? 1 : min(P.num_dists, 8);
+  const int first_dist = (kind == GOTO_REDBALL || kind == GOTO_REDBALLGREY) ? 2 : 1;        // job 0 the agent, job 1 the red ball (those two levels)
+  const int njobs = first_dist + ndist;
+  for (uint32_t attempt = 0; attempt < 4096 && !rng.dead(); attempt++) {
+    out.retries = attempt;
+    g.clear_with_walls();
+    int j = 0, tries = 0;
+    bool hdr = false, ok = true;
+    int ax = -1, ay = -1;
+    uint32_t adir = 0, ci = 0, ti = 0, dcol = 0, dtyp = 0;
+    uint64_t dpos = 0;
+    bool red_or_blue_ball = false;
+    while (j < njobs) {
+      const int d = j - first_dist;
+      const bool need_hdr = d >= 0 && !hdr;
+      int v0, v1;
+      dynobs_draw_xy(rng, 0, need_hdr ? 6 : W, 0, need_hdr ? 3 : H, v0, v1);
+      // a header: the distractor's colour and type; its tries follow
+      ci = need_hdr ? (uint32_t)v0 : ci; ti = need_hdr ? (uint32_t)v1 : ti;
+      // a try (place_obj: the count, the two draws, the cell, the agent's cell, reject_next_to)
+      const bool try_ = !need_hdr;
+      tries += try_ ? 1 : 0;
+      const int k = try_ ? v1 * W + v0 : 0;
+      const int dx = ax - v0, dy = ay - v1;
+      const bool near = j > 0 && (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy) < 2;             // (the agent's own cell included; job 0 runs with the agent at (-1, -1) and no reject_fn)
+      const bool acc = try_ && (uint32_t)g.p[k] == (uint32_t)CELL_EMPTY && !near;
+      const bool giveup = try_ && !acc && tries > 1000;                                     // the 1001st rejected try: RecursionError -> the whole level again
+      if (acc && j == 0) {
+        // place_agent: the position, then the direction; RoomGrid.place_agent repeats it while the cell in front holds an object
+        ax = v0; ay = v1;
+        adir = (uint32_t)rand_int(rng, 0, 4);
+        const uint32_t f = g.get(ax + dir_dx(adir), ay + dir_dy(adir));
+        j = (f == CELL_EMPTY || cell_type(f) == T_WALL) ? 1 : 0;
+      } else if (acc) {
+        const uint32_t color = color_from_sorted(ci);
+        const uint32_t cell = d < 0 ? (uint32_t)CELL_BALL_RED : make_cell(T_KEY + ti, color);
+        g.set(v0, v1, cell);
+        if (d >= 0) {
+          dpos |= (uint64_t)(uint32_t)k << (8 * d); dcol |= ci << (4 * d); dtyp |= ti << (4 * d);
+          red_or_blue_ball |= ti == 1u && (color == C_RED || color == C_BLUE);
+        }
+        j++;
+      }
+      hdr = acc ? false : (hdr || need_hdr);
+      tries = acc ? 0 : tries;
+      if (giveup) { ok = false; j = njobs; }
+    }
+    if (!ok) continue;
+    out.ax = (uint32_t)ax; out.ay = (uint32_t)ay; out.dir = adir;
+    int x, y;
+    uint32_t desc = CELL_BALL_RED;
+    if (kind == GOTO_REDBALLGREY)                                // dist.color = "grey"
+      for (int d = 0; d < ndist; d++) {
+        const int idx = (int)((dpos >> (8 * d)) & 0xFF);
+        g.set(idx % W, idx / W, make_cell(T_KEY + ((dtyp >> (4 * d)) & 15u), C_GREY));
+      }
+    if (kind == GOTO_REDBLUEBALL) {
+      if (red_or_blue_ball) continue;                            // RejectSampling("can only have one blue or red ball")
+      desc = make_cell(T_BALL, rand_int(rng, 0, 2) == 0 ? (uint32_t)C_RED : (uint32_t)C_BLUE);
+      if (!place_obj(rng, g, desc, 0, 0, W, H, ax, ay, true, 1000, x, y)) continue;
+    }
+    uint64_t passable, objects, matches;
+    if (kind != GOTO_OBJ) {
+      g.reach_masks(passable, objects, desc, matches);
+      uint64_t reach = 1ull << (ay * W + ax);
+      for (;;) {
+        const uint64_t grow = (((reach & ~colL) << 1) | ((reach & ~col0) >> 1) | (reach << W) | (reach >> W)) & all;
+        const uint64_t next = reach | (grow & passable);
+        if (next == reach) break;
+        reach = next;
+      }
+      const uint64_t visited = (reach | ((reach & ~colL) << 1) | ((reach & ~col0) >> 1) | (reach << W) | (reach >> W)) & all;
+      if (objects & ~visited) continue;           // RejectSampling("unreachable object")
+    }
+    uint32_t kk = 0;
+    if (kind == GOTO_LOCAL) kk = (uint32_t)rand_int(rng, 0, ndist);               // _rand_elem(objs)
+    if (kind == GOTO_OBJ || kind == GOTO_LOCAL) desc = make_cell(T_KEY + ((dtyp >> (4 * kk)) & 15u), color_from_sorted((dcol >> (4 * kk)) & 15u));
+    g.reach_masks(passable, objects, desc, matches);
+    out.aux = matches;
+    const uint32_t many = __builtin_popcountll(matches) > 1 ? 1u : 0u;
+    if (kind == GOTO_OBJ || kind == GOTO_LOCAL) out.mission = many * 18u + ((dcol >> (4 * kk)) & 15u) * 3u + ((dtyp >> (4 * kk)) & 15u);
+    else if (kind == GOTO_REDBLUEBALL) out.mission = cell_color(desc) == C_BLUE ? 1u : 0u;
+    else out.mission = many;
     return;
   }
   out.failed = true;

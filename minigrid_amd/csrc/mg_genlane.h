@@ -105,7 +105,7 @@ MG_HD void generate_episode_lane(R& rng, LaneGrid& g, const GenParams& P, GenRes
     case 0: gen_empty(rng, g, P, out); return;
     case 1: gen_doorkey(rng, g, P, out); return;
     case 2: gen_crossing(rng, g, P, out); return;
-    case 3: case 16: case 17: case 18: case 19: gen_goto(rng, g, P, out); return;
+    case 3: case 16: case 17: case 18: case 19: gen_goto_lane(rng, g, P, out); return;      // (gen_goto as one loop of draws: mg_gen.h)
     case 4: gen_lavagap(rng, g, P, out); return;
     case 5: gen_distshift(rng, g, P, out); return;
     case 6: gen_fourrooms(rng, g, P, out); return;
