@@ -390,6 +390,8 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="empty8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--env-id", default="", help="tuning aid: any registered id instead of the workload's (the line's config.env_id says so; profiles are "
+                                                  "quoted per workload NAME, so such a line carries no profile-backed roofline)")
     ap.add_argument("--fused", type=int, default=1, help="1: the fused rollout kernel (up to max_fused_steps steps per k_step launch, "
                     "grids resident in LDS, every step's outputs to its own trajectory slot); 0: one k_step launch per step")
     ap.add_argument("--gather-obs", type=int, default=0, help="RCCL all-gather the obs tensor every step")
@@ -434,6 +436,8 @@ def main(argv=None):
         assert dist.get_world_size() == args.gpus
 
     env_id, n_per_gpu, obs_mode = WORKLOADS[args.workload]
+    if args.env_id:
+        env_id = args.env_id
     if args.envs_per_gpu:
         n_per_gpu = args.envs_per_gpu
     if args.obs_mode:
@@ -555,7 +559,7 @@ def main(argv=None):
         # id u16, 2 bytes reserved); the grid and the agent record are read and written once per launch, not per step
         hbm_min = obe + 16 + (2 * (env.width * env.height) + 16) / spl
         floor_bytes_per_launch = hbm_min * n_per_gpu * steps_per_launch_avg
-        quotable = not args.obs_mode and args.view == 7 and use_gpu
+        quotable = not args.obs_mode and not args.env_id and args.view == 7 and use_gpu
         traffic = pmc_traffic_bytes(args.workload, n_per_gpu, spl) if quotable else None
         # the counters are per FULL launch (spl steps); a region whose last launch is shorter moves proportionally less on average
         real_bytes_per_launch = traffic * steps_per_launch_avg / spl if traffic else floor_bytes_per_launch

@@ -190,7 +190,11 @@ typedef struct mg_config {
                                  < 0 = -traj_slots preferred, halved like the default while the ring would exceed 2 GB       */
   int32_t babyai_done_actions; /* envs/babyai/core/verifier.py:26 use_done_actions (the reference reads BABYAI_DONE_ACTIONS when it is imported):
                                  only the `done` action reports -- success iff the previous action completed the instruction, failure
-                                 otherwise (verifier.py:228-242).  RoomGridLevel-based levels only; ignored elsewhere.  Default 0.           */
+                                 otherwise (verifier.py:228-242).  RoomGridLevel-based levels only; ignored elsewhere.  Default 0.
+                                 1 = the reference stepped with INTEGER actions (env.step(6), a numpy vector of actions: what
+                                 gymnasium.vector.SyncVectorEnv passes); 2 = stepped with the enum member (env.step(env.actions.done)):
+                                 AndInstr.verify's `action is self.env.actions.done` branch (verifier.py:561-563) is then taken --
+                                 `done` while both halves report failure fails the instruction.                                     */
 } mg_config;
 
 /* Borrowed device pointers to the outputs of the last step/reset = slot 0 of the trajectory ring.  The ring has

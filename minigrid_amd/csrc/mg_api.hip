@@ -398,7 +398,7 @@ static void fill_step_params(mg_env* e, StepParams& P, int phase) {
     const int k = e->cfg.env_kind;
     const bool babyai = k == MG_ENV_GOTO_REDBALL || (k >= MG_ENV_GOTO_REDBALLGREY && k <= MG_ENV_GOTO_LOCAL) || (k >= MG_ENV_PICKUPDIST && k <= MG_ENV_BABYAI_KEYCORRIDOR) ||
                         (k >= MG_ENV_BABYAI_GOTO && k <= MG_ENV_LEVELGEN);
-    P.done_actions = (e->cfg.babyai_done_actions != 0 && babyai) ? 1 : 0;
+    P.done_actions = (e->cfg.babyai_done_actions != 0 && babyai) ? (e->cfg.babyai_done_actions == 2 ? 2 : 1) : 0;      // (2: AndInstr's enum-identity branch, mg_verify.h)
   }
   P.obs_wg_stride = (unsigned long long)e->epw * (unsigned long long)e->map_bytes;
   P.rng = e->rng; P.dyn_n = std::min(e->cfg.num_dists, 8); P.dyn_sx = e->cfg.agent_start_x; P.dyn_sy = e->cfg.agent_start_y; P.dyn_sdir = e->cfg.agent_start_dir;
@@ -759,6 +759,11 @@ static const char* configure_obs(mg_env* e) {
   // BabyAI-GoTo x 131 072: 4.29 -> 6.03 G env-steps/s, MultiRoom-N6 x 65 536: 2.48 -> 3.93 (profiles/r6/ab_connect_all_shadows.txt); KeyCorridorS3R3 (small
   // grid) is indifferent (23.5 / 23.1).
   if (e->cells > 256) e->roll_shadows = 0;
+  // (round 6) TWO for the small levels whose episodes are at most 64 steps long (BabyAI-GoToRedBall and the other single-room GoTo levels: max_steps =
+  // room_size^2): with the generators no longer what a GoToRedBall step waits for (gen_goto_lane, mg_gen.h), a second reset of an env within a 32-step launch
+  // -- every env ends an episode at least once in two launches -- is worth the second staged set: x 32 768 13.2 -> 14.0 G env-steps/s, three runs each
+  // (profiles/r6/ab_fullyobs_lds_occupancy.txt; DoorKey-8x8 / Empty-8x8, episodes of hundreds of steps: 31.2 -> 28.9 / 30.6 -> 29.1 with two, as in round 3)
+  if (e->cells <= 64 && e->cfg.max_steps > 0 && e->cfg.max_steps <= 64 && !e->sentence && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
   if (e->k.roll_shadows == 1) e->roll_shadows = 1;
   if (e->k.roll_shadows == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
   if (e->k.roll_shadows == 0 && !e->static_gen) e->roll_shadows = 0;    // no staging: every reset fetches its spare from the ring in HBM inside the loop
@@ -2151,7 +2156,7 @@ int mg_selftest_verify(int32_t W, int32_t H, int32_t n, int32_t done_actions, co
     a.carry = o[3] ? cell_from_triple((uint32_t)o[3], (uint32_t)o[4], 0) : 0u;
     if (a.carry == CELL_EMPTY) a.carry = 0;
     uint32_t ms = 0, err = 0;
-    status[i] = (int32_t)verify_action(records + (size_t)i * INSTR_WORDS, g.data(), W, H, a, (uint32_t)actions[i], ms, err, done_actions != 0);
+    status[i] = (int32_t)verify_action(records + (size_t)i * INSTR_WORDS, g.data(), W, H, a, (uint32_t)actions[i], ms, err, done_actions);
     max_steps[i] = (int32_t)ms; errbits[i] = err;
   }
   return MG_OK;

@@ -69,7 +69,7 @@ __global__ void k_verify(const VerifyParams V) {
   sent[0] = I[IW_MISSION]; sent[1] = I[IW_MISSION + 1];
   if (V.phase != PHASE_STEP) return;
   uint32_t max_steps = 0, errbits = 0;
-  const uint32_t status = verify_action(I, V.grid + (size_t)e * V.CS, V.W, V.H, a, (uint32_t)V.rec[V.off_action + (size_t)e * 16], max_steps, errbits, V.done_actions != 0);
+  const uint32_t status = verify_action(I, V.grid + (size_t)e * V.CS, V.W, V.H, a, (uint32_t)V.rec[V.off_action + (size_t)e * 16], max_steps, errbits, V.done_actions);
   const uint32_t term = status != R_CONTINUE, trunc = a.step >= max_steps;
   *(double*)(V.rec + V.off_reward + (size_t)e * 16) = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;
   V.rec[V.off_term + (size_t)e * 16] = (uint8_t)term;

@@ -437,6 +437,17 @@ constexpr int ROLL_LOG_SYNC_BYTES = 64;                       // ... behind its 
 #define MG_SCAL_BY_ENCODE 0
 #endif
 constexpr int ROLL_LOG_BYTES = ROLL_LOG_SYNC_BYTES + ROLL_LOG_STEPS * 64 * 8 + (MG_SCAL_BY_ENCODE ? ROLL_LOG_STEPS * 64 * 2 : 0);   // (pose, delta) per env and entry (+ the step count the reward is priced on)
+#ifndef MG_RG_WPE
+// waves per SIMD the register allocation of k_roll7<GG_ROOMGRID> (the 7x7 view) aims at: 3 = 151 VGPRs, 4 = 128 (eight dwords spilled).  With 151 only
+// three of a CU's four workgroup slots were usable (12 waves): round 6, profiles/r6/ab_roomgrid_waves_per_simd.txt -- KeyCorridorS3R3 x 131 072 22.0 -> 24.5 G,
+// Unlock 20.0 -> 21.2, GoToRedBall x 65 536 12.7 -> 16.3, x 131 072 15.6 -> 18.1 (x 32 768, two workgroups per CU: unchanged)
+#define MG_RG_WPE 4
+#endif
+#ifndef MG_LR_WPE
+// ... and of k_roll7<GG_LIGHT> / <GG_ROOMS> (the 7x7 view, not STAGED): 3 = 159 / 140 VGPRs, 4 = 128 (profiles/r6/ab_light_rooms_waves_per_simd.txt, x 131 072:
+// Fetch-8x8-N3 19.8 -> 24.5 G, BabyAI-PickupDist 14.8 -> 16.7, PutNextLocal 11.4 -> 13.2, OpenRedDoor 18.4 -> 21.5; Memory / LockedRoom unchanged)
+#define MG_LR_WPE 4
+#endif
 #ifndef MG_DYN_WPE
 // waves per SIMD the register allocation of k_roll7<GG_DYNOBS> aims at: 4 = 128 VGPRs (three spilled, outside the placement loop) against 149.
 // Measured (profiles/r4/dynobs_waves_sweep2.txt, 65 536 envs): 16x16 12.5 us per step against 18.2, 8x8 12.3 against 17.8, Random-6x6 17.6 against 24.5
@@ -481,7 +492,7 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // SIMD, every latency of the step exposed.  With one copy per workgroup (the dynamics wave's, which also stages the step's 49 codes per env) a second
 // wave takes the output-space encode and the stores, exactly as for the sentence levels (same 22 x 22 grids) since round 4.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false, bool STAGED = false>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : (GG == GG_ROOMGRID && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
   static_assert(!STAGED || (!FULL && !ONE && GG != GG_DYNOBS && GG != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -836,7 +847,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
         // (attribution builds, MG_EXP bit 2048: the step without its verifier -- nothing ever succeeds, the episode limit still comes from the record)
         uint32_t status = R_CONTINUE;
         if (MG_EXPBIT(P, 2048)) max_steps = (uint32_t)(I[0] >> 39) & 0xFFFFu;
-        else status = verify_action(I, IWd, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions != 0);
+        else status = verify_action(I, IWd, mygrid, W, H, a, o.act_in, max_steps, verr, P.done_actions);
         S.errbits |= verr;
         o.term = status != R_CONTINUE; o.trunc = a.step >= max_steps;
         o.reward = status == R_SUCCESS ? reward_exact(a.step, (int)max_steps) : 0.0;

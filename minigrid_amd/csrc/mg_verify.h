@@ -125,7 +125,7 @@ struct InstrRef {
 // step (InstrWords::load).  Returns the instruction's status (R_CONTINUE / R_SUCCESS / R_FAILURE) and the episode's max_steps; OR-s tracking
 // errors into errbits; stores the words it changed.
 MG_HD uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out,
-                            uint32_t& errbits, bool done_actions = false) {
+                            uint32_t& errbits, int done_actions = 0) {
   InstrRef R;
   R.I = I; R.g = g; R.W = W; R.H = H; R.errbits = 0;
   R.w_magic = (65536u + (uint32_t)W - 1u) / (uint32_t)W;                  // (W is uniform: scalar arithmetic)
@@ -187,11 +187,13 @@ MG_HD uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int 
   auto done_get = [&](uint32_t n, int which) -> uint32_t { return (dn >> (4u * n + 2u * (uint32_t)which)) & 3u; };
   auto done_set = [&](uint32_t n, int which, uint32_t v) { const uint32_t sh = 4u * n + 2u * (uint32_t)which; dn = (dn & ~(3u << sh)) | (v << sh); };
   // (AndInstr.verify's `use_done_actions and action is self.env.actions.done` branch, verifier.py:561-563, is an IDENTITY test against the enum member:
-  // integer actions -- the only kind a vector of actions holds -- never take it.  This is the integer behaviour)
+  // integer actions -- the only kind a vector of actions holds -- never take it: done_actions = 1 is that integer behaviour, what env.step(6) and
+  // gymnasium.vector.SyncVectorEnv give the reference; done_actions = 2 is env.step(env.actions.done), the branch taken.  INTEGRATION.md section 4.)
   auto and_verify = [&](uint32_t n) -> uint32_t {
     const uint32_t nd = nodef(n), ia = (nd >> 2) & 7u, ib = (nd >> 5) & 7u;
     if (done_get(n, 0) != R_SUCCESS) done_set(n, 0, leaf(ia));
     if (done_get(n, 1) != R_SUCCESS) done_set(n, 1, leaf(ib));
+    if (done_actions == 2 && act == A_DONE && done_get(n, 0) == R_FAILURE && done_get(n, 1) == R_FAILURE) return (uint32_t)R_FAILURE;
     return (done_get(n, 0) == R_SUCCESS && done_get(n, 1) == R_SUCCESS) ? (uint32_t)R_SUCCESS : (uint32_t)R_CONTINUE;
   };
   auto sub_verify = [&](uint32_t idx) -> uint32_t { return idx < 4u ? leaf(idx) : and_verify(idx - 4u); };
@@ -245,7 +247,7 @@ MG_HD uint32_t verify_action(uint64_t* I, InstrWords& Wd, const uint8_t* g, int 
 }
 // (the form that loads the words itself: k_verify, after a step kernel)
 MG_HD uint32_t verify_action(uint64_t* I, const uint8_t* g, int W, int H, const Agent& a, uint32_t act, uint32_t& max_steps_out, uint32_t& errbits,
-                            bool done_actions = false) {
+                            int done_actions = 0) {
   InstrWords Wd;
   Wd.load(I);
   return verify_action(I, Wd, g, W, H, a, act, max_steps_out, errbits, done_actions);

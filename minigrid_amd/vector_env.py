@@ -57,7 +57,7 @@ class MiniGridVecEnv(_VectorEnvBase):
                  image_only: bool = False, agent_view_size: int = 7, no_death_types: Sequence[str] = (),
                  death_cost: float = -1.0, dict_mission: bool = False, tile_size: int = 8, highlight: bool = True,
                  spare_ring: int = 0, traj_slots: int = 0, stuck_place_agent: str = "raise", final_obs: bool = False,
-                 babyai_done_actions: Optional[bool] = None):
+                 babyai_done_actions=None):
         if obs_mode not in _OBS_MODES:
             raise ValueError(f"obs_mode must be one of {sorted(_OBS_MODES)}")
         # ViewSizeWrapper.__init__ asserts (wrappers.py:650-651)
@@ -96,7 +96,9 @@ class MiniGridVecEnv(_VectorEnvBase):
         if babyai_done_actions is None:
             import os
             babyai_done_actions = bool(os.environ.get("BABYAI_DONE_ACTIONS", False))
-        self.babyai_done_actions = bool(babyai_done_actions)
+        # True: the reference stepped with integer actions (env.step(6), SyncVectorEnv's numpy elements); "enum": stepped with Actions members
+        # (env.step(env.actions.done)), which alone take AndInstr.verify's `action is self.env.actions.done` branch (verifier.py:561-563)
+        self.babyai_done_actions = "enum" if babyai_done_actions == "enum" else bool(babyai_done_actions)
         # what pickling needs to build the same env again (__getstate__)
         self._ctor = dict(env_id=env_id, num_envs=int(num_envs), autoreset_mode=autoreset_mode, rng=rng, env_index_base=int(env_index_base),
                           max_steps=max_steps, output=output, spare_ring=int(spare_ring), traj_slots=int(traj_slots),
@@ -137,7 +139,7 @@ class MiniGridVecEnv(_VectorEnvBase):
             agent_start_dir=s.agent_start[2], num_crossings=s.num_crossings, obstacle_type=s.obstacle_type,
             num_dists=s.num_dists, strip2_row=s.strip2_row, room_size=s.room_size, random_length=int(s.random_length),
             env_index_base=self.env_index_base, tile_size=int(tile_size), rgb_highlight=int(bool(highlight)),
-            spare_ring=int(spare_ring), traj_slots=int(traj_slots), babyai_done_actions=int(self.babyai_done_actions))
+            spare_ring=int(spare_ring), traj_slots=int(traj_slots), babyai_done_actions=2 if self.babyai_done_actions == "enum" else int(self.babyai_done_actions))
         self.tile_size, self.highlight = int(tile_size), bool(highlight)
         self.spare_ring, self.traj_slots_arg = int(spare_ring), int(traj_slots)
         self.rng_kind = rng

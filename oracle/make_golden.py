@@ -45,6 +45,11 @@ DONE_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocal-v0", "BabyAI-PickupDist-v
             "BabyAI-GoTo-v0", "BabyAI-PutNextLocal-v0", "BabyAI-OpenDoorDebug-v0", "BabyAI-ActionObjDoor-v0", "BabyAI-UnlockLocal-v0",
             "BabyAI-OpenTwoDoors-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-MoveTwoAcrossS5N2-v0"]
 
+# `BABYAI_DONE_ACTIONS=1 python oracle/make_golden.py done_enum`: the same mode stepped with Actions MEMBERS (env.step(env.actions.done)) instead of
+# integers -- AndInstr.verify's `action is self.env.actions.done` (verifier.py:561) is an identity test only a member passes: done_enum_*.npz
+ENUM_ACTIONS = len(sys.argv) > 1 and sys.argv[1] == "done_enum"
+DONE_ENUM_IDS = ["BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-SynthSeq-v0"]
+
 MISSIONS = {
     "MiniGrid-Empty": ["get to the green goal square"],
     "MiniGrid-DoorKey": ["use the key to open the door and then get to the goal"],
@@ -624,7 +629,7 @@ def rollout(env_id, seed, T, mode, noise=0.25):
             r, term, trunc = 0.0, False, False
             pending = False
         else:
-            obs, r, term, trunc, _ = env.step(a)
+            obs, r, term, trunc, _ = env.step(env.unwrapped.actions(a) if ENUM_ACTIONS else a)
             pending = bool(term or trunc)
         assert obs["direction"] == env.unwrapped.agent_dir
         rec["actions"].append(a)
@@ -1073,10 +1078,21 @@ def main_done():
         print("done-actions", env_id, flush=True)
 
 
+def main_done_enum():
+    """Goldens of AndInstr.verify's enum-identity branch (verifier.py:556-571): `BABYAI_DONE_ACTIONS=1 ... make_golden.py done_enum`."""
+    from minigrid.envs.babyai.core import verifier
+    assert DONE_MODE and verifier.use_done_actions and ENUM_ACTIONS, "run with BABYAI_DONE_ACTIONS=1 in the environment"
+    for env_id in DONE_ENUM_IDS:
+        np.savez_compressed(os.path.join(OUT, f"done_enum_{env_id}.npz"), **make_rollouts(env_id, [0, 1, 2, 3, 4, 1337], 300))
+        print("done-actions (enum members)", env_id, flush=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "done":
         return main_done()
+    if len(sys.argv) > 1 and sys.argv[1] == "done_enum":
+        return main_done_enum()
     assert not DONE_MODE, "BABYAI_DONE_ACTIONS is set: only `make_golden.py done` may run in that mode"
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         return main_wide()

@@ -372,7 +372,7 @@ class OracleVec:
     """N independent reference-semantics envs stepped in lockstep on the CPU (scalar C)."""
 
     def __init__(self, env_id: str, num_envs: int, full_obs: bool = False, obs: str | None = None, view_size: int = 7,
-                 no_death_types=(), death_cost: float = -1.0, tile_size: int = 8, highlight: bool = True, done_actions: bool = False,
+                 no_death_types=(), death_cost: float = -1.0, tile_size: int = 8, highlight: bool = True, done_actions=False,
                  **overrides):
         """obs: "partial" | "full" (FullyObsWrapper) | "onehot" (OneHotPartialObsWrapper) | "symbolic"
         (SymbolicObsWrapper, returned as int8); view_size: ViewSizeWrapper; no_death_types/death_cost: NoDeath."""
@@ -390,7 +390,7 @@ class OracleVec:
         for t in no_death_types:
             mask |= 1 << OBJECT_TO_IDX[t]
         self.cfg = OracleCfg(full_obs=kind, view_size=int(view_size), no_death_mask=mask, death_cost=float(death_cost),
-                             done_actions=int(bool(done_actions)),      # BABYAI_DONE_ACTIONS (verifier.py:26)
+                             done_actions=2 if done_actions == "enum" else int(bool(done_actions)),      # BABYAI_DONE_ACTIONS (verifier.py:26); "enum": stepped with Actions members (:561)
                              **{k: int(v) for k, v in s.items()})
         self.n = num_envs
         self.W, self.H = self.cfg.width, self.cfg.height

@@ -632,6 +632,56 @@ DONE_IDS = ["BabyAI-GoToRedBall-v0", "BabyAI-GoToLocal-v0", "BabyAI-PickupDist-v
             "BabyAI-OpenTwoDoors-v0", "BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-MoveTwoAcrossS5N2-v0"]
 
 
+DONE_ENUM_IDS = ["BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-SynthSeq-v0"]
+
+
+@pytest.mark.parametrize("env_id", DONE_ENUM_IDS)
+def test_done_actions_with_enum_members_equal_the_reference_goldens_and_the_oracle(env_id):
+    """`babyai_done_actions="enum"` = the reference in BABYAI_DONE_ACTIONS mode stepped with Actions MEMBERS: AndInstr.verify's
+    `action is self.env.actions.done` branch (verifier.py:561-563) is taken -- `done` while both halves report failure fails the instruction.
+    The reference's goldens step by step (one launch per step), then 1 500 envs against the oracle, stepped and fused."""
+    import minigrid_amd as mg
+    from oracle import oracle as O
+    g = golden(f"done_enum_{env_id}.npz")
+    for mode in ("random", "solver"):
+        seeds, acts = g["seeds"], g[f"{mode}_actions"]
+        S, T = acts.shape
+        env = mg.make_vec(env_id, S, babyai_done_actions="enum")
+        obs, _ = env.reset(seed=[int(x) for x in seeds])
+        assert (obs["image"] == g[f"{mode}_obs"][:, 0]).all()
+        for t in range(T):
+            obs, rew, term, trunc, _ = env.step(acts[:, t])
+            assert (obs["image"] == g[f"{mode}_obs"][:, t + 1]).all(), (env_id, mode, t)
+            assert rew.tobytes() == g[f"{mode}_reward"][:, t].tobytes(), (env_id, mode, t)
+            assert (term == g[f"{mode}_term"][:, t]).all() and (trunc == g[f"{mode}_trunc"][:, t]).all(), (env_id, mode, t)
+        env.close()
+    n = 1500
+    env = mg.make_vec(env_id, n, babyai_done_actions="enum", traj_slots=16)
+    orc = O.OracleVec(env_id, n, done_actions="enum")
+    plain = O.OracleVec(env_id, n, done_actions=True)
+    obs, _ = env.reset(seed=11)
+    assert (obs["image"] == orc.reset(seeds=np.arange(11, 11 + n, dtype=np.uint64))[0]).all()
+    plain.reset(seeds=np.arange(11, 11 + n, dtype=np.uint64))
+    rng = np.random.default_rng(2)
+    differs = False
+    for t in range(120):
+        a = rng.choice(7, size=n, p=[0.14, 0.14, 0.3, 0.1, 0.08, 0.1, 0.14]).astype(np.uint8)
+        obs, rew, term, trunc, _ = env.step(a)
+        oo, orew, oterm, otrunc, _, _ = orc.step(a)
+        assert (obs["image"] == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, t)
+        if not differs:
+            differs = not (plain.step(a)[2] == oterm).all()
+    assert differs or env_id == "BabyAI-GoToSeqS5R2-v0", "the enum branch was never taken"
+    for c in range(4):                                       # fused launches of the device policy
+        env.rollout(16, action_seed=5, fused=True)
+        for k in reversed(range(16)):
+            img, rew, term, trunc, d, m, act = env.trajectory(k)
+            oo, orew, oterm, otrunc, od, om = orc.step(act)
+            assert (img == oo).all() and rew.tobytes() == orew.tobytes() and (term == oterm).all() and (trunc == otrunc).all(), (env_id, "fused", c, k)
+    assert (env.get_rng_state() == orc.get_rng()).all()
+    env.close()
+
+
 @pytest.mark.parametrize("env_id", DONE_IDS)
 def test_done_actions_equal_the_reference_goldens_and_the_oracle(env_id):
     """use_done_actions (verifier.py:26, 228-242; `babyai_done_actions=True` = the reference imported with BABYAI_DONE_ACTIONS=1): the goldens

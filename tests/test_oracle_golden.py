@@ -153,6 +153,37 @@ def test_done_actions_rollouts_match_reference(env_id, mode):
         assert (g["solver_term"] & done_steps).sum() >= 3 and not (g["solver_term"] & ~done_steps).any()
 
 
+DONE_ENUM_IDS = ["BabyAI-GoToSeqS5R2-v0", "BabyAI-MiniBossLevel-v0", "BabyAI-SynthSeq-v0"]
+
+
+@pytest.mark.parametrize("env_id", DONE_ENUM_IDS)
+def test_done_actions_with_enum_members_match_reference(env_id):
+    """AndInstr.verify's `use_done_actions and action is self.env.actions.done` (verifier.py:561-563) is an IDENTITY test: it holds for
+    env.step(env.actions.done), never for an integer.  Goldens: the unmodified reference in BABYAI_DONE_ACTIONS mode stepped with Actions MEMBERS
+    (`BABYAI_DONE_ACTIONS=1 python oracle/make_golden.py done_enum`); the oracle follows them with done_actions="enum" and -- the branch is
+    exercised -- leaves them with the integer behaviour (done_actions=True) somewhere."""
+    g = golden(f"done_enum_{env_id}.npz")
+    diverged = 0
+    for how in ("enum", True):
+        for mode in ("random", "solver"):
+            seeds, acts = g["seeds"], g[f"{mode}_actions"]
+            S, T = acts.shape
+            v = O.OracleVec(env_id, S, done_actions=how)
+            obs, d, m = v.reset(seeds=seeds)
+            assert (obs == g[f"{mode}_obs"][:, 0]).all()
+            for t in range(T):
+                obs, rew, term, trunc, d, m = v.step(acts[:, t])
+                same = ((obs == g[f"{mode}_obs"][:, t + 1]).all() and rew.tobytes() == g[f"{mode}_reward"][:, t].tobytes() and
+                        (term == g[f"{mode}_term"][:, t]).all() and (trunc == g[f"{mode}_trunc"][:, t]).all())
+                if how == "enum":
+                    assert same, (env_id, mode, t)
+                elif not same:
+                    diverged += 1
+                    break
+    if env_id != "BabyAI-GoToSeqS5R2-v0":
+        assert diverged >= 1, "the enum goldens never took AndInstr's failure branch"
+
+
 def test_done_actions_goldens_hold_successes():
     n = sum(int((golden(f"done_{e}.npz")["solver_reward"] > 0).sum()) for e in DONE_IDS)
     assert n >= 10, n

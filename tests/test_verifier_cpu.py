@@ -116,7 +116,7 @@ def _case(rng, done_actions):
     return grid, (ax, ay, d, carry_t, carry_c), act, words
 
 
-@pytest.mark.parametrize("done_actions", [0, 1])
+@pytest.mark.parametrize("done_actions", [0, 1, 2])          # 2: AndInstr's enum-identity branch (verifier.py:561)
 def test_verifier_equals_the_sequential_restatement_on_random_reachable_records(done_actions):
     L = B.load()
     rng = np.random.default_rng(7 + done_actions)
@@ -136,7 +136,7 @@ def test_verifier_equals_the_sequential_restatement_on_random_reachable_records(
     assert L.mg_selftest_verify(W, H, n, done_actions, p(grids), p(agents), p(acts), p(recs), p(status), p(ms), p(err)) == 0
     seen = {"status": set(), "err": 0, "picked": 0, "dropped": 0, "changed_leaf": 0}
     for i, (g, ag, act, words) in enumerate(cases):
-        st, m, e, new = V.verify_step(words, g, W, H, ag, act, bool(done_actions))
+        st, m, e, new = V.verify_step(words, g, W, H, ag, act, done_actions)
         got = [int(w) for w in recs[i]]
         assert (int(status[i]), int(ms[i]), int(err[i]) & V.ERR_TRACKED) == (st, m, e), (i, act, ag, hex(words[0]))
         bad = [k for k in range(40) if got[k] != new[k]]

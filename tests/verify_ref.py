@@ -174,6 +174,8 @@ def verify_step(words, grid, W, H, agent, act, done_actions):
             done_set(n, 0, leaf(ia))
         if done_get(n, 1) != SUCCESS:
             done_set(n, 1, leaf(ib))
+        if done_actions == 2 and act == A_DONE and done_get(n, 0) == FAILURE and done_get(n, 1) == FAILURE:
+            return FAILURE                                    # `action is self.env.actions.done` (verifier.py:561): stepped with the enum member
         return SUCCESS if done_get(n, 0) == SUCCESS and done_get(n, 1) == SUCCESS else CONT
 
     def sub_verify(idx):
