@@ -762,7 +762,7 @@ static const char* configure_obs(mg_env* e) {
   // (round 6) TWO for the small levels whose episodes are at most 64 steps long (BabyAI-GoToRedBall and the other single-room GoTo levels: max_steps =
   // room_size^2): with the generators no longer what a GoToRedBall step waits for (gen_goto_lane, mg_gen.h), a second reset of an env within a 32-step launch
   // -- every env ends an episode at least once in two launches -- is worth the second staged set: x 32 768 13.2 -> 14.0 G env-steps/s, three runs each
-  // (profiles/r6/ab_fullyobs_lds_occupancy.txt; DoorKey-8x8 / Empty-8x8, episodes of hundreds of steps: 31.2 -> 28.9 / 30.6 -> 29.1 with two, as in round 3)
+  // (profiles/r6/ab_shadow_sets_fullyobs_gotoredball.txt; DoorKey-8x8 / Empty-8x8, episodes of hundreds of steps: 31.2 -> 28.9 / 30.6 -> 29.1 with two, as in round 3)
   if (e->cells <= 64 && e->cfg.max_steps > 0 && e->cfg.max_steps <= 64 && !e->sentence && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
   if (e->k.roll_shadows == 1) e->roll_shadows = 1;
   if (e->k.roll_shadows == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
@@ -797,7 +797,7 @@ static const char* configure_obs(mg_env* e) {
     if (e->dyn_inloop) nw = 3;
     // the big grids (more than 256 cells) of the ring levels: the STAGED split (mg_roll.h) -- the dynamics wave + ONE encode wave over one copy of the grids
     // (a private copy per wave left them one wave per workgroup).
-    e->staged_big = e->fast7 && !e->fast_full && !e->sentence && !e->dyn_inloop && !e->static_gen && e->cells > 256;
+    e->staged_big = e->fast7 && !e->fast_full && !e->sentence && !e->dyn_inloop && !e->static_gen && e->cells > 256;     // (round 6, profiles/r6/ab_staged_threshold.txt: staging from 16 x 16 on is a wash -- DoorKey-16x16 +3 %, ObstructedMaze-Full +6 %, KeyCorridorS6R3 -3 %, ObstructedMaze-2Dlhb -5 % -- and below that a loss: MemoryS11 18.0 -> 12.9 G, KeyCorridorS4R3 20.4 -> 15.1)
     if (e->staged_big) nw = 2;
     if (e->k.roll_nw >= 1 && e->k.roll_nw <= ROLL_MAX_WAVES) nw = e->k.roll_nw;
     e->roll_nw = nw;
