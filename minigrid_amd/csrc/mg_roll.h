@@ -399,21 +399,31 @@ MG_D void store16(uint8_t* base, uint32_t off, const uint4& v, bool nt) {
 }
 // NQ quads by threads l0, l0 + STRIDE, ...: software-pipelined -- every code dword first, then the lookups of quad it + 1 are issued before
 // quad it is packed and stored
+#ifndef MG_ALIGN_ROUNDS
+#define MG_ALIGN_ROUNDS 1        // (0: A/B builds -- every workgroup's rounds counted from its block's first quad, as before round 6)
+#endif
+// LINE-ALIGNED ROUNDS (round 6).  A workgroup's block of a step's observation tensor is 64 * 147 = 9 408 bytes = 73.5 cache lines: every other workgroup's block
+// starts 64 bytes into a 128-byte line, and with rounds counted from the block's first quad each of its 768-byte rounds had a half line at both ends.  `shift`
+// (0, or 16 quads = 192 bytes for a block that starts mid-line: 12 * 16 = 64 mod 128) moves the SHORT round to the front: quads [0, 16) first, then full rounds from
+// quad 16 on, each starting on a line.  Measured on the attribution build before it was built (blocks moved down to their line start, MG_EXP bit 16384,
+// profiles/r6/attribution_store_alignment.txt): Empty-8x8 x 65 536 2.18-2.25 -> 2.06-2.09 us per step.  (Needs NQ = a multiple of STRIDE + 16.)
 template <int STRIDE, int NQ, bool NT>
-MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase, bool do_store = true) {
-  constexpr int NIT = (NQ + STRIDE - 1) / STRIDE;
+MG_D void encode_quads(int l0, const uint8_t* codes, const uint32_t* slut, uint8_t* obase, bool do_store = true, int shift = 0) {
+  constexpr int NIT = (NQ + STRIDE - 1) / STRIDE, REM = NQ - STRIDE * (NIT - 1);     // REM quads in the short round
   uint32_t cw[NIT], tq[2][4];
+  // round it of this lane: the full rounds first (from quad `shift` on), the short round last in program order -- its quads are the block's first ones when shifted
+  auto quad_of = [&](int it) { return it + 1 < NIT ? shift + STRIDE * it + l0 : min((shift ? 0 : STRIDE * (NIT - 1)) + l0, NQ - 1); };
 #pragma unroll
-  for (int it = 0; it < NIT; it++) cw[it] = ((const uint32_t*)codes)[(it + 1) * STRIDE > NQ ? min(l0 + STRIDE * it, NQ - 1) : l0 + STRIDE * it];
+  for (int it = 0; it < NIT; it++) cw[it] = ((const uint32_t*)codes)[quad_of(it)];
   obs7_quad_lookup(cw[0], slut, tq[0]);
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    const int u = l0 + STRIDE * it;
+    const int u = quad_of(it);
     if (it + 1 < NIT) obs7_quad_lookup(cw[it + 1], slut, tq[(it + 1) & 1]);
     uint32_t o3[3];
     obs7_quad_pack(tq[it & 1], o3);
     Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-    if (((it + 1) * STRIDE <= NQ || u < NQ) && do_store) store12(obase, (uint32_t)u * 12u, v, NT);
+    if ((it + 1 < NIT || l0 < REM) && do_store) store12(obase, (uint32_t)u * 12u, v, NT);
   }
 }
 
@@ -928,21 +938,45 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       // (attribution builds, MG_EXP bit 256: every workgroup's observations go to a 1.2 MB window that stays in L2 -- the same store
       // instructions without the HBM write stream: is the observation stream's cost its issue or its bandwidth?)
       if (MG_EXPBIT(P, 256)) obase = P.obs + (size_t)(wg & 127) * P.obs_wg_stride;
+      // (attribution builds, MG_EXP bit 16384: every workgroup's block moved down to the 128-byte line it starts in -- an odd workgroup's block starts 64 bytes into a
+      // line, so each of its 768-byte rounds has a half line at both ends; the moved block overlaps its neighbour's tail: timing only)
+      if (MG_EXPBIT(P, 16384)) obase -= (size_t)(obase - P.obs) & 127u;
       const int nbytes = nvalid * OBE;
       const int nvec = nbytes >> 4;
 #if MG_ENCODE_QUADS
       if (!FULL && nvalid == 64) {
         // 784 cell quads: thirteen rounds, the last one 16 lanes wide
-        encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, codes, slut, obase, !MG_EXPBIT(P, 32));
+        // (a block starts mid-line when wg * 64 * 147 = 64 mod 128, i.e. for the odd workgroups of a 64-env launch shape; the tensor itself starts on a 256-byte boundary)
+        encode_quads<64, 64 * VIEW_CELLS / 4, NT>(lane, codes, slut, obase, !MG_EXPBIT(P, 32), (MG_ALIGN_ROUNDS && ((uintptr_t)obase & 127u) == 64u) ? 16 : 0);
       } else if (!FULL && nvalid == 32) {
         encode_quads<64, 32 * VIEW_CELLS / 4, NT>(lane, codes, slut, obase, !MG_EXPBIT(P, 32));      // 32-env workgroups: 392 quads, seven rounds
       } else if (FULL && nvalid == 64) {
-        const int nq = 16 * cells;                                                // 64 * cells / 4 quads
-        for (int u = lane; u < nq; u += 64) {
+        // 16 * cells quads (64 * cells / 4), rounds of 64 in BLOCKS of four: the four code dwords first, then the sixteen lookups, then four packs and stores --
+        // a round by itself is two dependent LDS latencies (code, then table) in front of every store, and FullyObs runs two waves per SIMD: nothing hides them
+        // (round 6; LavaCrossing 9 x 9: 20.25 rounds per step in ONE wave).  Rounds past the end re-read the last quad and store nothing.
+        const int nq = 16 * cells;
+        // (line-aligned rounds as in encode_quads: a block that starts mid-line -- odd workgroups of an odd cell count -- writes its first 16 quads by themselves)
+        const int qs = (MG_ALIGN_ROUNDS && ((uintptr_t)obase & 127u) == 64u) ? 16 : 0;
+        if (qs && lane < qs) {
           uint32_t o3[3];
-          obs7_quad((uint32_t)u, codes, slut, o3);
+          obs7_quad((uint32_t)lane, codes, slut, o3);
           Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
-          store12(obase, (uint32_t)u * 12u, v, nt);
+          if (!MG_EXPBIT(P, 32)) store12(obase, (uint32_t)lane * 12u, v, nt);
+        }
+        for (int u0 = qs + lane; u0 < nq; u0 += 256) {
+          uint32_t cw4[4], t4[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) cw4[r] = ((const uint32_t*)codes)[min(u0 + 64 * r, nq - 1)];
+#pragma unroll
+          for (int r = 0; r < 4; r++) obs7_quad_lookup(cw4[r], slut, t4[r]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int u = u0 + 64 * r;
+            uint32_t o3[3];
+            obs7_quad_pack(t4[r], o3);
+            Out12 v; v.x = o3[0]; v.y = o3[1]; v.z = o3[2];
+            if (u < nq && !MG_EXPBIT(P, 32)) store12(obase, (uint32_t)u * 12u, v, nt);
+          }
         }
       } else {
 #else
@@ -1076,6 +1110,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           // the stream as this step's observation shows it: the agent's own cell reads (10, 0, dir) (wrappers.py:422-424)
           const uint32_t gt_pos = (uint32_t)(lane * cells) + a.x * (uint32_t)H + a.y;
           uint32_t gt_old = 0;
+          if (!MG_EXPBIT(P, 8192)) {           // (attribution builds: the step without its staging copy -- what does the copy cost the dynamics wave?)
           if (active) { gt_old = scodes[gt_pos]; scodes[gt_pos] = (uint8_t)(T_AGENT_MARK | (a.dir << 4)); }
           MG_LDS_SYNC();
           const uint4* src = (const uint4*)scodes;
@@ -1083,6 +1118,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
           for (int c = lane; c < 4 * cells; c += 64) dst[c] = src[c];            // 64 * cells bytes = 4 * cells 16-byte pieces
           MG_LDS_SYNC();
           if (active) scodes[gt_pos] = (uint8_t)gt_old;
+          }
         } else {
           // (PutNext(start_carrying): the episode's first observation shows the object where it was and empty hands -- the codes are staged that way)
           Agent av = a;
@@ -1238,7 +1274,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     uint8_t* obase = P.obs + (size_t)P.slot0 * P.obs_stride + (size_t)wg * P.obs_wg_stride;
     const int nbytes = nvalid * OBE, nvec = nbytes >> 4;
     if (MG_ENCODE_QUADS && !FULL && nvalid == 64 && nthreads == 64 * ROLL_MAX_WAVES) {
-      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase);     // four rounds, the last one 16 threads wide
+      if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 64 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase, true, (MG_ALIGN_ROUNDS && ((uintptr_t)obase & 127u) == 64u) ? 16 : 0);     // four rounds, one of them 16 threads wide
     } else if (MG_ENCODE_QUADS && !FULL && nvalid == 32 && nthreads == 64 * ROLL_MAX_WAVES) {
       if (!MG_EXPBIT(P, 2)) encode_quads<64 * ROLL_MAX_WAVES, 32 * VIEW_CELLS / 4, false>(tid, codes0, slut, obase);
     } else if (MG_ENCODE_QUADS && nvalid == 64) {
