@@ -29,7 +29,9 @@ _STEP = _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_s
 _GEN = _COMMON + ["mg_gen.h", "mg_genk.h", "mg_gen_tu.inc"]
 # translation unit -> the headers it is built from (its own file included)
 UNITS = {
-    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", "mg_genlane.h", "mg_knobs.h", ABI_HEADER],
+    "mg_api.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_kernels_aux.h", "mg_genlane.h", "mg_knobs.h", "mg_host.h", ABI_HEADER],
+    # the host self-test entry points (mg_selftest_*): the per-env device code on the CPU, no handle
+    "mg_selftest.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_genlane.h", "mg_host.h", ABI_HEADER],
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
     "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP,
 }

@@ -372,19 +372,4 @@ __global__ void k_aux_rebuild(const uint8_t* grid, const uint64_t* agent, uint64
   aux[n] = w;
 }
 
-// the VALU primitives of mg_roll.h on the device, for the GPU test that compares them with their host forms
-__global__ void k_selftest_prims(int n, const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  out[i] = perm_b32(a[i], b[i], c[i]);
-  out[n + i] = udot4(a[i], b[i], c[i]);
-  out[2 * n + i] = brev32(a[i]);
-  out[3 * n + i] = expand4(a[i]);
-  uint32_t m, up;
-  vis_row_carry(a[i] & 0x7Fu, b[i] & 0x7Fu, &m, &up);
-  out[4 * n + i] = m | (up << 8);
-  const uint32_t two = 2u;
-  out[5 * n + i] = MG_BYTE_X4(a[i], 0, two) ^ (MG_BYTE_X4(a[i], 1, two) << 10) ^ (MG_BYTE_X4(a[i], 2, two) << 20) ^ (MG_BYTE_X4(a[i], 3, two) << 22);
-}
-
 }  // namespace mg
