@@ -738,7 +738,15 @@ static const char* configure_obs(mg_env* e) {
   // room_size^2): with the generators no longer what a GoToRedBall step waits for (gen_goto_lane, mg_gen.h), a second reset of an env within a 32-step launch
   // -- every env ends an episode at least once in two launches -- is worth the second staged set: x 32 768 13.2 -> 14.0 G env-steps/s, three runs each
   // (profiles/r6/ab_shadow_sets_fullyobs_gotoredball.txt; DoorKey-8x8 / Empty-8x8, episodes of hundreds of steps: 31.2 -> 28.9 / 30.6 -> 29.1 with two, as in round 3)
-  if (e->cells <= 64 && e->cfg.max_steps > 0 && e->cfg.max_steps <= 64 && !e->sentence && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
+  // -- while the batch leaves the CUs a fourth workgroup slot to give away: the second set is 5.4 KB of a workgroup's LDS (43 instead of 37.6 KB: three resident
+  // workgroups per CU instead of four).  profiles/r6/ab_shadow_sets_by_batch_size.txt, two sets against one: x 16 384 7.36 / 7.03 G, x 32 768 13.97 / 13.18, x 49 152
+  // 14.7 / 14.3, x 65 536 14.3 / 16.1, x 131 072 16.8 / 18.4 -- so: up to three workgroups per CU (49 152 envs on 256 CUs)
+  {
+    int cus = 256;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+    if (e->cells <= 64 && e->cfg.max_steps > 0 && e->cfg.max_steps <= 64 && !e->sentence && !e->static_gen && !e->live_gen && e->cb >= 2 &&
+        (e->N + 63) / 64 <= 3 * cus) e->roll_shadows = 2;
+  }
   if (e->k.roll_shadows == 1) e->roll_shadows = 1;
   if (e->k.roll_shadows == 2 && !e->static_gen && !e->live_gen && e->cb >= 2) e->roll_shadows = 2;
   if (e->k.roll_shadows == 0 && !e->static_gen) e->roll_shadows = 0;    // no staging: every reset fetches its spare from the ring in HBM inside the loop
