@@ -775,6 +775,15 @@ static const char* configure_obs(mg_env* e) {
     // 7.63 us per step, 7.92 with two encode waves, 8.42 with the round-3 time split, whose second wave replayed the dynamics: profiles/r4/lava_split.txt)
     if (e->fast_full) nw = 2;
     while (nw > 1 && roll_lds_bytes(e, nw, true, roll_split_ok(e, nw)) > 53 * 1024) nw--;
+    // (round 6) the 9 x 9 levels: four waves are 48 KB of LDS = three workgroups per CU, three waves 38.5 KB = four.  Where that decides whether the WHOLE batch is
+    // resident at once -- more than three, at most four workgroups per CU -- three waves win: x 65 536 LavaCrossingS9N1 17.9 -> 20.3 G, SimpleCrossingS9N3 21.5 ->
+    // 22.9, MemoryS9 15.2 -> 17.7; larger batches are a wash either way (profiles/r6/ab_9x9_waves_per_workgroup.txt)
+    if (nw == 4 && !e->fast_full) {
+      int cus = 256;
+      { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount; }
+      const long long wgs = ((long long)e->N + 63) / 64;
+      if (wgs > 3LL * cus && wgs <= 4LL * cus && roll_lds_bytes(e, 4, false, roll_split_ok(e, 4)) > 40 * 1024 && roll_lds_bytes(e, 3, false, roll_split_ok(e, 3)) <= 40 * 1024) nw = 3;
+    }
     // DynamicObstacles in the loop: the dynamics wave + two encode waves over ONE copy of the grids (roll_layout; 31 KB at 16 x 16).  The level's
     // step is its placement loop, so the encode waves idle most of the time: three waves of ~150 VGPRs leave room for four workgroups per CU.
     if (e->dyn_inloop) nw = 3;
