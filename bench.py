@@ -390,6 +390,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="empty8x8", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--max-steps", type=int, default=0, help="tuning aid: override the level's max_steps (1 GPU only; no profile-backed roofline)")
     ap.add_argument("--env-id", default="", help="tuning aid: any registered id instead of the workload's (the line's config.env_id says so; profiles are "
                                                   "quoted per workload NAME, so such a line carries no profile-backed roofline)")
     ap.add_argument("--fused", type=int, default=1, help="1: the fused rollout kernel (up to max_fused_steps steps per k_step launch, "
@@ -457,7 +458,8 @@ def main(argv=None):
         assert env.env_index_base == rank * n_per_gpu and env.num_envs == n_per_gpu
     else:
         import minigrid_amd as mg
-        env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view)
+        env = mg.make_vec(env_id, n_per_gpu, obs_mode=obs_mode, device=local_rank, output="torch", agent_view_size=args.view,
+                          **({"max_steps": args.max_steps} if args.max_steps else {}))
     if use_gpu:
         from minigrid_amd import _binding
         build_info = _binding.load().mg_build_info().decode()
@@ -559,7 +561,7 @@ def main(argv=None):
         # id u16, 2 bytes reserved); the grid and the agent record are read and written once per launch, not per step
         hbm_min = obe + 16 + (2 * (env.width * env.height) + 16) / spl
         floor_bytes_per_launch = hbm_min * n_per_gpu * steps_per_launch_avg
-        quotable = not args.obs_mode and not args.env_id and args.view == 7 and use_gpu
+        quotable = not args.obs_mode and not args.env_id and not args.max_steps and args.view == 7 and use_gpu
         traffic = pmc_traffic_bytes(args.workload, n_per_gpu, spl) if quotable else None
         # the counters are per FULL launch (spl steps); a region whose last launch is shorter moves proportionally less on average
         real_bytes_per_launch = traffic * steps_per_launch_avg / spl if traffic else floor_bytes_per_launch
