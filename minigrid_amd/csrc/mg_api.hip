@@ -26,6 +26,10 @@
 #include "mg_knobs.h"
 #include "mg_host.h"
 
+#ifndef MG_GOTO_TU
+#define MG_GOTO_TU 1          // (0: A/B builds -- the GoTo levels on k_roll7<GG_ROOMGRID> like the rest of their rule group, as before round 6)
+#endif
+
 using namespace mg;
 
 static thread_local std::string g_create_error;
@@ -501,6 +505,7 @@ static int launch_step(mg_env* e, StepParams& P) {
     else if (in_loop_verify) launch_roll_sentence(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
+    else if (MG_GOTO_TU && gg == GG_ROOMGRID && e->rule == RULE_GOTO && !P.staged) launch_roll_goto(full, grid, nw, (size_t)L.total, e->stream, P);      // (k_roll7<GG_GOTO>: the rule by itself)
     else if (gg == GG_ROOMGRID) launch_roll_roomgrid(full, grid, nw, (size_t)L.total, e->stream, P);
     else launch_roll_rooms(full, grid, nw, (size_t)L.total, e->stream, P);
     launched = true;
@@ -883,7 +888,7 @@ static int alloc_obs(mg_env* e) {
     if (need > lds_max[e->device & 63]) {
       HIP_TRY(e, step_max_lds_none(need)); HIP_TRY(e, step_max_lds_light(need)); HIP_TRY(e, step_max_lds_roomgrid(need)); HIP_TRY(e, step_max_lds_rooms(need));
       HIP_TRY(e, roll_max_lds_none(need)); HIP_TRY(e, roll_max_lds_light(need)); HIP_TRY(e, roll_max_lds_roomgrid(need)); HIP_TRY(e, roll_max_lds_rooms(need));
-      HIP_TRY(e, roll_max_lds_sentence(need)); HIP_TRY(e, roll_max_lds_dynobs(need));
+      HIP_TRY(e, roll_max_lds_sentence(need)); HIP_TRY(e, roll_max_lds_dynobs(need)); HIP_TRY(e, roll_max_lds_goto(need));
       lds_max[e->device & 63] = need;
     }
   }

@@ -502,7 +502,7 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // SIMD, every latency of the step exposed.  With one copy per workgroup (the dynamics wave's, which also stages the step's 49 codes per env) a second
 // wave takes the output-space encode and the stores, exactly as for the sentence levels (same 22 x 22 grids) since round 4.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false, bool STAGED = false>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : (GG == GG_ROOMGRID && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : ((GG == GG_ROOMGRID || GG == GG_GOTO) && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
   static_assert(!STAGED || (!FULL && !ONE && GG != GG_DYNOBS && GG != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int sp_hi = wave == 0 ? P.split[1] : wave == 1 ? P.split[2] : wave == 2 ? P.split[3] : P.split[4];
   const int j_begin = share ? 0 : sp_lo, j_end = share ? (wave == sw ? P.T : 0) : sp_hi;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
+  const bool goto_rule = GG == GG_GOTO || (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
                          (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
 
   // ---- prologue: every load up front (see k_step: no global load may sit in the step loop), and every INDEPENDENT load issued before
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const bool maskok = mask_byte != 0u;
   uint8_t* mygrid = sgrid + lane * GS;
   S.cur = S.targets;
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
+  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && (a.flags & FLAG_TARGETS_STALE)) {
     const uint32_t desc = goto_desc(P, a.mission);
     S.cur = 0;
     for (int k = 0; k < P.cells; k++) S.cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
@@ -1301,7 +1301,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (!last_wave) return;
   if constexpr (GG == GG_DYNOBS)         // episodes drawn inside the loop count like the generator kernels' (mg_get_counters sums the slots)
     if (ngen) atomicAdd(&P.counters[(size_t)P.stat_gen_off + 2u * (((uint32_t)wg * 64u + (uint32_t)lane) & (STAT_GEN_SLOTS - 1u))], (unsigned long long)ngen);
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if (GG == GG_GOTO || P.rule == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (S.cur != S.targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; S.rec_dirty = true; }
   }

@@ -526,7 +526,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
       }
       if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
       trunc = a.step >= (uint32_t)P.max_steps;
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && !MG_EXPBIT(P, 128)) {
+      if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && !MG_EXPBIT(P, 128)) {
         // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
         // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
         // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
@@ -777,7 +777,7 @@ k_step(const StepParams P) {
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   // levels with an auxiliary word.  The single-room rules share the variant of the BASELINE GoToRedBall config; the heavier multi-room
   // ones live in the GG_ROOMS variants so that they do not cost it registers (202 VGPRs with everything in one variant)
-  const bool goto_rule = (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
+  const bool goto_rule = GG == GG_GOTO || (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
                          (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
 
   // ---- every independent load is issued up front ----
@@ -830,7 +830,7 @@ k_step(const StepParams P) {
   a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + el * GS;
   cur = targets;
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
+  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && (a.flags & FLAG_TARGETS_STALE)) {
     const uint32_t desc = goto_desc(P, a.mission);
     cur = 0;
     for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
@@ -915,7 +915,7 @@ k_step(const StepParams P) {
   }
 
   // ---- launch end: state back to HBM, refill requests, statistics ----
-  if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTO) {
+  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if (GG == GG_GOTO || P.rule == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (cur != targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; rec_dirty = true; }
   }
