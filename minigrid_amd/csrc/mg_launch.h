@@ -27,6 +27,8 @@ void launch_roll_sentence(bool full, dim3 grid, int nw, size_t lds, hipStream_t 
 hipError_t roll_max_lds_sentence(int bytes);
 void launch_roll_goto(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);          // (mg_step_goto.hip: GG_GOTO)
 hipError_t roll_max_lds_goto(int bytes);
+void launch_roll_pickup(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);        // (mg_step_pickup.hip: GG_PICKUP)
+hipError_t roll_max_lds_pickup(int bytes);
 // (DynamicObstacles' k_roll7: the stream draws of its step() and reset() inside the step loop; mg_step_dynobs.hip)
 void launch_roll_dynobs(bool philox, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_dynobs(int bytes);

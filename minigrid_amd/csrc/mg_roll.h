@@ -502,7 +502,7 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // SIMD, every latency of the step exposed.  With one copy per workgroup (the dynamics wave's, which also stages the step's 49 codes per env) a second
 // wave takes the output-space encode and the stores, exactly as for the sentence levels (same 22 x 22 grids) since round 4.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false, bool STAGED = false>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : ((GG == GG_ROOMGRID || GG == GG_GOTO) && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : ((GG == GG_ROOMGRID || GG == GG_GOTO || GG == GG_PICKUP) && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
   static_assert(!STAGED || (!FULL && !ONE && GG != GG_DYNOBS && GG != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
   static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

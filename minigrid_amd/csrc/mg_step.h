@@ -639,7 +639,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         }
         if (open) { term = 1; success = true; }
       }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
+      if constexpr (GG == GG_ROOMGRID || GG == GG_PICKUP) if ((GG == GG_PICKUP || P.rule == RULE_PICKUP) && act == A_PICKUP && a.carry != 0) {
         // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
         // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
         const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
