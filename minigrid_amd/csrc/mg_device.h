@@ -220,11 +220,13 @@ MG_HD void report_errors(uint32_t* err, uint32_t bits) {
 }
 
 // generator / rule groups (see mg_gen.h "Groups")
-// (GG_GOTO, round 6: a STEP-kernel group only -- GG_ROOMGRID's RULE_GOTO by itself: k_roll7<GG_GOTO> carries none of the group's other four rules, which cost the
-// dynamics loop of the GoTo levels 6 % (profiles/r6/ab_fixed_rule_not_adopted.txt measured it, mg_step_goto.hip builds it); the generators know nothing of it)
-enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15, GG_GOTO = 32, GG_PICKUP = 64,       // (GG_PICKUP: likewise RULE_PICKUP by itself -- UnlockPickup, BlockedUnlockPickup, KeyCorridor, ObstructedMaze: mg_step_pickup.hip)
-            
+enum : int { GG_NONE = 0, GG_LIGHT = 1, GG_ROOMGRID = 2, GG_ROOMS = 4, GG_SENTENCE = 8, GG_ALL = 15,
               GG_DYNOBS = 16 };    // (step kernels only: k_roll7 with DynamicObstacles' moves and resets inside the step loop, mg_dynobs.h)
+// A STEP kernel's GG may also name ONE rule of its group (round 6): the group in the low byte, rule + 1 above it.  gg_group / gg_rule take it apart; the generators
+// only ever see plain groups.
+constexpr int GG_RULE(int group, int rule) { return group | ((rule + 1) << 8); }
+MG_HD constexpr int gg_group(int GG) { return GG & 0xFF; }
+MG_HD constexpr int gg_rule(int GG) { return (GG >> 8) - 1; }          // -1: the launch parameter decides (StepParams::rule)
 MG_HD int gen_group_of_kind(int kind) { return (kind >= 50 && kind <= 53) ? GG_SENTENCE : (kind >= 21 && kind <= 49) ? GG_ROOMS : (kind == 3 || (kind >= 9 && kind <= 11) || kind == 14 || (kind >= 16 && kind <= 20)) ? GG_ROOMGRID : GG_LIGHT; }
 
 // `counters` layout (u64): [0..15] scratch (debug stamps) | one episodes-finished slot per 64-env wave |

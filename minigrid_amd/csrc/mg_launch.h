@@ -25,10 +25,17 @@ MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_S
 // (the sentence levels' k_roll7: the verifier inside the step loop; mg_step_sentence.hip)
 void launch_roll_sentence(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_sentence(int bytes);
-void launch_roll_goto(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);          // (mg_step_goto.hip: GG_GOTO)
+// (one-rule units, mg_step_{goto,pickup,gotobig,pickupdesc,fetch}.hip: GG_RULE(group, rule))
+void launch_roll_goto(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_goto(int bytes);
-void launch_roll_pickup(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);        // (mg_step_pickup.hip: GG_PICKUP)
+void launch_roll_pickup(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_pickup(int bytes);
+void launch_roll_gotobig(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
+hipError_t roll_max_lds_gotobig(int bytes);
+void launch_roll_pickupdesc(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
+hipError_t roll_max_lds_pickupdesc(int bytes);
+void launch_roll_fetch(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
+hipError_t roll_max_lds_fetch(int bytes);
 // (DynamicObstacles' k_roll7: the stream draws of its step() and reset() inside the step loop; mg_step_dynobs.hip)
 void launch_roll_dynobs(bool philox, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_dynobs(int bytes);

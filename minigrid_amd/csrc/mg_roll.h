@@ -502,9 +502,9 @@ MG_HD void image_stream_build(const uint8_t* g, uint8_t* gt, int W, int H) {    
 // SIMD, every latency of the step exposed.  With one copy per workgroup (the dynamics wave's, which also stages the step's 49 codes per env) a second
 // wave takes the output-space encode and the stores, exactly as for the sentence levels (same 22 x 22 grids) since round 4.
 template <int GG, bool FULL, bool NT, class RNG = Pcg64Stream, bool ONE = false, bool STAGED = false>
-__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (GG == GG_NONE && !FULL) ? 4 : ((GG == GG_ROOMGRID || GG == GG_GOTO || GG == GG_PICKUP) && !FULL) ? MG_RG_WPE : GG == GG_DYNOBS ? MG_DYN_WPE : GG == GG_SENTENCE ? 2 : ((GG == GG_LIGHT || GG == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
-  static_assert(!STAGED || (!FULL && !ONE && GG != GG_DYNOBS && GG != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
-  static_assert(GG != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
+__global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(STAGED ? 2 : (gg_group(GG) == GG_NONE && !FULL) ? 4 : (gg_group(GG) == GG_ROOMGRID && !FULL) ? MG_RG_WPE : gg_group(GG) == GG_DYNOBS ? MG_DYN_WPE : gg_group(GG) == GG_SENTENCE ? 2 : ((gg_group(GG) == GG_LIGHT || gg_group(GG) == GG_ROOMS) && !FULL) ? MG_LR_WPE : 3, 8))) k_roll7(const StepParams P) {
+  static_assert(!STAGED || (!FULL && !ONE && gg_group(GG) != GG_DYNOBS && gg_group(GG) != GG_SENTENCE), "STAGED: the 7x7 view of the ring levels (the others stage by themselves)");
+  static_assert(gg_group(GG) != GG_DYNOBS || !FULL, "DynamicObstacles' in-loop path is built for the 7x7 view");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int NW = nthreads >> 6;
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int ek = split_mode ? (wave - dw - 1 + NW) % NW : 0;        // encode wave index 0 .. NW - 2 (split mode)
   // DynamicObstacles, the sentence levels and FullyObs split differently (the staged split, see the loops below): ONE copy of the grids, the
   // dynamics wave's, which also stages every step's codes (FullyObs: a copy of its image-order stream)
-  const bool dsplit = (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL || STAGED) && split_mode;
+  const bool dsplit = (gg_group(GG) == GG_DYNOBS || gg_group(GG) == GG_SENTENCE || FULL || STAGED) && split_mode;
   const int mycopy = (share || dsplit) ? 0 : wave;
   uint8_t* sgrid = smem + P.off_grid + mycopy * (EPW * GS);          // this wave's private copy of the workgroup's grids
   uint8_t* scodes = smem + P.off_T + (dsplit ? 0 : split_mode ? min(ek, NW - 2) : mycopy) * P.codes_stride;   // the wave's code stream (FULL: its image-order stream of the 64 grids)
@@ -553,8 +553,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const int sp_hi = wave == 0 ? P.split[1] : wave == 1 ? P.split[2] : wave == 2 ? P.split[3] : P.split[4];
   const int j_begin = share ? 0 : sp_lo, j_end = share ? (wave == sw ? P.T : 0) : sp_hi;
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
-  const bool goto_rule = GG == GG_GOTO || (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
-                         (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
+  const bool goto_rule = (gg_group(GG) == GG_ROOMGRID && (MG_RULE(GG, P) == RULE_GOTO || MG_RULE(GG, P) == RULE_GOTOOBJ || MG_RULE(GG, P) == RULE_PUTNEAR)) ||
+                         (gg_group(GG) == GG_ROOMS && (MG_RULE(GG, P) == RULE_GOTO_BIG || MG_RULE(GG, P) == RULE_PUTNEXT || MG_RULE(GG, P) == RULE_OPENDOOR));
 
   // ---- prologue: every load up front (see k_step: no global load may sit in the step loop), and every INDEPENDENT load issued before
   // the first one is waited for: a one-step launch (Env.step) is a chain of memory round trips and little else
@@ -565,9 +565,9 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint64_t rec_ld = P.agent[ec];
   EnvRegs S;
   Agent& a = S.a;
-  const uint64_t tg_ld = (goto_rule || GG == GG_DYNOBS) ? P.aux[ec] : 0ull;     // (GG_DYNOBS: the obstacle list)
+  const uint64_t tg_ld = (goto_rule || gg_group(GG) == GG_DYNOBS) ? P.aux[ec] : 0ull;     // (GG_DYNOBS: the obstacle list)
   RNG rng;                                                                        // GG_DYNOBS: this env's stream
-  if constexpr (GG == GG_DYNOBS) rng.load(P.rng, N, (size_t)ec);
+  if constexpr (gg_group(GG) == GG_DYNOBS) rng.load(P.rng, N, (size_t)ec);
   const uint32_t h_ld = P.head ? P.head[ec] : 0u;
   const uint32_t mask_ld = P.obs_mask ? (uint32_t)P.obs_mask[ec] : 1u;
   const bool stage_acts = P.phase == PHASE_STEP && P.act_src == ACT_SRC_BUFFER;
@@ -608,8 +608,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const uint32_t act0 = act_ld;
   // shared, read-only after the barrier: the decode table, the shadow spares, the caller's actions
   for (int k = tid; k < 256; k += nthreads) slut[k] = cell_triple((uint32_t)k);
-  if constexpr (GG == GG_DYNOBS) for (int k = tid; k < CS; k += nthreads) smem[P.off_tmpl + k] = (uint8_t)dynobs_template_cell(k, W, H, P.w_magic);
-  if constexpr (GG == GG_SENTENCE && MG_INSTR_LDS) {
+  if constexpr (gg_group(GG) == GG_DYNOBS) for (int k = tid; k < CS; k += nthreads) smem[P.off_tmpl + k] = (uint8_t)dynobs_template_cell(k, W, H, P.w_magic);
+  if constexpr (gg_group(GG) == GG_SENTENCE && MG_INSTR_LDS) {
     // the workgroup's instruction records: consecutive in global memory (INSTR_WORDS u64 per env), 8 bytes per lane, coalesced
     const uint64_t* gi = P.instr + (size_t)env0 * INSTR_WORDS;
     for (int k = tid; k < nvalid * INSTR_WORDS; k += nthreads) {
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   const bool maskok = mask_byte != 0u;
   uint8_t* mygrid = sgrid + lane * GS;
   S.cur = S.targets;
-  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && (a.flags & FLAG_TARGETS_STALE)) {
+  if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
     const uint32_t desc = goto_desc(P, a.mission);
     S.cur = 0;
     for (int k = 0; k < P.cells; k++) S.cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // the constant grid copied from the template, one env at a time by the whole wave, then the agent and the obstacles placed by the lane),
   // `move` lanes move their obstacles (step(), before MiniGridEnv.step) -- all under one loop of placement tries
   auto dyn_draws = [&](bool regen, bool move, uint32_t flags_after_regen) __attribute__((always_inline)) {
-    if constexpr (GG == GG_DYNOBS) {
+    if constexpr (gg_group(GG) == GG_DYNOBS) {
       unsigned long long rm = __ballot(regen);
       if (rm) {
         const uint32_t* tm = (const uint32_t*)(smem + P.off_tmpl);
@@ -742,8 +742,8 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // step AHEAD: RESET_PENDING is raised by the step that ends the episode and honoured by the next one, so the load is issued at the end of step j and
   // its result is written into the LDS grid at the start of step j + 1, behind step j's observation (up to two envs per step; a third falls back to the
   // per-lane copy).  The first step of a launch fetches and commits in place.
-  constexpr bool COOP = STAGED || GG == GG_SENTENCE || ONE;
-  const bool coop = COOP && GG != GG_DYNOBS && P.use_shadow == 0 && !P.static_gen && P.head != nullptr && cpe > 8 && cpe <= 64 && !MG_EXPBIT(P, 4096);
+  constexpr bool COOP = STAGED || gg_group(GG) == GG_SENTENCE || ONE;
+  const bool coop = COOP && gg_group(GG) != GG_DYNOBS && P.use_shadow == 0 && !P.static_gen && P.head != nullptr && cpe > 8 && cpe <= 64 && !MG_EXPBIT(P, 4096);
   uint4 pf0 = make_uint4(0, 0, 0, 0), pf1 = make_uint4(0, 0, 0, 0);
   unsigned long long pf_mask = 0ull;
   uint64_t pf_agent = 0ull, pf_aux = 0ull;                 // every pending lane's own spare record (a lane-level load, issued with the grids')
@@ -811,12 +811,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       } else act = sact[j * 64 + lane];
     }
     o.act_in = act;
-    if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
-    if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
-    if constexpr (GG == GG_DYNOBS) if (act >= 3u) act = A_LEFT;
+    if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
+    if constexpr (gg_group(GG) == GG_NONE) if (MG_RULE(GG, P) == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+    if constexpr (gg_group(GG) == GG_DYNOBS) if (act >= 3u) act = A_LEFT;
     o.reward = 0.0; o.term = 0; o.trunc = 0; o.sent0 = 0; o.sent1 = 0;
     S.errbits = 0;
-    if constexpr (GG == GG_DYNOBS) {
+    if constexpr (gg_group(GG) == GG_DYNOBS) {
       if (P.phase == PHASE_STEP) {
         // NEXT_STEP autoreset: the env whose episode the previous step ended is redrawn now and comes out FRESH (this step only observes it,
         // like an env the host's live refill redrew before the launch); everyone else's obstacles move
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     // the sentence levels: the hot words of the env's instruction record, requested BEFORE the step's own work so that the verifier below finds
     // them arrived (mg_verify.h InstrWords; an env that takes a new episode in this step does not verify, and its record is replaced below)
     InstrWords IWd;
-    if constexpr (GG == GG_SENTENCE) if (active && P.phase == PHASE_STEP && !MG_EXPBIT(P, 2048))
+    if constexpr (gg_group(GG) == GG_SENTENCE) if (active && P.phase == PHASE_STEP && !MG_EXPBIT(P, 2048))
       IWd.load(MG_INSTR_LDS ? sinstr + lane * ROLL_INSTR_STRIDE : P.instr + (size_t)e * INSTR_WORDS);
     MG_MARK("transition");
     if (j == 0) coop_fetch();                                // (later steps: issued at the end of the step before)
@@ -835,12 +835,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     if (!MG_EXPBIT(P, 16)) env_transition<GG, 1>(P, C, S, act, o.reward, o.term, o.trunc);
     if constexpr (COOP) { C.spare_in_lds = false; C.spare_rec_pf = false; }
     MG_MARK("after_transition");
-    if constexpr (GG == GG_DYNOBS) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
+    if constexpr (gg_group(GG) == GG_DYNOBS) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
       // Gymnasium's SAME_STEP autoreset: the step that ended the episode also redraws the env; the observation below is the new episode's
       // first, reward / terminated / truncated stay the ended one's
       dyn_draws(active && (o.term | o.trunc) != 0u, false, 0u);
     }
-    if constexpr (GG == GG_SENTENCE) if (active) {
+    if constexpr (gg_group(GG) == GG_SENTENCE) if (active) {
       // The sentence levels' verifier inside the step loop (round 2 ran it as a second kernel after every one-step launch): one lane per env on
       // the env's instruction record, which no other wave touches (one wave per workgroup: the time split would replay it); the grid it looks
       // at is the LDS copy.  (The record can be staged in LDS for the launch as well -- MG_INSTR_LDS above; what made the verifier 66 of the 90 us of
@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       }
       o.sent0 = I[IW_MISSION]; o.sent1 = I[IW_MISSION + 1];
     }
-    if constexpr (GG == GG_SENTENCE) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
+    if constexpr (gg_group(GG) == GG_SENTENCE) if (P.autoreset_same_step && P.phase == PHASE_STEP) {
       // Gymnasium's SAME_STEP autoreset for the sentence levels (round 4): their episodes end in the verifier, i.e. after env_transition's own
       // SAME_STEP branch; the envs the verifier just ended take their next episode now (env_transition in reset-only mode), their instruction
       // record comes with it, and the observation below is the new episode's first -- reward / terminated / truncated stay the ended one's
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
     if constexpr (!ONE) if (P.phase == PHASE_STEP && j + 1 < P.T) coop_fetch();
     o.show_taken = false;
-    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
+    if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
       // PutNext(start_carrying): the episode's first core observation shows the object where it was and empty hands (see k_step)
       o.show_taken = true;
       a.flags &= ~FLAG_SHOW_TAKEN; S.rec_dirty = true;
@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       v.z = o.term | (o.trunc << 8) | (a.dir << 16) | (o.act_in << 24);
       v.w = a.mission & 0xFFFFu;
       *(uint4*)(ob + o_scal) = v;
-      if constexpr (GG == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = o.sent0; sp[1] = o.sent1; }
+      if constexpr (gg_group(GG) == GG_SENTENCE) { uint64_t* sp = (uint64_t*)(ob + P.off_sentence) + (size_t)e * 2; sp[0] = o.sent0; sp[1] = o.sent1; }
     }
   };
   // gen_obs of the 64 envs as they stand in this wave's grids -> the observation of trajectory slot slot_out:
@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   // halves in different waves, everything else passes its own staging and 3)
   auto observe = [&](int slot_out, const Agent& av, bool show_taken, uint32_t taken_idx, uint32_t taken_code, uint8_t* codes_arg, int parts) {
     uint8_t* const codes = (FULL && parts == 3) ? scodes : codes_arg;   // (FullyObs encodes its own image-order stream, or -- parts 2 -- a staged copy of one)
-    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)taken_code;
+    if constexpr (gg_group(GG) == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)taken_code;
     MG_MARK("codes");
     uint32_t gt_pos = 0, gt_old = 0;
     if constexpr (FULL) {
@@ -930,7 +930,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
       obs7_stage(D, next0, lane, (uint32_t*)codes);
     }
     MG_MARK("codes_end");
-    if constexpr (GG == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)CELL_EMPTY;
+    if constexpr (gg_group(GG) == GG_ROOMS) if (show_taken) mygrid[taken_idx] = (uint8_t)CELL_EMPTY;
     MG_LDS_SYNC();
     MG_MARK("chunks");
     if ((parts & 2) && !MG_EXPBIT(P, 2) && !share) {
@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
     }
   } else if constexpr (ONE) {
     // (never: the one-step kernel has no split)
-  } else if constexpr (GG == GG_DYNOBS || GG == GG_SENTENCE || FULL || STAGED) {
+  } else if constexpr (gg_group(GG) == GG_DYNOBS || gg_group(GG) == GG_SENTENCE || FULL || STAGED) {
     // ---- DynamicObstacles and the sentence levels (and, STAGED, the big grids of the other levels), split: the dynamics wave also STAGES every step's codes (gather, orientation, visibility -- the part of gen_obs
     // that needs the grid), into a ring of ROLL_DSPLIT_RING code stagings; the other waves only run the output-space encode and the stores, step
     // j by encode wave j mod (NW - 1).  The level's step is its placement loop (a 128-bit multiply per try, ~16 tries deep for the unluckiest
@@ -1299,13 +1299,13 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (errs_mine && active) report_errors(P.err, errs_mine);
   if (fin_total && lane == 0) atomicAdd(&P.counters[STAT_EPISODES + wg], (unsigned long long)fin_total);
   if (!last_wave) return;
-  if constexpr (GG == GG_DYNOBS)         // episodes drawn inside the loop count like the generator kernels' (mg_get_counters sums the slots)
+  if constexpr (gg_group(GG) == GG_DYNOBS)         // episodes drawn inside the loop count like the generator kernels' (mg_get_counters sums the slots)
     if (ngen) atomicAdd(&P.counters[(size_t)P.stat_gen_off + 2u * (((uint32_t)wg * 64u + (uint32_t)lane) & (STAT_GEN_SLOTS - 1u))], (unsigned long long)ngen);
-  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if (GG == GG_GOTO || P.rule == RULE_GOTO) {
+  if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (S.cur != S.targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; S.rec_dirty = true; }
   }
-  if constexpr (GG == GG_SENTENCE && MG_INSTR_LDS) {
+  if constexpr (gg_group(GG) == GG_SENTENCE && MG_INSTR_LDS) {
     // the records go back the way they came (this wave is the only one that touched them; its own LDS writes are in order before these reads)
     uint64_t* gi = P.instr + (size_t)env0 * INSTR_WORDS;
     for (int k = lane; k < nvalid * INSTR_WORDS; k += 64) {
@@ -1316,12 +1316,12 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (active) {
     if (S.rec_dirty) P.agent[e] = agent_pack(a);
     if (goto_rule && S.aux_dirty) P.aux[e] = S.targets;
-    if constexpr (GG == GG_DYNOBS) {
+    if constexpr (gg_group(GG) == GG_DYNOBS) {
       if (obst_dirty) P.aux[e] = obst;
       if (P.phase == PHASE_STEP) rng.store(P.rng, N, (size_t)e);
     }
     // (sentence levels: k_verify publishes head, after it copied the consumed slot's instruction record)
-    if (S.h != h_in && !(GG == GG_NONE && P.rule == RULE_SENTENCE)) P.head[e] = S.h;
+    if (S.h != h_in && !(gg_group(GG) == GG_NONE && MG_RULE(GG, P) == RULE_SENTENCE)) P.head[e] = S.h;
   }
   {
     const unsigned long long wb = __ballot(active && S.wb_all);        // envs whose whole live grid changed (new episode, fused launch)
@@ -1340,7 +1340,7 @@ __global__ void __launch_bounds__(64 * ROLL_MAX_WAVES) __attribute__((amdgpu_wav
   if (P.seg_count) {
     const bool want = active && (P.live_gen ? ((a.flags & FLAG_RESET_PENDING) != 0u && P.phase == PHASE_STEP) : (S.h != h_in));
     const unsigned long long m = __ballot(want);
-    if (GG == GG_DYNOBS && P.live_gen == 2) {
+    if (gg_group(GG) == GG_DYNOBS && P.live_gen == 2) {
       // (in-loop redraws: every earlier request was served by this launch's first step -- the list becomes the envs waiting NOW)
       const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (want) P.seg[(size_t)wg * P.seg_cap + rank] = (uint32_t)e;

@@ -42,6 +42,10 @@ constexpr int MAX_FUSED_STEPS = 32;                // steps per k_step launch: t
 
 enum : int { PHASE_STEP = 0, PHASE_OBSERVE = 1 };
 enum : int { ACT_SRC_BUFFER = 0, ACT_SRC_PHILOX = 1 };
+// The level rule as a kernel reads it.  A step kernel is instantiated per rule GROUP (GG: it carries its group's rules behind wave-uniform tests of the launch parameter)
+// or -- round 6 -- for ONE rule of a group (GG_RULE(group, rule), mg_device.h: the rule is a compile-time constant and the group's other rules are compiled out;
+// carrying them cost the dynamics loop 6-12 %: profiles/r6/ab_fixed_rule_*.txt).
+#define MG_RULE(GG, P) (gg_rule(GG) >= 0 ? gg_rule(GG) : (P).rule)
 enum : int { RULE_NONE = 0, RULE_GOTO = 1, RULE_FETCH = 2, RULE_GOTODOOR = 3, RULE_UNLOCK = 4, RULE_PICKUP = 5,
               RULE_REDBLUE = 6, RULE_MEMORY = 7, RULE_DYNOBS = 8, RULE_GOTOOBJ = 9,
               RULE_PICKUPDESC = 10, RULE_OPENFRONT = 11, RULE_PUTNEAR = 12, RULE_GOTO_BIG = 13, RULE_PUTNEXT = 14, RULE_OPENDOOR = 15, RULE_SENTENCE = 16 };
@@ -466,14 +470,14 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
       }
       if (a.flags & FLAG_STUCK) errbits |= ERR_GENERATOR;   // the reference would never return from this reset() (mg_gen.h room_stuck)
       a.step = 0; a.flags &= FLAG_SHOW_TAKEN;           // (carrying: nothing, except PutNext's start_carrying episodes)
-      if constexpr (GG == GG_NONE || GG == GG_SENTENCE) if (P.rule == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify / k_roll7<GG_SENTENCE> installs the instruction record
+      if constexpr (gg_group(GG) == GG_NONE || gg_group(GG) == GG_SENTENCE) if (MG_RULE(GG, P) == RULE_SENTENCE) a.flags |= FLAG_NEW_EPISODE;   // k_verify / k_roll7<GG_SENTENCE> installs the instruction record
       rec_dirty = true; wb_all = true;
       if (!P.static_gen) h++;
   };
   if (active) {
     if ((a.flags & FLAG_RESET_PENDING) && reset_enabled && maskok && !MG_EXPBIT(P, 64)) {
       // (GG_DYNOBS has no spare ring: k_roll7 redraws the env in place before it gets here, the host's live refill before an observe launch)
-      if constexpr (GG == GG_DYNOBS) errbits |= ERR_GENERATOR; else take_spare();
+      if constexpr (gg_group(GG) == GG_DYNOBS) errbits |= ERR_GENERATOR; else take_spare();
     } else if (C.reset_only) {
     } else if (a.flags & FLAG_FRESH) {
       a.flags &= ~(FLAG_FRESH | FLAG_NOT_CLEAR);       // drawn by the generator launch just before this one: observe only
@@ -518,7 +522,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
       const uint32_t toggled = tt | (tt == T_EMPTY ? 0u : fcol) | (((OPAQUE_TYPES >> tt) & 1u) << 7);
       uint32_t newF = is_tog ? toggled : picks ? (uint32_t)CELL_EMPTY : drops ? pre_carry : F;
       a.carry = picks ? F : drops ? 0u : pre_carry;
-      if constexpr (GG == GG_ROOMS) if (is_tog && ftype == T_BOX_DOORKEY) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (is_tog && ftype == T_BOX_DOORKEY) {
         // KeyInBox: Box.toggle leaves what the box contains, the key of the level's only door (world_object.py:290-293)
         uint32_t dc = 0;
         for (int k = 0; k < P.cells; k++) { const uint32_t c = mygrid[k]; if (cell_ref_type(c) == T_DOOR) dc = cell_color(c); }
@@ -526,7 +530,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
       }
       if (newF != F && inb) { dirty_idx = (int)fidx; dirty_code = newF; }
       trunc = a.step >= (uint32_t)P.max_steps;
-      if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && !MG_EXPBIT(P, 128)) {
+      if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTO && !MG_EXPBIT(P, 128)) {
         // RoomGridLevel.step (roomgrid_level.py:87-104) + GoToInstr.verify_action (verifier.py:309-316): success iff
         // the post-action front cell is one of the TRACKED POSITIONS of the described objects.  They are positions,
         // not objects: refreshed only at reset and after a drop (update_objs_poss), so they go stale while a target is
@@ -540,7 +544,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         const int gx = (int)a.x + dir_dx(a.dir), gy = (int)a.y + dir_dy(a.dir);
         if ((unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && ((targets >> (gy * W + gx)) & 1ull)) { term = 1; success = true; }
       }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_GOTO_BIG) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_GOTO_BIG) {
         // GoToInstr on grids of more than 64 cells (the multi-room BabyAI GoTo levels).  Tracked positions T = the cells holding a
         // described object at the last refresh (reset, every drop ACTION).  Between refreshes nothing can add such a cell (only
         // a drop does, and a drop refreshes), so T = {cells holding the object NOW} + S, S = where one was removed since (picked up,
@@ -571,7 +575,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           else if (act == A_TOGGLE && inb && cell_type(newF) == T_DOOR && cell_color(newF) == cell_color(desc)) { term = 1; success = true; }
         }
       }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_PUTNEXT && act == A_DROP && pre_carry != 0 && newF != F) {
         // RoomGridLevel.step + PutNextInstr.verify_action (verifier.py:406-431): this drop put down the object to move
         // (preCarrying is it; every object of these levels is the only one of its type and colour) and it now lies next to
         // (Manhattan distance 1) the fixed object, wherever that is NOW (update_objs_poss runs on every drop action).  A drop
@@ -591,13 +595,13 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           if (next) { term = 1; success = true; }
         }
       }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENDOOR && act == A_TOGGLE && inb) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_OPENDOOR && act == A_TOGGLE && inb) {
         // OpenInstr.verify_action incl. strict mode (verifier.py:270-287): the described doors = `targets`, a COLOR_TO_IDX bit mask
         // fixed at reset (by colour, or by where the doors were relative to the agent then; the four doors' colours differ)
         if (cell_type(newF) == T_DOOR && ((targets >> cell_color(newF)) & 1ull)) { term = 1; success = true; }
         else if (P.rule_div == 1 && cell_ref_type(newF) == T_DOOR) term = 1;
       }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_GOTOOBJ) {
+      if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTOOBJ) {
         // GoToObjectEnv.step (gotoobject.py:137-153): toggle ends the episode; done ends it, rewarded when the agent
         // stands next to target_pos (the one-bit board drawn at reset)
         if (act == A_TOGGLE) term = 1;
@@ -607,7 +611,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           term = 1; success = (targets & ring) != 0;
         }
       }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_PUTNEAR) {
+      if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_PUTNEAR) {
         // PutNearEnv.step (putnear.py:177-199).  Mission id = ((move colour * 3 + move type) * 6 + target colour) * 3 + target type
         // (COLOR_NAMES / [key, ball, box] indices); target_pos is a POSITION fixed at reset: the one-bit board `targets`.
         const uint32_t mv = a.mission / 18u;
@@ -621,14 +625,14 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           term = 1;
         }
       }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_FETCH && a.carry != 0) {
+      if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_FETCH && a.carry != 0) {
         // FetchEnv.step (fetch.py:162-175): carrying anything ends the episode; the target (type, colour) is encoded
         // in the mission id = syntax*12 + COLOR_NAMES index*2 + (key 0 | ball 1)
         const uint32_t m12 = a.mission % 12u;
         const uint32_t target = make_cell((m12 & 1u) ? (uint32_t)T_BALL : (uint32_t)T_KEY, color_from_sorted(m12 >> 1));
         term = 1; success = a.carry == target;
       }
-      if constexpr (GG == GG_ROOMGRID) if (P.rule == RULE_UNLOCK && act == A_TOGGLE) {
+      if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_UNLOCK && act == A_TOGGLE) {
         // UnlockEnv.step (unlock.py:90-98): after a toggle, success iff THE door is open.  The level has one door, in
         // the wall column between the two rooms (x = rule_cell); scanning the column is exact even past termination.
         bool open = false;
@@ -639,13 +643,13 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         }
         if (open) { term = 1; success = true; }
       }
-      if constexpr (GG == GG_ROOMGRID || GG == GG_PICKUP) if ((GG == GG_PICKUP || P.rule == RULE_PICKUP) && act == A_PICKUP && a.carry != 0) {
+      if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_PICKUP && act == A_PICKUP && a.carry != 0) {
         // UnlockPickupEnv.step (unlockpickup.py:99-107) & co.: `self.carrying == self.obj`; the target is the only
         // object of its (type, colour): type = rule_cell, colour from the mission id / rule_div
         const uint32_t target = make_cell((uint32_t)P.rule_cell, color_from_sorted(a.mission / (uint32_t)P.rule_div));
         if (a.carry == target) { term = 1; success = true; }
       }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_PICKUPDESC && act == A_PICKUP && a.carry != 0) {
         // RoomGridLevel.step + PickupInstr.verify_action (roomgrid_level.py:87-104, verifier.py:343-363): success iff the
         // object was picked up by THIS action (preCarrying is None) and matches the description the mission id encodes
         // (desc.obj_set = the objects matching at reset; attributes never change, so membership = matching);
@@ -656,13 +660,13 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         if (newF != F && match) { term = 1; success = true; }
         else if (P.rule_div == 2) term = 1;
       }
-      if constexpr (GG == GG_ROOMS) if (P.rule == RULE_OPENFRONT && act == A_TOGGLE) {
+      if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_OPENFRONT && act == A_TOGGLE) {
         // OpenInstr.verify_action (verifier.py:270-287): the cell in front is the described door (the level's only one)
         // and it is open after the toggle
         // (rule_div == 6: the description names a colour -- mission id % 6 -- and any door of that colour counts)
         if (inb && cell_type(newF) == T_DOOR && (P.rule_div != 6 || cell_color(newF) == color_from_sorted(a.mission % 6u))) { term = 1; success = true; }
       }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_REDBLUE) {
+      if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_REDBLUE) {
         // RedBlueDoorsEnv.step (redbluedoors.py:104-126): open states of the two doors before / after the action.
         // The doors sit somewhere in the two inner wall columns (x = H/2 and H/2 + H - 1).
         bool red_before = false, red_after = false, blue_before = false, blue_after = false;
@@ -678,7 +682,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         if (blue_after) { term = 1; success = red_before; }
         else if (red_after && blue_before) { term = 1; success = false; }
       }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY) {
+      if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_MEMORY) {
         // MemoryEnv.step (memory.py:155-162): success_pos / failure_pos are the two hallway-end cells next to the
         // objects at (hallway_end + 1, H/2 -+ 2); nothing can move those objects (pickup is remapped to toggle), so
         // "the agent stands at H/2 -+ 1 right below/above a key or ball" identifies them, and the match is decided by
@@ -690,7 +694,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           if (cell_type(o) == T_KEY || cell_type(o) == T_BALL) { term = 1; success = cell_type(o) == cell_type(st); }
         }
       }
-      if constexpr (GG == GG_LIGHT) if (P.rule == RULE_GOTODOOR) {
+      if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_GOTODOOR) {
         // GoToDoorEnv.step (gotodoor.py:133-149): toggle ends the episode; done ends it, rewarded next to the target
         // door = the door whose colour the mission names (door colours are distinct and doors never move)
         if (act == A_TOGGLE) term = 1;
@@ -708,7 +712,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
           term = 1; success = next_to;
         }
       }
-      if (P.done_actions && P.rule != RULE_SENTENCE) {            // (the sentence levels: inside verify_action, per leaf)
+      if (P.done_actions && MG_RULE(GG, P) != RULE_SENTENCE) {            // (the sentence levels: inside verify_action, per leaf)
         // ActionInstr.verify with use_done_actions (verifier.py:228-242), levels with ONE action instruction (the rules above are its
         // verify_action): `done` reports success iff the previous action completed the instruction, else failure; every other action only
         // remembers whether it matched (the method returns None: RoomGridLevel.step carries on).  The host sets the switch for the
@@ -718,7 +722,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
         else { a.flags = matched ? (a.flags | FLAG_LAST_MATCH) : (a.flags & ~FLAG_LAST_MATCH); term = 0; success = false; }
       }
       if (success) reward = reward_exact(a.step, P.max_steps);       // three IEEE-rounded f64 operations, like CPython's
-      if constexpr (GG == GG_NONE || GG == GG_DYNOBS) if (GG == GG_DYNOBS || P.rule == RULE_DYNOBS) {
+      if constexpr (gg_group(GG) == GG_NONE || gg_group(GG) == GG_DYNOBS) if (gg_group(GG) == GG_DYNOBS || MG_RULE(GG, P) == RULE_DYNOBS) {
         // DynamicObstaclesEnv.step (dynamicobstacles.py:162-165): walking into what WAS an obstacle or wall before the
         // obstacles moved (k_move_obstacles / k_roll7<GG_DYNOBS> recorded it) costs -1 and ends the episode, whatever happened since
         if (act == A_FORWARD && (a.flags & FLAG_NOT_CLEAR)) { reward = -1.0; term = 1; }
@@ -743,7 +747,7 @@ MG_HD void env_transition(const StepParams& P, const LaneCtx& C, EnvRegs& S, uin
       // that ends an episode also resets the env; the observation returned is the new episode's first, reward / terminated / truncated
       // are the ended episode's
       // (GG_DYNOBS: k_roll7 redraws the env in place right after this call)
-      if constexpr (GG != GG_DYNOBS) if ((term | trunc) && P.autoreset_same_step) { S.ev_dirty_idx = -1; take_spare(); }
+      if constexpr (gg_group(GG) != GG_DYNOBS) if ((term | trunc) && P.autoreset_same_step) { S.ev_dirty_idx = -1; take_spare(); }
     }
   }
 }
@@ -777,8 +781,8 @@ k_step(const StepParams P) {
   const bool reset_enabled = P.autoreset_next_step || P.phase == PHASE_OBSERVE;
   // levels with an auxiliary word.  The single-room rules share the variant of the BASELINE GoToRedBall config; the heavier multi-room
   // ones live in the GG_ROOMS variants so that they do not cost it registers (202 VGPRs with everything in one variant)
-  const bool goto_rule = GG == GG_GOTO || (GG == GG_ROOMGRID && (P.rule == RULE_GOTO || P.rule == RULE_GOTOOBJ || P.rule == RULE_PUTNEAR)) ||
-                         (GG == GG_ROOMS && (P.rule == RULE_GOTO_BIG || P.rule == RULE_PUTNEXT || P.rule == RULE_OPENDOOR));
+  const bool goto_rule = (gg_group(GG) == GG_ROOMGRID && (MG_RULE(GG, P) == RULE_GOTO || MG_RULE(GG, P) == RULE_GOTOOBJ || MG_RULE(GG, P) == RULE_PUTNEAR)) ||
+                         (gg_group(GG) == GG_ROOMS && (MG_RULE(GG, P) == RULE_GOTO_BIG || MG_RULE(GG, P) == RULE_PUTNEXT || MG_RULE(GG, P) == RULE_OPENDOOR));
 
   // ---- every independent load is issued up front ----
   const uint64_t rec = active ? P.agent[e] : 0ull;
@@ -830,7 +834,7 @@ k_step(const StepParams P) {
   a = agent_unpack(rec);
   uint8_t* mygrid = sgrid + el * GS;
   cur = targets;
-  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if ((GG == GG_GOTO || P.rule == RULE_GOTO) && (a.flags & FLAG_TARGETS_STALE)) {
+  if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTO && (a.flags & FLAG_TARGETS_STALE)) {
     const uint32_t desc = goto_desc(P, a.mission);
     cur = 0;
     for (int k = 0; k < P.cells; k++) cur |= (uint64_t)((uint32_t)mygrid[k] == desc) << k;
@@ -859,8 +863,8 @@ k_step(const StepParams P) {
       } else act = sact[j * EPW + el];
     }
     const uint32_t act_in = act;
-    if constexpr (GG == GG_LIGHT) if (P.rule == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
-    if constexpr (GG == GG_NONE) if (P.rule == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
+    if constexpr (gg_group(GG) == GG_LIGHT) if (MG_RULE(GG, P) == RULE_MEMORY && act == A_PICKUP) act = A_TOGGLE;    // MemoryEnv.step (memory.py:151-153)
+    if constexpr (gg_group(GG) == GG_NONE) if (MG_RULE(GG, P) == RULE_DYNOBS && act >= 3u) act = A_LEFT;             // "Invalid action" (dynamicobstacles.py:137-139)
     double reward = 0.0;
     uint32_t term = 0, trunc = 0;
     env_transition<GG, LPE>(P, C, S, act, reward, term, trunc);
@@ -880,7 +884,7 @@ k_step(const StepParams P) {
     const int obe = P.OBE;
     Agent av = a;
     bool show_taken = false;
-    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
+    if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_PUTNEXT && active && (a.flags & FLAG_SHOW_TAKEN)) {
       // PutNext(start_carrying).reset (putnext.py:205-214) takes the object off the grid AFTER MiniGridEnv.reset made the
       // observation: the episode's first core observation (and what OneHotPartialObsWrapper makes of it) shows it where it was, and
       // empty hands.  The wrappers that look at the env when they are called (FullyObs, Symbolic, RGBImg*) see the state after.
@@ -890,7 +894,7 @@ k_step(const StepParams P) {
       }
       a.flags &= ~FLAG_SHOW_TAKEN; rec_dirty = true;
     }
-    if constexpr (GG == GG_ROOMS) if (P.rule == RULE_PUTNEXT) MG_LDS_SYNC();
+    if constexpr (gg_group(GG) == GG_ROOMS) if (MG_RULE(GG, P) == RULE_PUTNEXT) MG_LDS_SYNC();
     if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
       static_assert(MODE == 1 || MODE == 3 || LPE == 1, "the generic view encode runs one lane per env");
       obs_view_generic<MODE>(P, av, mygrid, slut, srows, sT + el * obe, active);
@@ -898,7 +902,7 @@ k_step(const StepParams P) {
       obs_full<MODE, LPE>(P, av, mygrid, slut, (uint32_t*)sT, lane, nvalid * LPE);
     }
     MG_LDS_SYNC();
-    if constexpr (GG == GG_ROOMS) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
+    if constexpr (gg_group(GG) == GG_ROOMS) if (show_taken && lead) mygrid[(int)(targets & 0xFFFFull)] = (uint8_t)CELL_EMPTY;
 
     // ---- the wave's observations are one contiguous byte stream in LDS and in HBM: 16 B per lane per store ----
     {
@@ -915,7 +919,7 @@ k_step(const StepParams P) {
   }
 
   // ---- launch end: state back to HBM, refill requests, statistics ----
-  if constexpr (GG == GG_ROOMGRID || GG == GG_GOTO) if (GG == GG_GOTO || P.rule == RULE_GOTO) {
+  if constexpr (gg_group(GG) == GG_ROOMGRID) if (MG_RULE(GG, P) == RULE_GOTO) {
     const uint32_t fl = (a.flags & ~FLAG_TARGETS_STALE) | (cur != targets ? FLAG_TARGETS_STALE : 0u);
     if (fl != a.flags) { a.flags = fl; rec_dirty = true; }
   }
@@ -924,7 +928,7 @@ k_step(const StepParams P) {
     if (goto_rule && aux_dirty) P.aux[e] = targets;
     // (sentence levels: k_verify publishes head, after it copied the consumed slot's instruction record -- a refill running on the
     // generator stream treats every slot below head + R as free the moment head moves)
-    if (h != h_in && !(GG == GG_NONE && P.rule == RULE_SENTENCE)) P.head[e] = h;
+    if (h != h_in && !(gg_group(GG) == GG_NONE && MG_RULE(GG, P) == RULE_SENTENCE)) P.head[e] = h;
     if (errbits) report_errors(P.err, errbits);
   }
   {
