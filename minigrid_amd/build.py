@@ -33,8 +33,11 @@ UNITS = {
     # the host self-test entry points (mg_selftest_*): the per-env device code on the CPU, no handle
     "mg_selftest.hip": _COMMON + ["mg_step.h", "mg_roll.h", "mg_verify.h", "mg_dynobs.h", "mg_gen.h", "mg_genk.h", "mg_kernels.h", "mg_genlane.h", "mg_host.h", ABI_HEADER],
     "mg_step_none.hip": _STEP, "mg_step_light.hip": _STEP, "mg_step_roomgrid.hip": _STEP, "mg_step_rooms.hip": _STEP,
-    "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP, "mg_step_goto.hip": _STEP, "mg_step_pickup.hip": _STEP, "mg_step_gotobig.hip": _STEP, "mg_step_pickupdesc.hip": _STEP, "mg_step_fetch.hip": _STEP,
+    "mg_step_sentence.hip": _STEP, "mg_step_dynobs.hip": _STEP, 
 }
+# the one-rule units (mg_launch.h MG_ONE_RULE_UNITS): k_roll7 for ONE rule of a rule group
+for _n in ("goto", "pickup", "unlock", "gotoobj", "putnear", "gotobig", "pickupdesc", "openfront", "putnext", "opendoor", "fetch", "gotodoor", "redblue", "memory"):
+    UNITS[f"mg_step_{_n}.hip"] = _STEP
 for _u in ("", "_a", "_b", "_c", "_d"):          # the lane-per-episode generator kernels, by generator function (mg_gen_lane_tu.inc)
     UNITS[f"mg_gen_lane{_u}.hip"] = _GEN + ["mg_genlane.h", "mg_genmr.h", "mg_gen_lane_tu.inc"]
 for _g in ("rooms", "sentence", "roomgrid", "light"):

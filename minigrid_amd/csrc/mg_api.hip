@@ -503,12 +503,11 @@ static int launch_step(mg_env* e, StepParams& P) {
     const bool full = e->fast_full;
     if (e->dyn_inloop) launch_roll_dynobs(e->cfg.rng_mode == MG_RNG_PHILOX, grid, nw, (size_t)L.total, e->stream, P);
     else if (in_loop_verify) launch_roll_sentence(full, grid, nw, (size_t)L.total, e->stream, P);
-    // (round 6: the rules that have a unit of their own -- RULE_x alone instead of its whole group: mg_step_{goto,pickup,gotobig,pickupdesc,fetch}.hip)
-    else if (MG_GOTO_TU && gg == GG_ROOMGRID && e->rule == RULE_GOTO && !P.staged) launch_roll_goto(full, grid, nw, (size_t)L.total, e->stream, P);
-    else if (MG_GOTO_TU && gg == GG_ROOMGRID && e->rule == RULE_PICKUP && !P.staged) launch_roll_pickup(full, grid, nw, (size_t)L.total, e->stream, P);
-    else if (MG_GOTO_TU && gg == GG_ROOMS && e->rule == RULE_GOTO_BIG) launch_roll_gotobig(full, grid, nw, (size_t)L.total, e->stream, P);
-    else if (MG_GOTO_TU && gg == GG_ROOMS && e->rule == RULE_PICKUPDESC) launch_roll_pickupdesc(full, grid, nw, (size_t)L.total, e->stream, P);
-    else if (MG_GOTO_TU && gg == GG_LIGHT && e->rule == RULE_FETCH && !P.staged) launch_roll_fetch(full, grid, nw, (size_t)L.total, e->stream, P);
+    // (round 6: the rules that have a unit of their own -- RULE_x alone instead of its whole group: MG_ONE_RULE_UNITS, mg_launch.h; a unit without the STAGED split leaves
+    // a staged launch to its group's unit)
+#define MG_TRY_UNIT(NAME, GROUP, RULE, STAGED) else if (MG_GOTO_TU && gg == GROUP && e->rule == RULE && (STAGED || !P.staged)) launch_roll_##NAME(full, grid, nw, (size_t)L.total, e->stream, P);
+    MG_ONE_RULE_UNITS(MG_TRY_UNIT)
+#undef MG_TRY_UNIT
     else if (gg == GG_NONE) launch_roll_none(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_LIGHT) launch_roll_light(full, grid, nw, (size_t)L.total, e->stream, P);
     else if (gg == GG_ROOMGRID) launch_roll_roomgrid(full, grid, nw, (size_t)L.total, e->stream, P);
@@ -893,7 +892,11 @@ static int alloc_obs(mg_env* e) {
     if (need > lds_max[e->device & 63]) {
       HIP_TRY(e, step_max_lds_none(need)); HIP_TRY(e, step_max_lds_light(need)); HIP_TRY(e, step_max_lds_roomgrid(need)); HIP_TRY(e, step_max_lds_rooms(need));
       HIP_TRY(e, roll_max_lds_none(need)); HIP_TRY(e, roll_max_lds_light(need)); HIP_TRY(e, roll_max_lds_roomgrid(need)); HIP_TRY(e, roll_max_lds_rooms(need));
-      HIP_TRY(e, roll_max_lds_sentence(need)); HIP_TRY(e, roll_max_lds_dynobs(need)); HIP_TRY(e, roll_max_lds_goto(need)); HIP_TRY(e, roll_max_lds_pickup(need)); HIP_TRY(e, roll_max_lds_gotobig(need)); HIP_TRY(e, roll_max_lds_pickupdesc(need)); HIP_TRY(e, roll_max_lds_fetch(need));
+      HIP_TRY(e, roll_max_lds_sentence(need)); HIP_TRY(e, roll_max_lds_dynobs(need)); 
+#define MG_UNIT_LDS(NAME, GROUP, RULE, STAGED) HIP_TRY(e, roll_max_lds_##NAME(need));
+      MG_ONE_RULE_UNITS(MG_UNIT_LDS)
+#undef MG_UNIT_LDS
+     
       lds_max[e->device & 63] = need;
     }
   }

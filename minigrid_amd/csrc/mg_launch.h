@@ -25,17 +25,27 @@ MG_DECL_STEP_TU(none) MG_DECL_STEP_TU(light) MG_DECL_STEP_TU(roomgrid) MG_DECL_S
 // (the sentence levels' k_roll7: the verifier inside the step loop; mg_step_sentence.hip)
 void launch_roll_sentence(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_sentence(int bytes);
-// (one-rule units, mg_step_{goto,pickup,gotobig,pickupdesc,fetch}.hip: GG_RULE(group, rule))
-void launch_roll_goto(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
-hipError_t roll_max_lds_goto(int bytes);
-void launch_roll_pickup(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
-hipError_t roll_max_lds_pickup(int bytes);
-void launch_roll_gotobig(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
-hipError_t roll_max_lds_gotobig(int bytes);
-void launch_roll_pickupdesc(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
-hipError_t roll_max_lds_pickupdesc(int bytes);
-void launch_roll_fetch(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
-hipError_t roll_max_lds_fetch(int bytes);
+// ONE-RULE UNITS (round 6; mg_step_<name>.hip = k_roll7<GG_RULE(group, rule)>, the group's other rules compiled out): name, rule group, rule, has the STAGED split
+#define MG_ONE_RULE_UNITS(X) \
+  X(goto, GG_ROOMGRID, RULE_GOTO, 0) \
+  X(pickup, GG_ROOMGRID, RULE_PICKUP, 0) \
+  X(unlock, GG_ROOMGRID, RULE_UNLOCK, 0) \
+  X(gotoobj, GG_ROOMGRID, RULE_GOTOOBJ, 0) \
+  X(putnear, GG_ROOMGRID, RULE_PUTNEAR, 0) \
+  X(gotobig, GG_ROOMS, RULE_GOTO_BIG, 1) \
+  X(pickupdesc, GG_ROOMS, RULE_PICKUPDESC, 1) \
+  X(openfront, GG_ROOMS, RULE_OPENFRONT, 1) \
+  X(putnext, GG_ROOMS, RULE_PUTNEXT, 1) \
+  X(opendoor, GG_ROOMS, RULE_OPENDOOR, 1) \
+  X(fetch, GG_LIGHT, RULE_FETCH, 0) \
+  X(gotodoor, GG_LIGHT, RULE_GOTODOOR, 0) \
+  X(redblue, GG_LIGHT, RULE_REDBLUE, 0) \
+  X(memory, GG_LIGHT, RULE_MEMORY, 1)
+#define MG_UNIT_DECL(NAME, GROUP, RULE, STAGED) \
+  void launch_roll_##NAME(bool full, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P); \
+  hipError_t roll_max_lds_##NAME(int bytes);
+MG_ONE_RULE_UNITS(MG_UNIT_DECL)
+#undef MG_UNIT_DECL
 // (DynamicObstacles' k_roll7: the stream draws of its step() and reset() inside the step loop; mg_step_dynobs.hip)
 void launch_roll_dynobs(bool philox, dim3 grid, int nw, size_t lds, hipStream_t st, const StepParams& P);
 hipError_t roll_max_lds_dynobs(int bytes);
